@@ -1,0 +1,161 @@
+/*
+ * isochrones_amd — C ABI of the MI355X-native isochrones hot path.
+ *
+ * This is the drop-in boundary.  The reference (timothydmorton/isochrones, pure Python +
+ * numba) has no FFI; its de-facto operator boundary is the argument list of the numba
+ * functions below, which take nothing but dense float64 arrays, axis vectors and column
+ * indices.  Each entry point here states which of those it replaces (paths relative to the
+ * reference checkout):
+ *
+ *   iso_table_*      <- DFInterpolator.grid / .index_columns        isochrones/interp.py:571-614
+ *   iso_interp       <- interp_values_{2,3,4}d (+ scalar forms)     isochrones/interp.py:208-392
+ *   iso_ic_*         <- ModelGridInterpolator (grid+BC binding)     isochrones/models.py:253-445
+ *   iso_interp_mag   <- interp_mags / interp_mag                    isochrones/mags.py:8-124
+ *   iso_model_*      <- BasicStarModel.__init__ (obs, priors)       isochrones/starmodel.py:1370-1484
+ *   iso_lnpost       <- StarModel.lnpost -> BasicStarModel.lnprior / .lnlike -> star_lnlike
+ *                       isochrones/starmodel.py:538-542,1563-1635; isochrones/likelihood.py:16-147;
+ *                       isochrones/priors.py (default prior lnpdf's)
+ *   iso_unit_cube    <- BasicStarModel.mnest_prior                  isochrones/starmodel.py:1637-1640
+ *
+ * Conventions
+ *   - All sample buffers (x, pars, outputs) are DEVICE pointers (HIP, the ctx's device); table
+ *     and descriptor inputs of the *_create calls are HOST pointers and are copied.
+ *   - Everything is float64 (the reference computes in float64; indices are int32/int64).
+ *   - Calls are asynchronous on `stream` (a hipStream_t passed as void*, NULL = default
+ *     stream).  Tables are immutable after creation; a ctx is bound to one device.
+ *   - Return value: ISO_OK or a negative error code; iso_last_error() gives a thread-local
+ *     message.  Numeric problems are reported in-band exactly like the reference
+ *     (NaN / -inf), never as an error code.
+ *   - Strided parameter access: parameter p of sample i is pars[i*stride_n + p*stride_p]
+ *     (SoA [n_par][N]: stride_n=1, stride_p=N;  row-major [N][n_par]: stride_n=n_par, stride_p=1).
+ */
+#ifndef ISOCHRONES_AMD_H
+#define ISOCHRONES_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ISO_OK            0
+#define ISO_ERR_INVALID  -1   /* bad argument / shape */
+#define ISO_ERR_HIP      -2   /* HIP runtime failure (message has the hipError string) */
+#define ISO_ERR_NOMEM    -3
+
+#define ISO_MAX_DIM       4
+#define ISO_MAX_BANDS    32
+#define ISO_MAX_STARS     3
+#define ISO_MAX_PARAMS    7   /* n_stars + 4 */
+#define ISO_MAX_COLS     64   /* columns selectable by one iso_interp call */
+
+/* parametrisations (reference: isochrones/models.py:664-669, 691-696) */
+#define ISO_KIND_TRACK    0   /* (mass, eep, feh, distance, AV); grid axes (feh, mass, eep) */
+#define ISO_KIND_ISO      1   /* (eep[,eep_1[,eep_2]], age, feh, distance, AV); grid axes (age, feh, eep) */
+
+/* prior families (reference: isochrones/priors.py) */
+#define ISO_PRIOR_FLAT       1  /* FlatPrior        :283-293  */
+#define ISO_PRIOR_FLATLOG    2  /* FlatLogPrior     :296-306  */
+#define ISO_PRIOR_POWERLAW   3  /* PowerLawPrior    :309-342   a = alpha */
+#define ISO_PRIOR_GAUSS      4  /* GaussianPrior    :235-257   a = mean, b = sigma, c = lognorm */
+#define ISO_PRIOR_LOGNORMAL  5  /* LogNormalPrior   :260-280   a = mu, b = sigma */
+#define ISO_PRIOR_CHABRIER   6  /* BrokenPrior(LogNormal, PowerLaw) :143-232,514-519
+                                   a = mu, b = sigma, c = alpha, d = breakpoint,
+                                   e,f = norms[0..1], g,h = power-law component bounds */
+#define ISO_PRIOR_FEH        7  /* FehPrior         :345-381   a = halo_fraction, b = norm, c = local(1/0) */
+
+typedef struct iso_prior {
+    int32_t kind;       /* ISO_PRIOR_* */
+    int32_t bounded;    /* 1: (lo,hi) are enforced by BoundedPrior.lnpdf/__call__; 0: bounds=None */
+    double  lo, hi;     /* Prior.bounds */
+    double  a, b, c, d, e, f, g, h;
+} iso_prior;
+
+/* One unresolved 1-3 star system: observations + priors.
+ * (reference: BasicStarModel.__init__/lnlike/lnprior, isochrones/starmodel.py:1370-1635) */
+typedef struct iso_model_desc {
+    int32_t n_stars;                       /* 1, 2, 3 */
+    int32_t n_bands;
+    int32_t bc_cols[ISO_MAX_BANDS];        /* column of each observed band in the BC table */
+    double  mag_val[ISO_MAX_BANDS];
+    double  mag_unc[ISO_MAX_BANDS];
+    double  spec_val[3];                   /* Teff, logg, feh; NaN = not observed */
+    double  spec_unc[3];
+    int32_t has_parallax;                  /* parallax [mas]; model = 1000/distance */
+    int32_t has_numax;
+    int32_t has_dnu;                       /* only honoured if has_numax (as the reference) */
+    int32_t reserved0;
+    double  plx_val, plx_unc;
+    double  numax_val, numax_unc;
+    double  dnu_val, dnu_unc;              /* reference uses unc := val (starmodel.py:1612); host decides */
+    /* priors, one per parameter *name* */
+    iso_prior prior_mass, prior_age, prior_feh, prior_distance, prior_AV;
+    double  eep_lo, eep_hi;                /* EEP_prior bounds (priors.py:409-421) */
+    /* BasicStarModel.bounds(par) per parameter, in param_names order (starmodel.py:1538-1558);
+     * what mnest_prior maps the unit cube onto.  Usually equal to the priors' bounds, but the
+     * reference lets them diverge (e.g. halo_fraction= replaces the feh prior, :1477-1478). */
+    double  bound_lo[ISO_MAX_PARAMS];
+    double  bound_hi[ISO_MAX_PARAMS];
+} iso_model_desc;
+
+typedef struct iso_ctx   iso_ctx;
+typedef struct iso_table iso_table;   /* dense N-D table + axes, resident in HBM */
+typedef struct iso_ic    iso_ic;      /* model table + BC table + column binding */
+typedef struct iso_model iso_model;   /* iso_ic + iso_model_desc */
+
+const char* iso_last_error(void);
+const char* iso_version(void);
+
+int  iso_ctx_create(iso_ctx** out, int device);
+void iso_ctx_destroy(iso_ctx* ctx);
+
+/* shape[ndim+1] = (n_0..n_{ndim-1}, n_col); grid C-contiguous, last axis = column
+ * (the layout of DFInterpolator.grid, isochrones/interp.py:607-609); axes[d] has shape[d]
+ * strictly increasing values.  ndim in {2,3,4}. */
+int  iso_table_create(iso_ctx* ctx, int ndim, const int64_t* shape, const double* grid,
+                      const double* const* axes, iso_table** out);
+void iso_table_destroy(iso_table* t);
+
+/* out[i*k + c] = multilinear interpolation of column icols[c] at (x[0][i],..,x[ndim-1][i]).
+ * x = HOST array of ndim DEVICE pointers; icols = HOST array.  (interp_values_{2,3,4}d) */
+int  iso_interp(iso_table* t, const double* const* x, int64_t n, const int32_t* icols, int k,
+                double* out, void* stream);
+
+/* Bind a 3-D model table and a 4-D BC table.  cols[0..3] = (Teff, logg, feh, Mbol) columns of
+ * the model table (models.py:416-428); prior_cols[0..1] = (age, dt_deep) for tracks or
+ * (mass, dm_deep) for isochrones (priors.py:423-429), or -1,-1 if the table lacks them;
+ * astero_cols[0..1] = (nu_max, delta_nu) or -1,-1.  Builds the packed hot-column table. */
+int  iso_ic_create(iso_ctx* ctx, iso_table* model_grid, iso_table* bc_grid, int kind,
+                   const int32_t cols[4], const int32_t prior_cols[2], const int32_t astero_cols[2],
+                   iso_ic** out);
+void iso_ic_destroy(iso_ic* ic);
+
+/* interp_mags: pars = 5 parameters per sample in the ic's parametrisation (strided, see top).
+ * Teff/logg/feh [n], mags [n, nb] row-major; any output pointer may be NULL. */
+int  iso_interp_mag(iso_ic* ic, const double* pars, int64_t stride_n, int64_t stride_p, int64_t n,
+                    const int32_t* bc_cols, int nb,
+                    double* Teff, double* logg, double* feh, double* mags, void* stream);
+
+int  iso_model_create(iso_ic* ic, const iso_model_desc* desc, iso_model** out);
+void iso_model_destroy(iso_model* m);
+int  iso_model_n_params(const iso_model* m);
+
+/* lnpost = lnprior + lnlike, or -inf where lnprior is not finite (starmodel.py:538-542).
+ * lnprior_out / lnlike_out are optional (NULL to skip); when requested they hold the values
+ * BasicStarModel.lnprior / .lnlike would return for every sample (lnlike is then evaluated even
+ * where the prior is -inf). */
+int  iso_lnpost(iso_model* m, const double* pars, int64_t stride_n, int64_t stride_p, int64_t n,
+                double* lnpost_out, double* lnprior_out, double* lnlike_out, void* stream);
+
+/* mnest_prior: cube[i,p] <- lo_p + (hi_p - lo_p) * cube[i,p], in place (starmodel.py:1637-1640). */
+int  iso_unit_cube(iso_model* m, double* cube, int64_t stride_n, int64_t stride_p, int64_t n, void* stream);
+
+/* Time `reps` back-to-back iso_lnpost launches with hipEvents on `stream`; returns the mean
+ * milliseconds per launch in *ms_per_launch (measurement helper for bench.py). */
+int  iso_time_lnpost(iso_model* m, const double* pars, int64_t stride_n, int64_t stride_p, int64_t n,
+                     double* lnpost_out, int reps, void* stream, double* ms_per_launch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ISOCHRONES_AMD_H */

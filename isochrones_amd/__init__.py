@@ -1,0 +1,12 @@
+"""isochrones_amd — MI355X-native implementation of the isochrones hot path
+(DFInterpolator N-D interpolation -> interp_mag -> star_lnlike -> StarModel.lnpost).
+
+Host side: Python mirroring the reference's interface for this path; compute: hand-written
+HIP kernels for gfx950 behind the C ABI in include/isochrones_amd.h (no CPU fallback)."""
+from .interp import DFInterpolator
+from .models import (ModelGridInterpolator, EvolutionTrackInterpolator, IsochroneInterpolator,
+                     synthetic_track, synthetic_isochrone, get_ichrone)
+from .starmodel import (BasicStarModel, StarModel, SingleStarModel, BinaryStarModel, TripleStarModel)
+from . import priors, grids
+
+__version__ = "0.1.0"

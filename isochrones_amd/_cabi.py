@@ -1,0 +1,133 @@
+"""ctypes binding of the C ABI declared in include/isochrones_amd.h.
+
+The shared library (isochrones_amd/csrc/libiso_hip.so) is hand-written HIP for gfx950; there is
+no CPU fallback: if the library is missing or fails to load, every entry point raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+ISO_MAX_BANDS = 32
+ISO_MAX_STARS = 3
+ISO_MAX_PARAMS = 7
+ISO_MAX_COLS = 64
+
+KIND_TRACK = 0
+KIND_ISO = 1
+
+PRIOR_FLAT = 1
+PRIOR_FLATLOG = 2
+PRIOR_POWERLAW = 3
+PRIOR_GAUSS = 4
+PRIOR_LOGNORMAL = 5
+PRIOR_CHABRIER = 6
+PRIOR_FEH = 7
+
+
+class IsoPrior(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32),
+        ("bounded", C.c_int32),
+        ("lo", C.c_double),
+        ("hi", C.c_double),
+        ("a", C.c_double), ("b", C.c_double), ("c", C.c_double), ("d", C.c_double),
+        ("e", C.c_double), ("f", C.c_double), ("g", C.c_double), ("h", C.c_double),
+    ]
+
+
+class IsoModelDesc(C.Structure):
+    _fields_ = [
+        ("n_stars", C.c_int32),
+        ("n_bands", C.c_int32),
+        ("bc_cols", C.c_int32 * ISO_MAX_BANDS),
+        ("mag_val", C.c_double * ISO_MAX_BANDS),
+        ("mag_unc", C.c_double * ISO_MAX_BANDS),
+        ("spec_val", C.c_double * 3),
+        ("spec_unc", C.c_double * 3),
+        ("has_parallax", C.c_int32),
+        ("has_numax", C.c_int32),
+        ("has_dnu", C.c_int32),
+        ("reserved0", C.c_int32),
+        ("plx_val", C.c_double), ("plx_unc", C.c_double),
+        ("numax_val", C.c_double), ("numax_unc", C.c_double),
+        ("dnu_val", C.c_double), ("dnu_unc", C.c_double),
+        ("prior_mass", IsoPrior), ("prior_age", IsoPrior), ("prior_feh", IsoPrior),
+        ("prior_distance", IsoPrior), ("prior_AV", IsoPrior),
+        ("eep_lo", C.c_double), ("eep_hi", C.c_double),
+        ("bound_lo", C.c_double * ISO_MAX_PARAMS), ("bound_hi", C.c_double * ISO_MAX_PARAMS),
+    ]
+
+
+#: every symbol include/isochrones_amd.h declares (tests check the .so exports all of them)
+EXPORTED_SYMBOLS = (
+    "iso_last_error", "iso_version", "iso_ctx_create", "iso_ctx_destroy",
+    "iso_table_create", "iso_table_destroy", "iso_interp",
+    "iso_ic_create", "iso_ic_destroy", "iso_interp_mag",
+    "iso_model_create", "iso_model_destroy", "iso_model_n_params",
+    "iso_lnpost", "iso_unit_cube", "iso_time_lnpost",
+)
+
+_LIB = None
+
+
+def library_path() -> str:
+    env = os.environ.get("ISOCHRONES_AMD_LIB")
+    if env:
+        return env
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libiso_hip.so")
+
+
+class IsoError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the HIP library with argtypes set.  Raises if it is absent."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise IsoError(
+            "isochrones_amd: HIP library not found at %s — build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (there is no CPU fallback)" % path)
+    L = C.CDLL(path)
+    vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+    pd = C.c_void_p  # device pointers travel as integers
+    L.iso_last_error.restype = C.c_char_p
+    L.iso_last_error.argtypes = []
+    L.iso_version.restype = C.c_char_p
+    L.iso_version.argtypes = []
+    L.iso_ctx_create.argtypes = [C.POINTER(vp), C.c_int]
+    L.iso_ctx_destroy.argtypes = [vp]
+    L.iso_ctx_destroy.restype = None
+    L.iso_table_create.argtypes = [vp, C.c_int, C.POINTER(i64), C.POINTER(dbl),
+                                   C.POINTER(C.POINTER(dbl)), C.POINTER(vp)]
+    L.iso_table_destroy.argtypes = [vp]
+    L.iso_table_destroy.restype = None
+    L.iso_interp.argtypes = [vp, C.POINTER(pd), i64, C.POINTER(i32), C.c_int, pd, vp]
+    L.iso_ic_create.argtypes = [vp, vp, vp, C.c_int, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32),
+                                C.POINTER(vp)]
+    L.iso_ic_destroy.argtypes = [vp]
+    L.iso_ic_destroy.restype = None
+    L.iso_interp_mag.argtypes = [vp, pd, i64, i64, i64, C.POINTER(i32), C.c_int, pd, pd, pd, pd, vp]
+    L.iso_model_create.argtypes = [vp, C.POINTER(IsoModelDesc), C.POINTER(vp)]
+    L.iso_model_destroy.argtypes = [vp]
+    L.iso_model_destroy.restype = None
+    L.iso_model_n_params.argtypes = [vp]
+    L.iso_lnpost.argtypes = [vp, pd, i64, i64, i64, pd, pd, pd, vp]
+    L.iso_unit_cube.argtypes = [vp, pd, i64, i64, i64, vp]
+    L.iso_time_lnpost.argtypes = [vp, pd, i64, i64, i64, pd, C.c_int, vp, C.POINTER(dbl)]
+    for name in EXPORTED_SYMBOLS:
+        fn = getattr(L, name)
+        if fn.restype is C.c_int:
+            fn.restype = C.c_int
+    _LIB = L
+    return L
+
+
+def check(rc: int):
+    if rc != 0:
+        msg = lib().iso_last_error()
+        raise IsoError("isochrones_amd C-ABI error %d: %s" % (rc, (msg or b"").decode()))

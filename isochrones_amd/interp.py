@@ -1,0 +1,159 @@
+"""``DFInterpolator`` — N-D multilinear interpolation of the columns of a dense table, evaluated
+by the HIP kernels of libiso_hip (K3 ``interp_nd``).
+
+Mirrors the surface of the reference class (isochrones/interp.py:571-698): attributes ``grid``,
+``index_columns``, ``index_names``, ``columns``, ``column_index``, ``n_columns``, ``ndim``;
+``__call__(p, cols="all")`` returns ``[k]`` for all-scalar ``p`` and ``[N, k]`` for array ``p``
+(with numpy broadcasting), NaN for NaN / out-of-grid queries.  In addition ``p`` may hold CUDA
+tensors, in which case the result stays on the device.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _cabi, device as dev
+
+
+def _is_scalar(v):
+    return isinstance(v, (float, int)) and not isinstance(v, bool)
+
+
+class DFInterpolator:
+    def __init__(self, df=None, filename=None, recalc=False, is_full=False, *, grid=None,
+                 index_columns=None, columns=None, index_names=None):
+        self.filename = filename
+        self.is_full = is_full
+        self._handles = {}          # device index -> iso_table*
+        if df is not None:
+            self.columns = list(df.columns)
+            self.index_columns = tuple(np.array(l, dtype=float) for l in df.index.levels)
+            self.index_names = list(df.index.names)
+            self.grid = self._make_grid(df, recalc=recalc)
+        else:
+            self.columns = list(columns)
+            self.index_columns = tuple(np.ascontiguousarray(a, dtype=float) for a in index_columns)
+            self.index_names = list(index_names) if index_names is not None else [
+                "x%d" % i for i in range(len(self.index_columns))]
+            self.grid = np.ascontiguousarray(grid, dtype=float)
+        self.n_columns = len(self.columns)
+        self.ndim = len(self.index_columns)
+        if self.ndim not in (2, 3, 4):
+            raise ValueError("DFInterpolator supports 2-, 3- and 4-dimensional tables")
+        if self.grid.shape != tuple(len(a) for a in self.index_columns) + (self.n_columns,):
+            raise ValueError("grid shape %s does not match axes/columns" % (self.grid.shape,))
+        for a in self.index_columns:
+            if a.size < 2 or not np.all(np.diff(a) > 0):
+                raise ValueError("every index level needs >= 2 strictly increasing values")
+        self.column_index = {c: i for i, c in enumerate(self.columns)}
+
+    @classmethod
+    def from_arrays(cls, grid, index_columns, columns, index_names=None):
+        return cls(grid=grid, index_columns=index_columns, columns=columns, index_names=index_names)
+
+    # -- table construction (reference: _make_grid, interp.py:590-614) ---------------------
+    def _make_grid(self, df, recalc=False):
+        if self.filename is not None and os.path.exists(self.filename) and not recalc:
+            d = np.load(self.filename)
+            if list(d["columns"]) != list(self.columns):
+                raise ValueError("DataFrame columns do not match columns loaded from full grid!")
+            return np.ascontiguousarray(d["grid"], dtype=float)
+        shape = [len(l) for l in df.index.levels] + [len(df.columns)]
+        values = np.asarray(df.values, dtype=float)
+        if self.is_full:
+            grid = values.reshape(shape)
+        else:
+            # scatter the (possibly ragged) rows into a NaN-initialised product grid
+            grid = np.full(shape, np.nan)
+            codes = [np.asarray(c) for c in df.index.codes]
+            grid[tuple(codes)] = values
+        grid = np.ascontiguousarray(grid)
+        if self.filename is not None:
+            np.savez(self.filename, grid=grid, columns=self.columns)
+        return grid
+
+    def add_column(self, values, name):
+        """Append a column (reference: interp.py:616-623); device copies are rebuilt lazily."""
+        newgrid = np.empty(self.grid.shape[:-1] + (self.n_columns + 1,))
+        newgrid[..., :-1] = self.grid
+        newgrid[..., -1] = values
+        self.column_index[name] = self.n_columns
+        self.n_columns += 1
+        self.columns = self.columns + [name]
+        self.grid = newgrid
+        self.release()
+
+    # -- device residency -------------------------------------------------------------------
+    def handle(self, device=None):
+        """iso_table* for `device` (uploaded once, then resident in HBM)."""
+        if device is None:
+            device = dev.current_device()
+        h = self._handles.get(device)
+        if h is None:
+            ctx = dev.context(device)
+            shape = (C.c_int64 * (self.ndim + 1))(*self.grid.shape)
+            dp = C.POINTER(C.c_double)
+            axes = (dp * self.ndim)(*[a.ctypes.data_as(dp) for a in self.index_columns])
+            h = C.c_void_p()
+            _cabi.check(_cabi.lib().iso_table_create(ctx, self.ndim, shape, self.grid.ctypes.data_as(dp),
+                                                     axes, C.byref(h)))
+            self._handles[device] = h
+        return h
+
+    def release(self):
+        for h in self._handles.values():
+            _cabi.lib().iso_table_destroy(h)
+        self._handles = {}
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+    # -- evaluation -------------------------------------------------------------------------
+    def _icols(self, cols):
+        if isinstance(cols, str) and cols == "all":
+            return np.arange(self.n_columns, dtype=np.int32)
+        return np.array([self.column_index[c] for c in cols], dtype=np.int32)
+
+    def interp_device(self, xs, icols, device=None):
+        """xs: ndim float64 CUDA tensors of equal length N -> CUDA tensor [N, k]."""
+        if device is None:
+            device = xs[0].device.index
+        n = xs[0].numel()
+        icols = np.ascontiguousarray(icols, dtype=np.int32)
+        k = icols.size
+        out = dev.empty_f64((n, k), device)
+        if n == 0 or k == 0:
+            return out
+        if k > _cabi.ISO_MAX_COLS:
+            parts = [self.interp_device(xs, icols[i:i + _cabi.ISO_MAX_COLS], device)
+                     for i in range(0, k, _cabi.ISO_MAX_COLS)]
+            import torch
+            return torch.cat(parts, dim=1)
+        xp = (C.c_void_p * self.ndim)(*[x.data_ptr() for x in xs])
+        _cabi.check(_cabi.lib().iso_interp(self.handle(device), xp, n, icols.ctypes.data_as(C.POINTER(C.c_int32)),
+                                           k, dev.ptr(out), dev.stream_ptr(device)))
+        return out
+
+    def __call__(self, p, cols="all"):
+        icols = self._icols(cols)
+        p = list(p)[: self.ndim] if len(p) > self.ndim else list(p)
+        if len(p) != self.ndim:
+            raise ValueError("expected %d coordinates, got %d" % (self.ndim, len(p)))
+        if any(dev.is_tensor(x) and x.is_cuda for x in p):
+            import torch
+            device = next(x.device.index for x in p if dev.is_tensor(x) and x.is_cuda)
+            xs = torch.broadcast_tensors(*[dev.to_device_f64(x, device) for x in p])
+            xs = [x.reshape(-1).contiguous() for x in xs]
+            return self.interp_device(xs, icols, device)
+        device = dev.current_device()
+        if all(_is_scalar(x) for x in p):
+            xs = [dev.to_device_f64([float(x)], device) for x in p]
+            return self.interp_device(xs, icols, device).cpu().numpy()[0]
+        b = np.broadcast(*p)
+        xs = [dev.to_device_f64(np.atleast_1d(np.resize(x, b.shape)).astype(float).ravel(), device) for x in p]
+        return self.interp_device(xs, icols, device).cpu().numpy()

@@ -1,0 +1,293 @@
+"""``ModelGridInterpolator`` — a stellar-model table bound to a bolometric-correction table.
+
+Keeps the reference's call surface for the hot path (isochrones/models.py:253-718):
+``interp_value(pars, props)``, ``interp_mag(pars, bands)``, ``__call__``, the property shortcuts
+(``mass``, ``Teff``, ``logg`` ...), ``param_names``, ``param_index_order``, ``eep_replaces``,
+``eep_bounds``, ``model_grid`` / ``bc_grid`` with ``.interp`` = :class:`DFInterpolator` and
+``get_limits``.  Evaluation happens in libiso_hip (kernels K3 ``interp_nd`` and K4
+``interp_mag``); inputs may be scalars (reference behaviour: returns scalars/1-D arrays),
+numpy arrays (broadcast, returns numpy) or CUDA tensors (returns CUDA tensors, nothing leaves
+the device).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _cabi, device as dev, grids
+from .interp import DFInterpolator
+
+
+class TableGrid:
+    """Holder of one dense table — the slice of the reference's ``Grid`` API
+    (isochrones/grid.py:10-144) that the numeric path reads."""
+
+    eep_replaces = None
+    bounds = ()
+
+    def __init__(self, interp: DFInterpolator, limits=None, bands=None):
+        self.interp = interp
+        self._limits = dict(self.bounds)
+        self._limits.update(limits or {})
+        self.bands = list(bands) if bands is not None else None
+
+    @property
+    def columns(self):
+        return self.interp.columns
+
+    def get_limits(self, prop):
+        if prop not in self._limits:
+            col = self.interp.grid[..., self.interp.column_index[prop]]
+            self._limits[prop] = (float(np.nanmin(col)), float(np.nanmax(col)))
+        return self._limits[prop]
+
+
+class EvolutionTrackGrid(TableGrid):
+    """index (initial_feh, initial_mass, EEP) — reference: isochrones/mist/models.py:164-173"""
+    eep_replaces = "age"
+    bounds = (("age", (5, 10.13)), ("feh", (-4, 0.5)), ("eep", (0, 1710)), ("mass", (0.1, 300)))
+
+    @property
+    def fehs(self):
+        return self.interp.index_columns[0]
+
+    @property
+    def masses(self):
+        return self.interp.index_columns[1]
+
+
+class IsochroneGrid(TableGrid):
+    """index (log10 age, feh, EEP) — reference: isochrones/mist/models.py:88-99"""
+    eep_replaces = "mass"
+    bounds = (("age", (5, 10.13)), ("feh", (-4, 0.5)), ("eep", (0, 1710)), ("mass", (0.1, 300)))
+
+    @property
+    def ages(self):
+        return self.interp.index_columns[0]
+
+    @property
+    def fehs(self):
+        return self.interp.index_columns[1]
+
+
+class BolometricCorrectionGrid(TableGrid):
+    """index (Teff, logg, [Fe/H], Av), one column per band — reference: isochrones/bc.py:9-118"""
+
+
+class ModelGridInterpolator:
+    param_names = None
+    eep_replaces = None
+    _param_index_order = (1, 2, 0, 3, 4)
+    eep_bounds = (0, 1710)
+    kind = None
+
+    def __init__(self, model_grid: TableGrid, bc_grid: TableGrid, bands=None, eep_bounds=None):
+        self.model_grid = model_grid
+        self.bc_grid = bc_grid
+        self.bands = list(bands) if bands is not None else list(bc_grid.interp.columns)
+        self.param_index_order = list(self._param_index_order)
+        if eep_bounds is not None:
+            self.eep_bounds = tuple(eep_bounds)
+        self._handles = {}
+        ci = model_grid.interp.column_index
+        missing = [c for c in ("Teff", "logg", "feh", "Mbol") if c not in ci]
+        if missing:
+            raise ValueError("model table lacks column(s) %s" % missing)
+        prior_names = ("age", "dt_deep") if self.eep_replaces == "age" else ("mass", "dm_deep")
+        self._cols = [ci[c] for c in ("Teff", "logg", "feh", "Mbol")]
+        self._prior_cols = [ci.get(prior_names[0], -1), ci.get(prior_names[1], -1)]
+        if -1 in self._prior_cols:
+            self._prior_cols = [-1, -1]
+        self._astero_cols = [ci.get("nu_max", -1), ci.get("delta_nu", -1)]
+        if -1 in self._astero_cols:
+            self._astero_cols = [-1, -1]
+
+    # -- limits -----------------------------------------------------------------------------
+    minfeh = property(lambda s: s.model_grid.get_limits("feh")[0])
+    maxfeh = property(lambda s: s.model_grid.get_limits("feh")[1])
+    mineep = property(lambda s: s.model_grid.get_limits("eep")[0])
+    maxeep = property(lambda s: s.model_grid.get_limits("eep")[1])
+    minage = property(lambda s: s.model_grid.get_limits("age")[0])
+    maxage = property(lambda s: s.model_grid.get_limits("age")[1])
+    minmass = property(lambda s: s.model_grid.get_limits("mass")[0])
+    maxmass = property(lambda s: s.model_grid.get_limits("mass")[1])
+
+    @property
+    def fehs(self):
+        return self.model_grid.fehs
+
+    # -- device residency -------------------------------------------------------------------
+    def handle(self, device=None):
+        """iso_ic* for `device`: both tables uploaded once + packed hot-column table built."""
+        if device is None:
+            device = dev.current_device()
+        h = self._handles.get(device)
+        if h is None:
+            ctx = dev.context(device)
+            mg = self.model_grid.interp.handle(device)
+            bc = self.bc_grid.interp.handle(device)
+            _, cols = dev.i32_array(self._cols)
+            _, pcols = dev.i32_array(self._prior_cols)
+            _, acols = dev.i32_array(self._astero_cols)
+            h = C.c_void_p()
+            _cabi.check(_cabi.lib().iso_ic_create(ctx, mg, bc, self.kind, cols, pcols, acols, C.byref(h)))
+            self._handles[device] = h
+        return h
+
+    def release(self):
+        for h in self._handles.values():
+            _cabi.lib().iso_ic_destroy(h)
+        self._handles = {}
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+    # -- hot path ---------------------------------------------------------------------------
+    def interp_value(self, pars, props):
+        """Interpolate model-table columns ``props`` at ``pars`` (in ``param_names`` order; only
+        the first three are used).  reference: isochrones/models.py:390-400"""
+        i0, i1, i2 = self.param_index_order[:3]
+        p = [pars[i0], pars[i1], pars[i2]]
+        p = [float(x) if isinstance(x, (np.floating, np.integer)) else x for x in p]
+        return self.model_grid.interp(p, props)
+
+    def _band_cols(self, bands):
+        cols = self.bc_grid.interp.columns
+        return np.array([cols.index(b) for b in bands], dtype=np.int32)
+
+    def interp_mag_device(self, pars, bands=None, device=None):
+        """pars: CUDA float64 tensor [5, N] (SoA) -> (Teff[N], logg[N], feh[N], mags[N, nb]) tensors."""
+        bands = self.bands if bands is None else bands
+        if device is None:
+            device = pars.device.index
+        n = pars.shape[1]
+        nb = len(bands)
+        if nb > _cabi.ISO_MAX_BANDS:
+            raise ValueError("at most %d bands per call" % _cabi.ISO_MAX_BANDS)
+        Teff = dev.empty_f64((n,), device)
+        logg = dev.empty_f64((n,), device)
+        feh = dev.empty_f64((n,), device)
+        mags = dev.empty_f64((n, nb), device)
+        if n:
+            bc_cols, bcp = dev.i32_array(self._band_cols(bands))
+            _cabi.check(_cabi.lib().iso_interp_mag(self.handle(device), dev.ptr(pars), 1, n, n, bcp, nb,
+                                                   dev.ptr(Teff), dev.ptr(logg), dev.ptr(feh), dev.ptr(mags),
+                                                   dev.stream_ptr(device)))
+        return Teff, logg, feh, mags
+
+    def interp_mag(self, pars, bands):
+        """(Teff, logg, feh, mags) at ``pars`` = the five ``param_names``.
+        reference: isochrones/models.py:402-445 (scalar form -> mags.interp_mag, array form ->
+        mags.interp_mags)."""
+        bands = list(bands) if bands else []
+        if dev.is_tensor(pars) and pars.is_cuda:
+            p = pars.to(dtype=pars.dtype).double()
+            if p.dim() == 1:
+                p = p[:, None]
+            return self.interp_mag_device(p.contiguous(), bands)
+        if not isinstance(pars, np.ndarray) and any(dev.is_tensor(x) and x.is_cuda for x in pars):
+            import torch
+            device = next(x.device.index for x in pars if dev.is_tensor(x) and x.is_cuda)
+            xs = torch.broadcast_tensors(*[dev.to_device_f64(x, device) for x in pars])
+            p = torch.stack([x.reshape(-1) for x in xs]).contiguous()
+            return self.interp_mag_device(p, bands, device)
+        device = dev.current_device()
+        scalar = False
+        try:
+            arr = np.atleast_1d(pars).astype(float).squeeze()
+            if arr.ndim > 1 or arr.shape != (5,):
+                raise ValueError
+            scalar = True
+            p = arr.reshape(5, 1)
+        except (TypeError, ValueError):
+            b = np.broadcast(*pars)
+            p = np.array([np.resize(x, b.shape).astype(float).ravel() for x in pars])
+        Teff, logg, feh, mags = self.interp_mag_device(dev.to_device_f64(p, device), bands, device)
+        Teff, logg, feh, mags = (t.cpu().numpy() for t in (Teff, logg, feh, mags))
+        if scalar:
+            return Teff[0], logg[0], feh[0], mags[0]
+        return Teff, logg, feh, mags
+
+    # property shortcuts (reference: models.py:358-388)
+    def _prop(self, prop, *pars):
+        return np.squeeze(self.interp_value(pars, [prop]))
+
+    def mass(self, *pars): return self._prop("mass", *pars)
+    def initial_mass(self, *pars): return self._prop("initial_mass", *pars)
+    def radius(self, *pars): return self._prop("radius", *pars)
+    def Teff(self, *pars): return self._prop("Teff", *pars)
+    def logg(self, *pars): return self._prop("logg", *pars)
+    def feh(self, *pars): return self._prop("feh", *pars)
+    def density(self, *pars): return self._prop("density", *pars)
+    def nu_max(self, *pars): return self._prop("nu_max", *pars)
+    def delta_nu(self, *pars): return self._prop("delta_nu", *pars)
+
+    def __call__(self, p1, p2, p3, distance=10.0, AV=0.0):
+        """All model columns + every band's magnitude, as a DataFrame
+        (reference: isochrones/models.py:471-482)."""
+        import pandas as pd
+        p1, p2, p3, dist, AV = [np.atleast_1d(a).astype(float).ravel()
+                                for a in np.broadcast_arrays(p1, p2, p3, distance, AV)]
+        pars = [p1, p2, p3, dist, AV]
+        prop_cols = list(self.model_grid.interp.columns)
+        props = self.interp_value(pars, prop_cols)
+        _, _, _, mags = self.interp_mag(pars, self.bands)
+        cols = prop_cols + ["{}_mag".format(b) for b in self.bands]
+        values = np.concatenate([np.atleast_2d(props), np.atleast_2d(mags)], axis=1)
+        return pd.DataFrame(values, columns=cols)
+
+
+class EvolutionTrackInterpolator(ModelGridInterpolator):
+    """(mass, eep, feh, distance, AV) over a (feh, mass, eep) table — reference: models.py:664-688"""
+    param_names = ("mass", "eep", "feh", "distance", "AV")
+    eep_replaces = "age"
+    _param_index_order = (2, 0, 1, 3, 4)
+    kind = _cabi.KIND_TRACK
+
+
+class IsochroneInterpolator(ModelGridInterpolator):
+    """(eep, age, feh, distance, AV) over an (age, feh, eep) table — reference: models.py:691-718"""
+    param_names = ("eep", "age", "feh", "distance", "AV")
+    eep_replaces = "mass"
+    _param_index_order = (1, 2, 0, 3, 4)
+    kind = _cabi.KIND_ISO
+
+
+# ------------------------------------------------------------------------------------------
+# factories over the synthetic MIST-shaped tables (real MIST data needs the network)
+# ------------------------------------------------------------------------------------------
+
+def _bc(bands, bc_axes=None):
+    g, ax, cols = grids.synthetic_bc_grid(tuple(bands), bc_axes)
+    return BolometricCorrectionGrid(DFInterpolator.from_arrays(g, ax, cols, ["Teff", "logg", "[Fe/H]", "Av"]),
+                                    bands=bands)
+
+
+def synthetic_track(bands=grids.DEFAULT_BANDS, fehs=None, masses=None, eeps=None, bc_axes=None,
+                    limits=None, eep_bounds=None, ragged=True):
+    """MIST_EvolutionTrack-shaped interpolator over the synthetic tables."""
+    g, ax, cols = grids.synthetic_track_grid(fehs, masses, eeps, ragged=ragged)
+    mg = EvolutionTrackGrid(DFInterpolator.from_arrays(g, ax, cols, ["initial_feh", "initial_mass", "EEP"]),
+                            limits=limits)
+    return EvolutionTrackInterpolator(mg, _bc(bands, bc_axes), bands=bands, eep_bounds=eep_bounds)
+
+
+def synthetic_isochrone(bands=grids.DEFAULT_BANDS, ages=None, fehs=None, eeps=None, bc_axes=None,
+                        limits=None, eep_bounds=None, ragged=True):
+    """MIST_Isochrone-shaped interpolator over the synthetic tables."""
+    g, ax, cols = grids.synthetic_iso_grid(ages, fehs, eeps, ragged=ragged)
+    mg = IsochroneGrid(DFInterpolator.from_arrays(g, ax, cols, ["log10_isochrone_age_yr", "feh", "EEP"]),
+                       limits=limits)
+    return IsochroneInterpolator(mg, _bc(bands, bc_axes), bands=bands, eep_bounds=eep_bounds)
+
+
+def get_ichrone(models="mist", bands=None, tracks=False, **kwargs):
+    """Reference-style factory (isochrones/isochrone.py:48-78) over the synthetic tables."""
+    if models not in ("mist", "synthetic"):
+        raise ValueError("only the MIST-shaped synthetic tables are available offline")
+    bands = grids.DEFAULT_BANDS if bands is None else tuple(bands)
+    return synthetic_track(bands, **kwargs) if tracks else synthetic_isochrone(bands, **kwargs)

@@ -1,0 +1,376 @@
+"""Host-side prior descriptions.
+
+On the GPU the priors are evaluated inside the fused ``lnpost`` kernel; the host only owns the
+per-model *constants* (bounds, normalisations) and packs them into ``iso_prior`` records
+(include/isochrones_amd.h).  Class names and the meaning of ``bounds`` follow the reference
+(isochrones/priors.py) so that ``StarModel._priors`` / ``set_prior`` / ``set_bounds`` read the
+same; only the families the reference's ``BasicStarModel`` installs by default (plus the
+simple bounded ones) are supported on the device — anything else raises at model build time.
+
+Normalisation constants are obtained exactly the way the reference obtains them
+(``scipy.integrate.quad`` over the same integrand: priors.py:42-45 for ``FehPrior``,
+:171-203 for the broken Chabrier IMF) so that they agree to the last bit; closed forms are
+used as a cross-check in the tests and as a fallback when scipy is unavailable.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from . import _cabi
+
+_ROOT_2PI = float(np.sqrt(2 * np.pi))
+_LN10 = float(np.log(10))
+
+try:  # scipy is part of the image; keep a closed-form fallback anyway
+    from scipy.integrate import quad as _quad
+except Exception:  # pragma: no cover
+    _quad = None
+
+
+def _ncdf(z):
+    return 0.5 * math.erfc(-z / math.sqrt(2.0))
+
+
+class Prior:
+    """Common surface: ``bounds``, ``pdf(x)``, ``lnpdf(x)``, ``__call__`` (= pdf), ``desc()``."""
+
+    kind = 0
+    bounded = 0
+    _bounds = (-np.inf, np.inf)
+
+    @property
+    def bounds(self):
+        return self._bounds
+
+    @bounds.setter
+    def bounds(self, new):
+        self._bounds = (float(new[0]), float(new[1]))
+        self._rebuild()
+
+    def _rebuild(self):
+        pass
+
+    def _raw(self, x):
+        raise NotImplementedError
+
+    def pdf(self, x):
+        lo, hi = self.bounds
+        if x < lo or x > hi:
+            return 0.0
+        return self._raw(x)
+
+    __call__ = pdf
+
+    def lnpdf(self, x):
+        if self.bounded:
+            lo, hi = self.bounds
+            if x < lo or x > hi:
+                return -np.inf
+        p = self.pdf(x)
+        return float(np.log(p)) if p else -np.inf
+
+    def sample(self, n, rng=None):
+        raise NotImplementedError
+
+    def _fields(self):
+        return {}
+
+    def desc(self) -> _cabi.IsoPrior:
+        d = _cabi.IsoPrior()
+        d.kind = self.kind
+        d.bounded = self.bounded
+        d.lo, d.hi = self.bounds
+        for k, v in self._fields().items():
+            setattr(d, k, float(v))
+        return d
+
+
+class FlatPrior(Prior):
+    kind = _cabi.PRIOR_FLAT
+    bounded = 1
+
+    def __init__(self, bounds):
+        self._bounds = (float(bounds[0]), float(bounds[1]))
+
+    def _raw(self, x):
+        lo, hi = self.bounds
+        return 1.0 / (hi - lo)
+
+    def sample(self, n, rng=None):
+        rng = rng or np.random.default_rng()
+        lo, hi = self.bounds
+        return rng.random(n) * (hi - lo) + lo
+
+
+class FlatLogPrior(Prior):
+    """pdf flat in 10**x (x is a log10 quantity)."""
+    kind = _cabi.PRIOR_FLATLOG
+    bounded = 1
+
+    def __init__(self, bounds):
+        self._bounds = (float(bounds[0]), float(bounds[1]))
+
+    def _raw(self, x):
+        lo, hi = self.bounds
+        return _LN10 * 10 ** x / (10 ** hi - 10 ** lo)
+
+    def sample(self, n, rng=None):
+        rng = rng or np.random.default_rng()
+        lo, hi = self.bounds
+        return np.log10(rng.random(n) * (10 ** hi - 10 ** lo) + 10 ** lo)
+
+
+class PowerLawPrior(Prior):
+    kind = _cabi.PRIOR_POWERLAW
+    bounded = 1
+
+    def __init__(self, alpha, bounds):
+        self.alpha = float(alpha)
+        self._bounds = (float(bounds[0]), float(bounds[1]))
+
+    def _C(self):
+        lo, hi = self.bounds
+        a1 = 1 + self.alpha
+        return a1 / (hi ** a1 - lo ** a1)
+
+    def _raw(self, x):
+        return self._C() * x ** self.alpha
+
+    def lnpdf(self, x):
+        lo, hi = self.bounds
+        if x < lo or x > hi:
+            return -np.inf
+        with np.errstate(divide="ignore"):
+            return float(np.log(self._C()) + self.alpha * np.log(x))
+
+    def sample(self, n, rng=None):
+        rng = rng or np.random.default_rng()
+        lo, hi = self.bounds
+        a1 = 1 + self.alpha
+        u = rng.random(n)
+        return (u * (hi ** a1 - lo ** a1) + lo ** a1) ** (1 / a1)
+
+    def _fields(self):
+        return dict(a=self.alpha)
+
+
+class GaussianPrior(Prior):
+    kind = _cabi.PRIOR_GAUSS
+
+    def __init__(self, mean, sigma, bounds=None):
+        self.mean, self.sigma = float(mean), float(sigma)
+        if bounds is not None:
+            self.bounded = 1
+            self._bounds = (float(bounds[0]), float(bounds[1]))
+            a, b = (self._bounds[0] - mean) / sigma, (self._bounds[1] - mean) / sigma
+            self.norm = _ncdf(b) - _ncdf(a)
+        else:
+            self.bounded = 0
+            self.norm = 1.0
+        self.lognorm = math.log(self.norm)
+
+    def _raw(self, x):
+        z = (x - self.mean) / self.sigma
+        return math.exp(-(z * z) / 2.0) / _ROOT_2PI / self.sigma / self.norm
+
+    def lnpdf(self, x):
+        if self.bounded and (x < self._bounds[0] or x > self._bounds[1]):
+            return -np.inf
+        z = (x - self.mean) / self.sigma
+        return -(z * z) / 2.0 - math.log(_ROOT_2PI) - math.log(self.sigma) - self.lognorm
+
+    def sample(self, n, rng=None):
+        rng = rng or np.random.default_rng()
+        out = rng.standard_normal(n) * self.sigma + self.mean
+        if self.bounded:
+            lo, hi = self._bounds
+            bad = (out < lo) | (out > hi)
+            while bad.any():
+                out[bad] = rng.standard_normal(int(bad.sum())) * self.sigma + self.mean
+                bad = (out < lo) | (out > hi)
+        return out
+
+    def _fields(self):
+        return dict(a=self.mean, b=self.sigma, c=self.lognorm)
+
+
+class LogNormalPrior(Prior):
+    kind = _cabi.PRIOR_LOGNORMAL
+
+    def __init__(self, mu, sigma):
+        self.mu, self.sigma = float(mu), float(sigma)
+        self.scale = float(np.exp(mu))
+        self._bounds = (0.0, np.inf)
+
+    def _raw(self, x):
+        s = self.sigma
+        y = x / self.scale
+        return (1.0 / _ROOT_2PI) / (s * y) * np.exp(-0.5 * (np.log(y) / s) ** 2) / self.scale
+
+    def lnpdf(self, x):
+        s = self.sigma
+        y = x / self.scale
+        return float(np.log(1.0 / _ROOT_2PI) - (np.log(s) + np.log(y)) - 0.5 * (np.log(y) / s) ** 2 - self.mu)
+
+    def sample(self, n, rng=None):
+        rng = rng or np.random.default_rng()
+        return np.exp(rng.standard_normal(n) * self.sigma + self.mu)
+
+    def _fields(self):
+        return dict(a=self.mu, b=self.sigma)
+
+
+class ChabrierPrior(Prior):
+    """Chabrier (2003) IMF: log-normal below the breakpoint, power law above, continuous at the
+    breakpoint and normalised over ``bounds`` (reference: priors.py:143-232, 514-519)."""
+    kind = _cabi.PRIOR_CHABRIER
+
+    def __init__(self, bounds=(0.1, 100.0), mu=math.log(0.079), sigma=0.69 * math.log(10),
+                 alpha=-2.35, breakpoint=1.0, powerlaw_bounds=(1.0, 100.0)):
+        self.low = LogNormalPrior(mu, sigma)
+        self.high = PowerLawPrior(alpha, powerlaw_bounds)
+        self.breakpoint = float(breakpoint)
+        self._bounds = (float(bounds[0]), float(bounds[1]))
+        self._rebuild()
+
+    def _rebuild(self):
+        lo, hi = self._bounds
+        bp = self.breakpoint
+        ratio = self.high(bp) / self.low(bp)
+        if _quad is not None:
+            tot = (_quad(lambda x: self.low(x) / 1.0, lo, bp, limit=200)[0]
+                   + _quad(lambda x: self.high(x) / ratio, bp, hi, limit=200)[0])
+        else:  # pragma: no cover
+            tot = self.closed_form_total(ratio)
+        self.norms = np.array([1.0, ratio]) * tot
+        self.lognorms = np.log(self.norms)
+
+    def closed_form_total(self, ratio=None):
+        lo, hi = self._bounds
+        bp = self.breakpoint
+        if ratio is None:
+            ratio = self.high(bp) / self.low(bp)
+        s, mu = self.low.sigma, self.low.mu
+        low_mass = _ncdf((math.log(bp) - mu) / s) - (_ncdf((math.log(lo) - mu) / s) if lo > 0 else 0.0)
+        plo, phi = self.high.bounds
+        a1 = 1 + self.high.alpha
+        top = min(hi, phi)
+        high_mass = (top ** a1 - max(bp, plo) ** a1) / (phi ** a1 - plo ** a1) if top > bp else 0.0
+        return low_mass + high_mass / ratio
+
+    def _raw(self, x):
+        if x < self.breakpoint:
+            return self.low(x) / self.norms[0]
+        return self.high(x) / self.norms[1]
+
+    def lnpdf(self, x):
+        # no bounds test on this path in the reference (BrokenPrior._lnpdf)
+        if x < self.breakpoint:
+            return self.low.lnpdf(x) - self.lognorms[0]
+        return self.high.lnpdf(x) - self.lognorms[1]
+
+    def sample(self, n, rng=None):
+        rng = rng or np.random.default_rng()
+        lo, hi = self._bounds
+        out = np.empty(n)
+        filled = 0
+        # rejection from a log-uniform proposal — adequate for start-point generation
+        pmax = max(self.pdf(x) * x for x in np.geomspace(max(lo, 1e-3), hi, 400))
+        while filled < n:
+            m = max(2 * (n - filled), 64)
+            x = np.exp(rng.uniform(np.log(max(lo, 1e-3)), np.log(hi), m))
+            keep = rng.random(m) * pmax * 1.05 < np.array([self.pdf(v) * v for v in x])
+            take = x[keep][: n - filled]
+            out[filled:filled + take.size] = take
+            filled += take.size
+        return out
+
+    def _fields(self):
+        return dict(a=self.low.mu, b=self.low.sigma, c=self.high.alpha, d=self.breakpoint,
+                    e=self.norms[0], f=self.norms[1], g=self.high.bounds[0], h=self.high.bounds[1])
+
+
+class FehPrior(Prior):
+    """Two-Gaussian local disk + halo metallicity distribution (reference: priors.py:345-381)."""
+    kind = _cabi.PRIOR_FEH
+
+    def __init__(self, halo_fraction=0.001, local=True, bounds=None):
+        self.halo_fraction = float(halo_fraction)
+        self.local = bool(local)
+        self._norm = 1.0
+        if bounds is not None:
+            self.bounds = bounds
+
+    def _rebuild(self):
+        lo, hi = self._bounds
+        if _quad is not None:
+            self._norm = _quad(self._shape, lo, hi)[0]
+        else:  # pragma: no cover
+            self._norm = self.closed_form_norm()
+
+    def closed_form_norm(self):
+        lo, hi = self._bounds
+        comps = ([(0.8, 0.016, 0.15), (0.2, -0.15, 0.22)] if self.local else [(1.0, -0.3, 0.3)])
+        disk = sum(w * (_ncdf((hi - m) / s) - _ncdf((lo - m) / s)) for w, m, s in comps)
+        if self.local:
+            disk *= _ROOT_2PI / 2.5066282746310007
+        halo = _ncdf((hi + 1.5) / 0.4) - _ncdf((lo + 1.5) / 0.4)
+        return self.halo_fraction * halo + (1 - self.halo_fraction) * disk
+
+    def _shape(self, feh):
+        if self.local:
+            disk = (1.0 / 2.5066282746310007
+                    * (0.8 / 0.15 * np.exp(-0.5 * (feh - 0.016) ** 2.0 / 0.15 ** 2.0)
+                       + 0.2 / 0.22 * np.exp(-0.5 * (feh + 0.15) ** 2.0 / 0.22 ** 2.0)))
+        else:
+            mu, sig = -0.3, 0.3
+            disk = 1.0 / np.sqrt(2 * np.pi) / sig * np.exp(-0.5 * (feh - mu) ** 2 / sig ** 2)
+        hmu, hsig = -1.5, 0.4
+        halo = 1.0 / np.sqrt(2 * np.pi * hsig ** 2) * np.exp(-0.5 * (feh - hmu) ** 2 / hsig ** 2)
+        return self.halo_fraction * halo + (1 - self.halo_fraction) * disk
+
+    def _raw(self, x):
+        return self._shape(x) / self._norm
+
+    def sample(self, n, rng=None):
+        rng = rng or np.random.default_rng()
+        comps = ([(0.8, 0.016, 0.15), (0.2, -0.15, 0.22)] if self.local else [(1.0, -0.3, 0.3)])
+        w = np.array([c[0] for c in comps]) * (1 - self.halo_fraction)
+        w = np.append(w, self.halo_fraction)
+        mus = np.array([c[1] for c in comps] + [-1.5])
+        sig = np.array([c[2] for c in comps] + [0.4])
+        k = rng.choice(len(w), size=n, p=w / w.sum())
+        out = rng.standard_normal(n) * sig[k] + mus[k]
+        lo, hi = self.bounds
+        bad = (out < lo) | (out > hi)
+        while bad.any():
+            kk = rng.choice(len(w), size=int(bad.sum()), p=w / w.sum())
+            out[bad] = rng.standard_normal(kk.size) * sig[kk] + mus[kk]
+            bad = (out < lo) | (out > hi)
+        return out
+
+    def _fields(self):
+        return dict(a=self.halo_fraction, b=self._norm, c=1.0 if self.local else 0.0)
+
+
+class AgePrior(FlatLogPrior):
+    """Uniform in linear age; the parameter is log10(age/yr)."""
+
+    def __init__(self, bounds=(5, 10.15)):
+        super().__init__(bounds)
+
+
+class DistancePrior(PowerLawPrior):
+    def __init__(self, max_distance=10000):
+        super().__init__(alpha=2.0, bounds=(0, max_distance))
+
+
+class AVPrior(FlatPrior):
+    def __init__(self, bounds=(0, 1.0)):
+        super().__init__(bounds)
+
+
+DEVICE_PRIOR_TYPES = (FlatPrior, FlatLogPrior, PowerLawPrior, GaussianPrior, LogNormalPrior,
+                      ChabrierPrior, FehPrior)

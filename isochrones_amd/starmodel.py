@@ -1,0 +1,334 @@
+"""``BasicStarModel`` (+ Single/Binary/TripleStarModel): the posterior of an unresolved 1-3 star
+system, evaluated by the fused HIP ``lnpost`` kernel.
+
+Call surface follows the reference (isochrones/starmodel.py:1361-2007): constructor keywords
+``Teff=(val, unc)``, ``logg=``, ``feh=``, ``parallax=``, ``nu_max=``, ``delta_nu=``, ``<band>=``,
+``N``, ``eep_bounds``, ``maxAV``, ``max_distance``, ``halo_fraction``; ``param_names``,
+``n_params``, ``bands``, ``spec_props``, ``bounds(prop)``, ``set_bounds``, ``set_prior``,
+``lnpost(p)``, ``lnlike(p)``, ``lnprior(p)``, ``mnest_prior(cube, ndim, nparams)``,
+``mnest_loglike``.  ``p`` may be
+
+* one parameter vector  -> python float (what emcee / MultiNest callbacks expect),
+* a numpy array ``[N, n_params]`` (emcee ``vectorize=True`` convention) -> numpy ``[N]``,
+* a CUDA float64 tensor ``[N, n_params]`` or, with ``soa=True``, ``[n_params, N]`` -> CUDA ``[N]``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import logging
+
+import numpy as np
+
+from . import _cabi, device as dev
+from .priors import (AgePrior, AVPrior, ChabrierPrior, DistancePrior, FehPrior, DEVICE_PRIOR_TYPES)
+
+logger = logging.getLogger("isochrones_amd")
+
+_NOT_A_BAND = ("RA", "dec", "ra", "Dec", "maxAV", "parallax", "AV", "logg", "Teff", "feh", "density",
+               "separation", "PA", "resolution", "relative", "N", "index", "id", "nu_max", "delta_nu")
+
+
+class EEPPrior:
+    """Marker for the EEP prior: pdf(eep) = orig_prior(orig(eep)) * d(orig)/d(eep), evaluated on
+    the device by interpolating (age, dt_deep) or (mass, dm_deep) (reference: priors.py:409-429)."""
+
+    def __init__(self, ic, orig_prior, bounds=None):
+        self.ic = ic
+        self.orig_prior = orig_prior
+        self.bounds = tuple(bounds) if bounds is not None else tuple(ic.eep_bounds)
+        self.orig_par = ic.eep_replaces
+
+
+class BasicStarModel:
+    def __init__(self, ic, eep_bounds=None, name="", directory=".", N=1, maxAV=None, max_distance=None,
+                 halo_fraction=None, ra=None, dec=None, obs=None, use_emcee=False, **kwargs):
+        self._ic = ic
+        self.eep_bounds = tuple(eep_bounds) if eep_bounds is not None else tuple(ic.eep_bounds)
+        self.name = str(name)
+        self.ra, self.dec = ra, dec
+        if N not in (1, 2, 3):
+            raise ValueError("N must be 1, 2 or 3")
+        if N > 1 and ic.eep_replaces == "age":
+            raise ValueError("Can only fit mulitple stars with IsochroneInterpolator!")
+        self.N = N
+        if ic.eep_replaces == "age":
+            self.mass_index, self.feh_index, self.distance_index, self.AV_index = 0, 2, 3, 4
+        else:
+            self.age_index = N
+            self.feh_index, self.distance_index, self.AV_index = N + 1, N + 2, N + 3
+
+        self.kwargs = {}
+        for k, v in kwargs.items():
+            try:
+                val, unc = v
+                if not (np.isnan(val) or np.isnan(unc)):
+                    self.kwargs[k] = (np.float64(val), np.float64(unc))
+            except TypeError:
+                logger.warning("kwarg {}={} ignored!".format(k, v))
+
+        self._priors = {"mass": ChabrierPrior(), "feh": FehPrior(), "age": AgePrior(),
+                        "distance": DistancePrior(), "AV": AVPrior()}
+        self._priors["eep"] = EEPPrior(ic, self._priors[ic.eep_replaces], bounds=eep_bounds)
+        self._bounds = {"mass": None, "feh": None, "age": None,
+                        "distance": self._priors["distance"].bounds, "AV": self._priors["AV"].bounds,
+                        "eep": self._priors["eep"].bounds}
+        for par in ("mass", "feh", "age"):   # snap to the table's limits (starmodel.py:1459-1460)
+            self.bounds(par)
+        if maxAV is not None:
+            self.set_bounds(AV=(0, maxAV))
+        if max_distance is not None:
+            self.set_bounds(distance=(0, max_distance))
+        elif "parallax" in kwargs:
+            value, unc = kwargs["parallax"]
+            if value > 0:
+                self.set_bounds(distance=(0, 1.0 / value * 2000))
+            elif value < 0:
+                self.set_bounds(distance=(0, 1.0 / np.abs(unc) * 2000))
+        if halo_fraction is not None:
+            self._priors["feh"] = FehPrior(halo_fraction=halo_fraction)
+        self._handles = {}
+
+    # -- description ------------------------------------------------------------------------
+    @property
+    def ic(self):
+        return self._ic
+
+    @property
+    def labelstring(self):
+        return {1: "single", 2: "binary", 3: "triple"}[self.N]
+
+    @property
+    def param_names(self):
+        base = tuple(self.ic.param_names)
+        if self.N == 1:
+            return base
+        return tuple(["eep_%d" % i for i in range(self.N)] + list(base[1:]))
+
+    @property
+    def n_params(self):
+        return len(self.param_names)
+
+    @property
+    def bands(self):
+        return [k for k in self.kwargs if k in self.ic.bc_grid.bands]
+
+    @property
+    def props(self):
+        return [k for k in self.kwargs if k in _NOT_A_BAND]
+
+    @property
+    def spec_props(self):
+        return [self.kwargs.get(k, (np.nan, np.nan)) for k in ("Teff", "logg", "feh")]
+
+    def bounds(self, prop):
+        if prop in ("eep_0", "eep_1", "eep_2"):
+            prop = "eep"
+        if self._bounds[prop] is None:
+            if prop not in ("mass", "feh", "age"):
+                raise ValueError("Unknown property {}".format(prop))
+            lo, hi = self.ic.model_grid.get_limits(prop)
+            self._bounds[prop] = (lo, hi)
+            self._priors[prop].bounds = (lo, hi)
+            self._dirty()
+        return self._bounds[prop]
+
+    def set_bounds(self, **kwargs):
+        for k, v in kwargs.items():
+            if len(v) != 2:
+                raise ValueError("Must provide (min, max)")
+            self._bounds[k] = tuple(v)
+            self._priors[k].bounds = tuple(v)
+        self._dirty()
+
+    def set_prior(self, **kwargs):
+        for prop, prior in kwargs.items():
+            if prop == "eep" or not isinstance(prior, DEVICE_PRIOR_TYPES):
+                raise NotImplementedError("prior %r for %r is not evaluable on the device" % (prior, prop))
+            self._priors[prop] = prior
+            self._bounds[prop] = prior.bounds
+            if prop == self.ic.eep_replaces:
+                self._priors["eep"].orig_prior = prior
+        self._dirty()
+
+    def model_desc(self) -> _cabi.IsoModelDesc:
+        """Pack observations + prior constants into the C-ABI descriptor (host only)."""
+        d = _cabi.IsoModelDesc()
+        d.n_stars = self.N
+        bands = self.bands
+        if len(bands) > _cabi.ISO_MAX_BANDS:
+            raise ValueError("at most %d bands" % _cabi.ISO_MAX_BANDS)
+        d.n_bands = len(bands)
+        ci = self.ic.bc_grid.interp.column_index
+        for j, b in enumerate(bands):
+            d.bc_cols[j] = ci[b]
+            d.mag_val[j], d.mag_unc[j] = self.kwargs[b]
+        for j, (val, unc) in enumerate(self.spec_props):
+            d.spec_val[j], d.spec_unc[j] = val, unc
+        if "parallax" in self.kwargs:
+            d.has_parallax = 1
+            d.plx_val, d.plx_unc = self.kwargs["parallax"]
+        if "nu_max" in self.kwargs:
+            if -1 in self.ic._astero_cols:
+                raise ValueError("model table has no nu_max/delta_nu columns")
+            d.has_numax = 1
+            d.numax_val, d.numax_unc = self.kwargs["nu_max"]
+            if "delta_nu" in self.kwargs:
+                d.has_dnu = 1
+                # the reference passes the *value* as the uncertainty (starmodel.py:1612)
+                d.dnu_val = self.kwargs["delta_nu"][0]
+                d.dnu_unc = self.kwargs["delta_nu"][0]
+        for name in ("mass", "age", "feh", "distance", "AV"):
+            setattr(d, "prior_" + name, self._priors[name].desc())
+        d.eep_lo, d.eep_hi = self._priors["eep"].bounds
+        for j, par in enumerate(self.param_names):
+            d.bound_lo[j], d.bound_hi[j] = self.bounds(par)
+        return d
+
+    # -- device -----------------------------------------------------------------------------
+    def _dirty(self):
+        for h in getattr(self, "_handles", {}).values():
+            _cabi.lib().iso_model_destroy(h)
+        self._handles = {}
+
+    def handle(self, device=None):
+        if device is None:
+            device = dev.current_device()
+        h = self._handles.get(device)
+        if h is None:
+            if -1 in self.ic._prior_cols:
+                raise ValueError("model table lacks the (%s, d%s_deep) columns the EEP prior needs"
+                                 % (self.ic.eep_replaces, "t" if self.ic.eep_replaces == "age" else "m"))
+            desc = self.model_desc()
+            h = C.c_void_p()
+            _cabi.check(_cabi.lib().iso_model_create(self.ic.handle(device), C.byref(desc), C.byref(h)))
+            self._handles[device] = h
+        return h
+
+    def __del__(self):
+        try:
+            self._dirty()
+        except Exception:
+            pass
+
+    def evaluate_device(self, pars, soa=False, parts=False):
+        """pars: CUDA float64 tensor, [N, n_params] (or [n_params, N] if soa).
+        Returns lnpost[N] or (lnpost, lnprior, lnlike)."""
+        if pars.dim() != 2:
+            raise ValueError("pars must be 2-D")
+        npar = self.n_params
+        if soa:
+            if pars.shape[0] != npar:
+                raise ValueError("expected [%d, N]" % npar)
+            n, stride_n, stride_p = pars.shape[1], 1, pars.shape[1]
+        else:
+            if pars.shape[1] != npar:
+                raise ValueError("expected [N, %d]" % npar)
+            n, stride_n, stride_p = pars.shape[0], npar, 1
+        device = pars.device.index
+        pars = pars.contiguous()
+        post = dev.empty_f64((n,), device)
+        prior = dev.empty_f64((n,), device) if parts else None
+        like = dev.empty_f64((n,), device) if parts else None
+        if n:
+            _cabi.check(_cabi.lib().iso_lnpost(self.handle(device), dev.ptr(pars), stride_n, stride_p, n,
+                                               dev.ptr(post), dev.ptr(prior), dev.ptr(like),
+                                               dev.stream_ptr(device)))
+        return (post, prior, like) if parts else post
+
+    def _evaluate(self, p, which, soa=False):
+        if dev.is_tensor(p) and p.is_cuda:
+            import torch
+            single = p.dim() == 1
+            pp = p.double()[None, :] if single else p.double()
+            out = self.evaluate_device(pp, soa=soa and not single, parts=which != 0)
+            out = out if which == 0 else out[which]
+            return out[0] if single else out
+        arr = np.asarray(p, dtype=float)
+        single = arr.ndim == 1
+        a2 = arr[None, :] if single else arr
+        device = dev.current_device()
+        out = self.evaluate_device(dev.to_device_f64(a2, device), soa=soa and not single, parts=which != 0)
+        out = (out if which == 0 else out[which]).cpu().numpy()
+        return float(out[0]) if single else out
+
+    def lnpost(self, p, soa=False):
+        return self._evaluate(p, 0, soa)
+
+    def lnprior(self, p, soa=False):
+        return self._evaluate(p, 1, soa)
+
+    def lnlike(self, p, soa=False):
+        return self._evaluate(p, 2, soa)
+
+    # -- nested-sampling style API (reference: starmodel.py:1637-1645) -----------------------
+    def mnest_prior(self, cube, ndim=None, nparams=None):
+        """Unit cube -> parameter bounds, in place.  ``cube`` may be a 1-D sequence (reference
+        behaviour, handled on the host: it is 5-7 multiply-adds) or a CUDA tensor [N, n_params]
+        (transformed by the device kernel)."""
+        if dev.is_tensor(cube) and cube.is_cuda:
+            c2 = cube if cube.dim() == 2 else cube[None, :]
+            if not c2.is_contiguous() or c2.dtype.itemsize != 8:
+                raise ValueError("cube must be a contiguous float64 tensor")
+            n = c2.shape[0]
+            _cabi.check(_cabi.lib().iso_unit_cube(self.handle(c2.device.index), dev.ptr(c2), self.n_params, 1, n,
+                                                  dev.stream_ptr(c2.device.index)))
+            return cube
+        for i, par in enumerate(self.param_names):
+            lo, hi = self.bounds(par)
+            cube[i] = (hi - lo) * cube[i] + lo
+        return cube
+
+    def mnest_loglike(self, cube, ndim=None, nparams=None):
+        return self.lnpost(cube)
+
+    # -- start points -----------------------------------------------------------------------
+    def sample_from_prior(self, n, rng=None, require_valid=True, max_tries=50):
+        """[n, n_params] draws: non-EEP parameters from their priors, EEPs uniform in bounds;
+        rows with a non-finite lnpost are redrawn (reference: starmodel.py:1716-1748 resamples
+        EEPs with prior weights; here validity is enforced through the batched lnpost)."""
+        rng = rng or np.random.default_rng()
+        names = self.param_names
+
+        def draw(m):
+            cols = []
+            for nme in names:
+                if nme.startswith("eep"):
+                    lo, hi = self.bounds(nme)
+                    cols.append(rng.uniform(lo, hi, m))
+                else:
+                    cols.append(self._priors[nme].sample(m, rng))
+            x = np.array(cols).T
+            if self.N > 1:   # eep_0 >= eep_1 >= eep_2
+                x[:, :self.N] = -np.sort(-x[:, :self.N], axis=1)
+            return x
+
+        out = draw(n)
+        if not require_valid:
+            return out
+        for _ in range(max_tries):
+            bad = ~np.isfinite(self.lnpost(out))
+            if not bad.any():
+                break
+            out[bad] = draw(int(bad.sum()))
+        return out
+
+
+class SingleStarModel(BasicStarModel):
+    def __init__(self, *args, **kwargs):
+        kwargs["N"] = 1
+        super().__init__(*args, **kwargs)
+
+
+class BinaryStarModel(BasicStarModel):
+    def __init__(self, *args, **kwargs):
+        kwargs["N"] = 2
+        super().__init__(*args, **kwargs)
+
+
+class TripleStarModel(BasicStarModel):
+    def __init__(self, *args, **kwargs):
+        kwargs["N"] = 3
+        super().__init__(*args, **kwargs)
+
+
+StarModel = BasicStarModel
