@@ -1,0 +1,210 @@
+#!/usr/bin/env python
+"""Benchmark of the isochrones hot path on MI355X.
+
+Metric (BASELINE.json): lnpost evaluations / second on a 10^6-sample batch over the MIST-shaped
+grid.  A "step" is one pass of the fused lnpost kernel over one batch of synthetic samples that
+are already resident in HBM.  Workload = BASELINE configs[1]: one Sun-like star
+(Teff/logg/feh + V magnitude), evolution-track parametrisation (mass, eep, feh, distance, AV),
+full-size synthetic MIST track table [15,196,1710,18] + BC table [70,26,18,13,1].
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--n 1000000] [--workload prior|posterior]
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): every rank evaluates its own
+star's batch — independent posteriors, no data-path collective (weak scaling); the only
+collectives are the timing barrier and the max-over-ranks reduction.
+
+Prints ONE JSON line (rank 0) with the driver's contract keys plus `roofline` and `cpu_baseline`.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+#: algorithmic bytes per lnpost evaluation, single star / 1 band:
+#: 8 corners x (4 likelihood + 2 prior columns) x 8 B + 16 BC corners x 8 B + (5 params + 1 out) x 8 B
+BYTES_PER_EVAL_SINGLE_1BAND = 8 * 6 * 8 + 16 * 1 * 8 + 6 * 8
+
+
+def make_samples(rng, n, workload):
+    """[n, 5] float64 (mass, eep, feh, distance, AV) rows."""
+    if workload == "prior":
+        # prior-wide: uniform over the table's extent -> uncorrelated gathers over the whole table
+        lo = np.array([0.1, 1.0, -4.0, 1.0, 0.0])
+        hi = np.array([10.0, 1710.0, 0.5, 3000.0, 1.0])
+        return rng.uniform(lo, hi, size=(n, 5))
+    if workload == "posterior":
+        # MCMC-like: a Gaussian ball around a Sun-like solution -> cache-resident gathers
+        c = np.array([1.0, 355.0, 0.0, 100.0, 0.1])
+        w = np.array([0.05, 15.0, 0.1, 5.0, 0.05])
+        x = c + w * rng.standard_normal((n, 5))
+        x[:, 4] = np.abs(x[:, 4])
+        return x
+    raise ValueError(workload)
+
+
+def build_model(bands=("V",)):
+    import isochrones_amd as ia
+    ic = ia.synthetic_track(bands=bands)          # full MIST-shaped tables
+    mod = ia.SingleStarModel(ic, Teff=(5770, 100), logg=(4.5, 0.1), feh=(0.0, 0.15), V=(10.0, 0.05))
+    return ic, mod
+
+
+def cpu_baseline(ic, mod, pars_host, budget_s=12.0):
+    """Time the C oracle (the reference's algorithm restated, oracle/iso_oracle.c) on this host."""
+    from oracle import oracle as orc
+    m, b = ic.model_grid.interp, ic.bc_grid.interp
+    oic = orc.OracleIC(ic.kind, orc.OracleTable(m.grid, m.index_columns), orc.OracleTable(b.grid, b.index_columns),
+                       ic._cols, ic._prior_cols, ic._astero_cols)
+    desc = mod.model_desc()
+    cores = max(1, min(orc.max_threads(), os.cpu_count() or 1))
+    probe = np.ascontiguousarray(pars_host[:20000].T)
+    oic.lnpost(desc, probe, nthreads=cores, parts=False)
+    t = time.perf_counter()
+    oic.lnpost(desc, probe, nthreads=cores, parts=False)
+    rate = probe.shape[1] / (time.perf_counter() - t)
+    n = int(min(pars_host.shape[0], max(20000, rate * budget_s)))
+    sample = np.ascontiguousarray(pars_host[:n].T)
+    t = time.perf_counter()
+    out = oic.lnpost(desc, sample, nthreads=cores, parts=False)
+    dt = time.perf_counter() - t
+    n1 = int(min(n, max(20000, rate / cores * 4.0)))
+    s1 = np.ascontiguousarray(pars_host[:n1].T)
+    t = time.perf_counter()
+    oic.lnpost(desc, s1, nthreads=1, parts=False)
+    dt1 = time.perf_counter() - t
+    return dict(value=n / dt, unit="evals/s", cores=cores, kind="port",
+                sample="first %d samples of the same batch, C restatement of the reference "
+                       "(oracle/iso_oracle.c), OpenMP static over %d threads" % (n, cores),
+                value_1thread=n1 / dt1), out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--n", type=int, default=1_000_000)
+    ap.add_argument("--workload", default="prior", choices=["prior", "posterior"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import ctypes as C
+    from isochrones_amd import _cabi, device as dev
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    torch.cuda.set_device(local_rank)
+    distributed = world > 1
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    ic, mod = build_model()
+    # rank r evaluates star r of the catalog: same observables, its own seeded sample batch
+    rng = np.random.default_rng(12345 + rank)
+    pars_host = make_samples(rng, args.n, args.workload)
+    pars = torch.as_tensor(np.ascontiguousarray(pars_host.T), device="cuda")     # SoA [5, n], HBM resident
+    out = torch.empty(args.n, dtype=torch.float64, device="cuda")
+    handle = mod.handle(local_rank)
+    lib = _cabi.lib()
+    stream = dev.stream_ptr(local_rank)
+    ms = C.c_double()
+
+    def run(reps):
+        _cabi.check(lib.iso_time_lnpost(handle, dev.ptr(pars), 1, args.n, args.n, dev.ptr(out), reps, stream,
+                                        C.byref(ms)))
+        return ms.value
+
+    if args.warmup > 0:
+        run(args.warmup)
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    kernel_ms = run(args.steps)            # K launches bracketed by HIP events on this stream
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        tmax = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed, kernel_ms = float(tmax[0]), float(tmax[1])
+
+    total_evals = float(args.n) * args.steps * world
+    value = total_evals / elapsed
+    bytes_per_launch = BYTES_PER_EVAL_SINGLE_1BAND * args.n
+    achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+    traffic = None
+    pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc_file):
+        try:
+            rec = json.load(open(pmc_file))
+            key = "%s_n%d" % (args.workload, args.n)
+            traffic = rec.get(key, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    result = {
+        "metric": "lnpost evals/sec over MIST grid (10^6-sample batch)",
+        "value": value,
+        "unit": "evals/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": "cfg2: single Sun-like star (Teff/logg/feh + V), track parametrisation, "
+                               "synthetic MIST-shaped tables [15,196,1710,18]+[70,26,18,13,1], %d-sample "
+                               "lnpost batch per GPU, samples '%s', fused interp+prior+likelihood kernel"
+                               % (args.n, args.workload),
+                   "samples": args.workload, "batch": args.n, "parallelism": "independent stars per GPU"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "kernel_ms": kernel_ms, "bytes_per_eval": BYTES_PER_EVAL_SINGLE_1BAND},
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            base, ref = cpu_baseline(ic, mod, pars_host)
+            got = out[: ref.size].cpu().numpy()
+            fin = np.isfinite(ref)
+            ok = (np.array_equal(np.isnan(got), np.isnan(ref)) and np.array_equal(np.isneginf(got), np.isneginf(ref)))
+            rel = float(np.max(np.abs(got[fin] - ref[fin]) / np.maximum(1.0, np.abs(ref[fin])))) if fin.any() else 0.0
+            base["parity_max_rel_err"] = rel
+            base["parity_pattern_ok"] = bool(ok)
+            base["finite_fraction"] = float(fin.mean())
+            result["cpu_baseline"] = base
+            result["speedup_vs_cpu_all_cores"] = value / base["value"]
+        else:
+            result["cpu_baseline"] = None
+        print(json.dumps(result))
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -92,6 +92,12 @@ def lib():
         raise IsoError(
             "isochrones_amd: HIP library not found at %s — build it with "
             "`python -c 'import __graft_entry__ as g; g.build()'` (there is no CPU fallback)" % path)
+    try:
+        # torch bundles its own libamdhip64 (same SONAME); importing it first makes this library
+        # bind to that runtime, so torch's streams / allocations and ours are one HIP context.
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover
+        pass
     L = C.CDLL(path)
     vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
     pd = C.c_void_p  # device pointers travel as integers

@@ -1,0 +1,1353 @@
+// isochrones_amd — hand-written HIP (gfx950 / CDNA4) implementation of the isochrones hot path
+// behind the C ABI of include/isochrones_amd.h.
+//
+// Kernels (all float64, gather/latency bound — no MFMA on purpose, this is interpolation):
+//   k_interp<ND>        K3  N-D bracket search + multilinear gather of an arbitrary column subset
+//                           (reference semantics: isochrones/interp.py:10-35, 63-338)
+//   k_interp_mag        K4  3-D model gather -> 4-D BC gather -> magnitudes
+//                           (reference semantics: isochrones/mags.py:8-124)
+//   k_lnpost<...>       K1+K2 fused: priors + 1-3 component stars + likelihood reduce
+//                           (isochrones/likelihood.py:16-147, starmodel.py:538-542,1563-1635,
+//                            priors.py lnpdf's)
+//   k_unit_cube             mnest_prior (starmodel.py:1637-1640)
+//   k_pack_hot / k_pack_bc  one-off table repacks (hot columns AoS; model's bands only)
+//
+// Mapping: one lane = one sample, 256-thread workgroups (4 wave64), grid-stride over samples.
+// Short irregular axes are staged in LDS once per workgroup and searched with a branch-free
+// bisection; exactly-uniform axes (the integer EEP axis) are indexed in O(1).  The bracket rule
+//   i = clamp(#{a_j <= x} - 1, 0, n-2),  t = (x - a_i) / (a_{i+1} - a_i)
+// reproduces the reference's searchsorted/find_indices results bit-for-bit (an exact node hit
+// gives t = 0 either way) and defines the reference's undefined exact-upper-edge query as
+// (n-2, t=1).  Zero-weight corners are still accumulated so NaN padding propagates exactly
+// like the reference (docs/interpolate.ipynb cell 14).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/isochrones_amd.h"
+
+// ======================================================================================
+// host-side bookkeeping
+// ======================================================================================
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg)
+{
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(ISO_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));      \
+    } while (0)
+
+constexpr int BLOCK = 256;
+constexpr int MAX_LDS_AXIS_DOUBLES = 6144;   // 48 KiB of staged axes at most
+constexpr int HOT_COLS = 8;                  // Teff logg feh Mbol prior_val prior_deriv nu_max delta_nu
+
+struct AxisD {
+    const double* g;   // device copy
+    int n;
+    int lds_off;       // offset (doubles) into the workgroup's LDS staging area, -1 = not staged
+    int uniform;       // 1: a_i == a0 + i*step exactly (with and without FMA)
+    double a0, step;
+};
+
+}  // namespace
+
+struct iso_ctx {
+    int device;
+};
+
+struct iso_table {
+    iso_ctx* ctx;
+    int ndim;
+    int64_t shape[ISO_MAX_DIM + 1];
+    int64_t ncells;
+    double* d_grid;
+    double* d_axes[ISO_MAX_DIM];
+    std::vector<double> h_axes[ISO_MAX_DIM];
+    AxisD ax[ISO_MAX_DIM];
+};
+
+namespace {
+
+struct Grid3V {           // packed hot-column model table
+    AxisD ax[3];
+    const double* hot;    // [n0][n1][n2][HOT_COLS]
+    int64_t s0, s1;       // cell strides of axes 0, 1 (axis 2 stride = 1)
+};
+
+struct Grid4V {           // BC table (all columns, or packed to the model's bands)
+    AxisD ax[4];
+    const double* tab;    // [nT][ng][nf][nA][ncol]
+    int ncol;
+    int64_t s0, s1, s2;   // cell strides of axes 0..2 (axis 3 stride = 1)
+};
+
+// ---- device-side prior record with everything constant pre-evaluated on the host ----------
+struct DevPrior {
+    int kind, bounded;
+    double lo, hi;
+    double a, b, c, d, e, f, g, h;
+    double k0, k1, k2, k3, k4, k5;
+};
+
+struct DevModel {
+    int n_stars, n_bands, kind;
+    int has_parallax, has_numax, has_dnu;
+    double mag_val[ISO_MAX_BANDS];
+    double mag_g0[ISO_MAX_BANDS];    // log(1/sqrt(2 pi)) + log(unc)
+    double mag_unc2[ISO_MAX_BANDS];  // unc*unc
+    double spec_val[3], spec_g0[3], spec_unc2[3];
+    double plx_val, plx_g0, plx_unc2;
+    double numax_val, numax_g0, numax_unc2;
+    double dnu_val, dnu_g0, dnu_unc2;
+    DevPrior prior_mass, prior_age, prior_feh, prior_distance, prior_AV;
+    double eep_lo, eep_hi;
+    double bound_lo[ISO_MAX_PARAMS], bound_hi[ISO_MAX_PARAMS];
+};
+
+}  // namespace
+
+struct iso_ic {
+    iso_ctx* ctx;
+    iso_table* model;
+    iso_table* bc;
+    int kind;
+    int32_t cols[4], prior_cols[2], astero_cols[2];
+    double* d_hot;
+    Grid3V g3;
+    Grid4V g4;           // full BC table view
+    int lds_doubles;     // LDS staging size for model + BC axes
+};
+
+struct iso_model {
+    iso_ic* ic;
+    iso_model_desc desc;
+    DevModel* d_model;
+    double* d_bc_hot;    // BC table restricted to the model's bands, [..][nb]
+    Grid4V g4;           // view of d_bc_hot
+};
+
+// ======================================================================================
+// device code
+// ======================================================================================
+namespace {
+
+__device__ __forceinline__ double d_nan() { return __longlong_as_double(0x7ff8000000000000LL); }
+__device__ __forceinline__ double d_inf() { return __longlong_as_double(0x7ff0000000000000LL); }
+
+// Cooperative copy of the non-uniform axes into LDS.  Must be followed by __syncthreads().
+template <int NAX>
+__device__ __forceinline__ void stage_axes(const AxisD* ax, double* lds)
+{
+#pragma unroll
+    for (int d = 0; d < NAX; ++d) {
+        if (ax[d].lds_off >= 0) {
+            const double* __restrict__ src = ax[d].g;
+            double* dst = lds + ax[d].lds_off;
+            for (int j = threadIdx.x; j < ax[d].n; j += blockDim.x) dst[j] = src[j];
+        }
+    }
+}
+
+// Branch-free bisection on a sorted axis: base = largest index with a[base] <= x, clamped to n-2.
+template <typename PTR>
+__device__ __forceinline__ void bisect(PTR ax, int n, double x, int& i, double& t)
+{
+    int base = 0, len = n;
+    while (len > 1) {
+        const int half = len >> 1;
+        base = (ax[base + half] <= x) ? base + half : base;
+        len -= half;
+    }
+    base = min(base, n - 2);
+    const double lo = ax[base], hi = ax[base + 1];
+    i = base;
+    t = (x - lo) / (hi - lo);
+}
+
+// Bracket of x on one axis.  Precondition: a_0 <= x <= a_{n-1} (caller has done the bounds
+// test, reference isochrones/interp.py:106-114).
+__device__ __forceinline__ void bracket(const AxisD& A, const double* lds, double x, int& i, double& t)
+{
+    const int n = A.n;
+    if (A.uniform) {
+        // O(1) index with an exact fix-up against the node values (node(i) reproduces the stored
+        // axis value bit-for-bit, verified on the host at table creation).
+        const double a0 = A.a0, st = A.step;
+        int k = (int)((x - a0) / st);
+        k = max(0, min(k, n - 2));
+        double lo = fma((double)k, st, a0);
+        if (lo > x) {
+            --k;
+        } else if (k < n - 2 && fma((double)(k + 1), st, a0) <= x) {
+            ++k;
+        }
+        k = max(0, min(k, n - 2));
+        lo = fma((double)k, st, a0);
+        const double hi = fma((double)(k + 1), st, a0);
+        i = k;
+        t = (x - lo) / (hi - lo);
+        return;
+    }
+    if (A.lds_off >= 0) bisect(lds + A.lds_off, n, x, i, t);   // LDS address space (ds_read)
+    else bisect(A.g, n, x, i, t);                              // global
+}
+
+__device__ __forceinline__ bool out_of_axis(const AxisD& A, const double* lds, double x)
+{
+    double first, last;
+    if (A.uniform) {
+        first = A.a0;
+        last = fma((double)(A.n - 1), A.step, A.a0);
+    } else {
+        if (A.lds_off >= 0) {
+            first = lds[A.lds_off];
+            last = lds[A.lds_off + A.n - 1];
+        } else {
+            first = A.g[0];
+            last = A.g[A.n - 1];
+        }
+    }
+    // written so that NaN is *not* out of bounds here (the NaN test comes first in the reference)
+    return (x < first) || (x > last);
+}
+
+// -------------------------------------------------------------------------------------------
+// K3: generic N-D interpolation of k selected columns
+// -------------------------------------------------------------------------------------------
+struct InterpArgs {
+    AxisD ax[ISO_MAX_DIM];
+    int64_t stride[ISO_MAX_DIM];   // cell strides
+    const double* grid;
+    int ncol;
+    const double* x[ISO_MAX_DIM];
+    int64_t n;
+    int k;
+    int32_t icols[ISO_MAX_COLS];
+    double* out;
+};
+
+template <int ND>
+__global__ __launch_bounds__(BLOCK) void k_interp(const InterpArgs A)
+{
+    extern __shared__ double lds[];
+    stage_axes<ND>(A.ax, lds);
+    __syncthreads();
+    const int64_t stride_grid = (int64_t)gridDim.x * BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < A.n; i += stride_grid) {
+        double x[ND];
+        bool bad = false;
+#pragma unroll
+        for (int d = 0; d < ND; ++d) {
+            x[d] = A.x[d][i];
+            bad |= (x[d] != x[d]);
+        }
+        if (!bad) {
+#pragma unroll
+            for (int d = 0; d < ND; ++d) bad |= out_of_axis(A.ax[d], lds, x[d]);
+        }
+        double* o = A.out + i * A.k;
+        if (bad) {
+            for (int c = 0; c < A.k; ++c) o[c] = d_nan();
+            continue;
+        }
+        int idx[ND];
+        double t[ND];
+        int64_t base = 0;
+#pragma unroll
+        for (int d = 0; d < ND; ++d) {
+            bracket(A.ax[d], lds, x[d], idx[d], t[d]);
+            base += (int64_t)idx[d] * A.stride[d];
+        }
+        double w[1 << ND];
+        int64_t off[1 << ND];
+#pragma unroll
+        for (int j = 0; j < (1 << ND); ++j) {
+            double ww = 1.0;
+            int64_t oo = base;
+#pragma unroll
+            for (int d = 0; d < ND; ++d) {
+                const int bit = (j >> (ND - 1 - d)) & 1;
+                ww *= bit ? t[d] : (1 - t[d]);
+                oo += bit ? A.stride[d] : 0;
+            }
+            w[j] = ww;
+            off[j] = oo * A.ncol;
+        }
+        for (int c = 0; c < A.k; ++c) {
+            const double* __restrict__ col = A.grid + A.icols[c];
+            double v = 0.0;
+#pragma unroll
+            for (int j = 0; j < (1 << ND); ++j) v += col[off[j]] * w[j];
+            o[c] = v;
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------
+// shared device pieces of K4 / K1+K2
+// -------------------------------------------------------------------------------------------
+
+// 3-D bracket of one star on the hot table.  Returns false (values undefined) if NaN / oob.
+struct Cell3 {
+    int64_t base;     // cell index of the (i0,i1,i2) corner
+    double t0, t1, t2;
+};
+
+__device__ __forceinline__ bool locate3(const Grid3V& G, const double* lds, double x0, double x1, double x2,
+                                        Cell3& c)
+{
+    if (x0 != x0 || x1 != x1 || x2 != x2) return false;
+    if (out_of_axis(G.ax[0], lds, x0) || out_of_axis(G.ax[1], lds, x1) || out_of_axis(G.ax[2], lds, x2))
+        return false;
+    int i0, i1, i2;
+    bracket(G.ax[0], lds, x0, i0, c.t0);
+    bracket(G.ax[1], lds, x1, i1, c.t1);
+    bracket(G.ax[2], lds, x2, i2, c.t2);
+    c.base = (int64_t)i0 * G.s0 + (int64_t)i1 * G.s1 + i2;
+    return true;
+}
+
+// Gather the first NC hot columns of the 8 corners (corner order and weight products as the
+// reference: bit (2-k) of j offsets axis k; weight = ((1 * w0) * w1) * w2).
+template <int NC>
+__device__ __forceinline__ void gather3(const Grid3V& G, const Cell3& c, double* __restrict__ v)
+{
+#pragma unroll
+    for (int q = 0; q < NC; ++q) v[q] = 0.0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int b0 = (j >> 2) & 1, b1 = (j >> 1) & 1, b2 = j & 1;
+        double w = 1.0;
+        w *= b0 ? c.t0 : (1 - c.t0);
+        w *= b1 ? c.t1 : (1 - c.t1);
+        w *= b2 ? c.t2 : (1 - c.t2);
+        const int64_t cell = c.base + (b0 ? G.s0 : 0) + (b1 ? G.s1 : 0) + b2;
+        const double2* __restrict__ p = reinterpret_cast<const double2*>(G.hot + cell * HOT_COLS);
+#pragma unroll
+        for (int q = 0; q < NC; q += 2) {
+            const double2 u = p[q >> 1];
+            v[q] += u.x * w;
+            if (q + 1 < NC) v[q + 1] += u.y * w;
+        }
+    }
+}
+
+struct Cell4 {
+    int64_t base;
+    double t0, t1, t2, t3;
+};
+
+__device__ __forceinline__ bool locate4(const Grid4V& G, const double* lds, double x0, double x1, double x2,
+                                        double x3, Cell4& c)
+{
+    if (x0 != x0 || x1 != x1 || x2 != x2 || x3 != x3) return false;
+    if (out_of_axis(G.ax[0], lds, x0) || out_of_axis(G.ax[1], lds, x1) || out_of_axis(G.ax[2], lds, x2) ||
+        out_of_axis(G.ax[3], lds, x3))
+        return false;
+    int i0, i1, i2, i3;
+    bracket(G.ax[0], lds, x0, i0, c.t0);
+    bracket(G.ax[1], lds, x1, i1, c.t1);
+    bracket(G.ax[2], lds, x2, i2, c.t2);
+    bracket(G.ax[3], lds, x3, i3, c.t3);
+    c.base = (int64_t)i0 * G.s0 + (int64_t)i1 * G.s1 + (int64_t)i2 * G.s2 + i3;
+    return true;
+}
+
+__device__ __forceinline__ double weight4(const Cell4& c, int j)
+{
+    double w = 1.0;
+    w *= ((j >> 3) & 1) ? c.t0 : (1 - c.t0);
+    w *= ((j >> 2) & 1) ? c.t1 : (1 - c.t1);
+    w *= ((j >> 1) & 1) ? c.t2 : (1 - c.t2);
+    w *= (j & 1) ? c.t3 : (1 - c.t3);
+    return w;
+}
+
+__device__ __forceinline__ int64_t corner4(const Grid4V& G, const Cell4& c, int j)
+{
+    return c.base + (((j >> 3) & 1) ? G.s0 : 0) + (((j >> 2) & 1) ? G.s1 : 0) + (((j >> 1) & 1) ? G.s2 : 0) +
+           (j & 1);
+}
+
+// one column of the BC table at a located cell
+__device__ __forceinline__ double gather4_col(const Grid4V& G, const Cell4& c, int col)
+{
+    double v = 0.0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v += G.tab[corner4(G, c, j) * G.ncol + col] * weight4(c, j);
+    return v;
+}
+
+// NB contiguous columns (packed BC table, ncol == NB) at a located cell
+template <int NB>
+__device__ __forceinline__ void gather4_packed(const Grid4V& G, const Cell4& c, double* __restrict__ v)
+{
+#pragma unroll
+    for (int b = 0; b < NB; ++b) v[b] = 0.0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const double w = weight4(c, j);
+        const double* __restrict__ p = G.tab + corner4(G, c, j) * NB;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) v[b] += p[b] * w;
+    }
+}
+
+// parameter permutation: (mass, eep, feh) -> table axes (feh, mass, eep);  (eep, age, feh) -> (age, feh, eep)
+template <int KIND>
+__device__ __forceinline__ void to_axes(double p0, double p1, double p2, double& x0, double& x1, double& x2)
+{
+    if (KIND == ISO_KIND_TRACK) {
+        x0 = p2; x1 = p0; x2 = p1;
+    } else {
+        x0 = p1; x1 = p2; x2 = p0;
+    }
+}
+
+// -------------------------------------------------------------------------------------------
+// K4: interp_mag
+// -------------------------------------------------------------------------------------------
+struct MagArgs {
+    Grid3V g3;
+    Grid4V g4;
+    int kind;
+    const double* pars;
+    int64_t stride_n, stride_p, n;
+    int nb;
+    int32_t bc_cols[ISO_MAX_BANDS];
+    double *Teff, *logg, *feh, *mags;
+};
+
+template <int KIND>
+__global__ __launch_bounds__(BLOCK) void k_interp_mag(const MagArgs A)
+{
+    extern __shared__ double lds[];
+    stage_axes<3>(A.g3.ax, lds);
+    stage_axes<4>(A.g4.ax, lds);
+    __syncthreads();
+    const int64_t stride_grid = (int64_t)gridDim.x * BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < A.n; i += stride_grid) {
+        const double* __restrict__ p = A.pars + i * A.stride_n;
+        const double p0 = p[0], p1 = p[A.stride_p], p2 = p[2 * A.stride_p];
+        const double dist = p[3 * A.stride_p], AV = p[4 * A.stride_p];
+        double x0, x1, x2;
+        to_axes<KIND>(p0, p1, p2, x0, x1, x2);
+        double star[4] = {d_nan(), d_nan(), d_nan(), d_nan()};
+        Cell3 c3;
+        if (locate3(A.g3, lds, x0, x1, x2, c3)) gather3<4>(A.g3, c3, star);
+        if (A.Teff) A.Teff[i] = star[0];
+        if (A.logg) A.logg[i] = star[1];
+        if (A.feh) A.feh[i] = star[2];
+        if (A.mags) {
+            Cell4 c4;
+            const bool ok = locate4(A.g4, lds, star[0], star[1], star[2], AV, c4);
+            const double dm = 5 * log10(dist / 10.0);
+            for (int b = 0; b < A.nb; ++b) {
+                const double bc = ok ? gather4_col(A.g4, c4, A.bc_cols[b]) : d_nan();
+                A.mags[i * A.nb + b] = star[3] + dm - bc;
+            }
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------
+// priors
+// -------------------------------------------------------------------------------------------
+#define LOG_INV_ROOT_2PI (-0.91893853320467267)   // log(1/sqrt(2 pi))
+#define INV_ROOT_2PI 0.3989422804014327
+#define LN10 2.302585092994046
+
+__device__ __forceinline__ double lognormal_pdf(const DevPrior& P, double x, double mu, double sigma,
+                                                double scale)
+{
+    const double y = x / scale;
+    const double ly = log(y) / sigma;
+    return INV_ROOT_2PI / (sigma * y) * exp(-0.5 * (ly * ly)) / scale;
+}
+
+__device__ __forceinline__ double lognormal_lnpdf(double x, double mu, double sigma, double scale,
+                                                  double log_sigma)
+{
+    const double y = x / scale;
+    const double l = log(y);
+    const double ly = l / sigma;
+    return LOG_INV_ROOT_2PI - (log_sigma + l) - 0.5 * (ly * ly) - mu;
+}
+
+__device__ __forceinline__ double feh_shape(const DevPrior& P, double feh)
+{
+    double disk;
+    if (P.c != 0.0) {
+        const double u = feh - 0.016, v = feh + 0.15;
+        disk = 1.0 / 2.5066282746310007 *
+               (0.8 / 0.15 * exp(-0.5 * (u * u) / (0.15 * 0.15)) + 0.2 / 0.22 * exp(-0.5 * (v * v) / (0.22 * 0.22)));
+    } else {
+        const double u = feh + 0.3;
+        disk = INV_ROOT_2PI / 0.3 * exp(-0.5 * (u * u) / (0.3 * 0.3));
+    }
+    const double h = feh + 1.5;
+    const double halo = P.k0 * exp(-0.5 * (h * h) / (0.4 * 0.4));   // k0 = 1/sqrt(2 pi 0.4^2)
+    return P.a * halo + (1 - P.a) * disk;
+}
+
+// _pdf(x) of a family (no bounds handling)
+__device__ double prior_raw(const DevPrior& P, double x)
+{
+    switch (P.kind) {
+    case ISO_PRIOR_FLAT: return P.k0;                                  // 1/(hi-lo)
+    case ISO_PRIOR_FLATLOG: return LN10 * exp10(x) / P.k0;             // k0 = 10^hi - 10^lo
+    case ISO_PRIOR_POWERLAW: return P.k0 * pow(x, P.a);                // k0 = C
+    case ISO_PRIOR_GAUSS: {
+        const double z = (x - P.a) / P.b;
+        return exp(-(z * z) / 2.0) * INV_ROOT_2PI / P.b / P.k0;        // k0 = exp(lognorm)
+    }
+    case ISO_PRIOR_LOGNORMAL: return lognormal_pdf(P, x, P.a, P.b, P.k0);   // k0 = exp(mu)
+    case ISO_PRIOR_CHABRIER:
+        if (x < P.d) {
+            const double c = (x < 0) ? 0.0 : lognormal_pdf(P, x, P.a, P.b, P.k0);
+            return c / P.e;
+        } else {
+            const double c = (x < P.g || x > P.h) ? 0.0 : P.k2 * pow(x, P.c);   // k2 = C of the power law
+            return c / P.f;
+        }
+    case ISO_PRIOR_FEH: return feh_shape(P, x);
+    }
+    return d_nan();
+}
+
+// prior(x): the reference's __call__ form (pdf with its bounds tests)
+__device__ double prior_call(const DevPrior& P, double x)
+{
+    if (P.kind == ISO_PRIOR_LOGNORMAL) {
+        if (x < 0) return 0.0;
+        return lognormal_pdf(P, x, P.a, P.b, P.k0);
+    }
+    if (x < P.lo || x > P.hi) return 0.0;
+    const double r = prior_raw(P, x);
+    return (P.kind == ISO_PRIOR_FEH) ? r / P.b : r;
+}
+
+__device__ double prior_lnpdf(const DevPrior& P, double x)
+{
+    switch (P.kind) {
+    case ISO_PRIOR_FLAT:
+    case ISO_PRIOR_FLATLOG: {
+        if (x < P.lo || x > P.hi) return -d_inf();
+        const double pdf = prior_raw(P, x);
+        return pdf != 0 ? log(pdf) : -d_inf();
+    }
+    case ISO_PRIOR_POWERLAW:
+        if (P.bounded && (x < P.lo || x > P.hi)) return -d_inf();
+        return P.k1 + P.a * log(x);                                    // k1 = log(C)
+    case ISO_PRIOR_GAUSS: {
+        if (P.bounded && (x < P.lo || x > P.hi)) return -d_inf();
+        const double z = (x - P.a) / P.b;
+        return (-(z * z) / 2.0 + LOG_INV_ROOT_2PI) - P.k1 - P.c;       // k1 = log(sigma)
+    }
+    case ISO_PRIOR_LOGNORMAL: return lognormal_lnpdf(x, P.a, P.b, P.k0, P.k1);   // k1 = log(sigma)
+    case ISO_PRIOR_CHABRIER:
+        if (x < P.d) return lognormal_lnpdf(x, P.a, P.b, P.k0, P.k1) - P.k3;     // k3 = log(e)
+        if (x < P.g || x > P.h) return -d_inf();
+        return (P.k5 + P.c * log(x)) - P.k4;                     // k5 = log(C), k4 = log(f)
+    case ISO_PRIOR_FEH: {
+        const double pdf = prior_call(P, x);
+        return pdf != 0 ? log(pdf) : -d_inf();
+    }
+    }
+    return d_nan();
+}
+
+__device__ __forceinline__ double gauss_term(double val, double g0, double unc2, double model)
+{
+    const double r = val - model;
+    return g0 - 0.5 * r * r / unc2;
+}
+
+// -------------------------------------------------------------------------------------------
+// K1+K2 fused: lnpost
+// -------------------------------------------------------------------------------------------
+struct PostArgs {
+    Grid3V g3;
+    Grid4V g4;           // packed to the model's bands (ncol == n_bands)
+    const DevModel* m;
+    const double* pars;
+    int64_t stride_n, stride_p, n;
+    double *lnpost, *lnprior, *lnlike;
+};
+
+// NB > 0: compile-time band count (register-resident accumulators); NB == 0: runtime loop.
+template <int KIND, int NS, int NB, bool PARTS>
+__global__ __launch_bounds__(BLOCK) void k_lnpost(const PostArgs A)
+{
+    extern __shared__ double lds[];
+    stage_axes<3>(A.g3.ax, lds);
+    stage_axes<4>(A.g4.ax, lds);
+    __syncthreads();
+    const DevModel& M = *A.m;
+    constexpr int NP = NS + 4;
+    const int64_t stride_grid = (int64_t)gridDim.x * BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < A.n; i += stride_grid) {
+        double p[NP];
+        {
+            const double* __restrict__ src = A.pars + i * A.stride_n;
+#pragma unroll
+            for (int j = 0; j < NP; ++j) p[j] = src[j * A.stride_p];
+        }
+        const double q1 = p[NS], feh_par = p[NS + 1], dist = p[NS + 2], AV = p[NS + 3];
+        // q1: track -> eep (p[1]); iso -> age.   For the track case NS == 1: p = (mass, eep, feh, d, AV)
+
+        // ---- locate + gather every component on the hot model table ----
+        Cell3 c3[NS];
+        bool ok3[NS];
+        double star[NS][6];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            double x0, x1, x2;
+            if (KIND == ISO_KIND_TRACK) to_axes<KIND>(p[0], p[1], p[2], x0, x1, x2);
+            else to_axes<KIND>(p[s], q1, feh_par, x0, x1, x2);
+            ok3[s] = locate3(A.g3, lds, x0, x1, x2, c3[s]);
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            if (ok3[s]) {
+                gather3<6>(A.g3, c3[s], star[s]);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 6; ++q) star[s][q] = d_nan();
+            }
+        }
+
+        // ---- lnprior (reference: starmodel.py:1616-1635) ----
+        double lnp = 0.0;
+        bool rejected = false;
+        if (NS == 2) rejected = p[1] > p[0];
+        if (NS == 3) rejected = !(p[0] > p[1]) && (p[1] > p[2]);
+        if (KIND == ISO_KIND_TRACK) lnp += prior_lnpdf(M.prior_mass, p[0]);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const double eep = (KIND == ISO_KIND_TRACK) ? p[1] : p[s];
+            double term;
+            if (eep < M.eep_lo || eep > M.eep_hi) {
+                term = -d_inf();
+            } else {
+                const DevPrior& orig = (KIND == ISO_KIND_TRACK) ? M.prior_age : M.prior_mass;
+                const double pdf = prior_call(orig, star[s][4]) * star[s][5];
+                term = (pdf != 0) ? log(pdf) : -d_inf();
+            }
+            lnp += term;
+        }
+        if (KIND == ISO_KIND_ISO) lnp += prior_lnpdf(M.prior_age, q1);
+        lnp += prior_lnpdf(M.prior_feh, feh_par);
+        lnp += prior_lnpdf(M.prior_distance, dist);
+        lnp += prior_lnpdf(M.prior_AV, AV);
+        if (rejected) lnp = -d_inf();
+        const bool prior_ok = isfinite(lnp);
+
+        // ---- lnlike (reference: likelihood.py:16-147, starmodel.py:1599-1612) ----
+        double lnl = d_nan();
+        if (PARTS || prior_ok) {
+            lnl = 0.0;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const double val = M.spec_val[q];
+                if (val == val) lnl += gauss_term(val, M.spec_g0[q], M.spec_unc2[q], star[0][q]);
+            }
+            const double dm = 5 * log10(dist / 10.0);
+            Cell4 c4[NS];
+            bool ok4[NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) ok4[s] = locate4(A.g4, lds, star[s][0], star[s][1], star[s][2], AV, c4[s]);
+            if (NB > 0) {
+                double tot[NB > 0 ? NB : 1];
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    double bc[NB > 0 ? NB : 1];
+                    if (ok4[s]) {
+                        gather4_packed<(NB > 0 ? NB : 1)>(A.g4, c4[s], bc);
+                    } else {
+#pragma unroll
+                        for (int b = 0; b < NB; ++b) bc[b] = d_nan();
+                    }
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) {
+                        const double mag = star[s][3] + dm - bc[b];
+                        if (NS == 1) tot[b] = mag;
+                        else tot[b] = (s == 0 ? 0.0 : tot[b]) + exp10(-0.4 * mag);
+                    }
+                }
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    const double mag = (NS == 1) ? tot[b] : -2.5 * log10(tot[b]);
+                    lnl += gauss_term(M.mag_val[b], M.mag_g0[b], M.mag_unc2[b], mag);
+                }
+            } else {
+                for (int b = 0; b < M.n_bands; ++b) {
+                    double tot = 0.0;
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) {
+                        const double bc = ok4[s] ? gather4_col(A.g4, c4[s], b) : d_nan();
+                        const double mag = star[s][3] + dm - bc;
+                        if (NS == 1) tot = mag;
+                        else tot += exp10(-0.4 * mag);
+                    }
+                    const double mag = (NS == 1) ? tot : -2.5 * log10(tot);
+                    lnl += gauss_term(M.mag_val[b], M.mag_g0[b], M.mag_unc2[b], mag);
+                }
+            }
+            if (M.has_parallax) lnl += gauss_term(M.plx_val, M.plx_g0, M.plx_unc2, 1000.0 / dist);
+            if (M.has_numax) {
+                double a2[8];
+                if (ok3[0]) {
+                    gather3<8>(A.g3, c3[0], a2);
+                } else {
+                    a2[6] = a2[7] = d_nan();
+                }
+                lnl += gauss_term(M.numax_val, M.numax_g0, M.numax_unc2, a2[6]);
+                if (M.has_dnu) lnl += gauss_term(M.dnu_val, M.dnu_g0, M.dnu_unc2, a2[7]);
+            }
+        }
+        if (A.lnpost) A.lnpost[i] = prior_ok ? lnp + lnl : -d_inf();
+        if (PARTS) {
+            if (A.lnprior) A.lnprior[i] = lnp;
+            if (A.lnlike) A.lnlike[i] = lnl;
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------
+// small kernels
+// -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_unit_cube(const DevModel* m, double* cube, int64_t stride_n,
+                                                    int64_t stride_p, int64_t n)
+{
+    const int np = m->n_stars + 4;
+    const int64_t total = n * np;
+    for (int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x; e < total; e += (int64_t)gridDim.x * BLOCK) {
+        const int64_t i = e / np;
+        const int p = (int)(e - i * np);
+        double* c = cube + i * stride_n + p * stride_p;
+        const double lo = m->bound_lo[p], hi = m->bound_hi[p];
+        *c = (hi - lo) * *c + lo;
+    }
+}
+
+struct PackHotArgs {
+    const double* grid;
+    int ncol;
+    int64_t ncells;
+    int32_t src[HOT_COLS];   // -1 -> NaN fill
+    double* hot;
+};
+
+__global__ __launch_bounds__(BLOCK) void k_pack_hot(const PackHotArgs A)
+{
+    const int64_t total = A.ncells * HOT_COLS;
+    for (int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x; e < total; e += (int64_t)gridDim.x * BLOCK) {
+        const int64_t cell = e / HOT_COLS;
+        const int q = (int)(e - cell * HOT_COLS);
+        const int s = A.src[q];
+        A.hot[e] = (s >= 0) ? A.grid[cell * A.ncol + s] : d_nan();
+    }
+}
+
+struct PackBcArgs {
+    const double* grid;
+    int ncol, nb;
+    int64_t ncells;
+    int32_t src[ISO_MAX_BANDS];
+    double* out;
+};
+
+__global__ __launch_bounds__(BLOCK) void k_pack_bc(const PackBcArgs A)
+{
+    const int64_t total = A.ncells * A.nb;
+    for (int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x; e < total; e += (int64_t)gridDim.x * BLOCK) {
+        const int64_t cell = e / A.nb;
+        const int b = (int)(e - cell * A.nb);
+        A.out[e] = A.grid[cell * A.ncol + A.src[b]];
+    }
+}
+
+// ======================================================================================
+// host helpers
+// ======================================================================================
+int grid_blocks(int64_t n)
+{
+    int64_t b = (n + BLOCK - 1) / BLOCK;
+    const int64_t cap = 256 * 8;   // 256 CUs x 8 workgroups, grid-stride beyond that
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+bool axis_uniform(const std::vector<double>& a, double& a0, double& step)
+{
+    if (a.size() < 2) return false;
+    a0 = a[0];
+    step = a[1] - a[0];
+    if (!(step > 0)) return false;
+    for (size_t i = 0; i < a.size(); ++i) {
+        const double plain = (double)i * step + a0;
+        const double fused = std::fma((double)i, step, a0);
+        if (plain != a[i] || fused != a[i]) return false;
+    }
+    // the O(1) index also needs (x - a0)/step to be within one cell of the truth: guaranteed for
+    // exact arithmetic nodes; keep the fast path to modest sizes
+    return a.size() < (1u << 24);
+}
+
+// assign LDS offsets to the non-uniform axes of up to two tables; returns doubles used
+int assign_lds(AxisD* a, int na, AxisD* b, int nb)
+{
+    int used = 0;
+    AxisD* sets[2] = {a, b};
+    int counts[2] = {na, nb};
+    for (int s = 0; s < 2; ++s)
+        for (int d = 0; d < counts[s]; ++d) {
+            AxisD& A = sets[s][d];
+            A.lds_off = -1;
+            if (A.uniform) continue;
+            if (used + A.n <= MAX_LDS_AXIS_DOUBLES) {
+                A.lds_off = used;
+                used += A.n;
+            }
+        }
+    return used;
+}
+
+hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = (hipSetDevice(dev) == hipSuccess);
+    }
+    ~DeviceGuard()
+    {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+double host_powerlaw_C(double alpha, double lo, double hi)
+{
+    return (1 + alpha) / (std::pow(hi, 1 + alpha) - std::pow(lo, 1 + alpha));
+}
+
+DevPrior make_dev_prior(const iso_prior& P)
+{
+    DevPrior D;
+    std::memset(&D, 0, sizeof(D));
+    D.kind = P.kind;
+    D.bounded = P.bounded;
+    D.lo = P.lo; D.hi = P.hi;
+    D.a = P.a; D.b = P.b; D.c = P.c; D.d = P.d; D.e = P.e; D.f = P.f; D.g = P.g; D.h = P.h;
+    switch (P.kind) {
+    case ISO_PRIOR_FLAT:
+        D.k0 = 1.0 / (P.hi - P.lo);
+        break;
+    case ISO_PRIOR_FLATLOG:
+        D.k0 = std::pow(10.0, P.hi) - std::pow(10.0, P.lo);
+        break;
+    case ISO_PRIOR_POWERLAW:
+        D.k0 = host_powerlaw_C(P.a, P.lo, P.hi);
+        D.k1 = std::log(D.k0);
+        break;
+    case ISO_PRIOR_GAUSS:
+        D.k0 = std::exp(P.c);
+        D.k1 = std::log(P.b);
+        break;
+    case ISO_PRIOR_LOGNORMAL:
+        D.k0 = std::exp(P.a);
+        D.k1 = std::log(P.b);
+        break;
+    case ISO_PRIOR_CHABRIER:
+        D.k0 = std::exp(P.a);
+        D.k1 = std::log(P.b);
+        D.k2 = host_powerlaw_C(P.c, P.g, P.h);
+        D.k3 = std::log(P.e);
+        D.k4 = std::log(P.f);
+        D.k5 = std::log(D.k2);
+        break;
+    case ISO_PRIOR_FEH:
+        D.k0 = 1.0 / std::sqrt(2 * M_PI * 0.4 * 0.4);
+        break;
+    }
+    return D;
+}
+
+bool prior_kind_ok(int k) { return k >= ISO_PRIOR_FLAT && k <= ISO_PRIOR_FEH; }
+
+void gauss_consts(double unc, double& g0, double& unc2)
+{
+    g0 = std::log(1.0 / std::sqrt(2 * M_PI)) + std::log(unc);
+    unc2 = unc * unc;
+}
+
+}  // namespace
+
+// ======================================================================================
+// C ABI
+// ======================================================================================
+extern "C" {
+
+const char* iso_last_error(void) { return g_err.c_str(); }
+
+const char* iso_version(void) { return "isochrones_amd 0.1.0 (gfx950 HIP)"; }
+
+int iso_ctx_create(iso_ctx** out, int device)
+{
+    if (!out) return fail(ISO_ERR_INVALID, "iso_ctx_create: out is NULL");
+    int count = 0;
+    HIP_TRY(hipGetDeviceCount(&count));
+    if (device < 0 || device >= count) return fail(ISO_ERR_INVALID, "iso_ctx_create: no such device");
+    iso_ctx* c = new (std::nothrow) iso_ctx;
+    if (!c) return fail(ISO_ERR_NOMEM, "iso_ctx_create: out of host memory");
+    c->device = device;
+    *out = c;
+    return ISO_OK;
+}
+
+void iso_ctx_destroy(iso_ctx* ctx) { delete ctx; }
+
+int iso_table_create(iso_ctx* ctx, int ndim, const int64_t* shape, const double* grid, const double* const* axes,
+                     iso_table** out)
+{
+    if (!ctx || !shape || !grid || !axes || !out) return fail(ISO_ERR_INVALID, "iso_table_create: NULL argument");
+    if (ndim < 2 || ndim > ISO_MAX_DIM) return fail(ISO_ERR_INVALID, "iso_table_create: ndim must be 2, 3 or 4");
+    int64_t ncells = 1;
+    for (int d = 0; d < ndim; ++d) {
+        if (shape[d] < 2 || shape[d] > (1 << 30)) return fail(ISO_ERR_INVALID, "iso_table_create: axis length < 2");
+        ncells *= shape[d];
+    }
+    if (shape[ndim] < 1) return fail(ISO_ERR_INVALID, "iso_table_create: no columns");
+    for (int d = 0; d < ndim; ++d)
+        for (int64_t j = 0; j < shape[d]; ++j) {
+            const double v = axes[d][j];
+            if (!(v == v) || (j > 0 && !(axes[d][j - 1] < v)))
+                return fail(ISO_ERR_INVALID, "iso_table_create: axis values must be strictly increasing");
+        }
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return fail(ISO_ERR_HIP, "iso_table_create: hipSetDevice failed");
+    iso_table* t = new (std::nothrow) iso_table();
+    if (!t) return fail(ISO_ERR_NOMEM, "iso_table_create: out of host memory");
+    t->ctx = ctx;
+    t->ndim = ndim;
+    t->ncells = ncells;
+    t->d_grid = nullptr;
+    for (int d = 0; d < ISO_MAX_DIM; ++d) t->d_axes[d] = nullptr;
+    for (int d = 0; d <= ndim; ++d) t->shape[d] = shape[d];
+    const size_t bytes = (size_t)ncells * (size_t)shape[ndim] * sizeof(double);
+    hipError_t e = hipMalloc(&t->d_grid, bytes);
+    if (e == hipSuccess) e = hipMemcpy(t->d_grid, grid, bytes, hipMemcpyHostToDevice);
+    for (int d = 0; d < ndim && e == hipSuccess; ++d) {
+        t->h_axes[d].assign(axes[d], axes[d] + shape[d]);
+        e = hipMalloc(&t->d_axes[d], shape[d] * sizeof(double));
+        if (e == hipSuccess) e = hipMemcpy(t->d_axes[d], axes[d], shape[d] * sizeof(double), hipMemcpyHostToDevice);
+        AxisD& A = t->ax[d];
+        A.g = t->d_axes[d];
+        A.n = (int)shape[d];
+        A.lds_off = -1;
+        A.uniform = axis_uniform(t->h_axes[d], A.a0, A.step) ? 1 : 0;
+    }
+    if (e != hipSuccess) {
+        std::string msg = std::string("iso_table_create: ") + hipGetErrorString(e);
+        iso_table_destroy(t);
+        return fail(e == hipErrorOutOfMemory ? ISO_ERR_NOMEM : ISO_ERR_HIP, msg);
+    }
+    *out = t;
+    return ISO_OK;
+}
+
+void iso_table_destroy(iso_table* t)
+{
+    if (!t) return;
+    DeviceGuard guard(t->ctx->device);
+    if (t->d_grid) (void)hipFree(t->d_grid);
+    for (int d = 0; d < ISO_MAX_DIM; ++d)
+        if (t->d_axes[d]) (void)hipFree(t->d_axes[d]);
+    delete t;
+}
+
+int iso_interp(iso_table* t, const double* const* x, int64_t n, const int32_t* icols, int k, double* out,
+               void* stream)
+{
+    if (!t || !x || !icols || (!out && n > 0)) return fail(ISO_ERR_INVALID, "iso_interp: NULL argument");
+    if (k < 1 || k > ISO_MAX_COLS) return fail(ISO_ERR_INVALID, "iso_interp: k out of range");
+    if (n < 0) return fail(ISO_ERR_INVALID, "iso_interp: n < 0");
+    if (n == 0) return ISO_OK;
+    InterpArgs A;
+    std::memset(&A, 0, sizeof(A));
+    for (int d = 0; d < t->ndim; ++d) {
+        A.ax[d] = t->ax[d];
+        A.x[d] = x[d];
+        if (!x[d]) return fail(ISO_ERR_INVALID, "iso_interp: NULL coordinate pointer");
+    }
+    const int lds = assign_lds(A.ax, t->ndim, nullptr, 0);
+    int64_t s = 1;
+    for (int d = t->ndim - 1; d >= 0; --d) {
+        A.stride[d] = s;
+        s *= t->shape[d];
+    }
+    A.grid = t->d_grid;
+    A.ncol = (int)t->shape[t->ndim];
+    A.n = n;
+    A.k = k;
+    for (int c = 0; c < k; ++c) {
+        if (icols[c] < 0 || icols[c] >= A.ncol) return fail(ISO_ERR_INVALID, "iso_interp: column index out of range");
+        A.icols[c] = icols[c];
+    }
+    A.out = out;
+    DeviceGuard guard(t->ctx->device);
+    const dim3 g(grid_blocks(n)), b(BLOCK);
+    const size_t shmem = (size_t)lds * sizeof(double);
+    switch (t->ndim) {
+    case 2: hipLaunchKernelGGL(k_interp<2>, g, b, shmem, as_stream(stream), A); break;
+    case 3: hipLaunchKernelGGL(k_interp<3>, g, b, shmem, as_stream(stream), A); break;
+    default: hipLaunchKernelGGL(k_interp<4>, g, b, shmem, as_stream(stream), A); break;
+    }
+    HIP_TRY(hipGetLastError());
+    return ISO_OK;
+}
+
+int iso_ic_create(iso_ctx* ctx, iso_table* model_grid, iso_table* bc_grid, int kind, const int32_t cols[4],
+                  const int32_t prior_cols[2], const int32_t astero_cols[2], iso_ic** out)
+{
+    if (!ctx || !model_grid || !bc_grid || !cols || !prior_cols || !astero_cols || !out)
+        return fail(ISO_ERR_INVALID, "iso_ic_create: NULL argument");
+    if (model_grid->ndim != 3) return fail(ISO_ERR_INVALID, "iso_ic_create: model table must be 3-D");
+    if (bc_grid->ndim != 4) return fail(ISO_ERR_INVALID, "iso_ic_create: BC table must be 4-D");
+    if (kind != ISO_KIND_TRACK && kind != ISO_KIND_ISO) return fail(ISO_ERR_INVALID, "iso_ic_create: bad kind");
+    if (model_grid->ctx->device != ctx->device || bc_grid->ctx->device != ctx->device)
+        return fail(ISO_ERR_INVALID, "iso_ic_create: tables live on another device");
+    const int ncol = (int)model_grid->shape[3];
+    for (int q = 0; q < 4; ++q)
+        if (cols[q] < 0 || cols[q] >= ncol) return fail(ISO_ERR_INVALID, "iso_ic_create: column index out of range");
+    for (int q = 0; q < 2; ++q) {
+        if (prior_cols[q] < -1 || prior_cols[q] >= ncol || astero_cols[q] < -1 || astero_cols[q] >= ncol)
+            return fail(ISO_ERR_INVALID, "iso_ic_create: column index out of range");
+    }
+    DeviceGuard guard(ctx->device);
+    iso_ic* ic = new (std::nothrow) iso_ic();
+    if (!ic) return fail(ISO_ERR_NOMEM, "iso_ic_create: out of host memory");
+    ic->ctx = ctx;
+    ic->model = model_grid;
+    ic->bc = bc_grid;
+    ic->kind = kind;
+    std::memcpy(ic->cols, cols, sizeof(ic->cols));
+    std::memcpy(ic->prior_cols, prior_cols, sizeof(ic->prior_cols));
+    std::memcpy(ic->astero_cols, astero_cols, sizeof(ic->astero_cols));
+    ic->d_hot = nullptr;
+    const size_t bytes = (size_t)model_grid->ncells * HOT_COLS * sizeof(double);
+    hipError_t e = hipMalloc(&ic->d_hot, bytes);
+    if (e != hipSuccess) {
+        delete ic;
+        return fail(e == hipErrorOutOfMemory ? ISO_ERR_NOMEM : ISO_ERR_HIP,
+                    std::string("iso_ic_create: hipMalloc(hot table): ") + hipGetErrorString(e));
+    }
+    PackHotArgs P;
+    P.grid = model_grid->d_grid;
+    P.ncol = ncol;
+    P.ncells = model_grid->ncells;
+    const int32_t src[HOT_COLS] = {cols[0], cols[1], cols[2], cols[3], prior_cols[0], prior_cols[1],
+                                   astero_cols[0], astero_cols[1]};
+    std::memcpy(P.src, src, sizeof(src));
+    P.hot = ic->d_hot;
+    hipLaunchKernelGGL(k_pack_hot, dim3(grid_blocks(P.ncells * HOT_COLS)), dim3(BLOCK), 0, 0, P);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) {
+        (void)hipFree(ic->d_hot);
+        delete ic;
+        return fail(ISO_ERR_HIP, std::string("iso_ic_create: pack kernel: ") + hipGetErrorString(e));
+    }
+    for (int d = 0; d < 3; ++d) ic->g3.ax[d] = model_grid->ax[d];
+    ic->g3.hot = ic->d_hot;
+    ic->g3.s1 = model_grid->shape[2];
+    ic->g3.s0 = model_grid->shape[1] * model_grid->shape[2];
+    for (int d = 0; d < 4; ++d) ic->g4.ax[d] = bc_grid->ax[d];
+    ic->g4.tab = bc_grid->d_grid;
+    ic->g4.ncol = (int)bc_grid->shape[4];
+    ic->g4.s2 = bc_grid->shape[3];
+    ic->g4.s1 = bc_grid->shape[2] * bc_grid->shape[3];
+    ic->g4.s0 = bc_grid->shape[1] * bc_grid->shape[2] * bc_grid->shape[3];
+    ic->lds_doubles = assign_lds(ic->g3.ax, 3, ic->g4.ax, 4);
+    *out = ic;
+    return ISO_OK;
+}
+
+void iso_ic_destroy(iso_ic* ic)
+{
+    if (!ic) return;
+    DeviceGuard guard(ic->ctx->device);
+    if (ic->d_hot) (void)hipFree(ic->d_hot);
+    delete ic;
+}
+
+int iso_interp_mag(iso_ic* ic, const double* pars, int64_t stride_n, int64_t stride_p, int64_t n,
+                   const int32_t* bc_cols, int nb, double* Teff, double* logg, double* feh, double* mags,
+                   void* stream)
+{
+    if (!ic || (!pars && n > 0)) return fail(ISO_ERR_INVALID, "iso_interp_mag: NULL argument");
+    if (nb < 0 || nb > ISO_MAX_BANDS) return fail(ISO_ERR_INVALID, "iso_interp_mag: nb out of range");
+    if (nb > 0 && !bc_cols) return fail(ISO_ERR_INVALID, "iso_interp_mag: bc_cols is NULL");
+    if (n < 0) return fail(ISO_ERR_INVALID, "iso_interp_mag: n < 0");
+    if (n == 0) return ISO_OK;
+    MagArgs A;
+    std::memset(&A, 0, sizeof(A));
+    A.g3 = ic->g3;
+    A.g4 = ic->g4;
+    A.kind = ic->kind;
+    A.pars = pars;
+    A.stride_n = stride_n;
+    A.stride_p = stride_p;
+    A.n = n;
+    A.nb = nb;
+    for (int b = 0; b < nb; ++b) {
+        if (bc_cols[b] < 0 || bc_cols[b] >= ic->g4.ncol)
+            return fail(ISO_ERR_INVALID, "iso_interp_mag: band column out of range");
+        A.bc_cols[b] = bc_cols[b];
+    }
+    A.Teff = Teff; A.logg = logg; A.feh = feh;
+    A.mags = nb > 0 ? mags : nullptr;
+    DeviceGuard guard(ic->ctx->device);
+    const dim3 g(grid_blocks(n)), b(BLOCK);
+    const size_t shmem = (size_t)ic->lds_doubles * sizeof(double);
+    if (ic->kind == ISO_KIND_TRACK) hipLaunchKernelGGL(k_interp_mag<ISO_KIND_TRACK>, g, b, shmem, as_stream(stream), A);
+    else hipLaunchKernelGGL(k_interp_mag<ISO_KIND_ISO>, g, b, shmem, as_stream(stream), A);
+    HIP_TRY(hipGetLastError());
+    return ISO_OK;
+}
+
+int iso_model_create(iso_ic* ic, const iso_model_desc* desc, iso_model** out)
+{
+    if (!ic || !desc || !out) return fail(ISO_ERR_INVALID, "iso_model_create: NULL argument");
+    if (desc->n_stars < 1 || desc->n_stars > ISO_MAX_STARS) return fail(ISO_ERR_INVALID, "iso_model_create: n_stars");
+    if (desc->n_stars > 1 && ic->kind == ISO_KIND_TRACK)
+        return fail(ISO_ERR_INVALID, "iso_model_create: multiple stars need the isochrone parametrisation");
+    if (desc->n_bands < 0 || desc->n_bands > ISO_MAX_BANDS) return fail(ISO_ERR_INVALID, "iso_model_create: n_bands");
+    if (ic->prior_cols[0] < 0 || ic->prior_cols[1] < 0)
+        return fail(ISO_ERR_INVALID, "iso_model_create: the model table has no EEP-prior columns");
+    if (desc->has_numax && (ic->astero_cols[0] < 0 || ic->astero_cols[1] < 0))
+        return fail(ISO_ERR_INVALID, "iso_model_create: the model table has no nu_max/delta_nu columns");
+    for (int b = 0; b < desc->n_bands; ++b)
+        if (desc->bc_cols[b] < 0 || desc->bc_cols[b] >= ic->g4.ncol)
+            return fail(ISO_ERR_INVALID, "iso_model_create: band column out of range");
+    const iso_prior* pr[5] = {&desc->prior_mass, &desc->prior_age, &desc->prior_feh, &desc->prior_distance,
+                              &desc->prior_AV};
+    for (int j = 0; j < 5; ++j)
+        if (!prior_kind_ok(pr[j]->kind)) return fail(ISO_ERR_INVALID, "iso_model_create: unknown prior family");
+
+    DeviceGuard guard(ic->ctx->device);
+    iso_model* m = new (std::nothrow) iso_model();
+    if (!m) return fail(ISO_ERR_NOMEM, "iso_model_create: out of host memory");
+    m->ic = ic;
+    m->desc = *desc;
+    m->d_model = nullptr;
+    m->d_bc_hot = nullptr;
+
+    DevModel H;
+    std::memset(&H, 0, sizeof(H));
+    H.n_stars = desc->n_stars;
+    H.n_bands = desc->n_bands;
+    H.kind = ic->kind;
+    H.has_parallax = desc->has_parallax;
+    H.has_numax = desc->has_numax;
+    H.has_dnu = desc->has_numax ? desc->has_dnu : 0;
+    for (int b = 0; b < desc->n_bands; ++b) {
+        H.mag_val[b] = desc->mag_val[b];
+        gauss_consts(desc->mag_unc[b], H.mag_g0[b], H.mag_unc2[b]);
+    }
+    for (int q = 0; q < 3; ++q) {
+        H.spec_val[q] = desc->spec_val[q];
+        gauss_consts(desc->spec_unc[q], H.spec_g0[q], H.spec_unc2[q]);
+    }
+    H.plx_val = desc->plx_val;
+    gauss_consts(desc->plx_unc, H.plx_g0, H.plx_unc2);
+    H.numax_val = desc->numax_val;
+    gauss_consts(desc->numax_unc, H.numax_g0, H.numax_unc2);
+    H.dnu_val = desc->dnu_val;
+    gauss_consts(desc->dnu_unc, H.dnu_g0, H.dnu_unc2);
+    H.prior_mass = make_dev_prior(desc->prior_mass);
+    H.prior_age = make_dev_prior(desc->prior_age);
+    H.prior_feh = make_dev_prior(desc->prior_feh);
+    H.prior_distance = make_dev_prior(desc->prior_distance);
+    H.prior_AV = make_dev_prior(desc->prior_AV);
+    H.eep_lo = desc->eep_lo;
+    H.eep_hi = desc->eep_hi;
+    for (int j = 0; j < ISO_MAX_PARAMS; ++j) {
+        H.bound_lo[j] = desc->bound_lo[j];
+        H.bound_hi[j] = desc->bound_hi[j];
+    }
+    hipError_t e = hipMalloc(&m->d_model, sizeof(DevModel));
+    if (e == hipSuccess) e = hipMemcpy(m->d_model, &H, sizeof(DevModel), hipMemcpyHostToDevice);
+
+    // BC table restricted to this model's bands (observation order), contiguous per cell
+    m->g4 = ic->g4;
+    if (e == hipSuccess && desc->n_bands > 0) {
+        const int64_t ncells = ic->bc->ncells;
+        e = hipMalloc(&m->d_bc_hot, (size_t)ncells * desc->n_bands * sizeof(double));
+        if (e == hipSuccess) {
+            PackBcArgs P;
+            P.grid = ic->bc->d_grid;
+            P.ncol = ic->g4.ncol;
+            P.nb = desc->n_bands;
+            P.ncells = ncells;
+            for (int b = 0; b < desc->n_bands; ++b) P.src[b] = desc->bc_cols[b];
+            P.out = m->d_bc_hot;
+            hipLaunchKernelGGL(k_pack_bc, dim3(grid_blocks(ncells * desc->n_bands)), dim3(BLOCK), 0, 0, P);
+            e = hipGetLastError();
+            if (e == hipSuccess) e = hipDeviceSynchronize();
+            m->g4.tab = m->d_bc_hot;
+            m->g4.ncol = desc->n_bands;
+        }
+    }
+    if (e != hipSuccess) {
+        std::string msg = std::string("iso_model_create: ") + hipGetErrorString(e);
+        iso_model_destroy(m);
+        return fail(e == hipErrorOutOfMemory ? ISO_ERR_NOMEM : ISO_ERR_HIP, msg);
+    }
+    *out = m;
+    return ISO_OK;
+}
+
+void iso_model_destroy(iso_model* m)
+{
+    if (!m) return;
+    DeviceGuard guard(m->ic->ctx->device);
+    if (m->d_model) (void)hipFree(m->d_model);
+    if (m->d_bc_hot) (void)hipFree(m->d_bc_hot);
+    delete m;
+}
+
+int iso_model_n_params(const iso_model* m) { return m ? m->desc.n_stars + 4 : ISO_ERR_INVALID; }
+
+}  // extern "C"
+
+namespace {
+
+template <int KIND, int NS, bool PARTS>
+void launch_lnpost_nb(int nb, dim3 g, dim3 b, size_t shmem, hipStream_t s, const PostArgs& A)
+{
+    switch (nb) {
+    case 1: hipLaunchKernelGGL((k_lnpost<KIND, NS, 1, PARTS>), g, b, shmem, s, A); break;
+    case 2: hipLaunchKernelGGL((k_lnpost<KIND, NS, 2, PARTS>), g, b, shmem, s, A); break;
+    case 3: hipLaunchKernelGGL((k_lnpost<KIND, NS, 3, PARTS>), g, b, shmem, s, A); break;
+    case 4: hipLaunchKernelGGL((k_lnpost<KIND, NS, 4, PARTS>), g, b, shmem, s, A); break;
+    case 5: hipLaunchKernelGGL((k_lnpost<KIND, NS, 5, PARTS>), g, b, shmem, s, A); break;
+    case 6: hipLaunchKernelGGL((k_lnpost<KIND, NS, 6, PARTS>), g, b, shmem, s, A); break;
+    case 7: hipLaunchKernelGGL((k_lnpost<KIND, NS, 7, PARTS>), g, b, shmem, s, A); break;
+    case 8: hipLaunchKernelGGL((k_lnpost<KIND, NS, 8, PARTS>), g, b, shmem, s, A); break;
+    default: hipLaunchKernelGGL((k_lnpost<KIND, NS, 0, PARTS>), g, b, shmem, s, A); break;
+    }
+}
+
+template <bool PARTS>
+void launch_lnpost(const iso_model* m, dim3 g, dim3 b, size_t shmem, hipStream_t s, const PostArgs& A)
+{
+    const int nb = m->desc.n_bands;
+    if (m->ic->kind == ISO_KIND_TRACK) {
+        launch_lnpost_nb<ISO_KIND_TRACK, 1, PARTS>(nb, g, b, shmem, s, A);
+    } else {
+        switch (m->desc.n_stars) {
+        case 1: launch_lnpost_nb<ISO_KIND_ISO, 1, PARTS>(nb, g, b, shmem, s, A); break;
+        case 2: launch_lnpost_nb<ISO_KIND_ISO, 2, PARTS>(nb, g, b, shmem, s, A); break;
+        default: launch_lnpost_nb<ISO_KIND_ISO, 3, PARTS>(nb, g, b, shmem, s, A); break;
+        }
+    }
+}
+
+int enqueue_lnpost(iso_model* m, const double* pars, int64_t stride_n, int64_t stride_p, int64_t n,
+                   double* lnpost_out, double* lnprior_out, double* lnlike_out, hipStream_t s)
+{
+    PostArgs A;
+    A.g3 = m->ic->g3;
+    A.g4 = m->g4;
+    A.m = m->d_model;
+    A.pars = pars;
+    A.stride_n = stride_n;
+    A.stride_p = stride_p;
+    A.n = n;
+    A.lnpost = lnpost_out;
+    A.lnprior = lnprior_out;
+    A.lnlike = lnlike_out;
+    const dim3 g(grid_blocks(n)), b(BLOCK);
+    const size_t shmem = (size_t)m->ic->lds_doubles * sizeof(double);
+    if (lnprior_out || lnlike_out) launch_lnpost<true>(m, g, b, shmem, s, A);
+    else launch_lnpost<false>(m, g, b, shmem, s, A);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(ISO_ERR_HIP, std::string("iso_lnpost launch: ") + hipGetErrorString(e));
+    return ISO_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int iso_lnpost(iso_model* m, const double* pars, int64_t stride_n, int64_t stride_p, int64_t n,
+               double* lnpost_out, double* lnprior_out, double* lnlike_out, void* stream)
+{
+    if (!m || (!pars && n > 0)) return fail(ISO_ERR_INVALID, "iso_lnpost: NULL argument");
+    if (n < 0) return fail(ISO_ERR_INVALID, "iso_lnpost: n < 0");
+    if (!lnpost_out && !lnprior_out && !lnlike_out) return fail(ISO_ERR_INVALID, "iso_lnpost: no output requested");
+    if (n == 0) return ISO_OK;
+    DeviceGuard guard(m->ic->ctx->device);
+    return enqueue_lnpost(m, pars, stride_n, stride_p, n, lnpost_out, lnprior_out, lnlike_out, as_stream(stream));
+}
+
+int iso_unit_cube(iso_model* m, double* cube, int64_t stride_n, int64_t stride_p, int64_t n, void* stream)
+{
+    if (!m || (!cube && n > 0)) return fail(ISO_ERR_INVALID, "iso_unit_cube: NULL argument");
+    if (n < 0) return fail(ISO_ERR_INVALID, "iso_unit_cube: n < 0");
+    if (n == 0) return ISO_OK;
+    DeviceGuard guard(m->ic->ctx->device);
+    hipLaunchKernelGGL(k_unit_cube, dim3(grid_blocks(n * (m->desc.n_stars + 4))), dim3(BLOCK), 0, as_stream(stream),
+                       m->d_model, cube, stride_n, stride_p, n);
+    HIP_TRY(hipGetLastError());
+    return ISO_OK;
+}
+
+int iso_time_lnpost(iso_model* m, const double* pars, int64_t stride_n, int64_t stride_p, int64_t n,
+                    double* lnpost_out, int reps, void* stream, double* ms_per_launch)
+{
+    if (!m || !pars || !lnpost_out || !ms_per_launch || reps < 1 || n < 1)
+        return fail(ISO_ERR_INVALID, "iso_time_lnpost: bad argument");
+    DeviceGuard guard(m->ic->ctx->device);
+    hipStream_t s = as_stream(stream);
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    int rc = ISO_OK;
+    HIP_TRY(hipEventRecord(e0, s));
+    for (int r = 0; r < reps && rc == ISO_OK; ++r)
+        rc = enqueue_lnpost(m, pars, stride_n, stride_p, n, lnpost_out, nullptr, nullptr, s);
+    hipError_t e = hipEventRecord(e1, s);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc != ISO_OK) return rc;
+    if (e != hipSuccess) return fail(ISO_ERR_HIP, std::string("iso_time_lnpost: ") + hipGetErrorString(e));
+    *ms_per_launch = (double)ms / reps;
+    return ISO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,142 @@
+"""CPU tests: the C-ABI library loads and exports every symbol the header declares (no compute
+calls without a GPU), and the host-side logic (priors, descriptor packing, table building)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import isochrones_amd as ia
+from isochrones_amd import _cabi, priors
+from tests import _fixtures as fx
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built_lib():
+    from isochrones_amd.csrc import build as hip_build
+    return hip_build.build()
+
+
+def test_header_symbols_exported(built_lib):
+    header = open(os.path.join(ROOT, "include", "isochrones_amd.h")).read()
+    declared = set(re.findall(r"\b(iso_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_cabi.EXPORTED_SYMBOLS)
+    lib = ctypes.CDLL(built_lib)
+    for sym in declared:
+        assert hasattr(lib, sym), sym
+    lib.iso_version.restype = ctypes.c_char_p
+    assert b"isochrones_amd" in lib.iso_version()
+
+
+def test_struct_layout_matches_header(built_lib):
+    """ctypes mirror vs the C compiler's layout of iso_prior / iso_model_desc."""
+    import subprocess, tempfile
+    src = r'''
+    #include <stdio.h>
+    #include <stddef.h>
+    #include "isochrones_amd.h"
+    int main(void){
+      printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(iso_prior), sizeof(iso_model_desc),
+             offsetof(iso_model_desc, mag_val), offsetof(iso_model_desc, has_parallax),
+             offsetof(iso_model_desc, prior_mass), offsetof(iso_model_desc, eep_lo),
+             offsetof(iso_model_desc, bound_lo));
+      return 0; }'''
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, "t.c")
+        open(c, "w").write(src)
+        exe = os.path.join(d, "t")
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
+        got = list(map(int, subprocess.check_output([exe]).split()))
+    M = _cabi.IsoModelDesc
+    want = [ctypes.sizeof(_cabi.IsoPrior), ctypes.sizeof(M), M.mag_val.offset, M.has_parallax.offset,
+            M.prior_mass.offset, M.eep_lo.offset, M.bound_lo.offset]
+    assert got == want
+
+
+def test_no_gpu_means_loud_failure():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    ic = ia.synthetic_track(bands=("V",), fehs=[-1, 0], masses=[0.8, 1.0, 1.2], eeps=np.arange(300., 340.))
+    mod = ia.SingleStarModel(ic, V=(10, 0.1))
+    with pytest.raises(_cabi.IsoError):
+        mod.lnpost([1.0, 320.0, -0.5, 100.0, 0.1])
+    with pytest.raises(_cabi.IsoError):
+        ic.interp_value([1.0, 320.0, -0.5], ["Teff"])
+
+
+def test_missing_library_is_loud(monkeypatch):
+    monkeypatch.setenv("ISOCHRONES_AMD_LIB", "/nonexistent/libiso_hip.so")
+    monkeypatch.setattr(_cabi, "_LIB", None)
+    with pytest.raises(_cabi.IsoError):
+        _cabi.lib()
+
+
+def test_prior_norms_match_reference_and_closed_forms():
+    for case in fx.MODEL_CASES:
+        meta = fx.load(case)["meta"]
+        mod = fx.make_model(meta)
+        assert np.allclose(mod._priors["mass"].norms, meta["mass_norms"], rtol=1e-13)
+        assert np.isclose(mod._priors["feh"]._norm, meta["feh_norm"], rtol=1e-13)
+        assert tuple(mod.bounds("distance")) == tuple(meta["distance_bounds"])
+        assert tuple(mod.bounds("AV")) == tuple(meta["AV_bounds"])
+        assert list(mod.param_names) == meta["param_names"]
+        m = mod._priors["mass"]
+        assert np.isclose(m.closed_form_total(), m.norms[0], rtol=1e-7)
+        f = mod._priors["feh"]
+        if np.isfinite(f.bounds[0]):
+            assert np.isclose(f.closed_form_norm(), f._norm, rtol=1e-9)
+
+
+def test_default_mist_norms():
+    """with MIST limits the reference finds norms [0.43777194, 8.45012957] and a feh
+    norm of 0.99918672."""
+    ic = ia.synthetic_track(bands=("V",), fehs=[-4, 0.5], masses=[0.1, 300.0], eeps=np.arange(1., 5.))
+    mod = ia.SingleStarModel(ic, V=(10, 0.1))
+    assert np.allclose(mod._priors["mass"].norms, [0.43777194, 8.45012957], rtol=1e-8)
+    assert np.isclose(mod._priors["feh"]._norm, 0.99918672, rtol=1e-8)
+    assert mod.bounds("age") == (5, 10.13) and mod.bounds("eep") == (0, 1710)
+
+
+def test_priors_integrate_to_one():
+    """reference tests/test_priors.py: every prior integrates to 1 over its bounds."""
+    from scipy.integrate import quad
+    ps = [priors.ChabrierPrior(bounds=(0.1, 100)), priors.FehPrior(bounds=(-4, 0.5)), priors.AgePrior(),
+          priors.DistancePrior(3000), priors.AVPrior(), priors.GaussianPrior(1.0, 0.3, bounds=(0, 2)),
+          priors.FlatLogPrior((-3, 1)), priors.PowerLawPrior(-2.35, (0.1, 10))]
+    for p in ps:
+        lo, hi = p.bounds
+        pts = [1.0] if isinstance(p, priors.ChabrierPrior) else None
+        tot = quad(p.pdf, lo, hi, points=pts, limit=200)[0]
+        assert np.isclose(tot, 1.0, rtol=1e-6), (type(p).__name__, tot)
+    f = priors.FehPrior(bounds=(-2, 0.5))
+    assert f(-2.5) == 0 and f(0.7) == 0 and f(0.0) > 0          # tests/test_priors.py:47-51
+    for p in ps:
+        x = p.sample(2000, np.random.default_rng(3))
+        assert np.all((x >= p.bounds[0]) & (x <= p.bounds[1]))
+
+
+def test_descriptor_packing():
+    meta = fx.load("iso_binary_phot6")["meta"]
+    mod = fx.make_model(meta)
+    d = mod.model_desc()
+    assert d.n_stars == 2 and d.n_bands == 6 and d.has_parallax == 1 and d.has_numax == 0
+    assert [mod.ic.bc_grid.interp.columns[d.bc_cols[j]] for j in range(6)] == ["J", "H", "K", "BP", "RP", "G"]
+    assert np.isnan(d.spec_val[0]) and d.prior_mass.kind == _cabi.PRIOR_CHABRIER
+    assert d.prior_distance.hi == 800.0     # 2000 / parallax
+    assert mod.param_names == ("eep_0", "eep_1", "age", "feh", "distance", "AV")
+    meta = fx.load("track_single_astero")["meta"]
+    d = fx.make_model(meta).model_desc()
+    assert d.has_numax == 1 and d.has_dnu == 1 and d.dnu_unc == d.dnu_val
+
+
+def test_synthetic_tables_shapes():
+    g, ax, cols = ia.grids.synthetic_track_grid(eeps=np.arange(1.0, 41.0))
+    assert g.shape == (15, 196, 40, 18) and len(cols) == 18
+    assert ia.grids.mist_masses().size == 196 and ia.grids.mist_log_ages().size == 107
+    assert [a.size for a in ia.grids.bc_axes()] == [70, 26, 18, 13]
+    g, ax, cols = ia.grids.synthetic_iso_grid(eeps=np.arange(100.0, 300.0))
+    assert g.shape == (107, 15, 200, 16) and np.isnan(g).any() and np.isfinite(g).any()

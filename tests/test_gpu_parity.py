@@ -1,0 +1,205 @@
+"""GPU parity tests (run with -m gpu on the MI355X box): the HIP path, called through the C ABI
+by the host layer, against (a) the committed golden vectors produced by the reference itself and
+(b) the CPU oracle on seeded random inputs.
+
+Tolerance: BASELINE.json's north_star asks for <= 1e-6 relative vs the reference CPU path; the
+kernels are float64 like the reference, so the tests hold them to RTOL = 1e-9 (differences come
+only from FMA contraction and device-libm ulps).  NaN / -inf patterns must match exactly."""
+import numpy as np
+import pytest
+
+import isochrones_amd as ia
+from isochrones_amd.interp import DFInterpolator
+from tests import _fixtures as fx
+
+pytestmark = pytest.mark.gpu
+
+NORTH_STAR_RTOL = 1e-6
+RTOL = 1e-9
+ATOL = 1e-11
+
+
+def test_library_loaded_and_version():
+    from isochrones_amd import _cabi
+    assert b"gfx950" in _cabi.lib().iso_version()
+
+
+def test_kats_3d_2d_4d():
+    k = fx.load("interp_kats")
+    t3 = DFInterpolator.from_arrays(k["t3_grid"], [k["t3_axes0"], k["t3_axes1"], k["t3_axes2"]], ["val"])
+    pts = k["t3_pts"]
+    got = t3([pts[:, 0], pts[:, 1], pts[:, 2]], ["val"])
+    fx.assert_close(got, k["t3_vals"], RTOL, what="3d")
+    # reference tests/test_interp.py:31,35 — scalar call form, exact at a node
+    assert t3([6.0, 50.0, 200.0], ["val"])[0] == 6.0 ** 2 * np.cos(5.0) + 200.0
+    assert np.isclose(t3([3.1, 44.0, 503.0], ["val"])[0], k["t3_scalar"][1], rtol=RTOL)
+    axes2 = [k["t2_axes0"], k["t2_axes1"]]
+    full = DFInterpolator.from_arrays(k["t2_grid"], axes2, ["sum", "product", "power"])
+    miss = DFInterpolator.from_arrays(k["t2_grid_missing"], axes2, ["sum", "product", "power"])
+    assert np.allclose(full([1.4, 2.1]), k["t2_doc_cell3"], atol=1e-12)          # docs/interpolate.ipynb cell 3
+    assert np.allclose(full([2.2, 4.6], ["product"]), k["t2_doc_cell5"], atol=1e-12)   # cell 5
+    assert np.allclose(miss([1.3, 2.2]), k["t2_doc_cell12"], atol=1e-12)         # cell 12
+    assert np.all(np.isnan(miss([2.3, 3.0])))                                    # cell 14
+    q = k["t2_pts"]
+    fx.assert_close(full([q[:, 0], q[:, 1]]), k["t2_vals"], RTOL, what="2d")
+    fx.assert_close(miss([q[:, 0], q[:, 1]]), k["t2_vals_missing"], RTOL, what="2d missing")
+    t4 = DFInterpolator.from_arrays(k["t4_grid"], [k["t4_axes%d" % i] for i in range(4)], ["a", "b", "c"])
+    p = k["t4_pts"]
+    fx.assert_close(t4([p[:, i] for i in range(4)], ["c", "a"]), k["t4_vals"], RTOL, atol=1e-13, what="4d")
+
+
+def test_dfinterpolator_from_dataframe_ragged():
+    """DataFrame constructor incl. the NaN-padding of a ragged index (interp.py:590-614)."""
+    import itertools
+    import pandas as pd
+    x, y = np.arange(1, 4), np.arange(1, 6)
+    index = pd.MultiIndex.from_product((x, y), names=["x", "y"])
+    df = pd.DataFrame(index=index)
+    df["sum"] = [a + b for a, b in itertools.product(x, y)]
+    df["product"] = [a * b for a, b in itertools.product(x, y)]
+    df["power"] = [a ** b for a, b in itertools.product(x, y)]
+    k = fx.load("interp_kats")
+    d = DFInterpolator(df)
+    assert np.array_equal(d.grid, k["t2_grid"])
+    dm = DFInterpolator(df.drop([(3, 3), (3, 4)]))
+    assert np.array_equal(dm.grid, k["t2_grid_missing"], equal_nan=True)
+    assert np.allclose(dm([1.3, 2.2]), [3.5, 2.86, 2.14], atol=1e-12)
+
+
+@pytest.mark.parametrize("case", fx.MODEL_CASES)
+def test_model_case_vs_reference_golden(case):
+    g = fx.load(case)
+    meta = g["meta"]
+    ic = fx.make_ic(meta)
+    mod = fx.make_model(meta, ic)
+    N = meta["n_stars"]
+    pars = g["pars"]
+    prim = [pars[:, 0]] + [pars[:, N + j] for j in range(4)]
+
+    vals = ic.interp_value(prim, meta["interp_value_cols"])
+    fx.assert_close(vals, g["interp_value"], RTOL, atol=ATOL, what="interp_value")
+    T, lg, fe, mags = ic.interp_mag(prim, meta["bands"])
+    ok = g["mag_defined"]
+    fx.assert_close(T[ok], g["Teff"][ok], RTOL, what="Teff")
+    fx.assert_close(lg[ok], g["logg"][ok], RTOL, what="logg")
+    fx.assert_close(fe[ok], g["feh"][ok], RTOL, atol=ATOL, what="feh")
+    fx.assert_close(mags[ok], g["mags"][ok], RTOL, atol=ATOL, what="mags")
+
+    fx.assert_close(mod.lnprior(pars), g["lnprior"], RTOL, atol=ATOL, what="lnprior")
+    fx.assert_close(mod.lnpost(pars), g["lnpost"], RTOL, atol=ATOL, what="lnpost")
+    d = ~g["lnlike_undefined"]
+    fx.assert_close(mod.lnlike(pars)[d], g["lnlike"][d], RTOL, atol=ATOL, what="lnlike")
+
+    # scalar call form returns python floats, as the reference does for a sampler callback
+    for i in (0, len(pars) // 2, len(pars) - 30):
+        v = mod.lnpost(pars[i])
+        assert isinstance(v, float)
+        fx.assert_close([v], [g["lnpost"][i]], RTOL, atol=ATOL, what="scalar lnpost")
+
+    # device-resident forms: row-major [N, n_par] and SoA [n_par, N]
+    import torch
+    dev_pars = torch.as_tensor(pars, device="cuda")
+    a = mod.lnpost(dev_pars)
+    b = mod.lnpost(dev_pars.T.contiguous(), soa=True)
+    assert a.is_cuda and torch.equal(torch.nan_to_num(a, nan=1.5), torch.nan_to_num(b, nan=1.5))
+    fx.assert_close(a.cpu().numpy(), g["lnpost"], RTOL, atol=ATOL, what="lnpost (device)")
+
+    # mnest_prior: host scalar form and device batch form
+    row = g["cube_in"][0].copy()
+    mod.mnest_prior(row, None, None)
+    fx.assert_close(row, g["cube_out"][0], 1e-15, what="mnest_prior scalar")
+    cube = torch.as_tensor(g["cube_in"].copy(), device="cuda")
+    mod.mnest_prior(cube)
+    fx.assert_close(cube.cpu().numpy(), g["cube_out"], 1e-15, what="mnest_prior device")
+
+
+def _random_model(kind, n_stars, bands, rng):
+    if kind == "track":
+        fehs = np.array([-2.0, -1.0, -0.5, -0.25, 0.0, 0.25, 0.5])
+        masses = ia.grids.mist_masses()[20:150:3]
+        eeps = np.arange(200.0, 900.0)
+        ic = ia.synthetic_track(bands=bands, fehs=fehs, masses=masses, eeps=eeps, eep_bounds=(200, 899),
+                                limits=dict(mass=(masses[0], masses[-1]), feh=(-2.0, 0.5), age=(5, 10.13)))
+        lo = np.array([masses[0], 200, -2.0, 5.0, 0.0])
+        hi = np.array([masses[-1], 899, 0.5, 2000.0, 1.0])
+    else:
+        ages = ia.grids.mist_log_ages()[40::3]
+        fehs = np.array([-2.0, -1.0, -0.5, -0.25, 0.0, 0.25, 0.5])
+        eeps = np.arange(150.0, 900.0)
+        ic = ia.synthetic_isochrone(bands=bands, ages=ages, fehs=fehs, eeps=eeps, eep_bounds=(150, 899),
+                                    limits=dict(age=(ages[0], ages[-1]), feh=(-2.0, 0.5)))
+        lo = np.array([150.0] * n_stars + [ages[0], -2.0, 5.0, 0.0])
+        hi = np.array([899.0] * n_stars + [ages[-1], 0.5, 2000.0, 1.0])
+    obs = dict(Teff=(5770, 100), logg=(4.4, 0.1), feh=(0.0, 0.15), parallax=(2.0, 0.05))
+    for j, b in enumerate(bands):
+        obs[b] = (10.0 + 0.3 * j, 0.02)
+    mod = ia.BasicStarModel(ic, N=n_stars, **obs)
+    return ic, mod, lo, hi
+
+
+@pytest.mark.parametrize("kind,n_stars,nb", [("track", 1, 1), ("track", 1, 3), ("iso", 1, 1), ("iso", 2, 6),
+                                             ("iso", 3, 2), ("iso", 2, 11), ("iso", 1, 0)])
+def test_random_batch_vs_oracle(kind, n_stars, nb):
+    """Mid-size tables, 2e5 seeded samples, every kernel specialisation (nb 0..8 compile-time,
+    >8 runtime loop) against the CPU oracle."""
+    rng = np.random.default_rng(1000 + 10 * n_stars + nb)
+    bands = ia.grids.DEFAULT_BANDS[:nb]
+    ic, mod, lo, hi = _random_model(kind, n_stars, bands, rng)
+    n = 200_000
+    span = hi - lo
+    pars = rng.uniform(lo - 0.02 * span, hi + 0.02 * span, size=(n, lo.size))
+    if n_stars > 1:
+        pars[: n // 2, :n_stars] = -np.sort(-pars[: n // 2, :n_stars], axis=1)
+    oic = fx.make_oracle_ic(ic)
+    w_post, w_prior, w_like = oic.lnpost(mod.model_desc(), pars.T.copy(), nthreads=8)
+    assert np.isfinite(w_post).sum() > n // 50
+    fx.assert_close(mod.lnpost(pars), w_post, RTOL, atol=ATOL, what="lnpost")
+    fx.assert_close(mod.lnprior(pars), w_prior, RTOL, atol=ATOL, what="lnprior")
+    fx.assert_close(mod.lnlike(pars), w_like, RTOL, atol=ATOL, what="lnlike")
+    if nb:
+        prim = np.column_stack([pars[:, 0]] + [pars[:, n_stars + j] for j in range(4)]).T.copy()
+        prim[3] = np.abs(prim[3]) + 1.0
+        wT, wg, wf, wm = oic.interp_mag(prim, [ic.bc_grid.interp.column_index[b] for b in bands], nthreads=8)
+        T, g_, f, m = ic.interp_mag(list(prim), list(bands))
+        fx.assert_close(T, wT, RTOL, what="Teff")
+        fx.assert_close(m, wm, RTOL, atol=ATOL, what="mags")
+
+
+def test_size_independent_properties_large_batch():
+    """10^6-sample batch: permutation equivariance, batch-split invariance, and exactness of
+    interpolation on a table whose columns are affine in the coordinates."""
+    import torch
+    rng = np.random.default_rng(7)
+    ic, mod, lo, hi = _random_model("track", 1, ("G",), rng)
+    n = 1_000_000
+    pars = torch.as_tensor(rng.uniform(lo, hi, size=(n, 5)), device="cuda")
+    full = mod.lnpost(pars)
+    perm = torch.randperm(n, device="cuda")
+    assert torch.equal(torch.nan_to_num(mod.lnpost(pars[perm]), nan=7.0), torch.nan_to_num(full[perm], nan=7.0))
+    parts = torch.cat([mod.lnpost(pars[:333_333]), mod.lnpost(pars[333_333:])])
+    assert torch.equal(torch.nan_to_num(parts, nan=7.0), torch.nan_to_num(full, nan=7.0))
+    # affine table: multilinear interpolation must reproduce it to rounding
+    ax = [np.linspace(0, 1, 9), np.sort(rng.uniform(0, 5, 40)), np.arange(1.0, 301.0)]
+    A, B, Cc = np.meshgrid(*ax, indexing="ij")
+    grid = np.stack([2 * A - 3 * B + 0.5 * Cc + 1, A + B + Cc], axis=-1)
+    t = DFInterpolator.from_arrays(grid, ax, ["u", "v"])
+    x = [torch.as_tensor(rng.uniform(a[0], a[-1], n), device="cuda") for a in ax]
+    out = t(x, ["u", "v"])
+    want_u = 2 * x[0] - 3 * x[1] + 0.5 * x[2] + 1
+    assert torch.allclose(out[:, 0], want_u, rtol=0, atol=1e-10)
+    assert torch.allclose(out[:, 1], x[0] + x[1] + x[2], rtol=0, atol=1e-10)
+
+
+def test_errors_are_loud():
+    from isochrones_amd import _cabi
+    k = fx.load("interp_kats")
+    t3 = DFInterpolator.from_arrays(k["t3_grid"], [k["t3_axes0"], k["t3_axes1"], k["t3_axes2"]], ["val"])
+    with pytest.raises(KeyError):
+        t3([1.0, 1.0, 1.0], ["nope"])
+    with pytest.raises(ValueError):
+        DFInterpolator.from_arrays(k["t3_grid"], [k["t3_axes0"][::-1], k["t3_axes1"], k["t3_axes2"]], ["val"])
+    ic = ia.synthetic_track(bands=("V",), fehs=[-1, 0], masses=[0.8, 1.0, 1.2], eeps=np.arange(300., 340.))
+    with pytest.raises(ValueError):
+        ia.BinaryStarModel(ic, V=(10, 0.1))      # multiples need the isochrone parametrisation
+    rc = _cabi.lib().iso_lnpost(None, None, 1, 1, 0, None, None, None, None)
+    assert rc == -1 and b"NULL" in _cabi.lib().iso_last_error()
