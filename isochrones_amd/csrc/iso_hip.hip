@@ -71,6 +71,7 @@ struct iso_ctx {
 };
 
 struct iso_table {
+    int device;
     iso_ctx* ctx;
     int ndim;
     int64_t shape[ISO_MAX_DIM + 1];
@@ -122,6 +123,7 @@ struct DevModel {
 }  // namespace
 
 struct iso_ic {
+    int device;
     iso_ctx* ctx;
     iso_table* model;
     iso_table* bc;
@@ -134,6 +136,7 @@ struct iso_ic {
 };
 
 struct iso_model {
+    int device;          // copied: destroy order of handles is up to the caller / a GC
     iso_ic* ic;
     iso_model_desc desc;
     DevModel* d_model;
@@ -742,7 +745,11 @@ __global__ __launch_bounds__(BLOCK) void k_unit_cube(const DevModel* m, double* 
         const int p = (int)(e - i * np);
         double* c = cube + i * stride_n + p * stride_p;
         const double lo = m->bound_lo[p], hi = m->bound_hi[p];
-        *c = (hi - lo) * *c + lo;
+        {
+#pragma clang fp contract(off)   // unfused: bit-identical to the reference's (hi - lo) * u + lo
+            const double prod = (hi - lo) * *c;
+            *c = prod + lo;
+        }
     }
 }
 
@@ -949,6 +956,7 @@ int iso_table_create(iso_ctx* ctx, int ndim, const int64_t* shape, const double*
     iso_table* t = new (std::nothrow) iso_table();
     if (!t) return fail(ISO_ERR_NOMEM, "iso_table_create: out of host memory");
     t->ctx = ctx;
+    t->device = ctx->device;
     t->ndim = ndim;
     t->ncells = ncells;
     t->d_grid = nullptr;
@@ -979,7 +987,7 @@ int iso_table_create(iso_ctx* ctx, int ndim, const int64_t* shape, const double*
 void iso_table_destroy(iso_table* t)
 {
     if (!t) return;
-    DeviceGuard guard(t->ctx->device);
+    DeviceGuard guard(t->device);
     if (t->d_grid) (void)hipFree(t->d_grid);
     for (int d = 0; d < ISO_MAX_DIM; ++d)
         if (t->d_axes[d]) (void)hipFree(t->d_axes[d]);
@@ -1048,6 +1056,7 @@ int iso_ic_create(iso_ctx* ctx, iso_table* model_grid, iso_table* bc_grid, int k
     iso_ic* ic = new (std::nothrow) iso_ic();
     if (!ic) return fail(ISO_ERR_NOMEM, "iso_ic_create: out of host memory");
     ic->ctx = ctx;
+    ic->device = ctx->device;
     ic->model = model_grid;
     ic->bc = bc_grid;
     ic->kind = kind;
@@ -1096,7 +1105,7 @@ int iso_ic_create(iso_ctx* ctx, iso_table* model_grid, iso_table* bc_grid, int k
 void iso_ic_destroy(iso_ic* ic)
 {
     if (!ic) return;
-    DeviceGuard guard(ic->ctx->device);
+    DeviceGuard guard(ic->device);
     if (ic->d_hot) (void)hipFree(ic->d_hot);
     delete ic;
 }
@@ -1159,6 +1168,7 @@ int iso_model_create(iso_ic* ic, const iso_model_desc* desc, iso_model** out)
     iso_model* m = new (std::nothrow) iso_model();
     if (!m) return fail(ISO_ERR_NOMEM, "iso_model_create: out of host memory");
     m->ic = ic;
+    m->device = ic->device;
     m->desc = *desc;
     m->d_model = nullptr;
     m->d_bc_hot = nullptr;
@@ -1231,7 +1241,7 @@ int iso_model_create(iso_ic* ic, const iso_model_desc* desc, iso_model** out)
 void iso_model_destroy(iso_model* m)
 {
     if (!m) return;
-    DeviceGuard guard(m->ic->ctx->device);
+    DeviceGuard guard(m->device);
     if (m->d_model) (void)hipFree(m->d_model);
     if (m->d_bc_hot) (void)hipFree(m->d_bc_hot);
     delete m;

@@ -90,6 +90,7 @@ class ModelGridInterpolator:
         if eep_bounds is not None:
             self.eep_bounds = tuple(eep_bounds)
         self._handles = {}
+        self._handle_tables = {}
         ci = model_grid.interp.column_index
         missing = [c for c in ("Teff", "logg", "feh", "Mbol") if c not in ci]
         if missing:
@@ -122,23 +123,28 @@ class ModelGridInterpolator:
         """iso_ic* for `device`: both tables uploaded once + packed hot-column table built."""
         if device is None:
             device = dev.current_device()
+        mg = self.model_grid.interp.handle(device)
+        bc = self.bc_grid.interp.handle(device)
         h = self._handles.get(device)
+        if h is not None and self._handle_tables.get(device) != (mg.value, bc.value):
+            _cabi.lib().iso_ic_destroy(h)      # a table was rebuilt (add_column): rebind
+            h = None
         if h is None:
             ctx = dev.context(device)
-            mg = self.model_grid.interp.handle(device)
-            bc = self.bc_grid.interp.handle(device)
-            _, cols = dev.i32_array(self._cols)
-            _, pcols = dev.i32_array(self._prior_cols)
-            _, acols = dev.i32_array(self._astero_cols)
+            keep0, cols = dev.i32_array(self._cols)          # keep the arrays alive across the call
+            keep1, pcols = dev.i32_array(self._prior_cols)
+            keep2, acols = dev.i32_array(self._astero_cols)
             h = C.c_void_p()
             _cabi.check(_cabi.lib().iso_ic_create(ctx, mg, bc, self.kind, cols, pcols, acols, C.byref(h)))
             self._handles[device] = h
+            self._handle_tables[device] = (mg.value, bc.value)
         return h
 
     def release(self):
         for h in self._handles.values():
             _cabi.lib().iso_ic_destroy(h)
         self._handles = {}
+        self._handle_tables = {}
 
     def __del__(self):
         try:
@@ -185,7 +191,7 @@ class ModelGridInterpolator:
         mags.interp_mags)."""
         bands = list(bands) if bands else []
         if dev.is_tensor(pars) and pars.is_cuda:
-            p = pars.to(dtype=pars.dtype).double()
+            p = pars.double()
             if p.dim() == 1:
                 p = p[:, None]
             return self.interp_mag_device(p.contiguous(), bands)

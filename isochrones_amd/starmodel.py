@@ -189,19 +189,25 @@ class BasicStarModel:
         for h in getattr(self, "_handles", {}).values():
             _cabi.lib().iso_model_destroy(h)
         self._handles = {}
+        self._handle_ic = {}
 
     def handle(self, device=None):
         if device is None:
             device = dev.current_device()
+        ich = self.ic.handle(device)
         h = self._handles.get(device)
+        if h is not None and self._handle_ic.get(device) != ich.value:
+            _cabi.lib().iso_model_destroy(h)   # the interpolator was rebound: rebuild
+            h = None
         if h is None:
             if -1 in self.ic._prior_cols:
                 raise ValueError("model table lacks the (%s, d%s_deep) columns the EEP prior needs"
                                  % (self.ic.eep_replaces, "t" if self.ic.eep_replaces == "age" else "m"))
             desc = self.model_desc()
             h = C.c_void_p()
-            _cabi.check(_cabi.lib().iso_model_create(self.ic.handle(device), C.byref(desc), C.byref(h)))
+            _cabi.check(_cabi.lib().iso_model_create(ich, C.byref(desc), C.byref(h)))
             self._handles[device] = h
+            self._handle_ic[device] = ich.value
         return h
 
     def __del__(self):
