@@ -96,8 +96,12 @@ def main():
     ap.add_argument("--n", type=int, default=1_000_000)
     ap.add_argument("--workload", default="prior", choices=["prior", "posterior"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--path", default=None, choices=["auto", "compact", "generic"],
+                    help="kernel/table-layout selection (default: library default = auto)")
     args = ap.parse_args()
 
+    if args.path:
+        os.environ["ISOCHRONES_AMD_PATH"] = args.path
     import torch
     import ctypes as C
     from isochrones_amd import _cabi, device as dev
@@ -181,7 +185,8 @@ def main():
                                "synthetic MIST-shaped tables [15,196,1710,18]+[70,26,18,13,1], %d-sample "
                                "lnpost batch per GPU, samples '%s', fused interp+prior+likelihood kernel"
                                % (args.n, args.workload),
-                   "samples": args.workload, "batch": args.n, "parallelism": "independent stars per GPU"},
+                   "samples": args.workload, "batch": args.n, "parallelism": "independent stars per GPU",
+                   "kernel_path": os.environ.get("ISOCHRONES_AMD_PATH", "auto")},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel_ms": kernel_ms, "bytes_per_eval": BYTES_PER_EVAL_SINGLE_1BAND},

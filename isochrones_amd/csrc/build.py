@@ -1,15 +1,25 @@
-"""Build libiso_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+"""Build libiso_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+The translation units are compiled in parallel and linked into one shared library."""
 from __future__ import annotations
 
+import glob
 import os
 import shutil
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = os.path.join(HERE, "iso_hip.hip")
 OUT = os.path.join(HERE, "libiso_hip.so")
-HEADER = os.path.join(HERE, "..", "..", "include", "isochrones_amd.h")
+OBJDIR = os.path.join(HERE, "build")
+HEADERS = [os.path.join(HERE, "..", "..", "include", "isochrones_amd.h"),
+           os.path.join(HERE, "iso_internal.h"), os.path.join(HERE, "iso_fast_kernel.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math", "-Wall",
+         "-Wno-unused-function"]
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(HERE, "*.hip")))
 
 
 def hipcc() -> str:
@@ -19,22 +29,32 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found")
 
 
-def up_to_date() -> bool:
-    if not os.path.exists(OUT):
-        return False
-    t = os.path.getmtime(OUT)
-    return all(os.path.getmtime(f) <= t for f in (SRC, HEADER, os.path.abspath(__file__)))
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and up_to_date():
-        return OUT
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-fno-fast-math", "-fgpu-rdc" if False else "-Wall", "-Wno-unused-function",
-           "-o", OUT, SRC]
-    if verbose:
-        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-    subprocess.check_call(cmd, cwd=HERE)
+    os.makedirs(OBJDIR, exist_ok=True)
+    cc = hipcc()
+    me = os.path.abspath(__file__)
+    jobs = []
+    objs = []
+    for src in sources():
+        obj = os.path.join(OBJDIR, os.path.basename(src)[:-4] + ".o")
+        objs.append(obj)
+        if force or _newer(obj, [src, me] + HEADERS):
+            cmd = [cc] + FLAGS + (["-Rpass-analysis=kernel-resource-usage"] if verbose else []) + ["-c", src, "-o", obj]
+            jobs.append(cmd)
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 2)) as ex:
+            for rc in ex.map(lambda c: subprocess.run(c, cwd=HERE).returncode, jobs):
+                if rc != 0:
+                    raise RuntimeError("hipcc failed")
+    if force or jobs or _newer(OUT, objs):
+        subprocess.check_call([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs, cwd=HERE)
     return OUT
 
 

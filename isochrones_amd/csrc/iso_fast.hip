@@ -1,0 +1,17 @@
+// Dispatcher of the fast fused lnpost kernels (instantiated in iso_fast_{track1,iso1,iso2,iso3}.hip).
+#include "iso_fast_kernel.h"
+
+namespace iso {
+
+bool launch_lnpost_fast(int kind, int n_stars, int n_bands, bool packed, const FastArgs& A, hipStream_t s)
+{
+    if (kind == ISO_KIND_TRACK) return n_stars == 1 && launch_fast_track1(n_bands, packed, A, s);
+    switch (n_stars) {
+    case 1: return launch_fast_iso1(n_bands, packed, A, s);
+    case 2: return launch_fast_iso2(n_bands, packed, A, s);
+    case 3: return launch_fast_iso3(n_bands, packed, A, s);
+    }
+    return false;
+}
+
+}  // namespace iso

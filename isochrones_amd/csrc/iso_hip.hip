@@ -25,25 +25,30 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
 #include <vector>
 
-#include "../../include/isochrones_amd.h"
-
 // ======================================================================================
 // host-side bookkeeping
 // ======================================================================================
+#include "iso_internal.h"
+
+using namespace iso;
+
 namespace {
-
 thread_local std::string g_err;
+}
 
+namespace iso {
 int fail(int code, const std::string& msg)
 {
     g_err = msg;
     return code;
 }
+}  // namespace iso
 
 #define HIP_TRY(expr)                                                                         \
     do {                                                                                      \
@@ -51,98 +56,6 @@ int fail(int code, const std::string& msg)
         if (e_ != hipSuccess)                                                                 \
             return fail(ISO_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));      \
     } while (0)
-
-constexpr int BLOCK = 256;
-constexpr int MAX_LDS_AXIS_DOUBLES = 6144;   // 48 KiB of staged axes at most
-constexpr int HOT_COLS = 8;                  // Teff logg feh Mbol prior_val prior_deriv nu_max delta_nu
-
-struct AxisD {
-    const double* g;   // device copy
-    int n;
-    int lds_off;       // offset (doubles) into the workgroup's LDS staging area, -1 = not staged
-    int uniform;       // 1: a_i == a0 + i*step exactly (with and without FMA)
-    double a0, step;
-};
-
-}  // namespace
-
-struct iso_ctx {
-    int device;
-};
-
-struct iso_table {
-    int device;
-    iso_ctx* ctx;
-    int ndim;
-    int64_t shape[ISO_MAX_DIM + 1];
-    int64_t ncells;
-    double* d_grid;
-    double* d_axes[ISO_MAX_DIM];
-    std::vector<double> h_axes[ISO_MAX_DIM];
-    AxisD ax[ISO_MAX_DIM];
-};
-
-namespace {
-
-struct Grid3V {           // packed hot-column model table
-    AxisD ax[3];
-    const double* hot;    // [n0][n1][n2][HOT_COLS]
-    int64_t s0, s1;       // cell strides of axes 0, 1 (axis 2 stride = 1)
-};
-
-struct Grid4V {           // BC table (all columns, or packed to the model's bands)
-    AxisD ax[4];
-    const double* tab;    // [nT][ng][nf][nA][ncol]
-    int ncol;
-    int64_t s0, s1, s2;   // cell strides of axes 0..2 (axis 3 stride = 1)
-};
-
-// ---- device-side prior record with everything constant pre-evaluated on the host ----------
-struct DevPrior {
-    int kind, bounded;
-    double lo, hi;
-    double a, b, c, d, e, f, g, h;
-    double k0, k1, k2, k3, k4, k5;
-};
-
-struct DevModel {
-    int n_stars, n_bands, kind;
-    int has_parallax, has_numax, has_dnu;
-    double mag_val[ISO_MAX_BANDS];
-    double mag_g0[ISO_MAX_BANDS];    // log(1/sqrt(2 pi)) + log(unc)
-    double mag_unc2[ISO_MAX_BANDS];  // unc*unc
-    double spec_val[3], spec_g0[3], spec_unc2[3];
-    double plx_val, plx_g0, plx_unc2;
-    double numax_val, numax_g0, numax_unc2;
-    double dnu_val, dnu_g0, dnu_unc2;
-    DevPrior prior_mass, prior_age, prior_feh, prior_distance, prior_AV;
-    double eep_lo, eep_hi;
-    double bound_lo[ISO_MAX_PARAMS], bound_hi[ISO_MAX_PARAMS];
-};
-
-}  // namespace
-
-struct iso_ic {
-    int device;
-    iso_ctx* ctx;
-    iso_table* model;
-    iso_table* bc;
-    int kind;
-    int32_t cols[4], prior_cols[2], astero_cols[2];
-    double* d_hot;
-    Grid3V g3;
-    Grid4V g4;           // full BC table view
-    int lds_doubles;     // LDS staging size for model + BC axes
-};
-
-struct iso_model {
-    int device;          // copied: destroy order of handles is up to the caller / a GC
-    iso_ic* ic;
-    iso_model_desc desc;
-    DevModel* d_model;
-    double* d_bc_hot;    // BC table restricted to the model's bands, [..][nb]
-    Grid4V g4;           // view of d_bc_hot
-};
 
 // ======================================================================================
 // device code
@@ -790,6 +703,38 @@ __global__ __launch_bounds__(BLOCK) void k_pack_bc(const PackBcArgs A)
     }
 }
 
+struct PackCornersArgs {
+    const double* src;      // compact table, `ncol` doubles per cell
+    int ncol, keep;         // keep the first `keep` columns of every corner
+    int ndim;               // 3 or 4
+    int64_t n[4];           // axis lengths
+    int64_t ncells;
+    double* out;            // [cell][2^ndim corners][keep]
+};
+
+// corner-packed layout: every cell carries its own 2^D corners (corner order = reference order)
+__global__ __launch_bounds__(BLOCK) void k_pack_corners(const PackCornersArgs A)
+{
+    const int nc = 1 << A.ndim;
+    const int64_t per = (int64_t)nc * A.keep;
+    const int64_t total = A.ncells * per;
+    for (int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x; e < total; e += (int64_t)gridDim.x * BLOCK) {
+        const int64_t cell = e / per;
+        const int r = (int)(e - cell * per);
+        const int j = r / A.keep, q = r - j * A.keep;
+        int64_t rem = cell, src_cell = 0, mul = 1;
+        for (int d = A.ndim - 1; d >= 0; --d) {
+            int64_t id = rem % A.n[d];
+            rem /= A.n[d];
+            const int bit = (j >> (A.ndim - 1 - d)) & 1;
+            id = min(id + bit, A.n[d] - 1);      // edge cells are never addressed (i <= n-2)
+            src_cell += id * mul;
+            mul *= A.n[d];
+        }
+        A.out[e] = A.src[src_cell * A.ncol + q];
+    }
+}
+
 // ======================================================================================
 // host helpers
 // ======================================================================================
@@ -869,9 +814,11 @@ DevPrior make_dev_prior(const iso_prior& P)
     switch (P.kind) {
     case ISO_PRIOR_FLAT:
         D.k0 = 1.0 / (P.hi - P.lo);
+        D.k1 = std::log(D.k0);
         break;
     case ISO_PRIOR_FLATLOG:
         D.k0 = std::pow(10.0, P.hi) - std::pow(10.0, P.lo);
+        D.k1 = std::log(std::log(10.0) / D.k0);
         break;
     case ISO_PRIOR_POWERLAW:
         D.k0 = host_powerlaw_C(P.a, P.lo, P.hi);
@@ -880,10 +827,13 @@ DevPrior make_dev_prior(const iso_prior& P)
     case ISO_PRIOR_GAUSS:
         D.k0 = std::exp(P.c);
         D.k1 = std::log(P.b);
+        D.r0 = 1.0 / P.b;
         break;
     case ISO_PRIOR_LOGNORMAL:
         D.k0 = std::exp(P.a);
         D.k1 = std::log(P.b);
+        D.r0 = 1.0 / D.k0;
+        D.r1 = 1.0 / P.b;
         break;
     case ISO_PRIOR_CHABRIER:
         D.k0 = std::exp(P.a);
@@ -892,9 +842,12 @@ DevPrior make_dev_prior(const iso_prior& P)
         D.k3 = std::log(P.e);
         D.k4 = std::log(P.f);
         D.k5 = std::log(D.k2);
+        D.r0 = 1.0 / D.k0;
+        D.r1 = 1.0 / P.b;
         break;
     case ISO_PRIOR_FEH:
         D.k0 = 1.0 / std::sqrt(2 * M_PI * 0.4 * 0.4);
+        D.r0 = 1.0 / P.b;
         break;
     }
     return D;
@@ -902,10 +855,53 @@ DevPrior make_dev_prior(const iso_prior& P)
 
 bool prior_kind_ok(int k) { return k >= ISO_PRIOR_FLAT && k <= ISO_PRIOR_FEH; }
 
-void gauss_consts(double unc, double& g0, double& unc2)
+void gauss_consts(double unc, double& g0, double& unc2, double* hinv = nullptr)
 {
     g0 = std::log(1.0 / std::sqrt(2 * M_PI)) + std::log(unc);
     unc2 = unc * unc;
+    if (hinv) *hinv = 0.5 / unc2;
+}
+
+// "auto" (default): fast kernel on corner-packed tables when eligible; "compact": fast kernel on
+// the compact tables; "generic": always the generic kernel.  For A/B measurements and tests.
+enum PathMode { PATH_AUTO = 0, PATH_COMPACT = 1, PATH_GENERIC = 2 };
+
+PathMode path_mode()
+{
+    const char* e = std::getenv("ISOCHRONES_AMD_PATH");
+    if (!e) return PATH_AUTO;
+    if (!std::strcmp(e, "generic")) return PATH_GENERIC;
+    if (!std::strcmp(e, "compact")) return PATH_COMPACT;
+    return PATH_AUTO;
+}
+
+constexpr int FAST_MAX_BLOB = 4096;   // doubles (32 KiB of LDS) the fast kernel may stage
+
+hipError_t pack_corners(const double* src, int ncol, int keep, int ndim, const int64_t* n, double** out)
+{
+    PackCornersArgs P;
+    P.src = src;
+    P.ncol = ncol;
+    P.keep = keep;
+    P.ndim = ndim;
+    P.ncells = 1;
+    for (int d = 0; d < 4; ++d) P.n[d] = 1;
+    for (int d = 0; d < ndim; ++d) {
+        P.n[d] = n[d];
+        P.ncells *= n[d];
+    }
+    const size_t bytes = (size_t)P.ncells * (size_t)(1 << ndim) * keep * sizeof(double);
+    hipError_t e = hipMalloc(out, bytes);
+    if (e != hipSuccess) return e;
+    P.out = *out;
+    hipLaunchKernelGGL(k_pack_corners, dim3(grid_blocks(P.ncells * (1 << ndim) * keep)), dim3(BLOCK), 0, 0, P);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) {
+        (void)hipFree(*out);
+        *out = nullptr;
+    }
+    return e;
 }
 
 }  // namespace
@@ -1098,6 +1094,17 @@ int iso_ic_create(iso_ctx* ctx, iso_table* model_grid, iso_table* bc_grid, int k
     ic->g4.s1 = bc_grid->shape[2] * bc_grid->shape[3];
     ic->g4.s0 = bc_grid->shape[1] * bc_grid->shape[2] * bc_grid->shape[3];
     ic->lds_doubles = assign_lds(ic->g3.ax, 3, ic->g4.ax, 4);
+    for (int d = 0; d < 3; ++d) ic->h_axes_model[d] = model_grid->h_axes[d];
+    for (int d = 0; d < 4; ++d) ic->h_axes_bc[d] = bc_grid->h_axes[d];
+    ic->d_hotq = nullptr;
+    if (path_mode() == PATH_AUTO && model_grid->ax[2].uniform) {
+        // corner-packed copy for the fast kernel: 8 corners x 6 columns per cell (384 B)
+        e = pack_corners(ic->d_hot, HOT_COLS, PACK_COLS, 3, model_grid->shape, &ic->d_hotq);
+        if (e != hipSuccess) {
+            ic->d_hotq = nullptr;      // not fatal: the compact table serves the fast kernel too
+            (void)hipGetLastError();
+        }
+    }
     *out = ic;
     return ISO_OK;
 }
@@ -1107,6 +1114,7 @@ void iso_ic_destroy(iso_ic* ic)
     if (!ic) return;
     DeviceGuard guard(ic->device);
     if (ic->d_hot) (void)hipFree(ic->d_hot);
+    if (ic->d_hotq) (void)hipFree(ic->d_hotq);
     delete ic;
 }
 
@@ -1172,6 +1180,9 @@ int iso_model_create(iso_ic* ic, const iso_model_desc* desc, iso_model** out)
     m->desc = *desc;
     m->d_model = nullptr;
     m->d_bc_hot = nullptr;
+    m->d_bcq = nullptr;
+    m->d_axes_blob = nullptr;
+    m->fast_ok = false;
 
     DevModel H;
     std::memset(&H, 0, sizeof(H));
@@ -1183,14 +1194,14 @@ int iso_model_create(iso_ic* ic, const iso_model_desc* desc, iso_model** out)
     H.has_dnu = desc->has_numax ? desc->has_dnu : 0;
     for (int b = 0; b < desc->n_bands; ++b) {
         H.mag_val[b] = desc->mag_val[b];
-        gauss_consts(desc->mag_unc[b], H.mag_g0[b], H.mag_unc2[b]);
+        gauss_consts(desc->mag_unc[b], H.mag_g0[b], H.mag_unc2[b], &H.mag_hinv[b]);
     }
     for (int q = 0; q < 3; ++q) {
         H.spec_val[q] = desc->spec_val[q];
-        gauss_consts(desc->spec_unc[q], H.spec_g0[q], H.spec_unc2[q]);
+        gauss_consts(desc->spec_unc[q], H.spec_g0[q], H.spec_unc2[q], &H.spec_hinv[q]);
     }
     H.plx_val = desc->plx_val;
-    gauss_consts(desc->plx_unc, H.plx_g0, H.plx_unc2);
+    gauss_consts(desc->plx_unc, H.plx_g0, H.plx_unc2, &H.plx_hinv);
     H.numax_val = desc->numax_val;
     gauss_consts(desc->numax_unc, H.numax_g0, H.numax_unc2);
     H.dnu_val = desc->dnu_val;
@@ -1229,6 +1240,55 @@ int iso_model_create(iso_ic* ic, const iso_model_desc* desc, iso_model** out)
             m->g4.ncol = desc->n_bands;
         }
     }
+    // ---- fast path: eligibility, staged axes (+ reciprocal spacings), corner-packed BC ----
+    const PathMode mode = path_mode();
+    if (e == hipSuccess && mode != PATH_GENERIC && desc->n_bands >= 1 && desc->n_bands <= 8 && !desc->has_numax &&
+        ic->model->ax[2].uniform) {
+        std::vector<double> blob;
+        FastAxis fa[6];
+        const std::vector<double>* src[6] = {&ic->h_axes_model[0], &ic->h_axes_model[1], &ic->h_axes_bc[0],
+                                             &ic->h_axes_bc[1], &ic->h_axes_bc[2], &ic->h_axes_bc[3]};
+        for (int a = 0; a < 6; ++a) {
+            const std::vector<double>& v = *src[a];
+            fa[a].off = (int)blob.size();
+            fa[a].n = (int)v.size();
+            blob.insert(blob.end(), v.begin(), v.end());
+            for (size_t j = 0; j + 1 < v.size(); ++j) blob.push_back(1.0 / (v[j + 1] - v[j]));
+            blob.push_back(0.0);
+        }
+        if ((int)blob.size() <= FAST_MAX_BLOB) {
+            e = hipMalloc(&m->d_axes_blob, blob.size() * sizeof(double));
+            if (e == hipSuccess)
+                e = hipMemcpy(m->d_axes_blob, blob.data(), blob.size() * sizeof(double), hipMemcpyHostToDevice);
+            if (e == hipSuccess && mode == PATH_AUTO && ic->d_hotq) {
+                hipError_t e2 = pack_corners(m->d_bc_hot, desc->n_bands, desc->n_bands, 4, ic->bc->shape, &m->d_bcq);
+                if (e2 != hipSuccess) {
+                    m->d_bcq = nullptr;
+                    (void)hipGetLastError();
+                }
+            }
+            if (e == hipSuccess) {
+                FastArgs& F = m->fast;
+                std::memset(&F, 0, sizeof(F));
+                F.m0 = fa[0]; F.m1 = fa[1];
+                F.b0 = fa[2]; F.b1 = fa[3]; F.b2 = fa[4]; F.b3 = fa[5];
+                F.e_a0 = ic->model->ax[2].a0;
+                F.e_step = ic->model->ax[2].step;
+                F.e_inv = 1.0 / F.e_step;
+                F.e_n = ic->model->ax[2].n;
+                F.axes_blob = m->d_axes_blob;
+                F.axes_len = (int)blob.size();
+                F.hot = ic->d_hot;
+                F.hotq = ic->d_hotq;
+                F.s0 = ic->g3.s0; F.s1 = ic->g3.s1;
+                F.bc = m->d_bc_hot;
+                F.bcq = m->d_bcq;
+                F.bs0 = m->g4.s0; F.bs1 = m->g4.s1; F.bs2 = m->g4.s2;
+                F.m = m->d_model;
+                m->fast_ok = true;
+            }
+        }
+    }
     if (e != hipSuccess) {
         std::string msg = std::string("iso_model_create: ") + hipGetErrorString(e);
         iso_model_destroy(m);
@@ -1244,6 +1304,8 @@ void iso_model_destroy(iso_model* m)
     DeviceGuard guard(m->device);
     if (m->d_model) (void)hipFree(m->d_model);
     if (m->d_bc_hot) (void)hipFree(m->d_bc_hot);
+    if (m->d_bcq) (void)hipFree(m->d_bcq);
+    if (m->d_axes_blob) (void)hipFree(m->d_axes_blob);
     delete m;
 }
 
@@ -1287,6 +1349,20 @@ void launch_lnpost(const iso_model* m, dim3 g, dim3 b, size_t shmem, hipStream_t
 int enqueue_lnpost(iso_model* m, const double* pars, int64_t stride_n, int64_t stride_p, int64_t n,
                    double* lnpost_out, double* lnprior_out, double* lnlike_out, hipStream_t s)
 {
+    if (m->fast_ok && !lnprior_out && !lnlike_out && lnpost_out) {
+        FastArgs F = m->fast;
+        F.pars = pars;
+        F.stride_n = stride_n;
+        F.stride_p = stride_p;
+        F.n = n;
+        F.lnpost = lnpost_out;
+        const bool packed = F.hotq != nullptr && F.bcq != nullptr;
+        if (launch_lnpost_fast(m->ic->kind, m->desc.n_stars, m->desc.n_bands, packed, F, s)) {
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return fail(ISO_ERR_HIP, std::string("iso_lnpost (fast) launch: ") + hipGetErrorString(e));
+            return ISO_OK;
+        }
+    }
     PostArgs A;
     A.g3 = m->ic->g3;
     A.g4 = m->g4;

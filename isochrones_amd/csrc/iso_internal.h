@@ -1,0 +1,144 @@
+// Internal definitions shared by the translation units of libiso_hip (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/isochrones_amd.h"
+
+namespace iso {
+
+int fail(int code, const std::string& msg);   // sets the thread-local error string
+
+constexpr int BLOCK = 256;
+constexpr int MAX_LDS_AXIS_DOUBLES = 6144;   // 48 KiB of staged axes at most
+constexpr int HOT_COLS = 8;                  // Teff logg feh Mbol prior_val prior_deriv nu_max delta_nu
+constexpr int PACK_COLS = 6;                 // columns kept in the corner-packed table
+constexpr int PACK_ENTRY = 8 * PACK_COLS;    // doubles per corner-packed cell (8 corners x 6 columns = 384 B)
+
+struct AxisD {
+    const double* g;   // device copy
+    int n;
+    int lds_off;       // offset (doubles) into the workgroup's LDS staging area, -1 = not staged
+    int uniform;       // 1: a_i == a0 + i*step exactly (with and without FMA)
+    double a0, step;
+};
+
+struct Grid3V {           // packed hot-column model table
+    AxisD ax[3];
+    const double* hot;    // [n0][n1][n2][HOT_COLS]
+    int64_t s0, s1;       // cell strides of axes 0, 1 (axis 2 stride = 1)
+};
+
+struct Grid4V {           // BC table (all columns, or packed to the model's bands)
+    AxisD ax[4];
+    const double* tab;    // [nT][ng][nf][nA][ncol]
+    int ncol;
+    int64_t s0, s1, s2;   // cell strides of axes 0..2 (axis 3 stride = 1)
+};
+
+// device-side prior record with everything constant pre-evaluated on the host
+struct DevPrior {
+    int kind, bounded;
+    double lo, hi;
+    double a, b, c, d, e, f, g, h;
+    double k0, k1, k2, k3, k4, k5;
+    double r0, r1, r2;    // reciprocals / log-constants used by the fast kernels
+};
+
+struct DevModel {
+    int n_stars, n_bands, kind;
+    int has_parallax, has_numax, has_dnu;
+    double mag_val[ISO_MAX_BANDS];
+    double mag_g0[ISO_MAX_BANDS];    // log(1/sqrt(2 pi)) + log(unc)
+    double mag_unc2[ISO_MAX_BANDS];  // unc*unc
+    double mag_hinv[ISO_MAX_BANDS];  // 0.5/(unc*unc)
+    double spec_val[3], spec_g0[3], spec_unc2[3], spec_hinv[3];
+    double plx_val, plx_g0, plx_unc2, plx_hinv;
+    double numax_val, numax_g0, numax_unc2;
+    double dnu_val, dnu_g0, dnu_unc2;
+    DevPrior prior_mass, prior_age, prior_feh, prior_distance, prior_AV;
+    double eep_lo, eep_hi;
+    double bound_lo[ISO_MAX_PARAMS], bound_hi[ISO_MAX_PARAMS];
+};
+
+// ---- fast-path descriptors ------------------------------------------------------------------
+struct FastAxis {
+    int off;   // LDS offset (doubles): values at [off, off+n), reciprocal spacings at [off+n, off+2n-1)
+    int n;
+};
+
+struct FastArgs {
+    FastAxis m0, m1;                 // model axes 0 and 1 (bisection in LDS)
+    double e_a0, e_step, e_inv;      // model axis 2 = EEP: exactly uniform, O(1) index
+    int e_n;
+    FastAxis b0, b1, b2, b3;         // BC axes
+    const double* axes_blob;         // [values | 1/spacing] of the six LDS axes, concatenated
+    int axes_len;                    // doubles
+    const double* hot;               // compact hot table [n0][n1][n2][HOT_COLS]
+    const double* hotq;              // corner-packed [n0][n1][n2][8 corners][PACK_COLS] (or null)
+    int64_t s0, s1;
+    const double* bc;                // BC restricted to the model's bands [..][nb]
+    const double* bcq;               // corner-packed BC [cells][16 corners][nb] (or null)
+    int64_t bs0, bs1, bs2;
+    const DevModel* m;
+    const double* pars;
+    int64_t stride_n, stride_p, n;
+    double* lnpost;
+};
+
+}  // namespace iso
+
+struct iso_ctx {
+    int device;
+};
+
+struct iso_table {
+    int device;
+    iso_ctx* ctx;
+    int ndim;
+    int64_t shape[ISO_MAX_DIM + 1];
+    int64_t ncells;
+    double* d_grid;
+    double* d_axes[ISO_MAX_DIM];
+    std::vector<double> h_axes[ISO_MAX_DIM];
+    iso::AxisD ax[ISO_MAX_DIM];
+};
+
+struct iso_ic {
+    int device;
+    iso_ctx* ctx;
+    iso_table* model;
+    iso_table* bc;
+    int kind;
+    int32_t cols[4], prior_cols[2], astero_cols[2];
+    double* d_hot;
+    double* d_hotq;          // corner-packed model table (fast path), may be null
+    iso::Grid3V g3;
+    iso::Grid4V g4;          // full BC table view
+    int lds_doubles;         // LDS staging size for model + BC axes (generic kernels)
+    std::vector<double> h_axes_model[3], h_axes_bc[4];
+};
+
+struct iso_model {
+    int device;              // copied: destroy order of handles is up to the caller / a GC
+    iso_ic* ic;
+    iso_model_desc desc;
+    iso::DevModel* d_model;
+    double* d_bc_hot;        // BC table restricted to the model's bands, [..][nb]
+    double* d_bcq;           // corner-packed BC for the model's bands, may be null
+    double* d_axes_blob;     // fast path: staged axes
+    iso::Grid4V g4;          // view of d_bc_hot
+    bool fast_ok;
+    iso::FastArgs fast;      // template filled at create time (pars/outputs set per call)
+};
+
+namespace iso {
+// defined in iso_fast_*.hip: launch the specialised fused kernel; returns false if no
+// specialisation exists for (kind, n_stars, n_bands)
+bool launch_lnpost_fast(int kind, int n_stars, int n_bands, bool packed, const FastArgs& A, hipStream_t s);
+}  // namespace iso

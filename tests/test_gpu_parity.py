@@ -66,8 +66,17 @@ def test_dfinterpolator_from_dataframe_ragged():
     assert np.allclose(dm([1.3, 2.2]), [3.5, 2.86, 2.14], atol=1e-12)
 
 
+@pytest.fixture(params=["auto", "compact", "generic"])
+def kernel_path(request, monkeypatch):
+    """lnpost kernel selection (read by libiso_hip when an interpolator / model is created):
+    auto = fast kernel on corner-packed tables, compact = fast kernel on compact tables,
+    generic = the generic kernel.  Every path must meet the same parity bar."""
+    monkeypatch.setenv("ISOCHRONES_AMD_PATH", request.param)
+    return request.param
+
+
 @pytest.mark.parametrize("case", fx.MODEL_CASES)
-def test_model_case_vs_reference_golden(case):
+def test_model_case_vs_reference_golden(case, kernel_path):
     g = fx.load(case)
     meta = g["meta"]
     ic = fx.make_ic(meta)
@@ -141,7 +150,7 @@ def _random_model(kind, n_stars, bands, rng):
 
 @pytest.mark.parametrize("kind,n_stars,nb", [("track", 1, 1), ("track", 1, 3), ("iso", 1, 1), ("iso", 2, 6),
                                              ("iso", 3, 2), ("iso", 2, 11), ("iso", 1, 0)])
-def test_random_batch_vs_oracle(kind, n_stars, nb):
+def test_random_batch_vs_oracle(kind, n_stars, nb, kernel_path):
     """Mid-size tables, 2e5 seeded samples, every kernel specialisation (nb 0..8 compile-time,
     >8 runtime loop) against the CPU oracle."""
     rng = np.random.default_rng(1000 + 10 * n_stars + nb)
