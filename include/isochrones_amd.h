@@ -16,6 +16,7 @@
  *                       isochrones/starmodel.py:538-542,1563-1635; isochrones/likelihood.py:16-147;
  *                       isochrones/priors.py (default prior lnpdf's)
  *   iso_unit_cube    <- BasicStarModel.mnest_prior                  isochrones/starmodel.py:1637-1640
+ *   iso_catalog_*    <- StarCatalog.iter_models + one lnpost per star  isochrones/catalog.py:126-139
  *
  * Conventions
  *   - All sample buffers (x, pars, outputs) are DEVICE pointers (HIP, the ctx's device); table
@@ -102,6 +103,7 @@ typedef struct iso_ctx   iso_ctx;
 typedef struct iso_table iso_table;   /* dense N-D table + axes, resident in HBM */
 typedef struct iso_ic    iso_ic;      /* model table + BC table + column binding */
 typedef struct iso_model iso_model;   /* iso_ic + iso_model_desc */
+typedef struct iso_catalog iso_catalog; /* iso_ic + many iso_model_desc sharing bands/multiplicity */
 
 const char* iso_last_error(void);
 const char* iso_version(void);
@@ -149,6 +151,15 @@ int  iso_lnpost(iso_model* m, const double* pars, int64_t stride_n, int64_t stri
 
 /* mnest_prior: cube[i,p] <- lo_p + (hi_p - lo_p) * cube[i,p], in place (starmodel.py:1637-1640). */
 int  iso_unit_cube(iso_model* m, double* cube, int64_t stride_n, int64_t stride_p, int64_t n, void* stream);
+
+/* A catalog = many independent systems observed in the same bands with the same multiplicity
+ * (reference: isochrones/catalog.py:19-139 StarCatalog.iter_models; scripts/batch_starfit shards
+ * them over processes).  iso_catalog_lnpost evaluates a batch of rows where row i belongs to
+ * star star_id[i] (DEVICE int32 array): S stars x W walkers in one launch.  Needs 1-8 bands. */
+int  iso_catalog_create(iso_ic* ic, const iso_model_desc* descs, int64_t n_models, iso_catalog** out);
+void iso_catalog_destroy(iso_catalog* c);
+int  iso_catalog_lnpost(iso_catalog* c, const int32_t* star_id, const double* pars, int64_t stride_n,
+                        int64_t stride_p, int64_t n, double* lnpost_out, void* stream);
 
 /* Time `reps` back-to-back iso_lnpost launches with hipEvents on `stream`; returns the mean
  * milliseconds per launch in *ms_per_launch (measurement helper for bench.py). */

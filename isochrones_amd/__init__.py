@@ -7,6 +7,8 @@ from .interp import DFInterpolator
 from .models import (ModelGridInterpolator, EvolutionTrackInterpolator, IsochroneInterpolator,
                      synthetic_track, synthetic_isochrone, get_ichrone)
 from .starmodel import (BasicStarModel, StarModel, SingleStarModel, BinaryStarModel, TripleStarModel)
+from .sampler import EnsembleSampler
+from .catalog import StarCatalog, CatalogPosterior, fit_catalog, synthetic_catalog, shard_of, shard_indices
 from . import priors, grids
 
 __version__ = "0.1.0"

@@ -66,6 +66,7 @@ EXPORTED_SYMBOLS = (
     "iso_ic_create", "iso_ic_destroy", "iso_interp_mag",
     "iso_model_create", "iso_model_destroy", "iso_model_n_params",
     "iso_lnpost", "iso_unit_cube", "iso_time_lnpost",
+    "iso_catalog_create", "iso_catalog_destroy", "iso_catalog_lnpost",
 )
 
 _LIB = None
@@ -125,6 +126,10 @@ def lib():
     L.iso_lnpost.argtypes = [vp, pd, i64, i64, i64, pd, pd, pd, vp]
     L.iso_unit_cube.argtypes = [vp, pd, i64, i64, i64, vp]
     L.iso_time_lnpost.argtypes = [vp, pd, i64, i64, i64, pd, C.c_int, vp, C.POINTER(dbl)]
+    L.iso_catalog_create.argtypes = [vp, C.POINTER(IsoModelDesc), i64, C.POINTER(vp)]
+    L.iso_catalog_destroy.argtypes = [vp]
+    L.iso_catalog_destroy.restype = None
+    L.iso_catalog_lnpost.argtypes = [vp, pd, pd, i64, i64, i64, pd, vp]
     for name in EXPORTED_SYMBOLS:
         fn = getattr(L, name)
         if fn.restype is C.c_int:

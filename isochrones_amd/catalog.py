@@ -1,0 +1,356 @@
+"""Catalog path: many independent stars, sharded over the GPUs of a node.
+
+Reference semantics being reproduced:
+
+* ``StarCatalog`` (isochrones/catalog.py:19-139): a DataFrame with ``{band}_mag``,
+  ``{band}_mag_unc`` and ``{prop}``, ``{prop}_unc`` columns; ``iter_models(ic, N)`` yields one
+  Single/Binary/TripleStarModel per row.
+* ``scripts/batch_starfit:60-62``: line NR of the star list goes to worker ``NR % NPROCS``
+  (NR is 1-based), workers never talk to each other, results are per-star.
+
+Here one process drives one GPU (``torch.distributed``, backend ``nccl`` = RCCL on ROCm, ``gloo``
+in the CPU tests).  Every rank builds the posteriors of *its* stars only and samples all of them
+in lock-step: S stars x W walkers are one ``iso_catalog_lnpost`` launch per half-step (each row
+carries its star's index).  There is no collective inside the sampling loop; the only exchange
+is one all-gather of fixed-size per-star result rows at the end.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import re
+
+import numpy as np
+
+from . import _cabi, device as dev
+from .starmodel import BasicStarModel
+
+
+def shard_of(i: int, world: int) -> int:
+    """Worker that owns star ``i`` (0-based): batch_starfit's ``NR % NPROCS`` with NR = i + 1."""
+    return (i + 1) % world
+
+
+def shard_indices(n: int, rank: int, world: int) -> np.ndarray:
+    idx = np.arange(n)
+    return idx[(idx + 1) % world == rank]
+
+
+class StarCatalog:
+    def __init__(self, df, bands=None, props=None, no_uncs=False):
+        self.df = df
+        if bands is None:
+            bands = [m.group(1) for m in (re.search("(.+)_mag$", c) for c in df.columns) if m]
+        self.bands = tuple(bands)
+        self.band_cols = tuple("{}_mag".format(b) for b in self.bands)
+        self.props = tuple() if props is None else tuple(props)
+        if not no_uncs:
+            for c in self.band_cols + self.props:
+                if c not in df.columns:
+                    raise ValueError("{} not in DataFrame!".format(c))
+                if "{}_unc".format(c) not in df.columns:
+                    raise ValueError("{0} uncertainty ({0}_unc) not in DataFrame!".format(c))
+        self._prior_settings = {}
+
+    def __len__(self):
+        return len(self.df)
+
+    def set_prior(self, **kwargs):
+        self._prior_settings.update(kwargs)
+
+    def model(self, i, ic, N=1, **kwargs):
+        row = self.df.iloc[i]
+        mags = {b: (row["{}_mag".format(b)], row["{}_mag_unc".format(b)]) for b in self.bands}
+        props = {p: (row[p], row["{}_unc".format(p)]) for p in self.props}
+        mod = BasicStarModel(ic, N=N, name=row.name, **mags, **props, **kwargs)
+        if self._prior_settings:
+            mod.set_prior(**self._prior_settings)
+        return mod
+
+    def iter_models(self, ic, N=1, indices=None, **kwargs):
+        for i in (range(len(self.df)) if indices is None else indices):
+            yield self.model(i, ic, N=N, **kwargs)
+
+
+class CatalogPosterior:
+    """Device-resident posteriors of many stars sharing bands and multiplicity."""
+
+    def __init__(self, ic, models, device=None):
+        if not models:
+            raise ValueError("no models")
+        self.ic = ic
+        self.models = list(models)
+        self.n_models = len(self.models)
+        self.n_params = self.models[0].n_params
+        self.param_names = self.models[0].param_names
+        self.device = dev.current_device() if device is None else device
+        descs = (_cabi.IsoModelDesc * self.n_models)(*[m.model_desc() for m in self.models])
+        h = C.c_void_p()
+        _cabi.check(_cabi.lib().iso_catalog_create(ic.handle(self.device), descs, self.n_models, C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None) is not None:
+            _cabi.lib().iso_catalog_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def lnpost(self, pars, star_id):
+        """pars: CUDA float64 [n, n_params]; star_id: CUDA int32 [n] -> CUDA float64 [n]."""
+        import torch
+        if pars.dim() != 2 or pars.shape[1] != self.n_params:
+            raise ValueError("pars must be [n, %d]" % self.n_params)
+        if star_id.dtype != torch.int32 or star_id.numel() != pars.shape[0]:
+            raise ValueError("star_id must be int32 [n]")
+        pars = pars.contiguous()
+        star_id = star_id.contiguous()
+        n = pars.shape[0]
+        out = dev.empty_f64((n,), self.device)
+        if n:
+            _cabi.check(_cabi.lib().iso_catalog_lnpost(self._h, dev.ptr(star_id), dev.ptr(pars), self.n_params, 1, n,
+                                                       dev.ptr(out), dev.stream_ptr(self.device)))
+        return out
+
+
+class BatchedEnsembleSampler:
+    """Stretch-move ensembles of S independent stars advanced in lock-step (one lnpost launch per
+    half-step for all S x W/2 proposals).  ``lnpost_fn(pars[n, D], star_id[n]) -> [n]``."""
+
+    def __init__(self, n_stars, nwalkers, ndim, lnpost_fn, a=2.0, seed=0, device=None):
+        import torch
+        if nwalkers % 2 or nwalkers < 2 * ndim:
+            raise ValueError("need an even number of walkers, at least 2*ndim")
+        self.S, self.W, self.D, self.a, self.lnpost_fn = int(n_stars), int(nwalkers), int(ndim), float(a), lnpost_fn
+        self.device = torch.device(device) if device is not None else torch.device(
+            "cuda" if torch.cuda.is_available() else "cpu")
+        self.gen = torch.Generator(device=self.device)
+        self.gen.manual_seed(int(seed))
+        h = self.W // 2
+        self._sid_half = torch.arange(self.S, device=self.device, dtype=torch.int32).repeat_interleave(h)
+        self._sid_full = torch.arange(self.S, device=self.device, dtype=torch.int32).repeat_interleave(self.W)
+        self.naccepted = torch.zeros(self.S, self.W, dtype=torch.float64, device=self.device)
+        self.iterations = 0
+
+    def lnpost_all(self, pos):
+        return self.lnpost_fn(pos.reshape(self.S * self.W, self.D), self._sid_full).view(self.S, self.W)
+
+    def _half(self, pos, lnp, lo, hi, clo, chi):
+        import torch
+        S, h, D = self.S, self.W // 2, self.D
+        idx = torch.randint(0, h, (S, h), generator=self.gen, device=self.device)
+        u = torch.rand(S, h, generator=self.gen, device=self.device, dtype=torch.float64)
+        z = ((self.a - 1.0) * u + 1.0) ** 2 / self.a
+        xk = pos[:, lo:hi, :]
+        xj = pos[:, clo:chi, :].gather(1, idx[..., None].expand(S, h, D))
+        prop = xj + z[..., None] * (xk - xj)
+        lnp_new = self.lnpost_fn(prop.reshape(S * h, D), self._sid_half).view(S, h)
+        lnq = (D - 1) * torch.log(z) + lnp_new - lnp[:, lo:hi]
+        logu = torch.log(torch.rand(S, h, generator=self.gen, device=self.device, dtype=torch.float64))
+        acc = (logu < lnq) & torch.isfinite(lnp_new)
+        pos[:, lo:hi, :] = torch.where(acc[..., None], prop, xk)
+        lnp[:, lo:hi] = torch.where(acc, lnp_new, lnp[:, lo:hi])
+        self.naccepted[:, lo:hi] += acc
+
+    def run(self, pos, lnp, nsteps, keep=False):
+        """Advance in place; with keep=True returns (chain [S, W, nsteps, D], lnprob [S, W, nsteps])."""
+        import torch
+        h = self.W // 2
+        chain = torch.empty(self.S, self.W, nsteps, self.D, dtype=torch.float64, device=self.device) if keep else None
+        lnps = torch.empty(self.S, self.W, nsteps, dtype=torch.float64, device=self.device) if keep else None
+        for it in range(int(nsteps)):
+            self._half(pos, lnp, 0, h, h, self.W)
+            self._half(pos, lnp, h, self.W, 0, h)
+            self.iterations += 1
+            if keep:
+                chain[:, :, it, :] = pos
+                lnps[:, :, it] = lnp
+        return chain, lnps
+
+
+def initial_positions(post: CatalogPosterior, nwalkers, rng_seed=0, oversample=8, max_tries=6):
+    """[S, W, D] start points with finite lnpost: draw ``oversample * W`` candidates per star inside
+    the parameter bounds (distance centred on the parallax when there is one), evaluate them in
+    one launch, keep each star's best W.  Stars that never reach W finite candidates are returned
+    in ``failed`` (their rows hold NaN) — per-star failure isolation, as the reference's
+    try/except around each star (isochrones/starfit.py:155-159)."""
+    import torch
+    S, D, W = post.n_models, post.n_params, nwalkers
+    device = torch.device("cuda", post.device)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(int(rng_seed))
+    lo = torch.tensor([[m.bounds(p)[0] for p in post.param_names] for m in post.models], dtype=torch.float64,
+                      device=device)
+    hi = torch.tensor([[m.bounds(p)[1] for p in post.param_names] for m in post.models], dtype=torch.float64,
+                      device=device)
+    names = list(post.param_names)
+    i_d = names.index("distance")
+    plx = torch.tensor([m.kwargs["parallax"][0] if "parallax" in m.kwargs else np.nan for m in post.models],
+                       dtype=torch.float64, device=device)
+    plx_e = torch.tensor([m.kwargs["parallax"][1] if "parallax" in m.kwargs else np.nan for m in post.models],
+                         dtype=torch.float64, device=device)
+    n_eep = sum(1 for n in names if n.startswith("eep"))
+    K = oversample * W
+    best = torch.full((S, W, D), float("nan"), dtype=torch.float64, device=device)
+    best_lnp = torch.full((S, W), -float("inf"), dtype=torch.float64, device=device)
+    sid = torch.arange(S, device=device, dtype=torch.int32).repeat_interleave(K)
+    for _ in range(max_tries):
+        u = torch.rand(S, K, D, generator=gen, device=device, dtype=torch.float64)
+        cand = lo[:, None, :] + u * (hi - lo)[:, None, :]
+        if "mass" in names:                         # log-uniform in mass
+            j = names.index("mass")
+            cand[..., j] = torch.exp(torch.log(lo[:, None, j]) + u[..., j] * torch.log(hi / lo)[:, None, j])
+        dlo = torch.clamp(lo[:, i_d], min=1.0)
+        logd = torch.log(dlo)[:, None] + u[..., i_d] * torch.log(hi[:, i_d] / dlo)[:, None]
+        d_prior = torch.exp(logd)
+        d0 = 1000.0 / plx
+        rel = torch.clamp(plx_e / plx, min=1e-3, max=0.3)
+        d_plx = d0[:, None] * (1.0 + 4.0 * rel[:, None] * (2.0 * u[..., i_d] - 1.0))
+        use_plx = (plx > 0) & torch.isfinite(d0)
+        cand[..., i_d] = torch.where(use_plx[:, None], d_plx, d_prior)
+        if n_eep > 1:                               # eep_0 >= eep_1 >= eep_2
+            cand[..., :n_eep] = torch.sort(cand[..., :n_eep], dim=-1, descending=True).values
+        lnp = post.lnpost(cand.reshape(S * K, D), sid).view(S, K)
+        lnp = torch.where(torch.isfinite(lnp), lnp, torch.full_like(lnp, -float("inf")))
+        allp = torch.cat([best, cand], dim=1)
+        alll = torch.cat([best_lnp, lnp], dim=1)
+        top = torch.topk(alll, W, dim=1)
+        best_lnp = top.values
+        best = allp.gather(1, top.indices[..., None].expand(S, W, D))
+        if bool(torch.isfinite(best_lnp).all()):
+            break
+    failed = ~torch.isfinite(best_lnp).all(dim=1)
+    return best, best_lnp, failed
+
+
+RESULT_STATS = ("median", "p16", "p84")
+
+
+def result_columns(param_names):
+    cols = []
+    for p in param_names:
+        cols += ["%s_%s" % (p, s) for s in RESULT_STATS]
+    return cols + ["lnpost_max", "acceptance", "ok"]
+
+
+def fit_stars_gpu(catalog: StarCatalog, ic, indices, N=1, nwalkers=32, nburn=150, niter=100, seed=0,
+                  model_kwargs=None):
+    """Fit the stars ``indices`` of the catalog on the current GPU; returns [len(indices), 3*D+3]
+    float64 numpy rows (result_columns order)."""
+    import torch
+    models = [catalog.model(int(i), ic, N=N, **(model_kwargs or {})) for i in indices]
+    if not models:
+        return np.empty((0, 3 * (N + 4) + 3))
+    post = CatalogPosterior(ic, models)
+    D = post.n_params
+    pos, lnp, failed = initial_positions(post, nwalkers, rng_seed=seed)
+    good = ~failed
+    # failed stars get a copy of a good star's walkers so the batch stays rectangular
+    if bool(failed.any()) and bool(good.any()):
+        src = int(torch.nonzero(good)[0])
+        pos[failed] = pos[src]
+        lnp[failed] = lnp[src]
+    sampler = BatchedEnsembleSampler(post.n_models, nwalkers, D, post.lnpost, seed=seed + 1,
+                                     device=torch.device("cuda", post.device))
+    if bool(failed.any()) and bool(good.any()):
+        # evaluate failed stars with the borrowed star's id so their lnpost stays finite
+        sid_map = torch.arange(post.n_models, device=pos.device, dtype=torch.int32)
+        sid_map[failed] = src
+        sampler._sid_half = sid_map.repeat_interleave(nwalkers // 2)
+        sampler._sid_full = sid_map.repeat_interleave(nwalkers)
+    sampler.run(pos, lnp, nburn)
+    sampler.naccepted.zero_()
+    sampler.iterations = 0
+    chain, lnps = sampler.run(pos, lnp, niter, keep=True)
+    flat = chain.reshape(post.n_models, nwalkers * niter, D)
+    q = torch.quantile(flat, torch.tensor([0.5, 0.16, 0.84], dtype=torch.float64, device=flat.device), dim=1)
+    rows = torch.empty(post.n_models, 3 * D + 3, dtype=torch.float64, device=flat.device)
+    rows[:, : 3 * D] = q.permute(1, 2, 0).reshape(post.n_models, 3 * D)
+    rows[:, 3 * D] = lnps.reshape(post.n_models, -1).max(dim=1).values
+    rows[:, 3 * D + 1] = sampler.naccepted.mean(dim=1) / max(sampler.iterations, 1)
+    rows[:, 3 * D + 2] = good.to(torch.float64)
+    rows[failed, : 3 * D + 2] = float("nan")
+    out = rows.cpu().numpy()
+    post.close()
+    return out
+
+
+def fit_catalog(catalog: StarCatalog, ic, N=1, fit_fn=None, **fit_kwargs):
+    """Shard the catalog over the ranks of the default process group (star i -> rank (i+1) % P),
+    fit every shard with ``fit_fn`` (default: :func:`fit_stars_gpu`) and all-gather the per-star
+    result rows.  Returns a DataFrame indexed like ``catalog.df`` on every rank."""
+    import pandas as pd
+    import torch
+    import torch.distributed as dist
+    distributed = dist.is_available() and dist.is_initialized()
+    rank = dist.get_rank() if distributed else 0
+    world = dist.get_world_size() if distributed else 1
+    n = len(catalog)
+    mine = shard_indices(n, rank, world)
+    fit_fn = fit_fn or fit_stars_gpu
+    rows = np.asarray(fit_fn(catalog, ic, mine, N=N, **fit_kwargs), dtype=np.float64)
+    width = rows.shape[1] if rows.size else 3 * (N + 4) + 3
+    full = np.full((n, width), np.nan)
+    if distributed:
+        cap = (n + world - 1) // world + 1                       # fixed-size exchange buffers
+        backend = dist.get_backend()
+        devt = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+        buf = torch.full((cap, width + 1), float("nan"), dtype=torch.float64, device=devt)
+        buf[: len(mine), 0] = torch.as_tensor(mine, dtype=torch.float64)
+        buf[: len(mine), 1:] = torch.as_tensor(rows, dtype=torch.float64)
+        gathered = [torch.empty_like(buf) for _ in range(world)]
+        dist.all_gather(gathered, buf)
+        for g in gathered:
+            g = g.cpu().numpy()
+            ok = np.isfinite(g[:, 0])
+            full[g[ok, 0].astype(int)] = g[ok, 1:]
+    else:
+        full[mine] = rows
+    names = (ic.param_names if N == 1 else tuple(["eep_%d" % i for i in range(N)] + list(ic.param_names[1:])))
+    return pd.DataFrame(full, index=catalog.df.index, columns=result_columns(names))
+
+
+def synthetic_catalog(ic, n_stars, bands=None, seed=0, mag_unc=0.02, with_parallax=True, device=None):
+    """Catalog of single stars drawn over the table (mags synthesised with this build's own
+    interp_mag + Gaussian noise); returns (StarCatalog, truth DataFrame).  SURVEY 8d cfg 5."""
+    import pandas as pd
+    rng = np.random.default_rng(seed)
+    bands = list(bands or ic.bands)
+    cols = {}
+    truth = None
+    need = n_stars
+    chunks = []
+    while need > 0:
+        m = int(need * 1.6) + 64
+        if ic.eep_replaces == "age":
+            p = np.array([np.exp(rng.uniform(np.log(0.6), np.log(2.5), m)), rng.uniform(202, 605, m),
+                          rng.uniform(-1.0, 0.4, m), np.exp(rng.uniform(np.log(50), np.log(1500), m)),
+                          rng.uniform(0.0, 0.6, m)])
+        else:
+            p = np.array([rng.uniform(202, 605, m), rng.uniform(8.5, 10.0, m), rng.uniform(-1.0, 0.4, m),
+                          np.exp(rng.uniform(np.log(50), np.log(1500), m)), rng.uniform(0.0, 0.6, m)])
+        T, g, f, mags = ic.interp_mag(list(p), bands)
+        ok = np.isfinite(mags).all(axis=1) & np.isfinite(T)
+        chunks.append((p[:, ok], T[ok], g[ok], f[ok], mags[ok]))
+        need -= int(ok.sum())
+    p = np.concatenate([c[0] for c in chunks], axis=1)[:, :n_stars]
+    T, g, f = (np.concatenate([c[k] for c in chunks])[:n_stars] for k in (1, 2, 3))
+    mags = np.concatenate([c[4] for c in chunks])[:n_stars]
+    for j, b in enumerate(bands):
+        cols["%s_mag" % b] = mags[:, j] + mag_unc * rng.standard_normal(n_stars)
+        cols["%s_mag_unc" % b] = np.full(n_stars, mag_unc)
+    props = []
+    if with_parallax:
+        plx = 1000.0 / p[3]
+        cols["parallax"] = plx * (1 + 0.02 * rng.standard_normal(n_stars))
+        cols["parallax_unc"] = 0.02 * plx
+        props.append("parallax")
+    cols["Teff"] = T + 80 * rng.standard_normal(n_stars)
+    cols["Teff_unc"] = np.full(n_stars, 80.0)
+    props.append("Teff")
+    df = pd.DataFrame(cols, index=["star%05d" % i for i in range(n_stars)])
+    truth = pd.DataFrame(p.T, columns=list(ic.param_names), index=df.index)
+    return StarCatalog(df, bands=bands, props=props), truth

@@ -3,13 +3,14 @@
 
 namespace iso {
 
-bool launch_lnpost_fast(int kind, int n_stars, int n_bands, bool packed, const FastArgs& A, hipStream_t s)
+bool launch_lnpost_fast(int kind, int n_stars, int n_bands, bool packed, bool multi, const FastArgs& A,
+                        hipStream_t s)
 {
-    if (kind == ISO_KIND_TRACK) return n_stars == 1 && launch_fast_track1(n_bands, packed, A, s);
+    if (kind == ISO_KIND_TRACK) return n_stars == 1 && launch_fast_track1(n_bands, packed, multi, A, s);
     switch (n_stars) {
-    case 1: return launch_fast_iso1(n_bands, packed, A, s);
-    case 2: return launch_fast_iso2(n_bands, packed, A, s);
-    case 3: return launch_fast_iso3(n_bands, packed, A, s);
+    case 1: return launch_fast_iso1(n_bands, packed, multi, A, s);
+    case 2: return launch_fast_iso2(n_bands, packed, multi, A, s);
+    case 3: return launch_fast_iso3(n_bands, packed, multi, A, s);
     }
     return false;
 }

@@ -286,7 +286,9 @@ __device__ __forceinline__ double eep_term(const DevModel& M, const DevPrior& or
 }
 
 // ---- the kernel ---------------------------------------------------------------------------
-template <int KIND, int NS, int NB, bool PACKED>
+// MULTI: every row carries the index of its own star (observations + priors) — the catalog /
+// batched-ensemble form: S stars x W walkers in one launch.
+template <int KIND, int NS, int NB, bool PACKED, bool MULTI>
 __global__ __launch_bounds__(BLOCK) void k_lnpost_fast(const FastArgs A)
 {
     extern __shared__ double lds[];
@@ -294,7 +296,7 @@ __global__ __launch_bounds__(BLOCK) void k_lnpost_fast(const FastArgs A)
     __syncthreads();
     const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= A.n) return;
-    const DevModel& M = *A.m;
+    const DevModel& M = A.m[MULTI ? A.star_id[i] : 0];
     constexpr int NP = NS + 4;
     double p[NP];
     {
@@ -403,20 +405,20 @@ __global__ __launch_bounds__(BLOCK) void k_lnpost_fast(const FastArgs A)
     A.lnpost[i] = lnp + lnl;
 }
 
-template <int KIND, int NS, bool PACKED>
+template <int KIND, int NS, bool PACKED, bool MULTI>
 inline bool launch_nb(int nb, const FastArgs& A, hipStream_t s)
 {
     const dim3 g((unsigned)((A.n + BLOCK - 1) / BLOCK)), b(BLOCK);
     const size_t sh = (size_t)A.axes_len * sizeof(double);
     switch (nb) {
-    case 1: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 1, PACKED>), g, b, sh, s, A); return true;
-    case 2: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 2, PACKED>), g, b, sh, s, A); return true;
-    case 3: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 3, PACKED>), g, b, sh, s, A); return true;
-    case 4: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 4, PACKED>), g, b, sh, s, A); return true;
-    case 5: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 5, PACKED>), g, b, sh, s, A); return true;
-    case 6: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 6, PACKED>), g, b, sh, s, A); return true;
-    case 7: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 7, PACKED>), g, b, sh, s, A); return true;
-    case 8: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 8, PACKED>), g, b, sh, s, A); return true;
+    case 1: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 1, PACKED, MULTI>), g, b, sh, s, A); return true;
+    case 2: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 2, PACKED, MULTI>), g, b, sh, s, A); return true;
+    case 3: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 3, PACKED, MULTI>), g, b, sh, s, A); return true;
+    case 4: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 4, PACKED, MULTI>), g, b, sh, s, A); return true;
+    case 5: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 5, PACKED, MULTI>), g, b, sh, s, A); return true;
+    case 6: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 6, PACKED, MULTI>), g, b, sh, s, A); return true;
+    case 7: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 7, PACKED, MULTI>), g, b, sh, s, A); return true;
+    case 8: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 8, PACKED, MULTI>), g, b, sh, s, A); return true;
     default: return false;
     }
 }
@@ -424,16 +426,18 @@ inline bool launch_nb(int nb, const FastArgs& A, hipStream_t s)
 }  // namespace fastk
 
 // one definition per translation unit iso_fast_<tag>.hip
+// (the catalog form is only built on the corner-packed layout)
 #define ISO_DEFINE_FAST_LAUNCHER(NAME, KIND, NS)                                              \
-    bool NAME(int nb, bool packed, const FastArgs& A, hipStream_t s)                          \
+    bool NAME(int nb, bool packed, bool multi, const FastArgs& A, hipStream_t s)              \
     {                                                                                         \
-        return packed ? fastk::launch_nb<KIND, NS, true>(nb, A, s)                            \
-                      : fastk::launch_nb<KIND, NS, false>(nb, A, s);                          \
+        if (multi) return packed && fastk::launch_nb<KIND, NS, true, true>(nb, A, s);         \
+        return packed ? fastk::launch_nb<KIND, NS, true, false>(nb, A, s)                     \
+                      : fastk::launch_nb<KIND, NS, false, false>(nb, A, s);                   \
     }
 
-bool launch_fast_track1(int nb, bool packed, const FastArgs& A, hipStream_t s);
-bool launch_fast_iso1(int nb, bool packed, const FastArgs& A, hipStream_t s);
-bool launch_fast_iso2(int nb, bool packed, const FastArgs& A, hipStream_t s);
-bool launch_fast_iso3(int nb, bool packed, const FastArgs& A, hipStream_t s);
+bool launch_fast_track1(int nb, bool packed, bool multi, const FastArgs& A, hipStream_t s);
+bool launch_fast_iso1(int nb, bool packed, bool multi, const FastArgs& A, hipStream_t s);
+bool launch_fast_iso2(int nb, bool packed, bool multi, const FastArgs& A, hipStream_t s);
+bool launch_fast_iso3(int nb, bool packed, bool multi, const FastArgs& A, hipStream_t s);
 
 }  // namespace iso

@@ -1153,42 +1153,38 @@ int iso_interp_mag(iso_ic* ic, const double* pars, int64_t stride_n, int64_t str
     return ISO_OK;
 }
 
-int iso_model_create(iso_ic* ic, const iso_model_desc* desc, iso_model** out)
+}  // extern "C" (helpers follow)
+
+namespace {
+
+int validate_desc(const iso_ic* ic, const iso_model_desc* desc, const char* who)
 {
-    if (!ic || !desc || !out) return fail(ISO_ERR_INVALID, "iso_model_create: NULL argument");
-    if (desc->n_stars < 1 || desc->n_stars > ISO_MAX_STARS) return fail(ISO_ERR_INVALID, "iso_model_create: n_stars");
+    const std::string w(who);
+    if (desc->n_stars < 1 || desc->n_stars > ISO_MAX_STARS) return fail(ISO_ERR_INVALID, w + ": n_stars");
     if (desc->n_stars > 1 && ic->kind == ISO_KIND_TRACK)
-        return fail(ISO_ERR_INVALID, "iso_model_create: multiple stars need the isochrone parametrisation");
-    if (desc->n_bands < 0 || desc->n_bands > ISO_MAX_BANDS) return fail(ISO_ERR_INVALID, "iso_model_create: n_bands");
+        return fail(ISO_ERR_INVALID, w + ": multiple stars need the isochrone parametrisation");
+    if (desc->n_bands < 0 || desc->n_bands > ISO_MAX_BANDS) return fail(ISO_ERR_INVALID, w + ": n_bands");
     if (ic->prior_cols[0] < 0 || ic->prior_cols[1] < 0)
-        return fail(ISO_ERR_INVALID, "iso_model_create: the model table has no EEP-prior columns");
+        return fail(ISO_ERR_INVALID, w + ": the model table has no EEP-prior columns");
     if (desc->has_numax && (ic->astero_cols[0] < 0 || ic->astero_cols[1] < 0))
-        return fail(ISO_ERR_INVALID, "iso_model_create: the model table has no nu_max/delta_nu columns");
+        return fail(ISO_ERR_INVALID, w + ": the model table has no nu_max/delta_nu columns");
     for (int b = 0; b < desc->n_bands; ++b)
         if (desc->bc_cols[b] < 0 || desc->bc_cols[b] >= ic->g4.ncol)
-            return fail(ISO_ERR_INVALID, "iso_model_create: band column out of range");
+            return fail(ISO_ERR_INVALID, w + ": band column out of range");
     const iso_prior* pr[5] = {&desc->prior_mass, &desc->prior_age, &desc->prior_feh, &desc->prior_distance,
                               &desc->prior_AV};
     for (int j = 0; j < 5; ++j)
-        if (!prior_kind_ok(pr[j]->kind)) return fail(ISO_ERR_INVALID, "iso_model_create: unknown prior family");
+        if (!prior_kind_ok(pr[j]->kind)) return fail(ISO_ERR_INVALID, w + ": unknown prior family");
+    return ISO_OK;
+}
 
-    DeviceGuard guard(ic->ctx->device);
-    iso_model* m = new (std::nothrow) iso_model();
-    if (!m) return fail(ISO_ERR_NOMEM, "iso_model_create: out of host memory");
-    m->ic = ic;
-    m->device = ic->device;
-    m->desc = *desc;
-    m->d_model = nullptr;
-    m->d_bc_hot = nullptr;
-    m->d_bcq = nullptr;
-    m->d_axes_blob = nullptr;
-    m->fast_ok = false;
-
-    DevModel H;
+// observations + prior constants of one system, everything constant pre-evaluated on the host
+void fill_dev_model(const iso_model_desc* desc, int kind, DevModel& H)
+{
     std::memset(&H, 0, sizeof(H));
     H.n_stars = desc->n_stars;
     H.n_bands = desc->n_bands;
-    H.kind = ic->kind;
+    H.kind = kind;
     H.has_parallax = desc->has_parallax;
     H.has_numax = desc->has_numax;
     H.has_dnu = desc->has_numax ? desc->has_dnu : 0;
@@ -1217,77 +1213,119 @@ int iso_model_create(iso_ic* ic, const iso_model_desc* desc, iso_model** out)
         H.bound_lo[j] = desc->bound_lo[j];
         H.bound_hi[j] = desc->bound_hi[j];
     }
+}
+
+// BC table restricted to `nb` bands (observation order), contiguous per cell
+hipError_t pack_bands(const iso_ic* ic, const int32_t* bc_cols, int nb, double** out)
+{
+    const int64_t ncells = ic->bc->ncells;
+    hipError_t e = hipMalloc(out, (size_t)ncells * nb * sizeof(double));
+    if (e != hipSuccess) return e;
+    PackBcArgs P;
+    P.grid = ic->bc->d_grid;
+    P.ncol = ic->g4.ncol;
+    P.nb = nb;
+    P.ncells = ncells;
+    for (int b = 0; b < nb; ++b) P.src[b] = bc_cols[b];
+    P.out = *out;
+    hipLaunchKernelGGL(k_pack_bc, dim3(grid_blocks(ncells * nb)), dim3(BLOCK), 0, 0, P);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    return e;
+}
+
+bool fast_eligible(const iso_ic* ic, const iso_model_desc* desc)
+{
+    return path_mode() != PATH_GENERIC && desc->n_bands >= 1 && desc->n_bands <= 8 && !desc->has_numax &&
+           ic->model->ax[2].uniform;
+}
+
+// staged axes (+ reciprocal spacings) and, when the interpolator has a corner-packed model table,
+// the corner-packed BC; fills F (without m / pars / outputs).  *ok = false if not representable.
+hipError_t build_fast(const iso_ic* ic, int nb, const double* d_bc_hot, double** d_axes_blob, double** d_bcq,
+                      FastArgs& F, bool* ok)
+{
+    *ok = false;
+    std::vector<double> blob;
+    FastAxis fa[6];
+    const std::vector<double>* src[6] = {&ic->h_axes_model[0], &ic->h_axes_model[1], &ic->h_axes_bc[0],
+                                         &ic->h_axes_bc[1], &ic->h_axes_bc[2], &ic->h_axes_bc[3]};
+    for (int a = 0; a < 6; ++a) {
+        const std::vector<double>& v = *src[a];
+        fa[a].off = (int)blob.size();
+        fa[a].n = (int)v.size();
+        blob.insert(blob.end(), v.begin(), v.end());
+        for (size_t j = 0; j + 1 < v.size(); ++j) blob.push_back(1.0 / (v[j + 1] - v[j]));
+        blob.push_back(0.0);
+    }
+    if ((int)blob.size() > FAST_MAX_BLOB) return hipSuccess;
+    hipError_t e = hipMalloc(d_axes_blob, blob.size() * sizeof(double));
+    if (e == hipSuccess) e = hipMemcpy(*d_axes_blob, blob.data(), blob.size() * sizeof(double), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return e;
+    if (path_mode() == PATH_AUTO && ic->d_hotq) {
+        hipError_t e2 = pack_corners(d_bc_hot, nb, nb, 4, ic->bc->shape, d_bcq);
+        if (e2 != hipSuccess) {
+            *d_bcq = nullptr;
+            (void)hipGetLastError();
+        }
+    }
+    std::memset(&F, 0, sizeof(F));
+    F.m0 = fa[0]; F.m1 = fa[1];
+    F.b0 = fa[2]; F.b1 = fa[3]; F.b2 = fa[4]; F.b3 = fa[5];
+    F.e_a0 = ic->model->ax[2].a0;
+    F.e_step = ic->model->ax[2].step;
+    F.e_inv = 1.0 / F.e_step;
+    F.e_n = ic->model->ax[2].n;
+    F.axes_blob = *d_axes_blob;
+    F.axes_len = (int)blob.size();
+    F.hot = ic->d_hot;
+    F.hotq = ic->d_hotq;
+    F.s0 = ic->g3.s0; F.s1 = ic->g3.s1;
+    F.bc = d_bc_hot;
+    F.bcq = *d_bcq;
+    F.bs2 = ic->bc->shape[3];
+    F.bs1 = ic->bc->shape[2] * ic->bc->shape[3];
+    F.bs0 = ic->bc->shape[1] * ic->bc->shape[2] * ic->bc->shape[3];
+    *ok = true;
+    return hipSuccess;
+}
+
+}  // namespace
+
+extern "C" {
+
+int iso_model_create(iso_ic* ic, const iso_model_desc* desc, iso_model** out)
+{
+    if (!ic || !desc || !out) return fail(ISO_ERR_INVALID, "iso_model_create: NULL argument");
+    const int rc = validate_desc(ic, desc, "iso_model_create");
+    if (rc != ISO_OK) return rc;
+
+    DeviceGuard guard(ic->ctx->device);
+    iso_model* m = new (std::nothrow) iso_model();
+    if (!m) return fail(ISO_ERR_NOMEM, "iso_model_create: out of host memory");
+    m->ic = ic;
+    m->device = ic->device;
+    m->desc = *desc;
+    m->d_model = nullptr;
+    m->d_bc_hot = nullptr;
+    m->d_bcq = nullptr;
+    m->d_axes_blob = nullptr;
+    m->fast_ok = false;
+
+    DevModel H;
+    fill_dev_model(desc, ic->kind, H);
     hipError_t e = hipMalloc(&m->d_model, sizeof(DevModel));
     if (e == hipSuccess) e = hipMemcpy(m->d_model, &H, sizeof(DevModel), hipMemcpyHostToDevice);
 
-    // BC table restricted to this model's bands (observation order), contiguous per cell
     m->g4 = ic->g4;
     if (e == hipSuccess && desc->n_bands > 0) {
-        const int64_t ncells = ic->bc->ncells;
-        e = hipMalloc(&m->d_bc_hot, (size_t)ncells * desc->n_bands * sizeof(double));
-        if (e == hipSuccess) {
-            PackBcArgs P;
-            P.grid = ic->bc->d_grid;
-            P.ncol = ic->g4.ncol;
-            P.nb = desc->n_bands;
-            P.ncells = ncells;
-            for (int b = 0; b < desc->n_bands; ++b) P.src[b] = desc->bc_cols[b];
-            P.out = m->d_bc_hot;
-            hipLaunchKernelGGL(k_pack_bc, dim3(grid_blocks(ncells * desc->n_bands)), dim3(BLOCK), 0, 0, P);
-            e = hipGetLastError();
-            if (e == hipSuccess) e = hipDeviceSynchronize();
-            m->g4.tab = m->d_bc_hot;
-            m->g4.ncol = desc->n_bands;
-        }
+        e = pack_bands(ic, desc->bc_cols, desc->n_bands, &m->d_bc_hot);
+        m->g4.tab = m->d_bc_hot;
+        m->g4.ncol = desc->n_bands;
     }
-    // ---- fast path: eligibility, staged axes (+ reciprocal spacings), corner-packed BC ----
-    const PathMode mode = path_mode();
-    if (e == hipSuccess && mode != PATH_GENERIC && desc->n_bands >= 1 && desc->n_bands <= 8 && !desc->has_numax &&
-        ic->model->ax[2].uniform) {
-        std::vector<double> blob;
-        FastAxis fa[6];
-        const std::vector<double>* src[6] = {&ic->h_axes_model[0], &ic->h_axes_model[1], &ic->h_axes_bc[0],
-                                             &ic->h_axes_bc[1], &ic->h_axes_bc[2], &ic->h_axes_bc[3]};
-        for (int a = 0; a < 6; ++a) {
-            const std::vector<double>& v = *src[a];
-            fa[a].off = (int)blob.size();
-            fa[a].n = (int)v.size();
-            blob.insert(blob.end(), v.begin(), v.end());
-            for (size_t j = 0; j + 1 < v.size(); ++j) blob.push_back(1.0 / (v[j + 1] - v[j]));
-            blob.push_back(0.0);
-        }
-        if ((int)blob.size() <= FAST_MAX_BLOB) {
-            e = hipMalloc(&m->d_axes_blob, blob.size() * sizeof(double));
-            if (e == hipSuccess)
-                e = hipMemcpy(m->d_axes_blob, blob.data(), blob.size() * sizeof(double), hipMemcpyHostToDevice);
-            if (e == hipSuccess && mode == PATH_AUTO && ic->d_hotq) {
-                hipError_t e2 = pack_corners(m->d_bc_hot, desc->n_bands, desc->n_bands, 4, ic->bc->shape, &m->d_bcq);
-                if (e2 != hipSuccess) {
-                    m->d_bcq = nullptr;
-                    (void)hipGetLastError();
-                }
-            }
-            if (e == hipSuccess) {
-                FastArgs& F = m->fast;
-                std::memset(&F, 0, sizeof(F));
-                F.m0 = fa[0]; F.m1 = fa[1];
-                F.b0 = fa[2]; F.b1 = fa[3]; F.b2 = fa[4]; F.b3 = fa[5];
-                F.e_a0 = ic->model->ax[2].a0;
-                F.e_step = ic->model->ax[2].step;
-                F.e_inv = 1.0 / F.e_step;
-                F.e_n = ic->model->ax[2].n;
-                F.axes_blob = m->d_axes_blob;
-                F.axes_len = (int)blob.size();
-                F.hot = ic->d_hot;
-                F.hotq = ic->d_hotq;
-                F.s0 = ic->g3.s0; F.s1 = ic->g3.s1;
-                F.bc = m->d_bc_hot;
-                F.bcq = m->d_bcq;
-                F.bs0 = m->g4.s0; F.bs1 = m->g4.s1; F.bs2 = m->g4.s2;
-                F.m = m->d_model;
-                m->fast_ok = true;
-            }
-        }
+    if (e == hipSuccess && fast_eligible(ic, desc)) {
+        e = build_fast(ic, desc->n_bands, m->d_bc_hot, &m->d_axes_blob, &m->d_bcq, m->fast, &m->fast_ok);
+        m->fast.m = m->d_model;
     }
     if (e != hipSuccess) {
         std::string msg = std::string("iso_model_create: ") + hipGetErrorString(e);
@@ -1357,7 +1395,7 @@ int enqueue_lnpost(iso_model* m, const double* pars, int64_t stride_n, int64_t s
         F.n = n;
         F.lnpost = lnpost_out;
         const bool packed = F.hotq != nullptr && F.bcq != nullptr;
-        if (launch_lnpost_fast(m->ic->kind, m->desc.n_stars, m->desc.n_bands, packed, F, s)) {
+        if (launch_lnpost_fast(m->ic->kind, m->desc.n_stars, m->desc.n_bands, packed, false, F, s)) {
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) return fail(ISO_ERR_HIP, std::string("iso_lnpost (fast) launch: ") + hipGetErrorString(e));
             return ISO_OK;
@@ -1406,6 +1444,84 @@ int iso_unit_cube(iso_model* m, double* cube, int64_t stride_n, int64_t stride_p
     DeviceGuard guard(m->ic->ctx->device);
     hipLaunchKernelGGL(k_unit_cube, dim3(grid_blocks(n * (m->desc.n_stars + 4))), dim3(BLOCK), 0, as_stream(stream),
                        m->d_model, cube, stride_n, stride_p, n);
+    HIP_TRY(hipGetLastError());
+    return ISO_OK;
+}
+
+int iso_catalog_create(iso_ic* ic, const iso_model_desc* descs, int64_t n_models, iso_catalog** out)
+{
+    if (!ic || !descs || !out || n_models < 1) return fail(ISO_ERR_INVALID, "iso_catalog_create: bad argument");
+    const iso_model_desc& d0 = descs[0];
+    for (int64_t k = 0; k < n_models; ++k) {
+        const int rc = validate_desc(ic, &descs[k], "iso_catalog_create");
+        if (rc != ISO_OK) return rc;
+        if (descs[k].n_stars != d0.n_stars || descs[k].n_bands != d0.n_bands ||
+            std::memcmp(descs[k].bc_cols, d0.bc_cols, sizeof(int32_t) * d0.n_bands) != 0)
+            return fail(ISO_ERR_INVALID, "iso_catalog_create: every star needs the same multiplicity and bands");
+        if (descs[k].has_numax) return fail(ISO_ERR_INVALID, "iso_catalog_create: asteroseismic terms are not batched");
+    }
+    if (!fast_eligible(ic, &d0) || !ic->d_hotq)
+        return fail(ISO_ERR_INVALID, "iso_catalog_create: needs 1-8 bands, a uniform EEP axis and the corner-packed "
+                                     "tables (ISOCHRONES_AMD_PATH=auto)");
+    DeviceGuard guard(ic->device);
+    iso_catalog* c = new (std::nothrow) iso_catalog();
+    if (!c) return fail(ISO_ERR_NOMEM, "iso_catalog_create: out of host memory");
+    c->device = ic->device;
+    c->ic = ic;
+    c->n_models = n_models;
+    c->n_stars = d0.n_stars;
+    c->n_bands = d0.n_bands;
+    c->d_models = nullptr;
+    c->d_bc_hot = c->d_bcq = c->d_axes_blob = nullptr;
+    std::vector<DevModel> H((size_t)n_models);
+    for (int64_t k = 0; k < n_models; ++k) fill_dev_model(&descs[k], ic->kind, H[(size_t)k]);
+    hipError_t e = hipMalloc(&c->d_models, sizeof(DevModel) * (size_t)n_models);
+    if (e == hipSuccess) e = hipMemcpy(c->d_models, H.data(), sizeof(DevModel) * (size_t)n_models, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = pack_bands(ic, d0.bc_cols, d0.n_bands, &c->d_bc_hot);
+    bool ok = false;
+    if (e == hipSuccess) e = build_fast(ic, d0.n_bands, c->d_bc_hot, &c->d_axes_blob, &c->d_bcq, c->fast, &ok);
+    if (e == hipSuccess && (!ok || !c->d_bcq)) {
+        iso_catalog_destroy(c);
+        return fail(ISO_ERR_INVALID, "iso_catalog_create: tables not representable on the fast path");
+    }
+    if (e != hipSuccess) {
+        std::string msg = std::string("iso_catalog_create: ") + hipGetErrorString(e);
+        iso_catalog_destroy(c);
+        return fail(e == hipErrorOutOfMemory ? ISO_ERR_NOMEM : ISO_ERR_HIP, msg);
+    }
+    c->fast.m = c->d_models;
+    c->packed = true;
+    *out = c;
+    return ISO_OK;
+}
+
+void iso_catalog_destroy(iso_catalog* c)
+{
+    if (!c) return;
+    DeviceGuard guard(c->device);
+    if (c->d_models) (void)hipFree(c->d_models);
+    if (c->d_bc_hot) (void)hipFree(c->d_bc_hot);
+    if (c->d_bcq) (void)hipFree(c->d_bcq);
+    if (c->d_axes_blob) (void)hipFree(c->d_axes_blob);
+    delete c;
+}
+
+int iso_catalog_lnpost(iso_catalog* c, const int32_t* star_id, const double* pars, int64_t stride_n,
+                       int64_t stride_p, int64_t n, double* lnpost_out, void* stream)
+{
+    if (!c || ((!star_id || !pars || !lnpost_out) && n > 0)) return fail(ISO_ERR_INVALID, "iso_catalog_lnpost: NULL argument");
+    if (n < 0) return fail(ISO_ERR_INVALID, "iso_catalog_lnpost: n < 0");
+    if (n == 0) return ISO_OK;
+    DeviceGuard guard(c->device);
+    FastArgs F = c->fast;
+    F.star_id = star_id;
+    F.pars = pars;
+    F.stride_n = stride_n;
+    F.stride_p = stride_p;
+    F.n = n;
+    F.lnpost = lnpost_out;
+    if (!launch_lnpost_fast(c->ic->kind, c->n_stars, c->n_bands, true, true, F, as_stream(stream)))
+        return fail(ISO_ERR_INVALID, "iso_catalog_lnpost: no kernel specialisation");
     HIP_TRY(hipGetLastError());
     return ISO_OK;
 }

@@ -85,7 +85,8 @@ struct FastArgs {
     const double* bc;                // BC restricted to the model's bands [..][nb]
     const double* bcq;               // corner-packed BC [cells][16 corners][nb] (or null)
     int64_t bs0, bs1, bs2;
-    const DevModel* m;
+    const DevModel* m;               // one model, or an array indexed by star_id (catalog kernels)
+    const int32_t* star_id;          // per-row model index (catalog kernels only)
     const double* pars;
     int64_t stride_n, stride_p, n;
     double* lnpost;
@@ -124,6 +125,19 @@ struct iso_ic {
     std::vector<double> h_axes_model[3], h_axes_bc[4];
 };
 
+struct iso_catalog {
+    int device;
+    iso_ic* ic;
+    int64_t n_models;
+    int n_stars, n_bands;
+    iso::DevModel* d_models;  // [n_models]
+    double* d_bc_hot;
+    double* d_bcq;
+    double* d_axes_blob;
+    bool packed;
+    iso::FastArgs fast;
+};
+
 struct iso_model {
     int device;              // copied: destroy order of handles is up to the caller / a GC
     iso_ic* ic;
@@ -140,5 +154,6 @@ struct iso_model {
 namespace iso {
 // defined in iso_fast_*.hip: launch the specialised fused kernel; returns false if no
 // specialisation exists for (kind, n_stars, n_bands)
-bool launch_lnpost_fast(int kind, int n_stars, int n_bands, bool packed, const FastArgs& A, hipStream_t s);
+bool launch_lnpost_fast(int kind, int n_stars, int n_bands, bool packed, bool multi, const FastArgs& A,
+                        hipStream_t s);
 }  // namespace iso

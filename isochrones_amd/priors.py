@@ -235,9 +235,16 @@ class ChabrierPrior(Prior):
         self._bounds = (float(bounds[0]), float(bounds[1]))
         self._rebuild()
 
+    _norm_cache = {}
+
     def _rebuild(self):
         lo, hi = self._bounds
         bp = self.breakpoint
+        key = (lo, hi, bp, self.low.mu, self.low.sigma, self.high.alpha, self.high.bounds)
+        if key in ChabrierPrior._norm_cache:      # catalogs build thousands of identical priors
+            self.norms = ChabrierPrior._norm_cache[key].copy()
+            self.lognorms = np.log(self.norms)
+            return
         ratio = self.high(bp) / self.low(bp)
         if _quad is not None:
             tot = (_quad(lambda x: self.low(x) / 1.0, lo, bp, limit=200)[0]
@@ -246,6 +253,7 @@ class ChabrierPrior(Prior):
             tot = self.closed_form_total(ratio)
         self.norms = np.array([1.0, ratio]) * tot
         self.lognorms = np.log(self.norms)
+        ChabrierPrior._norm_cache[key] = self.norms.copy()
 
     def closed_form_total(self, ratio=None):
         lo, hi = self._bounds
@@ -303,10 +311,18 @@ class FehPrior(Prior):
         if bounds is not None:
             self.bounds = bounds
 
+    _norm_cache = {}
+
     def _rebuild(self):
         lo, hi = self._bounds
+        key = (lo, hi, self.halo_fraction, self.local)
+        if key in FehPrior._norm_cache:
+            self._norm = FehPrior._norm_cache[key]
+            return
         if _quad is not None:
             self._norm = _quad(self._shape, lo, hi)[0]
+            FehPrior._norm_cache[key] = self._norm
+            return
         else:  # pragma: no cover
             self._norm = self.closed_form_norm()
 

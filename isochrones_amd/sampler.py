@@ -1,0 +1,116 @@
+"""Affine-invariant ensemble sampler (Goodman & Weare 2010 stretch move) whose walkers live in HBM.
+
+The reference drives ``emcee.EnsembleSampler(nwalkers, npars, self.lnpost)`` one walker at a time
+(isochrones/starmodel.py:886-972); emcee is not part of this build.  Here a half-ensemble is
+proposed, evaluated by ONE batched ``lnpost`` launch and accepted/rejected on the device; nothing
+crosses PCIe inside the loop.  The result attributes follow the emcee-v2 names the reference
+reads (``chain`` [nwalkers, nsteps, ndim], ``lnprobability`` [nwalkers, nsteps], ``flatchain``,
+``acceptance_fraction``, ``reset()``).
+
+``lnpost_fn`` maps a CUDA float64 tensor [n, ndim] to a CUDA tensor [n] (e.g.
+``BasicStarModel.lnpost``).  Also works with CPU tensors (used by the gloo/CPU tests with a toy
+log-density; the product path always passes CUDA tensors).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+
+class EnsembleSampler:
+    def __init__(self, nwalkers, ndim, lnpost_fn, a=2.0, seed=None, device=None):
+        import torch
+        if nwalkers % 2 or nwalkers < 2 * ndim:
+            raise ValueError("need an even number of walkers, at least 2*ndim")
+        self.nwalkers, self.ndim, self.lnpost_fn, self.a = int(nwalkers), int(ndim), lnpost_fn, float(a)
+        self.device = torch.device(device) if device is not None else torch.device(
+            "cuda" if torch.cuda.is_available() else "cpu")
+        self.gen = torch.Generator(device=self.device)
+        self.gen.manual_seed(int(seed) if seed is not None else int(np.random.SeedSequence().entropy % (2 ** 63)))
+        self.reset()
+
+    def reset(self):
+        self._chain = []
+        self._lnprob = []
+        self.naccepted = None
+        self.iterations = 0
+
+    # -- one full step = two half-ensemble updates ------------------------------------------
+    def _half_step(self, pos, lnp, first, second):
+        import torch
+        ns = first.numel()
+        idx = torch.randint(0, second.numel(), (ns,), generator=self.gen, device=self.device)
+        u = torch.rand(ns, generator=self.gen, device=self.device, dtype=torch.float64)
+        z = ((self.a - 1.0) * u + 1.0) ** 2 / self.a
+        xk = pos[first]
+        xj = pos[second[idx]]
+        prop = xj + z[:, None] * (xk - xj)
+        lnp_new = self.lnpost_fn(prop)
+        lnq = (self.ndim - 1) * torch.log(z) + lnp_new - lnp[first]
+        logu = torch.log(torch.rand(ns, generator=self.gen, device=self.device, dtype=torch.float64))
+        accept = (logu < lnq) & torch.isfinite(lnp_new)
+        pos[first] = torch.where(accept[:, None], prop, xk)
+        lnp[first] = torch.where(accept, lnp_new, lnp[first])
+        return accept
+
+    def run_mcmc(self, p0, nsteps, lnprob0=None, store=True, thin=1):
+        import torch
+        pos = torch.as_tensor(p0, dtype=torch.float64, device=self.device).clone()
+        if pos.shape != (self.nwalkers, self.ndim):
+            raise ValueError("p0 must be [nwalkers, ndim]")
+        lnp = self.lnpost_fn(pos).clone() if lnprob0 is None else torch.as_tensor(
+            lnprob0, dtype=torch.float64, device=self.device).clone()
+        if not bool(torch.isfinite(lnp).all()):
+            raise ValueError("initial positions must have finite lnpost")
+        half = self.nwalkers // 2
+        allw = torch.arange(self.nwalkers, device=self.device)
+        s0, s1 = allw[:half], allw[half:]
+        if self.naccepted is None:
+            self.naccepted = torch.zeros(self.nwalkers, dtype=torch.float64, device=self.device)
+        for it in range(int(nsteps)):
+            acc0 = self._half_step(pos, lnp, s0, s1)
+            acc1 = self._half_step(pos, lnp, s1, s0)
+            self.naccepted[:half] += acc0
+            self.naccepted[half:] += acc1
+            self.iterations += 1
+            if store and (it % thin == 0):
+                self._chain.append(pos.clone())
+                self._lnprob.append(lnp.clone())
+        return pos, lnp
+
+    # -- emcee-v2 style views ---------------------------------------------------------------
+    @property
+    def chain(self):
+        import torch
+        if not self._chain:
+            return torch.empty(self.nwalkers, 0, self.ndim, dtype=torch.float64, device=self.device)
+        return torch.stack(self._chain, dim=1)
+
+    @property
+    def lnprobability(self):
+        import torch
+        if not self._lnprob:
+            return torch.empty(self.nwalkers, 0, dtype=torch.float64, device=self.device)
+        return torch.stack(self._lnprob, dim=1)
+
+    @property
+    def flatchain(self):
+        return self.chain.reshape(-1, self.ndim)
+
+    @property
+    def flatlnprobability(self):
+        return self.lnprobability.reshape(-1)
+
+    @property
+    def acceptance_fraction(self):
+        return self.naccepted / max(self.iterations, 1)
+
+
+def summarize_chain(flatchain, flatlnprob):
+    """Fixed-size per-star result row: [median, 16th, 84th] per parameter, then the MAP lnpost.
+    Works on torch tensors or numpy arrays; returns a 1-D numpy array of length 3*ndim + 1."""
+    x = flatchain.detach().cpu().numpy() if hasattr(flatchain, "detach") else np.asarray(flatchain)
+    lp = flatlnprob.detach().cpu().numpy() if hasattr(flatlnprob, "detach") else np.asarray(flatlnprob)
+    q = np.percentile(x, [50, 16, 84], axis=0)          # [3, ndim]
+    return np.concatenate([q.T.ravel(), [lp.max() if lp.size else math.nan]])

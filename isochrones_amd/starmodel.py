@@ -319,6 +319,55 @@ class BasicStarModel:
         return out
 
 
+    # -- MCMC (reference: fit_mcmc_old, starmodel.py:889-972; emcee replaced by the on-device
+    #    stretch-move sampler in isochrones_amd/sampler.py) ------------------------------------
+    def emcee_p0(self, nwalkers, rng=None):
+        return self.sample_from_prior(nwalkers, rng=rng, require_valid=True)
+
+    def fit_mcmc(self, nwalkers=300, nburn=200, niter=100, p0=None, seed=None, **kwargs):
+        import torch
+        from .sampler import EnsembleSampler
+        rng = np.random.default_rng(seed)
+        npars = self.n_params
+        if p0 is None:
+            p0 = self.emcee_p0(nwalkers, rng=rng)
+        else:
+            p0 = rng.normal(size=(nwalkers, npars)) * 0.01 + np.asarray(p0, dtype=float)[None, :]
+        device = torch.device("cuda", dev.current_device())
+        sampler = EnsembleSampler(nwalkers, npars, self.lnpost, seed=int(rng.integers(2 ** 62)), device=device)
+        pos, prob = sampler.run_mcmc(p0, nburn, store=False)
+        sampler.reset()
+        sampler.run_mcmc(pos, niter, lnprob0=prob)
+        self._sampler = sampler
+        self._samples = None
+        return sampler
+
+    fit = fit_mcmc
+
+    @property
+    def sampler(self):
+        if getattr(self, "_sampler", None) is None:
+            raise AttributeError("MCMC must be run to access sampler")
+        return self._sampler
+
+    @property
+    def samples(self):
+        """Posterior samples as a DataFrame: the sampled parameters + lnprob (+ every model column
+        and band magnitude of a single star via ``ic(...)``, reference starmodel.py:1653-1714)."""
+        import pandas as pd
+        if getattr(self, "_samples", None) is None:
+            chain = self.sampler.flatchain.cpu().numpy()
+            df = pd.DataFrame(chain, columns=list(self.param_names))
+            df["lnprob"] = self.sampler.flatlnprobability.cpu().numpy()
+            if self.N == 1:
+                derived = self.ic(*[chain[:, j] for j in range(5)])
+                for c in derived.columns:
+                    if c not in df.columns:
+                        df[c] = derived[c].values
+            self._samples = df
+        return self._samples
+
+
 class SingleStarModel(BasicStarModel):
     def __init__(self, *args, **kwargs):
         kwargs["N"] = 1

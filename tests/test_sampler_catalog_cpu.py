@@ -1,0 +1,142 @@
+"""CPU tests of the host logic around the hot path: the stretch-move samplers (on CPU tensors with
+toy log-densities), the batch_starfit sharding rule, and the N>1 catalog path under a real
+world_size-2 `gloo` process group (fit function injected so no GPU is needed)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import isochrones_amd as ia
+from isochrones_amd.catalog import BatchedEnsembleSampler, result_columns
+from isochrones_amd.sampler import EnsembleSampler, summarize_chain
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_rule_matches_batch_starfit():
+    """scripts/batch_starfit:60-62: `awk "NR % NPROCS == i"` with 1-based NR."""
+    for world in (1, 2, 3, 8):
+        owners = [ia.shard_of(i, world) for i in range(50)]
+        assert owners == [(i + 1) % world for i in range(50)]
+        got = np.sort(np.concatenate([ia.shard_indices(50, r, world) for r in range(world)]))
+        assert np.array_equal(got, np.arange(50))          # a partition: every star exactly once
+        for r in range(world):
+            assert all(ia.shard_of(int(i), world) == r for i in ia.shard_indices(50, r, world))
+
+
+def test_ensemble_sampler_recovers_gaussian():
+    mu = torch.tensor([1.0, -2.0, 0.5], dtype=torch.float64)
+    sig = torch.tensor([0.5, 2.0, 0.1], dtype=torch.float64)
+    lnp = lambda x: -0.5 * (((x - mu) / sig) ** 2).sum(dim=1)
+    s = EnsembleSampler(40, 3, lnp, seed=3, device="cpu")
+    p0 = mu + 0.1 * torch.randn(40, 3, dtype=torch.float64, generator=torch.Generator().manual_seed(1))
+    pos, prob = s.run_mcmc(p0, 300, store=False)
+    s.reset()
+    s.run_mcmc(pos, 600, lnprob0=prob)
+    assert s.chain.shape == (40, 600, 3) and s.lnprobability.shape == (40, 600)
+    flat = s.flatchain.numpy()
+    assert np.allclose(flat.mean(axis=0), mu.numpy(), atol=0.15 * sig.numpy().max())
+    assert np.allclose(flat.std(axis=0), sig.numpy(), rtol=0.15)
+    acc = s.acceptance_fraction.numpy()
+    assert 0.2 < acc.mean() < 0.9
+    row = summarize_chain(s.flatchain, s.flatlnprobability)
+    assert row.shape == (10,) and abs(row[0] - 1.0) < 0.1
+
+
+def test_sampler_rejects_bad_start_and_nonfinite_proposals():
+    lnp = lambda x: torch.where(x[:, 0] > 0, -0.5 * (x ** 2).sum(dim=1), torch.full((x.shape[0],), -float("inf"),
+                                                                                dtype=torch.float64))
+    s = EnsembleSampler(8, 2, lnp, seed=0, device="cpu")
+    with pytest.raises(ValueError):
+        s.run_mcmc(-torch.ones(8, 2, dtype=torch.float64), 1)
+    pos, prob = s.run_mcmc(torch.rand(8, 2, dtype=torch.float64) + 0.1, 200)
+    assert bool((s.flatchain[:, 0] > 0).all())          # -inf proposals are never accepted
+
+
+def test_batched_sampler_independent_stars():
+    """S stars with different means advance in lock-step and do not mix."""
+    S, W, D = 5, 16, 2
+    centres = torch.arange(S, dtype=torch.float64)[:, None] * torch.tensor([10.0, -5.0], dtype=torch.float64)
+    def lnp(x, sid):
+        return -0.5 * ((x - centres[sid.long()]) ** 2).sum(dim=1)
+    s = BatchedEnsembleSampler(S, W, D, lnp, seed=5, device="cpu")
+    pos = centres[:, None, :] + 0.1 * torch.randn(S, W, D, dtype=torch.float64, generator=torch.Generator().manual_seed(2))
+    l0 = s.lnpost_all(pos)
+    s.run(pos, l0, 200)
+    chain, lnps = s.run(pos, l0, 300, keep=True)
+    assert chain.shape == (S, W, 300, D) and lnps.shape == (S, W, 300)
+    means = chain.reshape(S, -1, D).mean(dim=1)
+    assert torch.allclose(means, centres, atol=0.2)
+    stds = chain.reshape(S, -1, D).std(dim=1)
+    assert torch.allclose(stds, torch.ones_like(stds), rtol=0.2)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _gloo_worker(rank, world, port, n_stars, out_dir):
+    sys.path.insert(0, ROOT)
+    import pandas as pd
+    import torch.distributed as dist
+    import isochrones_amd as ia_
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    df = pd.DataFrame({"V_mag": np.linspace(8, 12, n_stars), "V_mag_unc": 0.02}, index=["s%03d" % i for i in range(n_stars)])
+    cat = ia_.StarCatalog(df, bands=["V"])
+    seen = []
+
+    def fake_fit(catalog, ic, indices, N=1, **kw):
+        seen.extend(int(i) for i in indices)
+        rows = np.zeros((len(indices), 3 * (N + 4) + 3))
+        rows[:, 0] = np.asarray(indices) * 10.0 + 1.0          # a value that identifies the star
+        rows[:, -3] = rank                                      # who fitted it
+        rows[:, -1] = 1.0
+        return rows
+
+    res = ia_.fit_catalog(cat, ic=None_IC(), N=1, fit_fn=fake_fit)
+    assert seen == [int(i) for i in ia_.shard_indices(n_stars, rank, world)]
+    res.to_pickle(os.path.join(out_dir, "res%d.pkl" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+class None_IC:
+    param_names = ("mass", "eep", "feh", "distance", "AV")
+
+
+@pytest.mark.parametrize("n_stars", [7, 16])
+def test_fit_catalog_world2_gloo(tmp_path, n_stars):
+    import pandas as pd
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_gloo_worker, args=(2, port, n_stars, str(tmp_path)), nprocs=2, join=True)
+    r0 = pd.read_pickle(tmp_path / "res0.pkl")
+    r1 = pd.read_pickle(tmp_path / "res1.pkl")
+    assert r0.equals(r1)                                        # all-gather: same table on every rank
+    assert list(r0.columns) == result_columns(None_IC.param_names)
+    assert np.array_equal(r0.iloc[:, 0].values, np.arange(n_stars) * 10.0 + 1.0)     # rows landed in order
+    assert np.array_equal(r0["lnpost_max"].values, (np.arange(n_stars) + 1) % 2)     # fitted by rank (i+1)%2
+    assert list(r0.index) == ["s%03d" % i for i in range(n_stars)]
+
+
+def test_star_catalog_schema():
+    import pandas as pd
+    df = pd.DataFrame({"J_mag": [9.0, 10.0], "J_mag_unc": [0.02, 0.03], "K_mag": [8.5, 9.4], "K_mag_unc": [0.02, 0.02],
+                       "parallax": [5.0, 2.0], "parallax_unc": [0.1, 0.1]})
+    cat = ia.StarCatalog(df, props=["parallax"])
+    assert cat.bands == ("J", "K") and len(cat) == 2
+    with pytest.raises(ValueError):
+        ia.StarCatalog(df.drop(columns=["K_mag_unc"]))
+    ic = ia.synthetic_isochrone(bands=("J", "K"), ages=[9.0, 9.5, 10.0], fehs=[-0.5, 0.0, 0.5], eeps=np.arange(300., 340.))
+    mods = list(cat.iter_models(ic, N=2))
+    assert len(mods) == 2 and mods[0].N == 2 and mods[1].bands == ["J", "K"]
+    assert mods[1].kwargs["parallax"] == (2.0, 0.1) and mods[1].bounds("distance") == (0, 1000.0)
