@@ -1,0 +1,198 @@
+#!/usr/bin/env python
+"""Secondary measurements for the other BASELINE.json configs (the driver's contract line is
+bench.py = configs[1]).  One JSON line per config:
+
+  cfg1  Sun-like single star, 1e4 lnpost samples on the CPU path (oracle, scalar-call / batch)
+  cfg3  binary (two-component flux sum), 6 bands + parallax, 1e6-sample batch, 1 GPU
+  cfg4  ensemble MCMC 256 walkers x 5000 steps with the GPU lnpost, wall-clock (+ CPU estimate)
+  cfg5  synthetic catalog, stars/s on the GPUs of this process group (weak scaling)
+
+    python bench_configs.py [--configs cfg1,cfg3,cfg4,cfg5] [--stars 10000]
+    python -m torch.distributed.run --nproc-per-node N bench_configs.py --configs cfg5
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0
+
+
+def _oracle_ic(ic):
+    from oracle import oracle as orc
+    m, b = ic.model_grid.interp, ic.bc_grid.interp
+    return orc.OracleIC(ic.kind, orc.OracleTable(m.grid, m.index_columns), orc.OracleTable(b.grid, b.index_columns),
+                        ic._cols, ic._prior_cols, ic._astero_cols)
+
+
+def _time_kernel(mod, pars_t, reps, warm=10):
+    import torch
+    from isochrones_amd import _cabi, device as dev
+    n = pars_t.shape[1]
+    out = torch.empty(n, dtype=torch.float64, device="cuda")
+    h = mod.handle(torch.cuda.current_device())
+    ms = C.c_double()
+    lib = _cabi.lib()
+    for r in (warm, reps):
+        _cabi.check(lib.iso_time_lnpost(h, dev.ptr(pars_t), 1, n, n, dev.ptr(out), r, dev.stream_ptr(), C.byref(ms)))
+    return ms.value, out
+
+
+def cfg1():
+    """The reference's own CPU-runnable case: 1e4 samples, Sun-like star, CPU path."""
+    import isochrones_amd as ia
+    import bench
+    ic, mod = bench.build_model()
+    rng = np.random.default_rng(12345)
+    pars = bench.make_samples(rng, 10_000, "posterior")
+    oic = _oracle_ic(ic)
+    desc = mod.model_desc()
+    soa = np.ascontiguousarray(pars.T)
+    oic.lnpost(desc, soa, parts=False)
+    t = time.perf_counter(); oic.lnpost(desc, soa, nthreads=1, parts=False); batch1 = time.perf_counter() - t
+    t = time.perf_counter()
+    for i in range(2000):                      # scalar-call mode: how the reference is really driven
+        oic.lnpost(desc, soa[:, i:i + 1], parts=False)
+    scalar = (time.perf_counter() - t) / 2000
+    return {"config": "cfg1", "metric": "CPU lnpost evals/s, 1e4 samples (C port of the reference, 1 thread)",
+            "batch_evals_per_s": 1e4 / batch1, "scalar_call_us": scalar * 1e6,
+            "reference_published_us_per_call": 69.0, "note": "published: notebooks/Overview.ipynb:738 (laptop, numba)"}
+
+
+def cfg3(n=1_000_000, reps=100):
+    import torch
+    import isochrones_amd as ia
+    bands = ("J", "H", "K", "BP", "RP", "G")
+    ic = ia.synthetic_isochrone(bands=bands)
+    mod = ia.BinaryStarModel(ic, J=(9.3, 0.02), H=(9.0, 0.02), K=(8.95, 0.02), BP=(10.7, 0.002), RP=(9.8, 0.002),
+                             G=(10.3, 0.001), parallax=(2.0, 0.05))
+    rng = np.random.default_rng(3)
+    out = {}
+    for workload in ("prior", "posterior"):
+        if workload == "prior":
+            lo = np.array([1.0, 1.0, 5.0, -4.0, 1.0, 0.0])
+            hi = np.array([1710.0, 1710.0, 10.3, 0.5, 1000.0, 1.0])
+            pars = rng.uniform(lo, hi, size=(n, 6))
+            pars[:, :2] = -np.sort(-pars[:, :2], axis=1)
+        else:
+            c = np.array([350.0, 300.0, 9.7, 0.0, 500.0, 0.2])
+            w = np.array([10.0, 10.0, 0.1, 0.1, 10.0, 0.05])
+            pars = c + w * rng.standard_normal((n, 6))
+            pars[:, 5] = np.abs(pars[:, 5])
+        pt = torch.as_tensor(np.ascontiguousarray(pars.T), device="cuda")
+        ms, res = _time_kernel(mod, pt, reps)
+        oic = _oracle_ic(ic)
+        ns = 50_000
+        t = time.perf_counter()
+        ref = oic.lnpost(mod.model_desc(), np.ascontiguousarray(pars[:ns].T), nthreads=os.cpu_count(), parts=False)
+        cpu = ns / (time.perf_counter() - t)
+        got = res[:ns].cpu().numpy()
+        fin = np.isfinite(ref)
+        rel = float(np.max(np.abs(got[fin] - ref[fin]) / np.maximum(1, np.abs(ref[fin])))) if fin.any() else 0.0
+        bytes_eval = 2 * 384 + 2 * 768 + 56
+        out[workload] = {"kernel_ms": ms, "evals_per_s": n / (ms * 1e-3), "achieved_GBs": bytes_eval * n / (ms * 1e-3) / 1e9,
+                         "frac_of_peak": bytes_eval * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "finite_fraction": float(fin.mean()),
+                         "cpu_all_cores_evals_per_s": cpu, "parity_max_rel_err": rel,
+                         "pattern_ok": bool(np.array_equal(np.isnan(got), np.isnan(ref)) and
+                                            np.array_equal(np.isneginf(got), np.isneginf(ref)))}
+    return {"config": "cfg3", "metric": "lnpost evals/s, binary 6 bands + parallax, 1e6 batch, 1 GPU",
+            "bytes_per_eval": 2360, "reference_published_us_per_call": 719.0, **out}
+
+
+def cfg4(nwalkers=256, nsteps=5000):
+    import torch
+    import bench
+    ic, mod = bench.build_model()
+    truth = np.array([1.0, 355.0, 0.0, 100.0, 0.1])
+    rng = np.random.default_rng(1)
+    p0 = truth + np.array([0.01, 2.0, 0.02, 1.0, 0.02]) * rng.standard_normal((nwalkers, 5))
+    p0[:, 4] = np.abs(p0[:, 4])
+    assert np.isfinite(mod.lnpost(p0)).all()
+    from isochrones_amd.sampler import EnsembleSampler
+    s = EnsembleSampler(nwalkers, 5, mod.lnpost, seed=2, device=torch.device("cuda"))
+    s.run_mcmc(p0, 20, store=False)                   # warm-up
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    pos, lp = s.run_mcmc(p0, nsteps, store=True)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t
+    acc = float(s.acceptance_fraction.mean())
+    # CPU side: the same number of lnpost calls one at a time through the C port
+    oic = _oracle_ic(ic)
+    desc = mod.model_desc()
+    soa = np.ascontiguousarray(p0.T)
+    t = time.perf_counter()
+    for i in range(2000):
+        oic.lnpost(desc, soa[:, i % nwalkers:i % nwalkers + 1], parts=False)
+    per_call = (time.perf_counter() - t) / 2000
+    calls = nwalkers * nsteps
+    return {"config": "cfg4", "metric": "wall-clock of a %d-walker x %d-step ensemble fit, GPU lnpost" % (nwalkers, nsteps),
+            "gpu_wall_s": wall, "lnpost_calls": calls, "us_per_step": wall / nsteps * 1e6, "acceptance": acc,
+            "cpu_scalar_call_us": per_call * 1e6, "cpu_estimated_wall_s": per_call * calls,
+            "reference_published_estimate_s": [69e-6 * calls, 719e-6 * calls]}
+
+
+def cfg5(n_stars=10_000, nwalkers=32, nburn=150, niter=100):
+    import torch
+    import torch.distributed as dist
+    import isochrones_amd as ia
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    bands = ["G", "BP", "RP"]
+    ic = ia.synthetic_track(bands=bands)
+    cat, truth = ia.synthetic_catalog(ic, n_stars, bands=bands, seed=7, mag_unc=0.01)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    res = ia.fit_catalog(cat, ic, nwalkers=nwalkers, nburn=nburn, niter=niter, seed=11 + rank)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    wall = time.perf_counter() - t
+    if world > 1:
+        tm = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        wall = float(tm[0])
+    ok = res["ok"].values == 1
+    rel_d = np.abs(res.loc[ok, "distance_median"].values - truth.loc[ok, "distance"].values) / truth.loc[ok, "distance"].values
+    out = {"config": "cfg5", "metric": "stars/s, synthetic catalog sharded over GPUs (batch_starfit path)",
+           "n_gpus": world, "n_stars": n_stars, "wall_s": wall, "stars_per_s": n_stars / wall,
+           "lnpost_evals": n_stars * nwalkers * (nburn + niter), "walkers": nwalkers, "steps": nburn + niter,
+           "ok_fraction": float(ok.mean()), "median_rel_distance_err": float(np.median(rel_d)),
+           "scaling": "weak/strong: fixed catalog split over ranks, no collective in the sampling loop"}
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return out if rank == 0 else None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--configs", default="cfg1,cfg3,cfg4,cfg5")
+    ap.add_argument("--stars", type=int, default=10_000)
+    args = ap.parse_args()
+    for name in args.configs.split(","):
+        fn = {"cfg1": cfg1, "cfg3": cfg3, "cfg4": cfg4, "cfg5": lambda: cfg5(args.stars)}[name.strip()]
+        r = fn()
+        if r is not None:
+            print(json.dumps(r), flush=True)
+
+
+if __name__ == "__main__":
+    main()
