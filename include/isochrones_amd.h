@@ -16,6 +16,7 @@
  *                       isochrones/starmodel.py:538-542,1563-1635; isochrones/likelihood.py:16-147;
  *                       isochrones/priors.py (default prior lnpdf's)
  *   iso_unit_cube    <- BasicStarModel.mnest_prior                  isochrones/starmodel.py:1637-1640
+ *   iso_eep_table_*, iso_interp_eep <- get_eep / interp_eeps      isochrones/models.py:501-542, interp.py:488-558
  *   iso_catalog_*    <- StarCatalog.iter_models + one lnpost per star  isochrones/catalog.py:126-139
  *
  * Conventions
@@ -151,6 +152,18 @@ int  iso_lnpost(iso_model* m, const double* pars, int64_t stride_n, int64_t stri
 
 /* mnest_prior: cube[i,p] <- lo_p + (hi_p - lo_p) * cube[i,p], in place (starmodel.py:1637-1640). */
 int  iso_unit_cube(iso_model* m, double* cube, int64_t stride_n, int64_t stride_p, int64_t n, void* stream);
+
+/* (mass, age, feh) -> EEP on the ragged per-track age arrays: the non-"accurate" get_eep of the
+ * reference (isochrones/models.py:501-542 -> interp_eeps, isochrones/interp.py:488-558).
+ * ages[n0*n1][n_eep] = log10 age along every (feh, mass) track (HOST, copied), lengths[n0*n1] =
+ * populated points per track, eep0 = EEP of array index 0 (1 for MIST).  x = age, x0 = feh,
+ * x1 = mass (DEVICE arrays). */
+typedef struct iso_eep_table iso_eep_table;
+int  iso_eep_table_create(iso_ctx* ctx, const double* ages, const int64_t* lengths, const double* ax0, int64_t n0,
+                          const double* ax1, int64_t n1, int64_t n_eep, double eep0, iso_eep_table** out);
+void iso_eep_table_destroy(iso_eep_table* t);
+int  iso_interp_eep(iso_eep_table* t, const double* x, const double* x0, const double* x1, int64_t n, double* out,
+                    void* stream);
 
 /* A catalog = many independent systems observed in the same bands with the same multiplicity
  * (reference: isochrones/catalog.py:19-139 StarCatalog.iter_models; scripts/batch_starfit shards

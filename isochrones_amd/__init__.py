@@ -9,6 +9,6 @@ from .models import (ModelGridInterpolator, EvolutionTrackInterpolator, Isochron
 from .starmodel import (BasicStarModel, StarModel, SingleStarModel, BinaryStarModel, TripleStarModel)
 from .sampler import EnsembleSampler
 from .catalog import StarCatalog, CatalogPosterior, fit_catalog, synthetic_catalog, shard_of, shard_indices
-from . import priors, grids
+from . import priors, grids, ingest
 
 __version__ = "0.1.0"

@@ -67,6 +67,7 @@ EXPORTED_SYMBOLS = (
     "iso_model_create", "iso_model_destroy", "iso_model_n_params",
     "iso_lnpost", "iso_unit_cube", "iso_time_lnpost",
     "iso_catalog_create", "iso_catalog_destroy", "iso_catalog_lnpost",
+    "iso_eep_table_create", "iso_eep_table_destroy", "iso_interp_eep",
 )
 
 _LIB = None
@@ -130,6 +131,11 @@ def lib():
     L.iso_catalog_destroy.argtypes = [vp]
     L.iso_catalog_destroy.restype = None
     L.iso_catalog_lnpost.argtypes = [vp, pd, pd, i64, i64, i64, pd, vp]
+    L.iso_eep_table_create.argtypes = [vp, C.POINTER(dbl), C.POINTER(i64), C.POINTER(dbl), i64, C.POINTER(dbl), i64,
+                                       i64, dbl, C.POINTER(vp)]
+    L.iso_eep_table_destroy.argtypes = [vp]
+    L.iso_eep_table_destroy.restype = None
+    L.iso_interp_eep.argtypes = [vp, pd, pd, pd, i64, pd, vp]
     for name in EXPORTED_SYMBOLS:
         fn = getattr(L, name)
         if fn.restype is C.c_int:

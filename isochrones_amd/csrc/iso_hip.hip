@@ -646,6 +646,76 @@ __global__ __launch_bounds__(BLOCK) void k_lnpost(const PostArgs A)
 }
 
 // -------------------------------------------------------------------------------------------
+// "next" row f2: (age, feh, mass) -> EEP on the ragged per-track age arrays
+// (reference semantics: isochrones/interp.py:488-558 interp_eep / interp_eeps)
+// -------------------------------------------------------------------------------------------
+struct EepArgs {
+    AxisD ax[2];              // feh, mass
+    const double* ages;       // [n0*n1][n_eep], NaN past `lengths`
+    const int64_t* lengths;   // [n0*n1]
+    int n1;
+    int64_t n_eep;
+    double eep0;              // EEP of array index 0 (1 for MIST)
+    const double *x, *x0, *x1;
+    int64_t n;
+    double* out;
+};
+
+// number of elements of arr[0..N) that are < x  (== the reference's searchsorted L)
+__device__ __forceinline__ int64_t count_less(const double* __restrict__ arr, double x, int64_t N)
+{
+    int64_t base = 0, len = N;
+    if (N <= 0) return 0;
+    while (len > 1) {                       // base = largest index with arr[base] < x, or 0
+        const int64_t half = len >> 1;
+        base = (arr[base + half] < x) ? base + half : base;
+        len -= half;
+    }
+    return (arr[base] < x) ? base + 1 : base;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_interp_eep(const EepArgs A)
+{
+    extern __shared__ double lds[];
+    stage_axes<2>(A.ax, lds);
+    __syncthreads();
+    const int64_t stride_grid = (int64_t)gridDim.x * BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < A.n; i += stride_grid) {
+        const double x = A.x[i], x0 = A.x0[i], x1 = A.x1[i];
+        double r = d_nan();
+        if (!(x != x || x0 != x0 || x1 != x1) && !out_of_axis(A.ax[0], lds, x0) && !out_of_axis(A.ax[1], lds, x1)) {
+            int i0, i1;
+            double d0, d1;
+            bracket(A.ax[0], lds, x0, i0, d0);
+            bracket(A.ax[1], lds, x1, i1, d1);
+            const int64_t ind[4] = {(int64_t)i0 * A.n1 + i1, (int64_t)i0 * A.n1 + i1 + 1,
+                                    (int64_t)(i0 + 1) * A.n1 + i1, (int64_t)(i0 + 1) * A.n1 + i1 + 1};
+            int64_t ie[4], len[4];
+            bool bad = false;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                len[k] = A.lengths[ind[k]];
+                ie[k] = count_less(A.ages + ind[k] * A.n_eep, x, len[k]);
+                bad |= ie[k] > A.n_eep - 1;
+            }
+            if (!bad) {
+                double e[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) e[k] = A.eep0 + (double)ie[k];
+                if (ie[0] >= len[0]) e[0] = e[1];      // sequential substitution, as the reference
+                if (ie[1] >= len[1]) e[1] = e[0];
+                if (ie[2] >= len[2]) e[2] = e[3];
+                if (ie[3] >= len[3]) e[3] = e[2];
+                const double e_0 = (1 - d1) * e[0] + d1 * e[1];
+                const double e_1 = (1 - d1) * e[2] + d1 * e[3];
+                r = (1 - d0) * e_0 + d0 * e_1;
+            }
+        }
+        A.out[i] = r;
+    }
+}
+
+// -------------------------------------------------------------------------------------------
 // small kernels
 // -------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(BLOCK) void k_unit_cube(const DevModel* m, double* cube, int64_t stride_n,
@@ -909,6 +979,15 @@ hipError_t pack_corners(const double* src, int ncol, int keep, int ndim, const i
 // ======================================================================================
 // C ABI
 // ======================================================================================
+struct iso_eep_table {
+    int device;
+    int64_t n0, n1, n_eep;
+    double eep0;
+    double *d_ages, *d_ax0, *d_ax1;
+    int64_t* d_lengths;
+    AxisD ax[2];
+};
+
 extern "C" {
 
 const char* iso_last_error(void) { return g_err.c_str(); }
@@ -1444,6 +1523,82 @@ int iso_unit_cube(iso_model* m, double* cube, int64_t stride_n, int64_t stride_p
     DeviceGuard guard(m->ic->ctx->device);
     hipLaunchKernelGGL(k_unit_cube, dim3(grid_blocks(n * (m->desc.n_stars + 4))), dim3(BLOCK), 0, as_stream(stream),
                        m->d_model, cube, stride_n, stride_p, n);
+    HIP_TRY(hipGetLastError());
+    return ISO_OK;
+}
+
+int iso_eep_table_create(iso_ctx* ctx, const double* ages, const int64_t* lengths, const double* ax0, int64_t n0,
+                         const double* ax1, int64_t n1, int64_t n_eep, double eep0, iso_eep_table** out)
+{
+    if (!ctx || !ages || !lengths || !ax0 || !ax1 || !out) return fail(ISO_ERR_INVALID, "iso_eep_table_create: NULL argument");
+    if (n0 < 2 || n1 < 2 || n_eep < 1) return fail(ISO_ERR_INVALID, "iso_eep_table_create: bad shape");
+    for (int64_t j = 1; j < n0; ++j)
+        if (!(ax0[j - 1] < ax0[j])) return fail(ISO_ERR_INVALID, "iso_eep_table_create: axis 0 not increasing");
+    for (int64_t j = 1; j < n1; ++j)
+        if (!(ax1[j - 1] < ax1[j])) return fail(ISO_ERR_INVALID, "iso_eep_table_create: axis 1 not increasing");
+    for (int64_t j = 0; j < n0 * n1; ++j)
+        if (lengths[j] < 0 || lengths[j] > n_eep) return fail(ISO_ERR_INVALID, "iso_eep_table_create: bad track length");
+    DeviceGuard guard(ctx->device);
+    iso_eep_table* t = new (std::nothrow) iso_eep_table();
+    if (!t) return fail(ISO_ERR_NOMEM, "iso_eep_table_create: out of host memory");
+    t->device = ctx->device;
+    t->n0 = n0; t->n1 = n1; t->n_eep = n_eep; t->eep0 = eep0;
+    t->d_ages = t->d_ax0 = t->d_ax1 = nullptr;
+    t->d_lengths = nullptr;
+    const size_t nt = (size_t)(n0 * n1);
+    hipError_t e = hipMalloc(&t->d_ages, nt * n_eep * sizeof(double));
+    if (e == hipSuccess) e = hipMemcpy(t->d_ages, ages, nt * n_eep * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc(&t->d_lengths, nt * sizeof(int64_t));
+    if (e == hipSuccess) e = hipMemcpy(t->d_lengths, lengths, nt * sizeof(int64_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc(&t->d_ax0, n0 * sizeof(double));
+    if (e == hipSuccess) e = hipMemcpy(t->d_ax0, ax0, n0 * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc(&t->d_ax1, n1 * sizeof(double));
+    if (e == hipSuccess) e = hipMemcpy(t->d_ax1, ax1, n1 * sizeof(double), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        std::string msg = std::string("iso_eep_table_create: ") + hipGetErrorString(e);
+        iso_eep_table_destroy(t);
+        return fail(e == hipErrorOutOfMemory ? ISO_ERR_NOMEM : ISO_ERR_HIP, msg);
+    }
+    t->ax[0] = AxisD{t->d_ax0, (int)n0, -1, 0, 0.0, 0.0};
+    t->ax[1] = AxisD{t->d_ax1, (int)n1, -1, 0, 0.0, 0.0};
+    (void)assign_lds(t->ax, 2, nullptr, 0);
+    *out = t;
+    return ISO_OK;
+}
+
+void iso_eep_table_destroy(iso_eep_table* t)
+{
+    if (!t) return;
+    DeviceGuard guard(t->device);
+    if (t->d_ages) (void)hipFree(t->d_ages);
+    if (t->d_lengths) (void)hipFree(t->d_lengths);
+    if (t->d_ax0) (void)hipFree(t->d_ax0);
+    if (t->d_ax1) (void)hipFree(t->d_ax1);
+    delete t;
+}
+
+int iso_interp_eep(iso_eep_table* t, const double* x, const double* x0, const double* x1, int64_t n, double* out,
+                   void* stream)
+{
+    if (!t || ((!x || !x0 || !x1 || !out) && n > 0)) return fail(ISO_ERR_INVALID, "iso_interp_eep: NULL argument");
+    if (n < 0) return fail(ISO_ERR_INVALID, "iso_interp_eep: n < 0");
+    if (n == 0) return ISO_OK;
+    EepArgs A;
+    A.ax[0] = t->ax[0];
+    A.ax[1] = t->ax[1];
+    A.ages = t->d_ages;
+    A.lengths = t->d_lengths;
+    A.n1 = (int)t->n1;
+    A.n_eep = t->n_eep;
+    A.eep0 = t->eep0;
+    A.x = x; A.x0 = x0; A.x1 = x1;
+    A.n = n;
+    A.out = out;
+    int lds = 0;
+    for (int d = 0; d < 2; ++d)
+        if (A.ax[d].lds_off >= 0) lds += A.ax[d].n;
+    DeviceGuard guard(t->device);
+    hipLaunchKernelGGL(k_interp_eep, dim3(grid_blocks(n)), dim3(BLOCK), (size_t)lds * sizeof(double), as_stream(stream), A);
     HIP_TRY(hipGetLastError());
     return ISO_OK;
 }

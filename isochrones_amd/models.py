@@ -145,6 +145,9 @@ class ModelGridInterpolator:
             _cabi.lib().iso_ic_destroy(h)
         self._handles = {}
         self._handle_tables = {}
+        for h in getattr(self, "_eep_handles", {}).values():
+            _cabi.lib().iso_eep_table_destroy(h)
+        self._eep_handles = {}
 
     def __del__(self):
         try:
@@ -231,6 +234,86 @@ class ModelGridInterpolator:
     def density(self, *pars): return self._prop("density", *pars)
     def nu_max(self, *pars): return self._prop("nu_max", *pars)
     def delta_nu(self, *pars): return self._prop("delta_nu", *pars)
+
+    # -- (mass, age, feh) -> EEP ("next" row f2; reference: models.py:501-542) --------------
+    def _eep_handle(self, device):
+        if self.eep_replaces != "age":
+            raise NotImplementedError("get_eep needs the evolution-track parametrisation (as the reference)")
+        h = getattr(self, "_eep_handles", {}).get(device)
+        if h is None:
+            from .ingest import ragged_age_arrays
+            dfi = self.model_grid.interp
+            ages, lengths = ragged_age_arrays(dfi, "age")
+            self._age_grid, self._array_lengths = ages, lengths
+            dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int64)
+            fehs, masses, eeps = dfi.index_columns
+            h = C.c_void_p()
+            _cabi.check(_cabi.lib().iso_eep_table_create(
+                dev.context(device), ages.ctypes.data_as(dp), lengths.ctypes.data_as(ip), fehs.ctypes.data_as(dp),
+                fehs.size, masses.ctypes.data_as(dp), masses.size, ages.shape[1], float(eeps[0]), C.byref(h)))
+            if not hasattr(self, "_eep_handles"):
+                self._eep_handles = {}
+            self._eep_handles[device] = h
+        return h
+
+    def get_eep(self, mass, age, feh, accurate=False, **kwargs):
+        """EEP of a star of given (mass, log10 age, feh): bilinear blend over the four neighbouring
+        tracks of the first EEP whose age exceeds ``age`` (reference ``interp_eep(s)``).  Scalars
+        -> float, arrays -> numpy, CUDA tensors -> CUDA tensor.  ``accurate=True`` (the reference's
+        Nelder-Mead refinement) is not provided."""
+        if accurate:
+            raise NotImplementedError("get_eep(accurate=True) is out of scope (host-side scipy minimisation)")
+        args = [mass, age, feh]
+        if any(dev.is_tensor(a) and a.is_cuda for a in args):
+            import torch
+            device = next(a.device.index for a in args if dev.is_tensor(a) and a.is_cuda)
+            m, a, f = [t.reshape(-1).contiguous() for t in
+                       torch.broadcast_tensors(*[dev.to_device_f64(x, device) for x in args])]
+            out = dev.empty_f64((m.numel(),), device)
+            _cabi.check(_cabi.lib().iso_interp_eep(self._eep_handle(device), dev.ptr(a), dev.ptr(f), dev.ptr(m),
+                                                   m.numel(), dev.ptr(out), dev.stream_ptr(device)))
+            return out
+        device = dev.current_device()
+        scalar = all(isinstance(x, (float, int, np.floating, np.integer)) for x in args)
+        b = np.broadcast(*args)
+        m, a, f = [dev.to_device_f64(np.atleast_1d(np.resize(x, b.shape)).astype(float).ravel(), device) for x in args]
+        out = dev.empty_f64((m.numel(),), device)
+        _cabi.check(_cabi.lib().iso_interp_eep(self._eep_handle(device), dev.ptr(a), dev.ptr(f), dev.ptr(m),
+                                               m.numel(), dev.ptr(out), dev.stream_ptr(device)))
+        res = out.cpu().numpy()
+        return float(res[0]) if scalar else res
+
+    def generate(self, mass, age, feh, props="all", bands=None, eeps=None, distance=10, AV=0, **kwargs):
+        """Model columns + magnitudes of stars given (mass, log10 age, feh) as a DataFrame
+        (reference: models.py:580-631, DataFrame form)."""
+        import pandas as pd
+        mass, age, feh, distance, AV = [np.atleast_1d(a).astype(float).ravel()
+                                        for a in np.broadcast_arrays(mass, age, feh, distance, AV)]
+        bands = self.bands if bands is None else list(bands)
+        if eeps is None:
+            eeps = np.atleast_1d(self.get_eep(mass, age, feh, **kwargs))
+        cols = list(self.model_grid.interp.columns) if props == "all" else list(props)
+        values = np.atleast_2d(self.interp_value([mass, eeps, feh], cols))
+        out = pd.DataFrame(values, columns=cols)
+        if bands:
+            _, _, _, mags = self.interp_mag([mass, eeps, feh, distance, AV], bands)
+            for j, b in enumerate(bands):
+                out["{}_mag".format(b)] = np.atleast_2d(mags)[:, j]
+        out["distance"] = distance
+        out["AV"] = AV
+        out["initial_feh"] = feh
+        out["requested_age"] = age
+        return out
+
+    def model_value(self, mass, age, feh, props):
+        props = [props] if isinstance(props, str) else list(props)
+        eep = self.get_eep(mass, age, feh)
+        return np.squeeze(self.interp_value([mass, eep, feh], props))
+
+    def model_mag(self, mass, age, feh, distance=10.0, AV=0.0, bands=None):
+        bands = self.bands if bands is None else list(bands)
+        eep = self.get_eep(mass, age, feh)
+        return np.squeeze(self.interp_mag([mass, eep, feh, distance, AV], bands)[3])
 
     def __call__(self, p1, p2, p3, distance=10.0, AV=0.0):
         """All model columns + every band's magnitude, as a DataFrame

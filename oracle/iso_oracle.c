@@ -550,3 +550,58 @@ int orc_max_threads(void)
     return 1;
 #endif
 }
+
+/* ---------------------------------------------------------------------------------------
+ * "next" row f2 — reference: isochrones/interp.py:488-558  interp_eep / interp_eeps
+ * (mass, age, feh) -> EEP on the ragged per-track age arrays.
+ *   ages[n0*n1][n_eep]  log10 age along every (feh, mass) track, NaN past `lengths`
+ *   x = age, x0 = feh (axis ax0), x1 = mass (axis ax1)
+ * The reference reads, but never uses, the dt_deep weights; the substitution chain for tracks
+ * that end before `x` is sequential, exactly as written there.
+ * ------------------------------------------------------------------------------------- */
+static int64_t orc_count_less(const double* arr, double x, int64_t N)
+{
+    int eq;
+    if (N <= 0) return 0;
+    return orc_searchsorted(arr, x, N, &eq);
+}
+
+double orc_interp_eep1(double x, double x0, double x1, const double* ax0, int64_t n0, const double* ax1,
+                       int64_t n1, const double* ages, const int64_t* lengths, int64_t n_eep)
+{
+    if (x != x || x0 != x0 || x1 != x1) return NAN;
+    orc_table T;
+    T.ndim = 2;
+    T.shape[0] = n0; T.shape[1] = n1; T.shape[2] = 1;
+    T.grid = NULL;
+    T.axes[0] = ax0; T.axes[1] = ax1;
+    double xs[2] = {x0, x1};
+    int64_t idx[ORC_MAX_DIM];
+    double d[ORC_MAX_DIM];
+    if (orc_find_indices(&T, xs, idx, d)) return NAN;
+    const int64_t i0 = idx[0], i1 = idx[1];
+    const int64_t ind[4] = {i0 * n1 + i1, i0 * n1 + (i1 + 1), (i0 + 1) * n1 + i1, (i0 + 1) * n1 + (i1 + 1)};
+    int64_t ie[4];
+    for (int k = 0; k < 4; ++k) ie[k] = orc_count_less(ages + ind[k] * n_eep, x, lengths[ind[k]]);
+    const int64_t max_i = n_eep - 1;
+    for (int k = 0; k < 4; ++k)
+        if (ie[k] > max_i) return NAN;
+    double e[4];
+    for (int k = 0; k < 4; ++k) e[k] = (double)(ie[k] + 1);
+    if (ie[0] >= lengths[ind[0]]) e[0] = e[1];
+    if (ie[1] >= lengths[ind[1]]) e[1] = e[0];
+    if (ie[2] >= lengths[ind[2]]) e[2] = e[3];
+    if (ie[3] >= lengths[ind[3]]) e[3] = e[2];
+    const double d0 = d[0], d1 = d[1];
+    const double eep_0 = (1 - d1) * e[0] + d1 * e[1];
+    const double eep_1 = (1 - d1) * e[2] + d1 * e[3];
+    return (1 - d0) * eep_0 + d0 * eep_1;
+}
+
+void orc_interp_eep(const double* x, const double* x0, const double* x1, int64_t n, const double* ax0, int64_t n0,
+                    const double* ax1, int64_t n1, const double* ages, const int64_t* lengths, int64_t n_eep,
+                    double* out)
+{
+    for (int64_t i = 0; i < n; ++i)
+        out[i] = orc_interp_eep1(x[i], x0[i], x1[i], ax0, n0, ax1, n1, ages, lengths, n_eep);
+}

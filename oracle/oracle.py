@@ -63,6 +63,9 @@ def lib():
         L.orc_unit_cube.argtypes = [C.POINTER(_cabi.IsoModelDesc), C.c_int, dp, C.c_int64, C.c_int64, C.c_int64]
         L.orc_unit_cube.restype = None
         L.orc_max_threads.restype = C.c_int
+        i64p = C.POINTER(C.c_int64)
+        L.orc_interp_eep.argtypes = [dp, dp, dp, C.c_int64, dp, C.c_int64, dp, C.c_int64, dp, i64p, C.c_int64, dp]
+        L.orc_interp_eep.restype = None
         _lib = L
     return _lib
 
@@ -153,3 +156,17 @@ def unit_cube(desc, kind, cube):
 
 def max_threads():
     return lib().orc_max_threads()
+
+
+def interp_eep(age, feh, mass, fehs, masses, age_grid, lengths):
+    """reference interp_eeps(xs=age, x0s=feh, x1s=mass, ...): EEP on the ragged age arrays."""
+    age, feh, mass = (np.ascontiguousarray(np.atleast_1d(a), dtype=np.float64) for a in (age, feh, mass))
+    fehs = np.ascontiguousarray(fehs, dtype=np.float64)
+    masses = np.ascontiguousarray(masses, dtype=np.float64)
+    age_grid = np.ascontiguousarray(age_grid, dtype=np.float64)
+    lengths = np.ascontiguousarray(lengths, dtype=np.int64)
+    assert age_grid.shape[0] == fehs.size * masses.size and lengths.size == age_grid.shape[0]
+    out = np.empty(age.size)
+    lib().orc_interp_eep(_dp(age), _dp(feh), _dp(mass), age.size, _dp(fehs), fehs.size, _dp(masses), masses.size,
+                         _dp(age_grid), lengths.ctypes.data_as(C.POINTER(C.c_int64)), age_grid.shape[1], _dp(out))
+    return out

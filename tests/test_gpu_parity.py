@@ -214,3 +214,66 @@ def test_errors_are_loud():
         ia.BinaryStarModel(ic, V=(10, 0.1))      # multiples need the isochrone parametrisation
     rc = _cabi.lib().iso_lnpost(None, None, 1, 1, 0, None, None, None, None)
     assert rc == -1 and b"NULL" in _cabi.lib().iso_last_error()
+
+
+def test_get_eep_and_generate():
+    """'next' row f2: get_eep (interp_eeps) vs the reference golden and the oracle; generate()."""
+    import torch
+    from oracle import oracle as orc
+    g = fx.load("interp_eep")
+    fehs, masses = g["fehs"], g["masses"]
+    n_eep = g["ages"].shape[1]
+    # rebuild a track interpolator whose `age` column is the fixture's ragged array
+    grid, ax, cols = ia.grids.synthetic_track_grid(fehs, masses, np.arange(1.0, n_eep + 1.0))
+    grid[..., cols.index("age")] = g["ages"].reshape(fehs.size, masses.size, n_eep)
+    grid[np.isnan(grid[..., cols.index("age")])] = np.nan
+    from isochrones_amd.models import EvolutionTrackGrid, EvolutionTrackInterpolator, BolometricCorrectionGrid
+    bcg, bax, bands = ia.grids.synthetic_bc_grid(("G",))
+    ic = EvolutionTrackInterpolator(EvolutionTrackGrid(DFInterpolator.from_arrays(grid, ax, cols)),
+                                    BolometricCorrectionGrid(DFInterpolator.from_arrays(bcg, bax, bands), bands=bands),
+                                    bands=bands)
+    got = ic.get_eep(g["mass"], g["age"], g["feh"])
+    fx.assert_close(got, g["eep"], 1e-12, what="get_eep vs reference")
+    dev_out = ic.get_eep(torch.as_tensor(g["mass"], device="cuda"), torch.as_tensor(g["age"], device="cuda"),
+                         torch.as_tensor(g["feh"], device="cuda"))
+    fx.assert_close(dev_out.cpu().numpy(), g["eep"], 1e-12, what="get_eep device")
+    k = int(np.flatnonzero(np.isfinite(g["eep"]))[0])
+    v = ic.get_eep(float(g["mass"][k]), float(g["age"][k]), float(g["feh"][k]))
+    assert isinstance(v, float) and np.isclose(v, g["eep"][k], rtol=1e-12)
+    # a larger random batch against the oracle
+    rng = np.random.default_rng(5)
+    n = 100_000
+    m, a, f = rng.uniform(0.45, 7.3, n), rng.uniform(4.8, 11.0, n), rng.uniform(-1.1, 0.55, n)
+    want = orc.interp_eep(a, f, m, fehs, masses, ic._age_grid, ic._array_lengths)
+    fx.assert_close(ic.get_eep(m, a, f), want, 1e-12, what="get_eep vs oracle")
+    # generate(): columns consistent with interp_value / interp_mag at the interpolated EEP
+    ok = np.flatnonzero(np.isfinite(want))[:50]
+    df = ic.generate(m[ok], a[ok], f[ok], distance=100.0, AV=0.1)
+    assert {"Teff", "logg", "age", "G_mag", "distance", "requested_age"} <= set(df.columns) and len(df) == 50
+    T = ic.interp_value([m[ok], want[ok], f[ok]], ["Teff"])[:, 0]
+    fx.assert_close(df["Teff"].values, T, 1e-12, what="generate Teff")
+    with pytest.raises(NotImplementedError):
+        ia.synthetic_isochrone(bands=("G",), ages=[9.0, 9.5], fehs=[-0.5, 0.0], eeps=np.arange(1., 9.)).get_eep(1.0, 9.2, 0.0)
+
+
+def test_ingest_derived_columns():
+    """'next' row f1: dt_deep / dm_deep as np.gradient over the populated points of each track."""
+    from isochrones_amd import ingest
+    g, ax, cols = ia.grids.synthetic_track_grid([-0.5, 0.0], [0.5, 1.0, 2.0], np.arange(1.0, 500.0))
+    keep = [c for c in cols if c != "dt_deep"]
+    dfi = DFInterpolator.from_arrays(g[..., [cols.index(c) for c in keep]], ax, keep)
+    ingest.add_dt_deep(dfi)
+    assert dfi.columns[-1] == "dt_deep"
+    d = dfi.grid[..., -1]
+    for i in range(2):
+        for j in range(3):
+            sa = dfi.grid[i, j, :, dfi.column_index["star_age"]]
+            okk = ~np.isnan(sa)
+            want = np.gradient(np.log10(sa[okk]), ax[2][okk])
+            assert np.allclose(d[i, j, okk], want, rtol=1e-13) and np.isnan(d[i, j, ~okk]).all()
+    analytic = g[..., cols.index("dt_deep")]
+    inner = ~np.isnan(analytic)
+    assert np.nanmax(np.abs(d[inner] - analytic[inner])) < 1e-3
+    # the table with the appended column serves queries after the (lazy) re-upload
+    v = dfi([0.0, 1.0, 250.0], ["dt_deep"])
+    assert np.isclose(v[0], d[1, 1, 249], rtol=1e-12)

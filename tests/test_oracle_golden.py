@@ -94,3 +94,11 @@ def test_threads_agree():
     a = oic.lnpost(mod.model_desc(), g["pars"].T.copy(), nthreads=1, parts=False)
     b = oic.lnpost(mod.model_desc(), g["pars"].T.copy(), nthreads=max(2, orc.max_threads()), parts=False)
     assert np.array_equal(a, b, equal_nan=True)
+
+
+def test_interp_eep_vs_reference():
+    """'next' row f2: the oracle's interp_eep against the reference's interp_eeps."""
+    g = fx.load("interp_eep")
+    got = orc.interp_eep(g["age"], g["feh"], g["mass"], g["fehs"], g["masses"], g["ages"], g["lengths"])
+    fx.assert_close(got, g["eep"], 1e-13, what="interp_eep")
+    assert np.isnan(g["eep"]).any() and np.isfinite(g["eep"]).sum() > 1000
