@@ -17,6 +17,7 @@
  *                       isochrones/priors.py (default prior lnpdf's)
  *   iso_unit_cube    <- BasicStarModel.mnest_prior                  isochrones/starmodel.py:1637-1640
  *   iso_eep_table_*, iso_interp_eep <- get_eep / interp_eeps      isochrones/models.py:501-542, interp.py:488-558
+ *   iso_sampler_*    <- emcee.EnsembleSampler driven by lnpost        isochrones/starmodel.py:886-972
  *   iso_catalog_*    <- StarCatalog.iter_models + one lnpost per star  isochrones/catalog.py:126-139
  *
  * Conventions
@@ -173,6 +174,21 @@ int  iso_catalog_create(iso_ic* ic, const iso_model_desc* descs, int64_t n_model
 void iso_catalog_destroy(iso_catalog* c);
 int  iso_catalog_lnpost(iso_catalog* c, const int32_t* star_id, const double* pars, int64_t stride_n,
                         int64_t stride_p, int64_t n, double* lnpost_out, void* stream);
+
+/* Device-resident affine-invariant ensemble sampler (stretch move, Goodman & Weare 2010) — what the
+ * reference obtains from emcee.EnsembleSampler(nwalkers, npars, self.lnpost).run_mcmc(...)
+ * (isochrones/starmodel.py:951-969), with the proposal, the fused lnpost and the accept step in one
+ * kernel per half-ensemble.  pos [n_ens*W, n_params] row-major and lnp [n_ens*W] are DEVICE arrays
+ * updated in place (lnp must hold lnpost(pos) on entry); chain [nsteps][n_ens*W][n_params],
+ * chain_lnp [nsteps][n_ens*W] and accepted [n_ens*W] (int32 counters) are optional DEVICE outputs.
+ * n_ens = 1 for a model, = n_models for a catalog (row = star*W + walker).  The model / catalog
+ * handle must outlive the sampler. */
+typedef struct iso_sampler iso_sampler;
+int  iso_sampler_create_model(iso_model* m, int nwalkers, double a, uint64_t seed, iso_sampler** out);
+int  iso_sampler_create_catalog(iso_catalog* c, int nwalkers, double a, uint64_t seed, iso_sampler** out);
+void iso_sampler_destroy(iso_sampler* s);
+int  iso_sampler_run(iso_sampler* s, double* pos, double* lnp, int nsteps, double* chain, double* chain_lnp,
+                     int32_t* accepted, void* stream);
 
 /* Time `reps` back-to-back iso_lnpost launches with hipEvents on `stream`; returns the mean
  * milliseconds per launch in *ms_per_launch (measurement helper for bench.py). */

@@ -68,6 +68,7 @@ EXPORTED_SYMBOLS = (
     "iso_lnpost", "iso_unit_cube", "iso_time_lnpost",
     "iso_catalog_create", "iso_catalog_destroy", "iso_catalog_lnpost",
     "iso_eep_table_create", "iso_eep_table_destroy", "iso_interp_eep",
+    "iso_sampler_create_model", "iso_sampler_create_catalog", "iso_sampler_destroy", "iso_sampler_run",
 )
 
 _LIB = None
@@ -136,6 +137,11 @@ def lib():
     L.iso_eep_table_destroy.argtypes = [vp]
     L.iso_eep_table_destroy.restype = None
     L.iso_interp_eep.argtypes = [vp, pd, pd, pd, i64, pd, vp]
+    L.iso_sampler_create_model.argtypes = [vp, C.c_int, dbl, C.c_uint64, C.POINTER(vp)]
+    L.iso_sampler_create_catalog.argtypes = [vp, C.c_int, dbl, C.c_uint64, C.POINTER(vp)]
+    L.iso_sampler_destroy.argtypes = [vp]
+    L.iso_sampler_destroy.restype = None
+    L.iso_sampler_run.argtypes = [vp, pd, pd, C.c_int, pd, pd, pd, vp]
     for name in EXPORTED_SYMBOLS:
         fn = getattr(L, name)
         if fn.restype is C.c_int:

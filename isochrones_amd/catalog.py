@@ -72,21 +72,96 @@ class StarCatalog:
 
 
 class CatalogPosterior:
-    """Device-resident posteriors of many stars sharing bands and multiplicity."""
+    """Device-resident posteriors of many stars sharing bands and multiplicity.
 
-    def __init__(self, ic, models, device=None):
-        if not models:
-            raise ValueError("no models")
+    Build it from a list of models, or — without creating one Python object per star — from a
+    :class:`StarCatalog` with :meth:`from_catalog` (descriptor records filled column-wise)."""
+
+    def __init__(self, ic, models=None, device=None, _descs=None, _template=None):
         self.ic = ic
-        self.models = list(models)
-        self.n_models = len(self.models)
-        self.n_params = self.models[0].n_params
-        self.param_names = self.models[0].param_names
         self.device = dev.current_device() if device is None else device
-        descs = (_cabi.IsoModelDesc * self.n_models)(*[m.model_desc() for m in self.models])
+        if _descs is None:
+            if not models:
+                raise ValueError("no models")
+            self.models = list(models)
+            template = self.models[0]
+            descs = (_cabi.IsoModelDesc * len(self.models))(*[m.model_desc() for m in self.models])
+            arr = np.frombuffer(descs, dtype=np.dtype(_cabi.IsoModelDesc))
+        else:
+            self.models = None
+            template = _template
+            arr = _descs
+            descs = (_cabi.IsoModelDesc * arr.shape[0]).from_buffer(arr)
+        self.template = template
+        self.n_models = int(arr.shape[0])
+        self.n_params = template.n_params
+        self.param_names = template.param_names
+        D = self.n_params
+        self.bounds_lo = np.array(arr["bound_lo"][:, :D])
+        self.bounds_hi = np.array(arr["bound_hi"][:, :D])
+        has = arr["has_parallax"] != 0
+        self.parallax = np.where(has, arr["plx_val"], np.nan)
+        self.parallax_unc = np.where(has, arr["plx_unc"], np.nan)
+        self._desc_array = arr
         h = C.c_void_p()
         _cabi.check(_cabi.lib().iso_catalog_create(ic.handle(self.device), descs, self.n_models, C.byref(h)))
         self._h = h
+
+    @classmethod
+    def from_catalog(cls, catalog, ic, N=1, indices=None, device=None, **model_kwargs):
+        arr, template = cls.build_descs(catalog, ic, N=N, indices=indices, **model_kwargs)
+        return cls(ic, device=device, _descs=arr, _template=template)
+
+    @staticmethod
+    def build_descs(catalog, ic, N=1, indices=None, **model_kwargs):
+        """Vectorised descriptor records (host only): one template model (row ``indices[0]``)
+        supplies priors, bands and flags; magnitudes, spectroscopic values, parallaxes and the
+        parallax-dependent distance bound (reference: starmodel.py:1465-1475) are filled per star
+        with numpy.  Returns (structured array of iso_model_desc, template model)."""
+        idx = np.arange(len(catalog)) if indices is None else np.asarray(indices, dtype=int)
+        if idx.size == 0:
+            raise ValueError("no stars")
+        template = catalog.model(int(idx[0]), ic, N=N, **model_kwargs)
+        d0 = template.model_desc()
+        dt = np.dtype(_cabi.IsoModelDesc)
+        arr = np.empty(idx.size, dtype=dt)
+        arr[:] = np.frombuffer(d0, dtype=dt)[0]
+        df = catalog.df.iloc[idx]
+        bands = template.bands
+        if len(bands) != len([b for b in catalog.bands if b in ic.bc_grid.bands]):
+            raise ValueError("template star lacks some of the catalog's bands")
+        for j, b in enumerate(bands):
+            v = df["{}_mag".format(b)].to_numpy(float)
+            u = df["{}_mag_unc".format(b)].to_numpy(float)
+            if np.isnan(v).any() or np.isnan(u).any():
+                raise ValueError("band %s has missing values; a batched catalog needs every band for every star" % b)
+            arr["mag_val"][:, j] = v
+            arr["mag_unc"][:, j] = u
+        for q, name in enumerate(("Teff", "logg", "feh")):
+            if name in catalog.props:
+                v = df[name].to_numpy(float)
+                u = df[name + "_unc"].to_numpy(float)
+                missing = np.isnan(v) | np.isnan(u)
+                arr["spec_val"][:, q] = np.where(missing, np.nan, v)
+                arr["spec_unc"][:, q] = np.where(missing, np.nan, u)
+        if "nu_max" in catalog.props or "delta_nu" in catalog.props:
+            raise ValueError("asteroseismic terms are not batched")
+        i_d = list(template.param_names).index("distance")
+        if "parallax" in catalog.props:
+            v = df["parallax"].to_numpy(float)
+            u = df["parallax_unc"].to_numpy(float)
+            has = ~(np.isnan(v) | np.isnan(u))
+            arr["has_parallax"] = has.astype(np.int32)
+            arr["plx_val"] = np.where(has, v, 0.0)
+            arr["plx_unc"] = np.where(has, u, 1.0)
+            if "max_distance" not in model_kwargs:
+                default_hi = 10000.0
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    hi = np.where(has & (v > 0), 1.0 / v * 2000, np.where(has & (v < 0), 1.0 / np.abs(u) * 2000,
+                                                                           default_hi))
+                arr["prior_distance"]["hi"] = hi
+                arr["bound_hi"][:, i_d] = hi
+        return arr, template
 
     def close(self):
         if getattr(self, "_h", None) is not None:
@@ -182,16 +257,12 @@ def initial_positions(post: CatalogPosterior, nwalkers, rng_seed=0, oversample=8
     device = torch.device("cuda", post.device)
     gen = torch.Generator(device=device)
     gen.manual_seed(int(rng_seed))
-    lo = torch.tensor([[m.bounds(p)[0] for p in post.param_names] for m in post.models], dtype=torch.float64,
-                      device=device)
-    hi = torch.tensor([[m.bounds(p)[1] for p in post.param_names] for m in post.models], dtype=torch.float64,
-                      device=device)
+    lo = torch.as_tensor(post.bounds_lo, dtype=torch.float64, device=device)
+    hi = torch.as_tensor(post.bounds_hi, dtype=torch.float64, device=device)
     names = list(post.param_names)
     i_d = names.index("distance")
-    plx = torch.tensor([m.kwargs["parallax"][0] if "parallax" in m.kwargs else np.nan for m in post.models],
-                       dtype=torch.float64, device=device)
-    plx_e = torch.tensor([m.kwargs["parallax"][1] if "parallax" in m.kwargs else np.nan for m in post.models],
-                         dtype=torch.float64, device=device)
+    plx = torch.as_tensor(post.parallax, dtype=torch.float64, device=device)
+    plx_e = torch.as_tensor(post.parallax_unc, dtype=torch.float64, device=device)
     n_eep = sum(1 for n in names if n.startswith("eep"))
     K = oversample * W
     best = torch.full((S, W, D), float("nan"), dtype=torch.float64, device=device)
@@ -237,14 +308,13 @@ def result_columns(param_names):
 
 
 def fit_stars_gpu(catalog: StarCatalog, ic, indices, N=1, nwalkers=32, nburn=150, niter=100, seed=0,
-                  model_kwargs=None):
+                  model_kwargs=None, fused=True):
     """Fit the stars ``indices`` of the catalog on the current GPU; returns [len(indices), 3*D+3]
     float64 numpy rows (result_columns order)."""
     import torch
-    models = [catalog.model(int(i), ic, N=N, **(model_kwargs or {})) for i in indices]
-    if not models:
+    if len(indices) == 0:
         return np.empty((0, 3 * (N + 4) + 3))
-    post = CatalogPosterior(ic, models)
+    post = CatalogPosterior.from_catalog(catalog, ic, N=N, indices=indices, **(model_kwargs or {}))
     D = post.n_params
     pos, lnp, failed = initial_positions(post, nwalkers, rng_seed=seed)
     good = ~failed
@@ -253,24 +323,37 @@ def fit_stars_gpu(catalog: StarCatalog, ic, indices, N=1, nwalkers=32, nburn=150
         src = int(torch.nonzero(good)[0])
         pos[failed] = pos[src]
         lnp[failed] = lnp[src]
-    sampler = BatchedEnsembleSampler(post.n_models, nwalkers, D, post.lnpost, seed=seed + 1,
-                                     device=torch.device("cuda", post.device))
-    if bool(failed.any()) and bool(good.any()):
-        # evaluate failed stars with the borrowed star's id so their lnpost stays finite
-        sid_map = torch.arange(post.n_models, device=pos.device, dtype=torch.int32)
-        sid_map[failed] = src
-        sampler._sid_half = sid_map.repeat_interleave(nwalkers // 2)
-        sampler._sid_full = sid_map.repeat_interleave(nwalkers)
-    sampler.run(pos, lnp, nburn)
-    sampler.naccepted.zero_()
-    sampler.iterations = 0
-    chain, lnps = sampler.run(pos, lnp, niter, keep=True)
+    if fused:
+        from .sampler import FusedEnsembleSampler
+        if bool(failed.any()) and bool(good.any()):
+            # a failed star keeps its own (hopeless) posterior: its borrowed walkers simply never move
+            lnp = torch.where(failed[:, None], torch.zeros_like(lnp), lnp)
+        sampler = FusedEnsembleSampler(post, nwalkers, seed=seed + 1)
+        pos, lnp = sampler.run_mcmc(pos, nburn, lnprob0=lnp, store=False)
+        sampler.reset()
+        sampler.run_mcmc(pos, niter, lnprob0=lnp, store=True)
+        chain, lnps = sampler.chain, sampler.lnprobability        # [S, W, niter, D], [S, W, niter]
+        acc_frac = sampler.acceptance_fraction.mean(dim=1)
+    else:
+        sampler = BatchedEnsembleSampler(post.n_models, nwalkers, D, post.lnpost, seed=seed + 1,
+                                         device=torch.device("cuda", post.device))
+        if bool(failed.any()) and bool(good.any()):
+            # evaluate failed stars with the borrowed star's id so their lnpost stays finite
+            sid_map = torch.arange(post.n_models, device=pos.device, dtype=torch.int32)
+            sid_map[failed] = src
+            sampler._sid_half = sid_map.repeat_interleave(nwalkers // 2)
+            sampler._sid_full = sid_map.repeat_interleave(nwalkers)
+        sampler.run(pos, lnp, nburn)
+        sampler.naccepted.zero_()
+        sampler.iterations = 0
+        chain, lnps = sampler.run(pos, lnp, niter, keep=True)
+        acc_frac = sampler.naccepted.mean(dim=1) / max(sampler.iterations, 1)
     flat = chain.reshape(post.n_models, nwalkers * niter, D)
     q = torch.quantile(flat, torch.tensor([0.5, 0.16, 0.84], dtype=torch.float64, device=flat.device), dim=1)
     rows = torch.empty(post.n_models, 3 * D + 3, dtype=torch.float64, device=flat.device)
     rows[:, : 3 * D] = q.permute(1, 2, 0).reshape(post.n_models, 3 * D)
     rows[:, 3 * D] = lnps.reshape(post.n_models, -1).max(dim=1).values
-    rows[:, 3 * D + 1] = sampler.naccepted.mean(dim=1) / max(sampler.iterations, 1)
+    rows[:, 3 * D + 1] = acc_frac
     rows[:, 3 * D + 2] = good.to(torch.float64)
     rows[failed, : 3 * D + 2] = float("nan")
     out = rows.cpu().numpy()

@@ -15,4 +15,15 @@ bool launch_lnpost_fast(int kind, int n_stars, int n_bands, bool packed, bool mu
     return false;
 }
 
+bool launch_stretch(int kind, int n_stars, int n_bands, const FastArgs& A, const StretchArgs& S, hipStream_t s)
+{
+    if (kind == ISO_KIND_TRACK) return n_stars == 1 && launch_stretch_track1(n_bands, A, S, s);
+    switch (n_stars) {
+    case 1: return launch_stretch_iso1(n_bands, A, S, s);
+    case 2: return launch_stretch_iso2(n_bands, A, S, s);
+    case 3: return launch_stretch_iso3(n_bands, A, S, s);
+    }
+    return false;
+}
+
 }  // namespace iso

@@ -288,22 +288,11 @@ __device__ __forceinline__ double eep_term(const DevModel& M, const DevPrior& or
 // ---- the kernel ---------------------------------------------------------------------------
 // MULTI: every row carries the index of its own star (observations + priors) — the catalog /
 // batched-ensemble form: S stars x W walkers in one launch.
-template <int KIND, int NS, int NB, bool PACKED, bool MULTI>
-__global__ __launch_bounds__(BLOCK) void k_lnpost_fast(const FastArgs A)
+// lnpost of one sample (p = the NS+4 parameters), shared by the batch kernel and the sampler kernel
+template <int KIND, int NS, int NB, bool PACKED>
+__device__ __forceinline__ double lnpost_one(const FastArgs& A, const double* lds, const DevModel& M,
+                                             const double* __restrict__ p)
 {
-    extern __shared__ double lds[];
-    for (int j = threadIdx.x; j < A.axes_len; j += BLOCK) lds[j] = A.axes_blob[j];
-    __syncthreads();
-    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= A.n) return;
-    const DevModel& M = A.m[MULTI ? A.star_id[i] : 0];
-    constexpr int NP = NS + 4;
-    double p[NP];
-    {
-        const double* __restrict__ src = A.pars + i * A.stride_n;
-#pragma unroll
-        for (int j = 0; j < NP; ++j) p[j] = src[j * A.stride_p];
-    }
     const double q1 = p[NS], feh_par = p[NS + 1], dist = p[NS + 2], AV = p[NS + 3];
 
     // ---- model table: axes 0/1 are shared by all components of an isochrone system ----
@@ -349,10 +338,7 @@ __global__ __launch_bounds__(BLOCK) void k_lnpost_fast(const FastArgs A)
     lnp += ln_pdf<true>(M.prior_distance, dist, ld);
     lnp += ln_pdf<false>(M.prior_AV, AV, 0.0);
     if (rejected) lnp = -f_inf();
-    if (!isfinite(lnp)) {
-        A.lnpost[i] = -f_inf();
-        return;
-    }
+    if (!isfinite(lnp)) return -f_inf();
 
     // ---- lnlike ----
     double lnl = 0.0;
@@ -402,7 +388,109 @@ __global__ __launch_bounds__(BLOCK) void k_lnpost_fast(const FastArgs A)
         const double r = M.plx_val - 1000.0 / dist;
         lnl += M.plx_g0 - r * r * M.plx_hinv;
     }
-    A.lnpost[i] = lnp + lnl;
+    return lnp + lnl;
+}
+
+template <int KIND, int NS, int NB, bool PACKED, bool MULTI>
+__global__ __launch_bounds__(BLOCK) void k_lnpost_fast(const FastArgs A)
+{
+    extern __shared__ double lds[];
+    for (int j = threadIdx.x; j < A.axes_len; j += BLOCK) lds[j] = A.axes_blob[j];
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= A.n) return;
+    const DevModel& M = A.m[MULTI ? A.star_id[i] : 0];
+    constexpr int NP = NS + 4;
+    double p[NP];
+    {
+        const double* __restrict__ src = A.pars + i * A.stride_n;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) p[j] = src[j * A.stride_p];
+    }
+    A.lnpost[i] = lnpost_one<KIND, NS, NB, PACKED>(A, lds, M, p);
+}
+
+// -------------------------------------------------------------------------------------------
+// Fused stretch-move half-step ("next" row f3: device-resident ensemble sampler).
+// One lane = one walker of the active half of one star's ensemble: draw a partner from the
+// complementary half (Philox4x32-10 counter RNG, keyed by seed, counter = (step, half, row)),
+// propose y = x_j + z (x_k - x_j), evaluate lnpost(y) with the same device function as the batch
+// kernel, accept / reject in place.  The active half only *reads* the other half, so a half-step
+// is race-free; two launches make one emcee-style iteration (Goodman & Weare 2010; the reference
+// drives emcee.EnsembleSampler with one Python lnpost call per walker, starmodel.py:951-969).
+// -------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t* out)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+template <int KIND, int NS, int NB>
+__global__ __launch_bounds__(BLOCK) void k_stretch_half(const FastArgs A, const StretchArgs S)
+{
+    extern __shared__ double lds[];
+    for (int j = threadIdx.x; j < A.axes_len; j += BLOCK) lds[j] = A.axes_blob[j];
+    __syncthreads();
+    const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= S.n_active) return;
+    constexpr int NP = NS + 4;
+    const int h = S.W >> 1;
+    const int64_t star = t / h;
+    const int k = (int)(t - star * h);
+    const int64_t row = star * S.W + (S.half ? h : 0) + k;
+    uint32_t rnd[4];
+    philox4x32_10((uint32_t)(2u * S.step + (uint32_t)S.half), (uint32_t)row, (uint32_t)((uint64_t)row >> 32), 0x51u,
+                  (uint32_t)S.seed, (uint32_t)(S.seed >> 32), rnd);
+    const int j = (int)(((uint64_t)rnd[0] * (uint64_t)h) >> 32);          // uniform in [0, h)
+    const int64_t prow = star * S.W + (S.half ? 0 : h) + j;
+    const double u1 = ((double)rnd[1] + (double)(rnd[2] & 0xFFFFu) * (1.0 / 65536.0)) * (1.0 / 4294967296.0);
+    const double u2 = ((double)rnd[3] + (double)(rnd[2] >> 16) * (1.0 / 65536.0) + 0.5 / 65536.0) * (1.0 / 4294967296.0);
+    const double zr = (S.a - 1.0) * u1 + 1.0;
+    const double z = zr * zr / S.a;
+    double xk[NP], y[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        xk[q] = S.pos[row * NP + q];
+        const double xj = S.pos[prow * NP + q];
+        y[q] = xj + z * (xk[q] - xj);
+    }
+    const DevModel& M = A.m[S.multi ? star : 0];
+    const double lnew = lnpost_one<KIND, NS, NB, true>(A, lds, M, y);
+    const double lnq = (NP - 1) * log(z) + lnew - S.lnp[row];
+    const bool acc = isfinite(lnew) && (log(u2) < lnq);
+    if (acc) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) S.pos[row * NP + q] = y[q];
+        S.lnp[row] = lnew;
+        if (S.accepted) S.accepted[row] += 1;
+    }
+}
+
+template <int KIND, int NS>
+inline bool launch_stretch_nb(int nb, const FastArgs& A, const StretchArgs& S, hipStream_t s)
+{
+    const dim3 g((unsigned)((S.n_active + BLOCK - 1) / BLOCK)), b(BLOCK);
+    const size_t sh = (size_t)A.axes_len * sizeof(double);
+    switch (nb) {
+    case 1: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 1>), g, b, sh, s, A, S); return true;
+    case 2: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 2>), g, b, sh, s, A, S); return true;
+    case 3: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 3>), g, b, sh, s, A, S); return true;
+    case 4: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 4>), g, b, sh, s, A, S); return true;
+    case 5: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 5>), g, b, sh, s, A, S); return true;
+    case 6: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 6>), g, b, sh, s, A, S); return true;
+    case 7: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 7>), g, b, sh, s, A, S); return true;
+    case 8: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 8>), g, b, sh, s, A, S); return true;
+    default: return false;
+    }
 }
 
 template <int KIND, int NS, bool PACKED, bool MULTI>
@@ -435,6 +523,16 @@ inline bool launch_nb(int nb, const FastArgs& A, hipStream_t s)
                       : fastk::launch_nb<KIND, NS, false, false>(nb, A, s);                   \
     }
 
+#define ISO_DEFINE_STRETCH_LAUNCHER(NAME, KIND, NS)                                           \
+    bool NAME(int nb, const FastArgs& A, const StretchArgs& S, hipStream_t s)                 \
+    {                                                                                         \
+        return fastk::launch_stretch_nb<KIND, NS>(nb, A, S, s);                               \
+    }
+
+bool launch_stretch_track1(int nb, const FastArgs& A, const StretchArgs& S, hipStream_t s);
+bool launch_stretch_iso1(int nb, const FastArgs& A, const StretchArgs& S, hipStream_t s);
+bool launch_stretch_iso2(int nb, const FastArgs& A, const StretchArgs& S, hipStream_t s);
+bool launch_stretch_iso3(int nb, const FastArgs& A, const StretchArgs& S, hipStream_t s);
 bool launch_fast_track1(int nb, bool packed, bool multi, const FastArgs& A, hipStream_t s);
 bool launch_fast_iso1(int nb, bool packed, bool multi, const FastArgs& A, hipStream_t s);
 bool launch_fast_iso2(int nb, bool packed, bool multi, const FastArgs& A, hipStream_t s);

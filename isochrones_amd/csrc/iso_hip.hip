@@ -1681,6 +1681,87 @@ int iso_catalog_lnpost(iso_catalog* c, const int32_t* star_id, const double* par
     return ISO_OK;
 }
 
+namespace {
+int sampler_common(iso_sampler* sp, int device, int kind, int n_stars, int n_bands, int64_t n_ens, const FastArgs& F,
+                   int multi, int nwalkers, double a, uint64_t seed)
+{
+    sp->device = device;
+    sp->kind = kind;
+    sp->n_stars = n_stars;
+    sp->n_bands = n_bands;
+    sp->n_params = n_stars + 4;
+    sp->n_ensembles = n_ens;
+    sp->W = nwalkers;
+    sp->a = a;
+    sp->seed = seed;
+    sp->step = 0;
+    sp->multi = multi;
+    sp->fast = F;
+    return ISO_OK;
+}
+}  // namespace
+
+int iso_sampler_create_model(iso_model* m, int nwalkers, double a, uint64_t seed, iso_sampler** out)
+{
+    if (!m || !out) return fail(ISO_ERR_INVALID, "iso_sampler_create_model: NULL argument");
+    if (nwalkers < 2 || (nwalkers & 1) || !(a > 1.0)) return fail(ISO_ERR_INVALID, "iso_sampler_create_model: need an even walker count and a > 1");
+    if (!m->fast_ok || !m->fast.hotq || !m->fast.bcq)
+        return fail(ISO_ERR_INVALID, "iso_sampler_create_model: the model is not on the corner-packed fast path "
+                                     "(needs 1-8 bands, uniform EEP axis, ISOCHRONES_AMD_PATH=auto)");
+    iso_sampler* sp = new (std::nothrow) iso_sampler();
+    if (!sp) return fail(ISO_ERR_NOMEM, "iso_sampler_create_model: out of host memory");
+    sampler_common(sp, m->device, m->ic->kind, m->desc.n_stars, m->desc.n_bands, 1, m->fast, 0, nwalkers, a, seed);
+    *out = sp;
+    return ISO_OK;
+}
+
+int iso_sampler_create_catalog(iso_catalog* c, int nwalkers, double a, uint64_t seed, iso_sampler** out)
+{
+    if (!c || !out) return fail(ISO_ERR_INVALID, "iso_sampler_create_catalog: NULL argument");
+    if (nwalkers < 2 || (nwalkers & 1) || !(a > 1.0)) return fail(ISO_ERR_INVALID, "iso_sampler_create_catalog: need an even walker count and a > 1");
+    iso_sampler* sp = new (std::nothrow) iso_sampler();
+    if (!sp) return fail(ISO_ERR_NOMEM, "iso_sampler_create_catalog: out of host memory");
+    sampler_common(sp, c->device, c->ic->kind, c->n_stars, c->n_bands, c->n_models, c->fast, 1, nwalkers, a, seed);
+    *out = sp;
+    return ISO_OK;
+}
+
+void iso_sampler_destroy(iso_sampler* s) { delete s; }
+
+int iso_sampler_run(iso_sampler* sp, double* pos, double* lnp, int nsteps, double* chain, double* chain_lnp,
+                    int32_t* accepted, void* stream)
+{
+    if (!sp || !pos || !lnp) return fail(ISO_ERR_INVALID, "iso_sampler_run: NULL argument");
+    if (nsteps < 0) return fail(ISO_ERR_INVALID, "iso_sampler_run: nsteps < 0");
+    DeviceGuard guard(sp->device);
+    hipStream_t s = as_stream(stream);
+    const int64_t rows = sp->n_ensembles * sp->W;
+    StretchArgs S;
+    S.pos = pos;
+    S.lnp = lnp;
+    S.accepted = accepted;
+    S.W = sp->W;
+    S.multi = sp->multi;
+    S.n_active = sp->n_ensembles * (sp->W / 2);
+    S.a = sp->a;
+    S.seed = sp->seed;
+    for (int it = 0; it < nsteps; ++it) {
+        S.step = sp->step++;
+        for (int half = 0; half < 2; ++half) {
+            S.half = half;
+            if (!launch_stretch(sp->kind, sp->n_stars, sp->n_bands, sp->fast, S, s))
+                return fail(ISO_ERR_INVALID, "iso_sampler_run: no kernel specialisation");
+        }
+        if (chain)
+            HIP_TRY(hipMemcpyAsync(chain + (int64_t)it * rows * sp->n_params, pos, sizeof(double) * rows * sp->n_params,
+                                   hipMemcpyDeviceToDevice, s));
+        if (chain_lnp)
+            HIP_TRY(hipMemcpyAsync(chain_lnp + (int64_t)it * rows, lnp, sizeof(double) * rows, hipMemcpyDeviceToDevice, s));
+    }
+    HIP_TRY(hipGetLastError());
+    return ISO_OK;
+}
+
 int iso_time_lnpost(iso_model* m, const double* pars, int64_t stride_n, int64_t stride_p, int64_t n,
                     double* lnpost_out, int reps, void* stream, double* ms_per_launch)
 {

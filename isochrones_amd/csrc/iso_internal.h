@@ -92,6 +92,19 @@ struct FastArgs {
     double* lnpost;
 };
 
+struct StretchArgs {
+    double* pos;          // [n_rows][n_params] row-major, n_rows = n_stars_in_batch * W
+    double* lnp;          // [n_rows]
+    int32_t* accepted;    // [n_rows] acceptance counters, may be null
+    int W;                // walkers per star (even)
+    int half;             // 0: update walkers [0, W/2) against [W/2, W); 1: the other way round
+    int multi;            // 1: A.m is an array indexed by the star of the row
+    int64_t n_active;     // n_stars_in_batch * W/2
+    double a;             // stretch scale
+    uint64_t seed;
+    uint32_t step;
+};
+
 }  // namespace iso
 
 struct iso_ctx {
@@ -151,7 +164,20 @@ struct iso_model {
     iso::FastArgs fast;      // template filled at create time (pars/outputs set per call)
 };
 
+struct iso_sampler {
+    int device;
+    int kind, n_stars, n_bands, n_params;
+    int64_t n_ensembles;     // stars sampled in lock-step (1 for a single model)
+    int W;
+    double a;
+    uint64_t seed;
+    uint32_t step;           // running step counter (keeps the RNG stream moving across runs)
+    int multi;
+    iso::FastArgs fast;      // tables + model(s); copied at create time (owner must outlive the sampler)
+};
+
 namespace iso {
+bool launch_stretch(int kind, int n_stars, int n_bands, const FastArgs& A, const StretchArgs& S, hipStream_t s);
 // defined in iso_fast_*.hip: launch the specialised fused kernel; returns false if no
 // specialisation exists for (kind, n_stars, n_bands)
 bool launch_lnpost_fast(int kind, int n_stars, int n_bands, bool packed, bool multi, const FastArgs& A,

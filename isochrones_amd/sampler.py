@@ -114,3 +114,114 @@ def summarize_chain(flatchain, flatlnprob):
     lp = flatlnprob.detach().cpu().numpy() if hasattr(flatlnprob, "detach") else np.asarray(flatlnprob)
     q = np.percentile(x, [50, 16, 84], axis=0)          # [3, ndim]
     return np.concatenate([q.T.ravel(), [lp.max() if lp.size else math.nan]])
+
+
+class FusedEnsembleSampler:
+    """The same stretch-move ensemble, but with proposal + fused lnpost + accept in ONE HIP kernel
+    per half-ensemble (``iso_sampler_*``; Philox counter RNG in-kernel).  ``target`` is a
+    :class:`BasicStarModel` (one ensemble) or a :class:`CatalogPosterior` (one ensemble per star,
+    all advanced in lock-step; row = star * nwalkers + walker).  A 256-walker half-step is a
+    single ~10 us launch instead of ~25 framework launches."""
+
+    def __init__(self, target, nwalkers, a=2.0, seed=0, device=None):
+        import ctypes as C
+        import torch
+        from . import _cabi, device as dev
+        from .catalog import CatalogPosterior
+        self.target = target
+        self.nwalkers = int(nwalkers)
+        self.ndim = target.n_params
+        self.is_catalog = isinstance(target, CatalogPosterior)
+        self.n_ensembles = target.n_models if self.is_catalog else 1
+        self.device_index = (target.device if self.is_catalog else
+                             (dev.current_device() if device is None else device))
+        self.device = torch.device("cuda", self.device_index)
+        h = C.c_void_p()
+        lib = _cabi.lib()
+        if self.is_catalog:
+            _cabi.check(lib.iso_sampler_create_catalog(target._h, self.nwalkers, float(a), int(seed), C.byref(h)))
+        else:
+            _cabi.check(lib.iso_sampler_create_model(target.handle(self.device_index), self.nwalkers, float(a),
+                                                     int(seed), C.byref(h)))
+        self._h = h
+        self.reset()
+
+    def close(self):
+        if getattr(self, "_h", None) is not None:
+            from . import _cabi
+            _cabi.lib().iso_sampler_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self):
+        import torch
+        self._chain, self._lnprob = None, None
+        self.accepted = torch.zeros(self.n_ensembles * self.nwalkers, dtype=torch.int32, device=self.device)
+        self.iterations = 0
+
+    def lnpost_rows(self, pos):
+        """lnpost of [n_ens*W, ndim] rows through the regular batch entry points."""
+        import torch
+        if self.is_catalog:
+            sid = torch.arange(self.n_ensembles, device=self.device, dtype=torch.int32).repeat_interleave(self.nwalkers)
+            return self.target.lnpost(pos, sid)
+        return self.target.lnpost(pos)
+
+    def run_mcmc(self, p0, nsteps, lnprob0=None, store=True):
+        """p0: [W, ndim] (model) or [S, W, ndim] (catalog).  Returns (pos, lnprob) in that shape."""
+        import torch
+        from . import _cabi, device as dev
+        rows = self.n_ensembles * self.nwalkers
+        pos = torch.as_tensor(p0, dtype=torch.float64, device=self.device).reshape(rows, self.ndim).contiguous().clone()
+        lnp = (self.lnpost_rows(pos) if lnprob0 is None else
+               torch.as_tensor(lnprob0, dtype=torch.float64, device=self.device).reshape(rows)).contiguous().clone()
+        if not bool(torch.isfinite(lnp).all()):
+            raise ValueError("initial positions must have finite lnpost")
+        chain = torch.empty(nsteps, rows, self.ndim, dtype=torch.float64, device=self.device) if store else None
+        clnp = torch.empty(nsteps, rows, dtype=torch.float64, device=self.device) if store else None
+        _cabi.check(_cabi.lib().iso_sampler_run(self._h, dev.ptr(pos), dev.ptr(lnp), int(nsteps), dev.ptr(chain),
+                                                dev.ptr(clnp), dev.ptr(self.accepted),
+                                                dev.stream_ptr(self.device_index)))
+        self.iterations += int(nsteps)
+        if store:
+            self._chain = chain if self._chain is None else torch.cat([self._chain, chain], dim=0)
+            self._lnprob = clnp if self._lnprob is None else torch.cat([self._lnprob, clnp], dim=0)
+        shape = (self.n_ensembles, self.nwalkers) if self.is_catalog else (self.nwalkers,)
+        return pos.view(*shape, self.ndim), lnp.view(*shape)
+
+    # emcee-v2 style views: [W, nsteps, ndim] for a model, [S, W, nsteps, ndim] for a catalog
+    @property
+    def chain(self):
+        import torch
+        if self._chain is None:
+            return torch.empty(self.nwalkers, 0, self.ndim, dtype=torch.float64, device=self.device)
+        c = self._chain.view(-1, self.n_ensembles, self.nwalkers, self.ndim).permute(1, 2, 0, 3)
+        return c if self.is_catalog else c[0]
+
+    @property
+    def lnprobability(self):
+        import torch
+        if self._lnprob is None:
+            return torch.empty(self.nwalkers, 0, dtype=torch.float64, device=self.device)
+        c = self._lnprob.view(-1, self.n_ensembles, self.nwalkers).permute(1, 2, 0)
+        return c if self.is_catalog else c[0]
+
+    @property
+    def flatchain(self):
+        return self.chain.reshape(-1, self.ndim) if not self.is_catalog else self.chain.reshape(
+            self.n_ensembles, -1, self.ndim)
+
+    @property
+    def flatlnprobability(self):
+        return self.lnprobability.reshape(-1) if not self.is_catalog else self.lnprobability.reshape(
+            self.n_ensembles, -1)
+
+    @property
+    def acceptance_fraction(self):
+        acc = self.accepted.to(dtype=__import__("torch").float64) / max(self.iterations, 1)
+        return acc.view(self.n_ensembles, self.nwalkers) if self.is_catalog else acc

@@ -324,9 +324,12 @@ class BasicStarModel:
     def emcee_p0(self, nwalkers, rng=None):
         return self.sample_from_prior(nwalkers, rng=rng, require_valid=True)
 
-    def fit_mcmc(self, nwalkers=300, nburn=200, niter=100, p0=None, seed=None, **kwargs):
+    def fit_mcmc(self, nwalkers=300, nburn=200, niter=100, p0=None, seed=None, fused=None, **kwargs):
+        """Burn in, reset, sample (reference: fit_mcmc_old).  ``fused`` selects the single-kernel
+        sampler (default: used whenever the model is on the corner-packed fast path, else the
+        framework-op sampler, which evaluates lnpost through the same HIP kernels)."""
         import torch
-        from .sampler import EnsembleSampler
+        from .sampler import EnsembleSampler, FusedEnsembleSampler
         rng = np.random.default_rng(seed)
         npars = self.n_params
         if p0 is None:
@@ -334,7 +337,15 @@ class BasicStarModel:
         else:
             p0 = rng.normal(size=(nwalkers, npars)) * 0.01 + np.asarray(p0, dtype=float)[None, :]
         device = torch.device("cuda", dev.current_device())
-        sampler = EnsembleSampler(nwalkers, npars, self.lnpost, seed=int(rng.integers(2 ** 62)), device=device)
+        sampler = None
+        if fused is None or fused:
+            try:
+                sampler = FusedEnsembleSampler(self, nwalkers, seed=int(rng.integers(2 ** 62)))
+            except _cabi.IsoError:
+                if fused:
+                    raise
+        if sampler is None:
+            sampler = EnsembleSampler(nwalkers, npars, self.lnpost, seed=int(rng.integers(2 ** 62)), device=device)
         pos, prob = sampler.run_mcmc(p0, nburn, store=False)
         sampler.reset()
         sampler.run_mcmc(pos, niter, lnprob0=prob)

@@ -96,3 +96,68 @@ def test_fit_catalog_single_gpu_recovers_truth():
     width = (res.loc[ok, "distance_p84"] - res.loc[ok, "distance_p16"]).values
     assert np.all(width > 0)
     assert 0.05 < res.loc[ok, "acceptance"].median() < 0.9
+
+
+def test_fused_sampler_consistency_and_statistics():
+    """'next' row f3: the single-kernel stretch-move sampler.  (a) its stored lnprob is exactly the
+    lnpost of its stored positions (same device function as the batch kernel); (b) never accepts a
+    non-finite proposal; (c) samples the same posterior as the framework-op sampler."""
+    import torch
+    from isochrones_amd.sampler import EnsembleSampler, FusedEnsembleSampler
+    ic = _small_track(("G", "BP", "RP"))
+    truth = np.array([1.05, 330.0, -0.1, 200.0, 0.15])
+    T, g, f, mags = ic.interp_mag(truth, ["G", "BP", "RP"])
+    mod = ia.SingleStarModel(ic, Teff=(T, 80), logg=(g, 0.1), feh=(f, 0.1), G=(mags[0], 0.01), BP=(mags[1], 0.01),
+                             RP=(mags[2], 0.01), parallax=(1000 / truth[3], 0.05))
+    W = 128
+    rng = np.random.default_rng(0)
+    p0 = truth + np.array([0.01, 1.0, 0.01, 1.0, 0.01]) * rng.standard_normal((W, 5))
+    p0[:, 4] = np.abs(p0[:, 4])
+    fs = FusedEnsembleSampler(mod, W, seed=7)
+    pos, lnp = fs.run_mcmc(p0, 400, store=False)
+    fs.reset()
+    pos, lnp = fs.run_mcmc(pos, 300, lnprob0=lnp)
+    assert fs.chain.shape == (W, 300, 5) and fs.lnprobability.shape == (W, 300)
+    # (a) exact bookkeeping
+    again = mod.lnpost(pos)
+    assert torch.allclose(again, lnp, rtol=1e-12, atol=1e-12)
+    flat = fs.flatchain
+    again = mod.lnpost(flat)
+    assert torch.allclose(again, fs.flatlnprobability, rtol=1e-12, atol=1e-12)
+    # (b)
+    assert bool(torch.isfinite(fs.flatlnprobability).all())
+    acc = float(fs.acceptance_fraction.mean())
+    assert 0.15 < acc < 0.8
+    # (c) against the framework-op sampler on the same posterior
+    ts = EnsembleSampler(W, 5, mod.lnpost, seed=11, device=torch.device("cuda"))
+    q, lq = ts.run_mcmc(p0, 400, store=False)
+    ts.reset()
+    ts.run_mcmc(q, 300, lnprob0=lq)
+    a, b = fs.flatchain.cpu().numpy(), ts.flatchain.cpu().numpy()
+    sd = b.std(axis=0)
+    assert np.all(np.abs(a.mean(axis=0) - b.mean(axis=0)) < 0.35 * sd), (a.mean(axis=0), b.mean(axis=0), sd)
+    assert np.all(np.abs(a.std(axis=0) / sd - 1.0) < 0.35)
+    # reproducible: same seed, same start -> identical chain
+    fs2 = FusedEnsembleSampler(mod, W, seed=7)
+    pos2, lnp2 = fs2.run_mcmc(p0, 400, store=False)
+    fs2.reset()
+    pos2, _ = fs2.run_mcmc(pos2, 300, lnprob0=lnp2)
+    assert torch.equal(pos2, pos)
+
+
+def test_fused_catalog_sampler_matches_per_star_bookkeeping():
+    import torch
+    from isochrones_amd.sampler import FusedEnsembleSampler
+    from isochrones_amd.catalog import initial_positions
+    ic = _small_track(("G", "BP", "RP"))
+    cat, truth = synthetic_catalog(ic, 12, bands=["G", "BP", "RP"], seed=3, mag_unc=0.01)
+    models = list(cat.iter_models(ic))
+    post = CatalogPosterior(ic, models)
+    pos, lnp, failed = initial_positions(post, 16, rng_seed=1)
+    assert not bool(failed.any())
+    fs = FusedEnsembleSampler(post, 16, seed=5)
+    pos, lnp = fs.run_mcmc(pos, 120, lnprob0=lnp, store=True)
+    assert fs.chain.shape == (12, 16, 120, 5)
+    for s in (0, 5, 11):                                  # every star's rows follow its own posterior
+        want = models[s].lnpost(pos[s])
+        assert torch.allclose(want, lnp[s], rtol=1e-12, atol=1e-12)

@@ -140,3 +140,37 @@ def test_star_catalog_schema():
     mods = list(cat.iter_models(ic, N=2))
     assert len(mods) == 2 and mods[0].N == 2 and mods[1].bands == ["J", "K"]
     assert mods[1].kwargs["parallax"] == (2.0, 0.1) and mods[1].bounds("distance") == (0, 1000.0)
+
+
+def test_vectorised_catalog_descriptors_equal_per_model_descriptors():
+    """CatalogPosterior.build_descs fills iso_model_desc records column-wise; they must be byte-
+    identical to the records of one BasicStarModel per row (incl. missing parallax / Teff)."""
+    import ctypes as C
+    import pandas as pd
+    from isochrones_amd import _cabi
+    from isochrones_amd.catalog import CatalogPosterior
+    rng = np.random.default_rng(2)
+    n = 40
+    df = pd.DataFrame({"G_mag": 10 + rng.random(n), "G_mag_unc": 0.01 + 0.01 * rng.random(n),
+                       "RP_mag": 9 + rng.random(n), "RP_mag_unc": 0.02,
+                       "parallax": 1 + 5 * rng.random(n), "parallax_unc": 0.05,
+                       "Teff": 5000 + 1000 * rng.random(n), "Teff_unc": 80.0})
+    df.loc[3, "parallax"] = np.nan
+    df.loc[5, "parallax"] = -0.2
+    df.loc[7, "Teff"] = np.nan
+    cat = ia.StarCatalog(df, bands=["G", "RP"], props=["parallax", "Teff"])
+    ic = ia.synthetic_track(bands=("G", "RP"), fehs=[-1, 0, .5], masses=[.5, 1, 2], eeps=np.arange(1., 50.))
+    arr, template = CatalogPosterior.build_descs(cat, ic)
+    assert arr.shape == (n,) and template.bands == ["G", "RP"]
+    for i in range(n):
+        want = bytes(cat.model(i, ic).model_desc())
+        got = arr[i].tobytes()
+        if got != want:
+            d = cat.model(i, ic).model_desc()
+            w = np.frombuffer(d, dtype=arr.dtype)[0]
+            for name in arr.dtype.names:
+                a, b = np.asarray(arr[i][name]), np.asarray(w[name])
+                assert a.tobytes() == b.tobytes() or (name in ("plx_val", "plx_unc") and not w["has_parallax"]), (i, name, a, b)
+    assert arr["has_parallax"][3] == 0 and arr["prior_distance"]["hi"][3] == 10000.0
+    assert np.isclose(arr["prior_distance"]["hi"][5], 2000 / 0.05)
+    assert np.isnan(arr["spec_val"][7, 0])
