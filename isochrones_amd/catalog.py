@@ -308,15 +308,26 @@ def result_columns(param_names):
 
 
 def fit_stars_gpu(catalog: StarCatalog, ic, indices, N=1, nwalkers=32, nburn=150, niter=100, seed=0,
-                  model_kwargs=None, fused=True):
+                  model_kwargs=None, fused=True, timings=None):
     """Fit the stars ``indices`` of the catalog on the current GPU; returns [len(indices), 3*D+3]
     float64 numpy rows (result_columns order)."""
     import torch
+    import time as _time
+
+    def _mark(name, _t=[_time.perf_counter()]):
+        if timings is not None:
+            torch.cuda.synchronize()
+            now = _time.perf_counter()
+            timings[name] = timings.get(name, 0.0) + now - _t[0]
+            _t[0] = now
+
     if len(indices) == 0:
         return np.empty((0, 3 * (N + 4) + 3))
     post = CatalogPosterior.from_catalog(catalog, ic, N=N, indices=indices, **(model_kwargs or {}))
+    _mark("build_posteriors")
     D = post.n_params
     pos, lnp, failed = initial_positions(post, nwalkers, rng_seed=seed)
+    _mark("initial_positions")
     good = ~failed
     # failed stars get a copy of a good star's walkers so the batch stays rectangular
     if bool(failed.any()) and bool(good.any()):
@@ -330,8 +341,10 @@ def fit_stars_gpu(catalog: StarCatalog, ic, indices, N=1, nwalkers=32, nburn=150
             lnp = torch.where(failed[:, None], torch.zeros_like(lnp), lnp)
         sampler = FusedEnsembleSampler(post, nwalkers, seed=seed + 1)
         pos, lnp = sampler.run_mcmc(pos, nburn, lnprob0=lnp, store=False)
+        _mark("burn_in")
         sampler.reset()
         sampler.run_mcmc(pos, niter, lnprob0=lnp, store=True)
+        _mark("sampling")
         chain, lnps = sampler.chain, sampler.lnprobability        # [S, W, niter, D], [S, W, niter]
         acc_frac = sampler.acceptance_fraction.mean(dim=1)
     else:
@@ -357,6 +370,7 @@ def fit_stars_gpu(catalog: StarCatalog, ic, indices, N=1, nwalkers=32, nburn=150
     rows[:, 3 * D + 2] = good.to(torch.float64)
     rows[failed, : 3 * D + 2] = float("nan")
     out = rows.cpu().numpy()
+    _mark("summaries")
     post.close()
     return out
 
