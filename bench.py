@@ -128,12 +128,20 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if args.gpus > 1 and world == 1:
         raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    # test hooks (single-GPU boxes): ISO_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and
+    # ISO_BENCH_BACKEND=gloo replaces RCCL for the timing barrier / max-reduce
+    backend = os.environ.get("ISO_BENCH_BACKEND", "nccl")
+    if os.environ.get("ISO_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     distributed = world > 1
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     ic, mod = build_model()
     # rank r evaluates star r of the catalog: same observables, its own seeded sample batch
@@ -165,7 +173,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if distributed:
-        tmax = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms = float(tmax[0]), float(tmax[1])
 
