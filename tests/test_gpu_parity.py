@@ -277,3 +277,56 @@ def test_ingest_derived_columns():
     # the table with the appended column serves queries after the (lazy) re-upload
     v = dfi([0.0, 1.0, 250.0], ["dt_deep"])
     assert np.isclose(v[0], d[1, 1, 249], rtol=1e-12)
+
+
+def test_batch_size_edges():
+    """Empty, single-sample, ragged (non multiple of the 256-thread workgroup) and very large
+    batches through every entry point."""
+    import torch
+    rng = np.random.default_rng(21)
+    ic, mod, lo, hi = _random_model("track", 1, ("G", "BP"), rng)
+    oic = fx.make_oracle_ic(ic)
+    desc = mod.model_desc()
+    for n in (0, 1, 63, 255, 256, 257, 1000):
+        pars = rng.uniform(lo, hi, size=(n, 5))
+        got = mod.lnpost(pars)
+        assert got.shape == (n,)
+        if n:
+            fx.assert_close(got, oic.lnpost(desc, pars.T.copy(), parts=False), RTOL, atol=ATOL, what="n=%d" % n)
+            fx.assert_close(mod.lnlike(pars), oic.lnpost(desc, pars.T.copy())[2], RTOL, atol=ATOL, what="lnlike n=%d" % n)
+        v = ic.interp_value([pars[:, 0], pars[:, 1], pars[:, 2]], ["Teff", "Mbol"])
+        assert v.shape == (n, 2)
+        T, g, f, m = ic.interp_mag([pars[:, j] for j in range(5)], ["G", "BP"])
+        if n == 1:      # five length-1 arrays squeeze to one parameter vector: scalar form, as the reference
+            assert np.ndim(T) == 0 and m.shape == (2,)
+        else:
+            assert T.shape == (n,) and m.shape == (n, 2)
+    # 10^7 samples: output fully written, checksum-of-chunks equals chunked evaluation
+    n = 10_000_000
+    big = torch.rand(n, 5, dtype=torch.float64, device="cuda") * torch.as_tensor(hi - lo, device="cuda") + torch.as_tensor(lo, device="cuda")
+    out = mod.lnpost(big)
+    assert out.shape == (n,) and not bool(torch.isnan(out[torch.isfinite(out)]).any())
+    k = 3_333_333
+    parts = torch.cat([mod.lnpost(big[:k]), mod.lnpost(big[k:2 * k]), mod.lnpost(big[2 * k:])])
+    assert torch.equal(torch.nan_to_num(parts, nan=3.0, neginf=-1e300), torch.nan_to_num(out, nan=3.0, neginf=-1e300))
+    fin = torch.isfinite(out)
+    assert 0.05 < float(fin.double().mean()) < 1.0
+    sub = big[::1000].cpu().numpy()
+    fx.assert_close(out[::1000].cpu().numpy(), oic.lnpost(desc, sub.T.copy(), parts=False), RTOL, atol=ATOL, what="1e7 subsample")
+
+
+def test_handles_survive_any_destroy_order():
+    import gc
+    rng = np.random.default_rng(2)
+    for order in range(3):
+        ic, mod, lo, hi = _random_model("iso", 2, ("G",), rng)
+        p = rng.uniform(lo, hi, size=(100, lo.size))
+        mod.lnpost(p)
+        if order == 0:
+            del ic; gc.collect(); del mod
+        elif order == 1:
+            del mod; gc.collect(); del ic
+        else:
+            ic.model_grid.interp.release(); ic.release(); mod._dirty()
+            mod.lnpost(p)            # everything is rebuilt lazily
+        gc.collect()
