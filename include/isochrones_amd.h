@@ -17,6 +17,7 @@
  *                       isochrones/priors.py (default prior lnpdf's)
  *   iso_unit_cube    <- BasicStarModel.mnest_prior                  isochrones/starmodel.py:1637-1640
  *   iso_eep_table_*, iso_interp_eep <- get_eep / interp_eeps      isochrones/models.py:501-542, interp.py:488-558
+ *   iso_tree_*       <- generic StarModel + ObservationTree           isochrones/starmodel.py:544-613, observation.py:464-491,1181-1234
  *   iso_sampler_*    <- emcee.EnsembleSampler driven by lnpost        isochrones/starmodel.py:886-972
  *   iso_catalog_*    <- StarCatalog.iter_models + one lnpost per star  isochrones/catalog.py:126-139
  *
@@ -101,6 +102,53 @@ typedef struct iso_model_desc {
     double  bound_hi[ISO_MAX_PARAMS];
 } iso_model_desc;
 
+/* ---- observation-tree models ("next" row f4) ---------------------------------------------
+ * The reference's generic StarModel keeps an ObservationTree of Python objects
+ * (isochrones/observation.py); its likelihood only needs, per observation node, the band, the
+ * set of model stars blended into it, the optional reference node (relative photometry) and the
+ * measurement.  iso_tree_desc is that flattened form (built on the host by
+ * isochrones_amd/observation.py:ObservationTree.program).  Parameters: for every system s (in
+ * sorted index order) n_stars[s] EEPs followed by age, feh, distance, AV
+ * (observation.py:1116-1148 p2pardict / param_description).  Isochrone parametrisation only
+ * (as the reference: starmodel.py:608-609). */
+#define ISO_TREE_MAX_SYSTEMS 4
+#define ISO_TREE_MAX_LEAVES  8
+#define ISO_TREE_MAX_BANDS  16
+#define ISO_TREE_MAX_TERMS  64
+#define ISO_TREE_MAX_SPEC   24
+#define ISO_TREE_MAX_PARAMS (ISO_TREE_MAX_LEAVES + 4 * ISO_TREE_MAX_SYSTEMS)
+
+typedef struct iso_tree_term {      /* one ObsNode (observation.py:464-491) */
+    int32_t  band;                  /* index into bc_cols */
+    int32_t  relative;              /* 1: compare (node - reference) with (mag - ref_mag) */
+    uint32_t mask;                  /* bit l set: leaf l lies below this node */
+    uint32_t ref_mask;              /* leaves below the reference node */
+    double   mag, unc, ref_mag;
+} iso_tree_term;
+
+typedef struct iso_tree_prop {      /* spectroscopy (a = value, b = sigma) or limit (a = min, b = max) */
+    int32_t leaf;
+    int32_t prop;                   /* 0 Teff, 1 logg, 2 feh */
+    double  a, b;
+} iso_tree_prop;
+
+typedef struct iso_tree_desc {
+    int32_t n_systems, n_leaves, n_bands, n_terms, n_spec, n_limits;
+    int32_t n_stars[ISO_TREE_MAX_SYSTEMS];
+    int32_t leaf_system[ISO_TREE_MAX_LEAVES];   /* leaves in parameter order */
+    int32_t leaf_slot[ISO_TREE_MAX_LEAVES];     /* which EEP of its system */
+    int32_t bc_cols[ISO_TREE_MAX_BANDS];
+    iso_tree_term terms[ISO_TREE_MAX_TERMS];    /* in the reference's children-first summation order */
+    iso_tree_prop spec[ISO_TREE_MAX_SPEC];
+    iso_tree_prop limits[ISO_TREE_MAX_SPEC];
+    int32_t has_plx[ISO_TREE_MAX_SYSTEMS], has_av[ISO_TREE_MAX_SYSTEMS];
+    double  plx_val[ISO_TREE_MAX_SYSTEMS], plx_unc[ISO_TREE_MAX_SYSTEMS];
+    double  av_val[ISO_TREE_MAX_SYSTEMS], av_unc[ISO_TREE_MAX_SYSTEMS];
+    iso_prior prior_mass, prior_age, prior_feh, prior_distance, prior_AV;
+    double  eep_lo, eep_hi;
+    double  bound_lo[4], bound_hi[4];           /* StarModel.bounds of age, feh, distance, AV (starmodel.py:563-566) */
+} iso_tree_desc;
+
 typedef struct iso_ctx   iso_ctx;
 typedef struct iso_table iso_table;   /* dense N-D table + axes, resident in HBM */
 typedef struct iso_ic    iso_ic;      /* model table + BC table + column binding */
@@ -174,6 +222,15 @@ int  iso_catalog_create(iso_ic* ic, const iso_model_desc* descs, int64_t n_model
 void iso_catalog_destroy(iso_catalog* c);
 int  iso_catalog_lnpost(iso_catalog* c, const int32_t* star_id, const double* pars, int64_t stride_n,
                         int64_t stride_p, int64_t n, double* lnpost_out, void* stream);
+
+/* Generic (observation-tree) StarModel: lnpost / lnprior / lnlike of starmodel.py:538-613 +
+ * observation.py:1181-1234.  Outputs as iso_lnpost; lnlike is -inf (never NaN) when not finite,
+ * as the reference. */
+typedef struct iso_tree_model iso_tree_model;
+int  iso_tree_model_create(iso_ic* ic, const iso_tree_desc* desc, iso_tree_model** out);
+void iso_tree_model_destroy(iso_tree_model* m);
+int  iso_tree_lnpost(iso_tree_model* m, const double* pars, int64_t stride_n, int64_t stride_p, int64_t n,
+                     double* lnpost_out, double* lnprior_out, double* lnlike_out, void* stream);
 
 /* Device-resident affine-invariant ensemble sampler (stretch move, Goodman & Weare 2010) — what the
  * reference obtains from emcee.EnsembleSampler(nwalkers, npars, self.lnpost).run_mcmc(...)

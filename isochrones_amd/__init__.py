@@ -6,7 +6,9 @@ HIP kernels for gfx950 behind the C ABI in include/isochrones_amd.h (no CPU fall
 from .interp import DFInterpolator
 from .models import (ModelGridInterpolator, EvolutionTrackInterpolator, IsochroneInterpolator,
                      synthetic_track, synthetic_isochrone, get_ichrone)
-from .starmodel import (BasicStarModel, StarModel, SingleStarModel, BinaryStarModel, TripleStarModel)
+from .starmodel import (BasicStarModel, StarModel, TreeStarModel, SingleStarModel, BinaryStarModel,
+                        TripleStarModel)
+from .observation import ObservationTree, Observation, Source
 from .sampler import EnsembleSampler
 from .catalog import StarCatalog, CatalogPosterior, fit_catalog, synthetic_catalog, shard_of, shard_indices
 from . import priors, grids, ingest

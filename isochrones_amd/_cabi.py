@@ -59,6 +59,37 @@ class IsoModelDesc(C.Structure):
     ]
 
 
+TREE_MAX_SYSTEMS, TREE_MAX_LEAVES, TREE_MAX_BANDS, TREE_MAX_TERMS, TREE_MAX_SPEC = 4, 8, 16, 64, 24
+
+
+class IsoTreeTerm(C.Structure):
+    _fields_ = [("band", C.c_int32), ("relative", C.c_int32), ("mask", C.c_uint32), ("ref_mask", C.c_uint32),
+                ("mag", C.c_double), ("unc", C.c_double), ("ref_mag", C.c_double)]
+
+
+class IsoTreeProp(C.Structure):
+    _fields_ = [("leaf", C.c_int32), ("prop", C.c_int32), ("a", C.c_double), ("b", C.c_double)]
+
+
+class IsoTreeDesc(C.Structure):
+    _fields_ = [
+        ("n_systems", C.c_int32), ("n_leaves", C.c_int32), ("n_bands", C.c_int32), ("n_terms", C.c_int32),
+        ("n_spec", C.c_int32), ("n_limits", C.c_int32),
+        ("n_stars", C.c_int32 * TREE_MAX_SYSTEMS),
+        ("leaf_system", C.c_int32 * TREE_MAX_LEAVES), ("leaf_slot", C.c_int32 * TREE_MAX_LEAVES),
+        ("bc_cols", C.c_int32 * TREE_MAX_BANDS),
+        ("terms", IsoTreeTerm * TREE_MAX_TERMS),
+        ("spec", IsoTreeProp * TREE_MAX_SPEC), ("limits", IsoTreeProp * TREE_MAX_SPEC),
+        ("has_plx", C.c_int32 * TREE_MAX_SYSTEMS), ("has_av", C.c_int32 * TREE_MAX_SYSTEMS),
+        ("plx_val", C.c_double * TREE_MAX_SYSTEMS), ("plx_unc", C.c_double * TREE_MAX_SYSTEMS),
+        ("av_val", C.c_double * TREE_MAX_SYSTEMS), ("av_unc", C.c_double * TREE_MAX_SYSTEMS),
+        ("prior_mass", IsoPrior), ("prior_age", IsoPrior), ("prior_feh", IsoPrior),
+        ("prior_distance", IsoPrior), ("prior_AV", IsoPrior),
+        ("eep_lo", C.c_double), ("eep_hi", C.c_double),
+        ("bound_lo", C.c_double * 4), ("bound_hi", C.c_double * 4),
+    ]
+
+
 #: every symbol include/isochrones_amd.h declares (tests check the .so exports all of them)
 EXPORTED_SYMBOLS = (
     "iso_last_error", "iso_version", "iso_ctx_create", "iso_ctx_destroy",
@@ -69,6 +100,7 @@ EXPORTED_SYMBOLS = (
     "iso_catalog_create", "iso_catalog_destroy", "iso_catalog_lnpost",
     "iso_eep_table_create", "iso_eep_table_destroy", "iso_interp_eep",
     "iso_sampler_create_model", "iso_sampler_create_catalog", "iso_sampler_destroy", "iso_sampler_run",
+    "iso_tree_model_create", "iso_tree_model_destroy", "iso_tree_lnpost",
 )
 
 _LIB = None
@@ -142,6 +174,10 @@ def lib():
     L.iso_sampler_destroy.argtypes = [vp]
     L.iso_sampler_destroy.restype = None
     L.iso_sampler_run.argtypes = [vp, pd, pd, C.c_int, pd, pd, pd, vp]
+    L.iso_tree_model_create.argtypes = [vp, C.POINTER(IsoTreeDesc), C.POINTER(vp)]
+    L.iso_tree_model_destroy.argtypes = [vp]
+    L.iso_tree_model_destroy.restype = None
+    L.iso_tree_lnpost.argtypes = [vp, pd, i64, i64, i64, pd, pd, pd, vp]
     for name in EXPORTED_SYMBOLS:
         fn = getattr(L, name)
         if fn.restype is C.c_int:

@@ -716,6 +716,159 @@ __global__ __launch_bounds__(BLOCK) void k_interp_eep(const EepArgs A)
 }
 
 // -------------------------------------------------------------------------------------------
+// "next" row f4: generic StarModel over a flattened ObservationTree
+// (reference semantics: isochrones/starmodel.py:538-613, observation.py:464-491, 1181-1234)
+// -------------------------------------------------------------------------------------------
+struct DevTree {
+    int n_systems, n_leaves, n_bands, n_terms, n_spec, n_limits, n_params;
+    int n_stars[ISO_TREE_MAX_SYSTEMS], sys_base[ISO_TREE_MAX_SYSTEMS];
+    int leaf_system[ISO_TREE_MAX_LEAVES], leaf_slot[ISO_TREE_MAX_LEAVES];
+    iso_tree_term terms[ISO_TREE_MAX_TERMS];
+    double term_g0[ISO_TREE_MAX_TERMS];          // log(1/sqrt(2 pi)) + log(unc)
+    iso_tree_prop spec[ISO_TREE_MAX_SPEC], limits[ISO_TREE_MAX_SPEC];
+    double spec_g0[ISO_TREE_MAX_SPEC];
+    int has_plx[ISO_TREE_MAX_SYSTEMS], has_av[ISO_TREE_MAX_SYSTEMS];
+    double plx_val[ISO_TREE_MAX_SYSTEMS], plx_unc[ISO_TREE_MAX_SYSTEMS], plx_g0[ISO_TREE_MAX_SYSTEMS];
+    double av_val[ISO_TREE_MAX_SYSTEMS], av_unc[ISO_TREE_MAX_SYSTEMS], av_g0[ISO_TREE_MAX_SYSTEMS];
+    DevPrior prior_mass, prior_age, prior_feh, prior_distance, prior_AV;
+    double eep_lo, eep_hi;
+    double bound_lo[4], bound_hi[4];
+};
+
+struct TreeArgs {
+    Grid3V g3;
+    Grid4V g4;            // BC packed to the tree's bands (ncol == n_bands)
+    const DevTree* T;
+    const double* pars;
+    int64_t stride_n, stride_p, n;
+    double *lnpost, *lnprior, *lnlike;
+};
+
+__device__ __forceinline__ double tree_addmags(const double (*flux)[ISO_TREE_MAX_BANDS], uint32_t mask, int band,
+                                               int n_leaves)
+{
+    double tot = 0.0;
+    for (int l = 0; l < n_leaves; ++l)
+        if (mask & (1u << l)) tot += flux[l][band];
+    return -2.5 * log10(tot);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_lnpost_tree(const TreeArgs A)
+{
+    extern __shared__ double lds[];
+    stage_axes<3>(A.g3.ax, lds);
+    stage_axes<4>(A.g4.ax, lds);
+    __syncthreads();
+    const DevTree& T = *A.T;
+    const int64_t stride_grid = (int64_t)gridDim.x * BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < A.n; i += stride_grid) {
+        double p[ISO_TREE_MAX_PARAMS];
+        {
+            const double* __restrict__ src = A.pars + i * A.stride_n;
+            for (int j = 0; j < T.n_params; ++j) p[j] = src[j * A.stride_p];
+        }
+        // ---- every model star: model-table gather, then magnitudes as fluxes ----
+        double star[ISO_TREE_MAX_LEAVES][6];
+        double flux[ISO_TREE_MAX_LEAVES][ISO_TREE_MAX_BANDS];
+        for (int l = 0; l < T.n_leaves; ++l) {
+            const int s = T.leaf_system[l];
+            const int base = T.sys_base[s], N = T.n_stars[s];
+            const double eep = p[base + T.leaf_slot[l]], age = p[base + N], feh = p[base + N + 1];
+            const double dist = p[base + N + 2], AV = p[base + N + 3];
+            Cell3 c3;
+            if (locate3(A.g3, lds, age, feh, eep, c3)) {
+                gather3<6>(A.g3, c3, star[l]);
+            } else {
+                for (int q = 0; q < 6; ++q) star[l][q] = d_nan();
+            }
+            Cell4 c4;
+            const bool ok = locate4(A.g4, lds, star[l][0], star[l][1], star[l][2], AV, c4);
+            const double dm = 5 * log10(dist / 10.0);
+            for (int b = 0; b < T.n_bands; ++b) {
+                const double bc = ok ? gather4_col(A.g4, c4, b) : d_nan();
+                flux[l][b] = exp10(-0.4 * (star[l][3] + dm - bc));
+            }
+        }
+        // ---- lnprior (starmodel.py:557-613) ----
+        double lnp = 0.0;
+        bool dead = false;
+        for (int s = 0; s < T.n_systems && !dead; ++s) {
+            const int base = T.sys_base[s], N = T.n_stars[s];
+            const DevPrior* pri[4] = {&T.prior_age, &T.prior_feh, &T.prior_distance, &T.prior_AV};
+            for (int j = 0; j < 4 && !dead; ++j) {
+                const double val = p[base + N + j];
+                if (val < T.bound_lo[j] || val > T.bound_hi[j]) { dead = true; break; }
+                lnp += prior_lnpdf(*pri[j], val);
+                if (!isfinite(lnp)) dead = true;
+            }
+            for (int j = 1; j < N && !dead; ++j)
+                if (!(p[base + j] <= p[base + j - 1])) dead = true;
+            if (dead) break;
+            for (int l = 0; l < T.n_leaves; ++l) {
+                if (T.leaf_system[l] != s) continue;
+                const double eep = p[base + T.leaf_slot[l]];
+                double term;
+                if (eep < T.eep_lo || eep > T.eep_hi) {
+                    term = -d_inf();
+                } else {
+                    const double pdf = prior_call(T.prior_mass, star[l][4]) * star[l][5];
+                    term = (pdf != 0) ? log(pdf) : -d_inf();
+                }
+                lnp += term;
+            }
+        }
+        if (dead) lnp = -d_inf();
+        const bool prior_ok = isfinite(lnp);
+        // ---- lnlike (observation.py:1181-1234): -inf as soon as the running sum is not finite ----
+        double lnl = d_nan();
+        if (A.lnlike || prior_ok) {
+            lnl = 0.0;
+            bool bad = false;
+            for (int t = 0; t < T.n_terms && !bad; ++t) {
+                const iso_tree_term& tt = T.terms[t];
+                double mag = tt.mag;
+                double mod = tree_addmags(flux, tt.mask, tt.band, T.n_leaves);
+                if (tt.relative) {
+                    mod -= tree_addmags(flux, tt.ref_mask, tt.band, T.n_leaves);
+                    mag -= tt.ref_mag;
+                }
+                const double r = mag - mod;
+                lnl += -0.5 * (r * r) / (tt.unc * tt.unc) + T.term_g0[t];
+                if (!isfinite(lnl)) bad = true;
+            }
+            for (int k = 0; k < T.n_spec && !bad; ++k) {
+                const iso_tree_prop& sp = T.spec[k];
+                const double r = sp.a - star[sp.leaf][sp.prop];
+                lnl += -0.5 * (r * r) / (sp.b * sp.b) + T.spec_g0[k];
+                if (!isfinite(lnl)) bad = true;
+            }
+            for (int k = 0; k < T.n_limits && !bad; ++k) {
+                const iso_tree_prop& lm = T.limits[k];
+                const double mod = star[lm.leaf][lm.prop];
+                if (mod < lm.a || mod > lm.b || !isfinite(mod)) bad = true;
+            }
+            if (!bad) {
+                for (int s = 0; s < T.n_systems; ++s)
+                    if (T.has_plx[s]) {
+                        const double r = T.plx_val[s] - 1.0 / p[T.sys_base[s] + T.n_stars[s] + 2] * 1000.0;
+                        lnl += -0.5 * (r * r) / (T.plx_unc[s] * T.plx_unc[s]) + T.plx_g0[s];
+                    }
+                for (int s = 0; s < T.n_systems; ++s)
+                    if (T.has_av[s]) {
+                        const double r = T.av_val[s] - p[T.sys_base[s] + T.n_stars[s] + 3];
+                        lnl += -0.5 * (r * r) / (T.av_unc[s] * T.av_unc[s]) + T.av_g0[s];
+                    }
+                if (!isfinite(lnl)) bad = true;
+            }
+            if (bad) lnl = -d_inf();
+        }
+        if (A.lnpost) A.lnpost[i] = prior_ok ? lnp + lnl : -d_inf();
+        if (A.lnprior) A.lnprior[i] = lnp;
+        if (A.lnlike) A.lnlike[i] = lnl;
+    }
+}
+
+// -------------------------------------------------------------------------------------------
 // small kernels
 // -------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(BLOCK) void k_unit_cube(const DevModel* m, double* cube, int64_t stride_n,
@@ -979,6 +1132,15 @@ hipError_t pack_corners(const double* src, int ncol, int keep, int ndim, const i
 // ======================================================================================
 // C ABI
 // ======================================================================================
+struct iso_tree_model {
+    int device;
+    iso_ic* ic;
+    int n_params;
+    DevTree* d_tree;
+    double* d_bc_hot;
+    Grid4V g4;
+};
+
 struct iso_eep_table {
     int device;
     int64_t n0, n1, n_eep;
@@ -1677,6 +1839,146 @@ int iso_catalog_lnpost(iso_catalog* c, const int32_t* star_id, const double* par
     F.lnpost = lnpost_out;
     if (!launch_lnpost_fast(c->ic->kind, c->n_stars, c->n_bands, true, true, F, as_stream(stream)))
         return fail(ISO_ERR_INVALID, "iso_catalog_lnpost: no kernel specialisation");
+    HIP_TRY(hipGetLastError());
+    return ISO_OK;
+}
+
+int iso_tree_model_create(iso_ic* ic, const iso_tree_desc* d, iso_tree_model** out)
+{
+    if (!ic || !d || !out) return fail(ISO_ERR_INVALID, "iso_tree_model_create: NULL argument");
+    if (ic->kind != ISO_KIND_ISO) return fail(ISO_ERR_INVALID, "iso_tree_model_create: isochrone parametrisation only");
+    if (ic->prior_cols[0] < 0 || ic->prior_cols[1] < 0)
+        return fail(ISO_ERR_INVALID, "iso_tree_model_create: the model table has no EEP-prior columns");
+    if (d->n_systems < 1 || d->n_systems > ISO_TREE_MAX_SYSTEMS || d->n_leaves < 1 || d->n_leaves > ISO_TREE_MAX_LEAVES ||
+        d->n_bands < 0 || d->n_bands > ISO_TREE_MAX_BANDS || d->n_terms < 0 || d->n_terms > ISO_TREE_MAX_TERMS ||
+        d->n_spec < 0 || d->n_spec > ISO_TREE_MAX_SPEC || d->n_limits < 0 || d->n_limits > ISO_TREE_MAX_SPEC)
+        return fail(ISO_ERR_INVALID, "iso_tree_model_create: counts out of range");
+    int total = 0;
+    for (int s = 0; s < d->n_systems; ++s) {
+        if (d->n_stars[s] < 1) return fail(ISO_ERR_INVALID, "iso_tree_model_create: empty system");
+        total += d->n_stars[s];
+    }
+    if (total != d->n_leaves) return fail(ISO_ERR_INVALID, "iso_tree_model_create: n_leaves != sum(n_stars)");
+    for (int l = 0; l < d->n_leaves; ++l)
+        if (d->leaf_system[l] < 0 || d->leaf_system[l] >= d->n_systems || d->leaf_slot[l] < 0 ||
+            d->leaf_slot[l] >= d->n_stars[d->leaf_system[l]])
+            return fail(ISO_ERR_INVALID, "iso_tree_model_create: bad leaf placement");
+    for (int b = 0; b < d->n_bands; ++b)
+        if (d->bc_cols[b] < 0 || d->bc_cols[b] >= ic->g4.ncol) return fail(ISO_ERR_INVALID, "iso_tree_model_create: band column out of range");
+    const uint32_t all = (d->n_leaves >= 32) ? 0xFFFFFFFFu : ((1u << d->n_leaves) - 1u);
+    for (int t = 0; t < d->n_terms; ++t) {
+        const iso_tree_term& tt = d->terms[t];
+        if (tt.band < 0 || tt.band >= d->n_bands || (tt.mask & ~all) || (tt.ref_mask & ~all))
+            return fail(ISO_ERR_INVALID, "iso_tree_model_create: bad observation term");
+    }
+    for (int k = 0; k < d->n_spec; ++k)
+        if (d->spec[k].leaf < 0 || d->spec[k].leaf >= d->n_leaves || d->spec[k].prop < 0 || d->spec[k].prop > 2)
+            return fail(ISO_ERR_INVALID, "iso_tree_model_create: bad spectroscopy entry");
+    for (int k = 0; k < d->n_limits; ++k)
+        if (d->limits[k].leaf < 0 || d->limits[k].leaf >= d->n_leaves || d->limits[k].prop < 0 || d->limits[k].prop > 2)
+            return fail(ISO_ERR_INVALID, "iso_tree_model_create: bad limit entry");
+    const iso_prior* pr[5] = {&d->prior_mass, &d->prior_age, &d->prior_feh, &d->prior_distance, &d->prior_AV};
+    for (int j = 0; j < 5; ++j)
+        if (!prior_kind_ok(pr[j]->kind)) return fail(ISO_ERR_INVALID, "iso_tree_model_create: unknown prior family");
+
+    DeviceGuard guard(ic->device);
+    iso_tree_model* m = new (std::nothrow) iso_tree_model();
+    if (!m) return fail(ISO_ERR_NOMEM, "iso_tree_model_create: out of host memory");
+    m->device = ic->device;
+    m->ic = ic;
+    m->d_tree = nullptr;
+    m->d_bc_hot = nullptr;
+    DevTree* H = new DevTree();
+    std::memset(H, 0, sizeof(DevTree));
+    H->n_systems = d->n_systems; H->n_leaves = d->n_leaves; H->n_bands = d->n_bands;
+    H->n_terms = d->n_terms; H->n_spec = d->n_spec; H->n_limits = d->n_limits;
+    int base = 0;
+    for (int s = 0; s < d->n_systems; ++s) {
+        H->n_stars[s] = d->n_stars[s];
+        H->sys_base[s] = base;
+        base += d->n_stars[s] + 4;
+        H->has_plx[s] = d->has_plx[s]; H->has_av[s] = d->has_av[s];
+        H->plx_val[s] = d->plx_val[s]; H->plx_unc[s] = d->plx_unc[s];
+        H->av_val[s] = d->av_val[s]; H->av_unc[s] = d->av_unc[s];
+        double u2;
+        gauss_consts(d->plx_unc[s], H->plx_g0[s], u2);
+        gauss_consts(d->av_unc[s], H->av_g0[s], u2);
+    }
+    H->n_params = base;
+    m->n_params = base;
+    for (int l = 0; l < d->n_leaves; ++l) {
+        H->leaf_system[l] = d->leaf_system[l];
+        H->leaf_slot[l] = d->leaf_slot[l];
+    }
+    for (int t = 0; t < d->n_terms; ++t) {
+        H->terms[t] = d->terms[t];
+        double u2;
+        gauss_consts(d->terms[t].unc, H->term_g0[t], u2);
+    }
+    for (int k = 0; k < d->n_spec; ++k) {
+        H->spec[k] = d->spec[k];
+        double u2;
+        gauss_consts(d->spec[k].b, H->spec_g0[k], u2);
+    }
+    for (int k = 0; k < d->n_limits; ++k) H->limits[k] = d->limits[k];
+    H->prior_mass = make_dev_prior(d->prior_mass);
+    H->prior_age = make_dev_prior(d->prior_age);
+    H->prior_feh = make_dev_prior(d->prior_feh);
+    H->prior_distance = make_dev_prior(d->prior_distance);
+    H->prior_AV = make_dev_prior(d->prior_AV);
+    H->eep_lo = d->eep_lo; H->eep_hi = d->eep_hi;
+    for (int j = 0; j < 4; ++j) {
+        H->bound_lo[j] = d->bound_lo[j];
+        H->bound_hi[j] = d->bound_hi[j];
+    }
+    hipError_t e = hipMalloc(&m->d_tree, sizeof(DevTree));
+    if (e == hipSuccess) e = hipMemcpy(m->d_tree, H, sizeof(DevTree), hipMemcpyHostToDevice);
+    delete H;
+    m->g4 = ic->g4;
+    if (e == hipSuccess && d->n_bands > 0) {
+        e = pack_bands(ic, d->bc_cols, d->n_bands, &m->d_bc_hot);
+        m->g4.tab = m->d_bc_hot;
+        m->g4.ncol = d->n_bands;
+    }
+    if (e != hipSuccess) {
+        std::string msg = std::string("iso_tree_model_create: ") + hipGetErrorString(e);
+        iso_tree_model_destroy(m);
+        return fail(e == hipErrorOutOfMemory ? ISO_ERR_NOMEM : ISO_ERR_HIP, msg);
+    }
+    *out = m;
+    return ISO_OK;
+}
+
+void iso_tree_model_destroy(iso_tree_model* m)
+{
+    if (!m) return;
+    DeviceGuard guard(m->device);
+    if (m->d_tree) (void)hipFree(m->d_tree);
+    if (m->d_bc_hot) (void)hipFree(m->d_bc_hot);
+    delete m;
+}
+
+int iso_tree_lnpost(iso_tree_model* m, const double* pars, int64_t stride_n, int64_t stride_p, int64_t n,
+                    double* lnpost_out, double* lnprior_out, double* lnlike_out, void* stream)
+{
+    if (!m || (!pars && n > 0)) return fail(ISO_ERR_INVALID, "iso_tree_lnpost: NULL argument");
+    if (n < 0) return fail(ISO_ERR_INVALID, "iso_tree_lnpost: n < 0");
+    if (!lnpost_out && !lnprior_out && !lnlike_out) return fail(ISO_ERR_INVALID, "iso_tree_lnpost: no output requested");
+    if (n == 0) return ISO_OK;
+    TreeArgs A;
+    A.g3 = m->ic->g3;
+    A.g4 = m->g4;
+    A.T = m->d_tree;
+    A.pars = pars;
+    A.stride_n = stride_n;
+    A.stride_p = stride_p;
+    A.n = n;
+    A.lnpost = lnpost_out;
+    A.lnprior = lnprior_out;
+    A.lnlike = lnlike_out;
+    DeviceGuard guard(m->device);
+    hipLaunchKernelGGL(k_lnpost_tree, dim3(grid_blocks(n)), dim3(BLOCK), (size_t)m->ic->lds_doubles * sizeof(double),
+                       as_stream(stream), A);
     HIP_TRY(hipGetLastError());
     return ISO_OK;
 }

@@ -397,4 +397,233 @@ class TripleStarModel(BasicStarModel):
         super().__init__(*args, **kwargs)
 
 
-StarModel = BasicStarModel
+
+# ==========================================================================================
+# generic (observation-tree) model — "next" row f4
+# ==========================================================================================
+class TreeStarModel:
+    """The reference's generic ``StarModel`` (isochrones/starmodel.py:63-661): photometry organised
+    in an :class:`~isochrones_amd.observation.ObservationTree` (resolved and blended sources,
+    relative photometry, several physical systems), evaluated on the device from the flattened
+    tree.  Isochrone parametrisation only, as the reference.  Parameter vector: for every system
+    its EEPs (descending) followed by age, feh, distance, AV (``param_names``).
+
+    Keyword measurements (``Teff=(v, e)``, ``logg=``, ``feh=``, ``parallax=``, ``AV=``, ``<band>=``)
+    are added to the tree exactly like the reference's ``_build_obs`` / ``_add_properties``; a
+    keyword of the form ``Teff_1=(v, e)`` addresses leaf ``0_1``."""
+
+    def __init__(self, ic, obs=None, N=1, index=0, name="", eep_bounds=None, maxAV=None, max_distance=None,
+                 **kwargs):
+        import re
+        from .observation import Observation, ObservationTree, Source
+        if ic.eep_replaces != "mass":
+            raise NotImplementedError("Prior not implemented for evolution track grids")
+        self._ic = ic
+        self.name = name
+        if obs is None:
+            obs = ObservationTree()
+            for k, v in kwargs.items():
+                if k in ic.bands:
+                    v = (v, np.nan) if np.size(v) != 2 else v
+                    o = Observation("", k, 99)           # bogus resolution, as the reference
+                    o.add_source(Source(v[0], v[1]))
+                    o._set_reference()
+                    obs.add_observation(o)
+            obs.define_models(ic, N=N, index=index)
+            add_props = True
+        else:
+            add_props = len(obs.model_nodes()) == 0
+            if add_props:
+                obs.define_models(ic, N=N, index=index)
+        self.obs = obs
+        if add_props:
+            for k, v in kwargs.items():
+                if k in ic.bands or k in ("maxAV", "max_distance"):
+                    continue
+                if k == "parallax":
+                    obs.add_parallax(v)
+                elif k == "AV":
+                    obs.add_AV(v)
+                elif k in ("Teff", "logg", "feh", "density"):
+                    obs.add_spectroscopy(**{k: v})
+                elif re.search(r"_", k):
+                    m = re.search(r"^(\w+)_(\w+)$", k)
+                    obs.add_spectroscopy(label="0_{}".format(m.group(2)), **{m.group(1): v})
+        self._priors = {"mass": ChabrierPrior(), "feh": FehPrior(), "age": AgePrior(),
+                        "distance": DistancePrior(), "AV": AVPrior()}
+        self._priors["eep"] = EEPPrior(ic, self._priors["mass"], bounds=eep_bounds)
+        self._bounds = {"mass": None, "feh": None, "age": None, "distance": self._priors["distance"].bounds,
+                        "AV": self._priors["AV"].bounds, "eep": self._priors["eep"].bounds}
+        if maxAV is not None:
+            self.set_bounds(AV=(0, maxAV))
+        if max_distance is not None:
+            self.set_bounds(distance=(0, max_distance))
+        self._handles = {}
+
+    ic = property(lambda self: self._ic)
+
+    @property
+    def param_names(self):
+        return tuple(self.obs.param_description)
+
+    param_description = param_names
+
+    @property
+    def n_params(self):
+        return len(self.param_names)
+
+    @property
+    def bands(self):
+        return [b for b in self.ic.bc_grid.bands if b in set(self.obs.bands)]
+
+    def bounds(self, prop):
+        if self._bounds[prop] is None:
+            if prop not in ("mass", "feh", "age"):
+                raise ValueError("Unknown property {}".format(prop))
+            lo, hi = self.ic.model_grid.get_limits(prop)
+            self._bounds[prop] = (lo, hi)
+            self._priors[prop].bounds = (lo, hi)
+            self._dirty()
+        return self._bounds[prop]
+
+    def set_bounds(self, **kwargs):
+        for k, v in kwargs.items():
+            if len(v) != 2:
+                raise ValueError("Must provide (min, max)")
+            self._bounds[k] = tuple(v)
+            self._priors[k].bounds = tuple(v)
+        self._dirty()
+
+    def tree_desc(self) -> _cabi.IsoTreeDesc:
+        """Pack the flattened tree + prior constants into the C-ABI record (host only)."""
+        bands = self.bands
+        prog = self.obs.program(bands)
+        d = _cabi.IsoTreeDesc()
+        if len(prog["systems"]) > _cabi.TREE_MAX_SYSTEMS or len(prog["leaf_system"]) > _cabi.TREE_MAX_LEAVES:
+            raise ValueError("at most %d systems / %d model stars" % (_cabi.TREE_MAX_SYSTEMS, _cabi.TREE_MAX_LEAVES))
+        if len(bands) > _cabi.TREE_MAX_BANDS or len(prog["terms"]) > _cabi.TREE_MAX_TERMS:
+            raise ValueError("at most %d bands / %d observation nodes" % (_cabi.TREE_MAX_BANDS, _cabi.TREE_MAX_TERMS))
+        if len(prog["spec"]) > _cabi.TREE_MAX_SPEC or len(prog["limits"]) > _cabi.TREE_MAX_SPEC:
+            raise ValueError("too many spectroscopic constraints")
+        d.n_systems, d.n_leaves, d.n_bands = len(prog["systems"]), len(prog["leaf_system"]), len(bands)
+        d.n_terms, d.n_spec, d.n_limits = len(prog["terms"]), len(prog["spec"]), len(prog["limits"])
+        for i, n in enumerate(prog["n_stars"]):
+            d.n_stars[i] = n
+        for i, (s, j) in enumerate(zip(prog["leaf_system"], prog["leaf_slot"])):
+            d.leaf_system[i], d.leaf_slot[i] = s, j
+        ci = self.ic.bc_grid.interp.column_index
+        for i, b in enumerate(bands):
+            d.bc_cols[i] = ci[b]
+        for i, t in enumerate(prog["terms"]):
+            e = d.terms[i]
+            e.band, e.relative, e.mask, e.ref_mask = t["band"], t["relative"], t["mask"], t["ref_mask"]
+            e.mag, e.unc, e.ref_mag = t["mag"], t["unc"], t["ref_mag"]
+        for i, t in enumerate(prog["spec"]):
+            d.spec[i].leaf, d.spec[i].prop, d.spec[i].a, d.spec[i].b = t["leaf"], t["prop"], t["val"], t["unc"]
+        for i, t in enumerate(prog["limits"]):
+            d.limits[i].leaf, d.limits[i].prop, d.limits[i].a, d.limits[i].b = t["leaf"], t["prop"], t["lo"], t["hi"]
+        for s, (v, e) in prog["parallax"].items():
+            d.has_plx[s], d.plx_val[s], d.plx_unc[s] = 1, v, e
+        for s, (v, e) in prog["AV"].items():
+            d.has_av[s], d.av_val[s], d.av_unc[s] = 1, v, e
+        for j, prop in enumerate(("age", "feh", "distance", "AV")):
+            d.bound_lo[j], d.bound_hi[j] = self.bounds(prop)        # also snaps feh/age priors to the table
+        for name in ("mass", "age", "feh", "distance", "AV"):
+            setattr(d, "prior_" + name, self._priors[name].desc())
+        d.eep_lo, d.eep_hi = self._priors["eep"].bounds
+        return d
+
+    def _dirty(self):
+        for h in getattr(self, "_handles", {}).values():
+            _cabi.lib().iso_tree_model_destroy(h)
+        self._handles = {}
+        self._handle_ic = {}
+
+    def handle(self, device=None):
+        if device is None:
+            device = dev.current_device()
+        ich = self.ic.handle(device)
+        h = self._handles.get(device)
+        if h is not None and self._handle_ic.get(device) != ich.value:
+            _cabi.lib().iso_tree_model_destroy(h)
+            h = None
+        if h is None:
+            desc = self.tree_desc()
+            h = C.c_void_p()
+            _cabi.check(_cabi.lib().iso_tree_model_create(ich, C.byref(desc), C.byref(h)))
+            self._handles[device] = h
+            self._handle_ic[device] = ich.value
+        return h
+
+    def __del__(self):
+        try:
+            self._dirty()
+        except Exception:
+            pass
+
+    def evaluate_device(self, pars, parts=False):
+        """pars: CUDA float64 [N, n_params] -> lnpost [N] or (lnpost, lnprior, lnlike)."""
+        npar = self.n_params
+        if pars.dim() != 2 or pars.shape[1] != npar:
+            raise ValueError("expected [N, %d]" % npar)
+        device = pars.device.index
+        pars = pars.contiguous()
+        n = pars.shape[0]
+        post = dev.empty_f64((n,), device)
+        prior = dev.empty_f64((n,), device) if parts else None
+        like = dev.empty_f64((n,), device) if parts else None
+        if n:
+            _cabi.check(_cabi.lib().iso_tree_lnpost(self.handle(device), dev.ptr(pars), npar, 1, n, dev.ptr(post),
+                                                    dev.ptr(prior), dev.ptr(like), dev.stream_ptr(device)))
+        return (post, prior, like) if parts else post
+
+    def _evaluate(self, p, which):
+        if dev.is_tensor(p) and p.is_cuda:
+            single = p.dim() == 1
+            out = self.evaluate_device(p.double()[None, :] if single else p.double(), parts=which != 0)
+            out = out if which == 0 else out[which]
+            return out[0] if single else out
+        arr = np.asarray(p, dtype=float)
+        single = arr.ndim == 1
+        device = dev.current_device()
+        out = self.evaluate_device(dev.to_device_f64(arr[None, :] if single else arr, device), parts=which != 0)
+        out = (out if which == 0 else out[which]).cpu().numpy()
+        return float(out[0]) if single else out
+
+    def lnpost(self, p):
+        return self._evaluate(p, 0)
+
+    def lnprior(self, p):
+        return self._evaluate(p, 1)
+
+    def lnlike(self, p):
+        return self._evaluate(p, 2)
+
+    def prior_transform(self, cube):
+        """Unit cube -> parameters (reference: starmodel.py:615-627)."""
+        cube = np.asarray(cube, dtype=float)
+        pars = cube * 0
+        i = 0
+        N = self.obs.Nstars
+        lo_e, hi_e = self._bounds["eep"]
+        for s in self.obs.systems:
+            n = N[s]
+            pars[..., i:i + n] = (hi_e - lo_e) * cube[..., i:i + n] + lo_e
+            for j, par in enumerate(("age", "feh", "distance", "AV")):
+                lo, hi = self.bounds(par)
+                pars[..., i + n + j] = (hi - lo) * cube[..., i + n + j] + lo
+            i += 4 + n
+        return pars
+
+    def mnest_loglike(self, cube, ndim=None, nparams=None):
+        return self.lnpost(cube)
+
+
+def StarModel(ic, obs=None, **kwargs):
+    """Factory with the reference's name: an :class:`ObservationTree` (or ``N``/keywords on an
+    isochrone grid that describe blended multi-system photometry) gives the generic tree model;
+    plain keyword measurements of one unresolved 1-3 star system give :class:`BasicStarModel`
+    (the reference pins both to the same numbers, tests/test_likelihood.py)."""
+    if obs is not None:
+        return TreeStarModel(ic, obs=obs, **kwargs)
+    return BasicStarModel(ic, **kwargs)

@@ -605,3 +605,136 @@ void orc_interp_eep(const double* x, const double* x0, const double* x1, int64_t
     for (int64_t i = 0; i < n; ++i)
         out[i] = orc_interp_eep1(x[i], x0[i], x1[i], ax0, n0, ax1, n1, ages, lengths, n_eep);
 }
+
+/* ---------------------------------------------------------------------------------------
+ * "next" row f4 — generic StarModel over an ObservationTree.
+ * reference: isochrones/starmodel.py:538-613 (lnpost / lnlike / lnprior),
+ *            isochrones/observation.py:464-491 (ObsNode.lnlike), :1116-1130 (p2pardict),
+ *            :1181-1234 (ObservationTree.lnlike), isochrones/utils.py:43-64 (addmags).
+ * The tree itself is flattened on the host (iso_tree_desc); this restates the arithmetic.
+ * ------------------------------------------------------------------------------------- */
+static double orc_addmags_mask(const double mags[][ISO_TREE_MAX_BANDS], uint32_t mask, int band, int n_leaves)
+{
+    /* utils.addmags: tot = sum 10**(-0.4 m); -2.5*log10(tot) — also for a single star */
+    double tot = 0;
+    for (int l = 0; l < n_leaves; ++l)
+        if (mask & (1u << l)) tot += pow(10.0, -0.4 * mags[l][band]);
+    return -2.5 * log10(tot);
+}
+
+static void orc_tree_leaf_pars(const iso_tree_desc* d, const double* p, int leaf, double out[5])
+{
+    int base = 0;
+    for (int s = 0; s < d->leaf_system[leaf]; ++s) base += d->n_stars[s] + 4;
+    const int N = d->n_stars[d->leaf_system[leaf]];
+    out[0] = p[base + d->leaf_slot[leaf]];
+    for (int j = 0; j < 4; ++j) out[1 + j] = p[base + N + j];
+}
+
+static double orc_tree_lnprior1(const orc_ic* ic, const iso_tree_desc* d, const double* p)
+{
+    /* starmodel.py:557-613 (isochrone grids only) */
+    iso_model_desc shim;                      /* eep prior helper reads eep bounds + priors from here */
+    memset(&shim, 0, sizeof(shim));
+    shim.prior_mass = d->prior_mass;
+    shim.prior_age = d->prior_age;
+    shim.eep_lo = d->eep_lo;
+    shim.eep_hi = d->eep_hi;
+    const iso_prior* pri[4] = {&d->prior_age, &d->prior_feh, &d->prior_distance, &d->prior_AV};
+    double lnp = 0;
+    int i = 0;
+    for (int s = 0; s < d->n_systems; ++s) {
+        const int N = d->n_stars[s];
+        for (int j = 0; j < 4; ++j) {
+            const double val = p[i + N + j];
+            if (val < d->bound_lo[j] || val > d->bound_hi[j]) return -INFINITY;
+            lnp += orc_prior_lnpdf(pri[j], val);
+            if (!isfinite(lnp)) return -INFINITY;
+        }
+        for (int j = 1; j < N; ++j)
+            if (!(p[i + j] <= p[i + j - 1])) return -INFINITY;      /* (eeps[1:] <= eeps[:-1]).all() */
+        for (int j = 0; j < N; ++j) lnp += orc_eep_lnpdf(ic, &shim, p[i + j], p[i + N], p[i + N + 1]);
+        i += N + 4;
+    }
+    return lnp;
+}
+
+static double orc_tree_lnlike1(const orc_ic* ic, const iso_tree_desc* d, const double* p)
+{
+    const double L = log(1.0 / sqrt(2 * M_PI));
+    double mags[ISO_TREE_MAX_LEAVES][ISO_TREE_MAX_BANDS];
+    double spec[ISO_TREE_MAX_LEAVES][3];
+    for (int l = 0; l < d->n_leaves; ++l) {
+        double q[5];
+        orc_tree_leaf_pars(d, p, l, q);
+        orc_interp_mag1(ic, q, d->bc_cols, d->n_bands, &spec[l][0], &spec[l][1], &spec[l][2], mags[l]);
+    }
+    double lnl = 0;
+    for (int t = 0; t < d->n_terms; ++t) {
+        const iso_tree_term* T = &d->terms[t];
+        double mag = T->mag, mod;
+        if (T->relative) {
+            mod = orc_addmags_mask(mags, T->mask, T->band, d->n_leaves) -
+                  orc_addmags_mask(mags, T->ref_mask, T->band, d->n_leaves);
+            mag -= T->ref_mag;
+        } else {
+            mod = orc_addmags_mask(mags, T->mask, T->band, d->n_leaves);
+        }
+        lnl += -0.5 * ((mag - mod) * (mag - mod)) / (T->unc * T->unc) + L + log(T->unc);
+        if (!isfinite(lnl)) return -INFINITY;
+    }
+    for (int k = 0; k < d->n_spec; ++k) {
+        const iso_tree_prop* S = &d->spec[k];
+        const double mod = spec[S->leaf][S->prop];
+        lnl += -0.5 * ((S->a - mod) * (S->a - mod)) / (S->b * S->b) + L + log(S->b);
+        if (!isfinite(lnl)) return -INFINITY;       /* checked per label in the reference; same outcome */
+    }
+    for (int k = 0; k < d->n_limits; ++k) {
+        const iso_tree_prop* S = &d->limits[k];
+        const double mod = spec[S->leaf][S->prop];
+        if (mod < S->a || mod > S->b || !isfinite(mod)) return -INFINITY;
+    }
+    int i = 0;
+    for (int s = 0; s < d->n_systems; ++s) {         /* parallax, then AV, per system */
+        const int N = d->n_stars[s];
+        if (d->has_plx[s]) {
+            const double mod = 1.0 / p[i + N + 2] * 1000.0;
+            lnl += -0.5 * ((d->plx_val[s] - mod) * (d->plx_val[s] - mod)) / (d->plx_unc[s] * d->plx_unc[s]) + L +
+                   log(d->plx_unc[s]);
+        }
+        i += N + 4;
+    }
+    i = 0;
+    for (int s = 0; s < d->n_systems; ++s) {
+        const int N = d->n_stars[s];
+        if (d->has_av[s]) {
+            const double AV = p[i + N + 3];
+            lnl += -0.5 * ((d->av_val[s] - AV) * (d->av_val[s] - AV)) / (d->av_unc[s] * d->av_unc[s]) + L +
+                   log(d->av_unc[s]);
+        }
+        i += N + 4;
+    }
+    if (!isfinite(lnl)) return -INFINITY;
+    return lnl;
+}
+
+void orc_tree_lnpost(const orc_ic* ic, const iso_tree_desc* d, const double* pars, int64_t stride_n,
+                     int64_t stride_p, int64_t n, double* lnpost, double* lnprior, double* lnlike, int nthreads)
+{
+    int np_ = 0;
+    for (int s = 0; s < d->n_systems; ++s) np_ += d->n_stars[s] + 4;
+    (void)nthreads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(nthreads > 0 ? nthreads : 1)
+#endif
+    for (int64_t i = 0; i < n; ++i) {
+        double p[ISO_TREE_MAX_PARAMS];
+        for (int j = 0; j < np_; ++j) p[j] = pars[i * stride_n + j * stride_p];
+        const double lp = orc_tree_lnprior1(ic, d, p);
+        double ll = NAN;
+        if (isfinite(lp) || lnlike) ll = orc_tree_lnlike1(ic, d, p);
+        if (lnprior) lnprior[i] = lp;
+        if (lnlike) lnlike[i] = ll;
+        if (lnpost) lnpost[i] = isfinite(lp) ? lp + ll : -INFINITY;      /* starmodel.py:538-542 */
+    }
+}

@@ -286,7 +286,96 @@ def run_eep_case():
     print("interp_eep: n=%d finite=%d nan=%d" % (n, np.isfinite(want).sum(), np.isnan(want).sum()))
 
 
+def _tree_cases(obs_mod, ic):
+    """(name, reference tree builder kwargs) — the configurations of docs/multiple.ipynb cells 21-36
+    plus the keyword form used by tests/test_likelihood.py."""
+    def build(name):
+        obs = obs_mod.ObservationTree(name=name)
+        for band, m in zip("JHK", (12.11, 11.74, 11.68)):
+            o = obs_mod.Observation("2MASS", band, 4)
+            o.add_source(obs_mod.Source(m, 0.02))
+            obs.add_observation(o)
+        o = obs_mod.Observation("AO", "K", 0.1)
+        o.add_source(obs_mod.Source(0.0, 0.02, separation=0, pa=0, relative=True, is_reference=True))
+        o.add_source(obs_mod.Source(2.43, 0.02, separation=0.2, pa=100, relative=True, is_reference=False))
+        obs.add_observation(o)
+        return obs
+    spec = dict(parallax=(2.0, 0.05), Teff=(5834.0, 100), logg=(4.43, 0.15), feh=(-0.01, 0.1))
+    return [
+        ("tree_resolved", build, dict(spec)),
+        ("tree_resolved_unassoc", build, dict(spec, index=[0, 1])),
+        ("tree_triple1", build, dict(N=[2, 1], index=[0, 0], parallax=(2.0, 0.05))),
+        ("tree_triple2", build, dict(N=[1, 2], index=[0, 1], Teff=(5834.0, 100))),
+        ("tree_double_binary", build, dict(N=2, index=[0, 1], AV=(0.2, 0.1))),
+        ("tree_kwargs_single", None, dict(Teff=(5800, 100), logg=(4.5, 0.1), J=(13.3, 0.05), K=(12.9, 0.05),
+                                          parallax=(2.0, 0.1))),
+        ("tree_kwargs_binary", None, dict(J=(13.3, 0.05), K=(12.9, 0.05), parallax=(2.0, 0.1), N=2)),
+        ("tree_kwargs_triple", None, dict(Teff=(5800, 100), J=(13.3, 0.05), K=(12.9, 0.05), N=3, maxAV=0.6)),
+    ]
+
+
+def run_tree_cases():
+    """Generic StarModel + ObservationTree of the reference (starmodel.py:63-661,
+    observation.py) on the small synthetic isochrone table."""
+    sm = rh.ref("starmodel")
+    obs_mod = rh.ref("observation")
+    rng = np.random.default_rng(777)
+    iso, bc = small_iso(), small_bc()
+    axes = iso[1]
+    limits = limits_of("iso", axes)
+    for name, build, kw in _tree_cases(obs_mod, None):
+        ic = rh.make_ref_ic("iso", iso, bc, limits, (axes[2][0], axes[2][-1]))
+        kw = dict(kw)
+        obs = build(name) if build is not None else None
+        mod = sm.StarModel(ic, obs=obs, **kw)
+        names = list(mod.param_names)
+        N = mod.obs.Nstars
+        # parameter samples: per system descending eeps near the table's middle, some violations
+        n = 400
+        cols = []
+        for s in mod.obs.systems:
+            e = rng.uniform(axes[2][0] - 2, axes[2][-1] + 2, size=(n, N[s]))
+            e[: int(0.85 * n)] = -np.sort(-e[: int(0.85 * n)], axis=1)
+            cols.append(e)
+            cols.append(rng.uniform(axes[0][0] - 0.05, axes[0][-1] + 0.05, (n, 1)))       # age
+            cols.append(rng.uniform(axes[1][0] - 0.05, axes[1][-1] + 0.05, (n, 1)))       # feh
+            cols.append(rng.uniform(100.0, 900.0, (n, 1)))                                # distance
+            cols.append(rng.uniform(-0.02, 1.02, (n, 1)))                                 # AV
+        pars = np.hstack(cols)
+        pars[0, 0] = np.nan
+        lnprior, lnlike, lnpost = np.empty(n), np.empty(n), np.empty(n)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            with np.errstate(all="ignore"):
+                for i in range(n):
+                    lnprior[i] = mod.lnprior(pars[i])
+                    lnlike[i] = mod.lnlike(pars[i])
+                    lnpost[i] = mod.lnpost(pars[i])
+        # the tree's structure as plain data
+        labels = mod.obs.leaf_labels
+        nodes = []
+        for nd in mod.obs:
+            if isinstance(nd, obs_mod.ObsNode) and not isinstance(nd, obs_mod.DummyObsNode):
+                nodes.append(dict(band=nd.band, relative=bool(nd.relative), mag=nd.value[0], unc=nd.value[1],
+                                  leaves=[l.label for l in nd.leaves],
+                                  ref_leaves=[l.label for l in nd.reference.leaves] if nd.reference is not None else None))
+        cube = rng.random((8, len(names)))
+        meta = dict(param_names=names, leaf_labels=labels, nodes=nodes, kwargs={k: (list(v) if isinstance(v, (tuple, list)) else v)
+                                                                               for k, v in kw.items()},
+                    limits={k: list(map(float, v)) for k, v in limits.items()}, eep_bounds=[float(axes[2][0]), float(axes[2][-1])],
+                    bands=list(BANDS), built=build is not None, systems=[int(s) for s in mod.obs.systems],
+                    Nstars={str(k): int(v) for k, v in N.items()})
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), meta=json.dumps(meta), pars=pars, lnprior=lnprior,
+                            lnlike=lnlike, lnpost=lnpost, cube_in=cube,
+                            cube_out=np.array([mod.prior_transform(c) for c in cube]))
+        print("%-24s n=%d npar=%d finite lnpost=%d -inf=%d nan=%d leaves=%s" % (
+            name, n, len(names), np.isfinite(lnpost).sum(), np.isneginf(lnpost).sum(), np.isnan(lnpost).sum(), labels))
+
+
 def main():
+    if "--only-tree" in sys.argv:
+        run_tree_cases()
+        return
     if "--only-eep" in sys.argv:
         run_eep_case()
         return
@@ -312,6 +401,7 @@ def main():
     run_model_case("iso_binary_phot6", "iso", 2, "phot6_plx", iso, bc, rng, 400, 400)
     run_model_case("iso_triple_phot6", "iso", 3, "phot6_plx", iso, bc, rng, 250, 250)
     run_eep_case()
+    run_tree_cases()
 
 
 if __name__ == "__main__":

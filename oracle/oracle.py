@@ -66,6 +66,9 @@ def lib():
         i64p = C.POINTER(C.c_int64)
         L.orc_interp_eep.argtypes = [dp, dp, dp, C.c_int64, dp, C.c_int64, dp, C.c_int64, dp, i64p, C.c_int64, dp]
         L.orc_interp_eep.restype = None
+        L.orc_tree_lnpost.argtypes = [C.POINTER(_IC), C.POINTER(_cabi.IsoTreeDesc), dp, C.c_int64, C.c_int64, C.c_int64,
+                                      dp, dp, dp, C.c_int]
+        L.orc_tree_lnpost.restype = None
         _lib = L
     return _lib
 
@@ -144,6 +147,15 @@ class OracleIC:
             return post, prior, like
         lib().orc_lnpost(C.byref(self.c), C.byref(desc), _dp(pars), 1, n, n, _dp(post), None, None, nthreads)
         return post
+
+
+def tree_lnpost(oic, desc, pars, nthreads=1):
+    """Generic (observation-tree) model: pars [n_params, N] (SoA) -> (lnpost, lnprior, lnlike)."""
+    pars = np.ascontiguousarray(pars, dtype=np.float64)
+    n = pars.shape[1]
+    post, prior, like = np.empty(n), np.empty(n), np.empty(n)
+    lib().orc_tree_lnpost(C.byref(oic.c), C.byref(desc), _dp(pars), 1, n, n, _dp(post), _dp(prior), _dp(like), nthreads)
+    return post, prior, like
 
 
 def unit_cube(desc, kind, cube):

@@ -39,10 +39,11 @@ def test_struct_layout_matches_header(built_lib):
     #include <stddef.h>
     #include "isochrones_amd.h"
     int main(void){
-      printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(iso_prior), sizeof(iso_model_desc),
+      printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(iso_prior), sizeof(iso_model_desc),
              offsetof(iso_model_desc, mag_val), offsetof(iso_model_desc, has_parallax),
              offsetof(iso_model_desc, prior_mass), offsetof(iso_model_desc, eep_lo),
-             offsetof(iso_model_desc, bound_lo));
+             offsetof(iso_model_desc, bound_lo), sizeof(iso_tree_desc), sizeof(iso_tree_term),
+             offsetof(iso_tree_desc, terms), offsetof(iso_tree_desc, prior_mass), offsetof(iso_tree_desc, bound_lo));
       return 0; }'''
     with tempfile.TemporaryDirectory() as d:
         c = os.path.join(d, "t.c")
@@ -51,8 +52,10 @@ def test_struct_layout_matches_header(built_lib):
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
         got = list(map(int, subprocess.check_output([exe]).split()))
     M = _cabi.IsoModelDesc
+    T = _cabi.IsoTreeDesc
     want = [ctypes.sizeof(_cabi.IsoPrior), ctypes.sizeof(M), M.mag_val.offset, M.has_parallax.offset,
-            M.prior_mass.offset, M.eep_lo.offset, M.bound_lo.offset]
+            M.prior_mass.offset, M.eep_lo.offset, M.bound_lo.offset, ctypes.sizeof(T),
+            ctypes.sizeof(_cabi.IsoTreeTerm), T.terms.offset, T.prior_mass.offset, T.bound_lo.offset]
     assert got == want
 
 

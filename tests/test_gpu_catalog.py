@@ -161,3 +161,59 @@ def test_fused_catalog_sampler_matches_per_star_bookkeeping():
     for s in (0, 5, 11):                                  # every star's rows follow its own posterior
         want = models[s].lnpost(pos[s])
         assert torch.allclose(want, lnp[s], rtol=1e-12, atol=1e-12)
+
+
+# ---- "next" row f4: generic StarModel over an ObservationTree ---------------------------------
+from tests.test_tree_cpu import TREE_CASES, make_tree_model  # noqa: E402
+
+
+@pytest.mark.parametrize("case", TREE_CASES)
+def test_tree_model_vs_reference_golden(case):
+    import torch
+    g = fx.load(case)
+    ic, mod = make_tree_model(g["meta"])
+    pars = g["pars"]
+    fx.assert_close(mod.lnprior(pars), g["lnprior"], RTOL, atol=ATOL, what="lnprior")
+    fx.assert_close(mod.lnlike(pars), g["lnlike"], RTOL, atol=1e-9, what="lnlike")
+    fx.assert_close(mod.lnpost(pars), g["lnpost"], RTOL, atol=1e-9, what="lnpost")
+    k = int(np.flatnonzero(np.isfinite(g["lnpost"]))[0])
+    v = mod.lnpost(pars[k])
+    assert isinstance(v, float) and np.isclose(v, g["lnpost"][k], rtol=RTOL)
+    dev_out = mod.lnpost(torch.as_tensor(pars, device="cuda"))
+    fx.assert_close(dev_out.cpu().numpy(), g["lnpost"], RTOL, atol=1e-9, what="lnpost device")
+
+
+def test_tree_model_random_batch_vs_oracle_and_basic_model():
+    """A 4-star, 2-system resolved configuration on mid-size tables against the oracle, and the
+    keyword (unresolved) form against BasicStarModel evaluated by the fused kernel."""
+    from oracle import oracle as orc
+    from tests.test_tree_cpu import build_notebook_tree
+    rng = np.random.default_rng(31)
+    ages = ia.grids.mist_log_ages()[60::2]
+    ic = ia.synthetic_isochrone(bands=("J", "H", "K"), ages=ages, fehs=[-1.0, -0.5, 0.0, 0.5], eeps=np.arange(150.0, 700.0),
+                                eep_bounds=(150, 699), limits=dict(age=(ages[0], ages[-1]), feh=(-1.0, 0.5)))
+    mod = ia.TreeStarModel(ic, obs=build_notebook_tree("x"), N=2, index=[0, 1], parallax=(2.0, 0.05), Teff=(5800, 100))
+    mod.obs.add_limit(label="1_0", logg=(3.0, None))
+    mod._dirty()
+    n = 100_000
+    cols = []
+    for s in range(2):
+        e = -np.sort(-rng.uniform(150, 699, size=(n, 2)), axis=1)
+        cols += [e, rng.uniform(ages[0], ages[-1], (n, 1)), rng.uniform(-1, 0.5, (n, 1)), rng.uniform(100, 900, (n, 1)),
+                 rng.uniform(0, 1, (n, 1))]
+    pars = np.hstack(cols)
+    want = orc.tree_lnpost(fx.make_oracle_ic(ic), mod.tree_desc(), pars.T.copy(), nthreads=8)
+    assert np.isfinite(want[0]).sum() > n // 20
+    fx.assert_close(mod.lnpost(pars), want[0], RTOL, atol=1e-9, what="tree lnpost")
+    fx.assert_close(mod.lnprior(pars), want[1], RTOL, atol=ATOL, what="tree lnprior")
+    fx.assert_close(mod.lnlike(pars), want[2], RTOL, atol=1e-9, what="tree lnlike")
+    # keyword form == BasicStarModel (reference tests/test_likelihood.py)
+    tree = ia.StarModel(ic, obs=None, J=(13.3, 0.05), K=(12.9, 0.05), parallax=(2.0, 0.1), N=2)
+    assert isinstance(tree, ia.BasicStarModel)
+    tmod = ia.TreeStarModel(ic, J=(13.3, 0.05), K=(12.9, 0.05), parallax=(2.0, 0.1), N=2)
+    basic = ia.BinaryStarModel(ic, J=(13.3, 0.05), K=(12.9, 0.05), parallax=(2.0, 0.1))
+    basic.set_bounds(distance=(0, 10000), mass=(0.1, 100.0))
+    p6 = pars[:, :6]
+    a, b = tmod.lnpost(p6), basic.lnpost(p6)
+    fin = np.isfinite(b)
+    assert fin.sum() > 1000 and np.allclose(a[fin], b[fin], rtol=1e-9, atol=1e-8)

@@ -1,0 +1,102 @@
+"""CPU: the host-side observation-tree builder (isochrones_amd/observation.py) and the oracle's
+generic-model restatement against golden data produced by the reference's own
+ObservationTree + StarModel (docs/multiple.ipynb configurations + keyword form)."""
+import numpy as np
+import pytest
+
+import isochrones_amd as ia
+from isochrones_amd.observation import Observation, ObservationTree, Source
+from oracle import oracle as orc
+from tests import _fixtures as fx
+
+TREE_CASES = ["tree_resolved", "tree_resolved_unassoc", "tree_triple1", "tree_triple2", "tree_double_binary",
+              "tree_kwargs_single", "tree_kwargs_binary", "tree_kwargs_triple"]
+
+
+def build_notebook_tree(name):
+    """docs/multiple.ipynb cell 21: three unresolved 2MASS bands + a resolved relative AO K image."""
+    obs = ObservationTree(name=name)
+    for band, m in zip("JHK", (12.11, 11.74, 11.68)):
+        o = Observation("2MASS", band, 4)
+        o.add_source(Source(m, 0.02))
+        obs.add_observation(o)
+    o = Observation("AO", "K", 0.1)
+    o.add_source(Source(0.0, 0.02, separation=0, pa=0, relative=True, is_reference=True))
+    o.add_source(Source(2.43, 0.02, separation=0.2, pa=100, relative=True, is_reference=False))
+    obs.add_observation(o)
+    return obs
+
+
+def make_tree_model(meta):
+    iso_meta = dict(kind="iso", limits=meta["limits"], eep_bounds=meta["eep_bounds"])
+    ic = fx.make_ic(iso_meta)
+    kw = {k: (tuple(v) if isinstance(v, list) and k not in ("N", "index") else v) for k, v in meta["kwargs"].items()}
+    obs = build_notebook_tree("t") if meta["built"] else None
+    return ic, ia.TreeStarModel(ic, obs=obs, **kw)
+
+
+@pytest.mark.parametrize("case", TREE_CASES)
+def test_tree_structure_and_oracle_vs_reference(case):
+    g = fx.load(case)
+    meta = g["meta"]
+    ic, mod = make_tree_model(meta)
+    # --- structure: same parameters, leaves, and per-node blending as the reference's tree ---
+    assert list(mod.param_names) == meta["param_names"]
+    assert mod.obs.leaf_labels == meta["leaf_labels"]
+    assert mod.obs.systems == meta["systems"] and {str(k): v for k, v in mod.obs.Nstars.items()} == meta["Nstars"]
+    mine = []
+    for n in mod.obs.obs_nodes():
+        mine.append(dict(band=n.observation.band, relative=n.source.relative, mag=n.source.mag, unc=n.source.e_mag,
+                         leaves=[l.label for l in n.leaves()],
+                         ref_leaves=[l.label for l in n.reference.leaves()] if n.reference is not None else None))
+    assert mine == meta["nodes"]
+    # --- numbers: oracle on the flattened tree vs the reference's StarModel ---
+    desc = mod.tree_desc()
+    oic = fx.make_oracle_ic(ic)
+    post, prior, like = orc.tree_lnpost(oic, desc, g["pars"].T.copy())
+    fx.assert_close(prior, g["lnprior"], 1e-11, atol=1e-12, what="lnprior")
+    fx.assert_close(like, g["lnlike"], 1e-11, atol=1e-11, what="lnlike")
+    fx.assert_close(post, g["lnpost"], 1e-11, atol=1e-11, what="lnpost")
+    fx.assert_close(mod.prior_transform(g["cube_in"]), g["cube_out"], 1e-15, what="prior_transform")
+    assert np.isfinite(g["lnpost"]).sum() > 50
+
+
+def test_keyword_tree_equals_basic_model_on_the_oracle():
+    """reference tests/test_likelihood.py: StarModel (tree) == BasicStarModel for unresolved systems
+    once the priors are identical."""
+    g = fx.load("tree_kwargs_binary")
+    meta = g["meta"]
+    ic, tree = make_tree_model(meta)
+    basic = ia.BinaryStarModel(ic, J=(13.3, 0.05), K=(12.9, 0.05), parallax=(2.0, 0.1))
+    basic.set_bounds(distance=(0, 10000))                      # the generic model keeps the default distance bound
+    basic.set_bounds(mass=(0.1, 100.0))                        # ... and the default Chabrier bounds
+    oic = fx.make_oracle_ic(ic)
+    pars = g["pars"]
+    ok = np.all(pars[:, 4:6] > 0, axis=1)
+    a = orc.tree_lnpost(oic, tree.tree_desc(), pars[ok].T.copy())
+    b = oic.lnpost(basic.model_desc(), pars[ok].T.copy())
+    fin = np.isfinite(b[0])
+    assert fin.sum() > 50
+    assert np.allclose(a[0][fin], b[0][fin], rtol=1e-10, atol=1e-9)
+    assert np.allclose(a[1][fin], b[1][fin], rtol=1e-10, atol=1e-9)
+
+
+def test_tree_from_df_and_errors():
+    import pandas as pd
+    df = pd.DataFrame(dict(name=["2MASS", "2MASS", "AO", "AO"], band=["J", "K", "K", "K"], resolution=[4.0, 4.0, 0.1, 0.1],
+                           mag=[12.1, 11.7, 0.0, 2.4], e_mag=[0.02] * 4, separation=[0, 0, 0, 0.2], pa=[0, 0, 0, 100],
+                           relative=[False, False, True, True]))
+    t = ObservationTree.from_df(df, name="x")
+    assert [str(o) for o in t.observations] == ["2MASS-J", "2MASS-K", "AO-K"]
+    t.define_models(None, N=1, index=[0, 1])
+    assert t.leaf_labels == ["0_0", "1_0"] and t.systems == [0, 1]
+    assert t.param_description == ["eep_0_0", "age_0", "feh_0", "distance_0", "AV_0",
+                                   "eep_1_0", "age_1", "feh_1", "distance_1", "AV_1"]
+    with pytest.raises(ValueError):
+        t.add_spectroscopy(label="3_0", Teff=(5000, 100))
+    with pytest.raises(ValueError):
+        t.add_parallax((1.0, 0.1), system=5)
+    t.add_limit(logg=(3.5, None))
+    prog = t.program(["J", "K"])
+    assert prog["limits"][0]["hi"] == np.inf and len(prog["terms"]) == 3          # the AO reference source adds no term
+    assert [x["mask"] for x in prog["terms"]] == [2, 3, 3] and prog["terms"][0]["ref_mask"] == 1
