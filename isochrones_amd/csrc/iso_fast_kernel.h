@@ -288,17 +288,184 @@ __device__ __forceinline__ double eep_term(const DevModel& M, const DevPrior& or
 // ---- the kernel ---------------------------------------------------------------------------
 // MULTI: every row carries the index of its own star (observations + priors) — the catalog /
 // batched-ensemble form: S stars x W walkers in one launch.
-// lnpost of one sample (p = the NS+4 parameters), shared by the batch kernel and the sampler kernel
+// ---- wave-cooperative gathers over the corner-packed tables --------------------------------
+// A lane-per-sample gather issues 24 + 8 x 16-B loads per lane with 64 unrelated addresses per
+// wave instruction; measured ceiling of that pattern on MI355X: 4.3 TB/s of useful bytes
+// (tools/gather_probe.hip).  Letting 8 lanes share one sample — lane j loads corner j's 48 B, so a
+// wave instruction covers 8 samples x 128 contiguous bytes — reaches 6.6 TB/s.  The sample's owner
+// lane publishes (cell, weights) in a wave-private LDS slot; each group of 8 lanes serves one
+// sample per iteration (8 iterations per wave), weights its corner, sums the 8 corners with DPP
+// row operations (no LDS traffic) and lane 0 of the group writes the result back to the owner's
+// response slot.  Slot strides (7 / 9 doubles) are chosen conflict-free for 64-bit LDS accesses.
+#ifndef ISO_STAR_BATCH
+#define ISO_STAR_BATCH 4
+#endif
+constexpr int REQ_STRIDE = 7;     // doubles per request slot  (header, t0..t3, pad)
+constexpr int RSP_STRIDE = 9;     // doubles per response slot (<= 8 values)
+constexpr int COOP_LDS_DOUBLES = BLOCK * (REQ_STRIDE + RSP_STRIDE);
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double x)
+{
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+
+// sum over the 8 lanes of an aligned group (every lane ends up with the group total)
+__device__ __forceinline__ double group8_sum(double x)
+{
+    x += dpp_f64<0xB1>(x);    // quad_perm [1,0,3,2]
+    x += dpp_f64<0x4E>(x);    // quad_perm [2,3,0,1]
+    x += dpp_f64<0x141>(x);   // row_half_mirror: lane k <-> 7-k within each 8 lanes
+    return x;
+}
+
+struct CoopLds {
+    double* req;    // this wave's 64 request slots
+    double* rsp;    // this wave's 64 response slots
+    int lane;
+};
+
+// Model table: every lane may own one request (need, cell, w); returns the 6 interpolated columns
+// of the lane's own sample in v (NaN if !need).  Must be called by all 64 lanes of the wave.
+__device__ __forceinline__ void coop_star(const FastArgs& A, const CoopLds& L, bool need, uint32_t cell, const W3& w,
+                                          double* __restrict__ v)
+{
+    double* mine = L.req + L.lane * REQ_STRIDE;
+    mine[0] = __hiloint2double(need ? 1 : 0, (int)cell);
+    mine[1] = w.t0;
+    mine[2] = w.t1;
+    mine[3] = w.t2;
+    __builtin_amdgcn_wave_barrier();
+    const unsigned long long m = __ballot(need);
+    const int j = L.lane & 7, grp = L.lane >> 3;
+    // batches of SB iterations: all 3*SB loads of a batch are in flight before the first use
+    constexpr int SB = ISO_STAR_BATCH;
+#pragma unroll
+    for (int half = 0; half < 8 / SB; ++half) {
+        if (((m >> (8 * SB * half)) & ((SB == 8) ? ~0ull : ((1ull << (8 * SB)) - 1ull))) == 0) continue;   // wave-uniform
+        double2 u[SB][3];
+        double ww[SB];
+#pragma unroll
+        for (int k = 0; k < SB; ++k) {
+            const int src = 8 * (SB * half + k) + grp;
+            const double* rq = L.req + src * REQ_STRIDE;
+            const double hdr = rq[0];
+            W3 ws;
+            ws.t0 = rq[1];
+            ws.t1 = rq[2];
+            ws.t2 = rq[3];
+            const bool nd = __double2hiint(hdr) != 0;
+            const uint32_t c = nd ? (uint32_t)__double2loint(hdr) : 0u;      // cell 0 is always readable
+            const double2* __restrict__ pc =
+                reinterpret_cast<const double2*>(A.hotq + (size_t)c * PACK_ENTRY + j * PACK_COLS);
+            u[k][0] = pc[0];
+            u[k][1] = pc[1];
+            u[k][2] = pc[2];
+            ww[k] = nd ? w3(ws, j) : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < SB; ++k) {
+            const int src = 8 * (SB * half + k) + grp;
+            double part[6];
+            part[0] = u[k][0].x * ww[k]; part[1] = u[k][0].y * ww[k];
+            part[2] = u[k][1].x * ww[k]; part[3] = u[k][1].y * ww[k];
+            part[4] = u[k][2].x * ww[k]; part[5] = u[k][2].y * ww[k];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) part[q] = group8_sum(part[q]);
+            if (j == 0) {
+                double* rs = L.rsp + src * RSP_STRIDE;
+#pragma unroll
+                for (int q = 0; q < 6; ++q) rs[q] = part[q];
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const double* rs = L.rsp + L.lane * RSP_STRIDE;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) v[q] = need ? rs[q] : f_nan();
+    __builtin_amdgcn_wave_barrier();
+}
+
+// BC table: lane j of a group handles corners 2j and 2j+1 (2*NB contiguous doubles)
+template <int NB>
+__device__ __forceinline__ void coop_bc(const FastArgs& A, const CoopLds& L, bool need, uint32_t cell, const W4& w,
+                                        double* __restrict__ v)
+{
+    double* mine = L.req + L.lane * REQ_STRIDE;
+    mine[0] = __hiloint2double(need ? 1 : 0, (int)cell);
+    mine[1] = w.t0;
+    mine[2] = w.t1;
+    mine[3] = w.t2;
+    mine[4] = w.t3;
+    __builtin_amdgcn_wave_barrier();
+    const unsigned long long m = __ballot(need);
+    const int j = L.lane & 7, grp = L.lane >> 3;
+    // batches sized so that <= 12 x 16-B loads per lane are in flight before the first use
+    constexpr int BATCH = (NB <= 1) ? 8 : (NB <= 3) ? 4 : (NB <= 6) ? 2 : 1;
+#pragma unroll
+    for (int r0 = 0; r0 < 8; r0 += BATCH) {
+        if (((m >> (8 * r0)) & ((BATCH == 8) ? ~0ull : ((1ull << (8 * BATCH)) - 1ull))) == 0) continue;   // wave-uniform
+        double x[BATCH][2 * NB];
+        double wa[BATCH], wb[BATCH];
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k) {
+            const int src = 8 * (r0 + k) + grp;
+            const double* rq = L.req + src * REQ_STRIDE;
+            const double hdr = rq[0];
+            W4 ws;
+            ws.t0 = rq[1];
+            ws.t1 = rq[2];
+            ws.t2 = rq[3];
+            ws.t3 = rq[4];
+            const bool nd = __double2hiint(hdr) != 0;
+            const uint32_t c = nd ? (uint32_t)__double2loint(hdr) : 0u;
+            const double2* __restrict__ pc =
+                reinterpret_cast<const double2*>(A.bcq + (size_t)c * (16 * NB) + (2 * j) * NB);
+#pragma unroll
+            for (int e = 0; e < NB; ++e) {
+                const double2 u = pc[e];
+                x[k][2 * e] = u.x;
+                x[k][2 * e + 1] = u.y;
+            }
+            wa[k] = nd ? w4(ws, 2 * j) : 0.0;
+            wb[k] = nd ? w4(ws, 2 * j + 1) : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k) {
+            const int src = 8 * (r0 + k) + grp;
+            double part[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) part[b] = group8_sum(x[k][b] * wa[k] + x[k][NB + b] * wb[k]);
+            if (j == 0) {
+                double* rs = L.rsp + src * RSP_STRIDE;
+#pragma unroll
+                for (int b = 0; b < NB; ++b) rs[b] = part[b];
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const double* rs = L.rsp + L.lane * RSP_STRIDE;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) v[b] = need ? rs[b] : f_nan();
+    __builtin_amdgcn_wave_barrier();
+}
+
+// lnpost of the lane's sample (p = its NS+4 parameters).  Shared by the batch kernel and the
+// sampler kernel.  With PACKED every gather is wave-cooperative, so ALL 64 lanes of the wave must
+// call this function together; `active` = the lane really has a sample (inactive lanes only help).
 template <int KIND, int NS, int NB, bool PACKED>
-__device__ __forceinline__ double lnpost_one(const FastArgs& A, const double* lds, const DevModel& M,
-                                             const double* __restrict__ p)
+__device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* lds, const CoopLds& L, bool active,
+                                              const DevModel& M, const double* __restrict__ p)
 {
     const double q1 = p[NS], feh_par = p[NS + 1], dist = p[NS + 2], AV = p[NS + 3];
 
     // ---- model table: axes 0/1 are shared by all components of an isochrone system ----
     const double x0 = (KIND == ISO_KIND_TRACK) ? p[2] : q1;        // feh | age
     const double x1 = (KIND == ISO_KIND_TRACK) ? p[0] : feh_par;   // mass | feh
-    const bool ok01 = !(x0 != x0) && !(x1 != x1) && !lds_oob(lds, A.m0, x0) && !lds_oob(lds, A.m1, x1);
+    const bool ok01 = active && !(x0 != x0) && !(x1 != x1) && !lds_oob(lds, A.m0, x0) && !lds_oob(lds, A.m1, x1);
     int i0 = 0, i1 = 0;
     W3 w;
     w.t0 = w.t1 = w.t2 = 0.0;
@@ -311,10 +478,13 @@ __device__ __forceinline__ double lnpost_one(const FastArgs& A, const double* ld
     for (int s = 0; s < NS; ++s) {
         const double eep = (KIND == ISO_KIND_TRACK) ? p[1] : p[s];
         const bool ok = ok01 && !(eep != eep) && !eep_oob(A, eep);
-        if (ok) {
-            int i2;
-            eep_bracket(A, eep, i2, w.t2);
-            gather_star<PACKED>(A, i0, i1, i2, w, star[s]);
+        int i2 = 0;
+        if (ok) eep_bracket(A, eep, i2, w.t2);
+        if (PACKED) {
+            const uint32_t cell = (uint32_t)((int64_t)i0 * A.s0 + (int64_t)i1 * A.s1 + i2);
+            coop_star(A, L, ok, cell, w, star[s]);
+        } else if (ok) {
+            gather_star<false>(A, i0, i1, i2, w, star[s]);
         } else {
 #pragma unroll
             for (int q = 0; q < 6; ++q) star[s][q] = f_nan();
@@ -338,7 +508,8 @@ __device__ __forceinline__ double lnpost_one(const FastArgs& A, const double* ld
     lnp += ln_pdf<true>(M.prior_distance, dist, ld);
     lnp += ln_pdf<false>(M.prior_AV, AV, 0.0);
     if (rejected) lnp = -f_inf();
-    if (!isfinite(lnp)) return -f_inf();
+    const bool prior_ok = active && isfinite(lnp);
+    if (!PACKED && !prior_ok) return -f_inf();      // lane-wise path: nothing cooperative follows
 
     // ---- lnlike ----
     double lnl = 0.0;
@@ -352,21 +523,27 @@ __device__ __forceinline__ double lnpost_one(const FastArgs& A, const double* ld
     }
     const double dm = fma(ld, 5.0 * kInvLn10, -5.0);   // 5*log10(d/10)
     double tot[NB];
-    const bool okA = !(AV != AV) && !lds_oob(lds, A.b3, AV);
+    const bool okA = prior_ok && !(AV != AV) && !lds_oob(lds, A.b3, AV);
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         const double T = star[s][0], g = star[s][1], f = star[s][2];
         const bool ok = okA && !(T != T) && !(g != g) && !(f != f) && !lds_oob(lds, A.b0, T) &&
                         !lds_oob(lds, A.b1, g) && !lds_oob(lds, A.b2, f);
         double bc[NB];
+        int j0 = 0, j1 = 0, j2 = 0, j3 = 0;
+        W4 w4v;
+        w4v.t0 = w4v.t1 = w4v.t2 = w4v.t3 = 0.0;
         if (ok) {
-            int j0, j1, j2, j3;
-            W4 w4v;
             lds_bracket(lds, A.b0, T, j0, w4v.t0);
             lds_bracket(lds, A.b1, g, j1, w4v.t1);
             lds_bracket(lds, A.b2, f, j2, w4v.t2);
             lds_bracket(lds, A.b3, AV, j3, w4v.t3);
-            gather_bc<NB, PACKED>(A, j0, j1, j2, j3, w4v, bc);
+        }
+        if (PACKED) {
+            const uint32_t cell = (uint32_t)((int64_t)j0 * A.bs0 + (int64_t)j1 * A.bs1 + (int64_t)j2 * A.bs2 + j3);
+            coop_bc<NB>(A, L, ok, cell, w4v, bc);
+        } else if (ok) {
+            gather_bc<NB, false>(A, j0, j1, j2, j3, w4v, bc);
         } else {
 #pragma unroll
             for (int b = 0; b < NB; ++b) bc[b] = f_nan();
@@ -388,7 +565,19 @@ __device__ __forceinline__ double lnpost_one(const FastArgs& A, const double* ld
         const double r = M.plx_val - 1000.0 / dist;
         lnl += M.plx_g0 - r * r * M.plx_hinv;
     }
-    return lnp + lnl;
+    return prior_ok ? lnp + lnl : -f_inf();
+}
+
+// LDS layout of the fast kernels: [axes blob, rounded to an even count][request slots][response slots]
+__device__ __forceinline__ CoopLds coop_lds(double* lds, int axes_len)
+{
+    const int base = (axes_len + 1) & ~1;
+    const int wave = threadIdx.x >> 6;
+    CoopLds L;
+    L.req = lds + base + wave * 64 * REQ_STRIDE;
+    L.rsp = lds + base + BLOCK * REQ_STRIDE + wave * 64 * RSP_STRIDE;
+    L.lane = threadIdx.x & 63;
+    return L;
 }
 
 template <int KIND, int NS, int NB, bool PACKED, bool MULTI>
@@ -397,17 +586,20 @@ __global__ __launch_bounds__(BLOCK) void k_lnpost_fast(const FastArgs A)
     extern __shared__ double lds[];
     for (int j = threadIdx.x; j < A.axes_len; j += BLOCK) lds[j] = A.axes_blob[j];
     __syncthreads();
+    const CoopLds L = coop_lds(lds, A.axes_len);
     const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= A.n) return;
-    const DevModel& M = A.m[MULTI ? A.star_id[i] : 0];
+    const bool active = i < A.n;
+    const int64_t ii = active ? i : (A.n - 1);         // inactive lanes shadow the last sample
+    const DevModel& M = A.m[MULTI ? A.star_id[ii] : 0];
     constexpr int NP = NS + 4;
     double p[NP];
     {
-        const double* __restrict__ src = A.pars + i * A.stride_n;
+        const double* __restrict__ src = A.pars + ii * A.stride_n;
 #pragma unroll
         for (int j = 0; j < NP; ++j) p[j] = src[j * A.stride_p];
     }
-    A.lnpost[i] = lnpost_one<KIND, NS, NB, PACKED>(A, lds, M, p);
+    const double r = lnpost_wave<KIND, NS, NB, PACKED>(A, lds, L, active, M, p);
+    if (active) A.lnpost[i] = r;
 }
 
 // -------------------------------------------------------------------------------------------
@@ -440,8 +632,10 @@ __global__ __launch_bounds__(BLOCK) void k_stretch_half(const FastArgs A, const 
     extern __shared__ double lds[];
     for (int j = threadIdx.x; j < A.axes_len; j += BLOCK) lds[j] = A.axes_blob[j];
     __syncthreads();
-    const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (t >= S.n_active) return;
+    const CoopLds L = coop_lds(lds, A.axes_len);
+    const int64_t t0 = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const bool active = t0 < S.n_active;
+    const int64_t t = active ? t0 : (S.n_active - 1);
     constexpr int NP = NS + 4;
     const int h = S.W >> 1;
     const int64_t star = t / h;
@@ -464,9 +658,9 @@ __global__ __launch_bounds__(BLOCK) void k_stretch_half(const FastArgs A, const 
         y[q] = xj + z * (xk[q] - xj);
     }
     const DevModel& M = A.m[S.multi ? star : 0];
-    const double lnew = lnpost_one<KIND, NS, NB, true>(A, lds, M, y);
+    const double lnew = lnpost_wave<KIND, NS, NB, true>(A, lds, L, active, M, y);
     const double lnq = (NP - 1) * log(z) + lnew - S.lnp[row];
-    const bool acc = isfinite(lnew) && (log(u2) < lnq);
+    const bool acc = active && isfinite(lnew) && (log(u2) < lnq);
     if (acc) {
 #pragma unroll
         for (int q = 0; q < NP; ++q) S.pos[row * NP + q] = y[q];
@@ -479,7 +673,7 @@ template <int KIND, int NS>
 inline bool launch_stretch_nb(int nb, const FastArgs& A, const StretchArgs& S, hipStream_t s)
 {
     const dim3 g((unsigned)((S.n_active + BLOCK - 1) / BLOCK)), b(BLOCK);
-    const size_t sh = (size_t)A.axes_len * sizeof(double);
+    const size_t sh = (size_t)(((A.axes_len + 1) & ~1) + COOP_LDS_DOUBLES) * sizeof(double);
     switch (nb) {
     case 1: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 1>), g, b, sh, s, A, S); return true;
     case 2: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 2>), g, b, sh, s, A, S); return true;
@@ -497,7 +691,7 @@ template <int KIND, int NS, bool PACKED, bool MULTI>
 inline bool launch_nb(int nb, const FastArgs& A, hipStream_t s)
 {
     const dim3 g((unsigned)((A.n + BLOCK - 1) / BLOCK)), b(BLOCK);
-    const size_t sh = (size_t)A.axes_len * sizeof(double);
+    const size_t sh = (size_t)(((A.axes_len + 1) & ~1) + (PACKED ? COOP_LDS_DOUBLES : 0)) * sizeof(double);
     switch (nb) {
     case 1: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 1, PACKED, MULTI>), g, b, sh, s, A); return true;
     case 2: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 2, PACKED, MULTI>), g, b, sh, s, A); return true;
