@@ -313,12 +313,32 @@ __device__ __forceinline__ double dpp_f64(double x)
     return __hiloint2double(hi, lo);
 }
 
-// sum over the 8 lanes of an aligned group (every lane ends up with the group total)
+// sum over the 8 lanes of an aligned group (every lane ends up with the group total).
+// ISO_REDUCE_MODE 0: three DPP row operations (VALU: 2 moves + 1 add per step);
+// 1: ds_swizzle butterflies (LDS crossbar, no LDS memory) — trades VALU slots for LDS-pipe slots.
+#ifndef ISO_REDUCE_MODE
+#define ISO_REDUCE_MODE 0
+#endif
+template <int XOR>
+__device__ __forceinline__ double swz_f64(double x)
+{
+    constexpr int pat = (XOR << 10) | 0x1F;
+    const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(x), pat);
+    const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(x), pat);
+    return __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ double group8_sum(double x)
 {
+#if ISO_REDUCE_MODE == 0
     x += dpp_f64<0xB1>(x);    // quad_perm [1,0,3,2]
     x += dpp_f64<0x4E>(x);    // quad_perm [2,3,0,1]
     x += dpp_f64<0x141>(x);   // row_half_mirror: lane k <-> 7-k within each 8 lanes
+#else
+    x += swz_f64<1>(x);
+    x += swz_f64<2>(x);
+    x += swz_f64<4>(x);
+#endif
     return x;
 }
 
