@@ -290,16 +290,18 @@ __device__ __forceinline__ double eep_term(const DevModel& M, const DevPrior& or
 // batched-ensemble form: S stars x W walkers in one launch.
 // ---- wave-cooperative gathers over the corner-packed tables --------------------------------
 // A lane-per-sample gather issues 24 + 8 x 16-B loads per lane with 64 unrelated addresses per
-// wave instruction; measured ceiling of that pattern on MI355X: 4.3 TB/s of useful bytes
-// (tools/gather_probe.hip).  Letting 8 lanes share one sample — lane j loads corner j's 48 B, so a
-// wave instruction covers 8 samples x 128 contiguous bytes — reaches 6.6 TB/s.  The sample's owner
-// lane publishes (cell, weights) in a wave-private LDS slot; each group of 8 lanes serves one
-// sample per iteration (8 iterations per wave), weights its corner, sums the 8 corners with DPP
-// row operations (no LDS traffic) and lane 0 of the group writes the result back to the owner's
-// response slot.  Slot strides (7 / 9 doubles) are chosen conflict-free for 64-bit LDS accesses.
-#ifndef ISO_STAR_BATCH
-#define ISO_STAR_BATCH 4
-#endif
+// wave instruction; measured ceiling of that pattern on MI355X: 4.4 TB/s of useful bytes
+// (tools/gather_probe.hip).  Letting 4 lanes share one sample — each wave instruction then covers
+// 16 samples x 64 contiguous bytes — reaches 7.1 TB/s.  The sample's owner lane publishes
+// (cell, t0..t3) in a wave-private LDS slot; each group of 4 lanes serves one sample per iteration
+// (4 iterations per wave), weights its share of the corners, sums over the group with two DPP
+// quad permutes (no LDS traffic) and writes the result to the owner's response slot.  The packed
+// tables are laid out for exactly this access (k_pack_star4 / k_pack_bc4 in iso_hip.hip):
+//   model cell: 24 double2 "pieces"; piece (k, j) = index 4k+j holds columns (2q, 2q+1), q = k%3,
+//               of corner c = 4*(k/3) + j  (c bit2/bit1/bit0 = +1 on axis 0/1/2);
+//   BC cell:    piece ((k*NB + e)*4 + j) = {band e at Av node i3, band e at i3+1} of the corner
+//               with axis-0 offset k and (axis-1, axis-2) offsets = the two bits of j.
+// Slot strides (7 / 9 doubles) are conflict-free for 64-bit LDS accesses.
 constexpr int REQ_STRIDE = 7;     // doubles per request slot  (header, t0..t3, pad)
 constexpr int RSP_STRIDE = 9;     // doubles per response slot (<= 8 values)
 constexpr int COOP_LDS_DOUBLES = BLOCK * (REQ_STRIDE + RSP_STRIDE);
@@ -313,32 +315,11 @@ __device__ __forceinline__ double dpp_f64(double x)
     return __hiloint2double(hi, lo);
 }
 
-// sum over the 8 lanes of an aligned group (every lane ends up with the group total).
-// ISO_REDUCE_MODE 0: three DPP row operations (VALU: 2 moves + 1 add per step);
-// 1: ds_swizzle butterflies (LDS crossbar, no LDS memory) — trades VALU slots for LDS-pipe slots.
-#ifndef ISO_REDUCE_MODE
-#define ISO_REDUCE_MODE 0
-#endif
-template <int XOR>
-__device__ __forceinline__ double swz_f64(double x)
+// sum over the 4 lanes of an aligned quad (every lane ends up with the total)
+__device__ __forceinline__ double quad_sum(double x)
 {
-    constexpr int pat = (XOR << 10) | 0x1F;
-    const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(x), pat);
-    const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(x), pat);
-    return __hiloint2double(hi, lo);
-}
-
-__device__ __forceinline__ double group8_sum(double x)
-{
-#if ISO_REDUCE_MODE == 0
     x += dpp_f64<0xB1>(x);    // quad_perm [1,0,3,2]
     x += dpp_f64<0x4E>(x);    // quad_perm [2,3,0,1]
-    x += dpp_f64<0x141>(x);   // row_half_mirror: lane k <-> 7-k within each 8 lanes
-#else
-    x += swz_f64<1>(x);
-    x += swz_f64<2>(x);
-    x += swz_f64<4>(x);
-#endif
     return x;
 }
 
@@ -360,46 +341,42 @@ __device__ __forceinline__ void coop_star(const FastArgs& A, const CoopLds& L, b
     mine[3] = w.t2;
     __builtin_amdgcn_wave_barrier();
     const unsigned long long m = __ballot(need);
-    const int j = L.lane & 7, grp = L.lane >> 3;
-    // batches of SB iterations: all 3*SB loads of a batch are in flight before the first use
-    constexpr int SB = ISO_STAR_BATCH;
+    const int j = L.lane & 3, grp = L.lane >> 2;
+    // two batches of two iterations: the 12 loads of a batch are in flight before the first use
 #pragma unroll
-    for (int half = 0; half < 8 / SB; ++half) {
-        if (((m >> (8 * SB * half)) & ((SB == 8) ? ~0ull : ((1ull << (8 * SB)) - 1ull))) == 0) continue;   // wave-uniform
-        double2 u[SB][3];
-        double ww[SB];
+    for (int half = 0; half < 2; ++half) {
+        if (((m >> (32 * half)) & 0xFFFFFFFFull) == 0) continue;          // wave-uniform
+        double2 u[2][6];
+        double wlo[2], whi[2];
 #pragma unroll
-        for (int k = 0; k < SB; ++k) {
-            const int src = 8 * (SB * half + k) + grp;
+        for (int k = 0; k < 2; ++k) {
+            const int src = 16 * (2 * half + k) + grp;
             const double* rq = L.req + src * REQ_STRIDE;
             const double hdr = rq[0];
-            W3 ws;
-            ws.t0 = rq[1];
-            ws.t1 = rq[2];
-            ws.t2 = rq[3];
+            const double t0 = rq[1], t1 = rq[2], t2 = rq[3];
             const bool nd = __double2hiint(hdr) != 0;
             const uint32_t c = nd ? (uint32_t)__double2loint(hdr) : 0u;      // cell 0 is always readable
-            const double2* __restrict__ pc =
-                reinterpret_cast<const double2*>(A.hotq + (size_t)c * PACK_ENTRY + j * PACK_COLS);
-            u[k][0] = pc[0];
-            u[k][1] = pc[1];
-            u[k][2] = pc[2];
-            ww[k] = nd ? w3(ws, j) : 0.0;
+            const double2* __restrict__ pc = reinterpret_cast<const double2*>(A.hotq + (size_t)c * PACK_ENTRY) + j;
+#pragma unroll
+            for (int e = 0; e < 6; ++e) u[k][e] = pc[4 * e];
+            const double g = ((j & 2) ? t1 : (1 - t1)) * ((j & 1) ? t2 : (1 - t2));
+            wlo[k] = nd ? (1 - t0) * g : 0.0;     // corners 0..3 (axis-0 offset 0)
+            whi[k] = nd ? t0 * g : 0.0;           // corners 4..7
         }
 #pragma unroll
-        for (int k = 0; k < SB; ++k) {
-            const int src = 8 * (SB * half + k) + grp;
+        for (int k = 0; k < 2; ++k) {
+            const int src = 16 * (2 * half + k) + grp;
             double part[6];
-            part[0] = u[k][0].x * ww[k]; part[1] = u[k][0].y * ww[k];
-            part[2] = u[k][1].x * ww[k]; part[3] = u[k][1].y * ww[k];
-            part[4] = u[k][2].x * ww[k]; part[5] = u[k][2].y * ww[k];
 #pragma unroll
-            for (int q = 0; q < 6; ++q) part[q] = group8_sum(part[q]);
-            if (j == 0) {
-                double* rs = L.rsp + src * RSP_STRIDE;
-#pragma unroll
-                for (int q = 0; q < 6; ++q) rs[q] = part[q];
+            for (int q = 0; q < 3; ++q) {
+                part[2 * q] = quad_sum(u[k][q].x * wlo[k] + u[k][3 + q].x * whi[k]);
+                part[2 * q + 1] = quad_sum(u[k][q].y * wlo[k] + u[k][3 + q].y * whi[k]);
             }
+            double* rs = L.rsp + src * RSP_STRIDE;
+            // spread the six stores over the quad: lane j writes values j and j+4
+            const double a0 = (j == 0) ? part[0] : (j == 1) ? part[1] : (j == 2) ? part[2] : part[3];
+            rs[j] = a0;
+            if (j < 2) rs[4 + j] = (j == 0) ? part[4] : part[5];
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -409,7 +386,7 @@ __device__ __forceinline__ void coop_star(const FastArgs& A, const CoopLds& L, b
     __builtin_amdgcn_wave_barrier();
 }
 
-// BC table: lane j of a group handles corners 2j and 2j+1 (2*NB contiguous doubles)
+// BC table: lane j of a quad handles the corners whose (axis-1, axis-2) offsets are the bits of j
 template <int NB>
 __device__ __forceinline__ void coop_bc(const FastArgs& A, const CoopLds& L, bool need, uint32_t cell, const W4& w,
                                         double* __restrict__ v)
@@ -422,47 +399,40 @@ __device__ __forceinline__ void coop_bc(const FastArgs& A, const CoopLds& L, boo
     mine[4] = w.t3;
     __builtin_amdgcn_wave_barrier();
     const unsigned long long m = __ballot(need);
-    const int j = L.lane & 7, grp = L.lane >> 3;
+    const int j = L.lane & 3, grp = L.lane >> 2;
     // batches sized so that <= 12 x 16-B loads per lane are in flight before the first use
-    constexpr int BATCH = (NB <= 1) ? 8 : (NB <= 3) ? 4 : (NB <= 6) ? 2 : 1;
+    constexpr int BATCH = (NB <= 1) ? 4 : (NB <= 3) ? 2 : 1;
 #pragma unroll
-    for (int r0 = 0; r0 < 8; r0 += BATCH) {
-        if (((m >> (8 * r0)) & ((BATCH == 8) ? ~0ull : ((1ull << (8 * BATCH)) - 1ull))) == 0) continue;   // wave-uniform
-        double x[BATCH][2 * NB];
-        double wa[BATCH], wb[BATCH];
+    for (int r0 = 0; r0 < 4; r0 += BATCH) {
+        if (((m >> (16 * r0)) & ((BATCH == 4) ? ~0ull : ((1ull << (16 * BATCH)) - 1ull))) == 0) continue;   // wave-uniform
+        double2 x[BATCH][2 * NB];
+        double wa[BATCH][2], wb[BATCH][2];
 #pragma unroll
         for (int k = 0; k < BATCH; ++k) {
-            const int src = 8 * (r0 + k) + grp;
+            const int src = 16 * (r0 + k) + grp;
             const double* rq = L.req + src * REQ_STRIDE;
             const double hdr = rq[0];
-            W4 ws;
-            ws.t0 = rq[1];
-            ws.t1 = rq[2];
-            ws.t2 = rq[3];
-            ws.t3 = rq[4];
+            const double t0 = rq[1], t1 = rq[2], t2 = rq[3], t3 = rq[4];
             const bool nd = __double2hiint(hdr) != 0;
             const uint32_t c = nd ? (uint32_t)__double2loint(hdr) : 0u;
-            const double2* __restrict__ pc =
-                reinterpret_cast<const double2*>(A.bcq + (size_t)c * (16 * NB) + (2 * j) * NB);
+            const double2* __restrict__ pc = reinterpret_cast<const double2*>(A.bcq + (size_t)c * (16 * NB)) + j;
 #pragma unroll
-            for (int e = 0; e < NB; ++e) {
-                const double2 u = pc[e];
-                x[k][2 * e] = u.x;
-                x[k][2 * e + 1] = u.y;
-            }
-            wa[k] = nd ? w4(ws, 2 * j) : 0.0;
-            wb[k] = nd ? w4(ws, 2 * j + 1) : 0.0;
+            for (int e = 0; e < 2 * NB; ++e) x[k][e] = pc[4 * e];           // e = kk*NB + band
+            const double g = nd ? ((j & 2) ? t1 : (1 - t1)) * ((j & 1) ? t2 : (1 - t2)) : 0.0;
+            wa[k][0] = (1 - t0) * g * (1 - t3);
+            wb[k][0] = (1 - t0) * g * t3;
+            wa[k][1] = t0 * g * (1 - t3);
+            wb[k][1] = t0 * g * t3;
         }
 #pragma unroll
         for (int k = 0; k < BATCH; ++k) {
-            const int src = 8 * (r0 + k) + grp;
-            double part[NB];
+            const int src = 16 * (r0 + k) + grp;
+            double* rs = L.rsp + src * RSP_STRIDE;
 #pragma unroll
-            for (int b = 0; b < NB; ++b) part[b] = group8_sum(x[k][b] * wa[k] + x[k][NB + b] * wb[k]);
-            if (j == 0) {
-                double* rs = L.rsp + src * RSP_STRIDE;
-#pragma unroll
-                for (int b = 0; b < NB; ++b) rs[b] = part[b];
+            for (int b = 0; b < NB; ++b) {
+                const double part = quad_sum(x[k][b].x * wa[k][0] + x[k][b].y * wb[k][0] +
+                                             x[k][NB + b].x * wa[k][1] + x[k][NB + b].y * wb[k][1]);
+                if (j == (b & 3)) rs[b] = part;
             }
         }
     }

@@ -928,33 +928,43 @@ __global__ __launch_bounds__(BLOCK) void k_pack_bc(const PackBcArgs A)
 
 struct PackCornersArgs {
     const double* src;      // compact table, `ncol` doubles per cell
-    int ncol, keep;         // keep the first `keep` columns of every corner
-    int ndim;               // 3 or 4
+    int ncol, keep;         // keep the first `keep` columns of every corner (BC: keep = ncol = n_bands)
+    int ndim;               // 3 (model table) or 4 (BC table)
     int64_t n[4];           // axis lengths
     int64_t ncells;
-    double* out;            // [cell][2^ndim corners][keep]
+    double* out;            // [cell][2^ndim * keep], laid out for the 4-lanes-per-sample gather
 };
 
-// corner-packed layout: every cell carries its own 2^D corners (corner order = reference order)
+// Corner-packed layout: every cell carries its own 2^D corners, ordered so that 4 cooperating lanes
+// read 64 contiguous bytes per load instruction (see iso_fast_kernel.h).
+//   ndim 3: double index e = 2*(4k + j) + comp  ->  corner c = 4*(k/3) + j, column 2*(k%3) + comp
+//   ndim 4: double index e = 2*((k*NB + band)*4 + j) + comp  ->  axis-0 offset k, (axis-1, axis-2)
+//           offsets = bits of j, axis-3 offset comp
 __global__ __launch_bounds__(BLOCK) void k_pack_corners(const PackCornersArgs A)
 {
-    const int nc = 1 << A.ndim;
-    const int64_t per = (int64_t)nc * A.keep;
+    const int per = (1 << A.ndim) * A.keep;
     const int64_t total = A.ncells * per;
     for (int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x; e < total; e += (int64_t)gridDim.x * BLOCK) {
         const int64_t cell = e / per;
         const int r = (int)(e - cell * per);
-        const int j = r / A.keep, q = r - j * A.keep;
+        const int comp = r & 1, piece = r >> 1, j = piece & 3, kk = piece >> 2;
+        int off[4], col;
+        if (A.ndim == 3) {
+            off[0] = kk / 3; off[1] = (j >> 1) & 1; off[2] = j & 1; off[3] = 0;
+            col = 2 * (kk % 3) + comp;
+        } else {
+            off[0] = kk / A.keep; off[1] = (j >> 1) & 1; off[2] = j & 1; off[3] = comp;
+            col = kk % A.keep;
+        }
         int64_t rem = cell, src_cell = 0, mul = 1;
         for (int d = A.ndim - 1; d >= 0; --d) {
             int64_t id = rem % A.n[d];
             rem /= A.n[d];
-            const int bit = (j >> (A.ndim - 1 - d)) & 1;
-            id = min(id + bit, A.n[d] - 1);      // edge cells are never addressed (i <= n-2)
+            id = min(id + off[d], A.n[d] - 1);      // edge cells are never addressed (i <= n-2)
             src_cell += id * mul;
             mul *= A.n[d];
         }
-        A.out[e] = A.src[src_cell * A.ncol + q];
+        A.out[e] = A.src[src_cell * A.ncol + col];
     }
 }
 

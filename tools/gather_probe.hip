@@ -55,6 +55,31 @@ __global__ __launch_bounds__(256) void k_coop(const double2* __restrict__ big, u
     }
 }
 
+// 4 lanes cooperate on one sample: instruction k covers bytes [64k, 64k+64) of the 384-B cell
+__global__ __launch_bounds__(256) void k_coop4(const double2* __restrict__ big, uint32_t ncell, const double2* __restrict__ bc,
+                                               uint32_t nbc, const double* __restrict__ pars, double* __restrict__ out, int n, uint32_t salt)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int i = t >> 2, sub = t & 3;
+    if (i >= n) return;
+    const uint32_t c = hash32(i * 2654435761u + salt) % ncell;
+    const double2* p = big + (size_t)c * 24;
+    double2 a[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) a[k] = p[4 * k + sub];
+    const uint32_t b = hash32(i * 40503u + salt + 17u) % nbc;
+    const double2 v0 = bc[(size_t)b * 8 + sub], v1 = bc[(size_t)b * 8 + 4 + sub];
+    double acc = v0.x + v0.y + v1.x + v1.y;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) acc += a[k].x + a[k].y;
+    acc += __shfl_xor(acc, 1);
+    acc += __shfl_xor(acc, 2);
+    if (sub == 0) {
+        for (int q = 0; q < 5; ++q) acc += pars[(size_t)q * n + i];
+        out[i] = acc;
+    }
+}
+
 int main()
 {
     const uint32_t ncell = 15u * 196u * 1710u, nbc = 70u * 26u * 18u * 13u;
@@ -70,16 +95,17 @@ int main()
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     const double bytes = (384.0 + 128.0 + 48.0) * n;
-    for (int variant = 0; variant < 2; ++variant) {
+    for (int variant = 0; variant < 3; ++variant) {
         for (int rep = 0; rep < 2; ++rep) {
             hipEventRecord(e0);
             for (int it = 0; it < 100; ++it) {
                 if (variant == 0) hipLaunchKernelGGL(k_lane, dim3((n + 255) / 256), dim3(256), 0, 0, big, ncell, bc, nbc, pars, out, n, (uint32_t)it);
-                else hipLaunchKernelGGL(k_coop, dim3((n * 8 + 255) / 256), dim3(256), 0, 0, big, ncell, bc, nbc, pars, out, n, (uint32_t)it);
+                else if (variant == 1) hipLaunchKernelGGL(k_coop, dim3((n * 8 + 255) / 256), dim3(256), 0, 0, big, ncell, bc, nbc, pars, out, n, (uint32_t)it);
+                else hipLaunchKernelGGL(k_coop4, dim3((n * 4 + 255) / 256), dim3(256), 0, 0, big, ncell, bc, nbc, pars, out, n, (uint32_t)it);
             }
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
-            if (rep) printf("%s: %.2f us/launch, %.0f GB/s of useful bytes (%.2f of 8 TB/s)\n", variant ? "8-lanes-per-sample" : "lane-per-sample  ",
+            if (rep) printf("%s: %.2f us/launch, %.0f GB/s of useful bytes (%.2f of 8 TB/s)\n", variant == 0 ? "lane-per-sample   " : variant == 1 ? "8-lanes-per-sample" : "4-lanes-per-sample",
                             ms * 10.0, bytes / (ms * 1e-5) / 1e9, bytes / (ms * 1e-5) / 8e12);
         }
     }
