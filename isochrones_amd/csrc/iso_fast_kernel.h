@@ -301,10 +301,12 @@ __device__ __forceinline__ double eep_term(const DevModel& M, const DevPrior& or
 //               of corner c = 4*(k/3) + j  (c bit2/bit1/bit0 = +1 on axis 0/1/2);
 //   BC cell:    piece ((k*NB + e)*4 + j) = {band e at Av node i3, band e at i3+1} of the corner
 //               with axis-0 offset k and (axis-1, axis-2) offsets = the two bits of j.
-// Slot strides (7 / 9 doubles) are conflict-free for 64-bit LDS accesses.
-constexpr int REQ_STRIDE = 7;     // doubles per request slot  (header, t0..t3, pad)
-constexpr int RSP_STRIDE = 9;     // doubles per response slot (<= 8 values)
-constexpr int COOP_LDS_DOUBLES = BLOCK * (REQ_STRIDE + RSP_STRIDE);
+// One slot per sample serves as request (header, t0..t3) and then as response (<= 8 values): a
+// slot's request is read only in the iteration that serves it, and its response is written later
+// in that same iteration, so the two may share storage.  Stride 9 doubles: conflict-free b64 access.
+constexpr int REQ_STRIDE = 9;
+constexpr int RSP_STRIDE = 9;
+constexpr int COOP_LDS_DOUBLES = BLOCK * REQ_STRIDE;
 
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double x)
@@ -565,7 +567,7 @@ __device__ __forceinline__ CoopLds coop_lds(double* lds, int axes_len)
     const int wave = threadIdx.x >> 6;
     CoopLds L;
     L.req = lds + base + wave * 64 * REQ_STRIDE;
-    L.rsp = lds + base + BLOCK * REQ_STRIDE + wave * 64 * RSP_STRIDE;
+    L.rsp = L.req;
     L.lane = threadIdx.x & 63;
     return L;
 }
