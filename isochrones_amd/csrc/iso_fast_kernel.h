@@ -572,8 +572,12 @@ __device__ __forceinline__ CoopLds coop_lds(double* lds, int axes_len)
     return L;
 }
 
+// waves per SIMD the register allocator must leave room for: 6 for the small single-star kernels
+// (88 -> 80 VGPR, a few dwords of scratch; measured +2 %), otherwise whatever the kernel needs
+constexpr int fast_min_waves(int ns, int nb) { return (ns == 1 && nb <= 2) ? 6 : 4; }
+
 template <int KIND, int NS, int NB, bool PACKED, bool MULTI>
-__global__ __launch_bounds__(BLOCK) void k_lnpost_fast(const FastArgs A)
+__global__ __launch_bounds__(BLOCK, fast_min_waves(NS, NB)) void k_lnpost_fast(const FastArgs A)
 {
     extern __shared__ double lds[];
     for (int j = threadIdx.x; j < A.axes_len; j += BLOCK) lds[j] = A.axes_blob[j];
