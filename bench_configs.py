@@ -152,6 +152,73 @@ def cfg4(nwalkers=256, nsteps=5000):
             "reference_published_estimate_s": [69e-6 * calls, 719e-6 * calls]}
 
 
+def primitives(n=1_000_000, reps=20):
+    """The batch primitives behind the public API: interp_mag with the 11 default bands
+    (1 816 algorithmic B/sample) and interp_value of all 18 columns."""
+    import torch
+    import isochrones_amd as ia
+    ic = ia.synthetic_track()                                    # 11 default bands
+    rng = np.random.default_rng(5)
+    lo = np.array([0.1, 1.0, -4.0, 1.0, 0.0]); hi = np.array([10.0, 1710.0, 0.5, 3000.0, 1.0])
+    pars = torch.as_tensor(np.ascontiguousarray(rng.uniform(lo, hi, size=(n, 5)).T), device="cuda")
+    out = {}
+    for name, fn, nbytes in (
+            ("interp_mag_11_bands", lambda: ic.interp_mag_device(pars, list(ic.bands)), 8 * 4 * 8 + 16 * 11 * 8 + 40 + 8 * 14),
+            ("interp_value_18_cols", lambda: ic.model_grid.interp.interp_device([pars[2], pars[0], pars[1]], np.arange(18)),
+             8 * 18 * 8 + 24 + 18 * 8)):
+        fn(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        out[name] = {"ms": ms, "samples_per_s": n / (ms * 1e-3), "algorithmic_GBs": nbytes * n / (ms * 1e-3) / 1e9,
+                     "bytes_per_sample": nbytes}
+    return {"config": "primitives", "metric": "batch API primitives, 1e6 samples (includes output allocation)", **out}
+
+
+def tree(n=1_000_000, reps=20):
+    """Generic observation-tree model (docs/multiple.ipynb resolved binary: 3 unresolved bands +
+    a resolved relative K image, 2 stars in one system); reference: 1.23 ms per lnpost call."""
+    import torch
+    import isochrones_amd as ia
+    from isochrones_amd.observation import Observation, ObservationTree, Source
+    ic = ia.synthetic_isochrone(bands=("J", "H", "K"))
+    obs = ObservationTree(name="resolved")
+    for band, m in zip("JHK", (12.11, 11.74, 11.68)):
+        o = Observation("2MASS", band, 4)
+        o.add_source(Source(m, 0.02))
+        obs.add_observation(o)
+    o = Observation("AO", "K", 0.1)
+    o.add_source(Source(0.0, 0.02, separation=0, pa=0, relative=True, is_reference=True))
+    o.add_source(Source(2.43, 0.02, separation=0.2, pa=100, relative=True, is_reference=False))
+    obs.add_observation(o)
+    mod = ia.StarModel(ic, obs=obs, parallax=(2.0, 0.05), Teff=(5834.0, 100), logg=(4.43, 0.15), feh=(-0.01, 0.1))
+    rng = np.random.default_rng(8)
+    c = np.array([300.0, 280.0, 9.6, 0.0, 400.0, 0.1]); w = np.array([10.0, 10.0, 0.1, 0.1, 20.0, 0.05])
+    pars = c + w * rng.standard_normal((n, 6))
+    pars[:, :2] = -np.sort(-pars[:, :2], axis=1)
+    pars[:, 5] = np.abs(pars[:, 5])
+    pt = torch.as_tensor(pars, device="cuda")
+    out = mod.lnpost(pt); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        out = mod.lnpost(pt)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    from oracle import oracle as orc
+    ns = 20_000
+    ref = orc.tree_lnpost(_oracle_ic(ic), mod.tree_desc(), np.ascontiguousarray(pars[:ns].T), nthreads=os.cpu_count())[0]
+    got = out[:ns].cpu().numpy()
+    fin = np.isfinite(ref)
+    rel = float(np.max(np.abs(got[fin] - ref[fin]) / np.maximum(1, np.abs(ref[fin])))) if fin.any() else 0.0
+    return {"config": "tree", "metric": "generic observation-tree lnpost, resolved binary, 1e6 batch",
+            "kernel_ms": ms, "evals_per_s": n / (ms * 1e-3), "finite_fraction": float(fin.mean()),
+            "parity_max_rel_err": rel, "reference_published_us_per_call": 1230.0}
+
+
 def cfg5(n_stars=10_000, nwalkers=32, nburn=150, niter=100):
     import torch
     import torch.distributed as dist
@@ -199,7 +266,8 @@ def main():
     ap.add_argument("--stars", type=int, default=10_000)
     args = ap.parse_args()
     for name in args.configs.split(","):
-        fn = {"cfg1": cfg1, "cfg3": cfg3, "cfg4": cfg4, "cfg5": lambda: cfg5(args.stars)}[name.strip()]
+        fn = {"cfg1": cfg1, "cfg3": cfg3, "cfg4": cfg4, "cfg5": lambda: cfg5(args.stars),
+              "primitives": primitives, "tree": tree}[name.strip()]
         r = fn()
         if r is not None:
             print(json.dumps(r), flush=True)

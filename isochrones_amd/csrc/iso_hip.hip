@@ -157,14 +157,29 @@ struct InterpArgs {
     double* out;
 };
 
+// Column-parallel mapping: G = ceil(k/2) adjacent lanes share one sample, lane `sub` owns the
+// selected columns 2*sub and 2*sub+1.  For every corner the G lanes read neighbouring columns of
+// the same table row (one or two cache lines) and finally write k contiguous doubles — coalesced
+// loads and stores with no cross-lane reduction; the bracket search is repeated by the G lanes
+// (cheap: ~150 VALU against >= 1 KB of gathered table per sample).  k = 1, 2 degenerate to one lane
+// per sample.
 template <int ND>
 __global__ __launch_bounds__(BLOCK) void k_interp(const InterpArgs A)
 {
     extern __shared__ double lds[];
     stage_axes<ND>(A.ax, lds);
     __syncthreads();
-    const int64_t stride_grid = (int64_t)gridDim.x * BLOCK;
-    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < A.n; i += stride_grid) {
+    const int G = (A.k + 1) >> 1;            // lanes per sample
+    const int S = 64 / G;                    // samples per wave
+    const int lane = threadIdx.x & 63;
+    const int slot = lane / G, sub = lane - slot * G;
+    if (slot >= S) return;                   // leftover lanes (no cross-lane operations below)
+    const int c0 = A.icols[2 * sub];
+    const bool two = (2 * sub + 1) < A.k;
+    const int c1 = two ? A.icols[2 * sub + 1] : c0;
+    const int64_t wave0 = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * BLOCK) >> 6;
+    for (int64_t i = wave0 * S + slot; i < A.n; i += nwaves * S) {
         double x[ND];
         bool bad = false;
 #pragma unroll
@@ -176,21 +191,21 @@ __global__ __launch_bounds__(BLOCK) void k_interp(const InterpArgs A)
 #pragma unroll
             for (int d = 0; d < ND; ++d) bad |= out_of_axis(A.ax[d], lds, x[d]);
         }
-        double* o = A.out + i * A.k;
+        double* o = A.out + i * A.k + 2 * sub;
         if (bad) {
-            for (int c = 0; c < A.k; ++c) o[c] = d_nan();
+            o[0] = d_nan();
+            if (two) o[1] = d_nan();
             continue;
         }
-        int idx[ND];
         double t[ND];
         int64_t base = 0;
 #pragma unroll
         for (int d = 0; d < ND; ++d) {
-            bracket(A.ax[d], lds, x[d], idx[d], t[d]);
-            base += (int64_t)idx[d] * A.stride[d];
+            int idx;
+            bracket(A.ax[d], lds, x[d], idx, t[d]);
+            base += (int64_t)idx * A.stride[d];
         }
-        double w[1 << ND];
-        int64_t off[1 << ND];
+        double v0 = 0.0, v1 = 0.0;
 #pragma unroll
         for (int j = 0; j < (1 << ND); ++j) {
             double ww = 1.0;
@@ -201,16 +216,12 @@ __global__ __launch_bounds__(BLOCK) void k_interp(const InterpArgs A)
                 ww *= bit ? t[d] : (1 - t[d]);
                 oo += bit ? A.stride[d] : 0;
             }
-            w[j] = ww;
-            off[j] = oo * A.ncol;
+            const double* __restrict__ cell = A.grid + oo * A.ncol;
+            v0 += cell[c0] * ww;
+            v1 += cell[c1] * ww;
         }
-        for (int c = 0; c < A.k; ++c) {
-            const double* __restrict__ col = A.grid + A.icols[c];
-            double v = 0.0;
-#pragma unroll
-            for (int j = 0; j < (1 << ND); ++j) v += col[off[j]] * w[j];
-            o[c] = v;
-        }
+        o[0] = v0;
+        if (two) o[1] = v1;
     }
 }
 
@@ -349,6 +360,11 @@ struct MagArgs {
     double *Teff, *logg, *feh, *mags;
 };
 
+// Column-parallel like k_interp: G = max(1, ceil(nb/2)) adjacent lanes share one sample; every lane
+// repeats the (cheap) model-table gather of the four stellar columns — the G lanes read identical
+// addresses, i.e. one request — and the BC brackets, then lane `sub` owns the bands 2*sub, 2*sub+1:
+// per corner the G lanes read neighbouring columns of one BC row and finally write nb contiguous
+// magnitudes.
 template <int KIND>
 __global__ __launch_bounds__(BLOCK) void k_interp_mag(const MagArgs A)
 {
@@ -356,8 +372,16 @@ __global__ __launch_bounds__(BLOCK) void k_interp_mag(const MagArgs A)
     stage_axes<3>(A.g3.ax, lds);
     stage_axes<4>(A.g4.ax, lds);
     __syncthreads();
-    const int64_t stride_grid = (int64_t)gridDim.x * BLOCK;
-    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < A.n; i += stride_grid) {
+    const int G = (A.nb + 1) >> 1 > 0 ? (A.nb + 1) >> 1 : 1;
+    const int S = 64 / G;
+    const int lane = threadIdx.x & 63;
+    const int slot = lane / G, sub = lane - slot * G;
+    if (slot >= S) return;
+    const bool has0 = (2 * sub) < A.nb, has1 = (2 * sub + 1) < A.nb;
+    const int c0 = has0 ? A.bc_cols[2 * sub] : 0, c1 = has1 ? A.bc_cols[2 * sub + 1] : c0;
+    const int64_t wave0 = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * BLOCK) >> 6;
+    for (int64_t i = wave0 * S + slot; i < A.n; i += nwaves * S) {
         const double* __restrict__ p = A.pars + i * A.stride_n;
         const double p0 = p[0], p1 = p[A.stride_p], p2 = p[2 * A.stride_p];
         const double dist = p[3 * A.stride_p], AV = p[4 * A.stride_p];
@@ -366,17 +390,29 @@ __global__ __launch_bounds__(BLOCK) void k_interp_mag(const MagArgs A)
         double star[4] = {d_nan(), d_nan(), d_nan(), d_nan()};
         Cell3 c3;
         if (locate3(A.g3, lds, x0, x1, x2, c3)) gather3<4>(A.g3, c3, star);
-        if (A.Teff) A.Teff[i] = star[0];
-        if (A.logg) A.logg[i] = star[1];
-        if (A.feh) A.feh[i] = star[2];
-        if (A.mags) {
+        if (sub == 0) {
+            if (A.Teff) A.Teff[i] = star[0];
+            if (A.logg) A.logg[i] = star[1];
+            if (A.feh) A.feh[i] = star[2];
+        }
+        if (A.mags && has0) {
             Cell4 c4;
             const bool ok = locate4(A.g4, lds, star[0], star[1], star[2], AV, c4);
             const double dm = 5 * log10(dist / 10.0);
-            for (int b = 0; b < A.nb; ++b) {
-                const double bc = ok ? gather4_col(A.g4, c4, A.bc_cols[b]) : d_nan();
-                A.mags[i * A.nb + b] = star[3] + dm - bc;
+            double b0 = d_nan(), b1 = d_nan();
+            if (ok) {
+                b0 = b1 = 0.0;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const double* __restrict__ row = A.g4.tab + corner4(A.g4, c4, j) * A.g4.ncol;
+                    const double ww = weight4(c4, j);
+                    b0 += row[c0] * ww;
+                    b1 += row[c1] * ww;
+                }
             }
+            double* o = A.mags + i * A.nb + 2 * sub;
+            o[0] = star[3] + dm - b0;
+            if (has1) o[1] = star[3] + dm - b1;
         }
     }
 }
@@ -1271,7 +1307,9 @@ int iso_interp(iso_table* t, const double* const* x, int64_t n, const int32_t* i
     }
     A.out = out;
     DeviceGuard guard(t->ctx->device);
-    const dim3 g(grid_blocks(n)), b(BLOCK);
+    const int lanes_per_sample = (k + 1) / 2, samples_per_wave = 64 / lanes_per_sample;
+    const int64_t waves = (n + samples_per_wave - 1) / samples_per_wave;
+    const dim3 g(grid_blocks(waves * 64)), b(BLOCK);
     const size_t shmem = (size_t)lds * sizeof(double);
     switch (t->ndim) {
     case 2: hipLaunchKernelGGL(k_interp<2>, g, b, shmem, as_stream(stream), A); break;
@@ -1396,7 +1434,9 @@ int iso_interp_mag(iso_ic* ic, const double* pars, int64_t stride_n, int64_t str
     A.Teff = Teff; A.logg = logg; A.feh = feh;
     A.mags = nb > 0 ? mags : nullptr;
     DeviceGuard guard(ic->ctx->device);
-    const dim3 g(grid_blocks(n)), b(BLOCK);
+    const int lanes_per_sample = nb > 1 ? (nb + 1) / 2 : 1, samples_per_wave = 64 / lanes_per_sample;
+    const int64_t waves = (n + samples_per_wave - 1) / samples_per_wave;
+    const dim3 g(grid_blocks(waves * 64)), b(BLOCK);
     const size_t shmem = (size_t)ic->lds_doubles * sizeof(double);
     if (ic->kind == ISO_KIND_TRACK) hipLaunchKernelGGL(k_interp_mag<ISO_KIND_TRACK>, g, b, shmem, as_stream(stream), A);
     else hipLaunchKernelGGL(k_interp_mag<ISO_KIND_ISO>, g, b, shmem, as_stream(stream), A);
