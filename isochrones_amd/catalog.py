@@ -375,10 +375,14 @@ def fit_stars_gpu(catalog: StarCatalog, ic, indices, N=1, nwalkers=32, nburn=150
     return out
 
 
-def fit_catalog(catalog: StarCatalog, ic, N=1, fit_fn=None, **fit_kwargs):
+def fit_catalog(catalog: StarCatalog, ic, N=1, fit_fn=None, checkpoint_dir=None, **fit_kwargs):
     """Shard the catalog over the ranks of the default process group (star i -> rank (i+1) % P),
     fit every shard with ``fit_fn`` (default: :func:`fit_stars_gpu`) and all-gather the per-star
-    result rows.  Returns a DataFrame indexed like ``catalog.df`` on every rank."""
+    result rows.  Returns a DataFrame indexed like ``catalog.df`` on every rank.
+
+    ``checkpoint_dir``: every rank stores its finished shard there (``shard_{rank}of{world}.npz``)
+    and a rerun with the same catalog and sharding loads it instead of refitting — the reference's
+    "skip stars whose results already exist" (isochrones/starfit.py:66-77)."""
     import pandas as pd
     import torch
     import torch.distributed as dist
@@ -388,7 +392,26 @@ def fit_catalog(catalog: StarCatalog, ic, N=1, fit_fn=None, **fit_kwargs):
     n = len(catalog)
     mine = shard_indices(n, rank, world)
     fit_fn = fit_fn or fit_stars_gpu
-    rows = np.asarray(fit_fn(catalog, ic, mine, N=N, **fit_kwargs), dtype=np.float64)
+    rows = None
+    ckpt = None
+    if checkpoint_dir is not None:
+        import os
+        os.makedirs(checkpoint_dir, exist_ok=True)
+        ckpt = os.path.join(checkpoint_dir, "shard_%dof%d.npz" % (rank, world))
+        if os.path.exists(ckpt):
+            try:
+                z = np.load(ckpt, allow_pickle=False)
+                if (np.array_equal(z["indices"], mine) and int(z["N"]) == N
+                        and list(z["names"]) == [str(x) for x in catalog.df.index[mine]]):
+                    rows = z["rows"]
+            except Exception:
+                rows = None
+    if rows is None:
+        rows = np.asarray(fit_fn(catalog, ic, mine, N=N, **fit_kwargs), dtype=np.float64)
+        if ckpt is not None:
+            tmp = ckpt + ".tmp.npz"
+            np.savez(tmp, indices=mine, rows=rows, N=N, names=np.array([str(x) for x in catalog.df.index[mine]]))
+            os.replace(tmp, ckpt)
     width = rows.shape[1] if rows.size else 3 * (N + 4) + 3
     full = np.full((n, width), np.nan)
     if distributed:

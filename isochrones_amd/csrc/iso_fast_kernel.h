@@ -450,7 +450,8 @@ __device__ __forceinline__ void coop_bc(const FastArgs& A, const CoopLds& L, boo
 // call this function together; `active` = the lane really has a sample (inactive lanes only help).
 template <int KIND, int NS, int NB, bool PACKED>
 __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* lds, const CoopLds& L, bool active,
-                                              const DevModel& M, const double* __restrict__ p)
+                                              const DevModel& M, const double* __restrict__ p, bool want_parts,
+                                              double& lnp_out, double& lnl_out)
 {
     const double q1 = p[NS], feh_par = p[NS + 1], dist = p[NS + 2], AV = p[NS + 3];
 
@@ -501,7 +502,10 @@ __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* l
     lnp += ln_pdf<false>(M.prior_AV, AV, 0.0);
     if (rejected) lnp = -f_inf();
     const bool prior_ok = active && isfinite(lnp);
-    if (!PACKED && !prior_ok) return -f_inf();      // lane-wise path: nothing cooperative follows
+    const bool go = active && (prior_ok || want_parts);     // evaluate the likelihood for this lane
+    lnp_out = lnp;
+    lnl_out = f_nan();
+    if (!PACKED && !go) return -f_inf();            // lane-wise path: nothing cooperative follows
 
     // ---- lnlike ----
     double lnl = 0.0;
@@ -515,7 +519,7 @@ __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* l
     }
     const double dm = fma(ld, 5.0 * kInvLn10, -5.0);   // 5*log10(d/10)
     double tot[NB];
-    const bool okA = prior_ok && !(AV != AV) && !lds_oob(lds, A.b3, AV);
+    const bool okA = go && !(AV != AV) && !lds_oob(lds, A.b3, AV);
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         const double T = star[s][0], g = star[s][1], f = star[s][2];
@@ -557,6 +561,7 @@ __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* l
         const double r = M.plx_val - 1000.0 / dist;
         lnl += M.plx_g0 - r * r * M.plx_hinv;
     }
+    lnl_out = go ? lnl : f_nan();
     return prior_ok ? lnp + lnl : -f_inf();
 }
 
@@ -594,8 +599,13 @@ __global__ __launch_bounds__(BLOCK, fast_min_waves(NS, NB)) void k_lnpost_fast(c
 #pragma unroll
         for (int j = 0; j < NP; ++j) p[j] = src[j * A.stride_p];
     }
-    const double r = lnpost_wave<KIND, NS, NB, PACKED>(A, lds, L, active, M, p);
-    if (active) A.lnpost[i] = r;
+    double lnp, lnl;
+    const double r = lnpost_wave<KIND, NS, NB, PACKED>(A, lds, L, active, M, p, A.lnlike != nullptr, lnp, lnl);
+    if (active) {
+        if (A.lnpost) A.lnpost[i] = r;
+        if (A.lnprior) A.lnprior[i] = lnp;
+        if (A.lnlike) A.lnlike[i] = lnl;
+    }
 }
 
 // -------------------------------------------------------------------------------------------
@@ -654,7 +664,8 @@ __global__ __launch_bounds__(BLOCK) void k_stretch_half(const FastArgs A, const 
         y[q] = xj + z * (xk[q] - xj);
     }
     const DevModel& M = A.m[S.multi ? star : 0];
-    const double lnew = lnpost_wave<KIND, NS, NB, true>(A, lds, L, active, M, y);
+    double lnp_unused, lnl_unused;
+    const double lnew = lnpost_wave<KIND, NS, NB, true>(A, lds, L, active, M, y, false, lnp_unused, lnl_unused);
     const double lnq = (NP - 1) * log(z) + lnew - S.lnp[row];
     const bool acc = active && isfinite(lnew) && (log(u2) < lnq);
     if (acc) {

@@ -1678,13 +1678,16 @@ void launch_lnpost(const iso_model* m, dim3 g, dim3 b, size_t shmem, hipStream_t
 int enqueue_lnpost(iso_model* m, const double* pars, int64_t stride_n, int64_t stride_p, int64_t n,
                    double* lnpost_out, double* lnprior_out, double* lnlike_out, hipStream_t s)
 {
-    if (m->fast_ok && !lnprior_out && !lnlike_out && lnpost_out) {
+    if (m->fast_ok) {
         FastArgs F = m->fast;
         F.pars = pars;
         F.stride_n = stride_n;
         F.stride_p = stride_p;
         F.n = n;
         F.lnpost = lnpost_out;
+        F.lnprior = lnprior_out;
+        // lnprior alone still needs the likelihood flag off; lnlike requested -> evaluate everywhere
+        F.lnlike = lnlike_out;
         const bool packed = F.hotq != nullptr && F.bcq != nullptr;
         if (launch_lnpost_fast(m->ic->kind, m->desc.n_stars, m->desc.n_bands, packed, false, F, s)) {
             hipError_t e = hipGetLastError();

@@ -90,6 +90,8 @@ struct FastArgs {
     const double* pars;
     int64_t stride_n, stride_p, n;
     double* lnpost;
+    double* lnprior;                 // optional: BasicStarModel.lnprior / .lnlike of every sample
+    double* lnlike;                  // (lnlike is then evaluated even where the prior is not finite)
 };
 
 struct StretchArgs {

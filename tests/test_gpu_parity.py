@@ -330,3 +330,22 @@ def test_handles_survive_any_destroy_order():
             ic.model_grid.interp.release(); ic.release(); mod._dirty()
             mod.lnpost(p)            # everything is rebuilt lazily
         gc.collect()
+
+
+def test_exact_upper_edge_is_defined(kernel_path):
+    """The reference reads past the table for a query exactly on an axis' last node (undefined);
+    this build defines it as the value at that node (i = n-2, t = 1) on every path."""
+    rng = np.random.default_rng(3)
+    ic, mod, lo, hi = _random_model("track", 1, ("G",), rng)
+    f, m, e = ic.model_grid.interp.index_columns
+    oic = fx.make_oracle_ic(ic)
+    pars = np.array([[m[-1], 450.0, 0.0, 300.0, 0.2], [1.0, e[-1], 0.0, 300.0, 0.2], [1.0, 450.0, f[-1], 300.0, 0.2],
+                     [m[-1], e[-1], f[-1], 300.0, 0.2], [m[0], e[0], f[0], 300.0, 0.2]])
+    want = oic.lnpost(mod.model_desc(), pars.T.copy())
+    got = mod.lnpost(pars)
+    fx.assert_close(got, want[0], 1e-9, atol=1e-9, what="upper edge lnpost")
+    v = ic.interp_value([pars[:, 0], pars[:, 1], pars[:, 2]], ["Teff", "Mbol"])
+    wv = oic.model.interp([pars[:, 2], pars[:, 0], pars[:, 1]], [ic.model_grid.interp.column_index[c] for c in ("Teff", "Mbol")])
+    fx.assert_close(v, wv, 1e-12, what="upper edge interp_value")
+    node = ic.model_grid.interp.grid[-1, 20, 100, ic.model_grid.interp.column_index["Teff"]]
+    assert np.isclose(ic.interp_value([m[20], e[100], f[-1]], ["Teff"])[0], node, rtol=1e-13)

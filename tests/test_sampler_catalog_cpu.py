@@ -174,3 +174,24 @@ def test_vectorised_catalog_descriptors_equal_per_model_descriptors():
     assert arr["has_parallax"][3] == 0 and arr["prior_distance"]["hi"][3] == 10000.0
     assert np.isclose(arr["prior_distance"]["hi"][5], 2000 / 0.05)
     assert np.isnan(arr["spec_val"][7, 0])
+
+
+def test_fit_catalog_checkpoint_resume(tmp_path):
+    """A rerun loads finished shards instead of refitting (single process, injected fit)."""
+    import pandas as pd
+    df = pd.DataFrame({"V_mag": np.linspace(8, 12, 9), "V_mag_unc": 0.02}, index=["s%d" % i for i in range(9)])
+    cat = ia.StarCatalog(df, bands=["V"])
+    calls = []
+
+    def fake_fit(catalog, ic, indices, N=1, **kw):
+        calls.append(len(indices))
+        rows = np.zeros((len(indices), 3 * (N + 4) + 3))
+        rows[:, 0] = np.asarray(indices) + 0.5
+        return rows
+
+    a = ia.fit_catalog(cat, ic=None_IC(), fit_fn=fake_fit, checkpoint_dir=str(tmp_path))
+    b = ia.fit_catalog(cat, ic=None_IC(), fit_fn=fake_fit, checkpoint_dir=str(tmp_path))
+    assert calls == [9] and a.equals(b)
+    cat2 = ia.StarCatalog(df.iloc[:7], bands=["V"])          # different catalog -> checkpoint ignored
+    ia.fit_catalog(cat2, ic=None_IC(), fit_fn=fake_fit, checkpoint_dir=str(tmp_path))
+    assert calls == [9, 7]
