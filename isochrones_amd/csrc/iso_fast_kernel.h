@@ -674,6 +674,12 @@ __global__ __launch_bounds__(BLOCK) void k_stretch_half(const FastArgs A, const 
         S.lnp[row] = lnew;
         if (S.accepted) S.accepted[row] += 1;
     }
+    // chain recording: each half-step kernel stores the rows it owns (their value for this step)
+    if (active && S.chain_pos) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) S.chain_pos[row * NP + q] = acc ? y[q] : xk[q];
+    }
+    if (active && S.chain_lnp) S.chain_lnp[row] = acc ? lnew : S.lnp[row];
 }
 
 template <int KIND, int NS>

@@ -1386,7 +1386,9 @@ int iso_ic_create(iso_ctx* ctx, iso_table* model_grid, iso_table* bc_grid, int k
     for (int d = 0; d < 3; ++d) ic->h_axes_model[d] = model_grid->h_axes[d];
     for (int d = 0; d < 4; ++d) ic->h_axes_bc[d] = bc_grid->h_axes[d];
     ic->d_hotq = nullptr;
-    if (path_mode() == PATH_AUTO && model_grid->ax[2].uniform) {
+    // (cell indices travel as 32-bit integers through the cooperative gather)
+    if (path_mode() == PATH_AUTO && model_grid->ax[2].uniform && model_grid->ncells < (int64_t(1) << 31) &&
+        bc_grid->ncells < (int64_t(1) << 31)) {
         // corner-packed copy for the fast kernel: 8 corners x 6 columns per cell (384 B)
         e = pack_corners(ic->d_hot, HOT_COLS, PACK_COLS, 3, model_grid->shape, &ic->d_hotq);
         if (e != hipSuccess) {
@@ -2102,16 +2104,13 @@ int iso_sampler_run(iso_sampler* sp, double* pos, double* lnp, int nsteps, doubl
     S.seed = sp->seed;
     for (int it = 0; it < nsteps; ++it) {
         S.step = sp->step++;
+        S.chain_pos = chain ? chain + (int64_t)it * rows * sp->n_params : nullptr;
+        S.chain_lnp = chain_lnp ? chain_lnp + (int64_t)it * rows : nullptr;
         for (int half = 0; half < 2; ++half) {
             S.half = half;
             if (!launch_stretch(sp->kind, sp->n_stars, sp->n_bands, sp->fast, S, s))
                 return fail(ISO_ERR_INVALID, "iso_sampler_run: no kernel specialisation");
         }
-        if (chain)
-            HIP_TRY(hipMemcpyAsync(chain + (int64_t)it * rows * sp->n_params, pos, sizeof(double) * rows * sp->n_params,
-                                   hipMemcpyDeviceToDevice, s));
-        if (chain_lnp)
-            HIP_TRY(hipMemcpyAsync(chain_lnp + (int64_t)it * rows, lnp, sizeof(double) * rows, hipMemcpyDeviceToDevice, s));
     }
     HIP_TRY(hipGetLastError());
     return ISO_OK;

@@ -105,6 +105,8 @@ struct StretchArgs {
     double a;             // stretch scale
     uint64_t seed;
     uint32_t step;
+    double* chain_pos;    // optional: this step's [n_rows][n_params] slab of the stored chain
+    double* chain_lnp;    // optional: this step's [n_rows] slab
 };
 
 }  // namespace iso
