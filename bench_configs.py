@@ -137,6 +137,18 @@ def cfg4(nwalkers=256, nsteps=5000):
     torch.cuda.synchronize()
     wall = time.perf_counter() - t
     acc = float(fsamp.acceptance_fraction.mean())
+    # sampler-callback forms (what emcee does with lnpost as its log-probability function)
+    one = truth.copy()
+    mod.lnpost(one)
+    t = time.perf_counter()
+    for _ in range(2000):
+        mod.lnpost(one)
+    host_scalar_us = (time.perf_counter() - t) / 2000 * 1e6
+    halfens = np.ascontiguousarray(p0[: nwalkers // 2])
+    t = time.perf_counter()
+    for _ in range(1000):
+        mod.lnpost(halfens)
+    host_vec_us = (time.perf_counter() - t) / 1000 * 1e6
     # CPU side: the same number of lnpost calls one at a time through the C port
     oic = _oracle_ic(ic)
     desc = mod.model_desc()
@@ -148,6 +160,9 @@ def cfg4(nwalkers=256, nsteps=5000):
     calls = nwalkers * nsteps
     return {"config": "cfg4", "metric": "wall-clock of a %d-walker x %d-step ensemble fit, GPU lnpost" % (nwalkers, nsteps),
             "gpu_wall_s": wall, "gpu_wall_s_framework_op_sampler": wall_ops, "lnpost_calls": calls, "us_per_step": wall / nsteps * 1e6, "acceptance": acc,
+            "host_callback_scalar_us": host_scalar_us, "host_callback_half_ensemble_us": host_vec_us,
+            "host_callback_estimated_wall_s": {"one_walker_per_call": host_scalar_us * 1e-6 * nwalkers * nsteps,
+                                               "vectorized_half_ensembles": host_vec_us * 1e-6 * 2 * nsteps},
             "cpu_scalar_call_us": per_call * 1e6, "cpu_estimated_wall_s": per_call * calls,
             "reference_published_estimate_s": [69e-6 * calls, 719e-6 * calls]}
 

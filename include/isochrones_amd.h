@@ -199,6 +199,13 @@ int  iso_model_n_params(const iso_model* m);
 int  iso_lnpost(iso_model* m, const double* pars, int64_t stride_n, int64_t stride_p, int64_t n,
                 double* lnpost_out, double* lnprior_out, double* lnlike_out, void* stream);
 
+/* The same for HOST arrays (pars [n][n_params] row-major): the sampler-callback form — what emcee /
+ * MultiNest do when they call StarModel.lnpost(p) with one parameter vector (starmodel.py:952,966,
+ * 1642-1645).  Parameters and results go through a pinned, device-mapped staging buffer owned by
+ * the model: one launch + one synchronise per call.  Not re-entrant per model. */
+int  iso_lnpost_host(iso_model* m, const double* pars, int64_t n, double* lnpost_out, double* lnprior_out,
+                     double* lnlike_out);
+
 /* mnest_prior: cube[i,p] <- lo_p + (hi_p - lo_p) * cube[i,p], in place (starmodel.py:1637-1640). */
 int  iso_unit_cube(iso_model* m, double* cube, int64_t stride_n, int64_t stride_p, int64_t n, void* stream);
 

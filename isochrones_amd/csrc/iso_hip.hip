@@ -26,6 +26,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <new>
 #include <string>
@@ -1604,6 +1605,8 @@ int iso_model_create(iso_ic* ic, const iso_model_desc* desc, iso_model** out)
     m->d_bcq = nullptr;
     m->d_axes_blob = nullptr;
     m->fast_ok = false;
+    m->h_stage = nullptr;
+    m->stage_rows = 0;
 
     DevModel H;
     fill_dev_model(desc, ic->kind, H);
@@ -1637,6 +1640,7 @@ void iso_model_destroy(iso_model* m)
     if (m->d_bc_hot) (void)hipFree(m->d_bc_hot);
     if (m->d_bcq) (void)hipFree(m->d_bcq);
     if (m->d_axes_blob) (void)hipFree(m->d_axes_blob);
+    if (m->h_stage) (void)hipHostFree(m->h_stage);
     delete m;
 }
 
@@ -1730,6 +1734,45 @@ int iso_lnpost(iso_model* m, const double* pars, int64_t stride_n, int64_t strid
     if (n == 0) return ISO_OK;
     DeviceGuard guard(m->ic->ctx->device);
     return enqueue_lnpost(m, pars, stride_n, stride_p, n, lnpost_out, lnprior_out, lnlike_out, as_stream(stream));
+}
+
+int iso_lnpost_host(iso_model* m, const double* pars, int64_t n, double* lnpost_out, double* lnprior_out,
+                    double* lnlike_out)
+{
+    if (!m || (!pars && n > 0)) return fail(ISO_ERR_INVALID, "iso_lnpost_host: NULL argument");
+    if (n < 0) return fail(ISO_ERR_INVALID, "iso_lnpost_host: n < 0");
+    if (!lnpost_out && !lnprior_out && !lnlike_out) return fail(ISO_ERR_INVALID, "iso_lnpost_host: no output requested");
+    if (n == 0) return ISO_OK;
+    DeviceGuard guard(m->device);
+    const int np_ = m->desc.n_stars + 4;
+    constexpr int64_t CAP = 8192;
+    if (!m->h_stage) {
+        // pinned + mapped: the kernel reads the parameters and writes the results straight through
+        // PCIe — one launch + one synchronise per call, no separate copies
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&m->h_stage), sizeof(double) * CAP * (np_ + 3), hipHostMallocMapped));
+        m->stage_rows = CAP;
+    }
+    double* h_pars = m->h_stage;
+    double* h_post = h_pars + CAP * np_;
+    double* h_prior = h_post + CAP;
+    double* h_like = h_prior + CAP;
+    double *d_pars = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&d_pars), h_pars, 0));
+    double* d_post = d_pars + CAP * np_;
+    double* d_prior = d_post + CAP;
+    double* d_like = d_prior + CAP;
+    for (int64_t done = 0; done < n; done += CAP) {
+        const int64_t c = std::min<int64_t>(CAP, n - done);
+        std::memcpy(h_pars, pars + done * np_, sizeof(double) * c * np_);
+        const int rc = enqueue_lnpost(m, d_pars, np_, 1, c, lnpost_out ? d_post : nullptr, lnprior_out ? d_prior : nullptr,
+                                      lnlike_out ? d_like : nullptr, nullptr);
+        if (rc != ISO_OK) return rc;
+        HIP_TRY(hipStreamSynchronize(nullptr));
+        if (lnpost_out) std::memcpy(lnpost_out + done, h_post, sizeof(double) * c);
+        if (lnprior_out) std::memcpy(lnprior_out + done, h_prior, sizeof(double) * c);
+        if (lnlike_out) std::memcpy(lnlike_out + done, h_like, sizeof(double) * c);
+    }
+    return ISO_OK;
 }
 
 int iso_unit_cube(iso_model* m, double* cube, int64_t stride_n, int64_t stride_p, int64_t n, void* stream)

@@ -166,6 +166,8 @@ struct iso_model {
     iso::Grid4V g4;          // view of d_bc_hot
     bool fast_ok;
     iso::FastArgs fast;      // template filled at create time (pars/outputs set per call)
+    double* h_stage;         // pinned, device-mapped staging for iso_lnpost_host (lazy)
+    int64_t stage_rows;
 };
 
 struct iso_sampler {

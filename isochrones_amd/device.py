@@ -15,11 +15,18 @@ def _torch():
     return torch
 
 
+_GPU_OK = False
+
+
 def require_gpu():
+    global _GPU_OK
     torch = _torch()
+    if _GPU_OK:
+        return torch
     if not torch.cuda.is_available():
         raise _cabi.IsoError("isochrones_amd needs an AMD GPU (HIP device); none is visible and there "
                              "is no CPU fallback")
+    _GPU_OK = True
     return torch
 
 

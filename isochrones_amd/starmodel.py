@@ -249,10 +249,22 @@ class BasicStarModel:
             out = self.evaluate_device(pp, soa=soa and not single, parts=which != 0)
             out = out if which == 0 else out[which]
             return out[0] if single else out
-        arr = np.asarray(p, dtype=float)
+        arr = np.ascontiguousarray(p, dtype=np.float64)
         single = arr.ndim == 1
         a2 = arr[None, :] if single else arr
         device = dev.current_device()
+        if a2.shape[0] <= 65536 and not (soa and not single):
+            # host arrays of sampler-callback size: one C call (pinned, device-mapped staging)
+            if a2.shape[1] != self.n_params:
+                raise ValueError("expected [N, %d]" % self.n_params)
+            n = a2.shape[0]
+            out = np.empty(n)
+            ptrs = [None, None, None]
+            ptrs[which] = out.ctypes.data
+            rc = _cabi.lib().iso_lnpost_host(self.handle(device), a2.ctypes.data, n, *ptrs)
+            if rc:
+                _cabi.check(rc)
+            return float(out[0]) if single else out
         out = self.evaluate_device(dev.to_device_f64(a2, device), soa=soa and not single, parts=which != 0)
         out = (out if which == 0 else out[which]).cpu().numpy()
         return float(out[0]) if single else out
