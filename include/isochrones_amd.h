@@ -224,7 +224,7 @@ int  iso_interp_eep(iso_eep_table* t, const double* x, const double* x0, const d
 /* A catalog = many independent systems observed in the same bands with the same multiplicity
  * (reference: isochrones/catalog.py:19-139 StarCatalog.iter_models; scripts/batch_starfit shards
  * them over processes).  iso_catalog_lnpost evaluates a batch of rows where row i belongs to
- * star star_id[i] (DEVICE int32 array): S stars x W walkers in one launch.  Needs 1-8 bands. */
+ * star star_id[i] (DEVICE int32 array): S stars x W walkers in one launch.  Needs 1-12 bands. */
 int  iso_catalog_create(iso_ic* ic, const iso_model_desc* descs, int64_t n_models, iso_catalog** out);
 void iso_catalog_destroy(iso_catalog* c);
 int  iso_catalog_lnpost(iso_catalog* c, const int32_t* star_id, const double* pars, int64_t stride_n,

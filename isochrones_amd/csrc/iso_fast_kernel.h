@@ -304,9 +304,10 @@ __device__ __forceinline__ double eep_term(const DevModel& M, const DevPrior& or
 // One slot per sample serves as request (header, t0..t3) and then as response (<= 8 values): a
 // slot's request is read only in the iteration that serves it, and its response is written later
 // in that same iteration, so the two may share storage.  Stride 9 doubles: conflict-free b64 access.
-constexpr int REQ_STRIDE = 9;
-constexpr int RSP_STRIDE = 9;
-constexpr int COOP_LDS_DOUBLES = BLOCK * REQ_STRIDE;
+// (13 doubles when more than 8 bands are gathered.)
+constexpr int slot_stride(int nb) { return nb <= 8 ? 9 : 13; }
+constexpr int coop_lds_doubles(int nb) { return BLOCK * slot_stride(nb); }
+constexpr int FAST_MAX_NB = 12;
 
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double x)
@@ -327,8 +328,9 @@ __device__ __forceinline__ double quad_sum(double x)
 
 struct CoopLds {
     double* req;    // this wave's 64 request slots
-    double* rsp;    // this wave's 64 response slots
+    double* rsp;    // this wave's 64 response slots (same storage)
     int lane;
+    int stride;     // doubles per slot (compile-time constant after inlining)
 };
 
 // Model table: every lane may own one request (need, cell, w); returns the 6 interpolated columns
@@ -336,7 +338,7 @@ struct CoopLds {
 __device__ __forceinline__ void coop_star(const FastArgs& A, const CoopLds& L, bool need, uint32_t cell, const W3& w,
                                           double* __restrict__ v)
 {
-    double* mine = L.req + L.lane * REQ_STRIDE;
+    double* mine = L.req + L.lane * L.stride;
     mine[0] = __hiloint2double(need ? 1 : 0, (int)cell);
     mine[1] = w.t0;
     mine[2] = w.t1;
@@ -353,7 +355,7 @@ __device__ __forceinline__ void coop_star(const FastArgs& A, const CoopLds& L, b
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int src = 16 * (2 * half + k) + grp;
-            const double* rq = L.req + src * REQ_STRIDE;
+            const double* rq = L.req + src * L.stride;
             const double hdr = rq[0];
             const double t0 = rq[1], t1 = rq[2], t2 = rq[3];
             const bool nd = __double2hiint(hdr) != 0;
@@ -374,7 +376,7 @@ __device__ __forceinline__ void coop_star(const FastArgs& A, const CoopLds& L, b
                 part[2 * q] = quad_sum(u[k][q].x * wlo[k] + u[k][3 + q].x * whi[k]);
                 part[2 * q + 1] = quad_sum(u[k][q].y * wlo[k] + u[k][3 + q].y * whi[k]);
             }
-            double* rs = L.rsp + src * RSP_STRIDE;
+            double* rs = L.rsp + src * L.stride;
             // spread the six stores over the quad: lane j writes values j and j+4
             const double a0 = (j == 0) ? part[0] : (j == 1) ? part[1] : (j == 2) ? part[2] : part[3];
             rs[j] = a0;
@@ -382,7 +384,7 @@ __device__ __forceinline__ void coop_star(const FastArgs& A, const CoopLds& L, b
         }
     }
     __builtin_amdgcn_wave_barrier();
-    const double* rs = L.rsp + L.lane * RSP_STRIDE;
+    const double* rs = L.rsp + L.lane * L.stride;
 #pragma unroll
     for (int q = 0; q < 6; ++q) v[q] = need ? rs[q] : f_nan();
     __builtin_amdgcn_wave_barrier();
@@ -393,7 +395,7 @@ template <int NB>
 __device__ __forceinline__ void coop_bc(const FastArgs& A, const CoopLds& L, bool need, uint32_t cell, const W4& w,
                                         double* __restrict__ v)
 {
-    double* mine = L.req + L.lane * REQ_STRIDE;
+    double* mine = L.req + L.lane * L.stride;
     mine[0] = __hiloint2double(need ? 1 : 0, (int)cell);
     mine[1] = w.t0;
     mine[2] = w.t1;
@@ -412,7 +414,7 @@ __device__ __forceinline__ void coop_bc(const FastArgs& A, const CoopLds& L, boo
 #pragma unroll
         for (int k = 0; k < BATCH; ++k) {
             const int src = 16 * (r0 + k) + grp;
-            const double* rq = L.req + src * REQ_STRIDE;
+            const double* rq = L.req + src * L.stride;
             const double hdr = rq[0];
             const double t0 = rq[1], t1 = rq[2], t2 = rq[3], t3 = rq[4];
             const bool nd = __double2hiint(hdr) != 0;
@@ -429,7 +431,7 @@ __device__ __forceinline__ void coop_bc(const FastArgs& A, const CoopLds& L, boo
 #pragma unroll
         for (int k = 0; k < BATCH; ++k) {
             const int src = 16 * (r0 + k) + grp;
-            double* rs = L.rsp + src * RSP_STRIDE;
+            double* rs = L.rsp + src * L.stride;
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
                 const double part = quad_sum(x[k][b].x * wa[k][0] + x[k][b].y * wb[k][0] +
@@ -439,7 +441,7 @@ __device__ __forceinline__ void coop_bc(const FastArgs& A, const CoopLds& L, boo
         }
     }
     __builtin_amdgcn_wave_barrier();
-    const double* rs = L.rsp + L.lane * RSP_STRIDE;
+    const double* rs = L.rsp + L.lane * L.stride;
 #pragma unroll
     for (int b = 0; b < NB; ++b) v[b] = need ? rs[b] : f_nan();
     __builtin_amdgcn_wave_barrier();
@@ -566,13 +568,16 @@ __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* l
 }
 
 // LDS layout of the fast kernels: [axes blob, rounded to an even count][request slots][response slots]
+template <int NB>
 __device__ __forceinline__ CoopLds coop_lds(double* lds, int axes_len)
 {
+    constexpr int REQ_STRIDE = slot_stride(NB);
     const int base = (axes_len + 1) & ~1;
     const int wave = threadIdx.x >> 6;
     CoopLds L;
     L.req = lds + base + wave * 64 * REQ_STRIDE;
     L.rsp = L.req;
+    L.stride = REQ_STRIDE;
     L.lane = threadIdx.x & 63;
     return L;
 }
@@ -587,7 +592,7 @@ __global__ __launch_bounds__(BLOCK, fast_min_waves(NS, NB)) void k_lnpost_fast(c
     extern __shared__ double lds[];
     for (int j = threadIdx.x; j < A.axes_len; j += BLOCK) lds[j] = A.axes_blob[j];
     __syncthreads();
-    const CoopLds L = coop_lds(lds, A.axes_len);
+    const CoopLds L = coop_lds<NB>(lds, A.axes_len);
     const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     const bool active = i < A.n;
     const int64_t ii = active ? i : (A.n - 1);         // inactive lanes shadow the last sample
@@ -638,7 +643,7 @@ __global__ __launch_bounds__(BLOCK) void k_stretch_half(const FastArgs A, const 
     extern __shared__ double lds[];
     for (int j = threadIdx.x; j < A.axes_len; j += BLOCK) lds[j] = A.axes_blob[j];
     __syncthreads();
-    const CoopLds L = coop_lds(lds, A.axes_len);
+    const CoopLds L = coop_lds<NB>(lds, A.axes_len);
     const int64_t t0 = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     const bool active = t0 < S.n_active;
     const int64_t t = active ? t0 : (S.n_active - 1);
@@ -686,16 +691,20 @@ template <int KIND, int NS>
 inline bool launch_stretch_nb(int nb, const FastArgs& A, const StretchArgs& S, hipStream_t s)
 {
     const dim3 g((unsigned)((S.n_active + BLOCK - 1) / BLOCK)), b(BLOCK);
-    const size_t sh = (size_t)(((A.axes_len + 1) & ~1) + COOP_LDS_DOUBLES) * sizeof(double);
+    auto sh = [&](int n) { return (size_t)(((A.axes_len + 1) & ~1) + coop_lds_doubles(n)) * sizeof(double); };
     switch (nb) {
-    case 1: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 1>), g, b, sh, s, A, S); return true;
-    case 2: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 2>), g, b, sh, s, A, S); return true;
-    case 3: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 3>), g, b, sh, s, A, S); return true;
-    case 4: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 4>), g, b, sh, s, A, S); return true;
-    case 5: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 5>), g, b, sh, s, A, S); return true;
-    case 6: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 6>), g, b, sh, s, A, S); return true;
-    case 7: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 7>), g, b, sh, s, A, S); return true;
-    case 8: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 8>), g, b, sh, s, A, S); return true;
+    case 1: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 1>), g, b, sh(1), s, A, S); return true;
+    case 2: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 2>), g, b, sh(2), s, A, S); return true;
+    case 3: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 3>), g, b, sh(3), s, A, S); return true;
+    case 4: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 4>), g, b, sh(4), s, A, S); return true;
+    case 5: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 5>), g, b, sh(5), s, A, S); return true;
+    case 6: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 6>), g, b, sh(6), s, A, S); return true;
+    case 7: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 7>), g, b, sh(7), s, A, S); return true;
+    case 8: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 8>), g, b, sh(8), s, A, S); return true;
+    case 9: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 9>), g, b, sh(9), s, A, S); return true;
+    case 10: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 10>), g, b, sh(10), s, A, S); return true;
+    case 11: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 11>), g, b, sh(11), s, A, S); return true;
+    case 12: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 12>), g, b, sh(12), s, A, S); return true;
     default: return false;
     }
 }
@@ -704,16 +713,20 @@ template <int KIND, int NS, bool PACKED, bool MULTI>
 inline bool launch_nb(int nb, const FastArgs& A, hipStream_t s)
 {
     const dim3 g((unsigned)((A.n + BLOCK - 1) / BLOCK)), b(BLOCK);
-    const size_t sh = (size_t)(((A.axes_len + 1) & ~1) + (PACKED ? COOP_LDS_DOUBLES : 0)) * sizeof(double);
+    auto sh = [&](int n) { return (size_t)(((A.axes_len + 1) & ~1) + (PACKED ? coop_lds_doubles(n) : 0)) * sizeof(double); };
     switch (nb) {
-    case 1: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 1, PACKED, MULTI>), g, b, sh, s, A); return true;
-    case 2: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 2, PACKED, MULTI>), g, b, sh, s, A); return true;
-    case 3: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 3, PACKED, MULTI>), g, b, sh, s, A); return true;
-    case 4: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 4, PACKED, MULTI>), g, b, sh, s, A); return true;
-    case 5: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 5, PACKED, MULTI>), g, b, sh, s, A); return true;
-    case 6: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 6, PACKED, MULTI>), g, b, sh, s, A); return true;
-    case 7: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 7, PACKED, MULTI>), g, b, sh, s, A); return true;
-    case 8: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 8, PACKED, MULTI>), g, b, sh, s, A); return true;
+    case 1: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 1, PACKED, MULTI>), g, b, sh(1), s, A); return true;
+    case 2: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 2, PACKED, MULTI>), g, b, sh(2), s, A); return true;
+    case 3: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 3, PACKED, MULTI>), g, b, sh(3), s, A); return true;
+    case 4: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 4, PACKED, MULTI>), g, b, sh(4), s, A); return true;
+    case 5: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 5, PACKED, MULTI>), g, b, sh(5), s, A); return true;
+    case 6: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 6, PACKED, MULTI>), g, b, sh(6), s, A); return true;
+    case 7: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 7, PACKED, MULTI>), g, b, sh(7), s, A); return true;
+    case 8: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 8, PACKED, MULTI>), g, b, sh(8), s, A); return true;
+    case 9: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 9, PACKED, MULTI>), g, b, sh(9), s, A); return true;
+    case 10: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 10, PACKED, MULTI>), g, b, sh(10), s, A); return true;
+    case 11: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 11, PACKED, MULTI>), g, b, sh(11), s, A); return true;
+    case 12: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 12, PACKED, MULTI>), g, b, sh(12), s, A); return true;
     default: return false;
     }
 }

@@ -1530,7 +1530,7 @@ hipError_t pack_bands(const iso_ic* ic, const int32_t* bc_cols, int nb, double**
 
 bool fast_eligible(const iso_ic* ic, const iso_model_desc* desc)
 {
-    return path_mode() != PATH_GENERIC && desc->n_bands >= 1 && desc->n_bands <= 8 && !desc->has_numax &&
+    return path_mode() != PATH_GENERIC && desc->n_bands >= 1 && desc->n_bands <= 12 && !desc->has_numax &&
            ic->model->ax[2].uniform;
 }
 
@@ -1876,7 +1876,7 @@ int iso_catalog_create(iso_ic* ic, const iso_model_desc* descs, int64_t n_models
         if (descs[k].has_numax) return fail(ISO_ERR_INVALID, "iso_catalog_create: asteroseismic terms are not batched");
     }
     if (!fast_eligible(ic, &d0) || !ic->d_hotq)
-        return fail(ISO_ERR_INVALID, "iso_catalog_create: needs 1-8 bands, a uniform EEP axis and the corner-packed "
+        return fail(ISO_ERR_INVALID, "iso_catalog_create: needs 1-12 bands, a uniform EEP axis and the corner-packed "
                                      "tables (ISOCHRONES_AMD_PATH=auto)");
     DeviceGuard guard(ic->device);
     iso_catalog* c = new (std::nothrow) iso_catalog();
@@ -2107,7 +2107,7 @@ int iso_sampler_create_model(iso_model* m, int nwalkers, double a, uint64_t seed
     if (nwalkers < 2 || (nwalkers & 1) || !(a > 1.0)) return fail(ISO_ERR_INVALID, "iso_sampler_create_model: need an even walker count and a > 1");
     if (!m->fast_ok || !m->fast.hotq || !m->fast.bcq)
         return fail(ISO_ERR_INVALID, "iso_sampler_create_model: the model is not on the corner-packed fast path "
-                                     "(needs 1-8 bands, uniform EEP axis, ISOCHRONES_AMD_PATH=auto)");
+                                     "(needs 1-12 bands, uniform EEP axis, ISOCHRONES_AMD_PATH=auto)");
     iso_sampler* sp = new (std::nothrow) iso_sampler();
     if (!sp) return fail(ISO_ERR_NOMEM, "iso_sampler_create_model: out of host memory");
     sampler_common(sp, m->device, m->ic->kind, m->desc.n_stars, m->desc.n_bands, 1, m->fast, 0, nwalkers, a, seed);
