@@ -305,6 +305,32 @@ class ModelGridInterpolator:
         out["requested_age"] = age
         return out
 
+    def generate_binary(self, mass_A, mass_B, age, feh, bands=None, **kwargs):
+        """Two coeval stars: per-component columns suffixed _0 / _1 plus the combined magnitudes
+        (reference: models.py:633-661)."""
+        import pandas as pd
+        bands = self.bands if bands is None else list(bands)
+        mass_A, mass_B = np.broadcast_arrays(mass_A, mass_B)
+        a = self.generate(mass_A, age, feh, bands=bands, **kwargs)
+        b = self.generate(mass_B, age, feh, bands=bands, **kwargs)
+        out = pd.concat([a.rename(columns={c: c + "_0" for c in a.columns}),
+                         b.rename(columns={c: c + "_1" for c in b.columns})], axis=1)
+        for band in bands:
+            m0 = a["{}_mag".format(band)].values
+            m1 = np.where(np.isnan(b["{}_mag".format(band)].values), np.inf, b["{}_mag".format(band)].values)
+            out["{}_mag".format(band)] = -2.5 * np.log10(10 ** (-0.4 * m0) + 10 ** (-0.4 * m1))
+        return out
+
+    def isochrone(self, age, feh=0.0, eep_range=None, distance=10.0, AV=0.0, dropna=True):
+        """All columns + magnitudes along one isochrone (reference: models.py:484-493)."""
+        if self.eep_replaces != "mass":
+            raise NotImplementedError("isochrone() needs the isochrone parametrisation")
+        if eep_range is None:
+            eep_range = self.model_grid.get_limits("eep")
+        eeps = np.arange(*eep_range, dtype=float)
+        df = self(eeps, age, feh, distance=distance, AV=AV)
+        return df.dropna() if dropna else df
+
     def model_value(self, mass, age, feh, props):
         props = [props] if isinstance(props, str) else list(props)
         eep = self.get_eep(mass, age, feh)
