@@ -37,9 +37,11 @@ def _newer(target, deps):
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
+    me = os.path.abspath(__file__)
+    if not force and not verbose and not _newer(OUT, sources() + HEADERS + [me]):
+        return OUT                       # library newer than every source: nothing to do
     os.makedirs(OBJDIR, exist_ok=True)
     cc = hipcc()
-    me = os.path.abspath(__file__)
     jobs = []
     objs = []
     for src in sources():
