@@ -10,7 +10,8 @@ from .starmodel import (BasicStarModel, StarModel, TreeStarModel, SingleStarMode
                         TripleStarModel)
 from .observation import ObservationTree, Observation, Source
 from .sampler import EnsembleSampler
-from .catalog import StarCatalog, CatalogPosterior, fit_catalog, synthetic_catalog, shard_of, shard_indices
+from .catalog import (StarCatalog, CatalogPosterior, fit_catalog, synthetic_catalog, shard_of, shard_indices,
+                      broadcast_interpolator)
 from . import priors, grids, ingest
 
 __version__ = "0.1.0"

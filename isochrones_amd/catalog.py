@@ -474,3 +474,54 @@ def synthetic_catalog(ic, n_stars, bands=None, seed=0, mag_unc=0.02, with_parall
     df = pd.DataFrame(cols, index=["star%05d" % i for i in range(n_stars)])
     truth = pd.DataFrame(p.T, columns=list(ic.param_names), index=df.index)
     return StarCatalog(df, bands=bands, props=props), truth
+
+
+def broadcast_interpolator(ic=None, src=0):
+    """Give every rank the interpolator that only rank ``src`` has loaded (one broadcast
+    of the tables at start-up instead of P reads of the table files).  Metadata travels as a small
+    pickled object, the dense float64 tables as tensors (RCCL over xGMI with the ``nccl`` backend —
+    the packed model table is ~0.7 GB —, host memory with ``gloo``).  Returns a
+    ModelGridInterpolator on every rank; without an initialised process group it returns ``ic``."""
+    import torch
+    import torch.distributed as dist
+    from .interp import DFInterpolator
+    from .models import (BolometricCorrectionGrid, EvolutionTrackGrid, EvolutionTrackInterpolator, IsochroneGrid,
+                         IsochroneInterpolator)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return ic
+    rank = dist.get_rank()
+    use_gpu = dist.get_backend() == "nccl"
+    devt = torch.device("cuda", torch.cuda.current_device()) if use_gpu else torch.device("cpu")
+    meta = [None]
+    if rank == src:
+        m, b = ic.model_grid.interp, ic.bc_grid.interp
+        meta[0] = dict(kind=ic.kind, bands=list(ic.bands), eep_bounds=tuple(ic.eep_bounds),
+                       model=dict(shape=m.grid.shape, columns=list(m.columns), names=list(m.index_names),
+                                  limits=dict(ic.model_grid._limits)),
+                       bc=dict(shape=b.grid.shape, columns=list(b.columns), names=list(b.index_names),
+                               bands=list(ic.bc_grid.bands or b.columns)))
+    dist.broadcast_object_list(meta, src=src)
+    meta = meta[0]
+
+    def bcast(arr, shape):
+        t = (torch.as_tensor(np.ascontiguousarray(arr, dtype=np.float64), device=devt) if rank == src
+             else torch.empty(shape, dtype=torch.float64, device=devt))
+        dist.broadcast(t, src=src)
+        return t.cpu().numpy()
+
+    tables = {}
+    for key in ("model", "bc"):
+        shape = tuple(meta[key]["shape"])
+        srcobj = (ic.model_grid.interp if key == "model" else ic.bc_grid.interp) if rank == src else None
+        grid = bcast(srcobj.grid if srcobj is not None else None, shape)
+        axes = [bcast(srcobj.index_columns[d] if srcobj is not None else None, (shape[d],)) for d in range(len(shape) - 1)]
+        tables[key] = (grid, axes)
+    if rank == src:
+        return ic
+    mg_cls, ic_cls = ((EvolutionTrackGrid, EvolutionTrackInterpolator) if meta["kind"] == _cabi.KIND_TRACK
+                      else (IsochroneGrid, IsochroneInterpolator))
+    mg = mg_cls(DFInterpolator.from_arrays(tables["model"][0], tables["model"][1], meta["model"]["columns"],
+                                           meta["model"]["names"]), limits=meta["model"]["limits"])
+    bcg = BolometricCorrectionGrid(DFInterpolator.from_arrays(tables["bc"][0], tables["bc"][1], meta["bc"]["columns"],
+                                                              meta["bc"]["names"]), bands=meta["bc"]["bands"])
+    return ic_cls(mg, bcg, bands=meta["bands"], eep_bounds=meta["eep_bounds"])

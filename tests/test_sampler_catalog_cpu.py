@@ -195,3 +195,34 @@ def test_fit_catalog_checkpoint_resume(tmp_path):
     cat2 = ia.StarCatalog(df.iloc[:7], bands=["V"])          # different catalog -> checkpoint ignored
     ia.fit_catalog(cat2, ic=None_IC(), fit_fn=fake_fit, checkpoint_dir=str(tmp_path))
     assert calls == [9, 7]
+
+
+def _bcast_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    import isochrones_amd as ia_
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ic = None
+    if rank == 0:           # only rank 0 "loads" the tables
+        ic = ia_.synthetic_isochrone(bands=("J", "K"), ages=[9.0, 9.5, 10.0], fehs=[-0.5, 0.0, 0.5],
+                                     eeps=np.arange(300., 340.), eep_bounds=(300, 339),
+                                     limits=dict(age=(9.0, 10.0), feh=(-0.5, 0.5)))
+    got = ia_.broadcast_interpolator(ic, src=0)
+    np.savez(os.path.join(out_dir, "ic%d.npz" % rank), grid=got.model_grid.interp.grid, bc=got.bc_grid.interp.grid,
+             ax0=got.model_grid.interp.index_columns[0], bcax3=got.bc_grid.interp.index_columns[3],
+             cols=np.array(got.model_grid.interp.columns), bands=np.array(got.bands),
+             lim=np.array(got.model_grid.get_limits("age")), eb=np.array(got.eep_bounds), kind=got.kind)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_broadcast_interpolator_world2_gloo(tmp_path):
+    """the tables loaded on rank 0 reach every rank through one broadcast."""
+    import torch.multiprocessing as mp
+    mp.spawn(_bcast_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    a, b = np.load(tmp_path / "ic0.npz"), np.load(tmp_path / "ic1.npz")
+    for k in a.files:
+        assert np.array_equal(a[k], b[k], equal_nan=True) if a[k].dtype.kind == "f" else np.array_equal(a[k], b[k]), k
+    assert b["grid"].shape == (3, 3, 40, 16) and list(b["bands"]) == ["J", "K"] and int(b["kind"]) == 1
