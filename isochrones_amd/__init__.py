@@ -7,7 +7,7 @@ from .interp import DFInterpolator
 from .models import (ModelGridInterpolator, EvolutionTrackInterpolator, IsochroneInterpolator,
                      synthetic_track, synthetic_isochrone, get_ichrone)
 from .starmodel import (BasicStarModel, StarModel, TreeStarModel, SingleStarModel, BinaryStarModel,
-                        TripleStarModel)
+                        TripleStarModel, IsoTrackModel)
 from .observation import ObservationTree, Observation, Source
 from .sampler import EnsembleSampler
 from .catalog import (StarCatalog, CatalogPosterior, fit_catalog, synthetic_catalog, shard_of, shard_indices,

@@ -16,6 +16,7 @@ from __future__ import annotations
 
 import ctypes as C
 import logging
+import math
 
 import numpy as np
 
@@ -639,3 +640,70 @@ def StarModel(ic, obs=None, **kwargs):
     if obs is not None:
         return TreeStarModel(ic, obs=obs, **kwargs)
     return BasicStarModel(ic, **kwargs)
+
+
+class IsoTrackModel:
+    """The reference's experimental model that asks one star to agree with *both* grids
+    (isochrones/starmodel.py:2010-2104): parameters (eep, mass, age, feh, distance, AV); the
+    likelihood is the sum of the isochrone-grid likelihood at (eep, age, feh, d, AV) and the
+    track-grid likelihood at (mass, eep, feh, d, AV), the parallax term counted once; the prior is
+    the track model's prior plus the age prior.  Composed on the device from two fused-kernel
+    evaluations (no new kernel)."""
+
+    param_names = ("eep", "mass", "age", "feh", "distance", "AV")
+
+    def __init__(self, iso, track, **kwargs):
+        self.iso, self.track = iso, track
+        no_plx = {k: v for k, v in kwargs.items() if k != "parallax"}
+        self._track_model = BasicStarModel(track, **kwargs)        # owns the priors and the parallax term
+        self._iso_model = BasicStarModel(iso, **no_plx)
+        self._priors = self._track_model._priors
+        self.kwargs = self._track_model.kwargs
+
+    ic = property(lambda self: self.track)
+    n_params = 6
+
+    def bounds(self, prop):
+        return self._track_model.bounds(prop)
+
+    def _split(self, p):
+        import torch
+        iso_p = torch.stack([p[:, 0], p[:, 2], p[:, 3], p[:, 4], p[:, 5]], dim=1).contiguous()
+        trk_p = torch.stack([p[:, 1], p[:, 0], p[:, 3], p[:, 4], p[:, 5]], dim=1).contiguous()
+        return iso_p, trk_p
+
+    def evaluate_device(self, p):
+        """p: CUDA float64 [N, 6] -> (lnpost, lnprior, lnlike) CUDA tensors."""
+        import torch
+        iso_p, trk_p = self._split(p)
+        _, t_prior, t_like = self._track_model.evaluate_device(trk_p, parts=True)
+        _, _, i_like = self._iso_model.evaluate_device(iso_p, parts=True)
+        age = p[:, 2]
+        ap = self._priors["age"]
+        lo, hi = ap.bounds
+        ln_age = math.log(math.log(10.0) / (10.0 ** hi - 10.0 ** lo)) + age * math.log(10.0)
+        ln_age = torch.where((age < lo) | (age > hi), torch.full_like(age, -float("inf")), ln_age)
+        lnprior = t_prior + ln_age
+        lnlike = i_like + t_like
+        lnpost = torch.where(torch.isfinite(lnprior), lnprior + lnlike, torch.full_like(lnprior, -float("inf")))
+        return lnpost, lnprior, lnlike
+
+    def _evaluate(self, p, which):
+        if dev.is_tensor(p) and p.is_cuda:
+            single = p.dim() == 1
+            out = self.evaluate_device(p.double()[None, :] if single else p.double())[which]
+            return out[0] if single else out
+        arr = np.asarray(p, dtype=float)
+        single = arr.ndim == 1
+        out = self.evaluate_device(dev.to_device_f64(arr[None, :] if single else arr, dev.current_device()))[which]
+        out = out.cpu().numpy()
+        return float(out[0]) if single else out
+
+    def lnpost(self, p):
+        return self._evaluate(p, 0)
+
+    def lnprior(self, p):
+        return self._evaluate(p, 1)
+
+    def lnlike(self, p):
+        return self._evaluate(p, 2)

@@ -372,7 +372,48 @@ def run_tree_cases():
             name, n, len(names), np.isfinite(lnpost).sum(), np.isneginf(lnpost).sum(), np.isnan(lnpost).sum(), labels))
 
 
+def run_isotrack_case():
+    """IsoTrackModel of the reference (starmodel.py:2010-2104) on a small isochrone table and a
+    small track table that share their EEP range."""
+    sm = rh.ref("starmodel")
+    rng = np.random.default_rng(99)
+    trk, bc = small_track(), small_bc()
+    iso = G.synthetic_iso_grid(np.array([7.5, 8.0, 8.5, 9.0, 9.5, 9.75, 10.0, 10.25]), np.array([-1.0, -0.5, 0.0, 0.5]),
+                               np.arange(420.0, 468.0))
+    lim_t, lim_i = limits_of("track", trk[1]), limits_of("iso", iso[1])
+    eb = (420.0, 467.0)
+    ic_t = rh.make_ref_ic("track", trk, bc, lim_t, eb)
+    ic_i = rh.make_ref_ic("iso", iso, bc, lim_i, eb)
+    obs = dict(Teff=(5770, 100), logg=(4.5, 0.1), V=(10.0, 0.05), J=(9.2, 0.03), parallax=(10.0, 0.1))
+    mod = sm.IsoTrackModel(ic_i, ic_t, **obs)
+    n = 600
+    pars = np.column_stack([rng.uniform(418, 469, n), rng.uniform(0.28, 8.2, n), rng.uniform(7.4, 8.7, n),
+                            rng.uniform(-1.05, 0.55, n), rng.uniform(20, 210, n), rng.uniform(-0.02, 1.02, n)])
+    ball = np.array([440.0, 1.0, 8.2, -0.1, 100.0, 0.2]) + np.array([5, 0.05, 0.1, 0.1, 5, 0.05]) * rng.standard_normal((300, 6))
+    pars = np.vstack([pars, ball])
+    pars[0, 2] = np.nan
+    n = pars.shape[0]
+    lnprior, lnlike, lnpost = np.empty(n), np.empty(n), np.empty(n)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        with np.errstate(all="ignore"):
+            for i in range(n):
+                lnprior[i] = mod.lnprior(pars[i])
+                lnlike[i] = mod.lnlike(pars[i])
+                lnpost[i] = mod.lnpost(pars[i])
+    meta = dict(obs={k: list(map(float, v)) for k, v in obs.items()}, limits_track={k: list(map(float, v)) for k, v in lim_t.items()},
+                limits_iso={k: list(map(float, v)) for k, v in lim_i.items()}, eep_bounds=list(eb), bands=list(BANDS),
+                iso_columns=list(iso[2]))
+    np.savez_compressed(os.path.join(OUT, "isotrack.npz"), meta=json.dumps(meta), pars=pars, lnprior=lnprior, lnlike=lnlike,
+                        lnpost=lnpost, iso_grid=iso[0], iso_ax0=iso[1][0], iso_ax1=iso[1][1], iso_ax2=iso[1][2])
+    print("isotrack: n=%d finite=%d -inf=%d nan=%d" % (n, np.isfinite(lnpost).sum(), np.isneginf(lnpost).sum(),
+                                                       np.isnan(lnpost).sum()))
+
+
 def main():
+    if "--only-isotrack" in sys.argv:
+        run_isotrack_case()
+        return
     if "--only-tree" in sys.argv:
         run_tree_cases()
         return
@@ -402,6 +443,7 @@ def main():
     run_model_case("iso_triple_phot6", "iso", 3, "phot6_plx", iso, bc, rng, 250, 250)
     run_eep_case()
     run_tree_cases()
+    run_isotrack_case()
 
 
 if __name__ == "__main__":

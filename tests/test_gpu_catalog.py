@@ -217,3 +217,17 @@ def test_tree_model_random_batch_vs_oracle_and_basic_model():
     a, b = tmod.lnpost(p6), basic.lnpost(p6)
     fin = np.isfinite(b)
     assert fin.sum() > 1000 and np.allclose(a[fin], b[fin], rtol=1e-9, atol=1e-8)
+
+
+def test_isotrack_model_vs_reference_golden():
+    from tests.test_tree_cpu import _isotrack_objects
+    import torch
+    g, iso, track, obs = _isotrack_objects()
+    mod = ia.IsoTrackModel(iso, track, **obs)
+    p = g["pars"]
+    fx.assert_close(mod.lnprior(p), g["lnprior"], RTOL, atol=ATOL, what="lnprior")
+    fx.assert_close(mod.lnlike(p), g["lnlike"], RTOL, atol=1e-9, what="lnlike")
+    fx.assert_close(mod.lnpost(p), g["lnpost"], RTOL, atol=1e-9, what="lnpost")
+    k = int(np.flatnonzero(np.isfinite(g["lnpost"]))[0])
+    assert np.isclose(mod.lnpost(p[k]), g["lnpost"][k], rtol=RTOL)
+    assert mod.lnpost(torch.as_tensor(p, device="cuda")).is_cuda

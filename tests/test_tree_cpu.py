@@ -100,3 +100,42 @@ def test_tree_from_df_and_errors():
     prog = t.program(["J", "K"])
     assert prog["limits"][0]["hi"] == np.inf and len(prog["terms"]) == 3          # the AO reference source adds no term
     assert [x["mask"] for x in prog["terms"]] == [2, 3, 3] and prog["terms"][0]["ref_mask"] == 1
+
+
+def _isotrack_objects():
+    from isochrones_amd.interp import DFInterpolator
+    from isochrones_amd.models import BolometricCorrectionGrid, IsochroneGrid, IsochroneInterpolator
+    g = fx.load("isotrack")
+    meta = g["meta"]
+    track = fx.make_ic(dict(kind="track", limits=meta["limits_track"], eep_bounds=meta["eep_bounds"]))
+    (_, _, _), (bg, bax, bands) = fx.table_parts("iso")
+    iso = IsochroneInterpolator(
+        IsochroneGrid(DFInterpolator.from_arrays(g["iso_grid"], [g["iso_ax0"], g["iso_ax1"], g["iso_ax2"]], meta["iso_columns"]),
+                      limits={k: tuple(v) for k, v in meta["limits_iso"].items()}),
+        BolometricCorrectionGrid(DFInterpolator.from_arrays(bg, bax, bands), bands=bands), bands=bands,
+        eep_bounds=meta["eep_bounds"])
+    obs = {k: tuple(v) for k, v in meta["obs"].items()}
+    return g, iso, track, obs
+
+
+def test_isotrack_oracle_composition_vs_reference():
+    """IsoTrackModel (starmodel.py:2010-2104) = track prior + age prior; iso likelihood + track
+    likelihood with the parallax term once — composed here from the oracle's two evaluations."""
+    import math
+    g, iso, track, obs = _isotrack_objects()
+    mod = ia.IsoTrackModel(iso, track, **obs)
+    p = g["pars"]
+    iso_p = np.column_stack([p[:, 0], p[:, 2], p[:, 3], p[:, 4], p[:, 5]])
+    trk_p = np.column_stack([p[:, 1], p[:, 0], p[:, 3], p[:, 4], p[:, 5]])
+    t = fx.make_oracle_ic(track).lnpost(mod._track_model.model_desc(), trk_p.T.copy())
+    i = fx.make_oracle_ic(iso).lnpost(mod._iso_model.model_desc(), iso_p.T.copy())
+    lo, hi = mod._priors["age"].bounds
+    age = p[:, 2]
+    with np.errstate(all="ignore"):
+        ln_age = np.where((age < lo) | (age > hi), -np.inf, math.log(math.log(10) / (10 ** hi - 10 ** lo)) + age * math.log(10))
+        prior = t[1] + ln_age
+        like = i[2] + t[2]
+        post = np.where(np.isfinite(prior), prior + like, -np.inf)
+    fx.assert_close(prior, g["lnprior"], 1e-11, atol=1e-12, what="lnprior")
+    fx.assert_close(like, g["lnlike"], 1e-11, atol=1e-11, what="lnlike")
+    fx.assert_close(post, g["lnpost"], 1e-11, atol=1e-11, what="lnpost")
