@@ -392,6 +392,13 @@ class BasicStarModel:
         return self._samples
 
 
+    @property
+    def derived_samples(self):
+        """Reference name for the table of derived quantities; here ``samples`` already carries the
+        sampled parameters and, for a single star, every model column and magnitude."""
+        return self.samples
+
+
 class SingleStarModel(BasicStarModel):
     def __init__(self, *args, **kwargs):
         kwargs["N"] = 1

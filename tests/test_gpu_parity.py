@@ -390,3 +390,35 @@ def test_isochrone_and_generate_binary():
     df = trk.generate_binary([1.0, 1.05], [0.8, 0.9], 8.0, 0.0, distance=50.0)
     tot = -2.5 * np.log10(10 ** (-0.4 * df["G_mag_0"]) + 10 ** (-0.4 * df["G_mag_1"]))
     assert np.allclose(df["G_mag"], tot) and np.all(df["G_mag"] < df["G_mag_0"])
+
+
+@pytest.mark.parametrize("kind,n_stars", [("track", 1), ("iso", 2), ("iso", 3)])
+def test_special_value_fuzz_vs_oracle(kind, n_stars, kernel_path):
+    """Every parameter slot takes NaN, +-inf, 0, -0, huge, tiny, negative and exact-node values (in
+    random combinations); the kernels must reproduce the oracle's value / NaN / -inf for each."""
+    rng = np.random.default_rng(77 + n_stars)
+    ic, mod, lo, hi = _random_model(kind, n_stars, ("G", "BP"), rng)
+    n, D = 40_000, lo.size
+    pars = rng.uniform(lo, hi, size=(n, D))
+    if n_stars > 1:
+        pars[:, :n_stars] = -np.sort(-pars[:, :n_stars], axis=1)
+    specials = np.array([np.nan, np.inf, -np.inf, 0.0, -0.0, 1e300, -1e300, 5e-324, 1e-300, -1.0, 1.0])
+    hit = rng.random((n, D)) < 0.08
+    pars[hit] = rng.choice(specials, size=int(hit.sum()))
+    ax = ic.model_grid.interp.index_columns
+    node_rows = rng.choice(n, 2000, replace=False)               # exact table nodes
+    if kind == "track":
+        pars[node_rows, 0] = rng.choice(ax[1], 2000)
+        pars[node_rows, 1] = rng.choice(ax[2], 2000)
+        pars[node_rows, 2] = rng.choice(ax[0], 2000)
+    else:
+        pars[node_rows, 0] = rng.choice(ax[2], 2000)
+        pars[node_rows, n_stars] = rng.choice(ax[0], 2000)
+        pars[node_rows, n_stars + 1] = rng.choice(ax[1], 2000)
+    oic = fx.make_oracle_ic(ic)
+    with np.errstate(all="ignore"):
+        want = oic.lnpost(mod.model_desc(), pars.T.copy(), nthreads=8)
+    fx.assert_close(mod.lnpost(pars), want[0], RTOL, atol=ATOL, what="lnpost")
+    fx.assert_close(mod.lnprior(pars), want[1], RTOL, atol=ATOL, what="lnprior")
+    d_ok = pars[:, n_stars + 2] > 0          # lnlike with distance <= 0 is undefined in the reference
+    fx.assert_close(mod.lnlike(pars)[d_ok], want[2][d_ok], RTOL, atol=ATOL, what="lnlike")
