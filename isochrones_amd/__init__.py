@@ -9,7 +9,8 @@ from .models import (ModelGridInterpolator, EvolutionTrackInterpolator, Isochron
 from .starmodel import (BasicStarModel, StarModel, TreeStarModel, SingleStarModel, BinaryStarModel,
                         TripleStarModel, IsoTrackModel)
 from .observation import ObservationTree, Observation, Source
-from .sampler import EnsembleSampler
+from ._cabi import IsoError
+from .sampler import EnsembleSampler, FusedEnsembleSampler
 from .catalog import (StarCatalog, CatalogPosterior, fit_catalog, synthetic_catalog, shard_of, shard_indices,
                       broadcast_interpolator)
 from . import priors, grids, ingest

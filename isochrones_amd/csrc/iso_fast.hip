@@ -26,4 +26,10 @@ bool launch_stretch(int kind, int n_stars, int n_bands, const FastArgs& A, const
     return false;
 }
 
+size_t stretch_persist_lds(int n_bands, int axes_len, int W, int n_params, int* ensembles_per_workgroup)
+{
+    if (ensembles_per_workgroup) *ensembles_per_workgroup = fastk::persist_group(W);
+    return fastk::stretch_persist_lds_bytes(axes_len, n_bands, W, n_params);
+}
+
 }  // namespace iso

@@ -48,6 +48,64 @@ __device__ __forceinline__ void lds_bracket(const double* lds, const FastAxis ax
     t = (x - a[base]) * a[ax.n + base];
 }
 
+// The same bisection for several axes in lock-step: the LDS reads of one level are issued back to back,
+// so a sample pays one LDS latency per level instead of one per level per axis (an axis that has
+// converged re-reads its node, which changes nothing).
+__device__ __forceinline__ void lds_bracket2(const double* lds, const FastAxis axa, const FastAxis axb, double xa,
+                                             double xb, int& ia, int& ib, double& ta, double& tb)
+{
+    const double* a = lds + axa.off;
+    const double* b = lds + axb.off;
+    int ba = 0, bb = 0, la = axa.n, lb = axb.n;
+    while ((la | lb) > 1) {
+        const int ha = la >> 1, hb = lb >> 1;
+        const double va = a[ba + ha], vb = b[bb + hb];
+        ba = (va <= xa) ? ba + ha : ba;
+        bb = (vb <= xb) ? bb + hb : bb;
+        la -= ha;
+        lb -= hb;
+    }
+    ba = min(ba, axa.n - 2);
+    bb = min(bb, axb.n - 2);
+    ia = ba;
+    ib = bb;
+    ta = (xa - a[ba]) * a[axa.n + ba];
+    tb = (xb - b[bb]) * b[axb.n + bb];
+}
+
+__device__ __forceinline__ void lds_bracket4(const double* lds, const FastAxis ax0, const FastAxis ax1,
+                                             const FastAxis ax2, const FastAxis ax3, double x0, double x1, double x2,
+                                             double x3, int& i0, int& i1, int& i2, int& i3, double& t0, double& t1,
+                                             double& t2, double& t3)
+{
+    const double* a0 = lds + ax0.off;
+    const double* a1 = lds + ax1.off;
+    const double* a2 = lds + ax2.off;
+    const double* a3 = lds + ax3.off;
+    int b0 = 0, b1 = 0, b2 = 0, b3 = 0, l0 = ax0.n, l1 = ax1.n, l2 = ax2.n, l3 = ax3.n;
+    while ((l0 | l1 | l2 | l3) > 1) {
+        const int h0 = l0 >> 1, h1 = l1 >> 1, h2 = l2 >> 1, h3 = l3 >> 1;
+        const double v0 = a0[b0 + h0], v1 = a1[b1 + h1], v2 = a2[b2 + h2], v3 = a3[b3 + h3];
+        b0 = (v0 <= x0) ? b0 + h0 : b0;
+        b1 = (v1 <= x1) ? b1 + h1 : b1;
+        b2 = (v2 <= x2) ? b2 + h2 : b2;
+        b3 = (v3 <= x3) ? b3 + h3 : b3;
+        l0 -= h0;
+        l1 -= h1;
+        l2 -= h2;
+        l3 -= h3;
+    }
+    b0 = min(b0, ax0.n - 2);
+    b1 = min(b1, ax1.n - 2);
+    b2 = min(b2, ax2.n - 2);
+    b3 = min(b3, ax3.n - 2);
+    i0 = b0; i1 = b1; i2 = b2; i3 = b3;
+    t0 = (x0 - a0[b0]) * a0[ax0.n + b0];
+    t1 = (x1 - a1[b1]) * a1[ax1.n + b1];
+    t2 = (x2 - a2[b2]) * a2[ax2.n + b2];
+    t3 = (x3 - a3[b3]) * a3[ax3.n + b3];
+}
+
 __device__ __forceinline__ bool eep_oob(const FastArgs& A, double x)
 {
     return (x < A.e_a0) || (x > fma((double)(A.e_n - 1), A.e_step, A.e_a0));
@@ -465,8 +523,7 @@ __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* l
     W3 w;
     w.t0 = w.t1 = w.t2 = 0.0;
     if (ok01) {
-        lds_bracket(lds, A.m0, x0, i0, w.t0);
-        lds_bracket(lds, A.m1, x1, i1, w.t1);
+        lds_bracket2(lds, A.m0, A.m1, x0, x1, i0, i1, w.t0, w.t1);
     }
     double star[NS][6];
 #pragma unroll
@@ -532,10 +589,7 @@ __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* l
         W4 w4v;
         w4v.t0 = w4v.t1 = w4v.t2 = w4v.t3 = 0.0;
         if (ok) {
-            lds_bracket(lds, A.b0, T, j0, w4v.t0);
-            lds_bracket(lds, A.b1, g, j1, w4v.t1);
-            lds_bracket(lds, A.b2, f, j2, w4v.t2);
-            lds_bracket(lds, A.b3, AV, j3, w4v.t3);
+            lds_bracket4(lds, A.b0, A.b1, A.b2, A.b3, T, g, f, AV, j0, j1, j2, j3, w4v.t0, w4v.t1, w4v.t2, w4v.t3);
         }
         if (PACKED) {
             const uint32_t cell = (uint32_t)((int64_t)j0 * A.bs0 + (int64_t)j1 * A.bs1 + (int64_t)j2 * A.bs2 + j3);
@@ -637,6 +691,58 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
+// One stretch move of walker k of the active half of one star's ensemble.  `pos` / `lnp` / `acc_cnt` are
+// that star's [W][NP] / [W] / [W] arrays (global memory in the step-wise kernel, LDS in the persistent
+// one), `chain_pos` / `chain_lnp` its slab of the stored chain for this step (or null).  The Philox
+// counter is (step, half, global row): both kernels draw identical numbers for a given move.
+template <int KIND, int NS, int NB>
+__device__ __forceinline__ void stretch_move(const FastArgs& A, const StretchArgs& S, double* lds, const CoopLds& L,
+                                             bool active, int64_t star, int k, int half, uint32_t step,
+                                             double* __restrict__ pos, double* __restrict__ lnp, int32_t* acc_cnt,
+                                             double* __restrict__ chain_pos, double* __restrict__ chain_lnp)
+{
+    constexpr int NP = NS + 4;
+    const int h = S.W >> 1;
+    const int lr = (half ? h : 0) + k;                  // row within the star's ensemble
+    const int64_t row = star * S.W + lr;
+    uint32_t rnd[4];
+    philox4x32_10((uint32_t)(2u * step + (uint32_t)half), (uint32_t)row, (uint32_t)((uint64_t)row >> 32), 0x51u,
+                  (uint32_t)S.seed, (uint32_t)(S.seed >> 32), rnd);
+    const int j = (int)(((uint64_t)rnd[0] * (uint64_t)h) >> 32);          // uniform in [0, h)
+    const int lp = (half ? 0 : h) + j;
+    const double u1 = ((double)rnd[1] + (double)(rnd[2] & 0xFFFFu) * (1.0 / 65536.0)) * (1.0 / 4294967296.0);
+    const double u2 = ((double)rnd[3] + (double)(rnd[2] >> 16) * (1.0 / 65536.0) + 0.5 / 65536.0) * (1.0 / 4294967296.0);
+    const double zr = (S.a - 1.0) * u1 + 1.0;
+    const double z = zr * zr / S.a;
+    double xk[NP], y[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        xk[q] = pos[lr * NP + q];
+        const double xj = pos[lp * NP + q];
+        y[q] = xj + z * (xk[q] - xj);
+    }
+    const double lold = lnp[lr];
+    const DevModel& M = A.m[S.multi ? star : 0];
+    double lnp_unused, lnl_unused;
+    const double lnew = lnpost_wave<KIND, NS, NB, true>(A, lds, L, active, M, y, false, lnp_unused, lnl_unused);
+    const double lnq = (NP - 1) * log(z) + lnew - lold;
+    const bool acc = active && isfinite(lnew) && (log(u2) < lnq);
+    if (acc) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) pos[lr * NP + q] = y[q];
+        lnp[lr] = lnew;
+        if (acc_cnt) acc_cnt[lr] += 1;
+    }
+    // chain recording: every move stores the row it owns (its value for this step)
+    if (active && chain_pos) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) chain_pos[lr * NP + q] = acc ? y[q] : xk[q];
+    }
+    if (active && chain_lnp) chain_lnp[lr] = acc ? lnew : lold;
+}
+
+// step-wise form: one launch = one half-step of every ensemble (grid over stars x W/2 walkers);
+// the throughput form for catalogs large enough to fill the chip
 template <int KIND, int NS, int NB>
 __global__ __launch_bounds__(BLOCK) void k_stretch_half(const FastArgs A, const StretchArgs S)
 {
@@ -651,46 +757,107 @@ __global__ __launch_bounds__(BLOCK) void k_stretch_half(const FastArgs A, const 
     const int h = S.W >> 1;
     const int64_t star = t / h;
     const int k = (int)(t - star * h);
-    const int64_t row = star * S.W + (S.half ? h : 0) + k;
-    uint32_t rnd[4];
-    philox4x32_10((uint32_t)(2u * S.step + (uint32_t)S.half), (uint32_t)row, (uint32_t)((uint64_t)row >> 32), 0x51u,
-                  (uint32_t)S.seed, (uint32_t)(S.seed >> 32), rnd);
-    const int j = (int)(((uint64_t)rnd[0] * (uint64_t)h) >> 32);          // uniform in [0, h)
-    const int64_t prow = star * S.W + (S.half ? 0 : h) + j;
-    const double u1 = ((double)rnd[1] + (double)(rnd[2] & 0xFFFFu) * (1.0 / 65536.0)) * (1.0 / 4294967296.0);
-    const double u2 = ((double)rnd[3] + (double)(rnd[2] >> 16) * (1.0 / 65536.0) + 0.5 / 65536.0) * (1.0 / 4294967296.0);
-    const double zr = (S.a - 1.0) * u1 + 1.0;
-    const double z = zr * zr / S.a;
-    double xk[NP], y[NP];
-#pragma unroll
-    for (int q = 0; q < NP; ++q) {
-        xk[q] = S.pos[row * NP + q];
-        const double xj = S.pos[prow * NP + q];
-        y[q] = xj + z * (xk[q] - xj);
+    const int64_t r0 = star * S.W;
+    stretch_move<KIND, NS, NB>(A, S, lds, L, active, star, k, S.half, S.step, S.pos + r0 * NP, S.lnp + r0,
+                               S.accepted ? S.accepted + r0 : nullptr, S.chain_pos ? S.chain_pos + r0 * NP : nullptr,
+                               S.chain_lnp ? S.chain_lnp + r0 : nullptr);
+}
+
+// persistent form: ALL S.nsteps iterations in a single launch.  A workgroup owns G = max(1, BLOCK / (W/2))
+// whole ensembles (one lane per walker of the active half, so a 32-walker catalog packs 16 stars into a
+// workgroup; a large ensemble is walked in chunks of BLOCK).  Positions, lnpost values and acceptance
+// counters live in LDS; the two half-steps of an iteration are separated by workgroup barriers instead
+// of kernel boundaries, so an iteration costs two dependent evaluation chains instead of two launches.
+// Same moves, same random numbers, bit-identical chains as the step-wise form.
+// LDS: [axes][request/response slots][pos R*NP][lnp R][acc R (int32)],  R = G * W rows
+__host__ __device__ constexpr int persist_group(int W) { return (W >> 1) >= BLOCK ? 1 : BLOCK / (W >> 1); }
+__host__ __device__ constexpr int persist_extra_doubles(int W, int np)
+{
+    return persist_group(W) * W * (np + 1) + (persist_group(W) * W + 1) / 2;
+}
+
+template <int KIND, int NS, int NB>
+__global__ __launch_bounds__(BLOCK) void k_stretch_persist(const FastArgs A, const StretchArgs S)
+{
+    extern __shared__ double lds[];
+    for (int j = threadIdx.x; j < A.axes_len; j += BLOCK) lds[j] = A.axes_blob[j];
+    const CoopLds L = coop_lds<NB>(lds, A.axes_len);
+    constexpr int NP = NS + 4;
+    const int W = S.W, h = W >> 1;
+    const int G = persist_group(W);
+    const int per = h < BLOCK ? h : BLOCK;               // lanes one ensemble occupies per chunk
+    const int64_t n_ens = S.n_active / h;
+    const int64_t star0 = (int64_t)blockIdx.x * G;
+    const int here = (int)((n_ens - star0) < G ? (n_ens - star0) : G);   // ensembles this workgroup owns
+    const int R = here * W;
+    const int64_t r0 = star0 * W;
+    double* lpos = lds + ((A.axes_len + 1) & ~1) + coop_lds_doubles(NB);
+    double* llnp = lpos + G * W * NP;
+    int32_t* lacc = reinterpret_cast<int32_t*>(llnp + G * W);
+    for (int j = threadIdx.x; j < R * NP; j += BLOCK) lpos[j] = S.pos[r0 * NP + j];
+    for (int j = threadIdx.x; j < R; j += BLOCK) {
+        llnp[j] = S.lnp[r0 + j];
+        lacc[j] = 0;
     }
-    const DevModel& M = A.m[S.multi ? star : 0];
-    double lnp_unused, lnl_unused;
-    const double lnew = lnpost_wave<KIND, NS, NB, true>(A, lds, L, active, M, y, false, lnp_unused, lnl_unused);
-    const double lnq = (NP - 1) * log(z) + lnew - S.lnp[row];
-    const bool acc = active && isfinite(lnew) && (log(u2) < lnq);
-    if (acc) {
-#pragma unroll
-        for (int q = 0; q < NP; ++q) S.pos[row * NP + q] = y[q];
-        S.lnp[row] = lnew;
-        if (S.accepted) S.accepted[row] += 1;
+    __syncthreads();
+    const int64_t rows_total = n_ens * W;
+    const int g = (int)threadIdx.x / per, kk = (int)threadIdx.x - g * per;
+    const bool mine = g < here;
+    const int gs = mine ? g : 0;                          // idle lanes shadow a move of the first ensemble
+    for (int it = 0; it < S.nsteps; ++it) {
+        double* cp = S.chain_pos ? S.chain_pos + ((int64_t)it * rows_total + r0 + gs * W) * NP : nullptr;
+        double* cl = S.chain_lnp ? S.chain_lnp + (int64_t)it * rows_total + r0 + gs * W : nullptr;
+        for (int half = 0; half < 2; ++half) {
+            for (int k0 = 0; k0 < h; k0 += per) {
+                const int k = k0 + kk;
+                const bool active = mine && k < h;
+                if (__any(active))                        // wave-uniform: idle waves go straight to the barrier
+                    stretch_move<KIND, NS, NB>(A, S, lds, L, active, star0 + gs, active ? k : h - 1, half,
+                                               S.step + (uint32_t)it, lpos + gs * W * NP, llnp + gs * W,
+                                               lacc + gs * W, cp, cl);
+            }
+            __syncthreads();
+        }
     }
-    // chain recording: each half-step kernel stores the rows it owns (their value for this step)
-    if (active && S.chain_pos) {
-#pragma unroll
-        for (int q = 0; q < NP; ++q) S.chain_pos[row * NP + q] = acc ? y[q] : xk[q];
+    for (int j = threadIdx.x; j < R * NP; j += BLOCK) S.pos[r0 * NP + j] = lpos[j];
+    for (int j = threadIdx.x; j < R; j += BLOCK) {
+        S.lnp[r0 + j] = llnp[j];
+        if (S.accepted) S.accepted[r0 + j] += lacc[j];
     }
-    if (active && S.chain_lnp) S.chain_lnp[row] = acc ? lnew : S.lnp[row];
+}
+
+// dynamic LDS of the persistent form; the host uses it to decide whether an ensemble fits
+inline size_t stretch_persist_lds_bytes(int axes_len, int nb, int W, int np)
+{
+    return (size_t)(((axes_len + 1) & ~1) + coop_lds_doubles(nb) + persist_extra_doubles(W, np)) * sizeof(double);
 }
 
 template <int KIND, int NS>
 inline bool launch_stretch_nb(int nb, const FastArgs& A, const StretchArgs& S, hipStream_t s)
 {
-    const dim3 g((unsigned)((S.n_active + BLOCK - 1) / BLOCK)), b(BLOCK);
+    const dim3 b(BLOCK);
+    if (S.nsteps > 0) {                                       // persistent: one workgroup per ensemble
+        const int64_t n_ens = S.n_active / (S.W >> 1);
+        const int G = persist_group(S.W);
+        const dim3 gp((unsigned)((n_ens + G - 1) / G));
+        auto shp = [&](int n) { return stretch_persist_lds_bytes(A.axes_len, n, S.W, NS + 4); };
+        switch (nb) {
+        case 1: hipLaunchKernelGGL((k_stretch_persist<KIND, NS, 1>), gp, b, shp(1), s, A, S); return true;
+        case 2: hipLaunchKernelGGL((k_stretch_persist<KIND, NS, 2>), gp, b, shp(2), s, A, S); return true;
+        case 3: hipLaunchKernelGGL((k_stretch_persist<KIND, NS, 3>), gp, b, shp(3), s, A, S); return true;
+        case 4: hipLaunchKernelGGL((k_stretch_persist<KIND, NS, 4>), gp, b, shp(4), s, A, S); return true;
+        case 5: hipLaunchKernelGGL((k_stretch_persist<KIND, NS, 5>), gp, b, shp(5), s, A, S); return true;
+        case 6: hipLaunchKernelGGL((k_stretch_persist<KIND, NS, 6>), gp, b, shp(6), s, A, S); return true;
+        case 7: hipLaunchKernelGGL((k_stretch_persist<KIND, NS, 7>), gp, b, shp(7), s, A, S); return true;
+        case 8: hipLaunchKernelGGL((k_stretch_persist<KIND, NS, 8>), gp, b, shp(8), s, A, S); return true;
+        case 9: hipLaunchKernelGGL((k_stretch_persist<KIND, NS, 9>), gp, b, shp(9), s, A, S); return true;
+        case 10: hipLaunchKernelGGL((k_stretch_persist<KIND, NS, 10>), gp, b, shp(10), s, A, S); return true;
+        case 11: hipLaunchKernelGGL((k_stretch_persist<KIND, NS, 11>), gp, b, shp(11), s, A, S); return true;
+        case 12: hipLaunchKernelGGL((k_stretch_persist<KIND, NS, 12>), gp, b, shp(12), s, A, S); return true;
+        default: return false;
+        }
+    }
+    const dim3 g((unsigned)((S.n_active + BLOCK - 1) / BLOCK));
     auto sh = [&](int n) { return (size_t)(((A.axes_len + 1) & ~1) + coop_lds_doubles(n)) * sizeof(double); };
     switch (nb) {
     case 1: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 1>), g, b, sh(1), s, A, S); return true;

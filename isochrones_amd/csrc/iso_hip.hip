@@ -2128,6 +2128,8 @@ int iso_sampler_create_catalog(iso_catalog* c, int nwalkers, double a, uint64_t 
 
 void iso_sampler_destroy(iso_sampler* s) { delete s; }
 
+static const size_t LDS_BYTES_PER_CU = 160 * 1024;     // gfx950
+
 int iso_sampler_run(iso_sampler* sp, double* pos, double* lnp, int nsteps, double* chain, double* chain_lnp,
                     int32_t* accepted, void* stream)
 {
@@ -2145,6 +2147,38 @@ int iso_sampler_run(iso_sampler* sp, double* pos, double* lnp, int nsteps, doubl
     S.n_active = sp->n_ensembles * (sp->W / 2);
     S.a = sp->a;
     S.seed = sp->seed;
+    // ISOCHRONES_AMD_SAMPLER = auto | persistent | stepwise.  The persistent kernel (one workgroup per
+    // ensemble, all iterations in one launch) wins while the catalog is too small for a half-step launch
+    // to fill the chip; both forms produce bit-identical chains.
+    const char* env = getenv("ISOCHRONES_AMD_SAMPLER");
+    const std::string mode = env ? env : "auto";
+    if (mode != "auto" && mode != "persistent" && mode != "stepwise")
+        return fail(ISO_ERR_INVALID, "ISOCHRONES_AMD_SAMPLER must be auto, persistent or stepwise");
+    int group = 1;
+    const size_t lds_bytes = stretch_persist_lds(sp->n_bands, sp->fast.axes_len, sp->W, sp->n_params, &group);
+    const bool fits = lds_bytes <= 64 * 1024;
+    if (mode == "persistent" && !fits)
+        return fail(ISO_ERR_INVALID, "iso_sampler_run: ensemble too large for the persistent kernel's LDS");
+    // auto: persistent while every workgroup of the launch is resident at once (LDS-limited occupancy);
+    // beyond that its workgroups would run in rounds and the step-wise form has the better throughput
+    int cus = 0;
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, sp->device));
+    const int64_t blocks = (sp->n_ensembles + group - 1) / group;
+    const int64_t resident = (int64_t)cus * std::max<int64_t>(1, (int64_t)(LDS_BYTES_PER_CU / lds_bytes));
+    const bool persistent = nsteps > 0 && fits && (mode == "persistent" || (mode == "auto" && blocks <= resident));
+    if (persistent) {
+        S.step = sp->step;
+        S.nsteps = nsteps;
+        S.half = 0;
+        S.chain_pos = chain;
+        S.chain_lnp = chain_lnp;
+        sp->step += (uint32_t)nsteps;
+        if (!launch_stretch(sp->kind, sp->n_stars, sp->n_bands, sp->fast, S, s))
+            return fail(ISO_ERR_INVALID, "iso_sampler_run: no kernel specialisation");
+        HIP_TRY(hipGetLastError());
+        return ISO_OK;
+    }
+    S.nsteps = 0;
     for (int it = 0; it < nsteps; ++it) {
         S.step = sp->step++;
         S.chain_pos = chain ? chain + (int64_t)it * rows * sp->n_params : nullptr;

@@ -105,6 +105,8 @@ struct StretchArgs {
     double a;             // stretch scale
     uint64_t seed;
     uint32_t step;
+    int nsteps;           // 0: step-wise kernel (one half-step per launch); > 0: persistent kernel, all
+                          // iterations in one launch (chain slabs then advance by n_rows per iteration)
     double* chain_pos;    // optional: this step's [n_rows][n_params] slab of the stored chain
     double* chain_lnp;    // optional: this step's [n_rows] slab
 };
@@ -184,6 +186,9 @@ struct iso_sampler {
 
 namespace iso {
 bool launch_stretch(int kind, int n_stars, int n_bands, const FastArgs& A, const StretchArgs& S, hipStream_t s);
+// dynamic LDS bytes one workgroup of the persistent sampler kernel needs for W-walker ensembles, and how
+// many ensembles such a workgroup owns
+size_t stretch_persist_lds(int n_bands, int axes_len, int W, int n_params, int* ensembles_per_workgroup);
 // defined in iso_fast_*.hip: launch the specialised fused kernel; returns false if no
 // specialisation exists for (kind, n_stars, n_bands)
 bool launch_lnpost_fast(int kind, int n_stars, int n_bands, bool packed, bool multi, const FastArgs& A,

@@ -163,6 +163,67 @@ def test_fused_catalog_sampler_matches_per_star_bookkeeping():
         assert torch.allclose(want, lnp[s], rtol=1e-12, atol=1e-12)
 
 
+def _run_fused(target, p0, lnp0, W, nsteps, mode, monkeypatch, seed=9):
+    from isochrones_amd.sampler import FusedEnsembleSampler
+    monkeypatch.setenv("ISOCHRONES_AMD_SAMPLER", mode)
+    fs = FusedEnsembleSampler(target, W, seed=seed)
+    pos, lnp = fs.run_mcmc(p0, nsteps, lnprob0=lnp0, store=True)
+    pos2, lnp2 = fs.run_mcmc(pos, 7, lnprob0=lnp, store=True)      # a second call continues the RNG stream
+    return pos2.clone(), lnp2.clone(), fs.chain.clone(), fs.lnprobability.clone(), fs.accepted.clone()
+
+
+@pytest.mark.parametrize("W", [16, 128, 600])
+def test_persistent_sampler_kernel_bit_identical_to_stepwise(W, monkeypatch):
+    """The one-launch persistent kernel (workgroup per ensemble, positions in LDS) and the
+    launch-per-half-step kernel make the same moves with the same Philox numbers: chains,
+    lnprob, final state and acceptance counters must agree bit for bit (W=600 exercises the
+    multi-chunk half, W=16 the mostly idle workgroup)."""
+    import torch
+    from isochrones_amd.catalog import initial_positions
+    ic = _small_track(("G", "BP", "RP"))
+    cat, truth = synthetic_catalog(ic, 5, bands=["G", "BP", "RP"], seed=4, mag_unc=0.01)
+    models = list(cat.iter_models(ic))
+    post = CatalogPosterior(ic, models)
+    pos, lnp, failed = initial_positions(post, W, rng_seed=2)
+    assert not bool(failed.any())
+    a = _run_fused(post, pos, lnp, W, 40, "stepwise", monkeypatch)
+    b = _run_fused(post, pos, lnp, W, 40, "persistent", monkeypatch)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    assert int(a[4].sum()) > 0
+    # single-model form
+    a = _run_fused(models[2], pos[2], lnp[2], W, 25, "stepwise", monkeypatch)
+    b = _run_fused(models[2], pos[2], lnp[2], W, 25, "persistent", monkeypatch)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+
+
+def test_persistent_sampler_binary_model_and_bad_mode(monkeypatch):
+    import torch
+    from isochrones_amd.sampler import FusedEnsembleSampler
+    ages = ia.grids.mist_log_ages()[60::2]
+    ic = ia.synthetic_isochrone(bands=("J", "H", "K"), ages=ages, fehs=[-1.0, -0.5, 0.0, 0.5], eeps=np.arange(150.0, 700.0),
+                                eep_bounds=(150, 699), limits=dict(age=(ages[0], ages[-1]), feh=(-1.0, 0.5)))
+    truth = np.array([380.0, 330.0, 9.6, -0.1, 300.0, 0.1])
+    mags = ic.interp_mag([truth[0], *truth[2:]], ["J", "H", "K"])[3]
+    mod = ia.BinaryStarModel(ic, J=(mags[0] - 0.3, 0.02), H=(mags[1] - 0.3, 0.02), K=(mags[2] - 0.3, 0.02),
+                             parallax=(1000 / 300.0, 0.05))
+    rng = np.random.default_rng(5)
+    W = 64
+    p0 = truth + np.array([1.0, 1.0, 0.01, 0.01, 1.0, 0.01]) * rng.standard_normal((W, 6))
+    p0[:, 5] = np.abs(p0[:, 5])
+    lnp0 = mod.lnpost(torch.as_tensor(p0, device="cuda"))
+    assert bool(torch.isfinite(lnp0).all())
+    a = _run_fused(mod, p0, lnp0, W, 30, "stepwise", monkeypatch)
+    b = _run_fused(mod, p0, lnp0, W, 30, "persistent", monkeypatch)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    monkeypatch.setenv("ISOCHRONES_AMD_SAMPLER", "bogus")
+    fs = FusedEnsembleSampler(mod, W, seed=1)
+    with pytest.raises(ia.IsoError):
+        fs.run_mcmc(p0, 2, lnprob0=lnp0)
+
+
 # ---- "next" row f4: generic StarModel over an ObservationTree ---------------------------------
 from tests.test_tree_cpu import TREE_CASES, make_tree_model  # noqa: E402
 
