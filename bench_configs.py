@@ -78,8 +78,17 @@ def cfg3(n=1_000_000, reps=100):
                              G=(10.3, 0.001), parallax=(2.0, 0.05))
     rng = np.random.default_rng(3)
     out = {}
-    for workload in ("prior", "posterior"):
-        if workload == "prior":
+    for workload in ("prior", "prior_valid", "posterior"):
+        if workload == "prior_valid":
+            # uniform over the populated part of the isochrone table: both components always reach
+            # the BC gather (uncorrelated 384 B + 768 B reads per component)
+            age = rng.uniform(6.0, 10.25, n)
+            first = ia.grids.iso_eep_range(age + 0.05)[0] + 1.0
+            last = ia.grids.iso_eep_range(age - 0.05)[1] - 1.0
+            e = first[:, None] + rng.uniform(0, 1, (n, 2)) * (last - first)[:, None]
+            pars = np.column_stack([e.max(axis=1), e.min(axis=1), age, rng.uniform(-4.0, 0.5, n),
+                                    rng.uniform(1.0, 1000.0, n), rng.uniform(0.0, 1.0, n)])
+        elif workload == "prior":
             lo = np.array([1.0, 1.0, 5.0, -4.0, 1.0, 0.0])
             hi = np.array([1710.0, 1710.0, 10.3, 0.5, 1000.0, 1.0])
             pars = rng.uniform(lo, hi, size=(n, 6))
