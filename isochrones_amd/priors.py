@@ -74,6 +74,26 @@ class Prior:
     def sample(self, n, rng=None):
         raise NotImplementedError
 
+    # the reference's self-checks (priors.py:74-104), used by its tests/test_priors.py
+    def test_integral(self):
+        from scipy.integrate import quad
+        lo, hi = self.bounds
+        pts = [b for b in getattr(self, "breakpoints", ()) if lo < b < hi] or None
+        assert np.isclose(1.0, quad(self.pdf, lo, hi, points=pts, limit=200)[0], rtol=1e-6)
+
+    def test_sampling(self, n=100000, rng=None):
+        """Histogram of ``sample(n)`` against the bin-averaged pdf: every bin with more than 50
+        draws within 6 sigma (Poisson), the reference's criterion."""
+        from scipy.integrate import quad
+        x = self.sample(n, rng)
+        rng_ = None if not np.all(np.isfinite(self.bounds)) else self.bounds
+        hn, b = np.histogram(x, range=rng_)
+        h = hn / (hn.sum() * np.diff(b))
+        pdf = np.array([quad(self.pdf, lo, hi, limit=200)[0] / (hi - lo) for lo, hi in zip(b[:-1], b[1:])])
+        ok = hn > 50
+        resid = np.abs(pdf[ok] - h[ok]) / pdf[ok] * np.sqrt(hn[ok])
+        assert resid.max() < 6, resid
+
     def _fields(self):
         return {}
 
@@ -232,6 +252,7 @@ class ChabrierPrior(Prior):
         self.low = LogNormalPrior(mu, sigma)
         self.high = PowerLawPrior(alpha, powerlaw_bounds)
         self.breakpoint = float(breakpoint)
+        self.breakpoints = (self.breakpoint,)
         self._bounds = (float(bounds[0]), float(bounds[1]))
         self._rebuild()
 
@@ -386,6 +407,20 @@ class DistancePrior(PowerLawPrior):
 class AVPrior(FlatPrior):
     def __init__(self, bounds=(0, 1.0)):
         super().__init__(bounds)
+
+
+class QPrior(PowerLawPrior):
+    """Mass-ratio prior (reference priors.py:502-505)."""
+
+    def __init__(self, bounds=(0.1, 1)):
+        super().__init__(alpha=0.3, bounds=bounds)
+
+
+class SalpeterPrior(PowerLawPrior):
+    """Salpeter IMF (reference priors.py:508-511)."""
+
+    def __init__(self, bounds=(0.1, 10)):
+        super().__init__(alpha=-2.35, bounds=bounds)
 
 
 DEVICE_PRIOR_TYPES = (FlatPrior, FlatLogPrior, PowerLawPrior, GaussianPrior, LogNormalPrior,

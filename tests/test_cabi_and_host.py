@@ -122,6 +122,20 @@ def test_priors_integrate_to_one():
         assert np.all((x >= p.bounds[0]) & (x <= p.bounds[1]))
 
 
+@pytest.mark.parametrize("name", ["AgePrior", "DistancePrior", "AVPrior", "QPrior", "SalpeterPrior", "FehPrior",
+                                  "ChabrierPrior"])
+def test_reference_prior_self_checks(name):
+    """reference tests/test_priors.py:1-58, test for test: integral == 1 and sample() follows pdf."""
+    p = getattr(priors, name)()
+    if name == "FehPrior":
+        assert p.bounds == (-np.inf, np.inf)
+        p.test_sampling(rng=np.random.default_rng(5))
+        p.bounds = (-3, 0.25)
+        assert p(-3.5) == 0 and p(0.4) == 0
+    p.test_integral()
+    p.test_sampling(rng=np.random.default_rng(6))
+
+
 def test_descriptor_packing():
     meta = fx.load("iso_binary_phot6")["meta"]
     mod = fx.make_model(meta)
