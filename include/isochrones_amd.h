@@ -242,7 +242,9 @@ int  iso_tree_lnpost(iso_tree_model* m, const double* pars, int64_t stride_n, in
 /* Device-resident affine-invariant ensemble sampler (stretch move, Goodman & Weare 2010) — what the
  * reference obtains from emcee.EnsembleSampler(nwalkers, npars, self.lnpost).run_mcmc(...)
  * (isochrones/starmodel.py:951-969), with the proposal, the fused lnpost and the accept step in one
- * kernel per half-ensemble.  pos [n_ens*W, n_params] row-major and lnp [n_ens*W] are DEVICE arrays
+ * kernel: either one launch per half-ensemble step, or — while all ensembles are resident on the chip at
+ * once — a single persistent launch for all nsteps iterations (same moves, same Philox numbers, identical
+ * chains; environment ISOCHRONES_AMD_SAMPLER=auto|persistent|stepwise overrides the choice).  pos [n_ens*W, n_params] row-major and lnp [n_ens*W] are DEVICE arrays
  * updated in place (lnp must hold lnpost(pos) on entry); chain [nsteps][n_ens*W][n_params],
  * chain_lnp [nsteps][n_ens*W] and accepted [n_ens*W] (int32 counters) are optional DEVICE outputs.
  * n_ens = 1 for a model, = n_models for a catalog (row = star*W + walker).  The model / catalog

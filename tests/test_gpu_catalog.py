@@ -172,7 +172,7 @@ def _run_fused(target, p0, lnp0, W, nsteps, mode, monkeypatch, seed=9):
     return pos2.clone(), lnp2.clone(), fs.chain.clone(), fs.lnprobability.clone(), fs.accepted.clone()
 
 
-@pytest.mark.parametrize("W", [16, 128, 600])
+@pytest.mark.parametrize("W", [16, 100, 128, 600])
 def test_persistent_sampler_kernel_bit_identical_to_stepwise(W, monkeypatch):
     """The one-launch persistent kernel (workgroup per ensemble, positions in LDS) and the
     launch-per-half-step kernel make the same moves with the same Philox numbers: chains,
