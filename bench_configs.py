@@ -193,19 +193,30 @@ def primitives(n=1_000_000, reps=20):
     lo = np.array([0.1, 1.0, -4.0, 1.0, 0.0]); hi = np.array([10.0, 1710.0, 0.5, 3000.0, 1.0])
     pars = torch.as_tensor(np.ascontiguousarray(rng.uniform(lo, hi, size=(n, 5)).T), device="cuda")
     out = {}
-    for name, fn, nbytes in (
-            ("interp_mag_11_bands", lambda: ic.interp_mag_device(pars, list(ic.bands)), 8 * 4 * 8 + 16 * 11 * 8 + 40 + 8 * 14),
-            ("interp_value_18_cols", lambda: ic.model_grid.interp.interp_device([pars[2], pars[0], pars[1]], np.arange(18)),
-             8 * 18 * 8 + 24 + 18 * 8)):
-        fn(); torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            fn()
-        e1.record(); torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / reps
-        out[name] = {"ms": ms, "samples_per_s": n / (ms * 1e-3), "algorithmic_GBs": nbytes * n / (ms * 1e-3) / 1e9,
-                     "bytes_per_sample": nbytes}
+    cases = []
+    for nb in (1, 3, 11):
+        bands = list(ic.bands)[:nb]
+        # algorithmic bytes: 8 corners x 4 columns + 16 corners x nb bands + 5 parameters in + 3 + nb out
+        cases.append(("interp_mag_%d_bands" % nb, (lambda b=bands: ic.interp_mag_device(pars, b)),
+                      8 * 4 * 8 + 16 * nb * 8 + 40 + 8 * (3 + nb)))
+    cases.append(("interp_value_18_cols", lambda: ic.model_grid.interp.interp_device([pars[2], pars[0], pars[1]], np.arange(18)),
+                  8 * 18 * 8 + 24 + 18 * 8))
+    for path in ("auto", "generic"):
+        os.environ["ISOCHRONES_AMD_PATH"] = path
+        for name, fn, nbytes in cases:
+            if path == "generic" and not name.startswith("interp_mag"):
+                continue
+            fn(); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record(); torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / reps
+            out[name + ("" if path == "auto" else "_generic_kernel")] = {
+                "ms": ms, "samples_per_s": n / (ms * 1e-3), "algorithmic_GBs": nbytes * n / (ms * 1e-3) / 1e9,
+                "bytes_per_sample": nbytes}
+    os.environ.pop("ISOCHRONES_AMD_PATH", None)
     return {"config": "primitives", "metric": "batch API primitives, 1e6 samples (includes output allocation)", **out}
 
 

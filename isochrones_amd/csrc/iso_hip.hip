@@ -1197,6 +1197,11 @@ struct iso_eep_table {
     AxisD ax[2];
 };
 
+namespace {
+void free_mag_pack(MagPack& mp);
+int acquire_mag_pack(iso_ic* ic, const int32_t* bc_cols, int nb, int64_t n, iso::FastArgs& F);
+}  // namespace
+
 extern "C" {
 
 const char* iso_last_error(void) { return g_err.c_str(); }
@@ -1407,6 +1412,7 @@ void iso_ic_destroy(iso_ic* ic)
     DeviceGuard guard(ic->device);
     if (ic->d_hot) (void)hipFree(ic->d_hot);
     if (ic->d_hotq) (void)hipFree(ic->d_hotq);
+    for (MagPack& mp : ic->mag_packs) free_mag_pack(mp);
     delete ic;
 }
 
@@ -1437,6 +1443,24 @@ int iso_interp_mag(iso_ic* ic, const double* pars, int64_t stride_n, int64_t str
     A.Teff = Teff; A.logg = logg; A.feh = feh;
     A.mags = nb > 0 ? mags : nullptr;
     DeviceGuard guard(ic->ctx->device);
+    if (nb >= 1 && nb <= 12 && mags && ic->d_hotq && path_mode() == PATH_AUTO) {
+        // large batches: corner-packed tables + wave-cooperative gathers (the pack for this band list
+        // is built once and kept); small ones are not worth building a pack for
+        FastArgs F;
+        const int rc = acquire_mag_pack(ic, bc_cols, nb, n, F);
+        if (rc < 0) return rc;
+        if (rc == 1) {
+            F.pars = pars;
+            F.stride_n = stride_n;
+            F.stride_p = stride_p;
+            F.n = n;
+            MagOut O{Teff, logg, feh, mags};
+            if (launch_interp_mag_fast(ic->kind, nb, F, O, as_stream(stream))) {
+                HIP_TRY(hipGetLastError());
+                return ISO_OK;
+            }
+        }
+    }
     const int lanes_per_sample = nb > 1 ? (nb + 1) / 2 : 1, samples_per_wave = 64 / lanes_per_sample;
     const int64_t waves = (n + samples_per_wave - 1) / samples_per_wave;
     const dim3 g(grid_blocks(waves * 64)), b(BLOCK);
@@ -1584,6 +1608,62 @@ hipError_t build_fast(const iso_ic* ic, int nb, const double* d_bc_hot, double**
     return hipSuccess;
 }
 
+
+void free_mag_pack(MagPack& mp)
+{
+    if (mp.d_bc_hot) (void)hipFree(mp.d_bc_hot);
+    if (mp.d_bcq) (void)hipFree(mp.d_bcq);
+    if (mp.d_axes_blob) (void)hipFree(mp.d_axes_blob);
+    mp.d_bc_hot = mp.d_bcq = mp.d_axes_blob = nullptr;
+}
+
+// Corner-packed BC table of a band list for iso_interp_mag.  Returns 1 and fills F when a pack exists (or
+// the batch is large enough to pay for building one: a pack costs one pass over the BC table), 0 when
+// the caller should use the generic kernel, < 0 on error.  At most MAG_PACK_SLOTS band lists are kept
+// (least recently used one is dropped; hipFree synchronises with kernels still reading it).
+const size_t MAG_PACK_SLOTS = 6;
+const int64_t MAG_PACK_BUILD_MIN_ROWS = 32768, MAG_PACK_USE_MIN_ROWS = 1024;
+
+int acquire_mag_pack(iso_ic* ic, const int32_t* bc_cols, int nb, int64_t n, FastArgs& F)
+{
+    if (n < MAG_PACK_USE_MIN_ROWS) return 0;
+    std::lock_guard<std::mutex> lock(ic->mag_mu);
+    for (MagPack& mp : ic->mag_packs)
+        if ((int)mp.cols.size() == nb && std::equal(mp.cols.begin(), mp.cols.end(), bc_cols)) {
+            mp.last_use = ++ic->mag_clock;
+            F = mp.fast;
+            return 1;
+        }
+    if (n < MAG_PACK_BUILD_MIN_ROWS) return 0;
+    MagPack mp;
+    mp.cols.assign(bc_cols, bc_cols + nb);
+    mp.d_bc_hot = mp.d_bcq = mp.d_axes_blob = nullptr;
+    bool ok = false;
+    hipError_t e = pack_bands(ic, bc_cols, nb, &mp.d_bc_hot);
+    if (e == hipSuccess) e = build_fast(ic, nb, mp.d_bc_hot, &mp.d_axes_blob, &mp.d_bcq, mp.fast, &ok);
+    if (e != hipSuccess || !ok || !mp.d_bcq) {
+        free_mag_pack(mp);
+        if (e == hipErrorOutOfMemory || e == hipSuccess) {     // no room / not representable: generic kernel
+            (void)hipGetLastError();
+            return 0;
+        }
+        return fail(ISO_ERR_HIP, std::string("iso_interp_mag: ") + hipGetErrorString(e));
+    }
+    (void)hipFree(mp.d_bc_hot);                                  // only the corner-packed copy is read
+    mp.d_bc_hot = nullptr;
+    mp.fast.bc = nullptr;
+    if (ic->mag_packs.size() >= MAG_PACK_SLOTS) {
+        size_t lru = 0;
+        for (size_t k = 1; k < ic->mag_packs.size(); ++k)
+            if (ic->mag_packs[k].last_use < ic->mag_packs[lru].last_use) lru = k;
+        free_mag_pack(ic->mag_packs[lru]);
+        ic->mag_packs.erase(ic->mag_packs.begin() + lru);
+    }
+    mp.last_use = ++ic->mag_clock;
+    F = mp.fast;
+    ic->mag_packs.push_back(mp);
+    return 1;
+}
 }  // namespace
 
 extern "C" {

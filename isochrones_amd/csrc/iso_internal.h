@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <cstring>
 #include <string>
+#include <mutex>
 #include <vector>
 
 #include "../../include/isochrones_amd.h"
@@ -129,6 +130,16 @@ struct iso_table {
     iso::AxisD ax[ISO_MAX_DIM];
 };
 
+// corner-packed BC table for one band list, built on first use by iso_interp_mag (fast form)
+struct MagPack {
+    std::vector<int32_t> cols;
+    double* d_bc_hot;
+    double* d_bcq;
+    double* d_axes_blob;
+    iso::FastArgs fast;
+    uint64_t last_use;
+};
+
 struct iso_ic {
     int device;
     iso_ctx* ctx;
@@ -142,6 +153,9 @@ struct iso_ic {
     iso::Grid4V g4;          // full BC table view
     int lds_doubles;         // LDS staging size for model + BC axes (generic kernels)
     std::vector<double> h_axes_model[3], h_axes_bc[4];
+    std::mutex mag_mu;       // guards mag_packs
+    std::vector<MagPack> mag_packs;
+    uint64_t mag_clock;
 };
 
 struct iso_catalog {
@@ -185,6 +199,11 @@ struct iso_sampler {
 };
 
 namespace iso {
+struct MagOut {
+    double *Teff, *logg, *feh, *mags;     // each may be null; mags is [n][nb]
+};
+// defined in iso_fast_mag.hip: interp_mag on the corner-packed tables (nb = 1..12)
+bool launch_interp_mag_fast(int kind, int nb, const FastArgs& A, const MagOut& O, hipStream_t s);
 bool launch_stretch(int kind, int n_stars, int n_bands, const FastArgs& A, const StretchArgs& S, hipStream_t s);
 // dynamic LDS bytes one workgroup of the persistent sampler kernel needs for W-walker ensembles, and how
 // many ensembles such a workgroup owns

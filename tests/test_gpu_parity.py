@@ -176,6 +176,47 @@ def test_random_batch_vs_oracle(kind, n_stars, nb, kernel_path):
         fx.assert_close(m, wm, RTOL, atol=ATOL, what="mags")
 
 
+def test_interp_mag_packed_path_matches_generic_kernel(monkeypatch):
+    """iso_interp_mag switches to the corner-packed tables for large batches (a pack per band list, built on
+    first use, at most 6 kept): both kernels against each other on the same samples incl. NaN / out-of-range
+    / exact-node inputs, optional outputs, small batches after a pack exists, and pack eviction."""
+    import torch
+    rng = np.random.default_rng(77)
+    bands = ia.grids.DEFAULT_BANDS[:8]
+    ic, mod, lo, hi = _random_model("track", 1, bands, rng)
+    n = 150_000
+    span = hi - lo
+    pars = rng.uniform(lo - 0.02 * span, hi + 0.02 * span, size=(n, 5))
+    pars[:50, 0] = ic.model_grid.masses[rng.integers(0, len(ic.model_grid.masses), 50)]      # exact nodes
+    pars[50:60, rng.integers(0, 5, 10)] = np.nan
+    pars[60:70, 3] = [0.0, -1.0, np.inf, 1e300, 1e-300, 10.0, 1.0, 5.0, 2.0, 3.0]
+    pars[70:80, 4] = [0.0, 1.0, -0.0, 1.0000001, np.inf, -np.inf, 0.5, 0.25, 0.75, 0.1]
+    pt = torch.as_tensor(np.ascontiguousarray(pars.T), device="cuda")
+    monkeypatch.setenv("ISOCHRONES_AMD_PATH", "auto")
+    ic.interp_mag_device(pt[:, :4].contiguous(), list(bands[:1]))      # interpolator handle built with packed tables
+    monkeypatch.setenv("ISOCHRONES_AMD_PATH", "generic")
+    ref = {}
+    for nb in (1, 2, 5, 8):
+        ref[nb] = [t.clone() for t in ic.interp_mag_device(pt, list(bands[:nb]))]
+    monkeypatch.setenv("ISOCHRONES_AMD_PATH", "auto")
+    for nb in (1, 2, 5, 8):
+        got = ic.interp_mag_device(pt, list(bands[:nb]))
+        for a, b, what in zip(got, ref[nb], ("Teff", "logg", "feh", "mags")):
+            fx.assert_close(a.cpu().numpy(), b.cpu().numpy(), 1e-12, atol=1e-12, what="%s nb=%d" % (what, nb))
+        small = ic.interp_mag_device(pt[:, :2000].contiguous(), list(bands[:nb]))     # pack exists -> packed kernel
+        assert torch.equal(torch.nan_to_num(small[3], nan=7.0), torch.nan_to_num(got[3][:2000], nan=7.0))
+    # more band lists than pack slots: earlier packs are dropped and rebuilt transparently
+    for k in range(8):
+        sel = [bands[k], bands[(k + 3) % 8]]
+        got = ic.interp_mag_device(pt, sel)
+        monkeypatch.setenv("ISOCHRONES_AMD_PATH", "generic")
+        want = ic.interp_mag_device(pt, sel)
+        monkeypatch.setenv("ISOCHRONES_AMD_PATH", "auto")
+        fx.assert_close(got[3].cpu().numpy(), want[3].cpu().numpy(), 1e-12, atol=1e-12, what="mags %s" % sel)
+    got = ic.interp_mag_device(pt, list(bands[:1]))
+    fx.assert_close(got[3].cpu().numpy(), ref[1][3].cpu().numpy(), 1e-12, atol=1e-12, what="mags after eviction")
+
+
 def test_size_independent_properties_large_batch():
     """10^6-sample batch: permutation equivariance, batch-split invariance, and exactness of
     interpolation on a table whose columns are affine in the coordinates."""
