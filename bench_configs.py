@@ -199,13 +199,16 @@ def primitives(n=1_000_000, reps=20):
         # algorithmic bytes: 8 corners x 4 columns + 16 corners x nb bands + 5 parameters in + 3 + nb out
         cases.append(("interp_mag_%d_bands" % nb, (lambda b=bands: ic.interp_mag_device(pars, b)),
                       8 * 4 * 8 + 16 * nb * 8 + 40 + 8 * (3 + nb)))
-    cases.append(("interp_value_18_cols", lambda: ic.model_grid.interp.interp_device([pars[2], pars[0], pars[1]], np.arange(18)),
-                  8 * 18 * 8 + 24 + 18 * 8))
+    ci = ic.model_grid.interp.column_index
+    for label, cols in (("18_cols", np.arange(18)), ("3_cols", np.array([ci["Teff"], ci["logg"], ci["age"]])),
+                        ("1_col", np.array([ci["radius"]]))):
+        kk = len(cols)
+        cases.append(("interp_value_" + label,
+                      (lambda c=cols: ic.model_grid.interp.interp_device([pars[2], pars[0], pars[1]], c)),
+                      8 * kk * 8 + 24 + kk * 8))
     for path in ("auto", "generic"):
         os.environ["ISOCHRONES_AMD_PATH"] = path
         for name, fn, nbytes in cases:
-            if path == "generic" and not name.startswith("interp_mag"):
-                continue
             fn(); torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()

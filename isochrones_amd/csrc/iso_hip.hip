@@ -227,6 +227,149 @@ __global__ __launch_bounds__(BLOCK) void k_interp(const InterpArgs A)
 }
 
 // -------------------------------------------------------------------------------------------
+// K3 on the "wide pack" of a 3-D table: layout [cell][column][corner 0..7] (corner bit2/bit1/bit0 = +1
+// on axis 0/1/2), i.e. the 8 corner values one column needs are one aligned 64-B piece.  A selected
+// column costs one such piece instead of 8 scattered rows, for any column subset; the price is 8x the
+// table in HBM (5.8 GB for the MIST track table - this part has 288 GB).  Built on the first large batch.
+//
+// One lane owns one sample for the bracket search and publishes (cell, t0, t1, t2) in a wave-private
+// LDS slot.  The wave's 64 x k (sample, column) units are then served by quads, 16 units per wave
+// instruction in row-major order of the output: each lane of a quad loads 16 B (two corners that
+// differ on axis 2), weights them, two DPP quad-permute adds finish the 8-corner sum, and the 16
+// results of a pass leave as one contiguous 128-B store.
+// -------------------------------------------------------------------------------------------
+struct WideArgs {
+    AxisD ax[3];
+    int64_t stride[3];
+    const double* wide;      // [ncells][ncol][8]
+    int ncol;
+    const double* x[3];
+    int64_t n;
+    int k;
+    uint64_t kinv;           // floor(2^32 / k) + 1: u / k == (u * kinv) >> 32 for u < 2^16 (k = 1: 2^32 + 1)
+    int lds_axes;            // doubles of staged axes
+    int32_t icols[ISO_MAX_COLS];
+    double* out;
+};
+
+struct PackWideArgs {
+    const double* grid;      // [n0][n1][n2][ncol]
+    double* out;
+    int64_t n0, n1, n2;
+    int ncol;
+};
+
+__global__ __launch_bounds__(BLOCK) void k_pack_wide(const PackWideArgs P)
+{
+    const int64_t total = P.n0 * P.n1 * P.n2 * P.ncol * 8;
+    for (int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x; e < total; e += (int64_t)gridDim.x * BLOCK) {
+        const int j = (int)(e & 7);
+        const int64_t r = e >> 3;
+        const int col = (int)(r % P.ncol);
+        const int64_t cell = r / P.ncol;
+        const int64_t i2 = cell % P.n2, i1 = (cell / P.n2) % P.n1, i0 = cell / (P.n2 * P.n1);
+        // the last cell of an axis is never a bracket's lower corner; its "+1" entries repeat the edge
+        const int64_t a0 = min(i0 + ((j >> 2) & 1), P.n0 - 1), a1 = min(i1 + ((j >> 1) & 1), P.n1 - 1),
+                      a2 = min(i2 + (j & 1), P.n2 - 1);
+        P.out[e] = P.grid[((a0 * P.n1 + a1) * P.n2 + a2) * P.ncol + col];
+    }
+}
+
+__device__ __forceinline__ double wide_dpp(double x, int which)
+{
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    if (which == 0) {
+        lo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, false);    // quad_perm [1,0,3,2]
+        hi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, false);
+    } else {
+        lo = __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xF, 0xF, false);    // quad_perm [2,3,0,1]
+        hi = __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xF, 0xF, false);
+    }
+    return __hiloint2double(hi, lo);
+}
+
+constexpr int WIDE_SLOT = 5;      // doubles per request slot (4 used; odd stride: conflict-free)
+constexpr int WIDE_UNROLL = 8;    // passes whose loads are in flight together
+
+__global__ __launch_bounds__(BLOCK) void k_interp3_wide(const WideArgs A)
+{
+    extern __shared__ double lds[];
+    stage_axes<3>(A.ax, lds);
+    int32_t* lcols = reinterpret_cast<int32_t*>(lds + A.lds_axes);
+    for (int j = threadIdx.x; j < A.k; j += BLOCK) lcols[j] = A.icols[j];
+    __syncthreads();
+    double* slots = lds + A.lds_axes + (ISO_MAX_COLS / 2) + (threadIdx.x >> 6) * 64 * WIDE_SLOT;
+    const int lane = threadIdx.x & 63;
+    const int64_t first = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) & ~(int64_t)63;   // the wave's first sample
+    const int64_t i = first + lane;
+    {
+        bool bad = i >= A.n;
+        double x[3] = {0.0, 0.0, 0.0};
+        if (!bad) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                x[d] = A.x[d][i];
+                bad |= (x[d] != x[d]);
+            }
+        }
+        if (!bad) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) bad |= out_of_axis(A.ax[d], lds, x[d]);
+        }
+        double t[3] = {0.0, 0.0, 0.0};
+        int64_t cell = -1;
+        if (!bad) {
+            cell = 0;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                int idx;
+                bracket(A.ax[d], lds, x[d], idx, t[d]);
+                cell += (int64_t)idx * A.stride[d];
+            }
+        }
+        double* mine = slots + lane * WIDE_SLOT;
+        mine[0] = __longlong_as_double(cell);
+        mine[1] = t[0];
+        mine[2] = t[1];
+        mine[3] = t[2];
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int j = lane & 3, grp = lane >> 2;
+    const int k = A.k;
+    const int here = (int)min((int64_t)64, A.n - first);       // samples of this wave
+    const int units = here * k;
+    double* __restrict__ out = A.out + first * k;
+    for (int u0 = 0; u0 < units; u0 += 16 * WIDE_UNROLL) {
+        double2 v[WIDE_UNROLL];
+        double wx[WIDE_UNROLL], wy[WIDE_UNROLL];
+        bool bad[WIDE_UNROLL];
+#pragma unroll
+        for (int r = 0; r < WIDE_UNROLL; ++r) {
+            const int u = min(u0 + 16 * r + grp, units - 1);
+            const int s = (int)(((uint64_t)(uint32_t)u * A.kinv) >> 32);      // u / k
+            const int c = u - s * k;
+            const double* rq = slots + s * WIDE_SLOT;
+            const long long cell = __double_as_longlong(rq[0]);
+            const double t0 = rq[1], t1 = rq[2], t2 = rq[3];
+            bad[r] = cell < 0;
+            const int64_t cc = bad[r] ? 0 : cell;
+            v[r] = *reinterpret_cast<const double2*>(A.wide + ((cc * A.ncol + lcols[c]) << 3) + 2 * j);
+            const double g = ((j & 2) ? t0 : (1 - t0)) * ((j & 1) ? t1 : (1 - t1));
+            wx[r] = g * (1 - t2);
+            wy[r] = g * t2;
+        }
+#pragma unroll
+        for (int r = 0; r < WIDE_UNROLL; ++r) {
+            double part = v[r].x * wx[r] + v[r].y * wy[r];
+            part += wide_dpp(part, 0);
+            part += wide_dpp(part, 1);
+            const int u = u0 + 16 * r + grp;
+            if (j == 0 && u < units) out[u] = bad[r] ? d_nan() : part;
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------
 // shared device pieces of K4 / K1+K2
 // -------------------------------------------------------------------------------------------
 
@@ -1198,6 +1341,47 @@ struct iso_eep_table {
 };
 
 namespace {
+// Wide pack of a 3-D table (see k_interp3_wide): built by the first batch of >= WIDE_BUILD_MIN_ROWS rows if
+// it fits the budget; 1 = available, 0 = use the column-parallel kernel, < 0 = error.
+const int64_t WIDE_USE_MIN_ROWS = 1024, WIDE_BUILD_MIN_ROWS = 32768;
+const size_t WIDE_MAX_BYTES = (size_t)32 << 30;
+
+int ensure_wide_pack(iso_table* t, int64_t n)
+{
+    std::lock_guard<std::mutex> lock(t->wide_mu);
+    if (t->d_wide) return 1;
+    if (t->wide_failed || n < WIDE_BUILD_MIN_ROWS) return 0;
+    const size_t bytes = (size_t)t->ncells * (size_t)t->shape[3] * 8 * sizeof(double);
+    if (bytes > WIDE_MAX_BYTES) {
+        t->wide_failed = true;
+        return 0;
+    }
+    double* w = nullptr;
+    hipError_t e = hipMalloc(&w, bytes);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        t->wide_failed = true;        // no room: keep using the column-parallel kernel
+        return 0;
+    }
+    PackWideArgs P;
+    P.grid = t->d_grid;
+    P.out = w;
+    P.n0 = t->shape[0]; P.n1 = t->shape[1]; P.n2 = t->shape[2];
+    P.ncol = (int)t->shape[3];
+    hipLaunchKernelGGL(k_pack_wide, dim3(grid_blocks((int64_t)(bytes / sizeof(double)))), dim3(BLOCK), 0, 0, P);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) {
+        (void)hipFree(w);
+        return fail(ISO_ERR_HIP, std::string("iso_interp: wide pack: ") + hipGetErrorString(e));
+    }
+    t->d_wide = w;
+    return 1;
+}
+
+}  // namespace
+
+namespace {
 void free_mag_pack(MagPack& mp);
 int acquire_mag_pack(iso_ic* ic, const int32_t* bc_cols, int nb, int64_t n, iso::FastArgs& F);
 }  // namespace
@@ -1249,6 +1433,8 @@ int iso_table_create(iso_ctx* ctx, int ndim, const int64_t* shape, const double*
     t->ndim = ndim;
     t->ncells = ncells;
     t->d_grid = nullptr;
+    t->d_wide = nullptr;
+    t->wide_failed = false;
     for (int d = 0; d < ISO_MAX_DIM; ++d) t->d_axes[d] = nullptr;
     for (int d = 0; d <= ndim; ++d) t->shape[d] = shape[d];
     const size_t bytes = (size_t)ncells * (size_t)shape[ndim] * sizeof(double);
@@ -1278,6 +1464,7 @@ void iso_table_destroy(iso_table* t)
     if (!t) return;
     DeviceGuard guard(t->device);
     if (t->d_grid) (void)hipFree(t->d_grid);
+    if (t->d_wide) (void)hipFree(t->d_wide);
     for (int d = 0; d < ISO_MAX_DIM; ++d)
         if (t->d_axes[d]) (void)hipFree(t->d_axes[d]);
     delete t;
@@ -1313,6 +1500,31 @@ int iso_interp(iso_table* t, const double* const* x, int64_t n, const int32_t* i
     }
     A.out = out;
     DeviceGuard guard(t->ctx->device);
+    if (t->ndim == 3 && path_mode() == PATH_AUTO && n >= WIDE_USE_MIN_ROWS) {
+        const int rc = ensure_wide_pack(t, n);
+        if (rc < 0) return rc;
+        if (rc == 1) {
+            WideArgs W;
+            std::memset(&W, 0, sizeof(W));
+            for (int d = 0; d < 3; ++d) {
+                W.ax[d] = A.ax[d];
+                W.stride[d] = A.stride[d];
+                W.x[d] = x[d];
+            }
+            W.wide = t->d_wide;
+            W.ncol = A.ncol;
+            W.n = n;
+            W.k = k;
+            W.kinv = ((uint64_t)1 << 32) / (uint64_t)k + 1;
+            W.lds_axes = lds;
+            for (int c = 0; c < k; ++c) W.icols[c] = A.icols[c];
+            W.out = out;
+            const size_t sh = (size_t)(lds + ISO_MAX_COLS / 2 + BLOCK * WIDE_SLOT) * sizeof(double);
+            hipLaunchKernelGGL(k_interp3_wide, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), sh, as_stream(stream), W);
+            HIP_TRY(hipGetLastError());
+            return ISO_OK;
+        }
+    }
     const int lanes_per_sample = (k + 1) / 2, samples_per_wave = 64 / lanes_per_sample;
     const int64_t waves = (n + samples_per_wave - 1) / samples_per_wave;
     const dim3 g(grid_blocks(waves * 64)), b(BLOCK);

@@ -125,6 +125,9 @@ struct iso_table {
     int64_t shape[ISO_MAX_DIM + 1];
     int64_t ncells;
     double* d_grid;
+    double* d_wide;          // 3-D tables: [cell][column][corner] pack for k_interp3_wide (lazy), may be null
+    bool wide_failed;        // do not try to build it again
+    std::mutex wide_mu;
     double* d_axes[ISO_MAX_DIM];
     std::vector<double> h_axes[ISO_MAX_DIM];
     iso::AxisD ax[ISO_MAX_DIM];

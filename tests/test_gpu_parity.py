@@ -176,6 +176,37 @@ def test_random_batch_vs_oracle(kind, n_stars, nb, kernel_path):
         fx.assert_close(m, wm, RTOL, atol=ATOL, what="mags")
 
 
+@pytest.mark.parametrize("k", [1, 2, 3, 7, 18, 40])
+def test_interp_wide_pack_matches_column_parallel_kernel(k, monkeypatch):
+    """3-D DFInterpolator batches >= 32768 rows build the [cell][column][corner] pack and use the
+    quad-per-(sample, column) kernel; it must agree with the column-parallel kernel (which the oracle
+    tests pin) for any column subset, incl. NaN cells, NaN / out-of-range / exact-node / upper-edge inputs."""
+    import torch
+    rng = np.random.default_rng(100 + k)
+    ax = [np.sort(rng.uniform(-2, 2, 11)), np.array([0.1, 0.2, 0.5, 0.9, 1.0, 1.5, 4.0]), np.arange(1.0, 201.0)]
+    ncol = 40
+    grid = rng.standard_normal((11, 7, 200, ncol))
+    grid[3:5, 2:4, 150:, :] = np.nan                       # ragged tail
+    grid[7, 5, 20, 11] = np.nan                            # a single missing value in one column
+    t = DFInterpolator.from_arrays(grid, ax, ["c%d" % j for j in range(ncol)])
+    n = 70_001                                             # last wave partially filled
+    x = [rng.uniform(a[0] - 0.02 * (a[-1] - a[0]), a[-1] + 0.02 * (a[-1] - a[0]), n) for a in ax]
+    for d in range(3):
+        x[d][d * 100:d * 100 + 50] = rng.choice(ax[d], 50)            # exact nodes (incl. first / last)
+        x[d][1000 + d] = np.nan
+    x[0][2000:2010], x[1][2000:2010], x[2][2000:2010] = ax[0][-1], ax[1][-1], ax[2][-1]   # upper corner
+    cols = list(rng.choice(ncol, size=k, replace=False))
+    xt = [torch.as_tensor(v, device="cuda") for v in x]
+    monkeypatch.setenv("ISOCHRONES_AMD_PATH", "generic")
+    want = t.interp_device(xt, np.array(cols)).cpu().numpy()
+    monkeypatch.setenv("ISOCHRONES_AMD_PATH", "auto")
+    got = t.interp_device(xt, np.array(cols)).cpu().numpy()
+    assert got.shape == (n, k) and np.isfinite(want).mean() > 0.5
+    fx.assert_close(got, want, 1e-12, atol=1e-12, what="wide pack k=%d" % k)
+    small = t.interp_device([v[:1500].contiguous() for v in xt], np.array(cols)).cpu().numpy()
+    assert np.array_equal(np.nan_to_num(small, nan=7.0), np.nan_to_num(got[:1500], nan=7.0))
+
+
 def test_interp_mag_packed_path_matches_generic_kernel(monkeypatch):
     """iso_interp_mag switches to the corner-packed tables for large batches (a pack per band list, built on
     first use, at most 6 kept): both kernels against each other on the same samples incl. NaN / out-of-range
