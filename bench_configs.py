@@ -183,6 +183,21 @@ def cfg4(nwalkers=256, nsteps=5000):
             "reference_published_estimate_s": [69e-6 * calls, 719e-6 * calls]}
 
 
+def nested(nlive=1000):
+    """fit_multinest on the cfg-2 star (full-size tables): batched nested sampling, one fused lnpost
+    launch per proposal batch.  The reference runs MultiNest with one Python lnpost call per point."""
+    import bench
+    ic, mod = bench.build_model()
+    mod.fit_multinest(n_live_points=200, seed=0)          # warm-up (tables, pinned staging)
+    t = time.perf_counter()
+    res = mod.fit_multinest(n_live_points=nlive, seed=1)
+    wall = time.perf_counter() - t
+    return {"config": "nested", "metric": "wall-clock of fit_multinest, %d live points, cfg-2 star" % nlive,
+            "wall_s": wall, "lnpost_evaluations": res.ncall, "iterations": res.niter, "efficiency": res.efficiency,
+            "logz": res.logz, "logz_err": res.logz_err, "prior_fraction_with_support": res.prior_fraction,
+            "reference_published_estimate_s": [69e-6 * res.ncall, 719e-6 * res.ncall]}
+
+
 def primitives(n=1_000_000, reps=20):
     """The batch primitives behind the public API: interp_mag with the 11 default bands
     (1 816 algorithmic B/sample) and interp_value of all 18 columns."""
@@ -320,7 +335,7 @@ def main():
     args = ap.parse_args()
     for name in args.configs.split(","):
         fn = {"cfg1": cfg1, "cfg3": cfg3, "cfg4": cfg4, "cfg5": lambda: cfg5(args.stars),
-              "primitives": primitives, "tree": tree}[name.strip()]
+              "primitives": primitives, "tree": tree, "nested": nested}[name.strip()]
         r = fn()
         if r is not None:
             print(json.dumps(r), flush=True)

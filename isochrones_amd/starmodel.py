@@ -40,7 +40,54 @@ class EEPPrior:
         self.orig_par = ic.eep_replaces
 
 
-class BasicStarModel:
+class _NestedFitMixin:
+    """``fit_multinest`` / ``evidence`` for any model with ``param_names``, ``bounds(par)`` and a
+    batched ``lnpost``: the reference hands ``mnest_loglike`` (= lnpost) and the flat-box ``mnest_prior``
+    to pymultinest (starmodel.py:717-802); here the same likelihood and prior drive the batched nested
+    sampler in isochrones_amd/nested.py, every proposal batch being one fused lnpost launch."""
+
+    def fit_multinest(self, n_live_points=1000, basename=None, verbose=False, refit=False, overwrite=False,
+                      test=False, evidence_tolerance=0.5, seed=0, **kwargs):
+        from .nested import nested_sample
+        names = list(self.param_names)
+        lo = np.array([self.bounds(nm)[0] for nm in names], dtype=float)
+        hi = np.array([self.bounds(nm)[1] for nm in names], dtype=float)
+        run_kwargs = dict(nlive=int(n_live_points), tol=float(evidence_tolerance), seed=seed)
+        run_kwargs.update({k: v for k, v in kwargs.items() if k in ("enlarge", "batch", "max_batch", "max_calls", "max_iter")})
+        if test:
+            print("nested_sample() with the following kwargs: {}".format(run_kwargs))
+            return None
+        res = nested_sample(lambda th: self.lnpost(np.ascontiguousarray(th)), lo, hi, **run_kwargs)
+        self._nested = res
+        self._samples = None
+        self._fit_kind = "nested"
+        if verbose:
+            print("logZ = %.3f +/- %.3f  (%d iterations, %d lnpost evaluations, efficiency %.3f)"
+                  % (res.logz, res.logz_err, res.niter, res.ncall, res.efficiency))
+        if basename is not None:                     # MultiNest's equal-weight posterior file: params..., loglike
+            import os
+            folder = os.path.dirname(os.path.abspath(basename))
+            os.makedirs(folder, exist_ok=True)
+            x, ll = res.equal_weight_samples(rng=np.random.default_rng(seed))
+            np.savetxt("{}post_equal_weights.dat".format(basename), np.column_stack([x, ll]))
+        return res
+
+    @property
+    def evidence(self):
+        """(log evidence, its error) of the last nested fit (reference starmodel.py:813-819)."""
+        if getattr(self, "_nested", None) is None:
+            raise AttributeError("fit_multinest must be run to access the evidence")
+        return (self._nested.logz, self._nested.logz_err)
+
+    def _nested_frame(self):
+        import pandas as pd
+        x, ll = self._nested.equal_weight_samples(rng=np.random.default_rng(0))
+        df = pd.DataFrame(x, columns=list(self.param_names))
+        df["lnprob"] = ll
+        return df
+
+
+class BasicStarModel(_NestedFitMixin):
     def __init__(self, ic, eep_bounds=None, name="", directory=".", N=1, maxAV=None, max_distance=None,
                  halo_fraction=None, ra=None, dec=None, obs=None, use_emcee=False, **kwargs):
         self._ic = ic
@@ -364,6 +411,7 @@ class BasicStarModel:
         sampler.run_mcmc(pos, niter, lnprob0=prob)
         self._sampler = sampler
         self._samples = None
+        self._fit_kind = "mcmc"
         return sampler
 
     fit = fit_mcmc
@@ -380,9 +428,13 @@ class BasicStarModel:
         and band magnitude of a single star via ``ic(...)``, reference starmodel.py:1653-1714)."""
         import pandas as pd
         if getattr(self, "_samples", None) is None:
-            chain = self.sampler.flatchain.cpu().numpy()
-            df = pd.DataFrame(chain, columns=list(self.param_names))
-            df["lnprob"] = self.sampler.flatlnprobability.cpu().numpy()
+            if getattr(self, "_fit_kind", "mcmc") == "nested":
+                df = self._nested_frame()
+                chain = df[list(self.param_names)].values
+            else:
+                chain = self.sampler.flatchain.cpu().numpy()
+                df = pd.DataFrame(chain, columns=list(self.param_names))
+                df["lnprob"] = self.sampler.flatlnprobability.cpu().numpy()
             if self.N == 1:
                 derived = self.ic(*[chain[:, j] for j in range(5)])
                 for c in derived.columns:
@@ -421,7 +473,7 @@ class TripleStarModel(BasicStarModel):
 # ==========================================================================================
 # generic (observation-tree) model — "next" row f4
 # ==========================================================================================
-class TreeStarModel:
+class TreeStarModel(_NestedFitMixin):
     """The reference's generic ``StarModel`` (isochrones/starmodel.py:63-661): photometry organised
     in an :class:`~isochrones_amd.observation.ObservationTree` (resolved and blended sources,
     relative photometry, several physical systems), evaluated on the device from the flattened
@@ -637,6 +689,71 @@ class TreeStarModel:
 
     def mnest_loglike(self, cube, ndim=None, nparams=None):
         return self.lnpost(cube)
+
+    # -- fits (reference: StarModel.fit_mcmc / fit_multinest, starmodel.py:717-972) --------------
+    def sample_from_prior(self, n, rng=None, max_tries=200):
+        """[n, n_params] uniform draws from the parameter box with a finite lnpost (EEPs of a system
+        in descending order, as the reference's mnest_prior sorts them)."""
+        rng = rng or np.random.default_rng()
+
+        def draw(m):
+            x = self.prior_transform(rng.random((m, self.n_params)))
+            i = 0
+            for sname in self.obs.systems:
+                k = self.obs.Nstars[sname]
+                x[:, i:i + k] = -np.sort(-x[:, i:i + k], axis=1)
+                i += 4 + k
+            return x
+
+        out = draw(n)
+        for _ in range(max_tries):
+            bad = ~np.isfinite(self.lnpost(out))
+            if not bad.any():
+                return out
+            out[bad] = draw(int(bad.sum()))
+        raise RuntimeError("could not find %d starting points with a finite lnpost" % n)
+
+    emcee_p0 = sample_from_prior
+
+    def fit_mcmc(self, nwalkers=300, nburn=200, niter=100, p0=None, seed=None, **kwargs):
+        """Stretch-move ensemble on the device; every half-step evaluates the tree kernel once."""
+        import torch
+        from .sampler import EnsembleSampler
+        rng = np.random.default_rng(seed)
+        if p0 is None:
+            p0 = self.sample_from_prior(nwalkers, rng=rng)
+        else:
+            p0 = rng.normal(size=(nwalkers, self.n_params)) * 0.01 + np.asarray(p0, dtype=float)[None, :]
+        sampler = EnsembleSampler(nwalkers, self.n_params, self.lnpost, seed=int(rng.integers(2 ** 62)),
+                                  device=torch.device("cuda", dev.current_device()))
+        pos, prob = sampler.run_mcmc(p0, nburn, store=False)
+        sampler.reset()
+        sampler.run_mcmc(pos, niter, lnprob0=prob)
+        self._sampler = sampler
+        self._samples = None
+        self._fit_kind = "mcmc"
+        return sampler
+
+    fit = fit_mcmc
+
+    @property
+    def sampler(self):
+        if getattr(self, "_sampler", None) is None:
+            raise AttributeError("MCMC must be run to access sampler")
+        return self._sampler
+
+    @property
+    def samples(self):
+        """Posterior samples (sampled parameters + lnprob) of the last fit."""
+        import pandas as pd
+        if getattr(self, "_samples", None) is None:
+            if getattr(self, "_fit_kind", "mcmc") == "nested":
+                self._samples = self._nested_frame()
+            else:
+                df = pd.DataFrame(self.sampler.flatchain.cpu().numpy(), columns=list(self.param_names))
+                df["lnprob"] = self.sampler.flatlnprobability.cpu().numpy()
+                self._samples = df
+        return self._samples
 
 
 def StarModel(ic, obs=None, **kwargs):

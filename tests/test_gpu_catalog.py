@@ -224,6 +224,46 @@ def test_persistent_sampler_binary_model_and_bad_mode(monkeypatch):
         fs.run_mcmc(p0, 2, lnprob0=lnp0)
 
 
+def test_fit_multinest_native_matches_mcmc_posterior(tmp_path):
+    """fit_multinest (reference starmodel.py:717-802) through the batched nested sampler: the posterior
+    agrees with the ensemble sampler's, the evidence is reproducible within its error, the equal-weight
+    file is written, and the evidence equals a brute-force Monte-Carlo integral of exp(lnpost) over the box."""
+    import torch
+    ic = _small_track(("G", "BP", "RP"))
+    truth = np.array([1.05, 330.0, -0.1, 200.0, 0.15])
+    T, g, f, mags = ic.interp_mag(truth, ["G", "BP", "RP"])
+    mod = ia.SingleStarModel(ic, Teff=(T, 80), logg=(g, 0.1), feh=(f, 0.1), G=(mags[0], 0.02), BP=(mags[1], 0.02),
+                             RP=(mags[2], 0.02), parallax=(1000 / truth[3], 0.1), max_distance=1000)
+    base = str(tmp_path / "chains" / "single-")
+    res = mod.fit_multinest(n_live_points=600, basename=base, seed=1)
+    logz, err = mod.evidence
+    assert np.isfinite(logz) and 0.02 < err < 0.5 and res.ncall < 5e7
+    post = np.loadtxt(base + "post_equal_weights.dat")
+    assert post.shape[1] == 6 and post.shape[0] > 200
+    s_nest = mod.samples
+    assert {"mass", "eep", "feh", "distance", "AV", "lnprob", "Teff", "G_mag"} <= set(s_nest.columns)
+    res2 = mod.fit_multinest(n_live_points=600, seed=2)
+    assert abs(res2.logz - logz) < 4 * np.hypot(err, res2.logz_err) + 0.05
+    # brute force: Z = mean over the prior box of exp(lnpost)
+    names = mod.param_names
+    lo = np.array([mod.bounds(nm)[0] for nm in names]); hi = np.array([mod.bounds(nm)[1] for nm in names])
+    c, w = s_nest[list(names)].mean().values, 6 * s_nest[list(names)].std().values
+    blo, bhi = np.maximum(lo, c - w), np.minimum(hi, c + w)          # importance box around the posterior
+    rng = np.random.default_rng(3)
+    x = torch.as_tensor(rng.uniform(blo, bhi, size=(4_000_000, 5)), device="cuda")
+    lp = mod.lnpost(x)
+    lp = torch.where(torch.isfinite(lp), lp, torch.full_like(lp, -float("inf")))
+    brute = float(torch.logsumexp(lp, 0)) - np.log(x.shape[0]) + np.sum(np.log((bhi - blo) / (hi - lo)))
+    assert abs(brute - logz) < 4 * err + 0.1, (brute, logz, err)
+    # posterior vs the ensemble sampler
+    mod.fit_mcmc(nwalkers=200, nburn=400, niter=200, seed=5)
+    s_mc = mod.samples
+    for nm in ("mass", "feh", "distance"):
+        sd = s_mc[nm].std()
+        assert abs(s_nest[nm].mean() - s_mc[nm].mean()) < 0.3 * sd, nm
+        assert abs(s_nest[nm].std() / sd - 1) < 0.3, nm
+
+
 # ---- "next" row f4: generic StarModel over an ObservationTree ---------------------------------
 from tests.test_tree_cpu import TREE_CASES, make_tree_model  # noqa: E402
 
