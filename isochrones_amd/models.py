@@ -118,6 +118,29 @@ class ModelGridInterpolator:
     def fehs(self):
         return self.model_grid.fehs
 
+    @property
+    def ages(self):
+        if self.eep_replaces != "mass":
+            raise AttributeError("Age is not a dimension of this model grid!")
+        return self.model_grid.ages
+
+    @property
+    def masses(self):
+        if self.eep_replaces != "age":
+            raise AttributeError("Mass is not a dimension of this model grid!")
+        return self.model_grid.masses
+
+    # companion grid of the other parametrisation (reference: EvolutionTrackInterpolator.iso /
+    # IsochroneInterpolator.track, models.py:676-709); set by the factories
+    _companion_factory = None
+
+    def _companion(self):
+        if getattr(self, "_companion_obj", None) is None:
+            if self._companion_factory is None:
+                raise ValueError("{} has no companion grid type".format(type(self).__name__))
+            self._companion_obj = self._companion_factory()
+        return self._companion_obj
+
     # -- device residency -------------------------------------------------------------------
     def handle(self, device=None):
         """iso_ic* for `device`: both tables uploaded once + packed hot-column table built."""
@@ -256,13 +279,53 @@ class ModelGridInterpolator:
             self._eep_handles[device] = h
         return h
 
+    def max_eep(self, mass, feh):
+        """Last populated EEP shared by the tracks that bracket (mass, feh) (reference: models.py:498,
+        mist/eep.py hard-codes the MIST values; here it is read off the table)."""
+        if self.eep_replaces != "age":
+            raise NotImplementedError("max_eep needs the evolution-track parametrisation")
+        self._eep_handle(dev.current_device())
+        dfi = self.model_grid.interp
+        fehs, masses, eeps = dfi.index_columns
+        i = int(np.clip(np.searchsorted(fehs, feh, side="right") - 1, 0, fehs.size - 2))
+        j = int(np.clip(np.searchsorted(masses, mass, side="right") - 1, 0, masses.size - 2))
+        L = self._array_lengths.reshape(fehs.size, masses.size)[i:i + 2, j:j + 2]
+        return float(eeps[int(L.min()) - 1]) if L.min() > 0 else float("nan")
+
+    def mass_age_resid(self, eep, mass, age, feh):
+        raise NotImplementedError
+
+    def get_eep_accurate(self, mass, age, feh, eep0=300, resid_tol=0.02, method="nelder-mead", return_object=False,
+                         return_nan=False, **kwargs):
+        """Nelder-Mead refinement of the EEP against ``mass_age_resid`` (reference: models.py:544-578; a
+        host-side scalar loop over the device interpolator, as in the reference)."""
+        from scipy.optimize import minimize
+        eeps_to_try = [min(self.max_eep(mass, feh) - 20, 600), 100, 200]
+        while np.isnan(self.mass_age_resid(eep0, mass, age, feh)):
+            try:
+                eep0 = eeps_to_try.pop()
+            except IndexError:
+                if return_nan:
+                    return np.nan
+                raise ValueError("eep0 gives nan for all initial guesses! {}".format((mass, age, feh)))
+        result = minimize(lambda e: self.mass_age_resid(float(np.ravel(e)[0]), mass, age, feh), eep0, method=method,
+                          options=kwargs)
+        if return_object:
+            return result
+        if result.success and result.fun < resid_tol ** 2:
+            return float(np.ravel(result.x)[0])
+        if return_nan:
+            return np.nan
+        raise RuntimeError("EEP minimization not successful: {}".format((mass, age, feh)))
+
     def get_eep(self, mass, age, feh, accurate=False, **kwargs):
         """EEP of a star of given (mass, log10 age, feh): bilinear blend over the four neighbouring
         tracks of the first EEP whose age exceeds ``age`` (reference ``interp_eep(s)``).  Scalars
-        -> float, arrays -> numpy, CUDA tensors -> CUDA tensor.  ``accurate=True`` (the reference's
-        Nelder-Mead refinement) is not provided."""
+        -> float, arrays -> numpy, CUDA tensors -> CUDA tensor.  ``accurate=True`` refines a scalar
+        result with :meth:`get_eep_accurate` starting from the fast estimate, as the reference."""
         if accurate:
-            raise NotImplementedError("get_eep(accurate=True) is out of scope (host-side scipy minimisation)")
+            eep0 = self.get_eep(mass, age, feh)
+            return self.get_eep_accurate(mass, age, feh, eep0=eep0 if np.isfinite(eep0) else 300, **kwargs)
         args = [mass, age, feh]
         if any(dev.is_tensor(a) and a.is_cuda for a in args):
             import torch
@@ -363,6 +426,13 @@ class EvolutionTrackInterpolator(ModelGridInterpolator):
     _param_index_order = (2, 0, 1, 3, 4)
     kind = _cabi.KIND_TRACK
 
+    @property
+    def iso(self):
+        return self._companion()
+
+    def mass_age_resid(self, eep, mass, age, feh):
+        return (age - self.interp_value([mass, eep, feh], ["age"])) ** 2
+
 
 class IsochroneInterpolator(ModelGridInterpolator):
     """(eep, age, feh, distance, AV) over an (age, feh, eep) table — reference: models.py:691-718"""
@@ -370,6 +440,27 @@ class IsochroneInterpolator(ModelGridInterpolator):
     eep_replaces = "mass"
     _param_index_order = (1, 2, 0, 3, 4)
     kind = _cabi.KIND_ISO
+
+    @property
+    def track(self):
+        return self._companion()
+
+    def mass_age_resid(self, eep, mass, age, feh):
+        return (mass - self.interp_value([eep, age, feh], ["initial_mass"])) ** 2
+
+    def max_eep(self, mass, feh):
+        return self.track.max_eep(mass, feh)
+
+    def get_eep(self, mass, age, feh, accurate=False, **kwargs):
+        """Fast estimate from the companion track grid (reference: IsochroneInterpolator delegates to
+        ``self.track``), optionally refined against this grid's own initial_mass column."""
+        eep0 = self.track.get_eep(mass, age, feh)
+        if not accurate:
+            return eep0
+        return self.get_eep_accurate(mass, age, feh, eep0=eep0 if np.isfinite(eep0) else 300, **kwargs)
+
+    def generate(self, *args, **kwargs):
+        return self.track.generate(*args, **kwargs)
 
 
 # ------------------------------------------------------------------------------------------
@@ -388,7 +479,10 @@ def synthetic_track(bands=grids.DEFAULT_BANDS, fehs=None, masses=None, eeps=None
     g, ax, cols = grids.synthetic_track_grid(fehs, masses, eeps, ragged=ragged)
     mg = EvolutionTrackGrid(DFInterpolator.from_arrays(g, ax, cols, ["initial_feh", "initial_mass", "EEP"]),
                             limits=limits)
-    return EvolutionTrackInterpolator(mg, _bc(bands, bc_axes), bands=bands, eep_bounds=eep_bounds)
+    ic = EvolutionTrackInterpolator(mg, _bc(bands, bc_axes), bands=bands, eep_bounds=eep_bounds)
+    if fehs is None and masses is None and eeps is None:          # full-size tables: the companion is well defined
+        ic._companion_factory = lambda: synthetic_isochrone(bands, bc_axes=bc_axes)
+    return ic
 
 
 def synthetic_isochrone(bands=grids.DEFAULT_BANDS, ages=None, fehs=None, eeps=None, bc_axes=None,
@@ -397,7 +491,10 @@ def synthetic_isochrone(bands=grids.DEFAULT_BANDS, ages=None, fehs=None, eeps=No
     g, ax, cols = grids.synthetic_iso_grid(ages, fehs, eeps, ragged=ragged)
     mg = IsochroneGrid(DFInterpolator.from_arrays(g, ax, cols, ["log10_isochrone_age_yr", "feh", "EEP"]),
                        limits=limits)
-    return IsochroneInterpolator(mg, _bc(bands, bc_axes), bands=bands, eep_bounds=eep_bounds)
+    ic = IsochroneInterpolator(mg, _bc(bands, bc_axes), bands=bands, eep_bounds=eep_bounds)
+    if ages is None and fehs is None and eeps is None:
+        ic._companion_factory = lambda: synthetic_track(bands, bc_axes=bc_axes)
+    return ic
 
 
 def get_ichrone(models="mist", bands=None, tracks=False, **kwargs):

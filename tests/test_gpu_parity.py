@@ -324,8 +324,18 @@ def test_get_eep_and_generate():
     assert {"Teff", "logg", "age", "G_mag", "distance", "requested_age"} <= set(df.columns) and len(df) == 50
     T = ic.interp_value([m[ok], want[ok], f[ok]], ["Teff"])[:, 0]
     fx.assert_close(df["Teff"].values, T, 1e-12, what="generate Teff")
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError):           # an isochrone grid asks its companion track grid (reference: .track)
         ia.synthetic_isochrone(bands=("G",), ages=[9.0, 9.5], fehs=[-0.5, 0.0], eeps=np.arange(1., 9.)).get_eep(1.0, 9.2, 0.0)
+    # accurate=True: Nelder-Mead on (age - age(eep))^2 from the fast estimate (reference models.py:544-578)
+    for j in ok[:3]:
+        e = ic.get_eep(float(m[j]), float(a[j]), float(f[j]), accurate=True)
+        assert abs(ic.interp_value([float(m[j]), e, float(f[j])], ["age"])[0] - a[j]) < 0.02
+        assert 1.0 <= e <= ic.max_eep(float(m[j]), float(f[j]))
+    assert np.isclose(ic.mass_age_resid(want[ok[0]], m[ok[0]], a[ok[0]], f[ok[0]]),
+                      (a[ok[0]] - ic.interp_value([m[ok[0]], want[ok[0]], f[ok[0]]], ["age"])[0]) ** 2)
+    assert ic.masses is ic.model_grid.masses
+    with pytest.raises(AttributeError):
+        ic.ages
 
 
 def test_ingest_derived_columns():
