@@ -33,11 +33,26 @@ class EEPPrior:
     """Marker for the EEP prior: pdf(eep) = orig_prior(orig(eep)) * d(orig)/d(eep), evaluated on
     the device by interpolating (age, dt_deep) or (mass, dm_deep) (reference: priors.py:409-429)."""
 
-    def __init__(self, ic, orig_prior, bounds=None):
+    def __init__(self, ic, orig_prior, bounds=None, owner=None):
         self.ic = ic
-        self.orig_prior = orig_prior
+        self._owner = owner
+        self._orig_prior = orig_prior
         self.bounds = tuple(bounds) if bounds is not None else tuple(ic.eep_bounds)
         self.orig_par = ic.eep_replaces
+
+    # As in the reference, the EEP term keeps the prior object it was built with: set_prior() on the
+    # parameter EEP replaces does not reach it (starmodel.py:1447 + :629-632); assigning this attribute does.
+    @property
+    def orig_prior(self):
+        return self._orig_prior
+
+    @orig_prior.setter
+    def orig_prior(self, prior):
+        if not isinstance(prior, DEVICE_PRIOR_TYPES):
+            raise NotImplementedError("prior %r is not evaluable on the device" % (prior,))
+        self._orig_prior = prior
+        if self._owner is not None:
+            self._owner._dirty()
 
 
 class _NestedFitMixin:
@@ -116,7 +131,7 @@ class BasicStarModel(_NestedFitMixin):
 
         self._priors = {"mass": ChabrierPrior(), "feh": FehPrior(), "age": AgePrior(),
                         "distance": DistancePrior(), "AV": AVPrior()}
-        self._priors["eep"] = EEPPrior(ic, self._priors[ic.eep_replaces], bounds=eep_bounds)
+        self._priors["eep"] = EEPPrior(ic, self._priors[ic.eep_replaces], bounds=eep_bounds, owner=self)
         self._bounds = {"mass": None, "feh": None, "age": None,
                         "distance": self._priors["distance"].bounds, "AV": self._priors["AV"].bounds,
                         "eep": self._priors["eep"].bounds}
@@ -194,8 +209,6 @@ class BasicStarModel(_NestedFitMixin):
                 raise NotImplementedError("prior %r for %r is not evaluable on the device" % (prior, prop))
             self._priors[prop] = prior
             self._bounds[prop] = prior.bounds
-            if prop == self.ic.eep_replaces:
-                self._priors["eep"].orig_prior = prior
         self._dirty()
 
     def model_desc(self) -> _cabi.IsoModelDesc:
@@ -226,7 +239,9 @@ class BasicStarModel(_NestedFitMixin):
                 d.dnu_val = self.kwargs["delta_nu"][0]
                 d.dnu_unc = self.kwargs["delta_nu"][0]
         for name in ("mass", "age", "feh", "distance", "AV"):
-            setattr(d, "prior_" + name, self._priors[name].desc())
+            # the parameter EEP replaces only enters through the EEP term, with the EEP prior's own object
+            pr = self._priors["eep"].orig_prior if name == self.ic.eep_replaces else self._priors[name]
+            setattr(d, "prior_" + name, pr.desc())
         d.eep_lo, d.eep_hi = self._priors["eep"].bounds
         for j, par in enumerate(self.param_names):
             d.bound_lo[j], d.bound_hi[j] = self.bounds(par)
@@ -523,7 +538,7 @@ class TreeStarModel(_NestedFitMixin):
                     obs.add_spectroscopy(label="0_{}".format(m.group(2)), **{m.group(1): v})
         self._priors = {"mass": ChabrierPrior(), "feh": FehPrior(), "age": AgePrior(),
                         "distance": DistancePrior(), "AV": AVPrior()}
-        self._priors["eep"] = EEPPrior(ic, self._priors["mass"], bounds=eep_bounds)
+        self._priors["eep"] = EEPPrior(ic, self._priors["mass"], bounds=eep_bounds, owner=self)
         self._bounds = {"mass": None, "feh": None, "age": None, "distance": self._priors["distance"].bounds,
                         "AV": self._priors["AV"].bounds, "eep": self._priors["eep"].bounds}
         if maxAV is not None:
@@ -601,7 +616,8 @@ class TreeStarModel(_NestedFitMixin):
         for j, prop in enumerate(("age", "feh", "distance", "AV")):
             d.bound_lo[j], d.bound_hi[j] = self.bounds(prop)        # also snaps feh/age priors to the table
         for name in ("mass", "age", "feh", "distance", "AV"):
-            setattr(d, "prior_" + name, self._priors[name].desc())
+            pr = self._priors["eep"].orig_prior if name == "mass" else self._priors[name]
+            setattr(d, "prior_" + name, pr.desc())
         d.eep_lo, d.eep_hi = self._priors["eep"].bounds
         return d
 

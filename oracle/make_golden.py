@@ -134,7 +134,25 @@ OBS = {
 }
 
 
-def run_model_case(name, kind, n_stars, obs_key, model_table, bc_table, rng, n_wide, n_ball, extra_kw=None):
+def _ref_prior(spec):
+    """("Gaussian", mean, sigma, lo, hi) etc. -> a prior object of the REFERENCE (isochrones/priors.py)."""
+    pr = rh.ref("priors")
+    fam, args = spec[0], list(spec[1:])
+    if fam == "Gaussian":
+        return pr.GaussianPrior(args[0], args[1], bounds=tuple(args[2:4]) if len(args) == 4 else None)
+    if fam == "LogNormal":
+        return pr.LogNormalPrior(args[0], args[1])
+    if fam == "Flat":
+        return pr.FlatPrior(tuple(args))
+    if fam == "FlatLog":
+        return pr.FlatLogPrior(tuple(args))
+    if fam == "PowerLaw":
+        return pr.PowerLawPrior(args[0], tuple(args[1:3]))
+    raise ValueError(fam)
+
+
+def run_model_case(name, kind, n_stars, obs_key, model_table, bc_table, rng, n_wide, n_ball, extra_kw=None,
+                   priors=None, eep_orig_prior=None):
     sm = rh.ref("starmodel")
     limits = limits_of(kind, model_table[1])
     axes = model_table[1]
@@ -144,6 +162,10 @@ def run_model_case(name, kind, n_stars, obs_key, model_table, bc_table, rng, n_w
     obs = dict(OBS[obs_key])
     kw = dict(extra_kw or {})
     mod = cls(ic, **obs, **kw)
+    if priors:                     # StarModel.set_prior (starmodel.py:629-632)
+        mod.set_prior(**{k: _ref_prior(v) for k, v in priors.items()})
+    if eep_orig_prior:             # the prior the EEP term transforms (priors.py:409-429) is an attribute
+        mod._priors["eep"].orig_prior = _ref_prior(eep_orig_prior)
     pars = sample_pars(rng, kind, n_stars, axes, n_wide, n_ball)
     n = pars.shape[0]
     lnprior, lnlike, lnpost = np.empty(n), np.empty(n), np.empty(n)
@@ -175,13 +197,16 @@ def run_model_case(name, kind, n_stars, obs_key, model_table, bc_table, rng, n_w
             [prim[good, j] for j in range(5)], list(BANDS))
     cube = rng.random((16, n_stars + 4))
     cube_out = cube.copy()
-    for row in cube_out:
-        mod.mnest_prior(row, None, None)
-    meta = dict(kind=kind, n_stars=n_stars, obs={k: list(map(float, v)) for k, v in obs.items()}, kwargs=kw,
+    with np.errstate(all="ignore"):
+        for row in cube_out:
+            mod.mnest_prior(row, None, None)
+    custom = bool(priors or eep_orig_prior)
+    meta = dict(priors=priors or {}, eep_orig_prior=eep_orig_prior, kind=kind, n_stars=n_stars, obs={k: list(map(float, v)) for k, v in obs.items()}, kwargs=kw,
                 limits={k: list(map(float, v)) for k, v in limits.items()}, eep_bounds=list(map(float, eep_bounds)),
                 bands=list(BANDS), model_columns=list(model_table[2]), interp_value_cols=pcols,
                 param_names=list(mod.param_names),
-                mass_norms=list(map(float, mod._priors["mass"].norms)), feh_norm=float(mod._priors["feh"]._norm),
+                mass_norms=[] if custom else list(map(float, mod._priors["mass"].norms)),
+                feh_norm=float("nan") if custom else float(mod._priors["feh"]._norm),
                 distance_bounds=list(map(float, mod.bounds("distance"))), AV_bounds=list(map(float, mod.bounds("AV"))))
     out = dict(meta=json.dumps(meta), pars=pars, lnprior=lnprior, lnlike=lnlike, lnpost=lnpost,
                interp_value=np.asarray(vals), Teff=Teff, logg=logg, feh=feh, mags=mags,
@@ -410,7 +435,33 @@ def run_isotrack_case():
                                                        np.isnan(lnpost).sum()))
 
 
+def run_prior_cases(rng=None):
+    """Non-default prior families through set_prior (every family the device evaluates), including the
+    reference's quirk that set_prior on the parameter EEP replaces does NOT reach the EEP term (EEP_prior
+    keeps the object it was built with, starmodel.py:1447 + :629-632), and the explicit re-assignment of
+    EEP_prior.orig_prior that does."""
+    rng = rng or np.random.default_rng(20240808)
+    trk, iso, bc = small_track(), small_iso(), small_bc()
+    run_model_case("track_single_custom_priors", "track", 1, "spec_phot_plx", trk, bc, rng, 250, 250,
+                   priors=dict(mass=("LogNormal", float(np.log(1.0)), 0.4), age=("Gaussian", 9.6, 0.3, 8.0, 10.1),
+                               feh=("Flat", -1.5, 0.4), distance=("Gaussian", 150.0, 60.0, 1.0, 600.0),
+                               AV=("PowerLaw", 0.5, 0.0, 1.0)))
+    run_model_case("track_single_eep_orig_prior", "track", 1, "phot_only", trk, bc, rng, 150, 150,
+                   priors=dict(mass=("PowerLaw", -2.35, 0.1, 10.0), AV=("Gaussian", 0.2, 0.1, 0.0, 1.0)),
+                   eep_orig_prior=("Gaussian", 9.6, 0.3, 8.0, 10.1))
+    run_model_case("iso_binary_custom_priors", "iso", 2, "phot6_plx", iso, bc, rng, 250, 250,
+                   priors=dict(mass=("PowerLaw", -2.35, 0.1, 10.0), age=("Flat", 8.5, 10.1),
+                               feh=("Gaussian", -0.2, 0.3, -1.0, 0.5), distance=("LogNormal", float(np.log(300.0)), 0.5),
+                               AV=("Gaussian", 0.2, 0.1, 0.0, 1.0)),
+                   eep_orig_prior=("LogNormal", float(np.log(0.9)), 0.5))
+    run_model_case("iso_single_flatlog_age", "iso", 1, "spec_only", iso, bc, rng, 100, 100,
+                   priors=dict(age=("FlatLog", 8.0, 10.0), distance=("PowerLaw", 2.0, 0.0, 500.0)))
+
+
 def main():
+    if "--only-priors" in sys.argv:
+        run_prior_cases()
+        return
     if "--only-isotrack" in sys.argv:
         run_isotrack_case()
         return
@@ -444,6 +495,7 @@ def main():
     run_eep_case()
     run_tree_cases()
     run_isotrack_case()
+    run_prior_cases()
 
 
 if __name__ == "__main__":

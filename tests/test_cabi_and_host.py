@@ -82,6 +82,10 @@ def test_prior_norms_match_reference_and_closed_forms():
     for case in fx.MODEL_CASES:
         meta = fx.load(case)["meta"]
         mod = fx.make_model(meta)
+        assert tuple(mod.bounds("distance")) == tuple(meta["distance_bounds"])
+        assert tuple(mod.bounds("AV")) == tuple(meta["AV_bounds"])
+        if meta.get("priors") or meta.get("eep_orig_prior"):
+            continue                                   # default-prior constants below
         assert np.allclose(mod._priors["mass"].norms, meta["mass_norms"], rtol=1e-13)
         assert np.isclose(mod._priors["feh"]._norm, meta["feh_norm"], rtol=1e-13)
         assert tuple(mod.bounds("distance")) == tuple(meta["distance_bounds"])
