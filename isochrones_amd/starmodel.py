@@ -573,6 +573,16 @@ class TreeStarModel(_NestedFitMixin):
             self._dirty()
         return self._bounds[prop]
 
+    def set_prior(self, **kwargs):
+        """reference: StarModel.set_prior (starmodel.py:629-632); as there, the EEP term keeps the mass prior it
+        was built with (assign ``_priors["eep"].orig_prior`` to change it)."""
+        for prop, prior in kwargs.items():
+            if prop == "eep" or not isinstance(prior, DEVICE_PRIOR_TYPES):
+                raise NotImplementedError("prior %r for %r is not evaluable on the device" % (prior, prop))
+            self._priors[prop] = prior
+            self._bounds[prop] = prior.bounds
+        self._dirty()
+
     def set_bounds(self, **kwargs):
         for k, v in kwargs.items():
             if len(v) != 2:
