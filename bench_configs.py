@@ -183,6 +183,27 @@ def cfg4(nwalkers=256, nsteps=5000):
             "reference_published_estimate_s": [69e-6 * calls, 719e-6 * calls]}
 
 
+def astero(n=1_000_000, reps=50):
+    """cfg-2 star plus asteroseismic constraints (nu_max, delta_nu; reference starmodel.py:1603-1612):
+    fast kernel with the extra 128-B (nu_max, delta_nu) cell vs the generic kernel."""
+    import torch
+    import bench
+    import isochrones_amd as ia
+    out = {}
+    for path in ("auto", "generic"):
+        os.environ["ISOCHRONES_AMD_PATH"] = path
+        ic = ia.synthetic_track(bands=("V",))
+        mod = ia.SingleStarModel(ic, Teff=(5770, 100), logg=(4.5, 0.1), feh=(0.0, 0.15), V=(10.0, 0.05),
+                                 nu_max=(3000.0, 100.0), delta_nu=(135.0, 3.0))
+        pars = bench.make_samples(np.random.default_rng(12345), n, "prior_valid")
+        pt = torch.as_tensor(np.ascontiguousarray(pars.T), device="cuda")
+        ms, res = _time_kernel(mod, pt, reps)
+        out[path] = {"kernel_ms": ms, "evals_per_s": n / (ms * 1e-3), "finite_fraction": float(torch.isfinite(res).double().mean())}
+        del mod, ic
+    os.environ.pop("ISOCHRONES_AMD_PATH", None)
+    return {"config": "astero", "metric": "lnpost evals/s with nu_max + delta_nu terms, 1e6 batch", "bytes_per_eval": 560 + 128, **out}
+
+
 def nested(nlive=1000):
     """fit_multinest on the cfg-2 star (full-size tables): batched nested sampling, one fused lnpost
     launch per proposal batch.  The reference runs MultiNest with one Python lnpost call per point."""
@@ -335,7 +356,7 @@ def main():
     args = ap.parse_args()
     for name in args.configs.split(","):
         fn = {"cfg1": cfg1, "cfg3": cfg3, "cfg4": cfg4, "cfg5": lambda: cfg5(args.stars),
-              "primitives": primitives, "tree": tree, "nested": nested}[name.strip()]
+              "primitives": primitives, "tree": tree, "nested": nested, "astero": astero}[name.strip()]
         r = fn()
         if r is not None:
             print(json.dumps(r), flush=True)

@@ -448,6 +448,51 @@ __device__ __forceinline__ void coop_star(const FastArgs& A, const CoopLds& L, b
     __builtin_amdgcn_wave_barrier();
 }
 
+// One column pair of the model table on its own corner-packed array ([cell][8 corners][2], 128 B per cell:
+// the asteroseismic (nu_max, delta_nu) pair): same protocol as coop_star with two 16-B loads per lane.
+__device__ __forceinline__ void coop_pair(const double* __restrict__ tab, const CoopLds& L, bool need, uint32_t cell,
+                                          const W3& w, double* __restrict__ v)
+{
+    double* mine = L.req + L.lane * L.stride;
+    mine[0] = __hiloint2double(need ? 1 : 0, (int)cell);
+    mine[1] = w.t0;
+    mine[2] = w.t1;
+    mine[3] = w.t2;
+    __builtin_amdgcn_wave_barrier();
+    const unsigned long long m = __ballot(need);
+    const int j = L.lane & 3, grp = L.lane >> 2;
+    double2 lo[4], hi[4];
+    double wlo[4], whi[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const double* rq = L.req + (16 * k + grp) * L.stride;
+        const double hdr = rq[0];
+        const double t0 = rq[1], t1 = rq[2], t2 = rq[3];
+        const bool nd = __double2hiint(hdr) != 0;
+        const uint32_t c = nd ? (uint32_t)__double2loint(hdr) : 0u;
+        const double2* __restrict__ pc = reinterpret_cast<const double2*>(tab + (size_t)c * 16) + j;
+        lo[k] = pc[0];
+        hi[k] = pc[4];
+        const double g = ((j & 2) ? t1 : (1 - t1)) * ((j & 1) ? t2 : (1 - t2));
+        wlo[k] = nd ? (1 - t0) * g : 0.0;
+        whi[k] = nd ? t0 * g : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (((m >> (16 * k)) & 0xFFFFull) == 0) continue;                      // wave-uniform
+        const double a = quad_sum(lo[k].x * wlo[k] + hi[k].x * whi[k]);
+        const double b = quad_sum(lo[k].y * wlo[k] + hi[k].y * whi[k]);
+        double* rs = L.rsp + (16 * k + grp) * L.stride;
+        if (j == 0) rs[0] = a;
+        if (j == 1) rs[1] = b;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const double* rs = L.rsp + L.lane * L.stride;
+    v[0] = need ? rs[0] : f_nan();
+    v[1] = need ? rs[1] : f_nan();
+    __builtin_amdgcn_wave_barrier();
+}
+
 // BC table: lane j of a quad handles the corners whose (axis-1, axis-2) offsets are the bits of j
 template <int NB>
 __device__ __forceinline__ void coop_bc(const FastArgs& A, const CoopLds& L, bool need, uint32_t cell, const W4& w,
@@ -508,7 +553,7 @@ __device__ __forceinline__ void coop_bc(const FastArgs& A, const CoopLds& L, boo
 // lnpost of the lane's sample (p = its NS+4 parameters).  Shared by the batch kernel and the
 // sampler kernel.  With PACKED every gather is wave-cooperative, so ALL 64 lanes of the wave must
 // call this function together; `active` = the lane really has a sample (inactive lanes only help).
-template <int KIND, int NS, int NB, bool PACKED>
+template <int KIND, int NS, int NB, bool PACKED, bool ASTERO = false>
 __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* lds, const CoopLds& L, bool active,
                                               const DevModel& M, const double* __restrict__ p, bool want_parts,
                                               double& lnp_out, double& lnl_out)
@@ -526,6 +571,7 @@ __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* l
         lds_bracket2(lds, A.m0, A.m1, x0, x1, i0, i1, w.t0, w.t1);
     }
     double star[NS][6];
+    double astero[2] = {0.0, 0.0};
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         const double eep = (KIND == ISO_KIND_TRACK) ? p[1] : p[s];
@@ -535,6 +581,9 @@ __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* l
         if (PACKED) {
             const uint32_t cell = (uint32_t)((int64_t)i0 * A.s0 + (int64_t)i1 * A.s1 + i2);
             coop_star(A, L, ok, cell, w, star[s]);
+            // asteroseismic pair of the primary (reference starmodel.py:1603-1612); a separate instantiation,
+            // because even a never-taken branch here costs the common kernel registers (measured: +29 %)
+            if (ASTERO && s == 0) coop_pair(A.astq, L, ok && M.has_numax, cell, w, astero);
         } else if (ok) {
             gather_star<false>(A, i0, i1, i2, w, star[s]);
         } else {
@@ -617,6 +666,14 @@ __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* l
         const double r = M.plx_val - 1000.0 / dist;
         lnl += M.plx_g0 - r * r * M.plx_hinv;
     }
+    if (ASTERO && M.has_numax) {
+        const double r = M.numax_val - astero[0];
+        lnl += M.numax_g0 - r * r * M.numax_hinv;
+        if (M.has_dnu) {
+            const double r2 = M.dnu_val - astero[1];
+            lnl += M.dnu_g0 - r2 * r2 * M.dnu_hinv;
+        }
+    }
     lnl_out = go ? lnl : f_nan();
     return prior_ok ? lnp + lnl : -f_inf();
 }
@@ -640,7 +697,7 @@ __device__ __forceinline__ CoopLds coop_lds(double* lds, int axes_len)
 // (88 -> 80 VGPR, a few dwords of scratch; measured +2 %), otherwise whatever the kernel needs
 constexpr int fast_min_waves(int ns, int nb) { return (ns == 1 && nb <= 2) ? 6 : 4; }
 
-template <int KIND, int NS, int NB, bool PACKED, bool MULTI>
+template <int KIND, int NS, int NB, bool PACKED, bool MULTI, bool ASTERO = false>
 __global__ __launch_bounds__(BLOCK, fast_min_waves(NS, NB)) void k_lnpost_fast(const FastArgs A)
 {
     extern __shared__ double lds[];
@@ -659,7 +716,7 @@ __global__ __launch_bounds__(BLOCK, fast_min_waves(NS, NB)) void k_lnpost_fast(c
         for (int j = 0; j < NP; ++j) p[j] = src[j * A.stride_p];
     }
     double lnp, lnl;
-    const double r = lnpost_wave<KIND, NS, NB, PACKED>(A, lds, L, active, M, p, A.lnlike != nullptr, lnp, lnl);
+    const double r = lnpost_wave<KIND, NS, NB, PACKED, ASTERO>(A, lds, L, active, M, p, A.lnlike != nullptr, lnp, lnl);
     if (active) {
         if (A.lnpost) A.lnpost[i] = r;
         if (A.lnprior) A.lnprior[i] = lnp;
@@ -876,24 +933,24 @@ inline bool launch_stretch_nb(int nb, const FastArgs& A, const StretchArgs& S, h
     }
 }
 
-template <int KIND, int NS, bool PACKED, bool MULTI>
+template <int KIND, int NS, bool PACKED, bool MULTI, bool ASTERO = false>
 inline bool launch_nb(int nb, const FastArgs& A, hipStream_t s)
 {
     const dim3 g((unsigned)((A.n + BLOCK - 1) / BLOCK)), b(BLOCK);
     auto sh = [&](int n) { return (size_t)(((A.axes_len + 1) & ~1) + (PACKED ? coop_lds_doubles(n) : 0)) * sizeof(double); };
     switch (nb) {
-    case 1: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 1, PACKED, MULTI>), g, b, sh(1), s, A); return true;
-    case 2: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 2, PACKED, MULTI>), g, b, sh(2), s, A); return true;
-    case 3: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 3, PACKED, MULTI>), g, b, sh(3), s, A); return true;
-    case 4: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 4, PACKED, MULTI>), g, b, sh(4), s, A); return true;
-    case 5: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 5, PACKED, MULTI>), g, b, sh(5), s, A); return true;
-    case 6: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 6, PACKED, MULTI>), g, b, sh(6), s, A); return true;
-    case 7: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 7, PACKED, MULTI>), g, b, sh(7), s, A); return true;
-    case 8: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 8, PACKED, MULTI>), g, b, sh(8), s, A); return true;
-    case 9: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 9, PACKED, MULTI>), g, b, sh(9), s, A); return true;
-    case 10: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 10, PACKED, MULTI>), g, b, sh(10), s, A); return true;
-    case 11: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 11, PACKED, MULTI>), g, b, sh(11), s, A); return true;
-    case 12: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 12, PACKED, MULTI>), g, b, sh(12), s, A); return true;
+    case 1: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 1, PACKED, MULTI, ASTERO>), g, b, sh(1), s, A); return true;
+    case 2: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 2, PACKED, MULTI, ASTERO>), g, b, sh(2), s, A); return true;
+    case 3: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 3, PACKED, MULTI, ASTERO>), g, b, sh(3), s, A); return true;
+    case 4: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 4, PACKED, MULTI, ASTERO>), g, b, sh(4), s, A); return true;
+    case 5: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 5, PACKED, MULTI, ASTERO>), g, b, sh(5), s, A); return true;
+    case 6: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 6, PACKED, MULTI, ASTERO>), g, b, sh(6), s, A); return true;
+    case 7: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 7, PACKED, MULTI, ASTERO>), g, b, sh(7), s, A); return true;
+    case 8: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 8, PACKED, MULTI, ASTERO>), g, b, sh(8), s, A); return true;
+    case 9: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 9, PACKED, MULTI, ASTERO>), g, b, sh(9), s, A); return true;
+    case 10: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 10, PACKED, MULTI, ASTERO>), g, b, sh(10), s, A); return true;
+    case 11: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 11, PACKED, MULTI, ASTERO>), g, b, sh(11), s, A); return true;
+    case 12: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 12, PACKED, MULTI, ASTERO>), g, b, sh(12), s, A); return true;
     default: return false;
     }
 }
@@ -905,6 +962,7 @@ inline bool launch_nb(int nb, const FastArgs& A, hipStream_t s)
 #define ISO_DEFINE_FAST_LAUNCHER(NAME, KIND, NS)                                              \
     bool NAME(int nb, bool packed, bool multi, const FastArgs& A, hipStream_t s)              \
     {                                                                                         \
+        if (A.astq) return packed && !multi && fastk::launch_nb<KIND, NS, true, false, true>(nb, A, s); \
         if (multi) return packed && fastk::launch_nb<KIND, NS, true, true>(nb, A, s);         \
         return packed ? fastk::launch_nb<KIND, NS, true, false>(nb, A, s)                     \
                       : fastk::launch_nb<KIND, NS, false, false>(nb, A, s);                   \

@@ -1108,7 +1108,7 @@ __global__ __launch_bounds__(BLOCK) void k_pack_bc(const PackBcArgs A)
 
 struct PackCornersArgs {
     const double* src;      // compact table, `ncol` doubles per cell
-    int ncol, keep;         // keep the first `keep` columns of every corner (BC: keep = ncol = n_bands)
+    int ncol, keep, col0;   // keep columns col0 .. col0+keep-1 of every corner (BC: col0 = 0, keep = ncol = n_bands)
     int ndim;               // 3 (model table) or 4 (BC table)
     int64_t n[4];           // axis lengths
     int64_t ncells;
@@ -1117,7 +1117,8 @@ struct PackCornersArgs {
 
 // Corner-packed layout: every cell carries its own 2^D corners, ordered so that 4 cooperating lanes
 // read 64 contiguous bytes per load instruction (see iso_fast_kernel.h).
-//   ndim 3: double index e = 2*(4k + j) + comp  ->  corner c = 4*(k/3) + j, column 2*(k%3) + comp
+//   ndim 3: double index e = 2*(4k + j) + comp  ->  corner c = 4*(k/P) + j, column col0 + 2*(k%P) + comp,
+//           P = keep/2 column pairs (3 for the model table, 1 for the asteroseismic pair)
 //   ndim 4: double index e = 2*((k*NB + band)*4 + j) + comp  ->  axis-0 offset k, (axis-1, axis-2)
 //           offsets = bits of j, axis-3 offset comp
 __global__ __launch_bounds__(BLOCK) void k_pack_corners(const PackCornersArgs A)
@@ -1130,8 +1131,9 @@ __global__ __launch_bounds__(BLOCK) void k_pack_corners(const PackCornersArgs A)
         const int comp = r & 1, piece = r >> 1, j = piece & 3, kk = piece >> 2;
         int off[4], col;
         if (A.ndim == 3) {
-            off[0] = kk / 3; off[1] = (j >> 1) & 1; off[2] = j & 1; off[3] = 0;
-            col = 2 * (kk % 3) + comp;
+            const int pairs = A.keep >> 1;
+            off[0] = kk / pairs; off[1] = (j >> 1) & 1; off[2] = j & 1; off[3] = 0;
+            col = A.col0 + 2 * (kk % pairs) + comp;
         } else {
             off[0] = kk / A.keep; off[1] = (j >> 1) & 1; off[2] = j & 1; off[3] = comp;
             col = kk % A.keep;
@@ -1290,12 +1292,13 @@ PathMode path_mode()
 
 constexpr int FAST_MAX_BLOB = 4096;   // doubles (32 KiB of LDS) the fast kernel may stage
 
-hipError_t pack_corners(const double* src, int ncol, int keep, int ndim, const int64_t* n, double** out)
+hipError_t pack_corners(const double* src, int ncol, int keep, int ndim, const int64_t* n, double** out, int col0 = 0)
 {
     PackCornersArgs P;
     P.src = src;
     P.ncol = ncol;
     P.keep = keep;
+    P.col0 = col0;
     P.ndim = ndim;
     P.ncells = 1;
     for (int d = 0; d < 4; ++d) P.n[d] = 1;
@@ -1604,6 +1607,7 @@ int iso_ic_create(iso_ctx* ctx, iso_table* model_grid, iso_table* bc_grid, int k
     for (int d = 0; d < 3; ++d) ic->h_axes_model[d] = model_grid->h_axes[d];
     for (int d = 0; d < 4; ++d) ic->h_axes_bc[d] = bc_grid->h_axes[d];
     ic->d_hotq = nullptr;
+    ic->d_astq = nullptr;
     // (cell indices travel as 32-bit integers through the cooperative gather)
     if (path_mode() == PATH_AUTO && model_grid->ax[2].uniform && model_grid->ncells < (int64_t(1) << 31) &&
         bc_grid->ncells < (int64_t(1) << 31)) {
@@ -1624,6 +1628,7 @@ void iso_ic_destroy(iso_ic* ic)
     DeviceGuard guard(ic->device);
     if (ic->d_hot) (void)hipFree(ic->d_hot);
     if (ic->d_hotq) (void)hipFree(ic->d_hotq);
+    if (ic->d_astq) (void)hipFree(ic->d_astq);
     for (MagPack& mp : ic->mag_packs) free_mag_pack(mp);
     delete ic;
 }
@@ -1729,9 +1734,9 @@ void fill_dev_model(const iso_model_desc* desc, int kind, DevModel& H)
     H.plx_val = desc->plx_val;
     gauss_consts(desc->plx_unc, H.plx_g0, H.plx_unc2, &H.plx_hinv);
     H.numax_val = desc->numax_val;
-    gauss_consts(desc->numax_unc, H.numax_g0, H.numax_unc2);
+    gauss_consts(desc->numax_unc, H.numax_g0, H.numax_unc2, &H.numax_hinv);
     H.dnu_val = desc->dnu_val;
-    gauss_consts(desc->dnu_unc, H.dnu_g0, H.dnu_unc2);
+    gauss_consts(desc->dnu_unc, H.dnu_g0, H.dnu_unc2, &H.dnu_hinv);
     H.prior_mass = make_dev_prior(desc->prior_mass);
     H.prior_age = make_dev_prior(desc->prior_age);
     H.prior_feh = make_dev_prior(desc->prior_feh);
@@ -1766,8 +1771,9 @@ hipError_t pack_bands(const iso_ic* ic, const int32_t* bc_cols, int nb, double**
 
 bool fast_eligible(const iso_ic* ic, const iso_model_desc* desc)
 {
-    return path_mode() != PATH_GENERIC && desc->n_bands >= 1 && desc->n_bands <= 12 && !desc->has_numax &&
-           ic->model->ax[2].uniform;
+    // asteroseismic terms are only on the corner-packed form of the fast path
+    return path_mode() != PATH_GENERIC && desc->n_bands >= 1 && desc->n_bands <= 12 &&
+           (!desc->has_numax || (path_mode() == PATH_AUTO && ic->d_hotq)) && ic->model->ax[2].uniform;
 }
 
 // staged axes (+ reciprocal spacings) and, when the interpolator has a corner-packed model table,
@@ -1810,6 +1816,7 @@ hipError_t build_fast(const iso_ic* ic, int nb, const double* d_bc_hot, double**
     F.axes_len = (int)blob.size();
     F.hot = ic->d_hot;
     F.hotq = ic->d_hotq;
+    F.astq = nullptr;          // set by iso_model_create for asteroseismic models
     F.s0 = ic->g3.s0; F.s1 = ic->g3.s1;
     F.bc = d_bc_hot;
     F.bcq = *d_bcq;
@@ -1914,6 +1921,19 @@ int iso_model_create(iso_ic* ic, const iso_model_desc* desc, iso_model** out)
     if (e == hipSuccess && fast_eligible(ic, desc)) {
         e = build_fast(ic, desc->n_bands, m->d_bc_hot, &m->d_axes_blob, &m->d_bcq, m->fast, &m->fast_ok);
         m->fast.m = m->d_model;
+        if (e == hipSuccess && m->fast_ok && desc->has_numax) {
+            // (nu_max, delta_nu) = hot columns 6, 7, corner-packed once per interpolator (128 B per cell)
+            std::lock_guard<std::mutex> lock(ic->mag_mu);
+            if (!ic->d_astq && m->d_bcq) {
+                hipError_t e2 = pack_corners(ic->d_hot, HOT_COLS, 2, 3, ic->model->shape, &ic->d_astq, 6);
+                if (e2 != hipSuccess) {
+                    ic->d_astq = nullptr;
+                    (void)hipGetLastError();
+                }
+            }
+            m->fast.astq = ic->d_astq;
+            if (!m->fast.astq || !m->d_bcq) m->fast_ok = false;     // generic kernel
+        }
     }
     if (e != hipSuccess) {
         std::string msg = std::string("iso_model_create: ") + hipGetErrorString(e);
@@ -2397,7 +2417,7 @@ int iso_sampler_create_model(iso_model* m, int nwalkers, double a, uint64_t seed
 {
     if (!m || !out) return fail(ISO_ERR_INVALID, "iso_sampler_create_model: NULL argument");
     if (nwalkers < 2 || (nwalkers & 1) || !(a > 1.0)) return fail(ISO_ERR_INVALID, "iso_sampler_create_model: need an even walker count and a > 1");
-    if (!m->fast_ok || !m->fast.hotq || !m->fast.bcq)
+    if (!m->fast_ok || !m->fast.hotq || !m->fast.bcq || m->fast.astq)
         return fail(ISO_ERR_INVALID, "iso_sampler_create_model: the model is not on the corner-packed fast path "
                                      "(needs 1-12 bands, uniform EEP axis, ISOCHRONES_AMD_PATH=auto)");
     iso_sampler* sp = new (std::nothrow) iso_sampler();

@@ -60,8 +60,8 @@ struct DevModel {
     double mag_hinv[ISO_MAX_BANDS];  // 0.5/(unc*unc)
     double spec_val[3], spec_g0[3], spec_unc2[3], spec_hinv[3];
     double plx_val, plx_g0, plx_unc2, plx_hinv;
-    double numax_val, numax_g0, numax_unc2;
-    double dnu_val, dnu_g0, dnu_unc2;
+    double numax_val, numax_g0, numax_unc2, numax_hinv;
+    double dnu_val, dnu_g0, dnu_unc2, dnu_hinv;
     DevPrior prior_mass, prior_age, prior_feh, prior_distance, prior_AV;
     double eep_lo, eep_hi;
     double bound_lo[ISO_MAX_PARAMS], bound_hi[ISO_MAX_PARAMS];
@@ -82,6 +82,8 @@ struct FastArgs {
     int axes_len;                    // doubles
     const double* hot;               // compact hot table [n0][n1][n2][HOT_COLS]
     const double* hotq;              // corner-packed [n0][n1][n2][8 corners][PACK_COLS] (or null)
+    const double* astq;              // corner-packed (nu_max, delta_nu) [cell][8 corners][2], null unless the
+                                     // model has asteroseismic terms
     int64_t s0, s1;
     const double* bc;                // BC restricted to the model's bands [..][nb]
     const double* bcq;               // corner-packed BC [cells][16 corners][nb] (or null)
@@ -152,6 +154,8 @@ struct iso_ic {
     int32_t cols[4], prior_cols[2], astero_cols[2];
     double* d_hot;
     double* d_hotq;          // corner-packed model table (fast path), may be null
+    double* d_astq;          // corner-packed (nu_max, delta_nu) for the fast kernel, built by the first
+                             // asteroseismic model (guarded by mag_mu)
     iso::Grid3V g3;
     iso::Grid4V g4;          // full BC table view
     int lds_doubles;         // LDS staging size for model + BC axes (generic kernels)

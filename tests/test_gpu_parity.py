@@ -248,6 +248,43 @@ def test_interp_mag_packed_path_matches_generic_kernel(monkeypatch):
     fx.assert_close(got[3].cpu().numpy(), ref[1][3].cpu().numpy(), 1e-12, atol=1e-12, what="mags after eviction")
 
 
+@pytest.mark.parametrize("kind,n_stars,nb,dnu", [("track", 1, 2, True), ("iso", 1, 1, False), ("iso", 2, 5, True)])
+def test_asteroseismic_terms_fast_kernel_vs_oracle(kind, n_stars, nb, dnu, kernel_path):
+    """nu_max / delta_nu terms (starmodel.py:1603-1612; delta_nu uses its VALUE as the uncertainty) on every
+    kernel path — on `auto` through the ASTERO instantiation of the fused kernel with its own
+    corner-packed (nu_max, delta_nu) table — against the oracle, incl. the parts and the scalar form."""
+    rng = np.random.default_rng(4000 + n_stars + nb)
+    ic, mod0, lo, hi = _random_model(kind, n_stars, ia.grids.DEFAULT_BANDS[:nb], rng)
+    kw = dict(mod0.kwargs)
+    kw["nu_max"] = (2000.0, 150.0)
+    if dnu:
+        kw["delta_nu"] = (100.0, 3.0)
+    mod = ia.BasicStarModel(ic, N=n_stars, **kw)
+    d = mod.model_desc()
+    assert d.has_numax == 1 and d.has_dnu == int(dnu)
+    n = 120_000
+    span = hi - lo
+    pars = rng.uniform(lo - 0.02 * span, hi + 0.02 * span, size=(n, lo.size))
+    pars[:40, 0] = np.nan
+    if n_stars > 1:
+        pars[: n // 2, :n_stars] = -np.sort(-pars[: n // 2, :n_stars], axis=1)
+    oic = fx.make_oracle_ic(ic)
+    w_post, w_prior, w_like = oic.lnpost(d, pars.T.copy(), nthreads=8)
+    assert np.isfinite(w_post).sum() > n // 50
+    fx.assert_close(mod.lnpost(pars), w_post, RTOL, atol=ATOL, what="lnpost")
+    fx.assert_close(mod.lnlike(pars), w_like, RTOL, atol=ATOL, what="lnlike")
+    fx.assert_close(mod.lnprior(pars), w_prior, RTOL, atol=ATOL, what="lnprior")
+    k = int(np.flatnonzero(np.isfinite(w_post))[0])
+    assert np.isclose(mod.lnpost(pars[k]), w_post[k], rtol=RTOL)
+    # the terms really are in: the same model without them differs
+    assert not np.allclose(mod0.lnpost(pars[k:k + 1]), w_post[k:k + 1])
+    # sampling an asteroseismic model works (framework-op sampler around the same kernel)
+    if kind == "track" and kernel_path == "auto":
+        good = pars[np.isfinite(w_post)][:64]
+        s = mod.fit_mcmc(nwalkers=64, nburn=5, niter=5, p0=None if len(good) < 64 else good[0], seed=1)
+        assert s.chain.shape[1] == 5
+
+
 def test_size_independent_properties_large_batch():
     """10^6-sample batch: permutation equivariance, batch-split invariance, and exactness of
     interpolation on a table whose columns are affine in the coordinates."""
