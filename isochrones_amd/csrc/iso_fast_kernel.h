@@ -893,24 +893,25 @@ template <int KIND, int NS>
 inline bool launch_stretch_nb(int nb, const FastArgs& A, const StretchArgs& S, hipStream_t s)
 {
     const dim3 b(BLOCK);
-    if (S.nsteps > 0) {                                       // persistent: one workgroup per ensemble
+    if (S.nsteps > 0) {                                       // persistent: workgroups own whole ensembles
         const int64_t n_ens = S.n_active / (S.W >> 1);
         const int G = persist_group(S.W);
         const dim3 gp((unsigned)((n_ens + G - 1) / G));
         auto shp = [&](int n) { return stretch_persist_lds_bytes(A.axes_len, n, S.W, NS + 4); };
         switch (nb) {
-        case 1: hipLaunchKernelGGL((k_stretch_persist<KIND, NS, 1>), gp, b, shp(1), s, A, S); return true;
-        case 2: hipLaunchKernelGGL((k_stretch_persist<KIND, NS, 2>), gp, b, shp(2), s, A, S); return true;
-        case 3: hipLaunchKernelGGL((k_stretch_persist<KIND, NS, 3>), gp, b, shp(3), s, A, S); return true;
-        case 4: hipLaunchKernelGGL((k_stretch_persist<KIND, NS, 4>), gp, b, shp(4), s, A, S); return true;
-        case 5: hipLaunchKernelGGL((k_stretch_persist<KIND, NS, 5>), gp, b, shp(5), s, A, S); return true;
-        case 6: hipLaunchKernelGGL((k_stretch_persist<KIND, NS, 6>), gp, b, shp(6), s, A, S); return true;
-        case 7: hipLaunchKernelGGL((k_stretch_persist<KIND, NS, 7>), gp, b, shp(7), s, A, S); return true;
-        case 8: hipLaunchKernelGGL((k_stretch_persist<KIND, NS, 8>), gp, b, shp(8), s, A, S); return true;
-        case 9: hipLaunchKernelGGL((k_stretch_persist<KIND, NS, 9>), gp, b, shp(9), s, A, S); return true;
-        case 10: hipLaunchKernelGGL((k_stretch_persist<KIND, NS, 10>), gp, b, shp(10), s, A, S); return true;
-        case 11: hipLaunchKernelGGL((k_stretch_persist<KIND, NS, 11>), gp, b, shp(11), s, A, S); return true;
-        case 12: hipLaunchKernelGGL((k_stretch_persist<KIND, NS, 12>), gp, b, shp(12), s, A, S); return true;
+        // with S.occupancy_query set: report resident workgroups per CU of this instantiation, launch nothing
+#define ISO_PERSIST_CASE(N)                                                                               \
+        case N:                                                                                           \
+            if (S.occupancy_query)                                                                        \
+                return hipOccupancyMaxActiveBlocksPerMultiprocessor(S.occupancy_query,                    \
+                                                                    k_stretch_persist<KIND, NS, N>, BLOCK, \
+                                                                    shp(N)) == hipSuccess;                \
+            hipLaunchKernelGGL((k_stretch_persist<KIND, NS, N>), gp, b, shp(N), s, A, S);                 \
+            return true;
+            ISO_PERSIST_CASE(1) ISO_PERSIST_CASE(2) ISO_PERSIST_CASE(3) ISO_PERSIST_CASE(4) ISO_PERSIST_CASE(5)
+            ISO_PERSIST_CASE(6) ISO_PERSIST_CASE(7) ISO_PERSIST_CASE(8) ISO_PERSIST_CASE(9) ISO_PERSIST_CASE(10)
+            ISO_PERSIST_CASE(11) ISO_PERSIST_CASE(12)
+#undef ISO_PERSIST_CASE
         default: return false;
         }
     }

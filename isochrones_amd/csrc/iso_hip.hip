@@ -2440,7 +2440,6 @@ int iso_sampler_create_catalog(iso_catalog* c, int nwalkers, double a, uint64_t 
 
 void iso_sampler_destroy(iso_sampler* s) { delete s; }
 
-static const size_t LDS_BYTES_PER_CU = 160 * 1024;     // gfx950
 
 int iso_sampler_run(iso_sampler* sp, double* pos, double* lnp, int nsteps, double* chain, double* chain_lnp,
                     int32_t* accepted, void* stream)
@@ -2451,6 +2450,7 @@ int iso_sampler_run(iso_sampler* sp, double* pos, double* lnp, int nsteps, doubl
     hipStream_t s = as_stream(stream);
     const int64_t rows = sp->n_ensembles * sp->W;
     StretchArgs S;
+    S.occupancy_query = nullptr;
     S.pos = pos;
     S.lnp = lnp;
     S.accepted = accepted;
@@ -2471,12 +2471,19 @@ int iso_sampler_run(iso_sampler* sp, double* pos, double* lnp, int nsteps, doubl
     const bool fits = lds_bytes <= 64 * 1024;
     if (mode == "persistent" && !fits)
         return fail(ISO_ERR_INVALID, "iso_sampler_run: ensemble too large for the persistent kernel's LDS");
-    // auto: persistent while every workgroup of the launch is resident at once (LDS-limited occupancy);
-    // beyond that its workgroups would run in rounds and the step-wise form has the better throughput
-    int cus = 0;
+    // auto: persistent while every workgroup of the launch is resident at once (occupancy of this kernel
+    // instantiation as the runtime reports it); beyond that its workgroups would run in rounds and the
+    // step-wise form has the better throughput
+    int cus = 0, per_cu = 0;
     HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, sp->device));
     const int64_t blocks = (sp->n_ensembles + group - 1) / group;
-    const int64_t resident = (int64_t)cus * std::max<int64_t>(1, (int64_t)(LDS_BYTES_PER_CU / lds_bytes));
+    if (fits && mode == "auto") {
+        S.nsteps = 1;
+        S.occupancy_query = &per_cu;
+        if (!launch_stretch(sp->kind, sp->n_stars, sp->n_bands, sp->fast, S, s)) per_cu = 0;
+        S.occupancy_query = nullptr;
+    }
+    const int64_t resident = (int64_t)cus * per_cu;
     const bool persistent = nsteps > 0 && fits && (mode == "persistent" || (mode == "auto" && blocks <= resident));
     if (persistent) {
         S.step = sp->step;

@@ -112,6 +112,7 @@ struct StretchArgs {
                           // iterations in one launch (chain slabs then advance by n_rows per iteration)
     double* chain_pos;    // optional: this step's [n_rows][n_params] slab of the stored chain
     double* chain_lnp;    // optional: this step's [n_rows] slab
+    int* occupancy_query; // host side only, persistent form: non-null = report workgroups/CU, do not launch
 };
 
 }  // namespace iso

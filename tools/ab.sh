@@ -4,4 +4,4 @@ python tools/sampler_modes.py 2>&1 | python -c "
 import json,sys
 for l in sys.stdin:
     if l.startswith('{'):
-        d=json.loads(l); print(d['stars'], d['walkers'], round(d['stepwise_us_per_step'],1), round(d['persistent_us_per_step'],1))"
+        d=json.loads(l); print(d['stars'], d['walkers'], round(d['stepwise_us_per_step'],1), round(d['persistent_us_per_step'],1), round(d['auto_us_per_step'],1))"

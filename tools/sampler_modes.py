@@ -17,8 +17,9 @@ def main():
     from isochrones_amd.sampler import FusedEnsembleSampler
     ic = ia.get_ichrone("mist", bands=["G", "BP", "RP"], tracks=True)
     cases = [(1, 256, 2000), (1, 64, 2000), (16, 32, 1000), (256, 32, 500), (1024, 32, 250), (2048, 32, 250),
-             (4096, 32, 250), (10000, 32, 250), (1024, 128, 250)]
-    cat, _ = synthetic_catalog(ic, 10000, bands=["G", "BP", "RP"], seed=3, mag_unc=0.01)
+             (4096, 32, 250), (6000, 32, 250), (8192, 32, 250), (10000, 32, 250), (12288, 32, 250), (16384, 32, 250),
+             (1024, 128, 250)]
+    cat, _ = synthetic_catalog(ic, 16384, bands=["G", "BP", "RP"], seed=3, mag_unc=0.01)
     for S, W, nsteps in cases:
         post = CatalogPosterior.from_catalog(cat, ic, N=1, indices=np.arange(S))
         pos, lnp, failed = initial_positions(post, W, rng_seed=1)
@@ -28,7 +29,7 @@ def main():
             pos[failed] = pos[src]
             lnp[failed] = lnp[src]
         out = {"stars": S, "walkers": W, "nsteps": nsteps}
-        for mode in ("stepwise", "persistent"):
+        for mode in ("stepwise", "persistent", "auto"):
             os.environ["ISOCHRONES_AMD_SAMPLER"] = mode
             fs = FusedEnsembleSampler(post, W, seed=2)
             fs.run_mcmc(pos, 10, lnprob0=lnp, store=False)
