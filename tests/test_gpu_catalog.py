@@ -264,6 +264,23 @@ def test_fit_multinest_native_matches_mcmc_posterior(tmp_path):
         assert abs(s_nest[nm].std() / sd - 1) < 0.3, nm
 
 
+def test_reference_test_fits_flow(tmp_path):
+    """reference tests/test_fits.py:27-31,79-100 with its own (tiny) settings: StarModel(ic, **props) ->
+    fit_mcmc(nburn=20, niter=20, ninitial=20) -> samples; fit_multinest(n_live_points=5, max_iter=50, basename=...)."""
+    ic = ia.get_ichrone("mist", bands=["J", "K"])
+    props = dict(Teff=(5800, 100), logg=(4.5, 0.1), J=(3.58, 0.05), K=(3.22, 0.05))
+    mod = ia.StarModel(ic, **props)
+    mod.fit_mcmc(nburn=20, niter=20, ninitial=20, seed=3)
+    s = mod.samples
+    assert len(s) == 300 * 20 and np.isfinite(s["lnprob"]).all()
+    assert {"eep", "age", "feh", "distance", "AV", "Teff", "logg", "J_mag", "K_mag"} <= set(s.columns)
+    base = str(tmp_path / "chains" / "123456-")
+    res = mod.fit_multinest(n_live_points=5, max_iter=50, basename=base, verbose=False, seed=4)
+    assert res.niter <= 50 and np.isfinite(res.logz)
+    assert len(mod.samples) >= 1 and np.isfinite(mod.samples["lnprob"]).all()
+    assert len(np.atleast_2d(np.loadtxt(base + "post_equal_weights.dat"))) >= 1
+
+
 # ---- "next" row f4: generic StarModel over an ObservationTree ---------------------------------
 from tests.test_tree_cpu import TREE_CASES, make_tree_model  # noqa: E402
 
