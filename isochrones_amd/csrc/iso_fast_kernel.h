@@ -626,41 +626,43 @@ __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* l
         }
     }
     const double dm = fma(ld, 5.0 * kInvLn10, -5.0);   // 5*log10(d/10)
-    double tot[NB];
-    const bool okA = go && !(AV != AV) && !lds_oob(lds, A.b3, AV);
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        const double T = star[s][0], g = star[s][1], f = star[s][2];
-        const bool ok = okA && !(T != T) && !(g != g) && !(f != f) && !lds_oob(lds, A.b0, T) &&
-                        !lds_oob(lds, A.b1, g) && !lds_oob(lds, A.b2, f);
-        double bc[NB];
-        int j0 = 0, j1 = 0, j2 = 0, j3 = 0;
-        W4 w4v;
-        w4v.t0 = w4v.t1 = w4v.t2 = w4v.t3 = 0.0;
-        if (ok) {
-            lds_bracket4(lds, A.b0, A.b1, A.b2, A.b3, T, g, f, AV, j0, j1, j2, j3, w4v.t0, w4v.t1, w4v.t2, w4v.t3);
+    if constexpr (NB > 0) {          // NB = 0: spectroscopy / parallax only, the BC table is never touched
+        double tot[NB];
+        const bool okA = go && !(AV != AV) && !lds_oob(lds, A.b3, AV);
+    #pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const double T = star[s][0], g = star[s][1], f = star[s][2];
+            const bool ok = okA && !(T != T) && !(g != g) && !(f != f) && !lds_oob(lds, A.b0, T) &&
+                            !lds_oob(lds, A.b1, g) && !lds_oob(lds, A.b2, f);
+            double bc[NB];
+            int j0 = 0, j1 = 0, j2 = 0, j3 = 0;
+            W4 w4v;
+            w4v.t0 = w4v.t1 = w4v.t2 = w4v.t3 = 0.0;
+            if (ok) {
+                lds_bracket4(lds, A.b0, A.b1, A.b2, A.b3, T, g, f, AV, j0, j1, j2, j3, w4v.t0, w4v.t1, w4v.t2, w4v.t3);
+            }
+            if (PACKED) {
+                const uint32_t cell = (uint32_t)((int64_t)j0 * A.bs0 + (int64_t)j1 * A.bs1 + (int64_t)j2 * A.bs2 + j3);
+                coop_bc<NB>(A, L, ok, cell, w4v, bc);
+            } else if (ok) {
+                gather_bc<NB, false>(A, j0, j1, j2, j3, w4v, bc);
+            } else {
+    #pragma unroll
+                for (int b = 0; b < NB; ++b) bc[b] = f_nan();
+            }
+    #pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const double mag = star[s][3] + dm - bc[b];
+                if (NS == 1) tot[b] = mag;
+                else tot[b] = (s == 0 ? 0.0 : tot[b]) + exp10(-0.4 * mag);
+            }
         }
-        if (PACKED) {
-            const uint32_t cell = (uint32_t)((int64_t)j0 * A.bs0 + (int64_t)j1 * A.bs1 + (int64_t)j2 * A.bs2 + j3);
-            coop_bc<NB>(A, L, ok, cell, w4v, bc);
-        } else if (ok) {
-            gather_bc<NB, false>(A, j0, j1, j2, j3, w4v, bc);
-        } else {
-#pragma unroll
-            for (int b = 0; b < NB; ++b) bc[b] = f_nan();
-        }
-#pragma unroll
+    #pragma unroll
         for (int b = 0; b < NB; ++b) {
-            const double mag = star[s][3] + dm - bc[b];
-            if (NS == 1) tot[b] = mag;
-            else tot[b] = (s == 0 ? 0.0 : tot[b]) + exp10(-0.4 * mag);
+            const double mag = (NS == 1) ? tot[b] : -2.5 * log10(tot[b]);
+            const double r = M.mag_val[b] - mag;
+            lnl += M.mag_g0[b] - r * r * M.mag_hinv[b];
         }
-    }
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        const double mag = (NS == 1) ? tot[b] : -2.5 * log10(tot[b]);
-        const double r = M.mag_val[b] - mag;
-        lnl += M.mag_g0[b] - r * r * M.mag_hinv[b];
     }
     if (M.has_parallax) {
         const double r = M.plx_val - 1000.0 / dist;
@@ -908,7 +910,7 @@ inline bool launch_stretch_nb(int nb, const FastArgs& A, const StretchArgs& S, h
                                                                     shp(N)) == hipSuccess;                \
             hipLaunchKernelGGL((k_stretch_persist<KIND, NS, N>), gp, b, shp(N), s, A, S);                 \
             return true;
-            ISO_PERSIST_CASE(1) ISO_PERSIST_CASE(2) ISO_PERSIST_CASE(3) ISO_PERSIST_CASE(4) ISO_PERSIST_CASE(5)
+            ISO_PERSIST_CASE(0) ISO_PERSIST_CASE(1) ISO_PERSIST_CASE(2) ISO_PERSIST_CASE(3) ISO_PERSIST_CASE(4) ISO_PERSIST_CASE(5)
             ISO_PERSIST_CASE(6) ISO_PERSIST_CASE(7) ISO_PERSIST_CASE(8) ISO_PERSIST_CASE(9) ISO_PERSIST_CASE(10)
             ISO_PERSIST_CASE(11) ISO_PERSIST_CASE(12)
 #undef ISO_PERSIST_CASE
@@ -918,6 +920,7 @@ inline bool launch_stretch_nb(int nb, const FastArgs& A, const StretchArgs& S, h
     const dim3 g((unsigned)((S.n_active + BLOCK - 1) / BLOCK));
     auto sh = [&](int n) { return (size_t)(((A.axes_len + 1) & ~1) + coop_lds_doubles(n)) * sizeof(double); };
     switch (nb) {
+    case 0: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 0>), g, b, sh(0), s, A, S); return true;
     case 1: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 1>), g, b, sh(1), s, A, S); return true;
     case 2: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 2>), g, b, sh(2), s, A, S); return true;
     case 3: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 3>), g, b, sh(3), s, A, S); return true;
@@ -940,6 +943,7 @@ inline bool launch_nb(int nb, const FastArgs& A, hipStream_t s)
     const dim3 g((unsigned)((A.n + BLOCK - 1) / BLOCK)), b(BLOCK);
     auto sh = [&](int n) { return (size_t)(((A.axes_len + 1) & ~1) + (PACKED ? coop_lds_doubles(n) : 0)) * sizeof(double); };
     switch (nb) {
+    case 0: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 0, PACKED, MULTI, ASTERO>), g, b, sh(0), s, A); return true;
     case 1: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 1, PACKED, MULTI, ASTERO>), g, b, sh(1), s, A); return true;
     case 2: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 2, PACKED, MULTI, ASTERO>), g, b, sh(2), s, A); return true;
     case 3: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 3, PACKED, MULTI, ASTERO>), g, b, sh(3), s, A); return true;

@@ -1772,7 +1772,7 @@ hipError_t pack_bands(const iso_ic* ic, const int32_t* bc_cols, int nb, double**
 bool fast_eligible(const iso_ic* ic, const iso_model_desc* desc)
 {
     // asteroseismic terms are only on the corner-packed form of the fast path
-    return path_mode() != PATH_GENERIC && desc->n_bands >= 1 && desc->n_bands <= 12 &&
+    return path_mode() != PATH_GENERIC && desc->n_bands >= 0 && desc->n_bands <= 12 &&
            (!desc->has_numax || (path_mode() == PATH_AUTO && ic->d_hotq)) && ic->model->ax[2].uniform;
 }
 
@@ -1798,7 +1798,7 @@ hipError_t build_fast(const iso_ic* ic, int nb, const double* d_bc_hot, double**
     hipError_t e = hipMalloc(d_axes_blob, blob.size() * sizeof(double));
     if (e == hipSuccess) e = hipMemcpy(*d_axes_blob, blob.data(), blob.size() * sizeof(double), hipMemcpyHostToDevice);
     if (e != hipSuccess) return e;
-    if (path_mode() == PATH_AUTO && ic->d_hotq) {
+    if (path_mode() == PATH_AUTO && ic->d_hotq && nb > 0) {
         hipError_t e2 = pack_corners(d_bc_hot, nb, nb, 4, ic->bc->shape, d_bcq);
         if (e2 != hipSuccess) {
             *d_bcq = nullptr;
@@ -1924,7 +1924,7 @@ int iso_model_create(iso_ic* ic, const iso_model_desc* desc, iso_model** out)
         if (e == hipSuccess && m->fast_ok && desc->has_numax) {
             // (nu_max, delta_nu) = hot columns 6, 7, corner-packed once per interpolator (128 B per cell)
             std::lock_guard<std::mutex> lock(ic->mag_mu);
-            if (!ic->d_astq && m->d_bcq) {
+            if (!ic->d_astq && (m->d_bcq || desc->n_bands == 0)) {
                 hipError_t e2 = pack_corners(ic->d_hot, HOT_COLS, 2, 3, ic->model->shape, &ic->d_astq, 6);
                 if (e2 != hipSuccess) {
                     ic->d_astq = nullptr;
@@ -1932,7 +1932,7 @@ int iso_model_create(iso_ic* ic, const iso_model_desc* desc, iso_model** out)
                 }
             }
             m->fast.astq = ic->d_astq;
-            if (!m->fast.astq || !m->d_bcq) m->fast_ok = false;     // generic kernel
+            if (!m->fast.astq || (!m->d_bcq && desc->n_bands > 0)) m->fast_ok = false;     // generic kernel
         }
     }
     if (e != hipSuccess) {
@@ -2006,7 +2006,7 @@ int enqueue_lnpost(iso_model* m, const double* pars, int64_t stride_n, int64_t s
         F.lnprior = lnprior_out;
         // lnprior alone still needs the likelihood flag off; lnlike requested -> evaluate everywhere
         F.lnlike = lnlike_out;
-        const bool packed = F.hotq != nullptr && F.bcq != nullptr;
+        const bool packed = F.hotq != nullptr && (F.bcq != nullptr || m->desc.n_bands == 0);
         if (launch_lnpost_fast(m->ic->kind, m->desc.n_stars, m->desc.n_bands, packed, false, F, s)) {
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) return fail(ISO_ERR_HIP, std::string("iso_lnpost (fast) launch: ") + hipGetErrorString(e));
@@ -2187,7 +2187,7 @@ int iso_catalog_create(iso_ic* ic, const iso_model_desc* descs, int64_t n_models
             return fail(ISO_ERR_INVALID, "iso_catalog_create: every star needs the same multiplicity and bands");
         if (descs[k].has_numax) return fail(ISO_ERR_INVALID, "iso_catalog_create: asteroseismic terms are not batched");
     }
-    if (!fast_eligible(ic, &d0) || !ic->d_hotq)
+    if (!fast_eligible(ic, &d0) || !ic->d_hotq || d0.n_bands < 1)
         return fail(ISO_ERR_INVALID, "iso_catalog_create: needs 1-12 bands, a uniform EEP axis and the corner-packed "
                                      "tables (ISOCHRONES_AMD_PATH=auto)");
     DeviceGuard guard(ic->device);
@@ -2417,9 +2417,9 @@ int iso_sampler_create_model(iso_model* m, int nwalkers, double a, uint64_t seed
 {
     if (!m || !out) return fail(ISO_ERR_INVALID, "iso_sampler_create_model: NULL argument");
     if (nwalkers < 2 || (nwalkers & 1) || !(a > 1.0)) return fail(ISO_ERR_INVALID, "iso_sampler_create_model: need an even walker count and a > 1");
-    if (!m->fast_ok || !m->fast.hotq || !m->fast.bcq || m->fast.astq)
+    if (!m->fast_ok || !m->fast.hotq || (!m->fast.bcq && m->desc.n_bands > 0) || m->fast.astq)
         return fail(ISO_ERR_INVALID, "iso_sampler_create_model: the model is not on the corner-packed fast path "
-                                     "(needs 1-12 bands, uniform EEP axis, ISOCHRONES_AMD_PATH=auto)");
+                                     "(needs <= 12 bands, uniform EEP axis, no asteroseismic terms, ISOCHRONES_AMD_PATH=auto)");
     iso_sampler* sp = new (std::nothrow) iso_sampler();
     if (!sp) return fail(ISO_ERR_NOMEM, "iso_sampler_create_model: out of host memory");
     sampler_common(sp, m->device, m->ic->kind, m->desc.n_stars, m->desc.n_bands, 1, m->fast, 0, nwalkers, a, seed);
