@@ -73,6 +73,19 @@ def build_model(bands=("V",)):
     return ic, mod
 
 
+def cpu_quota_cores():
+    """CFS bandwidth quota of this container in CPUs (cgroup v2 cpu.max / v1 cfs_quota_us), None if unlimited."""
+    try:
+        if os.path.exists("/sys/fs/cgroup/cpu.max"):
+            q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+            return None if q == "max" else float(q) / float(per)
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except Exception:
+        return None
+
+
 def cpu_baseline(ic, mod, pars_host, wall_budget_s=4.0):
     """Time the C oracle (the reference's algorithm restated, oracle/iso_oracle.c) on this host:
     repeated passes over the same batch, all host cores (OpenMP static) for ~wall_budget_s of wall
@@ -83,14 +96,23 @@ def cpu_baseline(ic, mod, pars_host, wall_budget_s=4.0):
                        ic._cols, ic._prior_cols, ic._astero_cols)
     desc = mod.model_desc()
     cores = max(1, min(orc.max_threads(), os.cpu_count() or 1))
+    quota = cpu_quota_cores()
     soa = np.ascontiguousarray(pars_host.T)
     n = soa.shape[1]
     out = oic.lnpost(desc, soa, nthreads=cores, parts=False)          # warm-up (threads, page faults)
-    passes, t0 = 0, time.perf_counter()
+    # Containers often carry a CFS quota far below the host's core count (this pool: 16 of 256 CPUs): a pass
+    # that starts in a fresh quota period runs unthrottled, sustained passes are throttled.  `value` is the
+    # best pass (what the host cores can do - the conservative figure for any GPU/CPU ratio), the sustained
+    # rate under the quota is reported next to it.
+    times, t0 = [], time.perf_counter()
     while time.perf_counter() - t0 < wall_budget_s:
+        t = time.perf_counter()
         oic.lnpost(desc, soa, nthreads=cores, parts=False)
-        passes += 1
+        times.append(time.perf_counter() - t)
+        if quota and quota < cores:
+            time.sleep(0.2)                                            # let the quota period roll over
     dt = time.perf_counter() - t0
+    passes = len(times)
     n1 = min(n, 200_000)
     s1 = np.ascontiguousarray(soa[:, :n1])
     p1, t1 = 0, time.perf_counter()
@@ -98,10 +120,12 @@ def cpu_baseline(ic, mod, pars_host, wall_budget_s=4.0):
         oic.lnpost(desc, s1, nthreads=1, parts=False)
         p1 += 1
     dt1 = time.perf_counter() - t1
-    return dict(value=passes * n / dt, unit="evals/s", cores=cores, kind="port",
-                sample="%d passes over the same %d-sample batch (%.1f s wall, %.0f core-seconds), C restatement of "
-                       "the reference (oracle/iso_oracle.c), OpenMP static over %d threads; 1-thread figure: %d "
-                       "passes over the first %d samples (%.1f s)" % (passes, n, dt, dt * cores, cores, p1, n1, dt1),
+    return dict(value=n / min(times), unit="evals/s", cores=cores, kind="port",
+                sample="best of %d passes over the same %d-sample batch (%.1f s wall), C restatement of the reference "
+                       "(oracle/iso_oracle.c), OpenMP static over %d threads; container CPU quota: %s; 1-thread "
+                       "figure: %d passes over the first %d samples (%.1f s)"
+                       % (passes, n, dt, cores, ("%.1f CPUs" % quota) if quota else "none", p1, n1, dt1),
+                value_median_pass=n / float(np.median(times)), cpu_quota_cores=quota,
                 value_1thread=p1 * n1 / dt1), out
 
 
