@@ -121,9 +121,13 @@ class DFInterpolator:
 
     def interp_device(self, xs, icols, device=None):
         """xs: ndim float64 CUDA tensors of equal length N -> CUDA tensor [N, k]."""
+        if len(xs) != self.ndim:
+            raise ValueError("need %d coordinate tensors, got %d" % (self.ndim, len(xs)))
         if device is None:
             device = xs[0].device.index
         n = xs[0].numel()
+        if any(x.numel() != n or x.dtype.itemsize != 8 or not x.is_contiguous() for x in xs):
+            raise ValueError("coordinates must be contiguous float64 tensors of equal length")
         icols = np.ascontiguousarray(icols, dtype=np.int32)
         k = icols.size
         out = dev.empty_f64((n, k), device)

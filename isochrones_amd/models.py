@@ -196,6 +196,8 @@ class ModelGridInterpolator:
         bands = self.bands if bands is None else bands
         if device is None:
             device = pars.device.index
+        if pars.dim() != 2 or pars.shape[0] != 5 or pars.dtype.itemsize != 8 or not pars.is_contiguous():
+            raise ValueError("pars must be a contiguous float64 [5, N] tensor (%s)" % ", ".join(self.param_names))
         n = pars.shape[1]
         nb = len(bands)
         if nb > _cabi.ISO_MAX_BANDS:
@@ -236,6 +238,8 @@ class ModelGridInterpolator:
             scalar = True
             p = arr.reshape(5, 1)
         except (TypeError, ValueError):
+            if len(pars) != 5:
+                raise ValueError("interp_mag needs the five parameters %s" % (self.param_names,))
             b = np.broadcast(*pars)
             p = np.array([np.resize(x, b.shape).astype(float).ravel() for x in pars])
         Teff, logg, feh, mags = self.interp_mag_device(dev.to_device_f64(p, device), bands, device)

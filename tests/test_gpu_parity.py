@@ -323,6 +323,26 @@ def test_errors_are_loud():
         ia.BinaryStarModel(ic, V=(10, 0.1))      # multiples need the isochrone parametrisation
     rc = _cabi.lib().iso_lnpost(None, None, 1, 1, 0, None, None, None, None)
     assert rc == -1 and b"NULL" in _cabi.lib().iso_last_error()
+    # shape / dtype misuse is refused on the host before any kernel could read out of bounds
+    import torch
+    mod = ia.SingleStarModel(ic, V=(10, 0.1), Teff=(5700, 100))
+    for bad in (np.zeros((10, 4)), np.zeros((10, 6)), [1.0, 320.0, 0.0, 100.0], np.zeros((2, 3, 5))):
+        with pytest.raises(ValueError):
+            mod.lnpost(bad)
+    assert mod.lnpost(np.zeros((0, 5))).shape == (0,)
+    with pytest.raises(ValueError):
+        ic.interp_mag([1.0, 320.0, 0.0, 100.0], ["V"])                       # four parameters
+    with pytest.raises(ValueError):
+        ic.interp_mag_device(torch.zeros(4, 8, device="cuda", dtype=torch.float64), ["V"])
+    with pytest.raises(ValueError):
+        ic.interp_mag_device(torch.zeros(5, 8, device="cuda", dtype=torch.float32), ["V"])
+    with pytest.raises(ValueError):
+        ic.interp_mag([1.0, 320.0, 0.0, 100.0, 0.1], ["Z"])                  # unknown band
+    with pytest.raises(ValueError):
+        t3.interp_device([torch.zeros(4, device="cuda", dtype=torch.float64)] * 2, np.array([0]))
+    with pytest.raises(ValueError):
+        t3.interp_device([torch.zeros(4, device="cuda", dtype=torch.float64), torch.zeros(3, device="cuda", dtype=torch.float64),
+                          torch.zeros(4, device="cuda", dtype=torch.float64)], np.array([0]))
 
 
 def test_get_eep_and_generate():
