@@ -177,8 +177,8 @@ class CatalogPosterior:
     def lnpost(self, pars, star_id):
         """pars: CUDA float64 [n, n_params]; star_id: CUDA int32 [n] -> CUDA float64 [n]."""
         import torch
-        if pars.dim() != 2 or pars.shape[1] != self.n_params:
-            raise ValueError("pars must be [n, %d]" % self.n_params)
+        if pars.dim() != 2 or pars.shape[1] != self.n_params or pars.dtype != torch.float64:
+            raise ValueError("pars must be float64 [n, %d]" % self.n_params)
         if star_id.dtype != torch.int32 or star_id.numel() != pars.shape[0]:
             raise ValueError("star_id must be int32 [n]")
         pars = pars.contiguous()

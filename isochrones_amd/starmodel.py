@@ -282,8 +282,8 @@ class BasicStarModel(_NestedFitMixin):
     def evaluate_device(self, pars, soa=False, parts=False):
         """pars: CUDA float64 tensor, [N, n_params] (or [n_params, N] if soa).
         Returns lnpost[N] or (lnpost, lnprior, lnlike)."""
-        if pars.dim() != 2:
-            raise ValueError("pars must be 2-D")
+        if pars.dim() != 2 or pars.dtype.itemsize != 8 or not pars.dtype.is_floating_point:
+            raise ValueError("pars must be a 2-D float64 tensor")
         npar = self.n_params
         if soa:
             if pars.shape[0] != npar:
@@ -662,8 +662,8 @@ class TreeStarModel(_NestedFitMixin):
     def evaluate_device(self, pars, parts=False):
         """pars: CUDA float64 [N, n_params] -> lnpost [N] or (lnpost, lnprior, lnlike)."""
         npar = self.n_params
-        if pars.dim() != 2 or pars.shape[1] != npar:
-            raise ValueError("expected [N, %d]" % npar)
+        if pars.dim() != 2 or pars.shape[1] != npar or pars.dtype.itemsize != 8 or not pars.dtype.is_floating_point:
+            raise ValueError("expected a float64 [N, %d] tensor" % npar)
         device = pars.device.index
         pars = pars.contiguous()
         n = pars.shape[0]
