@@ -86,14 +86,20 @@ def cpu_quota_cores():
         return None
 
 
+def oracle_view(ic):
+    """The CPU checker's view of an interpolator's tables — the only place outside tests/ and
+    __graft_entry__.smoke() that touches oracle/ (the cpu_baseline legs here and in bench_configs.py)."""
+    from oracle import oracle as orc
+    m, b = ic.model_grid.interp, ic.bc_grid.interp
+    return orc, orc.OracleIC(ic.kind, orc.OracleTable(m.grid, m.index_columns), orc.OracleTable(b.grid, b.index_columns),
+                             ic._cols, ic._prior_cols, ic._astero_cols)
+
+
 def cpu_baseline(ic, mod, pars_host, wall_budget_s=4.0):
     """Time the C oracle (the reference's algorithm restated, oracle/iso_oracle.c) on this host:
     repeated passes over the same batch, all host cores (OpenMP static) for ~wall_budget_s of wall
     time, then one thread for about the same."""
-    from oracle import oracle as orc
-    m, b = ic.model_grid.interp, ic.bc_grid.interp
-    oic = orc.OracleIC(ic.kind, orc.OracleTable(m.grid, m.index_columns), orc.OracleTable(b.grid, b.index_columns),
-                       ic._cols, ic._prior_cols, ic._astero_cols)
+    orc, oic = oracle_view(ic)
     desc = mod.model_desc()
     cores = max(1, min(orc.max_threads(), os.cpu_count() or 1))
     quota = cpu_quota_cores()

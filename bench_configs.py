@@ -29,10 +29,8 @@ HBM_PEAK_GBS = 8000.0
 
 
 def _oracle_ic(ic):
-    from oracle import oracle as orc
-    m, b = ic.model_grid.interp, ic.bc_grid.interp
-    return orc.OracleIC(ic.kind, orc.OracleTable(m.grid, m.index_columns), orc.OracleTable(b.grid, b.index_columns),
-                        ic._cols, ic._prior_cols, ic._astero_cols)
+    import bench
+    return bench.oracle_view(ic)[1]          # CPU-baseline legs only (never the measured GPU path)
 
 
 def _time_kernel(mod, pars_t, reps, warm=10):
@@ -289,7 +287,8 @@ def tree(n=1_000_000, reps=20):
         out = mod.lnpost(pt)
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
-    from oracle import oracle as orc
+    import bench
+    orc = bench.oracle_view(ic)[0]
     ns = 20_000
     ref = orc.tree_lnpost(_oracle_ic(ic), mod.tree_desc(), np.ascontiguousarray(pars[:ns].T), nthreads=os.cpu_count())[0]
     got = out[:ns].cpu().numpy()

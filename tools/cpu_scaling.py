@@ -3,9 +3,8 @@ import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
-from tests import _fixtures as fx
 ic, mod = bench.build_model()
-oic = fx.make_oracle_ic(ic)
+oic = bench.oracle_view(ic)[1]
 desc = mod.model_desc()
 pars = bench.make_samples(np.random.default_rng(1), 400_000, "prior_valid")
 soa = np.ascontiguousarray(pars.T)
