@@ -899,22 +899,6 @@ __global__ __launch_bounds__(BLOCK) void k_interp_eep(const EepArgs A)
 // "next" row f4: generic StarModel over a flattened ObservationTree
 // (reference semantics: isochrones/starmodel.py:538-613, observation.py:464-491, 1181-1234)
 // -------------------------------------------------------------------------------------------
-struct DevTree {
-    int n_systems, n_leaves, n_bands, n_terms, n_spec, n_limits, n_params;
-    int n_stars[ISO_TREE_MAX_SYSTEMS], sys_base[ISO_TREE_MAX_SYSTEMS];
-    int leaf_system[ISO_TREE_MAX_LEAVES], leaf_slot[ISO_TREE_MAX_LEAVES];
-    iso_tree_term terms[ISO_TREE_MAX_TERMS];
-    double term_g0[ISO_TREE_MAX_TERMS];          // log(1/sqrt(2 pi)) + log(unc)
-    iso_tree_prop spec[ISO_TREE_MAX_SPEC], limits[ISO_TREE_MAX_SPEC];
-    double spec_g0[ISO_TREE_MAX_SPEC];
-    int has_plx[ISO_TREE_MAX_SYSTEMS], has_av[ISO_TREE_MAX_SYSTEMS];
-    double plx_val[ISO_TREE_MAX_SYSTEMS], plx_unc[ISO_TREE_MAX_SYSTEMS], plx_g0[ISO_TREE_MAX_SYSTEMS];
-    double av_val[ISO_TREE_MAX_SYSTEMS], av_unc[ISO_TREE_MAX_SYSTEMS], av_g0[ISO_TREE_MAX_SYSTEMS];
-    DevPrior prior_mass, prior_age, prior_feh, prior_distance, prior_AV;
-    double eep_lo, eep_hi;
-    double bound_lo[4], bound_hi[4];
-};
-
 struct TreeArgs {
     Grid3V g3;
     Grid4V g4;            // BC packed to the tree's bands (ncol == n_bands)
@@ -1332,6 +1316,11 @@ struct iso_tree_model {
     DevTree* d_tree;
     double* d_bc_hot;
     Grid4V g4;
+    int n_bands;
+    double* d_bcq;           // corner-packed BC for the tree's bands (fast form), may be null
+    double* d_axes_blob;
+    bool fast_ok;
+    FastArgs fast;
 };
 
 struct iso_eep_table {
@@ -2298,6 +2287,10 @@ int iso_tree_model_create(iso_ic* ic, const iso_tree_desc* d, iso_tree_model** o
     m->ic = ic;
     m->d_tree = nullptr;
     m->d_bc_hot = nullptr;
+    m->d_bcq = nullptr;
+    m->d_axes_blob = nullptr;
+    m->fast_ok = false;
+    m->n_bands = d->n_bands;
     DevTree* H = new DevTree();
     std::memset(H, 0, sizeof(DevTree));
     H->n_systems = d->n_systems; H->n_leaves = d->n_leaves; H->n_bands = d->n_bands;
@@ -2350,6 +2343,12 @@ int iso_tree_model_create(iso_ic* ic, const iso_tree_desc* d, iso_tree_model** o
         m->g4.tab = m->d_bc_hot;
         m->g4.ncol = d->n_bands;
     }
+    if (e == hipSuccess && path_mode() == PATH_AUTO && ic->d_hotq && d->n_bands >= 1 && d->n_bands <= 12 &&
+        ic->model->ax[2].uniform) {
+        bool ok = false;
+        e = build_fast(ic, d->n_bands, m->d_bc_hot, &m->d_axes_blob, &m->d_bcq, m->fast, &ok);
+        m->fast_ok = ok && m->d_bcq != nullptr;
+    }
     if (e != hipSuccess) {
         std::string msg = std::string("iso_tree_model_create: ") + hipGetErrorString(e);
         iso_tree_model_destroy(m);
@@ -2365,6 +2364,8 @@ void iso_tree_model_destroy(iso_tree_model* m)
     DeviceGuard guard(m->device);
     if (m->d_tree) (void)hipFree(m->d_tree);
     if (m->d_bc_hot) (void)hipFree(m->d_bc_hot);
+    if (m->d_bcq) (void)hipFree(m->d_bcq);
+    if (m->d_axes_blob) (void)hipFree(m->d_axes_blob);
     delete m;
 }
 
@@ -2375,6 +2376,21 @@ int iso_tree_lnpost(iso_tree_model* m, const double* pars, int64_t stride_n, int
     if (n < 0) return fail(ISO_ERR_INVALID, "iso_tree_lnpost: n < 0");
     if (!lnpost_out && !lnprior_out && !lnlike_out) return fail(ISO_ERR_INVALID, "iso_tree_lnpost: no output requested");
     if (n == 0) return ISO_OK;
+    if (m->fast_ok) {
+        FastArgs F = m->fast;
+        F.pars = pars;
+        F.stride_n = stride_n;
+        F.stride_p = stride_p;
+        F.n = n;
+        F.lnpost = lnpost_out;
+        F.lnprior = lnprior_out;
+        F.lnlike = lnlike_out;
+        DeviceGuard guard(m->device);
+        if (launch_tree_fast(m->n_bands, F, m->d_tree, as_stream(stream))) {
+            HIP_TRY(hipGetLastError());
+            return ISO_OK;
+        }
+    }
     TreeArgs A;
     A.g3 = m->ic->g3;
     A.g4 = m->g4;

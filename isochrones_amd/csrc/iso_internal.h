@@ -97,6 +97,23 @@ struct FastArgs {
     double* lnlike;                  // (lnlike is then evaluated even where the prior is not finite)
 };
 
+// flattened observation tree of a generic StarModel (constants pre-evaluated on the host)
+struct DevTree {
+    int n_systems, n_leaves, n_bands, n_terms, n_spec, n_limits, n_params;
+    int n_stars[ISO_TREE_MAX_SYSTEMS], sys_base[ISO_TREE_MAX_SYSTEMS];
+    int leaf_system[ISO_TREE_MAX_LEAVES], leaf_slot[ISO_TREE_MAX_LEAVES];
+    iso_tree_term terms[ISO_TREE_MAX_TERMS];
+    double term_g0[ISO_TREE_MAX_TERMS];          // log(1/sqrt(2 pi)) + log(unc)
+    iso_tree_prop spec[ISO_TREE_MAX_SPEC], limits[ISO_TREE_MAX_SPEC];
+    double spec_g0[ISO_TREE_MAX_SPEC];
+    int has_plx[ISO_TREE_MAX_SYSTEMS], has_av[ISO_TREE_MAX_SYSTEMS];
+    double plx_val[ISO_TREE_MAX_SYSTEMS], plx_unc[ISO_TREE_MAX_SYSTEMS], plx_g0[ISO_TREE_MAX_SYSTEMS];
+    double av_val[ISO_TREE_MAX_SYSTEMS], av_unc[ISO_TREE_MAX_SYSTEMS], av_g0[ISO_TREE_MAX_SYSTEMS];
+    DevPrior prior_mass, prior_age, prior_feh, prior_distance, prior_AV;
+    double eep_lo, eep_hi;
+    double bound_lo[4], bound_hi[4];
+};
+
 struct StretchArgs {
     double* pos;          // [n_rows][n_params] row-major, n_rows = n_stars_in_batch * W
     double* lnp;          // [n_rows]
@@ -212,6 +229,8 @@ struct MagOut {
 };
 // defined in iso_fast_mag.hip: interp_mag on the corner-packed tables (nb = 1..12)
 bool launch_interp_mag_fast(int kind, int nb, const FastArgs& A, const MagOut& O, hipStream_t s);
+// defined in iso_fast_tree.hip: observation-tree lnpost on the corner-packed tables (1..12 bands)
+bool launch_tree_fast(int nb, const FastArgs& A, const DevTree* T, hipStream_t s);
 bool launch_stretch(int kind, int n_stars, int n_bands, const FastArgs& A, const StretchArgs& S, hipStream_t s);
 // dynamic LDS bytes one workgroup of the persistent sampler kernel needs for W-walker ensembles, and how
 // many ensembles such a workgroup owns

@@ -285,8 +285,15 @@ def test_reference_test_fits_flow(tmp_path):
 from tests.test_tree_cpu import TREE_CASES, make_tree_model  # noqa: E402
 
 
+@pytest.fixture(params=["auto", "generic"])
+def tree_kernel_path(request, monkeypatch):
+    """auto: k_lnpost_tree_fast (cooperative gathers on the corner-packed tables); generic: k_lnpost_tree."""
+    monkeypatch.setenv("ISOCHRONES_AMD_PATH", request.param)
+    return request.param
+
+
 @pytest.mark.parametrize("case", TREE_CASES)
-def test_tree_model_vs_reference_golden(case):
+def test_tree_model_vs_reference_golden(case, tree_kernel_path):
     import torch
     g = fx.load(case)
     ic, mod = make_tree_model(g["meta"])
@@ -301,7 +308,7 @@ def test_tree_model_vs_reference_golden(case):
     fx.assert_close(dev_out.cpu().numpy(), g["lnpost"], RTOL, atol=1e-9, what="lnpost device")
 
 
-def test_tree_model_random_batch_vs_oracle_and_basic_model():
+def test_tree_model_random_batch_vs_oracle_and_basic_model(tree_kernel_path):
     """A 4-star, 2-system resolved configuration on mid-size tables against the oracle, and the
     keyword (unresolved) form against BasicStarModel evaluated by the fused kernel."""
     from oracle import oracle as orc
