@@ -773,14 +773,17 @@ __device__ __forceinline__ void stretch_move(const FastArgs& A, const StretchArg
     const double u2 = ((double)rnd[3] + (double)(rnd[2] >> 16) * (1.0 / 65536.0) + 0.5 / 65536.0) * (1.0 / 4294967296.0);
     const double zr = (S.a - 1.0) * u1 + 1.0;
     const double z = zr * zr / S.a;
+    // helper lanes (no walker of their own) only read the complementary half, which nobody writes in this
+    // half-step: they evaluate the partner's position and discard the result
+    const int lsrc = active ? lr : lp;
     double xk[NP], y[NP];
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
-        xk[q] = pos[lr * NP + q];
+        xk[q] = pos[lsrc * NP + q];
         const double xj = pos[lp * NP + q];
         y[q] = xj + z * (xk[q] - xj);
     }
-    const double lold = lnp[lr];
+    const double lold = lnp[lsrc];
     const DevModel& M = A.m[S.multi ? star : 0];
     double lnp_unused, lnl_unused;
     const double lnew = lnpost_wave<KIND, NS, NB, true>(A, lds, L, active, M, y, false, lnp_unused, lnl_unused);
