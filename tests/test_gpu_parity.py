@@ -5,6 +5,9 @@ by the host layer, against (a) the committed golden vectors produced by the refe
 Tolerance: BASELINE.json's north_star asks for <= 1e-6 relative vs the reference CPU path; the
 kernels are float64 like the reference, so the tests hold them to RTOL = 1e-9 (differences come
 only from FMA contraction and device-libm ulps).  NaN / -inf patterns must match exactly."""
+import os
+import sys
+
 import numpy as np
 import pytest
 
@@ -561,3 +564,15 @@ def test_special_value_fuzz_vs_oracle(kind, n_stars, kernel_path):
     fx.assert_close(mod.lnprior(pars), want[1], RTOL, atol=ATOL, what="lnprior")
     d_ok = pars[:, n_stars + 2] > 0          # lnlike with distance <= 0 is undefined in the reference
     fx.assert_close(mod.lnlike(pars)[d_ok], want[2][d_ok], RTOL, atol=ATOL, what="lnlike")
+
+
+def test_randomised_soak_short(monkeypatch):
+    """tools/soak.py for a few seconds: random model configurations (bands, stars, observables, prior
+    families, bounds) x special-value-laden samples on all three kernel paths against the oracle
+    (the long runs are recorded in profiles/r01/soak.txt)."""
+    import runpy
+    monkeypatch.setattr(sys, "argv", ["soak.py", "6", "11"])
+    with pytest.raises(SystemExit) as e:
+        runpy.run_path(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "soak.py"),
+                       run_name="__main__")
+    assert e.value.code == 0
