@@ -137,6 +137,24 @@ def main():
                     fails += 1
                     print("   pars", x[rr].tolist(), flush=True)
             evals += 3 * n
+            if path != "compact":
+                # the batch primitives of the same interpolator: interp_mag (packed BC tables on `auto`) and
+                # interp_value of a random column subset (wide pack on `auto`)
+                ns = cfg["n_stars"]
+                prim = np.ascontiguousarray(np.column_stack([x[:, 0]] + [x[:, ns + j] for j in range(4)]).T)
+                prim[3] = np.abs(prim[3]) + 1e-3
+                bsel = list(rng.choice(ic.bands, size=int(rng.integers(1, len(ic.bands) + 1)), replace=False))
+                wT, wg, wf, wm = oic.interp_mag(prim, [ic.bc_grid.interp.column_index[b] for b in bsel], nthreads=16)
+                gT, gg, gf, gm = ic.interp_mag(list(prim), bsel)
+                csel = list(rng.choice(len(ic.model_grid.interp.columns), size=int(rng.integers(1, 9)), replace=False))
+                order = ic.param_index_order
+                xs = [prim[order[0]], prim[order[1]], prim[order[2]]]
+                wv = oic.model.interp(xs, csel)
+                gv = ic.model_grid.interp(xs, [ic.model_grid.interp.columns[c] for c in csel])
+                for got, want, what in ((gT, wT, "Teff"), (gm, wm, "mags"), (gv, wv, "interp_value")):
+                    if same(np.ravel(got), np.ravel(want), what, cfg) >= 0:
+                        fails += 1
+                evals += 2 * n
         configs += 1
         ic.release()
     print("soak: %d configurations, %.3g GPU evaluations, %d mismatching checks, %.0f s; oracle lnpost: %d finite, %d -inf, %d NaN; "
