@@ -1,5 +1,7 @@
 """GPU tests of the catalog / sampler layer: batched multi-star lnpost vs the oracle, the
 on-device ensemble sampler driven by the fused kernel, and the end-to-end catalog fit."""
+import os
+
 import numpy as np
 import pytest
 
@@ -279,6 +281,29 @@ def test_reference_test_fits_flow(tmp_path):
     assert res.niter <= 50 and np.isfinite(res.logz)
     assert len(mod.samples) >= 1 and np.isfinite(mod.samples["lnprob"]).all()
     assert len(np.atleast_2d(np.loadtxt(base + "post_equal_weights.dat"))) >= 1
+
+
+def test_fit_catalog_two_ranks_on_the_gpu(tmp_path):
+    """SURVEY 8e end to end with real device fits: two ranks (gloo rendezvous, both on this box's GPU - RCCL needs
+    one GPU per rank) - rank 0 builds the tables, broadcast_interpolator ships them, each rank fits the shard
+    batch_starfit's rule gives it, all_gather returns the same table everywhere, truth is recovered."""
+    import subprocess, sys, socket
+    import pandas as pd
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, ISO_WORLD_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "tools", "catalog_world.py"), str(tmp_path), "48"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    r0, r1 = pd.read_pickle(tmp_path / "res0.pkl"), pd.read_pickle(tmp_path / "res1.pkl")
+    truth = pd.read_pickle(tmp_path / "truth.pkl")
+    assert r0.equals(r1) and len(r0) == 48
+    assert (r0["ok"] == 1).mean() > 0.9
+    rel = np.abs(r0["distance_median"].values - truth["distance"].values) / truth["distance"].values
+    assert np.nanmedian(rel) < 0.1
 
 
 # ---- "next" row f4: generic StarModel over an ObservationTree ---------------------------------
