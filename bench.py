@@ -126,7 +126,16 @@ def cpu_baseline(ic, mod, pars_host, wall_budget_s=4.0):
         oic.lnpost(desc, s1, nthreads=1, parts=False)
         p1 += 1
     dt1 = time.perf_counter() - t1
-    return dict(value=n / min(times), unit="evals/s", cores=cores, kind="port",
+    # scalar-call mode: one sample per call through the oracle's C ABI from a Python loop - how the reference
+    # is actually driven by its samplers (published there: 69 us per call single star, numba)
+    one = np.ascontiguousarray(soa[:, :1])
+    for _ in range(200):
+        oic.lnpost(desc, one, nthreads=1, parts=False)
+    tc = time.perf_counter()
+    for k in range(3000):
+        oic.lnpost(desc, one, nthreads=1, parts=False)
+    scalar_us = (time.perf_counter() - tc) / 3000 * 1e6
+    return dict(value=n / min(times), unit="evals/s", cores=cores, kind="port", scalar_call_us=scalar_us,
                 sample="best of %d passes over the same %d-sample batch (%.1f s wall), C restatement of the reference "
                        "(oracle/iso_oracle.c), OpenMP static over %d threads; container CPU quota: %s; 1-thread "
                        "figure: %d passes over the first %d samples (%.1f s)"
@@ -267,6 +276,15 @@ def main():
                           "algorithmic_GBs": BYTES_PER_EVAL_SINGLE_1BAND * args.n / (ms.value * 1e-3) / 1e9,
                           "finite_fraction": float(torch.isfinite(o2).double().mean())}
         result["other_workloads"] = extras
+        # end to end through the host-array API (numpy in, numpy out: H2D of 40 B + D2H of 8 B per sample
+        # around the same kernel) - reported for the record, never `value`
+        mod.lnpost(pars_host[:1000])
+        t_h = time.perf_counter()
+        for _ in range(3):
+            mod.lnpost(pars_host)
+        dt_h = (time.perf_counter() - t_h) / 3
+        result["host_array_path"] = {"ms": dt_h * 1e3, "evals_per_s": args.n / dt_h,
+                                     "note": "mod.lnpost(numpy [N,5]) -> numpy [N], PCIe transfers included"}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             base, ref = cpu_baseline(ic, mod, pars_host)
