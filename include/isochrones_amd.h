@@ -256,6 +256,15 @@ void iso_sampler_destroy(iso_sampler* s);
 int  iso_sampler_run(iso_sampler* s, double* pos, double* lnp, int nsteps, double* chain, double* chain_lnp,
                      int32_t* accepted, void* stream);
 
+/* Per-ensemble quantiles of a stored chain, on the device: the posterior summaries a catalog fit reports per
+ * star (the reference takes them from the pandas samples of every star, isochrones/starfit.py + catalog
+ * drivers).  chain is iso_sampler_run's chain output [nsteps][n_ens*W][n_params]; for every ensemble e and
+ * parameter d the nsteps*W values are sorted in LDS and out[(e*n_params + d)*nq + k] receives the q[k]
+ * quantile with linear interpolation between order statistics (numpy.percentile's default).  q is a HOST array
+ * of nq <= 8 levels in [0, 1]; nsteps*W <= 8192. */
+int  iso_chain_quantiles(iso_ctx* ctx, const double* chain, int64_t nsteps, int64_t n_ens, int W, int n_params,
+                         const double* q, int nq, double* out, void* stream);
+
 /* Time `reps` back-to-back iso_lnpost launches with hipEvents on `stream`; returns the mean
  * milliseconds per launch in *ms_per_launch (measurement helper for bench.py). */
 int  iso_time_lnpost(iso_model* m, const double* pars, int64_t stride_n, int64_t stride_p, int64_t n,

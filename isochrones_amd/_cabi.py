@@ -100,6 +100,7 @@ EXPORTED_SYMBOLS = (
     "iso_catalog_create", "iso_catalog_destroy", "iso_catalog_lnpost",
     "iso_eep_table_create", "iso_eep_table_destroy", "iso_interp_eep",
     "iso_sampler_create_model", "iso_sampler_create_catalog", "iso_sampler_destroy", "iso_sampler_run",
+    "iso_chain_quantiles",
     "iso_tree_model_create", "iso_tree_model_destroy", "iso_tree_lnpost",
 )
 
@@ -175,6 +176,7 @@ def lib():
     L.iso_sampler_destroy.argtypes = [vp]
     L.iso_sampler_destroy.restype = None
     L.iso_sampler_run.argtypes = [vp, pd, pd, C.c_int, pd, pd, pd, vp]
+    L.iso_chain_quantiles.argtypes = [vp, pd, i64, i64, C.c_int, C.c_int, C.POINTER(dbl), C.c_int, pd, vp]
     L.iso_tree_model_create.argtypes = [vp, C.POINTER(IsoTreeDesc), C.POINTER(vp)]
     L.iso_tree_model_destroy.argtypes = [vp]
     L.iso_tree_model_destroy.restype = None

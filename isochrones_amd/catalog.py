@@ -361,16 +361,19 @@ def fit_stars_gpu(catalog: StarCatalog, ic, indices, N=1, nwalkers=32, nburn=150
         sampler.iterations = 0
         chain, lnps = sampler.run(pos, lnp, niter, keep=True)
         acc_frac = sampler.naccepted.mean(dim=1) / max(sampler.iterations, 1)
-    # quantiles along a contiguous last axis (sorting a strided middle axis is several times slower)
-    flat = chain.reshape(post.n_models, nwalkers * niter, D).permute(0, 2, 1).contiguous()     # [S, D, W*niter]
-    srt = torch.sort(flat, dim=2).values
-    m = srt.shape[2]
-    pick = torch.tensor([0.5, 0.16, 0.84], dtype=torch.float64, device=flat.device) * (m - 1)
-    i0 = pick.floor().long()
-    i1 = torch.clamp(i0 + 1, max=m - 1)
-    frac = pick - i0.to(torch.float64)
-    q = srt[:, :, i0] * (1 - frac) + srt[:, :, i1] * frac                                       # [S, D, 3] (linear, as np.percentile)
-    rows = torch.empty(post.n_models, 3 * D + 3, dtype=torch.float64, device=flat.device)
+    if fused:
+        q = sampler.quantiles((0.5, 0.16, 0.84))                                                # [S, D, 3], LDS sort per (star, parameter)
+    else:
+        # quantiles along a contiguous last axis (sorting a strided middle axis is several times slower)
+        flat = chain.reshape(post.n_models, nwalkers * niter, D).permute(0, 2, 1).contiguous()  # [S, D, W*niter]
+        srt = torch.sort(flat, dim=2).values
+        m = srt.shape[2]
+        pick = torch.tensor([0.5, 0.16, 0.84], dtype=torch.float64, device=flat.device) * (m - 1)
+        i0 = pick.floor().long()
+        i1 = torch.clamp(i0 + 1, max=m - 1)
+        frac = pick - i0.to(torch.float64)
+        q = srt[:, :, i0] * (1 - frac) + srt[:, :, i1] * frac                                   # [S, D, 3] (linear, as np.percentile)
+    rows = torch.empty(post.n_models, 3 * D + 3, dtype=torch.float64, device=q.device)
     rows[:, : 3 * D] = q.reshape(post.n_models, 3 * D)
     rows[:, 3 * D] = lnps.reshape(post.n_models, -1).max(dim=1).values
     rows[:, 3 * D + 1] = acc_frac

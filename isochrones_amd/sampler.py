@@ -224,6 +224,36 @@ class FusedEnsembleSampler:
         return self.lnprobability.reshape(-1) if not self.is_catalog else self.lnprobability.reshape(
             self.n_ensembles, -1)
 
+    def quantiles(self, q=(0.5, 0.16, 0.84)):
+        """Per-ensemble quantiles of the stored chain, [S, ndim, len(q)] (model: [ndim, len(q)]) CUDA tensor,
+        linear interpolation between order statistics as ``numpy.percentile``.  One LDS sort per
+        (ensemble, parameter) on the device (``iso_chain_quantiles``); chains longer than 8 192 samples
+        per ensemble fall back to a framework sort."""
+        import ctypes as C
+        import torch
+        from . import _cabi, device as dev
+        if self._chain is None:
+            raise ValueError("no stored chain")
+        nsteps = self._chain.shape[0]
+        q = np.ascontiguousarray(q, dtype=np.float64)
+        if nsteps * self.nwalkers <= 8192 and q.size <= 8:
+            out = torch.empty(self.n_ensembles, self.ndim, q.size, dtype=torch.float64, device=self.device)
+            chain = self._chain.contiguous()
+            _cabi.check(_cabi.lib().iso_chain_quantiles(dev.context(self.device_index), dev.ptr(chain), nsteps,
+                                                        self.n_ensembles, self.nwalkers, self.ndim,
+                                                        q.ctypes.data_as(C.POINTER(C.c_double)), q.size, dev.ptr(out),
+                                                        dev.stream_ptr(self.device_index)))
+        else:
+            flat = self._chain.view(nsteps, self.n_ensembles, self.nwalkers, self.ndim).permute(1, 3, 0, 2)
+            srt = torch.sort(flat.reshape(self.n_ensembles, self.ndim, -1), dim=2).values
+            m = srt.shape[2]
+            pick = torch.as_tensor(q, device=self.device) * (m - 1)
+            i0 = pick.floor().long()
+            i1 = torch.clamp(i0 + 1, max=m - 1)
+            frac = pick - i0.to(torch.float64)
+            out = srt[:, :, i0] * (1 - frac) + srt[:, :, i1] * frac
+        return out if self.is_catalog else out[0]
+
     @property
     def acceptance_fraction(self):
         acc = self.accepted.to(dtype=__import__("torch").float64) / max(self.iterations, 1)

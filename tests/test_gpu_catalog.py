@@ -283,6 +283,31 @@ def test_reference_test_fits_flow(tmp_path):
     assert len(np.atleast_2d(np.loadtxt(base + "post_equal_weights.dat"))) >= 1
 
 
+def test_chain_quantiles_kernel_matches_numpy():
+    """iso_chain_quantiles (LDS bitonic sort per (ensemble, parameter)) vs numpy.percentile on the stored
+    chains of a catalog sampler and of a single model, incl. a non-power-of-two sample count."""
+    import torch
+    from isochrones_amd.sampler import FusedEnsembleSampler
+    from isochrones_amd.catalog import initial_positions
+    ic = _small_track(("G", "BP", "RP"))
+    cat, truth = synthetic_catalog(ic, 7, bands=["G", "BP", "RP"], seed=5, mag_unc=0.01)
+    models = list(cat.iter_models(ic))
+    post = CatalogPosterior(ic, models)
+    for W, nsteps in ((16, 37), (32, 100)):
+        pos, lnp, failed = initial_positions(post, W, rng_seed=1)
+        fs = FusedEnsembleSampler(post, W, seed=3)
+        fs.run_mcmc(pos, nsteps, lnprob0=lnp, store=True)
+        got = fs.quantiles((0.5, 0.16, 0.84, 0.0, 1.0)).cpu().numpy()
+        flat = fs.flatchain.cpu().numpy()                               # [S, W*nsteps, D]
+        want = np.percentile(flat, [50, 16, 84, 0, 100], axis=1)        # [5, S, D]
+        assert got.shape == (7, 5, 5)
+        assert np.allclose(got, np.moveaxis(want, 0, 2), rtol=1e-14, atol=0)
+    fs1 = FusedEnsembleSampler(models[1], 32, seed=4)
+    fs1.run_mcmc(pos[1], 50, lnprob0=lnp[1], store=True)
+    got = fs1.quantiles((0.5,)).cpu().numpy()
+    assert np.allclose(got[:, 0], np.percentile(fs1.flatchain.cpu().numpy(), 50, axis=0), rtol=1e-14, atol=0)
+
+
 def test_fit_catalog_two_ranks_on_the_gpu(tmp_path):
     """SURVEY 8e end to end with real device fits: two ranks (gloo rendezvous, both on this box's GPU - RCCL needs
     one GPU per rank) - rank 0 builds the tables, broadcast_interpolator ships them, each rank fits the shard
