@@ -13,6 +13,6 @@ from ._cabi import IsoError
 from .sampler import EnsembleSampler, FusedEnsembleSampler
 from .catalog import (StarCatalog, CatalogPosterior, fit_catalog, synthetic_catalog, shard_of, shard_indices,
                       broadcast_interpolator)
-from . import priors, grids, ingest
+from . import priors, grids, ingest, mist, nested
 
 __version__ = "0.1.0"

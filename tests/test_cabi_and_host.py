@@ -161,3 +161,18 @@ def test_synthetic_tables_shapes():
     assert [a.size for a in ia.grids.bc_axes()] == [70, 26, 18, 13]
     g, ax, cols = ia.grids.synthetic_iso_grid(eeps=np.arange(100.0, 300.0))
     assert g.shape == (107, 15, 200, 16) and np.isnan(g).any() and np.isfinite(g).any()
+
+
+def test_reference_style_entry_points_exist():
+    """Names a user of the reference imports for this path (isochrones/__init__.py, mist/__init__.py)."""
+    from isochrones_amd.mist import MIST_EvolutionTrack, MIST_Isochrone   # noqa: F401
+    from isochrones_amd.interp import DFInterpolator                      # noqa: F401
+    from isochrones_amd.starmodel import BasicStarModel, StarModel        # noqa: F401
+    for name in ("get_ichrone", "StarModel", "SingleStarModel", "BinaryStarModel", "TripleStarModel", "StarCatalog",
+                 "ObservationTree", "Observation", "Source", "priors"):
+        assert hasattr(ia, name), name
+    for name in ("interp_value", "interp_mag", "get_eep", "generate", "isochrone", "model_value", "model_mag", "mass", "radius"):
+        assert hasattr(ia.ModelGridInterpolator, name), name
+    for name in ("lnpost", "lnlike", "lnprior", "mnest_prior", "mnest_loglike", "fit_mcmc", "fit_multinest", "evidence",
+                 "samples", "derived_samples", "sample_from_prior", "emcee_p0", "set_prior", "set_bounds", "bounds"):
+        assert hasattr(ia.BasicStarModel, name), name
