@@ -78,3 +78,38 @@ def ragged_age_arrays(dfi: DFInterpolator, column="age"):
     for r in range(ages.shape[0]):
         out[r, : lengths[r]] = ages[r, : lengths[r]]
     return out, lengths
+
+
+# ---- self-contained table files ---------------------------------------------------------------
+# The reference keeps the BC tables only as HDF5 (bc.py:89-118) and its ``full_grid*.npz`` cache
+# without the axis vectors.  A machine that can read those (pandas + pytables) exports each table once
+# with ``save_table_npz(DFInterpolator(df), "mist_tracks.npz")``; the GPU box then needs numpy only.
+
+def save_table_npz(dfi: DFInterpolator, filename):
+    """grid + axes + column / index names of any DFInterpolator in one ``.npz``."""
+    arrays = {"grid": dfi.grid, "columns": np.array(list(dfi.columns)), "index_names": np.array(list(dfi.index_names))}
+    for d, ax in enumerate(dfi.index_columns):
+        arrays["axis%d" % d] = np.asarray(ax, dtype=float)
+    np.savez(filename, **arrays)
+
+
+def load_table_npz(filename):
+    d = np.load(filename, allow_pickle=False)
+    ndim = d["grid"].ndim - 1
+    return DFInterpolator.from_arrays(np.ascontiguousarray(d["grid"], dtype=float), [d["axis%d" % k] for k in range(ndim)],
+                                      [str(c) for c in d["columns"]], [str(c) for c in d["index_names"]])
+
+
+def interpolator_from_tables(model, bc, tracks, bands=None, limits=None, eep_bounds=None):
+    """ModelGridInterpolator over two tables (DFInterpolator objects or ``save_table_npz`` files): the model
+    table indexed (feh, mass, EEP) for ``tracks=True`` or (log age, feh, EEP) otherwise, with the reference's
+    column names (Teff, logg, feh, Mbol, age|mass, dt_deep|dm_deep, ...), and the BC table indexed
+    (Teff, logg, [Fe/H], Av) with one column per band."""
+    from .models import (BolometricCorrectionGrid, EvolutionTrackGrid, EvolutionTrackInterpolator, IsochroneGrid,
+                         IsochroneInterpolator)
+    model = load_table_npz(model) if isinstance(model, (str, bytes)) or hasattr(model, "__fspath__") else model
+    bc = load_table_npz(bc) if isinstance(bc, (str, bytes)) or hasattr(bc, "__fspath__") else bc
+    bands = list(bands) if bands is not None else list(bc.columns)
+    grid_cls, ic_cls = (EvolutionTrackGrid, EvolutionTrackInterpolator) if tracks else (IsochroneGrid, IsochroneInterpolator)
+    return ic_cls(grid_cls(model, limits=limits), BolometricCorrectionGrid(bc, bands=bands), bands=bands,
+                  eep_bounds=eep_bounds)

@@ -176,3 +176,22 @@ def test_reference_style_entry_points_exist():
     for name in ("lnpost", "lnlike", "lnprior", "mnest_prior", "mnest_loglike", "fit_mcmc", "fit_multinest", "evidence",
                  "samples", "derived_samples", "sample_from_prior", "emcee_p0", "set_prior", "set_bounds", "bounds"):
         assert hasattr(ia.BasicStarModel, name), name
+
+
+def test_table_files_round_trip(tmp_path):
+    """ingest.save_table_npz / load_table_npz / interpolator_from_tables: the real-data route that needs no
+    HDF5 support on the GPU box (tables exported once where pandas + pytables exist)."""
+    from isochrones_amd import ingest
+    ic = ia.synthetic_track(bands=("V", "G"), fehs=[-1, 0], masses=[0.8, 1.0, 1.2], eeps=np.arange(300., 340.))
+    ingest.save_table_npz(ic.model_grid.interp, tmp_path / "trk.npz")
+    ingest.save_table_npz(ic.bc_grid.interp, tmp_path / "bc.npz")
+    ic2 = ingest.interpolator_from_tables(tmp_path / "trk.npz", str(tmp_path / "bc.npz"), tracks=True, bands=["G"],
+                                          limits=dict(mass=(0.8, 1.2), feh=(-1, 0), age=(5, 10.13)), eep_bounds=(300, 339))
+    m1, m2 = ic.model_grid.interp, ic2.model_grid.interp
+    assert np.array_equal(m1.grid, m2.grid, equal_nan=True) and list(m1.columns) == list(m2.columns)
+    assert all(np.array_equal(a, b) for a, b in zip(m1.index_columns, m2.index_columns))
+    assert list(m2.index_names) == list(m1.index_names) and ic2.bands == ["G"] and ic2.eep_bounds == (300, 339)
+    assert np.array_equal(ic.bc_grid.interp.grid, ic2.bc_grid.interp.grid)
+    d1 = ia.SingleStarModel(ic, G=(10.0, 0.02), Teff=(5700, 100)).model_desc()
+    d2 = ia.SingleStarModel(ic2, G=(10.0, 0.02), Teff=(5700, 100)).model_desc()
+    assert d1.n_bands == d2.n_bands == 1 and d1.bc_cols[0] == d2.bc_cols[0] == 1
