@@ -39,6 +39,7 @@ class Prior:
     kind = 0
     bounded = 0
     _bounds = (-np.inf, np.inf)
+    _version = 0          # bumped on every mutation: models sharing a prior object notice (starmodel._prior_state)
 
     @property
     def bounds(self):
@@ -47,6 +48,7 @@ class Prior:
     @bounds.setter
     def bounds(self, new):
         self._bounds = (float(new[0]), float(new[1]))
+        self._version += 1
         self._rebuild()
 
     def _rebuild(self):

@@ -29,13 +29,24 @@ _NOT_A_BAND = ("RA", "dec", "ra", "Dec", "maxAV", "parallax", "AV", "logg", "Tef
                "separation", "PA", "resolution", "relative", "N", "index", "id", "nu_max", "delta_nu")
 
 
+def _prior_state(priors):
+    """Identity + mutation counters of the prior objects a model's device constants were packed from (prior
+    objects may be shared between models, as reference tests/test_likelihood.py does)."""
+    eep = priors["eep"]
+    return tuple((id(p), p._version) for p in (priors["mass"], priors["age"], priors["feh"], priors["distance"],
+                                               priors["AV"], eep.orig_prior)) + (id(eep), tuple(eep.bounds))
+
+
 class EEPPrior:
     """Marker for the EEP prior: pdf(eep) = orig_prior(orig(eep)) * d(orig)/d(eep), evaluated on
     the device by interpolating (age, dt_deep) or (mass, dm_deep) (reference: priors.py:409-429)."""
 
     def __init__(self, ic, orig_prior, bounds=None, owner=None):
+        import weakref
         self.ic = ic
-        self._owner = owner
+        self._owners = weakref.WeakSet()        # models whose device constants depend on this object
+        if owner is not None:
+            self._owners.add(owner)
         self._orig_prior = orig_prior
         self.bounds = tuple(bounds) if bounds is not None else tuple(ic.eep_bounds)
         self.orig_par = ic.eep_replaces
@@ -51,8 +62,8 @@ class EEPPrior:
         if not isinstance(prior, DEVICE_PRIOR_TYPES):
             raise NotImplementedError("prior %r is not evaluable on the device" % (prior,))
         self._orig_prior = prior
-        if self._owner is not None:
-            self._owner._dirty()
+        for owner in list(self._owners):
+            owner._dirty()
 
 
 class _NestedFitMixin:
@@ -149,7 +160,7 @@ class BasicStarModel(_NestedFitMixin):
                 self.set_bounds(distance=(0, 1.0 / np.abs(unc) * 2000))
         if halo_fraction is not None:
             self._priors["feh"] = FehPrior(halo_fraction=halo_fraction)
-        self._handles = {}
+        self._handles, self._handle_ic, self._handle_state = {}, {}, {}
 
     # -- description ------------------------------------------------------------------------
     @property
@@ -204,8 +215,14 @@ class BasicStarModel(_NestedFitMixin):
         self._dirty()
 
     def set_prior(self, **kwargs):
+        """reference: StarModel.set_prior (starmodel.py:629-632).  ``eep=`` takes another model's EEP prior
+        object (tests/test_likelihood.py:19-20 shares one between two models)."""
         for prop, prior in kwargs.items():
-            if prop == "eep" or not isinstance(prior, DEVICE_PRIOR_TYPES):
+            if prop == "eep":
+                if not isinstance(prior, EEPPrior):
+                    raise NotImplementedError("the EEP prior must be an EEPPrior (orig_prior x d orig / d EEP)")
+                prior._owners.add(self)
+            elif not isinstance(prior, DEVICE_PRIOR_TYPES):
                 raise NotImplementedError("prior %r for %r is not evaluable on the device" % (prior, prop))
             self._priors[prop] = prior
             self._bounds[prop] = prior.bounds
@@ -253,14 +270,17 @@ class BasicStarModel(_NestedFitMixin):
             _cabi.lib().iso_model_destroy(h)
         self._handles = {}
         self._handle_ic = {}
+        self._handle_state = {}
 
     def handle(self, device=None):
         if device is None:
             device = dev.current_device()
         ich = self.ic.handle(device)
         h = self._handles.get(device)
-        if h is not None and self._handle_ic.get(device) != ich.value:
-            _cabi.lib().iso_model_destroy(h)   # the interpolator was rebound: rebuild
+        state = _prior_state(self._priors)
+        if h is not None and (self._handle_ic.get(device) != ich.value or self._handle_state.get(device) != state):
+            _cabi.lib().iso_model_destroy(h)   # the interpolator was rebound / a shared prior object changed: rebuild
+            self._handles.pop(device, None)
             h = None
         if h is None:
             if -1 in self.ic._prior_cols:
@@ -271,6 +291,7 @@ class BasicStarModel(_NestedFitMixin):
             _cabi.check(_cabi.lib().iso_model_create(ich, C.byref(desc), C.byref(h)))
             self._handles[device] = h
             self._handle_ic[device] = ich.value
+            self._handle_state[device] = _prior_state(self._priors)       # packing may have snapped bounds
         return h
 
     def __del__(self):
@@ -541,11 +562,13 @@ class TreeStarModel(_NestedFitMixin):
         self._priors["eep"] = EEPPrior(ic, self._priors["mass"], bounds=eep_bounds, owner=self)
         self._bounds = {"mass": None, "feh": None, "age": None, "distance": self._priors["distance"].bounds,
                         "AV": self._priors["AV"].bounds, "eep": self._priors["eep"].bounds}
+        for par in ("feh", "age"):           # the reference snaps these to the table on first use (the generic
+            self.bounds(par)                 # StarModel never asks for the mass bounds: its Chabrier prior keeps (0.1, 100))
         if maxAV is not None:
             self.set_bounds(AV=(0, maxAV))
         if max_distance is not None:
             self.set_bounds(distance=(0, max_distance))
-        self._handles = {}
+        self._handles, self._handle_ic, self._handle_state = {}, {}, {}
 
     ic = property(lambda self: self._ic)
 
@@ -577,7 +600,11 @@ class TreeStarModel(_NestedFitMixin):
         """reference: StarModel.set_prior (starmodel.py:629-632); as there, the EEP term keeps the mass prior it
         was built with (assign ``_priors["eep"].orig_prior`` to change it)."""
         for prop, prior in kwargs.items():
-            if prop == "eep" or not isinstance(prior, DEVICE_PRIOR_TYPES):
+            if prop == "eep":
+                if not isinstance(prior, EEPPrior):
+                    raise NotImplementedError("the EEP prior must be an EEPPrior (orig_prior x d orig / d EEP)")
+                prior._owners.add(self)
+            elif not isinstance(prior, DEVICE_PRIOR_TYPES):
                 raise NotImplementedError("prior %r for %r is not evaluable on the device" % (prior, prop))
             self._priors[prop] = prior
             self._bounds[prop] = prior.bounds
@@ -636,14 +663,17 @@ class TreeStarModel(_NestedFitMixin):
             _cabi.lib().iso_tree_model_destroy(h)
         self._handles = {}
         self._handle_ic = {}
+        self._handle_state = {}
 
     def handle(self, device=None):
         if device is None:
             device = dev.current_device()
         ich = self.ic.handle(device)
         h = self._handles.get(device)
-        if h is not None and self._handle_ic.get(device) != ich.value:
+        state = _prior_state(self._priors)
+        if h is not None and (self._handle_ic.get(device) != ich.value or self._handle_state.get(device) != state):
             _cabi.lib().iso_tree_model_destroy(h)
+            self._handles.pop(device, None)
             h = None
         if h is None:
             desc = self.tree_desc()
@@ -651,6 +681,7 @@ class TreeStarModel(_NestedFitMixin):
             _cabi.check(_cabi.lib().iso_tree_model_create(ich, C.byref(desc), C.byref(h)))
             self._handles[device] = h
             self._handle_ic[device] = ich.value
+            self._handle_state[device] = _prior_state(self._priors)
         return h
 
     def __del__(self):

@@ -358,6 +358,29 @@ def test_tree_model_vs_reference_golden(case, tree_kernel_path):
     fx.assert_close(dev_out.cpu().numpy(), g["lnpost"], RTOL, atol=1e-9, what="lnpost device")
 
 
+@pytest.mark.parametrize("which", ["all", "spec", "phot"])
+def test_reference_test_likelihood_compare_starmodels(which):
+    """reference tests/test_likelihood.py:15-58, test for test: the generic StarModel (observation tree built
+    from keywords) and BasicStarModel give the same lnlike / lnprior / lnpost for N = 1, 2, 3 once they share
+    their prior objects (incl. the EEP prior), at the reference's own parameter vectors."""
+    ic = ia.get_ichrone("mist", bands=["J", "K"])
+    props = dict(Teff=(5800, 100), logg=(4.5, 0.1), J=(3.58, 0.05), K=(3.22, 0.05), parallax=(100, 0.1))
+    if which == "spec":
+        props = {k: props[k] for k in ("Teff", "logg", "parallax")}
+    elif which == "phot":
+        props = {k: props[k] for k in ("J", "K", "parallax")}
+    for N, pars in ((1, [300, 9.8, 0.01, 100, 0.1]), (2, [300, 280, 9.8, 0.01, 100, 0.1]),
+                    (3, [300, 280, 260.0, 9.8, 0.01, 100, 0.1])):
+        m1 = ia.TreeStarModel(ic, N=N, **props)
+        m2 = ia.BasicStarModel(ic, N=N, **props)
+        for k in ["mass", "feh", "age", "distance", "AV", "eep"]:
+            m2.set_prior(**{k: m1._priors[k]})
+        assert np.isfinite(m2.lnpost(pars))
+        assert np.isclose(m1.lnlike(pars), m2.lnlike(pars), rtol=1e-10)
+        assert np.isclose(m1.lnprior(pars), m2.lnprior(pars), rtol=1e-10)
+        assert np.isclose(m1.lnpost(pars), m2.lnpost(pars), rtol=1e-10)
+
+
 def test_tree_model_random_batch_vs_oracle_and_basic_model(tree_kernel_path):
     """A 4-star, 2-system resolved configuration on mid-size tables against the oracle, and the
     keyword (unresolved) form against BasicStarModel evaluated by the fused kernel."""
