@@ -329,7 +329,12 @@ class ModelGridInterpolator:
         result with :meth:`get_eep_accurate` starting from the fast estimate, as the reference."""
         if accurate:
             eep0 = self.get_eep(mass, age, feh)
-            return self.get_eep_accurate(mass, age, feh, eep0=eep0 if np.isfinite(eep0) else 300, **kwargs)
+            if np.ndim(eep0) == 0:
+                return self.get_eep_accurate(mass, age, feh, eep0=eep0 if np.isfinite(eep0) else 300, **kwargs)
+            b = np.broadcast(mass, age, feh)           # arrays: one refinement per star, as the reference
+            m, a, f = [np.resize(x, b.shape).astype(float).ravel() for x in (mass, age, feh)]
+            return np.array([self.get_eep_accurate(mi, ai, fi, eep0=e if np.isfinite(e) else 300, **kwargs)
+                             for mi, ai, fi, e in zip(m, a, f, np.ravel(eep0))])
         args = [mass, age, feh]
         if any(dev.is_tensor(a) and a.is_cuda for a in args):
             import torch
@@ -350,16 +355,18 @@ class ModelGridInterpolator:
         res = out.cpu().numpy()
         return float(res[0]) if scalar else res
 
-    def generate(self, mass, age, feh, props="all", bands=None, eeps=None, distance=10, AV=0, **kwargs):
-        """Model columns + magnitudes of stars given (mass, log10 age, feh) as a DataFrame
-        (reference: models.py:580-631, DataFrame form)."""
+    def generate(self, mass, age, feh, props="all", bands=None, eeps=None, return_df=True, return_dict=False,
+                 distance=10, AV=0, all_As=False, **kwargs):
+        """Model columns + magnitudes of stars given (mass, log10 age, feh): a DataFrame (default) or, with
+        ``return_dict``, a dict of arrays; ``all_As`` adds the per-band extinctions ``A_<band>``; other keywords
+        (``accurate=True`` ...) go to :meth:`get_eep` (reference: models.py:580-631)."""
         import pandas as pd
         mass, age, feh, distance, AV = [np.atleast_1d(a).astype(float).ravel()
                                         for a in np.broadcast_arrays(mass, age, feh, distance, AV)]
         bands = self.bands if bands is None else list(bands)
         if eeps is None:
             eeps = np.atleast_1d(self.get_eep(mass, age, feh, **kwargs))
-        cols = list(self.model_grid.interp.columns) if props == "all" else list(props)
+        cols = list(self.model_grid.interp.columns) if (isinstance(props, str) and props == "all") else list(props)
         values = np.atleast_2d(self.interp_value([mass, eeps, feh], cols))
         out = pd.DataFrame(values, columns=cols)
         if bands:
@@ -370,6 +377,12 @@ class ModelGridInterpolator:
         out["AV"] = AV
         out["initial_feh"] = feh
         out["requested_age"] = age
+        if all_As and bands:
+            _, _, _, true_mags = self.interp_mag([mass, eeps, feh, distance, np.zeros_like(AV)], bands)
+            for j, b in enumerate(bands):
+                out["A_{}".format(b)] = out["{}_mag".format(b)].values - np.atleast_2d(true_mags)[:, j]
+        if return_dict or not return_df:
+            return {c: out[c].values for c in out.columns}
         return out
 
     def generate_binary(self, mass_A, mass_B, age, feh, bands=None, **kwargs):

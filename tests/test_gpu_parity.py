@@ -576,3 +576,42 @@ def test_randomised_soak_short(monkeypatch):
         runpy.run_path(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "soak.py"),
                        run_name="__main__")
     assert e.value.code == 0
+
+
+def test_docs_grid_interpolator_notebook_flow():
+    """docs/grid_interpolator.ipynb, call for call, on the MIST-shaped synthetic tables (values differ from
+    the notebook's, the calls, shapes and cross-consistency do not)."""
+    import pandas as pd
+    from isochrones_amd.mist import MIST_EvolutionTrack, MIST_Isochrone
+    mist = MIST_Isochrone()
+    pars = [353, 9.78, -1.24]                                    # eep, log(age), feh
+    v = mist.interp_value(pars, ["mass", "radius", "Teff"])
+    assert v.shape == (3,) and np.all(np.isfinite(v))
+    T, g, f, mags = mist.interp_mag(pars + [200, 0.11], ["K", "BP", "RP"])
+    assert np.isfinite([T, g, f]).all() and mags.shape == (3,)
+    mist_track = MIST_EvolutionTrack()
+    tp = [float(v[0]), 353, -1.24]                               # mass, eep, feh [matching above]
+    w = mist_track.interp_value(tp, ["mass", "radius", "Teff", "age"])
+    assert w.shape == (4,) and np.isfinite(w).all()
+    assert np.isclose(mist_track.mass(*tp), w[0]) and isinstance(float(mist_track.mass(*tp)), float)
+    iso = mist.isochrone(9.53, 0.1)
+    assert isinstance(iso, pd.DataFrame) and len(iso) > 100 and {"Teff", "logg", "K_mag", "eep"} <= set(iso.columns)
+    assert np.allclose(iso["age"], 9.53) and not iso.isna().any().any()
+    df = mist_track([0.8, 0.9, 1.0], 350, 0.0, distance=100, AV=0.1)
+    assert len(df) == 3 and "G_mag" in df.columns and "distance" not in df.columns      # as the reference
+    far = mist_track([0.8, 0.9, 1.0], 350, 0.0, distance=1000, AV=0.1)
+    assert np.allclose(far["G_mag"] - df["G_mag"], 5.0)
+    gen = mist_track.generate([0.81, 0.91, 1.01], 9.51, 0.01)
+    assert len(gen) == 3 and np.allclose(gen["requested_age"], 9.51)
+    e = mist_track.get_eep(1.01, 9.51, 0.01)
+    ea = mist_track.get_eep(1.01, 9.51, 0.01, accurate=True)
+    assert isinstance(e, float) and isinstance(ea, float) and abs(e - ea) < 3
+    ages = [mist_track.interp_value([1.01, x, 0.01], ["age"])[0] for x in (e, ea)]
+    assert abs(ages[1] - 9.51) <= abs(ages[0] - 9.51) + 1e-9 and abs(ages[1] - 9.51) < 1e-3
+    df0 = mist_track.generate([0.81, 0.91, 1.01], 9.51, 0.01, accurate=True)
+    rel = ((gen - df0) / df0).mean()
+    assert np.all(np.abs(rel[["Teff", "radius", "mass"]]) < 0.01)
+    d = mist_track.generate(1.0, 9.6, 0.0, return_dict=True, all_As=True, AV=0.3, bands=["G", "K"])
+    assert isinstance(d, dict) and d["A_G"][0] > 0 and d["A_K"][0] > 0        # toy BC tables: no band ordering
+    big = mist_track.generate(np.ones(10000) * 1.01, np.ones(10000) * 9.82, np.ones(10000) * 0.02)
+    assert len(big) == 10000
