@@ -587,6 +587,8 @@ class TreeStarModel(_NestedFitMixin):
         return [b for b in self.ic.bc_grid.bands if b in set(self.obs.bands)]
 
     def bounds(self, prop):
+        if prop not in self._bounds:              # parameter names carry system / star suffixes: eep_0_1, age_0, ...
+            prop = prop.split("_")[0]
         if self._bounds[prop] is None:
             if prop not in ("mass", "feh", "age"):
                 raise ValueError("Unknown property {}".format(prop))

@@ -429,3 +429,33 @@ def test_isotrack_model_vs_reference_golden():
     k = int(np.flatnonzero(np.isfinite(g["lnpost"]))[0])
     assert np.isclose(mod.lnpost(p[k]), g["lnpost"][k], rtol=RTOL)
     assert mod.lnpost(torch.as_tensor(p, device="cuda")).is_cuda
+
+
+def test_tree_model_fits_and_quantile_errors():
+    """The generic (observation-tree) model through both fit drivers, and the C-ABI argument checks of
+    iso_chain_quantiles."""
+    import ctypes as C
+    import torch
+    from isochrones_amd import _cabi, device as dev
+    from tests.test_tree_cpu import build_notebook_tree
+    ages = ia.grids.mist_log_ages()[60::2]
+    ic = ia.synthetic_isochrone(bands=("J", "H", "K"), ages=ages, fehs=[-1.0, -0.5, 0.0, 0.5], eeps=np.arange(150.0, 700.0),
+                                eep_bounds=(150, 699), limits=dict(age=(ages[0], ages[-1]), feh=(-1.0, 0.5)))
+    mod = ia.StarModel(ic, obs=build_notebook_tree("x"), N=2, index=[0, 1], parallax=(2.0, 0.05), Teff=(5800, 100))
+    assert isinstance(mod, ia.TreeStarModel)
+    mod.fit_mcmc(nwalkers=40, nburn=20, niter=10, seed=2)
+    s = mod.samples
+    assert len(s) == 400 and list(s.columns[:-1]) == list(mod.param_names) and np.isfinite(s["lnprob"]).all()
+    res = mod.fit_multinest(n_live_points=60, max_iter=400, seed=3)
+    assert np.isfinite(res.logz) and res.niter <= 400
+    lz, err = mod.evidence
+    assert lz == res.logz and err > 0 and len(mod.samples) >= 1
+    # iso_chain_quantiles refuses what it cannot sort in LDS / bad levels
+    lib, ctx = _cabi.lib(), dev.context(0)
+    x = torch.zeros(4, 8, 3, dtype=torch.float64, device="cuda")
+    out = torch.zeros(1, 3, 1, dtype=torch.float64, device="cuda")
+    q = (C.c_double * 1)(0.5)
+    assert lib.iso_chain_quantiles(ctx, dev.ptr(x), 4, 1, 8, 3, q, 1, dev.ptr(out), None) == 0
+    assert lib.iso_chain_quantiles(ctx, dev.ptr(x), 2000, 1, 8, 3, q, 1, dev.ptr(out), None) != 0      # 16000 samples
+    assert lib.iso_chain_quantiles(ctx, dev.ptr(x), 4, 1, 8, 3, (C.c_double * 1)(1.5), 1, dev.ptr(out), None) != 0
+    assert lib.iso_chain_quantiles(ctx, None, 4, 1, 8, 3, q, 1, dev.ptr(out), None) != 0
