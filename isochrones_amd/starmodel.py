@@ -482,9 +482,31 @@ class BasicStarModel(_NestedFitMixin):
 
     @property
     def derived_samples(self):
-        """Reference name for the table of derived quantities; here ``samples`` already carries the
-        sampled parameters and, for a single star, every model column and magnitude."""
-        return self.samples
+        """Derived quantities of the posterior samples (reference: ``_make_samples``, starmodel.py:1653-1707):
+        one star: every model column and band magnitude from ``ic(*params)``; two / three stars: the sampled
+        parameters, each component's columns with ``_0`` / ``_1`` / ``_2`` suffixes and the combined
+        magnitudes; plus ``parallax``, ``distance``, ``AV``."""
+        import pandas as pd
+        if getattr(self, "_derived_samples", None) is not None and self._derived_for is self.samples:
+            return self._derived_samples
+        df = self.samples
+        if self.N == 1:
+            out = self.ic(*[df[c].values for c in self.param_names])
+        else:
+            out = df[list(self.param_names) + ["lnprob"]].copy()
+            for k in range(self.N):
+                comp = self.ic(*[df[c].values for c in ("eep_%d" % k, "age", "feh", "distance", "AV")])
+                keep = [c for c in comp.columns if c not in ("eep", "age")]
+                comp = comp[keep].rename(columns={c: "%s_%d" % (c, k) for c in keep if c not in ("distance", "AV")})
+                out = pd.concat([out, comp.drop(columns=[c for c in ("distance", "AV") if c in comp.columns])], axis=1)
+            for b in self.ic.bands:
+                flux = sum(10 ** (-0.4 * out["%s_mag_%d" % (b, k)].values) for k in range(self.N))
+                out[b + "_mag"] = -2.5 * np.log10(flux)
+        out["parallax"] = 1000.0 / df["distance"].values
+        out["distance"] = df["distance"].values
+        out["AV"] = df["AV"].values
+        self._derived_samples, self._derived_for = out, df
+        return out
 
 
 class SingleStarModel(BasicStarModel):

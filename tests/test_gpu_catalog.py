@@ -459,3 +459,26 @@ def test_tree_model_fits_and_quantile_errors():
     assert lib.iso_chain_quantiles(ctx, dev.ptr(x), 2000, 1, 8, 3, q, 1, dev.ptr(out), None) != 0      # 16000 samples
     assert lib.iso_chain_quantiles(ctx, dev.ptr(x), 4, 1, 8, 3, (C.c_double * 1)(1.5), 1, dev.ptr(out), None) != 0
     assert lib.iso_chain_quantiles(ctx, None, 4, 1, 8, 3, q, 1, dev.ptr(out), None) != 0
+
+
+def test_derived_samples_single_and_binary():
+    """reference _make_samples (starmodel.py:1653-1707): per-component columns and combined magnitudes."""
+    ages = ia.grids.mist_log_ages()[60::2]
+    ic = ia.synthetic_isochrone(bands=("J", "K"), ages=ages, fehs=[-1.0, -0.5, 0.0, 0.5], eeps=np.arange(150.0, 700.0),
+                                eep_bounds=(150, 699), limits=dict(age=(ages[0], ages[-1]), feh=(-1.0, 0.5)))
+    truth = [380.0, 9.6, -0.1, 300.0, 0.1]
+    mags = ic.interp_mag(truth, ["J", "K"])[3]
+    one = ia.SingleStarModel(ic, J=(mags[0], 0.02), K=(mags[1], 0.02), parallax=(1000 / 300.0, 0.05))
+    one.fit_mcmc(nwalkers=40, nburn=30, niter=10, seed=1)
+    d = one.derived_samples
+    assert len(d) == 400 and {"Teff", "logg", "mass", "J_mag", "K_mag", "parallax", "distance", "AV"} <= set(d.columns)
+    assert np.allclose(d["parallax"], 1000.0 / one.samples["distance"])
+    two = ia.BinaryStarModel(ic, J=(mags[0] - 0.4, 0.02), K=(mags[1] - 0.4, 0.02), parallax=(1000 / 300.0, 0.05))
+    two.fit_mcmc(nwalkers=40, nburn=30, niter=10, seed=2)
+    d2 = two.derived_samples
+    want = {"eep_0", "eep_1", "age", "feh", "Teff_0", "Teff_1", "mass_0", "mass_1", "J_mag_0", "J_mag_1", "J_mag", "K_mag",
+            "parallax", "distance", "AV", "lnprob"}
+    assert want <= set(d2.columns) and "eep" not in d2.columns
+    comb = -2.5 * np.log10(10 ** (-0.4 * d2["J_mag_0"]) + 10 ** (-0.4 * d2["J_mag_1"]))
+    assert np.allclose(d2["J_mag"], comb) and np.all(d2["J_mag"] <= d2["J_mag_0"] + 1e-12)
+    assert np.all(d2["mass_0"] >= d2["mass_1"] - 1e-9)          # eep_0 >= eep_1 at one age and composition
