@@ -384,41 +384,51 @@ class BasicStarModel(_NestedFitMixin):
         return self.lnpost(cube)
 
     # -- start points -----------------------------------------------------------------------
-    def sample_from_prior(self, n, rng=None, require_valid=True, max_tries=50):
-        """[n, n_params] draws: non-EEP parameters from their priors, EEPs uniform in bounds;
-        rows with a non-finite lnpost are redrawn (reference: starmodel.py:1716-1748 resamples
-        EEPs with prior weights; here validity is enforced through the batched lnpost)."""
+    def sample_from_prior(self, n, values=False, require_valid=True, rng=None, max_tries=50):
+        """Draws from the priors as a DataFrame (``values=True``: a plain [n, n_params] array), reference
+        starmodel.py:1716-1748: the non-EEP parameters from their prior objects, every EEP by weighted
+        resampling of uniform integer EEPs with weight orig_prior(orig(eep)) x d orig / d EEP
+        (``EEP_prior.sample``, priors.py:431-463; the weights come from one batched ``interp_value``); rows
+        with a non-finite lnpost are redrawn (``require_valid``; one batched lnpost per round)."""
+        import pandas as pd
         rng = rng or np.random.default_rng()
-        names = self.param_names
+        names = list(self.param_names)
+        if n == 0:
+            return np.empty((0, len(names))) if values else pd.DataFrame(columns=names)
+        eep_names = [nm for nm in names if nm.startswith("eep")]
+        orig_par = self.ic.eep_replaces
+        deriv = "dt_deep" if orig_par == "age" else "dm_deep"
 
         def draw(m):
-            cols = []
-            for nme in names:
-                if nme.startswith("eep"):
-                    lo, hi = self.bounds(nme)
-                    cols.append(rng.uniform(lo, hi, m))
-                else:
-                    cols.append(self._priors[nme].sample(m, rng))
-            x = np.array(cols).T
+            cols = {nm: self._priors[nm].sample(m, rng) for nm in names if nm not in eep_names}
+            lo, hi = self._priors["eep"].bounds
+            for nm in eep_names:
+                cand = rng.integers(int(np.ceil(lo)), max(int(np.floor(hi)), int(np.ceil(lo)) + 1), size=m).astype(float)
+                pars = [cols["mass"], cand, cols["feh"]] if orig_par == "age" else [cand, cols["age"], cols["feh"]]
+                v = np.atleast_2d(self.ic.interp_value(pars, [deriv, orig_par]))
+                op = self._priors["eep"].orig_prior
+                w = np.array([op(x) if np.isfinite(x) else 0.0 for x in v[:, 1]]) * v[:, 0]
+                w = np.where(np.isfinite(w) & (w > 0), w, 0.0)
+                cols[nm] = cand[rng.choice(m, size=m, p=w / w.sum())] if w.sum() > 0 else cand
+            x = np.column_stack([cols[nm] for nm in names])
             if self.N > 1:   # eep_0 >= eep_1 >= eep_2
                 x[:, :self.N] = -np.sort(-x[:, :self.N], axis=1)
             return x
 
         out = draw(n)
-        if not require_valid:
-            return out
-        for _ in range(max_tries):
-            bad = ~np.isfinite(self.lnpost(out))
-            if not bad.any():
-                break
-            out[bad] = draw(int(bad.sum()))
-        return out
+        if require_valid:
+            for _ in range(max_tries):
+                bad = ~np.isfinite(self.lnpost(out))
+                if not bad.any():
+                    break
+                out[bad] = draw(max(int(bad.sum()), 2))[: int(bad.sum())]
+        return out if values else pd.DataFrame(out, columns=names)
 
 
     # -- MCMC (reference: fit_mcmc_old, starmodel.py:889-972; emcee replaced by the on-device
     #    stretch-move sampler in isochrones_amd/sampler.py) ------------------------------------
     def emcee_p0(self, nwalkers, rng=None):
-        return self.sample_from_prior(nwalkers, rng=rng, require_valid=True)
+        return self.sample_from_prior(nwalkers, values=True, rng=rng, require_valid=True)
 
     def fit_mcmc(self, nwalkers=300, nburn=200, niter=100, p0=None, seed=None, fused=None, **kwargs):
         """Burn in, reset, sample (reference: fit_mcmc_old).  ``fused`` selects the single-kernel

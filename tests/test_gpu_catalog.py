@@ -482,3 +482,22 @@ def test_derived_samples_single_and_binary():
     comb = -2.5 * np.log10(10 ** (-0.4 * d2["J_mag_0"]) + 10 ** (-0.4 * d2["J_mag_1"]))
     assert np.allclose(d2["J_mag"], comb) and np.all(d2["J_mag"] <= d2["J_mag_0"] + 1e-12)
     assert np.all(d2["mass_0"] >= d2["mass_1"] - 1e-9)          # eep_0 >= eep_1 at one age and composition
+
+
+def test_sample_from_prior_reference_semantics():
+    """reference starmodel.py:1716-1748 / priors.py:431-463: DataFrame of valid prior draws, EEPs resampled
+    with the EEP-prior weights (integers within the EEP bounds), values=True gives the plain array."""
+    import pandas as pd
+    ic = _small_track(("G", "BP", "RP"))
+    mod = ia.SingleStarModel(ic, G=(10.0, 0.05), parallax=(5.0, 0.2))
+    df = mod.sample_from_prior(500, rng=np.random.default_rng(1))
+    assert isinstance(df, pd.DataFrame) and list(df.columns) == list(mod.param_names) and len(df) == 500
+    assert np.isfinite(mod.lnpost(df.values)).all()
+    assert np.all(df["eep"] == np.round(df["eep"])) and df["eep"].between(*mod.bounds("eep")).all()
+    # weights = AgePrior(log age) x d log age / d EEP with a prior flat in linear age: old (late) points dominate,
+    # i.e. the draws are visibly not uniform in EEP
+    assert (df["eep"] > 425).mean() > 0.7
+    arr = mod.sample_from_prior(7, values=True, rng=np.random.default_rng(2))
+    assert isinstance(arr, np.ndarray) and arr.shape == (7, 5)
+    assert len(mod.sample_from_prior(0)) == 0
+    assert mod.emcee_p0(16, rng=np.random.default_rng(3)).shape == (16, 5)
