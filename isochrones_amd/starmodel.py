@@ -519,6 +519,47 @@ class BasicStarModel(_NestedFitMixin):
         return out
 
 
+    # -- summaries over the samples (reference: starmodel.py:1755-1841) -----------------------------
+    @property
+    def physical_quantities(self):
+        if self.N == 1:
+            return ["mass", "radius", "age", "Teff", "logg", "feh", "distance", "AV"]
+        cols = []
+        for q in ("mass", "radius"):
+            cols += ["%s_%d" % (q, k) for k in range(self.N)] if self.N == 3 else []
+        if self.N == 2:
+            cols = ["mass_0", "radius_0", "mass_1", "radius_1", "Teff_0", "Teff_1", "logg_0", "logg_1"]
+        else:
+            cols = sum([["mass_%d" % k, "radius_%d" % k] for k in range(3)], []) + \
+                ["Teff_%d" % k for k in range(3)] + ["logg_%d" % k for k in range(3)]
+        return cols + ["age", "feh", "distance", "AV"]
+
+    @property
+    def observed_quantities(self):
+        cols = ["{}_mag".format(b) for b in self.bands]
+        if self.N == 1:
+            return cols + list(self.props)
+        return cols + [p if p in self.derived_samples.columns else "{}_0".format(p) for p in self.props]
+
+    @property
+    def posterior_predictive(self):
+        """Mean chi^2 per observable of the derived samples against the observations."""
+        d = self.derived_samples
+        chisq = 0
+        for b in self.bands:
+            val, unc = self.kwargs[b]
+            chisq = chisq + (val - d["{}_mag".format(b)]) ** 2 / unc ** 2
+        for pname, col in zip(self.props, self.observed_quantities[len(self.bands):]):
+            val, unc = self.kwargs[pname]
+            chisq = chisq + (val - d[col]) ** 2 / unc ** 2
+        return float(np.mean(chisq)) / (len(self.bands) + len(self.props))
+
+    @property
+    def map_pars(self):
+        s = self.samples
+        return s.loc[s["lnprob"].idxmax(), list(self.param_names)].values.astype(float)
+
+
 class SingleStarModel(BasicStarModel):
     def __init__(self, *args, **kwargs):
         kwargs["N"] = 1

@@ -482,6 +482,12 @@ def test_derived_samples_single_and_binary():
     comb = -2.5 * np.log10(10 ** (-0.4 * d2["J_mag_0"]) + 10 ** (-0.4 * d2["J_mag_1"]))
     assert np.allclose(d2["J_mag"], comb) and np.all(d2["J_mag"] <= d2["J_mag_0"] + 1e-12)
     assert np.all(d2["mass_0"] >= d2["mass_1"] - 1e-9)          # eep_0 >= eep_1 at one age and composition
+    # summaries over the samples (reference starmodel.py:1755-1841)
+    assert set(one.physical_quantities) <= set(d.columns) and set(two.physical_quantities) <= set(d2.columns)
+    assert one.observed_quantities == ["J_mag", "K_mag", "parallax"] and set(two.observed_quantities) <= set(d2.columns)
+    assert np.isfinite(one.posterior_predictive) and one.posterior_predictive > 0 and two.posterior_predictive > 0   # short chains
+    mp = one.map_pars
+    assert mp.shape == (5,) and np.isclose(one.lnpost(mp), one.samples["lnprob"].max())
 
 
 def test_sample_from_prior_reference_semantics():
