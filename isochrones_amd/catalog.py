@@ -54,7 +54,19 @@ class StarCatalog:
     def __len__(self):
         return len(self.df)
 
+    def get_measurement(self, prop, values=False):
+        return self.df[prop].values, self.df[prop + "_unc"].values
+
+    def iter_bands(self, **kwargs):
+        for b, col in zip(self.bands, self.band_cols):
+            yield b, self.get_measurement(col, **kwargs)
+
+    def iter_props(self, **kwargs):
+        for p in self.props:
+            yield p, self.get_measurement(p, **kwargs)
+
     def set_prior(self, **kwargs):
+        """Prior objects applied to every model of the catalog (reference: catalog.py:117-124)."""
         self._prior_settings.update(kwargs)
 
     def model(self, i, ic, N=1, **kwargs):
@@ -66,7 +78,10 @@ class StarCatalog:
             mod.set_prior(**self._prior_settings)
         return mod
 
-    def iter_models(self, ic, N=1, indices=None, **kwargs):
+    def iter_models(self, ic=None, N=1, indices=None, **kwargs):
+        if ic is None:
+            from .models import get_ichrone
+            ic = get_ichrone("mist", bands=self.bands)
         for i in (range(len(self.df)) if indices is None else indices):
             yield self.model(i, ic, N=N, **kwargs)
 
@@ -154,7 +169,8 @@ class CatalogPosterior:
             arr["has_parallax"] = has.astype(np.int32)
             arr["plx_val"] = np.where(has, v, 0.0)
             arr["plx_unc"] = np.where(has, u, 1.0)
-            if "max_distance" not in model_kwargs:
+            # (a distance prior installed through set_prior keeps its own bounds, as in the per-star models)
+            if "max_distance" not in model_kwargs and "distance" not in catalog._prior_settings:
                 default_hi = 10000.0
                 with np.errstate(divide="ignore", invalid="ignore"):
                     hi = np.where(has & (v > 0), 1.0 / v * 2000, np.where(has & (v < 0), 1.0 / np.abs(u) * 2000,

@@ -137,6 +137,9 @@ def test_star_catalog_schema():
     with pytest.raises(ValueError):
         ia.StarCatalog(df.drop(columns=["K_mag_unc"]))
     ic = ia.synthetic_isochrone(bands=("J", "K"), ages=[9.0, 9.5, 10.0], fehs=[-0.5, 0.0, 0.5], eeps=np.arange(300., 340.))
+    v, u = cat.get_measurement("parallax")
+    assert list(v) == [5.0, 2.0] and list(u) == [0.1, 0.1]
+    assert [b for b, _ in cat.iter_bands()] == ["J", "K"] and [p for p, _ in cat.iter_props()] == ["parallax"]
     mods = list(cat.iter_models(ic, N=2))
     assert len(mods) == 2 and mods[0].N == 2 and mods[1].bands == ["J", "K"]
     assert mods[1].kwargs["parallax"] == (2.0, 0.1) and mods[1].bounds("distance") == (0, 1000.0)
