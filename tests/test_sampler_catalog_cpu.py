@@ -177,6 +177,17 @@ def test_vectorised_catalog_descriptors_equal_per_model_descriptors():
     assert arr["has_parallax"][3] == 0 and arr["prior_distance"]["hi"][3] == 10000.0
     assert np.isclose(arr["prior_distance"]["hi"][5], 2000 / 0.05)
     assert np.isnan(arr["spec_val"][7, 0])
+    # catalog-wide prior objects (reference catalog.py:117-124) reach both forms identically
+    from isochrones_amd import priors as P
+    cat.set_prior(distance=P.GaussianPrior(300.0, 100.0, bounds=(1.0, 900.0)), feh=P.FlatPrior((-0.8, 0.3)),
+                  AV=P.PowerLawPrior(0.5, (0.0, 1.0)))
+    arr2, _ = CatalogPosterior.build_descs(cat, ic)
+    for i in (0, 3, 5, 11):
+        w = np.frombuffer(cat.model(i, ic).model_desc(), dtype=arr2.dtype)[0]
+        for name in arr2.dtype.names:
+            a, b = np.asarray(arr2[i][name]), np.asarray(w[name])
+            assert a.tobytes() == b.tobytes() or (name in ("plx_val", "plx_unc") and not w["has_parallax"]), (i, name, a, b)
+    assert arr2["prior_distance"]["hi"][5] == 900.0 and arr2["prior_distance"]["kind"][0] == _cabi.PRIOR_GAUSS
 
 
 def test_fit_catalog_checkpoint_resume(tmp_path):
