@@ -3,21 +3,53 @@
 // (iso_hip.hip) with every model-star gather done by the wave-cooperative coop_star / coop_bc of the
 // fused kernel.  One lane owns one sample; the leaf loop has a wave-uniform trip count, so all 64 lanes
 // reach every cooperative gather together.
+#include <cstdlib>
+
 #include "iso_fast_kernel.h"
 
 namespace iso {
 namespace fastk {
 
-template <int NB>
-__device__ __forceinline__ double tree_addmags(const double (*flux)[NB], uint32_t mask, int band, int n_leaves)
-{
-    double tot = 0.0;
-    for (int l = 0; l < n_leaves; ++l)
-        if (mask & (1u << l)) tot += flux[l][band];
-    return -2.5 * log10(tot);
-}
+// NL > 0: the tree has exactly NL model stars, every per-leaf array is indexed at compile time and lives
+// in registers (the common 1-4 star trees); NL = 0: runtime leaf count, arrays in per-lane scratch.
+template <int NB, int NL>
+struct TreeLeaves {
+    static constexpr bool STATIC = NL > 0;
+    static constexpr int ML = STATIC ? NL : ISO_TREE_MAX_LEAVES;
+    double star[ML][6];
+    double flux[ML][NB];
 
-template <int NB>
+    __device__ __forceinline__ double addmags(uint32_t mask, int band, int n_leaves) const
+    {
+        double tot = 0.0;
+        if constexpr (STATIC) {
+#pragma unroll
+            for (int l = 0; l < NL; ++l)
+#pragma unroll
+                for (int b = 0; b < NB; ++b) tot += (((mask >> l) & 1u) && b == band) ? flux[l][b] : 0.0;
+        } else {
+            for (int l = 0; l < n_leaves; ++l)
+                if (mask & (1u << l)) tot += flux[l][band];
+        }
+        return -2.5 * log10(tot);
+    }
+
+    __device__ __forceinline__ double prop(int leaf, int q) const
+    {
+        if constexpr (STATIC) {
+            double v = 0.0;
+#pragma unroll
+            for (int l = 0; l < NL; ++l)
+#pragma unroll
+                for (int k = 0; k < 6; ++k) v = (l == leaf && k == q) ? star[l][k] : v;
+            return v;
+        } else {
+            return star[leaf][q];
+        }
+    }
+};
+
+template <int NB, int NL>
 __global__ __launch_bounds__(BLOCK) void k_lnpost_tree_fast(const FastArgs A, const DevTree* __restrict__ Tp)
 {
     extern __shared__ double lds[];
@@ -28,19 +60,16 @@ __global__ __launch_bounds__(BLOCK) void k_lnpost_tree_fast(const FastArgs A, co
     const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     const bool active = i < A.n;
     const int64_t ii = active ? i : (A.n - 1);
-    double p[ISO_TREE_MAX_PARAMS];
-    {
-        const double* __restrict__ src = A.pars + ii * A.stride_n;
-        for (int j = 0; j < T.n_params; ++j) p[j] = src[j * A.stride_p];
-    }
+    const double* __restrict__ src = A.pars + ii * A.stride_n;
+    auto par = [&](int j) { return src[j * A.stride_p]; };        // parameters stay in memory (L1/L2 hits)
+    const int n_leaves = (NL > 0) ? NL : T.n_leaves;
+    TreeLeaves<NB, NL> S;
     // ---- every model star: model-table gather, then magnitudes as fluxes ----
-    double star[ISO_TREE_MAX_LEAVES][6];
-    double flux[ISO_TREE_MAX_LEAVES][NB];
-    for (int l = 0; l < T.n_leaves; ++l) {
+    auto leaf = [&](int l) {
         const int s = T.leaf_system[l];
         const int base = T.sys_base[s], N = T.n_stars[s];
-        const double eep = p[base + T.leaf_slot[l]], age = p[base + N], feh = p[base + N + 1];
-        const double dist = p[base + N + 2], AV = p[base + N + 3];
+        const double eep = par(base + T.leaf_slot[l]), age = par(base + N), feh = par(base + N + 1);
+        const double dist = par(base + N + 2), AV = par(base + N + 3);
         const bool ok3 = active && !(age != age) && !(feh != feh) && !(eep != eep) && !lds_oob(lds, A.m0, age) &&
                          !lds_oob(lds, A.m1, feh) && !eep_oob(A, eep);
         int i0 = 0, i1 = 0, i2 = 0;
@@ -53,7 +82,7 @@ __global__ __launch_bounds__(BLOCK) void k_lnpost_tree_fast(const FastArgs A, co
         double v[6];
         coop_star(A, L, ok3, (uint32_t)((int64_t)i0 * A.s0 + (int64_t)i1 * A.s1 + i2), w, v);
 #pragma unroll
-        for (int q = 0; q < 6; ++q) star[l][q] = v[q];
+        for (int q = 0; q < 6; ++q) S.star[l][q] = v[q];
         const double Tf = v[0], g = v[1], f = v[2];
         const bool ok4 = ok3 && !(AV != AV) && !(Tf != Tf) && !(g != g) && !(f != f) && !lds_oob(lds, A.b0, Tf) &&
                          !lds_oob(lds, A.b1, g) && !lds_oob(lds, A.b2, f) && !lds_oob(lds, A.b3, AV);
@@ -65,7 +94,13 @@ __global__ __launch_bounds__(BLOCK) void k_lnpost_tree_fast(const FastArgs A, co
         coop_bc<NB>(A, L, ok4, (uint32_t)((int64_t)j0 * A.bs0 + (int64_t)j1 * A.bs1 + (int64_t)j2 * A.bs2 + j3), w4v, bc);
         const double dm = 5 * log10(dist / 10.0);
 #pragma unroll
-        for (int b = 0; b < NB; ++b) flux[l][b] = exp10(-0.4 * (v[3] + dm - bc[b]));
+        for (int b = 0; b < NB; ++b) S.flux[l][b] = exp10(-0.4 * (v[3] + dm - bc[b]));
+    };
+    if constexpr (NL > 0) {
+#pragma unroll
+        for (int l = 0; l < NL; ++l) leaf(l);
+    } else {
+        for (int l = 0; l < n_leaves; ++l) leaf(l);
     }
     if (!active) return;                      // no cooperative work below
     // ---- lnprior (starmodel.py:557-613) ----
@@ -75,25 +110,31 @@ __global__ __launch_bounds__(BLOCK) void k_lnpost_tree_fast(const FastArgs A, co
         const int base = T.sys_base[s], N = T.n_stars[s];
         const DevPrior* pri[4] = {&T.prior_age, &T.prior_feh, &T.prior_distance, &T.prior_AV};
         for (int j = 0; j < 4 && !dead; ++j) {
-            const double val = p[base + N + j];
+            const double val = par(base + N + j);
             if (val < T.bound_lo[j] || val > T.bound_hi[j]) { dead = true; break; }
             lnp += ln_pdf<false>(*pri[j], val, 0.0);
             if (!isfinite(lnp)) dead = true;
         }
         for (int j = 1; j < N && !dead; ++j)
-            if (!(p[base + j] <= p[base + j - 1])) dead = true;
+            if (!(par(base + j) <= par(base + j - 1))) dead = true;
         if (dead) break;
-        for (int l = 0; l < T.n_leaves; ++l) {
-            if (T.leaf_system[l] != s) continue;
-            const double eep = p[base + T.leaf_slot[l]];
+        auto eep_prior = [&](int l) {
+            if (T.leaf_system[l] != s) return;
+            const double eep = par(base + T.leaf_slot[l]);
             double term;
             if (eep < T.eep_lo || eep > T.eep_hi) {
                 term = -f_inf();
             } else {
-                const double lc = ln_call(T.prior_mass, star[l][4]), deriv = star[l][5];
+                const double lc = ln_call(T.prior_mass, S.star[l][4]), deriv = S.star[l][5];
                 term = (lc == -f_inf()) ? ((deriv != deriv) ? f_nan() : -f_inf()) : lc + log(deriv);
             }
             lnp += term;
+        };
+        if constexpr (NL > 0) {
+#pragma unroll
+            for (int l = 0; l < NL; ++l) eep_prior(l);
+        } else {
+            for (int l = 0; l < n_leaves; ++l) eep_prior(l);
         }
     }
     if (dead) lnp = -f_inf();
@@ -106,9 +147,9 @@ __global__ __launch_bounds__(BLOCK) void k_lnpost_tree_fast(const FastArgs A, co
         for (int t = 0; t < T.n_terms && !bad; ++t) {
             const iso_tree_term& tt = T.terms[t];
             double mag = tt.mag;
-            double mod = tree_addmags<NB>(flux, tt.mask, tt.band, T.n_leaves);
+            double mod = S.addmags(tt.mask, tt.band, n_leaves);
             if (tt.relative) {
-                mod -= tree_addmags<NB>(flux, tt.ref_mask, tt.band, T.n_leaves);
+                mod -= S.addmags(tt.ref_mask, tt.band, n_leaves);
                 mag -= tt.ref_mag;
             }
             const double r = mag - mod;
@@ -117,24 +158,24 @@ __global__ __launch_bounds__(BLOCK) void k_lnpost_tree_fast(const FastArgs A, co
         }
         for (int k = 0; k < T.n_spec && !bad; ++k) {
             const iso_tree_prop& sp = T.spec[k];
-            const double r = sp.a - star[sp.leaf][sp.prop];
+            const double r = sp.a - S.prop(sp.leaf, sp.prop);
             lnl += -0.5 * (r * r) / (sp.b * sp.b) + T.spec_g0[k];
             if (!isfinite(lnl)) bad = true;
         }
         for (int k = 0; k < T.n_limits && !bad; ++k) {
             const iso_tree_prop& lm = T.limits[k];
-            const double mod = star[lm.leaf][lm.prop];
+            const double mod = S.prop(lm.leaf, lm.prop);
             if (mod < lm.a || mod > lm.b || !isfinite(mod)) bad = true;
         }
         if (!bad) {
             for (int s = 0; s < T.n_systems; ++s)
                 if (T.has_plx[s]) {
-                    const double r = T.plx_val[s] - 1.0 / p[T.sys_base[s] + T.n_stars[s] + 2] * 1000.0;
+                    const double r = T.plx_val[s] - 1.0 / par(T.sys_base[s] + T.n_stars[s] + 2) * 1000.0;
                     lnl += -0.5 * (r * r) / (T.plx_unc[s] * T.plx_unc[s]) + T.plx_g0[s];
                 }
             for (int s = 0; s < T.n_systems; ++s)
                 if (T.has_av[s]) {
-                    const double r = T.av_val[s] - p[T.sys_base[s] + T.n_stars[s] + 3];
+                    const double r = T.av_val[s] - par(T.sys_base[s] + T.n_stars[s] + 3);
                     lnl += -0.5 * (r * r) / (T.av_unc[s] * T.av_unc[s]) + T.av_g0[s];
                 }
             if (!isfinite(lnl)) bad = true;
@@ -148,19 +189,42 @@ __global__ __launch_bounds__(BLOCK) void k_lnpost_tree_fast(const FastArgs A, co
 
 }  // namespace fastk
 
-bool launch_tree_fast(int nb, const FastArgs& A, const DevTree* T, hipStream_t s)
+template <int NL>
+static bool launch_tree_nl(int nb, const FastArgs& A, const DevTree* T, hipStream_t s)
 {
     using namespace fastk;
     const dim3 g((unsigned)((A.n + BLOCK - 1) / BLOCK)), b(BLOCK);
     auto sh = [&](int n) { return (size_t)(((A.axes_len + 1) & ~1) + coop_lds_doubles(n)) * sizeof(double); };
     switch (nb) {
 #define ISO_TREE_CASE(N) \
-    case N: hipLaunchKernelGGL((k_lnpost_tree_fast<N>), g, b, sh(N), s, A, T); return true;
+    case N: hipLaunchKernelGGL((k_lnpost_tree_fast<N, NL>), g, b, sh(N), s, A, T); return true;
         ISO_TREE_CASE(1) ISO_TREE_CASE(2) ISO_TREE_CASE(3) ISO_TREE_CASE(4) ISO_TREE_CASE(5) ISO_TREE_CASE(6)
-        ISO_TREE_CASE(7) ISO_TREE_CASE(8) ISO_TREE_CASE(9) ISO_TREE_CASE(10) ISO_TREE_CASE(11) ISO_TREE_CASE(12)
+        ISO_TREE_CASE(7) ISO_TREE_CASE(8)
+    default: break;
+    }
+    if (NL != 0) return false;
+    switch (nb) {
+        ISO_TREE_CASE(9) ISO_TREE_CASE(10) ISO_TREE_CASE(11) ISO_TREE_CASE(12)
 #undef ISO_TREE_CASE
     default: return false;
     }
+}
+
+// n_leaves 1..4 with up to 8 bands run the register-resident instantiation, everything else the runtime one
+bool launch_tree_fast(int nb, int n_leaves, const FastArgs& A, const DevTree* T, hipStream_t s)
+{
+    // ISOCHRONES_AMD_TREE_RUNTIME_LEAVES=1 forces the runtime-leaf-count instantiation (tests: it otherwise
+    // only serves trees with more than 4 stars or more than 8 bands)
+    const char* rt = getenv("ISOCHRONES_AMD_TREE_RUNTIME_LEAVES");
+    if (nb <= 8 && !(rt && rt[0] == '1')) {
+        switch (n_leaves) {
+        case 1: return launch_tree_nl<1>(nb, A, T, s);
+        case 2: return launch_tree_nl<2>(nb, A, T, s);
+        case 3: return launch_tree_nl<3>(nb, A, T, s);
+        case 4: return launch_tree_nl<4>(nb, A, T, s);
+        }
+    }
+    return launch_tree_nl<0>(nb, A, T, s);
 }
 
 }  // namespace iso

@@ -1384,7 +1384,7 @@ struct iso_tree_model {
     DevTree* d_tree;
     double* d_bc_hot;
     Grid4V g4;
-    int n_bands;
+    int n_bands, n_leaves;
     double* d_bcq;           // corner-packed BC for the tree's bands (fast form), may be null
     double* d_axes_blob;
     bool fast_ok;
@@ -2359,6 +2359,7 @@ int iso_tree_model_create(iso_ic* ic, const iso_tree_desc* d, iso_tree_model** o
     m->d_axes_blob = nullptr;
     m->fast_ok = false;
     m->n_bands = d->n_bands;
+    m->n_leaves = d->n_leaves;
     DevTree* H = new DevTree();
     std::memset(H, 0, sizeof(DevTree));
     H->n_systems = d->n_systems; H->n_leaves = d->n_leaves; H->n_bands = d->n_bands;
@@ -2454,7 +2455,7 @@ int iso_tree_lnpost(iso_tree_model* m, const double* pars, int64_t stride_n, int
         F.lnprior = lnprior_out;
         F.lnlike = lnlike_out;
         DeviceGuard guard(m->device);
-        if (launch_tree_fast(m->n_bands, F, m->d_tree, as_stream(stream))) {
+        if (launch_tree_fast(m->n_bands, m->n_leaves, F, m->d_tree, as_stream(stream))) {
             HIP_TRY(hipGetLastError());
             return ISO_OK;
         }

@@ -230,7 +230,7 @@ struct MagOut {
 // defined in iso_fast_mag.hip: interp_mag on the corner-packed tables (nb = 1..12)
 bool launch_interp_mag_fast(int kind, int nb, const FastArgs& A, const MagOut& O, hipStream_t s);
 // defined in iso_fast_tree.hip: observation-tree lnpost on the corner-packed tables (1..12 bands)
-bool launch_tree_fast(int nb, const FastArgs& A, const DevTree* T, hipStream_t s);
+bool launch_tree_fast(int nb, int n_leaves, const FastArgs& A, const DevTree* T, hipStream_t s);
 bool launch_stretch(int kind, int n_stars, int n_bands, const FastArgs& A, const StretchArgs& S, hipStream_t s);
 // dynamic LDS bytes one workgroup of the persistent sampler kernel needs for W-walker ensembles, and how
 // many ensembles such a workgroup owns

@@ -335,10 +335,13 @@ def test_fit_catalog_two_ranks_on_the_gpu(tmp_path):
 from tests.test_tree_cpu import TREE_CASES, make_tree_model  # noqa: E402
 
 
-@pytest.fixture(params=["auto", "generic"])
+@pytest.fixture(params=["auto", "auto-runtime-leaves", "generic"])
 def tree_kernel_path(request, monkeypatch):
-    """auto: k_lnpost_tree_fast (cooperative gathers on the corner-packed tables); generic: k_lnpost_tree."""
-    monkeypatch.setenv("ISOCHRONES_AMD_PATH", request.param)
+    """auto: k_lnpost_tree_fast (cooperative gathers on the corner-packed tables; register-resident for 1-4
+    stars, or with a runtime star count); generic: k_lnpost_tree."""
+    monkeypatch.setenv("ISOCHRONES_AMD_PATH", request.param.split("-")[0])
+    if request.param.endswith("runtime-leaves"):
+        monkeypatch.setenv("ISOCHRONES_AMD_TREE_RUNTIME_LEAVES", "1")
     return request.param
 
 
