@@ -1,16 +1,18 @@
 // isochrones_amd — hand-written HIP (gfx950 / CDNA4) implementation of the isochrones hot path
 // behind the C ABI of include/isochrones_amd.h.
 //
-// Kernels (all float64, gather/latency bound — no MFMA on purpose, this is interpolation):
-//   k_interp<ND>        K3  N-D bracket search + multilinear gather of an arbitrary column subset
-//                           (reference semantics: isochrones/interp.py:10-35, 63-338)
-//   k_interp_mag        K4  3-D model gather -> 4-D BC gather -> magnitudes
-//                           (reference semantics: isochrones/mags.py:8-124)
-//   k_lnpost<...>       K1+K2 fused: priors + 1-3 component stars + likelihood reduce
-//                           (isochrones/likelihood.py:16-147, starmodel.py:538-542,1563-1635,
-//                            priors.py lnpdf's)
-//   k_unit_cube             mnest_prior (starmodel.py:1637-1640)
-//   k_pack_hot / k_pack_bc  one-off table repacks (hot columns AoS; model's bands only)
+// This file: the C ABI and its host-side bookkeeping.  Device code (all float64, gather/latency bound — no MFMA
+// on purpose, this is interpolation) lives in
+//   kernels/k_interp.h          K3  N-D bracket search + multilinear gather of an arbitrary column subset
+//                                   (isochrones/interp.py:10-35, 63-338); column-parallel and wide-pack forms
+//   kernels/k_interp_mag.h      K4  3-D model gather -> 4-D BC gather -> magnitudes (isochrones/mags.py:8-124)
+//   kernels/k_lnpost_generic.h  K1+K2 fused: priors + 1-3 component stars + likelihood reduce, any table shape
+//                                   (likelihood.py:16-147, starmodel.py:538-542,1563-1635, priors.py)
+//   kernels/k_lnpost_tree.h     generic StarModel over a flattened ObservationTree
+//   kernels/k_interp_eep.h, k_chain_quantiles.h, k_small_and_pack.h (mnest_prior, table packers)
+//   kernels/dev_*.h             shared device helpers (axis staging, brackets, gathers, prior families)
+//   iso_fast_kernel.h + iso_fast_*.hip   the fast fused kernels on the corner-packed tables (lnpost, sampler,
+//                                   interp_mag, tree), one translation unit per parametrisation / star count
 //
 // Mapping: one lane = one sample, 256-thread workgroups (4 wave64), grid-stride over samples.
 // Short irregular axes are staged in LDS once per workgroup and searched with a branch-free
@@ -63,1144 +65,16 @@ int fail(int code, const std::string& msg)
 // ======================================================================================
 namespace {
 
-__device__ __forceinline__ double d_nan() { return __longlong_as_double(0x7ff8000000000000LL); }
-__device__ __forceinline__ double d_inf() { return __longlong_as_double(0x7ff0000000000000LL); }
-
-// Cooperative copy of the non-uniform axes into LDS.  Must be followed by __syncthreads().
-template <int NAX>
-__device__ __forceinline__ void stage_axes(const AxisD* ax, double* lds)
-{
-#pragma unroll
-    for (int d = 0; d < NAX; ++d) {
-        if (ax[d].lds_off >= 0) {
-            const double* __restrict__ src = ax[d].g;
-            double* dst = lds + ax[d].lds_off;
-            for (int j = threadIdx.x; j < ax[d].n; j += blockDim.x) dst[j] = src[j];
-        }
-    }
-}
-
-// Branch-free bisection on a sorted axis: base = largest index with a[base] <= x, clamped to n-2.
-template <typename PTR>
-__device__ __forceinline__ void bisect(PTR ax, int n, double x, int& i, double& t)
-{
-    int base = 0, len = n;
-    while (len > 1) {
-        const int half = len >> 1;
-        base = (ax[base + half] <= x) ? base + half : base;
-        len -= half;
-    }
-    base = min(base, n - 2);
-    const double lo = ax[base], hi = ax[base + 1];
-    i = base;
-    t = (x - lo) / (hi - lo);
-}
-
-// Bracket of x on one axis.  Precondition: a_0 <= x <= a_{n-1} (caller has done the bounds
-// test, reference isochrones/interp.py:106-114).
-__device__ __forceinline__ void bracket(const AxisD& A, const double* lds, double x, int& i, double& t)
-{
-    const int n = A.n;
-    if (A.uniform) {
-        // O(1) index with an exact fix-up against the node values (node(i) reproduces the stored
-        // axis value bit-for-bit, verified on the host at table creation).
-        const double a0 = A.a0, st = A.step;
-        int k = (int)((x - a0) / st);
-        k = max(0, min(k, n - 2));
-        double lo = fma((double)k, st, a0);
-        if (lo > x) {
-            --k;
-        } else if (k < n - 2 && fma((double)(k + 1), st, a0) <= x) {
-            ++k;
-        }
-        k = max(0, min(k, n - 2));
-        lo = fma((double)k, st, a0);
-        const double hi = fma((double)(k + 1), st, a0);
-        i = k;
-        t = (x - lo) / (hi - lo);
-        return;
-    }
-    if (A.lds_off >= 0) bisect(lds + A.lds_off, n, x, i, t);   // LDS address space (ds_read)
-    else bisect(A.g, n, x, i, t);                              // global
-}
-
-__device__ __forceinline__ bool out_of_axis(const AxisD& A, const double* lds, double x)
-{
-    double first, last;
-    if (A.uniform) {
-        first = A.a0;
-        last = fma((double)(A.n - 1), A.step, A.a0);
-    } else {
-        if (A.lds_off >= 0) {
-            first = lds[A.lds_off];
-            last = lds[A.lds_off + A.n - 1];
-        } else {
-            first = A.g[0];
-            last = A.g[A.n - 1];
-        }
-    }
-    // written so that NaN is *not* out of bounds here (the NaN test comes first in the reference)
-    return (x < first) || (x > last);
-}
-
-// -------------------------------------------------------------------------------------------
-// K3: generic N-D interpolation of k selected columns
-// -------------------------------------------------------------------------------------------
-struct InterpArgs {
-    AxisD ax[ISO_MAX_DIM];
-    int64_t stride[ISO_MAX_DIM];   // cell strides
-    const double* grid;
-    int ncol;
-    const double* x[ISO_MAX_DIM];
-    int64_t n;
-    int k;
-    int32_t icols[ISO_MAX_COLS];
-    double* out;
-};
-
-// Column-parallel mapping: G = ceil(k/2) adjacent lanes share one sample, lane `sub` owns the
-// selected columns 2*sub and 2*sub+1.  For every corner the G lanes read neighbouring columns of
-// the same table row (one or two cache lines) and finally write k contiguous doubles — coalesced
-// loads and stores with no cross-lane reduction; the bracket search is repeated by the G lanes
-// (cheap: ~150 VALU against >= 1 KB of gathered table per sample).  k = 1, 2 degenerate to one lane
-// per sample.
-template <int ND>
-__global__ __launch_bounds__(BLOCK) void k_interp(const InterpArgs A)
-{
-    extern __shared__ double lds[];
-    stage_axes<ND>(A.ax, lds);
-    __syncthreads();
-    const int G = (A.k + 1) >> 1;            // lanes per sample
-    const int S = 64 / G;                    // samples per wave
-    const int lane = threadIdx.x & 63;
-    const int slot = lane / G, sub = lane - slot * G;
-    if (slot >= S) return;                   // leftover lanes (no cross-lane operations below)
-    const int c0 = A.icols[2 * sub];
-    const bool two = (2 * sub + 1) < A.k;
-    const int c1 = two ? A.icols[2 * sub + 1] : c0;
-    const int64_t wave0 = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
-    const int64_t nwaves = ((int64_t)gridDim.x * BLOCK) >> 6;
-    for (int64_t i = wave0 * S + slot; i < A.n; i += nwaves * S) {
-        double x[ND];
-        bool bad = false;
-#pragma unroll
-        for (int d = 0; d < ND; ++d) {
-            x[d] = A.x[d][i];
-            bad |= (x[d] != x[d]);
-        }
-        if (!bad) {
-#pragma unroll
-            for (int d = 0; d < ND; ++d) bad |= out_of_axis(A.ax[d], lds, x[d]);
-        }
-        double* o = A.out + i * A.k + 2 * sub;
-        if (bad) {
-            o[0] = d_nan();
-            if (two) o[1] = d_nan();
-            continue;
-        }
-        double t[ND];
-        int64_t base = 0;
-#pragma unroll
-        for (int d = 0; d < ND; ++d) {
-            int idx;
-            bracket(A.ax[d], lds, x[d], idx, t[d]);
-            base += (int64_t)idx * A.stride[d];
-        }
-        double v0 = 0.0, v1 = 0.0;
-#pragma unroll
-        for (int j = 0; j < (1 << ND); ++j) {
-            double ww = 1.0;
-            int64_t oo = base;
-#pragma unroll
-            for (int d = 0; d < ND; ++d) {
-                const int bit = (j >> (ND - 1 - d)) & 1;
-                ww *= bit ? t[d] : (1 - t[d]);
-                oo += bit ? A.stride[d] : 0;
-            }
-            const double* __restrict__ cell = A.grid + oo * A.ncol;
-            v0 += cell[c0] * ww;
-            v1 += cell[c1] * ww;
-        }
-        o[0] = v0;
-        if (two) o[1] = v1;
-    }
-}
-
-// -------------------------------------------------------------------------------------------
-// K3 on the "wide pack" of a 3-D table: layout [cell][column][corner 0..7] (corner bit2/bit1/bit0 = +1
-// on axis 0/1/2), i.e. the 8 corner values one column needs are one aligned 64-B piece.  A selected
-// column costs one such piece instead of 8 scattered rows, for any column subset; the price is 8x the
-// table in HBM (5.8 GB for the MIST track table - this part has 288 GB).  Built on the first large batch.
-//
-// One lane owns one sample for the bracket search and publishes (cell, t0, t1, t2) in a wave-private
-// LDS slot.  The wave's 64 x k (sample, column) units are then served by quads, 16 units per wave
-// instruction in row-major order of the output: each lane of a quad loads 16 B (two corners that
-// differ on axis 2), weights them, two DPP quad-permute adds finish the 8-corner sum, and the 16
-// results of a pass leave as one contiguous 128-B store.
-// -------------------------------------------------------------------------------------------
-struct WideArgs {
-    AxisD ax[3];
-    int64_t stride[3];
-    const double* wide;      // [ncells][ncol][8]
-    int ncol;
-    const double* x[3];
-    int64_t n;
-    int k;
-    uint64_t kinv;           // floor(2^32 / k) + 1: u / k == (u * kinv) >> 32 for u < 2^16 (k = 1: 2^32 + 1)
-    int lds_axes;            // doubles of staged axes
-    int32_t icols[ISO_MAX_COLS];
-    double* out;
-};
-
-struct PackWideArgs {
-    const double* grid;      // [n0][n1][n2][ncol]
-    double* out;
-    int64_t n0, n1, n2;
-    int ncol;
-};
-
-__global__ __launch_bounds__(BLOCK) void k_pack_wide(const PackWideArgs P)
-{
-    const int64_t total = P.n0 * P.n1 * P.n2 * P.ncol * 8;
-    for (int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x; e < total; e += (int64_t)gridDim.x * BLOCK) {
-        const int j = (int)(e & 7);
-        const int64_t r = e >> 3;
-        const int col = (int)(r % P.ncol);
-        const int64_t cell = r / P.ncol;
-        const int64_t i2 = cell % P.n2, i1 = (cell / P.n2) % P.n1, i0 = cell / (P.n2 * P.n1);
-        // the last cell of an axis is never a bracket's lower corner; its "+1" entries repeat the edge
-        const int64_t a0 = min(i0 + ((j >> 2) & 1), P.n0 - 1), a1 = min(i1 + ((j >> 1) & 1), P.n1 - 1),
-                      a2 = min(i2 + (j & 1), P.n2 - 1);
-        P.out[e] = P.grid[((a0 * P.n1 + a1) * P.n2 + a2) * P.ncol + col];
-    }
-}
-
-__device__ __forceinline__ double wide_dpp(double x, int which)
-{
-    int lo = __double2loint(x), hi = __double2hiint(x);
-    if (which == 0) {
-        lo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, false);    // quad_perm [1,0,3,2]
-        hi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, false);
-    } else {
-        lo = __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xF, 0xF, false);    // quad_perm [2,3,0,1]
-        hi = __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xF, 0xF, false);
-    }
-    return __hiloint2double(hi, lo);
-}
-
-constexpr int WIDE_SLOT = 5;      // doubles per request slot (4 used; odd stride: conflict-free)
-constexpr int WIDE_UNROLL = 8;    // passes whose loads are in flight together
-
-__global__ __launch_bounds__(BLOCK) void k_interp3_wide(const WideArgs A)
-{
-    extern __shared__ double lds[];
-    stage_axes<3>(A.ax, lds);
-    int32_t* lcols = reinterpret_cast<int32_t*>(lds + A.lds_axes);
-    for (int j = threadIdx.x; j < A.k; j += BLOCK) lcols[j] = A.icols[j];
-    __syncthreads();
-    double* slots = lds + A.lds_axes + (ISO_MAX_COLS / 2) + (threadIdx.x >> 6) * 64 * WIDE_SLOT;
-    const int lane = threadIdx.x & 63;
-    const int64_t first = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) & ~(int64_t)63;   // the wave's first sample
-    const int64_t i = first + lane;
-    {
-        bool bad = i >= A.n;
-        double x[3] = {0.0, 0.0, 0.0};
-        if (!bad) {
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                x[d] = A.x[d][i];
-                bad |= (x[d] != x[d]);
-            }
-        }
-        if (!bad) {
-#pragma unroll
-            for (int d = 0; d < 3; ++d) bad |= out_of_axis(A.ax[d], lds, x[d]);
-        }
-        double t[3] = {0.0, 0.0, 0.0};
-        int64_t cell = -1;
-        if (!bad) {
-            cell = 0;
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                int idx;
-                bracket(A.ax[d], lds, x[d], idx, t[d]);
-                cell += (int64_t)idx * A.stride[d];
-            }
-        }
-        double* mine = slots + lane * WIDE_SLOT;
-        mine[0] = __longlong_as_double(cell);
-        mine[1] = t[0];
-        mine[2] = t[1];
-        mine[3] = t[2];
-    }
-    __builtin_amdgcn_wave_barrier();
-    const int j = lane & 3, grp = lane >> 2;
-    const int k = A.k;
-    const int here = (int)min((int64_t)64, A.n - first);       // samples of this wave
-    const int units = here * k;
-    double* __restrict__ out = A.out + first * k;
-    for (int u0 = 0; u0 < units; u0 += 16 * WIDE_UNROLL) {
-        double2 v[WIDE_UNROLL];
-        double wx[WIDE_UNROLL], wy[WIDE_UNROLL];
-        bool bad[WIDE_UNROLL];
-#pragma unroll
-        for (int r = 0; r < WIDE_UNROLL; ++r) {
-            const int u = min(u0 + 16 * r + grp, units - 1);
-            const int s = (int)(((uint64_t)(uint32_t)u * A.kinv) >> 32);      // u / k
-            const int c = u - s * k;
-            const double* rq = slots + s * WIDE_SLOT;
-            const long long cell = __double_as_longlong(rq[0]);
-            const double t0 = rq[1], t1 = rq[2], t2 = rq[3];
-            bad[r] = cell < 0;
-            const int64_t cc = bad[r] ? 0 : cell;
-            v[r] = *reinterpret_cast<const double2*>(A.wide + ((cc * A.ncol + lcols[c]) << 3) + 2 * j);
-            const double g = ((j & 2) ? t0 : (1 - t0)) * ((j & 1) ? t1 : (1 - t1));
-            wx[r] = g * (1 - t2);
-            wy[r] = g * t2;
-        }
-#pragma unroll
-        for (int r = 0; r < WIDE_UNROLL; ++r) {
-            double part = v[r].x * wx[r] + v[r].y * wy[r];
-            part += wide_dpp(part, 0);
-            part += wide_dpp(part, 1);
-            const int u = u0 + 16 * r + grp;
-            if (j == 0 && u < units) out[u] = bad[r] ? d_nan() : part;
-        }
-    }
-}
-
-// -------------------------------------------------------------------------------------------
-// shared device pieces of K4 / K1+K2
-// -------------------------------------------------------------------------------------------
-
-// 3-D bracket of one star on the hot table.  Returns false (values undefined) if NaN / oob.
-struct Cell3 {
-    int64_t base;     // cell index of the (i0,i1,i2) corner
-    double t0, t1, t2;
-};
-
-__device__ __forceinline__ bool locate3(const Grid3V& G, const double* lds, double x0, double x1, double x2,
-                                        Cell3& c)
-{
-    if (x0 != x0 || x1 != x1 || x2 != x2) return false;
-    if (out_of_axis(G.ax[0], lds, x0) || out_of_axis(G.ax[1], lds, x1) || out_of_axis(G.ax[2], lds, x2))
-        return false;
-    int i0, i1, i2;
-    bracket(G.ax[0], lds, x0, i0, c.t0);
-    bracket(G.ax[1], lds, x1, i1, c.t1);
-    bracket(G.ax[2], lds, x2, i2, c.t2);
-    c.base = (int64_t)i0 * G.s0 + (int64_t)i1 * G.s1 + i2;
-    return true;
-}
-
-// Gather the first NC hot columns of the 8 corners (corner order and weight products as the
-// reference: bit (2-k) of j offsets axis k; weight = ((1 * w0) * w1) * w2).
-template <int NC>
-__device__ __forceinline__ void gather3(const Grid3V& G, const Cell3& c, double* __restrict__ v)
-{
-#pragma unroll
-    for (int q = 0; q < NC; ++q) v[q] = 0.0;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int b0 = (j >> 2) & 1, b1 = (j >> 1) & 1, b2 = j & 1;
-        double w = 1.0;
-        w *= b0 ? c.t0 : (1 - c.t0);
-        w *= b1 ? c.t1 : (1 - c.t1);
-        w *= b2 ? c.t2 : (1 - c.t2);
-        const int64_t cell = c.base + (b0 ? G.s0 : 0) + (b1 ? G.s1 : 0) + b2;
-        const double2* __restrict__ p = reinterpret_cast<const double2*>(G.hot + cell * HOT_COLS);
-#pragma unroll
-        for (int q = 0; q < NC; q += 2) {
-            const double2 u = p[q >> 1];
-            v[q] += u.x * w;
-            if (q + 1 < NC) v[q + 1] += u.y * w;
-        }
-    }
-}
-
-struct Cell4 {
-    int64_t base;
-    double t0, t1, t2, t3;
-};
-
-__device__ __forceinline__ bool locate4(const Grid4V& G, const double* lds, double x0, double x1, double x2,
-                                        double x3, Cell4& c)
-{
-    if (x0 != x0 || x1 != x1 || x2 != x2 || x3 != x3) return false;
-    if (out_of_axis(G.ax[0], lds, x0) || out_of_axis(G.ax[1], lds, x1) || out_of_axis(G.ax[2], lds, x2) ||
-        out_of_axis(G.ax[3], lds, x3))
-        return false;
-    int i0, i1, i2, i3;
-    bracket(G.ax[0], lds, x0, i0, c.t0);
-    bracket(G.ax[1], lds, x1, i1, c.t1);
-    bracket(G.ax[2], lds, x2, i2, c.t2);
-    bracket(G.ax[3], lds, x3, i3, c.t3);
-    c.base = (int64_t)i0 * G.s0 + (int64_t)i1 * G.s1 + (int64_t)i2 * G.s2 + i3;
-    return true;
-}
-
-__device__ __forceinline__ double weight4(const Cell4& c, int j)
-{
-    double w = 1.0;
-    w *= ((j >> 3) & 1) ? c.t0 : (1 - c.t0);
-    w *= ((j >> 2) & 1) ? c.t1 : (1 - c.t1);
-    w *= ((j >> 1) & 1) ? c.t2 : (1 - c.t2);
-    w *= (j & 1) ? c.t3 : (1 - c.t3);
-    return w;
-}
-
-__device__ __forceinline__ int64_t corner4(const Grid4V& G, const Cell4& c, int j)
-{
-    return c.base + (((j >> 3) & 1) ? G.s0 : 0) + (((j >> 2) & 1) ? G.s1 : 0) + (((j >> 1) & 1) ? G.s2 : 0) +
-           (j & 1);
-}
-
-// one column of the BC table at a located cell
-__device__ __forceinline__ double gather4_col(const Grid4V& G, const Cell4& c, int col)
-{
-    double v = 0.0;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) v += G.tab[corner4(G, c, j) * G.ncol + col] * weight4(c, j);
-    return v;
-}
-
-// NB contiguous columns (packed BC table, ncol == NB) at a located cell
-template <int NB>
-__device__ __forceinline__ void gather4_packed(const Grid4V& G, const Cell4& c, double* __restrict__ v)
-{
-#pragma unroll
-    for (int b = 0; b < NB; ++b) v[b] = 0.0;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const double w = weight4(c, j);
-        const double* __restrict__ p = G.tab + corner4(G, c, j) * NB;
-#pragma unroll
-        for (int b = 0; b < NB; ++b) v[b] += p[b] * w;
-    }
-}
-
-// parameter permutation: (mass, eep, feh) -> table axes (feh, mass, eep);  (eep, age, feh) -> (age, feh, eep)
-template <int KIND>
-__device__ __forceinline__ void to_axes(double p0, double p1, double p2, double& x0, double& x1, double& x2)
-{
-    if (KIND == ISO_KIND_TRACK) {
-        x0 = p2; x1 = p0; x2 = p1;
-    } else {
-        x0 = p1; x1 = p2; x2 = p0;
-    }
-}
-
-// -------------------------------------------------------------------------------------------
-// K4: interp_mag
-// -------------------------------------------------------------------------------------------
-struct MagArgs {
-    Grid3V g3;
-    Grid4V g4;
-    int kind;
-    const double* pars;
-    int64_t stride_n, stride_p, n;
-    int nb;
-    int32_t bc_cols[ISO_MAX_BANDS];
-    double *Teff, *logg, *feh, *mags;
-};
-
-// Column-parallel like k_interp: G = max(1, ceil(nb/2)) adjacent lanes share one sample; every lane
-// repeats the (cheap) model-table gather of the four stellar columns — the G lanes read identical
-// addresses, i.e. one request — and the BC brackets, then lane `sub` owns the bands 2*sub, 2*sub+1:
-// per corner the G lanes read neighbouring columns of one BC row and finally write nb contiguous
-// magnitudes.
-template <int KIND>
-__global__ __launch_bounds__(BLOCK) void k_interp_mag(const MagArgs A)
-{
-    extern __shared__ double lds[];
-    stage_axes<3>(A.g3.ax, lds);
-    stage_axes<4>(A.g4.ax, lds);
-    __syncthreads();
-    const int G = (A.nb + 1) >> 1 > 0 ? (A.nb + 1) >> 1 : 1;
-    const int S = 64 / G;
-    const int lane = threadIdx.x & 63;
-    const int slot = lane / G, sub = lane - slot * G;
-    if (slot >= S) return;
-    const bool has0 = (2 * sub) < A.nb, has1 = (2 * sub + 1) < A.nb;
-    const int c0 = has0 ? A.bc_cols[2 * sub] : 0, c1 = has1 ? A.bc_cols[2 * sub + 1] : c0;
-    const int64_t wave0 = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
-    const int64_t nwaves = ((int64_t)gridDim.x * BLOCK) >> 6;
-    for (int64_t i = wave0 * S + slot; i < A.n; i += nwaves * S) {
-        const double* __restrict__ p = A.pars + i * A.stride_n;
-        const double p0 = p[0], p1 = p[A.stride_p], p2 = p[2 * A.stride_p];
-        const double dist = p[3 * A.stride_p], AV = p[4 * A.stride_p];
-        double x0, x1, x2;
-        to_axes<KIND>(p0, p1, p2, x0, x1, x2);
-        double star[4] = {d_nan(), d_nan(), d_nan(), d_nan()};
-        Cell3 c3;
-        if (locate3(A.g3, lds, x0, x1, x2, c3)) gather3<4>(A.g3, c3, star);
-        if (sub == 0) {
-            if (A.Teff) A.Teff[i] = star[0];
-            if (A.logg) A.logg[i] = star[1];
-            if (A.feh) A.feh[i] = star[2];
-        }
-        if (A.mags && has0) {
-            Cell4 c4;
-            const bool ok = locate4(A.g4, lds, star[0], star[1], star[2], AV, c4);
-            const double dm = 5 * log10(dist / 10.0);
-            double b0 = d_nan(), b1 = d_nan();
-            if (ok) {
-                b0 = b1 = 0.0;
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    const double* __restrict__ row = A.g4.tab + corner4(A.g4, c4, j) * A.g4.ncol;
-                    const double ww = weight4(c4, j);
-                    b0 += row[c0] * ww;
-                    b1 += row[c1] * ww;
-                }
-            }
-            double* o = A.mags + i * A.nb + 2 * sub;
-            o[0] = star[3] + dm - b0;
-            if (has1) o[1] = star[3] + dm - b1;
-        }
-    }
-}
-
-// -------------------------------------------------------------------------------------------
-// priors
-// -------------------------------------------------------------------------------------------
-#define LOG_INV_ROOT_2PI (-0.91893853320467267)   // log(1/sqrt(2 pi))
-#define INV_ROOT_2PI 0.3989422804014327
-#define LN10 2.302585092994046
-
-__device__ __forceinline__ double lognormal_pdf(const DevPrior& P, double x, double mu, double sigma,
-                                                double scale)
-{
-    const double y = x / scale;
-    const double ly = log(y) / sigma;
-    return INV_ROOT_2PI / (sigma * y) * exp(-0.5 * (ly * ly)) / scale;
-}
-
-__device__ __forceinline__ double lognormal_lnpdf(double x, double mu, double sigma, double scale,
-                                                  double log_sigma)
-{
-    const double y = x / scale;
-    const double l = log(y);
-    const double ly = l / sigma;
-    return LOG_INV_ROOT_2PI - (log_sigma + l) - 0.5 * (ly * ly) - mu;
-}
-
-__device__ __forceinline__ double feh_shape(const DevPrior& P, double feh)
-{
-    double disk;
-    if (P.c != 0.0) {
-        const double u = feh - 0.016, v = feh + 0.15;
-        disk = 1.0 / 2.5066282746310007 *
-               (0.8 / 0.15 * exp(-0.5 * (u * u) / (0.15 * 0.15)) + 0.2 / 0.22 * exp(-0.5 * (v * v) / (0.22 * 0.22)));
-    } else {
-        const double u = feh + 0.3;
-        disk = INV_ROOT_2PI / 0.3 * exp(-0.5 * (u * u) / (0.3 * 0.3));
-    }
-    const double h = feh + 1.5;
-    const double halo = P.k0 * exp(-0.5 * (h * h) / (0.4 * 0.4));   // k0 = 1/sqrt(2 pi 0.4^2)
-    return P.a * halo + (1 - P.a) * disk;
-}
-
-// _pdf(x) of a family (no bounds handling)
-__device__ double prior_raw(const DevPrior& P, double x)
-{
-    switch (P.kind) {
-    case ISO_PRIOR_FLAT: return P.k0;                                  // 1/(hi-lo)
-    case ISO_PRIOR_FLATLOG: return LN10 * exp10(x) / P.k0;             // k0 = 10^hi - 10^lo
-    case ISO_PRIOR_POWERLAW: return P.k0 * pow(x, P.a);                // k0 = C
-    case ISO_PRIOR_GAUSS: {
-        const double z = (x - P.a) / P.b;
-        return exp(-(z * z) / 2.0) * INV_ROOT_2PI / P.b / P.k0;        // k0 = exp(lognorm)
-    }
-    case ISO_PRIOR_LOGNORMAL: return lognormal_pdf(P, x, P.a, P.b, P.k0);   // k0 = exp(mu)
-    case ISO_PRIOR_CHABRIER:
-        if (x < P.d) {
-            const double c = (x < 0) ? 0.0 : lognormal_pdf(P, x, P.a, P.b, P.k0);
-            return c / P.e;
-        } else {
-            const double c = (x < P.g || x > P.h) ? 0.0 : P.k2 * pow(x, P.c);   // k2 = C of the power law
-            return c / P.f;
-        }
-    case ISO_PRIOR_FEH: return feh_shape(P, x);
-    }
-    return d_nan();
-}
-
-// prior(x): the reference's __call__ form (pdf with its bounds tests)
-__device__ double prior_call(const DevPrior& P, double x)
-{
-    if (P.kind == ISO_PRIOR_LOGNORMAL) {
-        if (x < 0) return 0.0;
-        return lognormal_pdf(P, x, P.a, P.b, P.k0);
-    }
-    if (x < P.lo || x > P.hi) return 0.0;
-    const double r = prior_raw(P, x);
-    return (P.kind == ISO_PRIOR_FEH) ? r / P.b : r;
-}
-
-__device__ double prior_lnpdf(const DevPrior& P, double x)
-{
-    switch (P.kind) {
-    case ISO_PRIOR_FLAT:
-    case ISO_PRIOR_FLATLOG: {
-        if (x < P.lo || x > P.hi) return -d_inf();
-        const double pdf = prior_raw(P, x);
-        return pdf != 0 ? log(pdf) : -d_inf();
-    }
-    case ISO_PRIOR_POWERLAW:
-        if (P.bounded && (x < P.lo || x > P.hi)) return -d_inf();
-        return P.k1 + P.a * log(x);                                    // k1 = log(C)
-    case ISO_PRIOR_GAUSS: {
-        if (P.bounded && (x < P.lo || x > P.hi)) return -d_inf();
-        const double z = (x - P.a) / P.b;
-        return (-(z * z) / 2.0 + LOG_INV_ROOT_2PI) - P.k1 - P.c;       // k1 = log(sigma)
-    }
-    case ISO_PRIOR_LOGNORMAL: return lognormal_lnpdf(x, P.a, P.b, P.k0, P.k1);   // k1 = log(sigma)
-    case ISO_PRIOR_CHABRIER:
-        if (x < P.d) return lognormal_lnpdf(x, P.a, P.b, P.k0, P.k1) - P.k3;     // k3 = log(e)
-        if (x < P.g || x > P.h) return -d_inf();
-        return (P.k5 + P.c * log(x)) - P.k4;                     // k5 = log(C), k4 = log(f)
-    case ISO_PRIOR_FEH: {
-        const double pdf = prior_call(P, x);
-        return pdf != 0 ? log(pdf) : -d_inf();
-    }
-    }
-    return d_nan();
-}
-
-__device__ __forceinline__ double gauss_term(double val, double g0, double unc2, double model)
-{
-    const double r = val - model;
-    return g0 - 0.5 * r * r / unc2;
-}
-
-// -------------------------------------------------------------------------------------------
-// K1+K2 fused: lnpost
-// -------------------------------------------------------------------------------------------
-struct PostArgs {
-    Grid3V g3;
-    Grid4V g4;           // packed to the model's bands (ncol == n_bands)
-    const DevModel* m;
-    const double* pars;
-    int64_t stride_n, stride_p, n;
-    double *lnpost, *lnprior, *lnlike;
-};
-
-// NB > 0: compile-time band count (register-resident accumulators); NB == 0: runtime loop.
-template <int KIND, int NS, int NB, bool PARTS>
-__global__ __launch_bounds__(BLOCK) void k_lnpost(const PostArgs A)
-{
-    extern __shared__ double lds[];
-    stage_axes<3>(A.g3.ax, lds);
-    stage_axes<4>(A.g4.ax, lds);
-    __syncthreads();
-    const DevModel& M = *A.m;
-    constexpr int NP = NS + 4;
-    const int64_t stride_grid = (int64_t)gridDim.x * BLOCK;
-    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < A.n; i += stride_grid) {
-        double p[NP];
-        {
-            const double* __restrict__ src = A.pars + i * A.stride_n;
-#pragma unroll
-            for (int j = 0; j < NP; ++j) p[j] = src[j * A.stride_p];
-        }
-        const double q1 = p[NS], feh_par = p[NS + 1], dist = p[NS + 2], AV = p[NS + 3];
-        // q1: track -> eep (p[1]); iso -> age.   For the track case NS == 1: p = (mass, eep, feh, d, AV)
-
-        // ---- locate + gather every component on the hot model table ----
-        Cell3 c3[NS];
-        bool ok3[NS];
-        double star[NS][6];
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            double x0, x1, x2;
-            if (KIND == ISO_KIND_TRACK) to_axes<KIND>(p[0], p[1], p[2], x0, x1, x2);
-            else to_axes<KIND>(p[s], q1, feh_par, x0, x1, x2);
-            ok3[s] = locate3(A.g3, lds, x0, x1, x2, c3[s]);
-        }
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            if (ok3[s]) {
-                gather3<6>(A.g3, c3[s], star[s]);
-            } else {
-#pragma unroll
-                for (int q = 0; q < 6; ++q) star[s][q] = d_nan();
-            }
-        }
-
-        // ---- lnprior (reference: starmodel.py:1616-1635) ----
-        double lnp = 0.0;
-        bool rejected = false;
-        if (NS == 2) rejected = p[1] > p[0];
-        if (NS == 3) rejected = !(p[0] > p[1]) && (p[1] > p[2]);
-        if (KIND == ISO_KIND_TRACK) lnp += prior_lnpdf(M.prior_mass, p[0]);
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const double eep = (KIND == ISO_KIND_TRACK) ? p[1] : p[s];
-            double term;
-            if (eep < M.eep_lo || eep > M.eep_hi) {
-                term = -d_inf();
-            } else {
-                const DevPrior& orig = (KIND == ISO_KIND_TRACK) ? M.prior_age : M.prior_mass;
-                const double pdf = prior_call(orig, star[s][4]) * star[s][5];
-                term = (pdf != 0) ? log(pdf) : -d_inf();
-            }
-            lnp += term;
-        }
-        if (KIND == ISO_KIND_ISO) lnp += prior_lnpdf(M.prior_age, q1);
-        lnp += prior_lnpdf(M.prior_feh, feh_par);
-        lnp += prior_lnpdf(M.prior_distance, dist);
-        lnp += prior_lnpdf(M.prior_AV, AV);
-        if (rejected) lnp = -d_inf();
-        const bool prior_ok = isfinite(lnp);
-
-        // ---- lnlike (reference: likelihood.py:16-147, starmodel.py:1599-1612) ----
-        double lnl = d_nan();
-        if (PARTS || prior_ok) {
-            lnl = 0.0;
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                const double val = M.spec_val[q];
-                if (val == val) lnl += gauss_term(val, M.spec_g0[q], M.spec_unc2[q], star[0][q]);
-            }
-            const double dm = 5 * log10(dist / 10.0);
-            Cell4 c4[NS];
-            bool ok4[NS];
-#pragma unroll
-            for (int s = 0; s < NS; ++s) ok4[s] = locate4(A.g4, lds, star[s][0], star[s][1], star[s][2], AV, c4[s]);
-            if (NB > 0) {
-                double tot[NB > 0 ? NB : 1];
-#pragma unroll
-                for (int s = 0; s < NS; ++s) {
-                    double bc[NB > 0 ? NB : 1];
-                    if (ok4[s]) {
-                        gather4_packed<(NB > 0 ? NB : 1)>(A.g4, c4[s], bc);
-                    } else {
-#pragma unroll
-                        for (int b = 0; b < NB; ++b) bc[b] = d_nan();
-                    }
-#pragma unroll
-                    for (int b = 0; b < NB; ++b) {
-                        const double mag = star[s][3] + dm - bc[b];
-                        if (NS == 1) tot[b] = mag;
-                        else tot[b] = (s == 0 ? 0.0 : tot[b]) + exp10(-0.4 * mag);
-                    }
-                }
-#pragma unroll
-                for (int b = 0; b < NB; ++b) {
-                    const double mag = (NS == 1) ? tot[b] : -2.5 * log10(tot[b]);
-                    lnl += gauss_term(M.mag_val[b], M.mag_g0[b], M.mag_unc2[b], mag);
-                }
-            } else {
-                for (int b = 0; b < M.n_bands; ++b) {
-                    double tot = 0.0;
-#pragma unroll
-                    for (int s = 0; s < NS; ++s) {
-                        const double bc = ok4[s] ? gather4_col(A.g4, c4[s], b) : d_nan();
-                        const double mag = star[s][3] + dm - bc;
-                        if (NS == 1) tot = mag;
-                        else tot += exp10(-0.4 * mag);
-                    }
-                    const double mag = (NS == 1) ? tot : -2.5 * log10(tot);
-                    lnl += gauss_term(M.mag_val[b], M.mag_g0[b], M.mag_unc2[b], mag);
-                }
-            }
-            if (M.has_parallax) lnl += gauss_term(M.plx_val, M.plx_g0, M.plx_unc2, 1000.0 / dist);
-            if (M.has_numax) {
-                double a2[8];
-                if (ok3[0]) {
-                    gather3<8>(A.g3, c3[0], a2);
-                } else {
-                    a2[6] = a2[7] = d_nan();
-                }
-                lnl += gauss_term(M.numax_val, M.numax_g0, M.numax_unc2, a2[6]);
-                if (M.has_dnu) lnl += gauss_term(M.dnu_val, M.dnu_g0, M.dnu_unc2, a2[7]);
-            }
-        }
-        if (A.lnpost) A.lnpost[i] = prior_ok ? lnp + lnl : -d_inf();
-        if (PARTS) {
-            if (A.lnprior) A.lnprior[i] = lnp;
-            if (A.lnlike) A.lnlike[i] = lnl;
-        }
-    }
-}
-
-// -------------------------------------------------------------------------------------------
-// "next" row f2: (age, feh, mass) -> EEP on the ragged per-track age arrays
-// (reference semantics: isochrones/interp.py:488-558 interp_eep / interp_eeps)
-// -------------------------------------------------------------------------------------------
-struct EepArgs {
-    AxisD ax[2];              // feh, mass
-    const double* ages;       // [n0*n1][n_eep], NaN past `lengths`
-    const int64_t* lengths;   // [n0*n1]
-    int n1;
-    int64_t n_eep;
-    double eep0;              // EEP of array index 0 (1 for MIST)
-    const double *x, *x0, *x1;
-    int64_t n;
-    double* out;
-};
-
-// number of elements of arr[0..N) that are < x  (== the reference's searchsorted L)
-__device__ __forceinline__ int64_t count_less(const double* __restrict__ arr, double x, int64_t N)
-{
-    int64_t base = 0, len = N;
-    if (N <= 0) return 0;
-    while (len > 1) {                       // base = largest index with arr[base] < x, or 0
-        const int64_t half = len >> 1;
-        base = (arr[base + half] < x) ? base + half : base;
-        len -= half;
-    }
-    return (arr[base] < x) ? base + 1 : base;
-}
-
-__global__ __launch_bounds__(BLOCK) void k_interp_eep(const EepArgs A)
-{
-    extern __shared__ double lds[];
-    stage_axes<2>(A.ax, lds);
-    __syncthreads();
-    const int64_t stride_grid = (int64_t)gridDim.x * BLOCK;
-    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < A.n; i += stride_grid) {
-        const double x = A.x[i], x0 = A.x0[i], x1 = A.x1[i];
-        double r = d_nan();
-        if (!(x != x || x0 != x0 || x1 != x1) && !out_of_axis(A.ax[0], lds, x0) && !out_of_axis(A.ax[1], lds, x1)) {
-            int i0, i1;
-            double d0, d1;
-            bracket(A.ax[0], lds, x0, i0, d0);
-            bracket(A.ax[1], lds, x1, i1, d1);
-            const int64_t ind[4] = {(int64_t)i0 * A.n1 + i1, (int64_t)i0 * A.n1 + i1 + 1,
-                                    (int64_t)(i0 + 1) * A.n1 + i1, (int64_t)(i0 + 1) * A.n1 + i1 + 1};
-            int64_t ie[4], len[4];
-            bool bad = false;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                len[k] = A.lengths[ind[k]];
-                ie[k] = count_less(A.ages + ind[k] * A.n_eep, x, len[k]);
-                bad |= ie[k] > A.n_eep - 1;
-            }
-            if (!bad) {
-                double e[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) e[k] = A.eep0 + (double)ie[k];
-                if (ie[0] >= len[0]) e[0] = e[1];      // sequential substitution, as the reference
-                if (ie[1] >= len[1]) e[1] = e[0];
-                if (ie[2] >= len[2]) e[2] = e[3];
-                if (ie[3] >= len[3]) e[3] = e[2];
-                const double e_0 = (1 - d1) * e[0] + d1 * e[1];
-                const double e_1 = (1 - d1) * e[2] + d1 * e[3];
-                r = (1 - d0) * e_0 + d0 * e_1;
-            }
-        }
-        A.out[i] = r;
-    }
-}
-
-// -------------------------------------------------------------------------------------------
-// "next" row f4: generic StarModel over a flattened ObservationTree
-// (reference semantics: isochrones/starmodel.py:538-613, observation.py:464-491, 1181-1234)
-// -------------------------------------------------------------------------------------------
-struct TreeArgs {
-    Grid3V g3;
-    Grid4V g4;            // BC packed to the tree's bands (ncol == n_bands)
-    const DevTree* T;
-    const double* pars;
-    int64_t stride_n, stride_p, n;
-    double *lnpost, *lnprior, *lnlike;
-};
-
-__device__ __forceinline__ double tree_addmags(const double (*flux)[ISO_TREE_MAX_BANDS], uint32_t mask, int band,
-                                               int n_leaves)
-{
-    double tot = 0.0;
-    for (int l = 0; l < n_leaves; ++l)
-        if (mask & (1u << l)) tot += flux[l][band];
-    return -2.5 * log10(tot);
-}
-
-__global__ __launch_bounds__(BLOCK) void k_lnpost_tree(const TreeArgs A)
-{
-    extern __shared__ double lds[];
-    stage_axes<3>(A.g3.ax, lds);
-    stage_axes<4>(A.g4.ax, lds);
-    __syncthreads();
-    const DevTree& T = *A.T;
-    const int64_t stride_grid = (int64_t)gridDim.x * BLOCK;
-    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < A.n; i += stride_grid) {
-        double p[ISO_TREE_MAX_PARAMS];
-        {
-            const double* __restrict__ src = A.pars + i * A.stride_n;
-            for (int j = 0; j < T.n_params; ++j) p[j] = src[j * A.stride_p];
-        }
-        // ---- every model star: model-table gather, then magnitudes as fluxes ----
-        double star[ISO_TREE_MAX_LEAVES][6];
-        double flux[ISO_TREE_MAX_LEAVES][ISO_TREE_MAX_BANDS];
-        for (int l = 0; l < T.n_leaves; ++l) {
-            const int s = T.leaf_system[l];
-            const int base = T.sys_base[s], N = T.n_stars[s];
-            const double eep = p[base + T.leaf_slot[l]], age = p[base + N], feh = p[base + N + 1];
-            const double dist = p[base + N + 2], AV = p[base + N + 3];
-            Cell3 c3;
-            if (locate3(A.g3, lds, age, feh, eep, c3)) {
-                gather3<6>(A.g3, c3, star[l]);
-            } else {
-                for (int q = 0; q < 6; ++q) star[l][q] = d_nan();
-            }
-            Cell4 c4;
-            const bool ok = locate4(A.g4, lds, star[l][0], star[l][1], star[l][2], AV, c4);
-            const double dm = 5 * log10(dist / 10.0);
-            for (int b = 0; b < T.n_bands; ++b) {
-                const double bc = ok ? gather4_col(A.g4, c4, b) : d_nan();
-                flux[l][b] = exp10(-0.4 * (star[l][3] + dm - bc));
-            }
-        }
-        // ---- lnprior (starmodel.py:557-613) ----
-        double lnp = 0.0;
-        bool dead = false;
-        for (int s = 0; s < T.n_systems && !dead; ++s) {
-            const int base = T.sys_base[s], N = T.n_stars[s];
-            const DevPrior* pri[4] = {&T.prior_age, &T.prior_feh, &T.prior_distance, &T.prior_AV};
-            for (int j = 0; j < 4 && !dead; ++j) {
-                const double val = p[base + N + j];
-                if (val < T.bound_lo[j] || val > T.bound_hi[j]) { dead = true; break; }
-                lnp += prior_lnpdf(*pri[j], val);
-                if (!isfinite(lnp)) dead = true;
-            }
-            for (int j = 1; j < N && !dead; ++j)
-                if (!(p[base + j] <= p[base + j - 1])) dead = true;
-            if (dead) break;
-            for (int l = 0; l < T.n_leaves; ++l) {
-                if (T.leaf_system[l] != s) continue;
-                const double eep = p[base + T.leaf_slot[l]];
-                double term;
-                if (eep < T.eep_lo || eep > T.eep_hi) {
-                    term = -d_inf();
-                } else {
-                    const double pdf = prior_call(T.prior_mass, star[l][4]) * star[l][5];
-                    term = (pdf != 0) ? log(pdf) : -d_inf();
-                }
-                lnp += term;
-            }
-        }
-        if (dead) lnp = -d_inf();
-        const bool prior_ok = isfinite(lnp);
-        // ---- lnlike (observation.py:1181-1234): -inf as soon as the running sum is not finite ----
-        double lnl = d_nan();
-        if (A.lnlike || prior_ok) {
-            lnl = 0.0;
-            bool bad = false;
-            for (int t = 0; t < T.n_terms && !bad; ++t) {
-                const iso_tree_term& tt = T.terms[t];
-                double mag = tt.mag;
-                double mod = tree_addmags(flux, tt.mask, tt.band, T.n_leaves);
-                if (tt.relative) {
-                    mod -= tree_addmags(flux, tt.ref_mask, tt.band, T.n_leaves);
-                    mag -= tt.ref_mag;
-                }
-                const double r = mag - mod;
-                lnl += -0.5 * (r * r) / (tt.unc * tt.unc) + T.term_g0[t];
-                if (!isfinite(lnl)) bad = true;
-            }
-            for (int k = 0; k < T.n_spec && !bad; ++k) {
-                const iso_tree_prop& sp = T.spec[k];
-                const double r = sp.a - star[sp.leaf][sp.prop];
-                lnl += -0.5 * (r * r) / (sp.b * sp.b) + T.spec_g0[k];
-                if (!isfinite(lnl)) bad = true;
-            }
-            for (int k = 0; k < T.n_limits && !bad; ++k) {
-                const iso_tree_prop& lm = T.limits[k];
-                const double mod = star[lm.leaf][lm.prop];
-                if (mod < lm.a || mod > lm.b || !isfinite(mod)) bad = true;
-            }
-            if (!bad) {
-                for (int s = 0; s < T.n_systems; ++s)
-                    if (T.has_plx[s]) {
-                        const double r = T.plx_val[s] - 1.0 / p[T.sys_base[s] + T.n_stars[s] + 2] * 1000.0;
-                        lnl += -0.5 * (r * r) / (T.plx_unc[s] * T.plx_unc[s]) + T.plx_g0[s];
-                    }
-                for (int s = 0; s < T.n_systems; ++s)
-                    if (T.has_av[s]) {
-                        const double r = T.av_val[s] - p[T.sys_base[s] + T.n_stars[s] + 3];
-                        lnl += -0.5 * (r * r) / (T.av_unc[s] * T.av_unc[s]) + T.av_g0[s];
-                    }
-                if (!isfinite(lnl)) bad = true;
-            }
-            if (bad) lnl = -d_inf();
-        }
-        if (A.lnpost) A.lnpost[i] = prior_ok ? lnp + lnl : -d_inf();
-        if (A.lnprior) A.lnprior[i] = lnp;
-        if (A.lnlike) A.lnlike[i] = lnl;
-    }
-}
-
-// -------------------------------------------------------------------------------------------
-// posterior summaries of a stored chain: one workgroup sorts the nsteps*W values of one
-// (ensemble, parameter) pair in LDS (bitonic network on the next power of two, padded with +inf)
-// and writes the requested quantiles (linear interpolation between order statistics)
-// -------------------------------------------------------------------------------------------
-struct QuantArgs {
-    const double* chain;     // [nsteps][n_ens*W][D]
-    int64_t nsteps, n_ens;
-    int W, D, nq, P;         // P = power of two >= nsteps*W
-    double q[8];
-    double* out;             // [n_ens][D][nq]
-};
-
-__global__ __launch_bounds__(BLOCK) void k_chain_quantiles(const QuantArgs A)
-{
-    extern __shared__ double lds[];
-    const int64_t e = blockIdx.x / A.D;
-    const int d = (int)(blockIdx.x - e * A.D);
-    const int m = (int)(A.nsteps * A.W);
-    const int64_t rows = A.n_ens * A.W;
-    for (int i = threadIdx.x; i < A.P; i += BLOCK) {
-        double v = d_inf();
-        if (i < m) {
-            const int t = i / A.W, w = i - t * A.W;
-            v = A.chain[((int64_t)t * rows + e * A.W + w) * A.D + d];
-            if (v != v) v = d_inf();                 // NaN sorts last (cannot occur in an accepted chain)
-        }
-        lds[i] = v;
-    }
-    __syncthreads();
-    for (int k = 2; k <= A.P; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < A.P; i += BLOCK) {
-                const int x = i ^ j;
-                if (x > i) {
-                    const double a = lds[i], b = lds[x];
-                    const bool asc = (i & k) == 0;
-                    if ((a > b) == asc) {
-                        lds[i] = b;
-                        lds[x] = a;
-                    }
-                }
-            }
-            __syncthreads();
-        }
-    }
-    if ((int)threadIdx.x < A.nq) {
-        double pos;
-        {
-#pragma clang fp contract(off)   // numpy's virtual index for method="linear": n q + (1 + q (1 - 1 - 1)) - 1
-            const double qq = A.q[threadIdx.x];
-            pos = ((double)m * qq + (1.0 + qq * -1.0)) - 1.0;
-        }
-        int i0 = (int)floor(pos);
-        i0 = max(0, min(i0, m - 1));
-        const int i1 = min(i0 + 1, m - 1);
-        const double f = pos - (double)i0;
-        const double a = lds[i0], b = lds[i1];
-        double r;
-        {
-#pragma clang fp contract(off)   // numpy's _lerp, unfused: a + (b-a)t, from the upper end for t >= 0.5
-            const double diff = b - a;
-            r = (f >= 0.5) ? b - diff * (1 - f) : a + diff * f;
-        }
-        A.out[(e * A.D + d) * A.nq + threadIdx.x] = r;
-    }
-}
-
-// -------------------------------------------------------------------------------------------
-// small kernels
-// -------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k_unit_cube(const DevModel* m, double* cube, int64_t stride_n,
-                                                    int64_t stride_p, int64_t n)
-{
-    const int np = m->n_stars + 4;
-    const int64_t total = n * np;
-    for (int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x; e < total; e += (int64_t)gridDim.x * BLOCK) {
-        const int64_t i = e / np;
-        const int p = (int)(e - i * np);
-        double* c = cube + i * stride_n + p * stride_p;
-        const double lo = m->bound_lo[p], hi = m->bound_hi[p];
-        {
-#pragma clang fp contract(off)   // unfused: bit-identical to the reference's (hi - lo) * u + lo
-            const double prod = (hi - lo) * *c;
-            *c = prod + lo;
-        }
-    }
-}
-
-struct PackHotArgs {
-    const double* grid;
-    int ncol;
-    int64_t ncells;
-    int32_t src[HOT_COLS];   // -1 -> NaN fill
-    double* hot;
-};
-
-__global__ __launch_bounds__(BLOCK) void k_pack_hot(const PackHotArgs A)
-{
-    const int64_t total = A.ncells * HOT_COLS;
-    for (int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x; e < total; e += (int64_t)gridDim.x * BLOCK) {
-        const int64_t cell = e / HOT_COLS;
-        const int q = (int)(e - cell * HOT_COLS);
-        const int s = A.src[q];
-        A.hot[e] = (s >= 0) ? A.grid[cell * A.ncol + s] : d_nan();
-    }
-}
-
-struct PackBcArgs {
-    const double* grid;
-    int ncol, nb;
-    int64_t ncells;
-    int32_t src[ISO_MAX_BANDS];
-    double* out;
-};
-
-__global__ __launch_bounds__(BLOCK) void k_pack_bc(const PackBcArgs A)
-{
-    const int64_t total = A.ncells * A.nb;
-    for (int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x; e < total; e += (int64_t)gridDim.x * BLOCK) {
-        const int64_t cell = e / A.nb;
-        const int b = (int)(e - cell * A.nb);
-        A.out[e] = A.grid[cell * A.ncol + A.src[b]];
-    }
-}
-
-struct PackCornersArgs {
-    const double* src;      // compact table, `ncol` doubles per cell
-    int ncol, keep, col0;   // keep columns col0 .. col0+keep-1 of every corner (BC: col0 = 0, keep = ncol = n_bands)
-    int ndim;               // 3 (model table) or 4 (BC table)
-    int64_t n[4];           // axis lengths
-    int64_t ncells;
-    double* out;            // [cell][2^ndim * keep], laid out for the 4-lanes-per-sample gather
-};
-
-// Corner-packed layout: every cell carries its own 2^D corners, ordered so that 4 cooperating lanes
-// read 64 contiguous bytes per load instruction (see iso_fast_kernel.h).
-//   ndim 3: double index e = 2*(4k + j) + comp  ->  corner c = 4*(k/P) + j, column col0 + 2*(k%P) + comp,
-//           P = keep/2 column pairs (3 for the model table, 1 for the asteroseismic pair)
-//   ndim 4: double index e = 2*((k*NB + band)*4 + j) + comp  ->  axis-0 offset k, (axis-1, axis-2)
-//           offsets = bits of j, axis-3 offset comp
-__global__ __launch_bounds__(BLOCK) void k_pack_corners(const PackCornersArgs A)
-{
-    const int per = (1 << A.ndim) * A.keep;
-    const int64_t total = A.ncells * per;
-    for (int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x; e < total; e += (int64_t)gridDim.x * BLOCK) {
-        const int64_t cell = e / per;
-        const int r = (int)(e - cell * per);
-        const int comp = r & 1, piece = r >> 1, j = piece & 3, kk = piece >> 2;
-        int off[4], col;
-        if (A.ndim == 3) {
-            const int pairs = A.keep >> 1;
-            off[0] = kk / pairs; off[1] = (j >> 1) & 1; off[2] = j & 1; off[3] = 0;
-            col = A.col0 + 2 * (kk % pairs) + comp;
-        } else {
-            off[0] = kk / A.keep; off[1] = (j >> 1) & 1; off[2] = j & 1; off[3] = comp;
-            col = kk % A.keep;
-        }
-        int64_t rem = cell, src_cell = 0, mul = 1;
-        for (int d = A.ndim - 1; d >= 0; --d) {
-            int64_t id = rem % A.n[d];
-            rem /= A.n[d];
-            id = min(id + off[d], A.n[d] - 1);      // edge cells are never addressed (i <= n-2)
-            src_cell += id * mul;
-            mul *= A.n[d];
-        }
-        A.out[e] = A.src[src_cell * A.ncol + col];
-    }
-}
+#include "kernels/dev_common.h"
+#include "kernels/k_interp.h"
+#include "kernels/dev_gather.h"
+#include "kernels/k_interp_mag.h"
+#include "kernels/dev_priors.h"
+#include "kernels/k_lnpost_generic.h"
+#include "kernels/k_interp_eep.h"
+#include "kernels/k_lnpost_tree.h"
+#include "kernels/k_chain_quantiles.h"
+#include "kernels/k_small_and_pack.h"
 
 // ======================================================================================
 // host helpers

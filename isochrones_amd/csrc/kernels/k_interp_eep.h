@@ -1,0 +1,73 @@
+// (age, feh, mass) -> EEP on ragged per-track age arrays
+// (textually included by iso_hip.hip inside its anonymous namespace: one translation unit, device code only)
+#pragma once
+
+// -------------------------------------------------------------------------------------------
+// "next" row f2: (age, feh, mass) -> EEP on the ragged per-track age arrays
+// (reference semantics: isochrones/interp.py:488-558 interp_eep / interp_eeps)
+// -------------------------------------------------------------------------------------------
+struct EepArgs {
+    AxisD ax[2];              // feh, mass
+    const double* ages;       // [n0*n1][n_eep], NaN past `lengths`
+    const int64_t* lengths;   // [n0*n1]
+    int n1;
+    int64_t n_eep;
+    double eep0;              // EEP of array index 0 (1 for MIST)
+    const double *x, *x0, *x1;
+    int64_t n;
+    double* out;
+};
+
+// number of elements of arr[0..N) that are < x  (== the reference's searchsorted L)
+__device__ __forceinline__ int64_t count_less(const double* __restrict__ arr, double x, int64_t N)
+{
+    int64_t base = 0, len = N;
+    if (N <= 0) return 0;
+    while (len > 1) {                       // base = largest index with arr[base] < x, or 0
+        const int64_t half = len >> 1;
+        base = (arr[base + half] < x) ? base + half : base;
+        len -= half;
+    }
+    return (arr[base] < x) ? base + 1 : base;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_interp_eep(const EepArgs A)
+{
+    extern __shared__ double lds[];
+    stage_axes<2>(A.ax, lds);
+    __syncthreads();
+    const int64_t stride_grid = (int64_t)gridDim.x * BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < A.n; i += stride_grid) {
+        const double x = A.x[i], x0 = A.x0[i], x1 = A.x1[i];
+        double r = d_nan();
+        if (!(x != x || x0 != x0 || x1 != x1) && !out_of_axis(A.ax[0], lds, x0) && !out_of_axis(A.ax[1], lds, x1)) {
+            int i0, i1;
+            double d0, d1;
+            bracket(A.ax[0], lds, x0, i0, d0);
+            bracket(A.ax[1], lds, x1, i1, d1);
+            const int64_t ind[4] = {(int64_t)i0 * A.n1 + i1, (int64_t)i0 * A.n1 + i1 + 1,
+                                    (int64_t)(i0 + 1) * A.n1 + i1, (int64_t)(i0 + 1) * A.n1 + i1 + 1};
+            int64_t ie[4], len[4];
+            bool bad = false;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                len[k] = A.lengths[ind[k]];
+                ie[k] = count_less(A.ages + ind[k] * A.n_eep, x, len[k]);
+                bad |= ie[k] > A.n_eep - 1;
+            }
+            if (!bad) {
+                double e[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) e[k] = A.eep0 + (double)ie[k];
+                if (ie[0] >= len[0]) e[0] = e[1];      // sequential substitution, as the reference
+                if (ie[1] >= len[1]) e[1] = e[0];
+                if (ie[2] >= len[2]) e[2] = e[3];
+                if (ie[3] >= len[3]) e[3] = e[2];
+                const double e_0 = (1 - d1) * e[0] + d1 * e[1];
+                const double e_1 = (1 - d1) * e[2] + d1 * e[3];
+                r = (1 - d0) * e_0 + d0 * e_1;
+            }
+        }
+        A.out[i] = r;
+    }
+}

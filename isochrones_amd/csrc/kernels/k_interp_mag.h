@@ -1,0 +1,74 @@
+// K4: interp_mag, column-parallel over bands
+// (textually included by iso_hip.hip inside its anonymous namespace: one translation unit, device code only)
+#pragma once
+
+// -------------------------------------------------------------------------------------------
+// K4: interp_mag
+// -------------------------------------------------------------------------------------------
+struct MagArgs {
+    Grid3V g3;
+    Grid4V g4;
+    int kind;
+    const double* pars;
+    int64_t stride_n, stride_p, n;
+    int nb;
+    int32_t bc_cols[ISO_MAX_BANDS];
+    double *Teff, *logg, *feh, *mags;
+};
+
+// Column-parallel like k_interp: G = max(1, ceil(nb/2)) adjacent lanes share one sample; every lane
+// repeats the (cheap) model-table gather of the four stellar columns — the G lanes read identical
+// addresses, i.e. one request — and the BC brackets, then lane `sub` owns the bands 2*sub, 2*sub+1:
+// per corner the G lanes read neighbouring columns of one BC row and finally write nb contiguous
+// magnitudes.
+template <int KIND>
+__global__ __launch_bounds__(BLOCK) void k_interp_mag(const MagArgs A)
+{
+    extern __shared__ double lds[];
+    stage_axes<3>(A.g3.ax, lds);
+    stage_axes<4>(A.g4.ax, lds);
+    __syncthreads();
+    const int G = (A.nb + 1) >> 1 > 0 ? (A.nb + 1) >> 1 : 1;
+    const int S = 64 / G;
+    const int lane = threadIdx.x & 63;
+    const int slot = lane / G, sub = lane - slot * G;
+    if (slot >= S) return;
+    const bool has0 = (2 * sub) < A.nb, has1 = (2 * sub + 1) < A.nb;
+    const int c0 = has0 ? A.bc_cols[2 * sub] : 0, c1 = has1 ? A.bc_cols[2 * sub + 1] : c0;
+    const int64_t wave0 = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * BLOCK) >> 6;
+    for (int64_t i = wave0 * S + slot; i < A.n; i += nwaves * S) {
+        const double* __restrict__ p = A.pars + i * A.stride_n;
+        const double p0 = p[0], p1 = p[A.stride_p], p2 = p[2 * A.stride_p];
+        const double dist = p[3 * A.stride_p], AV = p[4 * A.stride_p];
+        double x0, x1, x2;
+        to_axes<KIND>(p0, p1, p2, x0, x1, x2);
+        double star[4] = {d_nan(), d_nan(), d_nan(), d_nan()};
+        Cell3 c3;
+        if (locate3(A.g3, lds, x0, x1, x2, c3)) gather3<4>(A.g3, c3, star);
+        if (sub == 0) {
+            if (A.Teff) A.Teff[i] = star[0];
+            if (A.logg) A.logg[i] = star[1];
+            if (A.feh) A.feh[i] = star[2];
+        }
+        if (A.mags && has0) {
+            Cell4 c4;
+            const bool ok = locate4(A.g4, lds, star[0], star[1], star[2], AV, c4);
+            const double dm = 5 * log10(dist / 10.0);
+            double b0 = d_nan(), b1 = d_nan();
+            if (ok) {
+                b0 = b1 = 0.0;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const double* __restrict__ row = A.g4.tab + corner4(A.g4, c4, j) * A.g4.ncol;
+                    const double ww = weight4(c4, j);
+                    b0 += row[c0] * ww;
+                    b1 += row[c1] * ww;
+                }
+            }
+            double* o = A.mags + i * A.nb + 2 * sub;
+            o[0] = star[3] + dm - b0;
+            if (has1) o[1] = star[3] + dm - b1;
+        }
+    }
+}

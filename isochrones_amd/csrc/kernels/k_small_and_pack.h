@@ -1,0 +1,105 @@
+// unit-cube transform and the one-off table packers
+// (textually included by iso_hip.hip inside its anonymous namespace: one translation unit, device code only)
+#pragma once
+
+// -------------------------------------------------------------------------------------------
+// small kernels
+// -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_unit_cube(const DevModel* m, double* cube, int64_t stride_n,
+                                                    int64_t stride_p, int64_t n)
+{
+    const int np = m->n_stars + 4;
+    const int64_t total = n * np;
+    for (int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x; e < total; e += (int64_t)gridDim.x * BLOCK) {
+        const int64_t i = e / np;
+        const int p = (int)(e - i * np);
+        double* c = cube + i * stride_n + p * stride_p;
+        const double lo = m->bound_lo[p], hi = m->bound_hi[p];
+        {
+#pragma clang fp contract(off)   // unfused: bit-identical to the reference's (hi - lo) * u + lo
+            const double prod = (hi - lo) * *c;
+            *c = prod + lo;
+        }
+    }
+}
+
+struct PackHotArgs {
+    const double* grid;
+    int ncol;
+    int64_t ncells;
+    int32_t src[HOT_COLS];   // -1 -> NaN fill
+    double* hot;
+};
+
+__global__ __launch_bounds__(BLOCK) void k_pack_hot(const PackHotArgs A)
+{
+    const int64_t total = A.ncells * HOT_COLS;
+    for (int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x; e < total; e += (int64_t)gridDim.x * BLOCK) {
+        const int64_t cell = e / HOT_COLS;
+        const int q = (int)(e - cell * HOT_COLS);
+        const int s = A.src[q];
+        A.hot[e] = (s >= 0) ? A.grid[cell * A.ncol + s] : d_nan();
+    }
+}
+
+struct PackBcArgs {
+    const double* grid;
+    int ncol, nb;
+    int64_t ncells;
+    int32_t src[ISO_MAX_BANDS];
+    double* out;
+};
+
+__global__ __launch_bounds__(BLOCK) void k_pack_bc(const PackBcArgs A)
+{
+    const int64_t total = A.ncells * A.nb;
+    for (int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x; e < total; e += (int64_t)gridDim.x * BLOCK) {
+        const int64_t cell = e / A.nb;
+        const int b = (int)(e - cell * A.nb);
+        A.out[e] = A.grid[cell * A.ncol + A.src[b]];
+    }
+}
+
+struct PackCornersArgs {
+    const double* src;      // compact table, `ncol` doubles per cell
+    int ncol, keep, col0;   // keep columns col0 .. col0+keep-1 of every corner (BC: col0 = 0, keep = ncol = n_bands)
+    int ndim;               // 3 (model table) or 4 (BC table)
+    int64_t n[4];           // axis lengths
+    int64_t ncells;
+    double* out;            // [cell][2^ndim * keep], laid out for the 4-lanes-per-sample gather
+};
+
+// Corner-packed layout: every cell carries its own 2^D corners, ordered so that 4 cooperating lanes
+// read 64 contiguous bytes per load instruction (see iso_fast_kernel.h).
+//   ndim 3: double index e = 2*(4k + j) + comp  ->  corner c = 4*(k/P) + j, column col0 + 2*(k%P) + comp,
+//           P = keep/2 column pairs (3 for the model table, 1 for the asteroseismic pair)
+//   ndim 4: double index e = 2*((k*NB + band)*4 + j) + comp  ->  axis-0 offset k, (axis-1, axis-2)
+//           offsets = bits of j, axis-3 offset comp
+__global__ __launch_bounds__(BLOCK) void k_pack_corners(const PackCornersArgs A)
+{
+    const int per = (1 << A.ndim) * A.keep;
+    const int64_t total = A.ncells * per;
+    for (int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x; e < total; e += (int64_t)gridDim.x * BLOCK) {
+        const int64_t cell = e / per;
+        const int r = (int)(e - cell * per);
+        const int comp = r & 1, piece = r >> 1, j = piece & 3, kk = piece >> 2;
+        int off[4], col;
+        if (A.ndim == 3) {
+            const int pairs = A.keep >> 1;
+            off[0] = kk / pairs; off[1] = (j >> 1) & 1; off[2] = j & 1; off[3] = 0;
+            col = A.col0 + 2 * (kk % pairs) + comp;
+        } else {
+            off[0] = kk / A.keep; off[1] = (j >> 1) & 1; off[2] = j & 1; off[3] = comp;
+            col = kk % A.keep;
+        }
+        int64_t rem = cell, src_cell = 0, mul = 1;
+        for (int d = A.ndim - 1; d >= 0; --d) {
+            int64_t id = rem % A.n[d];
+            rem /= A.n[d];
+            id = min(id + off[d], A.n[d] - 1);      // edge cells are never addressed (i <= n-2)
+            src_cell += id * mul;
+            mul *= A.n[d];
+        }
+        A.out[e] = A.src[src_cell * A.ncol + col];
+    }
+}
