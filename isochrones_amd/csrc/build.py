@@ -14,7 +14,7 @@ OUT = os.path.join(HERE, "libiso_hip.so")
 OBJDIR = os.path.join(HERE, "build")
 HEADERS = [os.path.join(HERE, "..", "..", "include", "isochrones_amd.h"),
            os.path.join(HERE, "iso_internal.h"), os.path.join(HERE, "iso_fast_kernel.h")] + \
-    sorted(glob.glob(os.path.join(HERE, "kernels", "*.h")))
+    sorted(glob.glob(os.path.join(HERE, "kernels", "*.h"))) + sorted(glob.glob(os.path.join(HERE, "fast", "*.h")))
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math", "-Wall",
          "-Wno-unused-function"]
 

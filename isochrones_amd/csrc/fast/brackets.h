@@ -1,0 +1,99 @@
+// bracket search on LDS-staged axes (with reciprocal spacings) and the O(1) EEP axis
+// (part of iso_fast_kernel.h: included inside namespace iso::fastk)
+#pragma once
+
+// ---- brackets -----------------------------------------------------------------------------
+__device__ __forceinline__ bool lds_oob(const double* lds, const FastAxis ax, double x)
+{
+    return (x < lds[ax.off]) || (x > lds[ax.off + ax.n - 1]);
+}
+
+__device__ __forceinline__ void lds_bracket(const double* lds, const FastAxis ax, double x, int& i, double& t)
+{
+    const double* a = lds + ax.off;
+    int base = 0, len = ax.n;
+    while (len > 1) {
+        const int half = len >> 1;
+        base = (a[base + half] <= x) ? base + half : base;
+        len -= half;
+    }
+    base = min(base, ax.n - 2);
+    i = base;
+    t = (x - a[base]) * a[ax.n + base];
+}
+
+// The same bisection for several axes in lock-step: the LDS reads of one level are issued back to back,
+// so a sample pays one LDS latency per level instead of one per level per axis (an axis that has
+// converged re-reads its node, which changes nothing).
+__device__ __forceinline__ void lds_bracket2(const double* lds, const FastAxis axa, const FastAxis axb, double xa,
+                                             double xb, int& ia, int& ib, double& ta, double& tb)
+{
+    const double* a = lds + axa.off;
+    const double* b = lds + axb.off;
+    int ba = 0, bb = 0, la = axa.n, lb = axb.n;
+    while ((la | lb) > 1) {
+        const int ha = la >> 1, hb = lb >> 1;
+        const double va = a[ba + ha], vb = b[bb + hb];
+        ba = (va <= xa) ? ba + ha : ba;
+        bb = (vb <= xb) ? bb + hb : bb;
+        la -= ha;
+        lb -= hb;
+    }
+    ba = min(ba, axa.n - 2);
+    bb = min(bb, axb.n - 2);
+    ia = ba;
+    ib = bb;
+    ta = (xa - a[ba]) * a[axa.n + ba];
+    tb = (xb - b[bb]) * b[axb.n + bb];
+}
+
+__device__ __forceinline__ void lds_bracket4(const double* lds, const FastAxis ax0, const FastAxis ax1,
+                                             const FastAxis ax2, const FastAxis ax3, double x0, double x1, double x2,
+                                             double x3, int& i0, int& i1, int& i2, int& i3, double& t0, double& t1,
+                                             double& t2, double& t3)
+{
+    const double* a0 = lds + ax0.off;
+    const double* a1 = lds + ax1.off;
+    const double* a2 = lds + ax2.off;
+    const double* a3 = lds + ax3.off;
+    int b0 = 0, b1 = 0, b2 = 0, b3 = 0, l0 = ax0.n, l1 = ax1.n, l2 = ax2.n, l3 = ax3.n;
+    while ((l0 | l1 | l2 | l3) > 1) {
+        const int h0 = l0 >> 1, h1 = l1 >> 1, h2 = l2 >> 1, h3 = l3 >> 1;
+        const double v0 = a0[b0 + h0], v1 = a1[b1 + h1], v2 = a2[b2 + h2], v3 = a3[b3 + h3];
+        b0 = (v0 <= x0) ? b0 + h0 : b0;
+        b1 = (v1 <= x1) ? b1 + h1 : b1;
+        b2 = (v2 <= x2) ? b2 + h2 : b2;
+        b3 = (v3 <= x3) ? b3 + h3 : b3;
+        l0 -= h0;
+        l1 -= h1;
+        l2 -= h2;
+        l3 -= h3;
+    }
+    b0 = min(b0, ax0.n - 2);
+    b1 = min(b1, ax1.n - 2);
+    b2 = min(b2, ax2.n - 2);
+    b3 = min(b3, ax3.n - 2);
+    i0 = b0; i1 = b1; i2 = b2; i3 = b3;
+    t0 = (x0 - a0[b0]) * a0[ax0.n + b0];
+    t1 = (x1 - a1[b1]) * a1[ax1.n + b1];
+    t2 = (x2 - a2[b2]) * a2[ax2.n + b2];
+    t3 = (x3 - a3[b3]) * a3[ax3.n + b3];
+}
+
+__device__ __forceinline__ bool eep_oob(const FastArgs& A, double x)
+{
+    return (x < A.e_a0) || (x > fma((double)(A.e_n - 1), A.e_step, A.e_a0));
+}
+
+__device__ __forceinline__ void eep_bracket(const FastArgs& A, double x, int& i, double& t)
+{
+    const int n = A.e_n;
+    int k = (int)((x - A.e_a0) * A.e_inv);
+    k = max(0, min(k, n - 2));
+    const double lo = fma((double)k, A.e_step, A.e_a0);
+    if (lo > x) --k;
+    else if (k < n - 2 && fma((double)(k + 1), A.e_step, A.e_a0) <= x) ++k;
+    k = max(0, min(k, n - 2));
+    i = k;
+    t = (x - fma((double)k, A.e_step, A.e_a0)) * A.e_inv;
+}

@@ -1,0 +1,210 @@
+// wave-cooperative gathers over the corner-packed tables (4 lanes per sample, LDS slots, DPP quad sums)
+// (part of iso_fast_kernel.h: included inside namespace iso::fastk)
+#pragma once
+
+// ---- the kernel ---------------------------------------------------------------------------
+// MULTI: every row carries the index of its own star (observations + priors) — the catalog /
+// batched-ensemble form: S stars x W walkers in one launch.
+// ---- wave-cooperative gathers over the corner-packed tables --------------------------------
+// A lane-per-sample gather issues 24 + 8 x 16-B loads per lane with 64 unrelated addresses per
+// wave instruction; measured ceiling of that pattern on MI355X: 4.4 TB/s of useful bytes
+// (tools/gather_probe.hip).  Letting 4 lanes share one sample — each wave instruction then covers
+// 16 samples x 64 contiguous bytes — reaches 7.1 TB/s.  The sample's owner lane publishes
+// (cell, t0..t3) in a wave-private LDS slot; each group of 4 lanes serves one sample per iteration
+// (4 iterations per wave), weights its share of the corners, sums over the group with two DPP
+// quad permutes (no LDS traffic) and writes the result to the owner's response slot.  The packed
+// tables are laid out for exactly this access (k_pack_star4 / k_pack_bc4 in iso_hip.hip):
+//   model cell: 24 double2 "pieces"; piece (k, j) = index 4k+j holds columns (2q, 2q+1), q = k%3,
+//               of corner c = 4*(k/3) + j  (c bit2/bit1/bit0 = +1 on axis 0/1/2);
+//   BC cell:    piece ((k*NB + e)*4 + j) = {band e at Av node i3, band e at i3+1} of the corner
+//               with axis-0 offset k and (axis-1, axis-2) offsets = the two bits of j.
+// One slot per sample serves as request (header, t0..t3) and then as response (<= 8 values): a
+// slot's request is read only in the iteration that serves it, and its response is written later
+// in that same iteration, so the two may share storage.  Stride 9 doubles: conflict-free b64 access.
+// (13 doubles when more than 8 bands are gathered.)
+constexpr int slot_stride(int nb) { return nb <= 8 ? 9 : 13; }
+constexpr int coop_lds_doubles(int nb) { return BLOCK * slot_stride(nb); }
+constexpr int FAST_MAX_NB = 12;
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double x)
+{
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+
+// sum over the 4 lanes of an aligned quad (every lane ends up with the total)
+__device__ __forceinline__ double quad_sum(double x)
+{
+    x += dpp_f64<0xB1>(x);    // quad_perm [1,0,3,2]
+    x += dpp_f64<0x4E>(x);    // quad_perm [2,3,0,1]
+    return x;
+}
+
+struct CoopLds {
+    double* req;    // this wave's 64 request slots
+    double* rsp;    // this wave's 64 response slots (same storage)
+    int lane;
+    int stride;     // doubles per slot (compile-time constant after inlining)
+};
+
+// Model table: every lane may own one request (need, cell, w); returns the 6 interpolated columns
+// of the lane's own sample in v (NaN if !need).  Must be called by all 64 lanes of the wave.
+__device__ __forceinline__ void coop_star(const FastArgs& A, const CoopLds& L, bool need, uint32_t cell, const W3& w,
+                                          double* __restrict__ v)
+{
+    double* mine = L.req + L.lane * L.stride;
+    mine[0] = __hiloint2double(need ? 1 : 0, (int)cell);
+    mine[1] = w.t0;
+    mine[2] = w.t1;
+    mine[3] = w.t2;
+    __builtin_amdgcn_wave_barrier();
+    const unsigned long long m = __ballot(need);
+    const int j = L.lane & 3, grp = L.lane >> 2;
+    // two batches of two iterations: the 12 loads of a batch are in flight before the first use
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        if (((m >> (32 * half)) & 0xFFFFFFFFull) == 0) continue;          // wave-uniform
+        double2 u[2][6];
+        double wlo[2], whi[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int src = 16 * (2 * half + k) + grp;
+            const double* rq = L.req + src * L.stride;
+            const double hdr = rq[0];
+            const double t0 = rq[1], t1 = rq[2], t2 = rq[3];
+            const bool nd = __double2hiint(hdr) != 0;
+            const uint32_t c = nd ? (uint32_t)__double2loint(hdr) : 0u;      // cell 0 is always readable
+            const double2* __restrict__ pc = reinterpret_cast<const double2*>(A.hotq + (size_t)c * PACK_ENTRY) + j;
+#pragma unroll
+            for (int e = 0; e < 6; ++e) u[k][e] = pc[4 * e];
+            const double g = ((j & 2) ? t1 : (1 - t1)) * ((j & 1) ? t2 : (1 - t2));
+            wlo[k] = nd ? (1 - t0) * g : 0.0;     // corners 0..3 (axis-0 offset 0)
+            whi[k] = nd ? t0 * g : 0.0;           // corners 4..7
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int src = 16 * (2 * half + k) + grp;
+            double part[6];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                part[2 * q] = quad_sum(u[k][q].x * wlo[k] + u[k][3 + q].x * whi[k]);
+                part[2 * q + 1] = quad_sum(u[k][q].y * wlo[k] + u[k][3 + q].y * whi[k]);
+            }
+            double* rs = L.rsp + src * L.stride;
+            // spread the six stores over the quad: lane j writes values j and j+4
+            const double a0 = (j == 0) ? part[0] : (j == 1) ? part[1] : (j == 2) ? part[2] : part[3];
+            rs[j] = a0;
+            if (j < 2) rs[4 + j] = (j == 0) ? part[4] : part[5];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const double* rs = L.rsp + L.lane * L.stride;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) v[q] = need ? rs[q] : f_nan();
+    __builtin_amdgcn_wave_barrier();
+}
+
+// One column pair of the model table on its own corner-packed array ([cell][8 corners][2], 128 B per cell:
+// the asteroseismic (nu_max, delta_nu) pair): same protocol as coop_star with two 16-B loads per lane.
+__device__ __forceinline__ void coop_pair(const double* __restrict__ tab, const CoopLds& L, bool need, uint32_t cell,
+                                          const W3& w, double* __restrict__ v)
+{
+    double* mine = L.req + L.lane * L.stride;
+    mine[0] = __hiloint2double(need ? 1 : 0, (int)cell);
+    mine[1] = w.t0;
+    mine[2] = w.t1;
+    mine[3] = w.t2;
+    __builtin_amdgcn_wave_barrier();
+    const unsigned long long m = __ballot(need);
+    const int j = L.lane & 3, grp = L.lane >> 2;
+    double2 lo[4], hi[4];
+    double wlo[4], whi[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const double* rq = L.req + (16 * k + grp) * L.stride;
+        const double hdr = rq[0];
+        const double t0 = rq[1], t1 = rq[2], t2 = rq[3];
+        const bool nd = __double2hiint(hdr) != 0;
+        const uint32_t c = nd ? (uint32_t)__double2loint(hdr) : 0u;
+        const double2* __restrict__ pc = reinterpret_cast<const double2*>(tab + (size_t)c * 16) + j;
+        lo[k] = pc[0];
+        hi[k] = pc[4];
+        const double g = ((j & 2) ? t1 : (1 - t1)) * ((j & 1) ? t2 : (1 - t2));
+        wlo[k] = nd ? (1 - t0) * g : 0.0;
+        whi[k] = nd ? t0 * g : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (((m >> (16 * k)) & 0xFFFFull) == 0) continue;                      // wave-uniform
+        const double a = quad_sum(lo[k].x * wlo[k] + hi[k].x * whi[k]);
+        const double b = quad_sum(lo[k].y * wlo[k] + hi[k].y * whi[k]);
+        double* rs = L.rsp + (16 * k + grp) * L.stride;
+        if (j == 0) rs[0] = a;
+        if (j == 1) rs[1] = b;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const double* rs = L.rsp + L.lane * L.stride;
+    v[0] = need ? rs[0] : f_nan();
+    v[1] = need ? rs[1] : f_nan();
+    __builtin_amdgcn_wave_barrier();
+}
+
+// BC table: lane j of a quad handles the corners whose (axis-1, axis-2) offsets are the bits of j
+template <int NB>
+__device__ __forceinline__ void coop_bc(const FastArgs& A, const CoopLds& L, bool need, uint32_t cell, const W4& w,
+                                        double* __restrict__ v)
+{
+    double* mine = L.req + L.lane * L.stride;
+    mine[0] = __hiloint2double(need ? 1 : 0, (int)cell);
+    mine[1] = w.t0;
+    mine[2] = w.t1;
+    mine[3] = w.t2;
+    mine[4] = w.t3;
+    __builtin_amdgcn_wave_barrier();
+    const unsigned long long m = __ballot(need);
+    const int j = L.lane & 3, grp = L.lane >> 2;
+    // batches sized so that <= 12 x 16-B loads per lane are in flight before the first use
+    constexpr int BATCH = (NB <= 1) ? 4 : (NB <= 3) ? 2 : 1;
+#pragma unroll
+    for (int r0 = 0; r0 < 4; r0 += BATCH) {
+        if (((m >> (16 * r0)) & ((BATCH == 4) ? ~0ull : ((1ull << (16 * BATCH)) - 1ull))) == 0) continue;   // wave-uniform
+        double2 x[BATCH][2 * NB];
+        double wa[BATCH][2], wb[BATCH][2];
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k) {
+            const int src = 16 * (r0 + k) + grp;
+            const double* rq = L.req + src * L.stride;
+            const double hdr = rq[0];
+            const double t0 = rq[1], t1 = rq[2], t2 = rq[3], t3 = rq[4];
+            const bool nd = __double2hiint(hdr) != 0;
+            const uint32_t c = nd ? (uint32_t)__double2loint(hdr) : 0u;
+            const double2* __restrict__ pc = reinterpret_cast<const double2*>(A.bcq + (size_t)c * (16 * NB)) + j;
+#pragma unroll
+            for (int e = 0; e < 2 * NB; ++e) x[k][e] = pc[4 * e];           // e = kk*NB + band
+            const double g = nd ? ((j & 2) ? t1 : (1 - t1)) * ((j & 1) ? t2 : (1 - t2)) : 0.0;
+            wa[k][0] = (1 - t0) * g * (1 - t3);
+            wb[k][0] = (1 - t0) * g * t3;
+            wa[k][1] = t0 * g * (1 - t3);
+            wb[k][1] = t0 * g * t3;
+        }
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k) {
+            const int src = 16 * (r0 + k) + grp;
+            double* rs = L.rsp + src * L.stride;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const double part = quad_sum(x[k][b].x * wa[k][0] + x[k][b].y * wb[k][0] +
+                                             x[k][NB + b].x * wa[k][1] + x[k][NB + b].y * wb[k][1]);
+                if (j == (b & 3)) rs[b] = part;
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const double* rs = L.rsp + L.lane * L.stride;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) v[b] = need ? rs[b] : f_nan();
+    __builtin_amdgcn_wave_barrier();
+}

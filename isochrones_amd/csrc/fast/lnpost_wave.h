@@ -1,0 +1,179 @@
+// lnpost of one sample per lane (shared by the batch, sampler and catalog kernels) and the batch kernel
+// (part of iso_fast_kernel.h: included inside namespace iso::fastk)
+#pragma once
+
+// lnpost of the lane's sample (p = its NS+4 parameters).  Shared by the batch kernel and the
+// sampler kernel.  With PACKED every gather is wave-cooperative, so ALL 64 lanes of the wave must
+// call this function together; `active` = the lane really has a sample (inactive lanes only help).
+template <int KIND, int NS, int NB, bool PACKED, bool ASTERO = false>
+__device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* lds, const CoopLds& L, bool active,
+                                              const DevModel& M, const double* __restrict__ p, bool want_parts,
+                                              double& lnp_out, double& lnl_out)
+{
+    const double q1 = p[NS], feh_par = p[NS + 1], dist = p[NS + 2], AV = p[NS + 3];
+
+    // ---- model table: axes 0/1 are shared by all components of an isochrone system ----
+    const double x0 = (KIND == ISO_KIND_TRACK) ? p[2] : q1;        // feh | age
+    const double x1 = (KIND == ISO_KIND_TRACK) ? p[0] : feh_par;   // mass | feh
+    const bool ok01 = active && !(x0 != x0) && !(x1 != x1) && !lds_oob(lds, A.m0, x0) && !lds_oob(lds, A.m1, x1);
+    int i0 = 0, i1 = 0;
+    W3 w;
+    w.t0 = w.t1 = w.t2 = 0.0;
+    if (ok01) {
+        lds_bracket2(lds, A.m0, A.m1, x0, x1, i0, i1, w.t0, w.t1);
+    }
+    double star[NS][6];
+    double astero[2] = {0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const double eep = (KIND == ISO_KIND_TRACK) ? p[1] : p[s];
+        const bool ok = ok01 && !(eep != eep) && !eep_oob(A, eep);
+        int i2 = 0;
+        if (ok) eep_bracket(A, eep, i2, w.t2);
+        if (PACKED) {
+            const uint32_t cell = (uint32_t)((int64_t)i0 * A.s0 + (int64_t)i1 * A.s1 + i2);
+            coop_star(A, L, ok, cell, w, star[s]);
+            // asteroseismic pair of the primary (reference starmodel.py:1603-1612); a separate instantiation,
+            // because even a never-taken branch here costs the common kernel registers (measured: +29 %)
+            if (ASTERO && s == 0) coop_pair(A.astq, L, ok && M.has_numax, cell, w, astero);
+        } else if (ok) {
+            gather_star<false>(A, i0, i1, i2, w, star[s]);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 6; ++q) star[s][q] = f_nan();
+        }
+    }
+
+    // ---- lnprior ----
+    const double ld = log(dist);
+    double lnp = 0.0;
+    bool rejected = false;
+    if (NS == 2) rejected = p[1] > p[0];
+    if (NS == 3) rejected = !(p[0] > p[1]) && (p[1] > p[2]);
+    if (KIND == ISO_KIND_TRACK) lnp += ln_pdf<false>(M.prior_mass, p[0], 0.0);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const double eep = (KIND == ISO_KIND_TRACK) ? p[1] : p[s];
+        lnp += eep_term(M, (KIND == ISO_KIND_TRACK) ? M.prior_age : M.prior_mass, eep, star[s][4], star[s][5]);
+    }
+    if (KIND == ISO_KIND_ISO) lnp += ln_pdf<false>(M.prior_age, q1, 0.0);
+    lnp += ln_pdf<false>(M.prior_feh, feh_par, 0.0);
+    lnp += ln_pdf<true>(M.prior_distance, dist, ld);
+    lnp += ln_pdf<false>(M.prior_AV, AV, 0.0);
+    if (rejected) lnp = -f_inf();
+    const bool prior_ok = active && isfinite(lnp);
+    const bool go = active && (prior_ok || want_parts);     // evaluate the likelihood for this lane
+    lnp_out = lnp;
+    lnl_out = f_nan();
+    if (!PACKED && !go) return -f_inf();            // lane-wise path: nothing cooperative follows
+
+    // ---- lnlike ----
+    double lnl = 0.0;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const double val = M.spec_val[q];
+        if (val == val) {
+            const double r = val - star[0][q];
+            lnl += M.spec_g0[q] - r * r * M.spec_hinv[q];
+        }
+    }
+    const double dm = fma(ld, 5.0 * kInvLn10, -5.0);   // 5*log10(d/10)
+    if constexpr (NB > 0) {          // NB = 0: spectroscopy / parallax only, the BC table is never touched
+        double tot[NB];
+        const bool okA = go && !(AV != AV) && !lds_oob(lds, A.b3, AV);
+    #pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const double T = star[s][0], g = star[s][1], f = star[s][2];
+            const bool ok = okA && !(T != T) && !(g != g) && !(f != f) && !lds_oob(lds, A.b0, T) &&
+                            !lds_oob(lds, A.b1, g) && !lds_oob(lds, A.b2, f);
+            double bc[NB];
+            int j0 = 0, j1 = 0, j2 = 0, j3 = 0;
+            W4 w4v;
+            w4v.t0 = w4v.t1 = w4v.t2 = w4v.t3 = 0.0;
+            if (ok) {
+                lds_bracket4(lds, A.b0, A.b1, A.b2, A.b3, T, g, f, AV, j0, j1, j2, j3, w4v.t0, w4v.t1, w4v.t2, w4v.t3);
+            }
+            if (PACKED) {
+                const uint32_t cell = (uint32_t)((int64_t)j0 * A.bs0 + (int64_t)j1 * A.bs1 + (int64_t)j2 * A.bs2 + j3);
+                coop_bc<NB>(A, L, ok, cell, w4v, bc);
+            } else if (ok) {
+                gather_bc<NB, false>(A, j0, j1, j2, j3, w4v, bc);
+            } else {
+    #pragma unroll
+                for (int b = 0; b < NB; ++b) bc[b] = f_nan();
+            }
+    #pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const double mag = star[s][3] + dm - bc[b];
+                if (NS == 1) tot[b] = mag;
+                else tot[b] = (s == 0 ? 0.0 : tot[b]) + exp10(-0.4 * mag);
+            }
+        }
+    #pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const double mag = (NS == 1) ? tot[b] : -2.5 * log10(tot[b]);
+            const double r = M.mag_val[b] - mag;
+            lnl += M.mag_g0[b] - r * r * M.mag_hinv[b];
+        }
+    }
+    if (M.has_parallax) {
+        const double r = M.plx_val - 1000.0 / dist;
+        lnl += M.plx_g0 - r * r * M.plx_hinv;
+    }
+    if (ASTERO && M.has_numax) {
+        const double r = M.numax_val - astero[0];
+        lnl += M.numax_g0 - r * r * M.numax_hinv;
+        if (M.has_dnu) {
+            const double r2 = M.dnu_val - astero[1];
+            lnl += M.dnu_g0 - r2 * r2 * M.dnu_hinv;
+        }
+    }
+    lnl_out = go ? lnl : f_nan();
+    return prior_ok ? lnp + lnl : -f_inf();
+}
+
+// LDS layout of the fast kernels: [axes blob, rounded to an even count][request slots][response slots]
+template <int NB>
+__device__ __forceinline__ CoopLds coop_lds(double* lds, int axes_len)
+{
+    constexpr int REQ_STRIDE = slot_stride(NB);
+    const int base = (axes_len + 1) & ~1;
+    const int wave = threadIdx.x >> 6;
+    CoopLds L;
+    L.req = lds + base + wave * 64 * REQ_STRIDE;
+    L.rsp = L.req;
+    L.stride = REQ_STRIDE;
+    L.lane = threadIdx.x & 63;
+    return L;
+}
+
+// waves per SIMD the register allocator must leave room for: 6 for the small single-star kernels
+// (88 -> 80 VGPR, a few dwords of scratch; measured +2 %), otherwise whatever the kernel needs
+constexpr int fast_min_waves(int ns, int nb) { return (ns == 1 && nb <= 2) ? 6 : 4; }
+
+template <int KIND, int NS, int NB, bool PACKED, bool MULTI, bool ASTERO = false>
+__global__ __launch_bounds__(BLOCK, fast_min_waves(NS, NB)) void k_lnpost_fast(const FastArgs A)
+{
+    extern __shared__ double lds[];
+    for (int j = threadIdx.x; j < A.axes_len; j += BLOCK) lds[j] = A.axes_blob[j];
+    __syncthreads();
+    const CoopLds L = coop_lds<NB>(lds, A.axes_len);
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const bool active = i < A.n;
+    const int64_t ii = active ? i : (A.n - 1);         // inactive lanes shadow the last sample
+    const DevModel& M = A.m[MULTI ? A.star_id[ii] : 0];
+    constexpr int NP = NS + 4;
+    double p[NP];
+    {
+        const double* __restrict__ src = A.pars + ii * A.stride_n;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) p[j] = src[j * A.stride_p];
+    }
+    double lnp, lnl;
+    const double r = lnpost_wave<KIND, NS, NB, PACKED, ASTERO>(A, lds, L, active, M, p, A.lnlike != nullptr, lnp, lnl);
+    if (active) {
+        if (A.lnpost) A.lnpost[i] = r;
+        if (A.lnprior) A.lnprior[i] = lnp;
+        if (A.lnlike) A.lnlike[i] = lnl;
+    }
+}

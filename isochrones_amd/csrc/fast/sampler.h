@@ -1,0 +1,165 @@
+// fused stretch-move sampler kernels: step-wise and persistent
+// (part of iso_fast_kernel.h: included inside namespace iso::fastk)
+#pragma once
+
+// -------------------------------------------------------------------------------------------
+// Fused stretch-move half-step ("next" row f3: device-resident ensemble sampler).
+// One lane = one walker of the active half of one star's ensemble: draw a partner from the
+// complementary half (Philox4x32-10 counter RNG, keyed by seed, counter = (step, half, row)),
+// propose y = x_j + z (x_k - x_j), evaluate lnpost(y) with the same device function as the batch
+// kernel, accept / reject in place.  The active half only *reads* the other half, so a half-step
+// is race-free; two launches make one emcee-style iteration (Goodman & Weare 2010; the reference
+// drives emcee.EnsembleSampler with one Python lnpost call per walker, starmodel.py:951-969).
+// -------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t* out)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// One stretch move of walker k of the active half of one star's ensemble.  `pos` / `lnp` / `acc_cnt` are
+// that star's [W][NP] / [W] / [W] arrays (global memory in the step-wise kernel, LDS in the persistent
+// one), `chain_pos` / `chain_lnp` its slab of the stored chain for this step (or null).  The Philox
+// counter is (step, half, global row): both kernels draw identical numbers for a given move.
+template <int KIND, int NS, int NB>
+__device__ __forceinline__ void stretch_move(const FastArgs& A, const StretchArgs& S, double* lds, const CoopLds& L,
+                                             bool active, int64_t star, int k, int half, uint32_t step,
+                                             double* __restrict__ pos, double* __restrict__ lnp, int32_t* acc_cnt,
+                                             double* __restrict__ chain_pos, double* __restrict__ chain_lnp)
+{
+    constexpr int NP = NS + 4;
+    const int h = S.W >> 1;
+    const int lr = (half ? h : 0) + k;                  // row within the star's ensemble
+    const int64_t row = star * S.W + lr;
+    uint32_t rnd[4];
+    philox4x32_10((uint32_t)(2u * step + (uint32_t)half), (uint32_t)row, (uint32_t)((uint64_t)row >> 32), 0x51u,
+                  (uint32_t)S.seed, (uint32_t)(S.seed >> 32), rnd);
+    const int j = (int)(((uint64_t)rnd[0] * (uint64_t)h) >> 32);          // uniform in [0, h)
+    const int lp = (half ? 0 : h) + j;
+    const double u1 = ((double)rnd[1] + (double)(rnd[2] & 0xFFFFu) * (1.0 / 65536.0)) * (1.0 / 4294967296.0);
+    const double u2 = ((double)rnd[3] + (double)(rnd[2] >> 16) * (1.0 / 65536.0) + 0.5 / 65536.0) * (1.0 / 4294967296.0);
+    const double zr = (S.a - 1.0) * u1 + 1.0;
+    const double z = zr * zr / S.a;
+    // helper lanes (no walker of their own) only read the complementary half, which nobody writes in this
+    // half-step: they evaluate the partner's position and discard the result
+    const int lsrc = active ? lr : lp;
+    double xk[NP], y[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        xk[q] = pos[lsrc * NP + q];
+        const double xj = pos[lp * NP + q];
+        y[q] = xj + z * (xk[q] - xj);
+    }
+    const double lold = lnp[lsrc];
+    const DevModel& M = A.m[S.multi ? star : 0];
+    double lnp_unused, lnl_unused;
+    const double lnew = lnpost_wave<KIND, NS, NB, true>(A, lds, L, active, M, y, false, lnp_unused, lnl_unused);
+    const double lnq = (NP - 1) * log(z) + lnew - lold;
+    const bool acc = active && isfinite(lnew) && (log(u2) < lnq);
+    if (acc) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) pos[lr * NP + q] = y[q];
+        lnp[lr] = lnew;
+        if (acc_cnt) acc_cnt[lr] += 1;
+    }
+    // chain recording: every move stores the row it owns (its value for this step)
+    if (active && chain_pos) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) chain_pos[lr * NP + q] = acc ? y[q] : xk[q];
+    }
+    if (active && chain_lnp) chain_lnp[lr] = acc ? lnew : lold;
+}
+
+// step-wise form: one launch = one half-step of every ensemble (grid over stars x W/2 walkers);
+// the throughput form for catalogs large enough to fill the chip
+template <int KIND, int NS, int NB>
+__global__ __launch_bounds__(BLOCK) void k_stretch_half(const FastArgs A, const StretchArgs S)
+{
+    extern __shared__ double lds[];
+    for (int j = threadIdx.x; j < A.axes_len; j += BLOCK) lds[j] = A.axes_blob[j];
+    __syncthreads();
+    const CoopLds L = coop_lds<NB>(lds, A.axes_len);
+    const int64_t t0 = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const bool active = t0 < S.n_active;
+    const int64_t t = active ? t0 : (S.n_active - 1);
+    constexpr int NP = NS + 4;
+    const int h = S.W >> 1;
+    const int64_t star = t / h;
+    const int k = (int)(t - star * h);
+    const int64_t r0 = star * S.W;
+    stretch_move<KIND, NS, NB>(A, S, lds, L, active, star, k, S.half, S.step, S.pos + r0 * NP, S.lnp + r0,
+                               S.accepted ? S.accepted + r0 : nullptr, S.chain_pos ? S.chain_pos + r0 * NP : nullptr,
+                               S.chain_lnp ? S.chain_lnp + r0 : nullptr);
+}
+
+// persistent form: ALL S.nsteps iterations in a single launch.  A workgroup owns G = max(1, BLOCK / (W/2))
+// whole ensembles (one lane per walker of the active half, so a 32-walker catalog packs 16 stars into a
+// workgroup; a large ensemble is walked in chunks of BLOCK).  Positions, lnpost values and acceptance
+// counters live in LDS; the two half-steps of an iteration are separated by workgroup barriers instead
+// of kernel boundaries, so an iteration costs two dependent evaluation chains instead of two launches.
+// Same moves, same random numbers, bit-identical chains as the step-wise form.
+// LDS: [axes][request/response slots][pos R*NP][lnp R][acc R (int32)],  R = G * W rows
+__host__ __device__ constexpr int persist_group(int W) { return (W >> 1) >= BLOCK ? 1 : BLOCK / (W >> 1); }
+__host__ __device__ constexpr int persist_extra_doubles(int W, int np)
+{
+    return persist_group(W) * W * (np + 1) + (persist_group(W) * W + 1) / 2;
+}
+
+template <int KIND, int NS, int NB>
+__global__ __launch_bounds__(BLOCK) void k_stretch_persist(const FastArgs A, const StretchArgs S)
+{
+    extern __shared__ double lds[];
+    for (int j = threadIdx.x; j < A.axes_len; j += BLOCK) lds[j] = A.axes_blob[j];
+    const CoopLds L = coop_lds<NB>(lds, A.axes_len);
+    constexpr int NP = NS + 4;
+    const int W = S.W, h = W >> 1;
+    const int G = persist_group(W);
+    const int per = h < BLOCK ? h : BLOCK;               // lanes one ensemble occupies per chunk
+    const int64_t n_ens = S.n_active / h;
+    const int64_t star0 = (int64_t)blockIdx.x * G;
+    const int here = (int)((n_ens - star0) < G ? (n_ens - star0) : G);   // ensembles this workgroup owns
+    const int R = here * W;
+    const int64_t r0 = star0 * W;
+    double* lpos = lds + ((A.axes_len + 1) & ~1) + coop_lds_doubles(NB);
+    double* llnp = lpos + G * W * NP;
+    int32_t* lacc = reinterpret_cast<int32_t*>(llnp + G * W);
+    for (int j = threadIdx.x; j < R * NP; j += BLOCK) lpos[j] = S.pos[r0 * NP + j];
+    for (int j = threadIdx.x; j < R; j += BLOCK) {
+        llnp[j] = S.lnp[r0 + j];
+        lacc[j] = 0;
+    }
+    __syncthreads();
+    const int64_t rows_total = n_ens * W;
+    const int g = (int)threadIdx.x / per, kk = (int)threadIdx.x - g * per;
+    const bool mine = g < here;
+    const int gs = mine ? g : 0;                          // idle lanes shadow a move of the first ensemble
+    for (int it = 0; it < S.nsteps; ++it) {
+        double* cp = S.chain_pos ? S.chain_pos + ((int64_t)it * rows_total + r0 + gs * W) * NP : nullptr;
+        double* cl = S.chain_lnp ? S.chain_lnp + (int64_t)it * rows_total + r0 + gs * W : nullptr;
+        for (int half = 0; half < 2; ++half) {
+            for (int k0 = 0; k0 < h; k0 += per) {
+                const int k = k0 + kk;
+                const bool active = mine && k < h;
+                if (__any(active))                        // wave-uniform: idle waves go straight to the barrier
+                    stretch_move<KIND, NS, NB>(A, S, lds, L, active, star0 + gs, active ? k : h - 1, half,
+                                               S.step + (uint32_t)it, lpos + gs * W * NP, llnp + gs * W,
+                                               lacc + gs * W, cp, cl);
+            }
+            __syncthreads();
+        }
+    }
+    for (int j = threadIdx.x; j < R * NP; j += BLOCK) S.pos[r0 * NP + j] = lpos[j];
+    for (int j = threadIdx.x; j < R; j += BLOCK) {
+        S.lnp[r0 + j] = llnp[j];
+        if (S.accepted) S.accepted[r0 + j] += lacc[j];
+    }
+}

@@ -28,940 +28,13 @@ constexpr double kInvRoot2Pi = 0.3989422804014327;
 constexpr double kLn10 = 2.302585092994046;
 constexpr double kInvLn10 = 0.43429448190325176;
 
-// ---- brackets -----------------------------------------------------------------------------
-__device__ __forceinline__ bool lds_oob(const double* lds, const FastAxis ax, double x)
-{
-    return (x < lds[ax.off]) || (x > lds[ax.off + ax.n - 1]);
-}
-
-__device__ __forceinline__ void lds_bracket(const double* lds, const FastAxis ax, double x, int& i, double& t)
-{
-    const double* a = lds + ax.off;
-    int base = 0, len = ax.n;
-    while (len > 1) {
-        const int half = len >> 1;
-        base = (a[base + half] <= x) ? base + half : base;
-        len -= half;
-    }
-    base = min(base, ax.n - 2);
-    i = base;
-    t = (x - a[base]) * a[ax.n + base];
-}
-
-// The same bisection for several axes in lock-step: the LDS reads of one level are issued back to back,
-// so a sample pays one LDS latency per level instead of one per level per axis (an axis that has
-// converged re-reads its node, which changes nothing).
-__device__ __forceinline__ void lds_bracket2(const double* lds, const FastAxis axa, const FastAxis axb, double xa,
-                                             double xb, int& ia, int& ib, double& ta, double& tb)
-{
-    const double* a = lds + axa.off;
-    const double* b = lds + axb.off;
-    int ba = 0, bb = 0, la = axa.n, lb = axb.n;
-    while ((la | lb) > 1) {
-        const int ha = la >> 1, hb = lb >> 1;
-        const double va = a[ba + ha], vb = b[bb + hb];
-        ba = (va <= xa) ? ba + ha : ba;
-        bb = (vb <= xb) ? bb + hb : bb;
-        la -= ha;
-        lb -= hb;
-    }
-    ba = min(ba, axa.n - 2);
-    bb = min(bb, axb.n - 2);
-    ia = ba;
-    ib = bb;
-    ta = (xa - a[ba]) * a[axa.n + ba];
-    tb = (xb - b[bb]) * b[axb.n + bb];
-}
-
-__device__ __forceinline__ void lds_bracket4(const double* lds, const FastAxis ax0, const FastAxis ax1,
-                                             const FastAxis ax2, const FastAxis ax3, double x0, double x1, double x2,
-                                             double x3, int& i0, int& i1, int& i2, int& i3, double& t0, double& t1,
-                                             double& t2, double& t3)
-{
-    const double* a0 = lds + ax0.off;
-    const double* a1 = lds + ax1.off;
-    const double* a2 = lds + ax2.off;
-    const double* a3 = lds + ax3.off;
-    int b0 = 0, b1 = 0, b2 = 0, b3 = 0, l0 = ax0.n, l1 = ax1.n, l2 = ax2.n, l3 = ax3.n;
-    while ((l0 | l1 | l2 | l3) > 1) {
-        const int h0 = l0 >> 1, h1 = l1 >> 1, h2 = l2 >> 1, h3 = l3 >> 1;
-        const double v0 = a0[b0 + h0], v1 = a1[b1 + h1], v2 = a2[b2 + h2], v3 = a3[b3 + h3];
-        b0 = (v0 <= x0) ? b0 + h0 : b0;
-        b1 = (v1 <= x1) ? b1 + h1 : b1;
-        b2 = (v2 <= x2) ? b2 + h2 : b2;
-        b3 = (v3 <= x3) ? b3 + h3 : b3;
-        l0 -= h0;
-        l1 -= h1;
-        l2 -= h2;
-        l3 -= h3;
-    }
-    b0 = min(b0, ax0.n - 2);
-    b1 = min(b1, ax1.n - 2);
-    b2 = min(b2, ax2.n - 2);
-    b3 = min(b3, ax3.n - 2);
-    i0 = b0; i1 = b1; i2 = b2; i3 = b3;
-    t0 = (x0 - a0[b0]) * a0[ax0.n + b0];
-    t1 = (x1 - a1[b1]) * a1[ax1.n + b1];
-    t2 = (x2 - a2[b2]) * a2[ax2.n + b2];
-    t3 = (x3 - a3[b3]) * a3[ax3.n + b3];
-}
-
-__device__ __forceinline__ bool eep_oob(const FastArgs& A, double x)
-{
-    return (x < A.e_a0) || (x > fma((double)(A.e_n - 1), A.e_step, A.e_a0));
-}
-
-__device__ __forceinline__ void eep_bracket(const FastArgs& A, double x, int& i, double& t)
-{
-    const int n = A.e_n;
-    int k = (int)((x - A.e_a0) * A.e_inv);
-    k = max(0, min(k, n - 2));
-    const double lo = fma((double)k, A.e_step, A.e_a0);
-    if (lo > x) --k;
-    else if (k < n - 2 && fma((double)(k + 1), A.e_step, A.e_a0) <= x) ++k;
-    k = max(0, min(k, n - 2));
-    i = k;
-    t = (x - fma((double)k, A.e_step, A.e_a0)) * A.e_inv;
-}
-
-// ---- gathers ------------------------------------------------------------------------------
-struct W3 {
-    double t0, t1, t2;
-};
-
-__device__ __forceinline__ double w3(const W3& w, int j)
-{
-    double r = 1.0;
-    r *= ((j >> 2) & 1) ? w.t0 : (1 - w.t0);
-    r *= ((j >> 1) & 1) ? w.t1 : (1 - w.t1);
-    r *= (j & 1) ? w.t2 : (1 - w.t2);
-    return r;
-}
-
-// six columns (Teff, logg, feh, Mbol, prior value, prior derivative) of one star
-template <bool PACKED>
-__device__ __forceinline__ void gather_star(const FastArgs& A, int i0, int i1, int i2, const W3& w,
-                                            double* __restrict__ v)
-{
-#pragma unroll
-    for (int q = 0; q < 6; ++q) v[q] = 0.0;
-    const int64_t cell = (int64_t)i0 * A.s0 + (int64_t)i1 * A.s1 + i2;
-    if (PACKED) {
-        const double2* __restrict__ p = reinterpret_cast<const double2*>(A.hotq + cell * PACK_ENTRY);
-        double2 u[24];
-#pragma unroll
-        for (int k = 0; k < 24; ++k) u[k] = p[k];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const double ww = w3(w, j);
-            v[0] += u[3 * j].x * ww;
-            v[1] += u[3 * j].y * ww;
-            v[2] += u[3 * j + 1].x * ww;
-            v[3] += u[3 * j + 1].y * ww;
-            v[4] += u[3 * j + 2].x * ww;
-            v[5] += u[3 * j + 2].y * ww;
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int64_t c = cell + (((j >> 2) & 1) ? A.s0 : 0) + (((j >> 1) & 1) ? A.s1 : 0) + (j & 1);
-            const double2* __restrict__ p = reinterpret_cast<const double2*>(A.hot + c * HOT_COLS);
-            const double2 u0 = p[0], u1 = p[1], u2 = p[2];
-            const double ww = w3(w, j);
-            v[0] += u0.x * ww;
-            v[1] += u0.y * ww;
-            v[2] += u1.x * ww;
-            v[3] += u1.y * ww;
-            v[4] += u2.x * ww;
-            v[5] += u2.y * ww;
-        }
-    }
-}
-
-struct W4 {
-    double t0, t1, t2, t3;
-};
-
-__device__ __forceinline__ double w4(const W4& w, int j)
-{
-    double r = 1.0;
-    r *= ((j >> 3) & 1) ? w.t0 : (1 - w.t0);
-    r *= ((j >> 2) & 1) ? w.t1 : (1 - w.t1);
-    r *= ((j >> 1) & 1) ? w.t2 : (1 - w.t2);
-    r *= (j & 1) ? w.t3 : (1 - w.t3);
-    return r;
-}
-
-template <int NB, bool PACKED>
-__device__ __forceinline__ void gather_bc(const FastArgs& A, int i0, int i1, int i2, int i3, const W4& w,
-                                          double* __restrict__ v)
-{
-#pragma unroll
-    for (int b = 0; b < NB; ++b) v[b] = 0.0;
-    const int64_t cell = (int64_t)i0 * A.bs0 + (int64_t)i1 * A.bs1 + (int64_t)i2 * A.bs2 + i3;
-    if (PACKED) {
-        const double* __restrict__ p = A.bcq + cell * (16 * NB);
-        if ((NB & 1) == 0) {
-            const double2* __restrict__ p2 = reinterpret_cast<const double2*>(p);
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const double ww = w4(w, j);
-#pragma unroll
-                for (int b = 0; b < NB; b += 2) {
-                    const double2 u = p2[(j * NB + b) >> 1];
-                    v[b] += u.x * ww;
-                    v[b + 1] += u.y * ww;
-                }
-            }
-        } else if (NB == 1) {
-            const double2* __restrict__ p2 = reinterpret_cast<const double2*>(p);
-#pragma unroll
-            for (int j = 0; j < 16; j += 2) {
-                const double2 u = p2[j >> 1];
-                v[0] += u.x * w4(w, j);
-                v[0] += u.y * w4(w, j + 1);
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const double ww = w4(w, j);
-#pragma unroll
-                for (int b = 0; b < NB; ++b) v[b] += p[j * NB + b] * ww;
-            }
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int64_t c = cell + (((j >> 3) & 1) ? A.bs0 : 0) + (((j >> 2) & 1) ? A.bs1 : 0) +
-                              (((j >> 1) & 1) ? A.bs2 : 0) + (j & 1);
-            const double* __restrict__ p = A.bc + c * NB;
-            const double ww = w4(w, j);
-#pragma unroll
-            for (int b = 0; b < NB; ++b) v[b] += p[b] * ww;
-        }
-    }
-}
-
-// ---- priors in log space ------------------------------------------------------------------
-__device__ __forceinline__ double lognormal_ln(const DevPrior& P, double lx)
-{
-    // lx = log(x); y = x/scale -> log(y) = lx - mu
-    const double l = lx - P.a;
-    const double ly = l * P.r1;
-    return kLogInvRoot2Pi - (P.k1 + l) - 0.5 * (ly * ly) - P.a;
-}
-
-__device__ __forceinline__ double feh_pdf(const DevPrior& P, double x)
-{
-    double disk;
-    if (P.c != 0.0) {
-        constexpr double c1 = 0.8 / 0.15 / 2.5066282746310007, c2 = 0.2 / 0.22 / 2.5066282746310007;
-        constexpr double e1 = -0.5 / (0.15 * 0.15), e2 = -0.5 / (0.22 * 0.22);
-        const double u = x - 0.016, v = x + 0.15;
-        disk = c1 * exp(e1 * (u * u)) + c2 * exp(e2 * (v * v));
-    } else {
-        constexpr double c0 = kInvRoot2Pi / 0.3, e0 = -0.5 / (0.3 * 0.3);
-        const double u = x + 0.3;
-        disk = c0 * exp(e0 * (u * u));
-    }
-    constexpr double eh = -0.5 / (0.4 * 0.4);
-    const double h = x + 1.5;
-    const double halo = P.k0 * exp(eh * (h * h));
-    return (P.a * halo + (1 - P.a) * disk) * P.r0;   // r0 = 1/norm
-}
-
-// log of the reference's lnpdf(x).  HAS_LX: lx = log(x) supplied by the caller.
-template <bool HAS_LX>
-__device__ __forceinline__ double ln_pdf(const DevPrior& P, double x, double lx)
-{
-    const bool outside = (x < P.lo) || (x > P.hi);
-    switch (P.kind) {
-    case ISO_PRIOR_FLAT: return outside ? -f_inf() : P.k1;
-    case ISO_PRIOR_FLATLOG: return outside ? -f_inf() : fma(x, kLn10, P.k1);
-    case ISO_PRIOR_POWERLAW: {
-        if (P.bounded && outside) return -f_inf();
-        const double l = HAS_LX ? lx : log(x);
-        return fma(P.a, l, P.k1);
-    }
-    case ISO_PRIOR_GAUSS: {
-        if (P.bounded && outside) return -f_inf();
-        const double z = (x - P.a) * P.r0;
-        return (-0.5 * (z * z) + kLogInvRoot2Pi) - P.k1 - P.c;
-    }
-    case ISO_PRIOR_LOGNORMAL: return lognormal_ln(P, HAS_LX ? lx : log(x));
-    case ISO_PRIOR_CHABRIER: {
-        const double l = HAS_LX ? lx : log(x);
-        if (x < P.d) return lognormal_ln(P, l) - P.k3;
-        if (x < P.g || x > P.h) return -f_inf();
-        return fma(P.c, l, P.k5) - P.k4;
-    }
-    case ISO_PRIOR_FEH: {
-        if (outside) return -f_inf();
-        const double pdf = feh_pdf(P, x);
-        return pdf != 0 ? log(pdf) : -f_inf();
-    }
-    }
-    return f_nan();
-}
-
-// log of the reference's prior(x) (the __call__ / pdf form): -inf where the pdf is exactly 0
-__device__ __forceinline__ double ln_call(const DevPrior& P, double x)
-{
-    const bool outside = (x < P.lo) || (x > P.hi);
-    switch (P.kind) {
-    case ISO_PRIOR_FLAT: return outside ? -f_inf() : P.k1;
-    case ISO_PRIOR_FLATLOG: return outside ? -f_inf() : fma(x, kLn10, P.k1);
-    case ISO_PRIOR_POWERLAW: return outside ? -f_inf() : fma(P.a, log(x), P.k1);
-    case ISO_PRIOR_GAUSS: {
-        if (outside) return -f_inf();
-        const double z = (x - P.a) * P.r0;
-        return (-0.5 * (z * z) + kLogInvRoot2Pi) - P.k1 - P.c;
-    }
-    case ISO_PRIOR_LOGNORMAL: return (x < 0) ? -f_inf() : lognormal_ln(P, log(x));
-    case ISO_PRIOR_CHABRIER: {
-        if (outside) return -f_inf();
-        if (x < P.d) return (x < 0) ? -f_inf() : lognormal_ln(P, log(x)) - P.k3;
-        if (x < P.g || x > P.h) return -f_inf();
-        return fma(P.c, log(x), P.k5) - P.k4;
-    }
-    case ISO_PRIOR_FEH: {
-        if (outside) return -f_inf();
-        const double pdf = feh_pdf(P, x);
-        return pdf != 0 ? log(pdf) : -f_inf();
-    }
-    }
-    return f_nan();
-}
-
-// EEP prior term: log( orig_prior(value) * derivative ), reference priors.py:423-429 + :130-140
-__device__ __forceinline__ double eep_term(const DevModel& M, const DevPrior& orig, double eep, double value,
-                                           double deriv)
-{
-    if (eep < M.eep_lo || eep > M.eep_hi) return -f_inf();
-    const double lc = ln_call(orig, value);
-    if (lc == -f_inf()) return (deriv != deriv) ? f_nan() : -f_inf();   // 0 * deriv
-    return lc + log(deriv);   // deriv == 0 -> -inf, deriv < 0 -> NaN, NaN -> NaN
-}
-
-// ---- the kernel ---------------------------------------------------------------------------
-// MULTI: every row carries the index of its own star (observations + priors) — the catalog /
-// batched-ensemble form: S stars x W walkers in one launch.
-// ---- wave-cooperative gathers over the corner-packed tables --------------------------------
-// A lane-per-sample gather issues 24 + 8 x 16-B loads per lane with 64 unrelated addresses per
-// wave instruction; measured ceiling of that pattern on MI355X: 4.4 TB/s of useful bytes
-// (tools/gather_probe.hip).  Letting 4 lanes share one sample — each wave instruction then covers
-// 16 samples x 64 contiguous bytes — reaches 7.1 TB/s.  The sample's owner lane publishes
-// (cell, t0..t3) in a wave-private LDS slot; each group of 4 lanes serves one sample per iteration
-// (4 iterations per wave), weights its share of the corners, sums over the group with two DPP
-// quad permutes (no LDS traffic) and writes the result to the owner's response slot.  The packed
-// tables are laid out for exactly this access (k_pack_star4 / k_pack_bc4 in iso_hip.hip):
-//   model cell: 24 double2 "pieces"; piece (k, j) = index 4k+j holds columns (2q, 2q+1), q = k%3,
-//               of corner c = 4*(k/3) + j  (c bit2/bit1/bit0 = +1 on axis 0/1/2);
-//   BC cell:    piece ((k*NB + e)*4 + j) = {band e at Av node i3, band e at i3+1} of the corner
-//               with axis-0 offset k and (axis-1, axis-2) offsets = the two bits of j.
-// One slot per sample serves as request (header, t0..t3) and then as response (<= 8 values): a
-// slot's request is read only in the iteration that serves it, and its response is written later
-// in that same iteration, so the two may share storage.  Stride 9 doubles: conflict-free b64 access.
-// (13 doubles when more than 8 bands are gathered.)
-constexpr int slot_stride(int nb) { return nb <= 8 ? 9 : 13; }
-constexpr int coop_lds_doubles(int nb) { return BLOCK * slot_stride(nb); }
-constexpr int FAST_MAX_NB = 12;
-
-template <int CTRL>
-__device__ __forceinline__ double dpp_f64(double x)
-{
-    int lo = __double2loint(x), hi = __double2hiint(x);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
-    return __hiloint2double(hi, lo);
-}
-
-// sum over the 4 lanes of an aligned quad (every lane ends up with the total)
-__device__ __forceinline__ double quad_sum(double x)
-{
-    x += dpp_f64<0xB1>(x);    // quad_perm [1,0,3,2]
-    x += dpp_f64<0x4E>(x);    // quad_perm [2,3,0,1]
-    return x;
-}
-
-struct CoopLds {
-    double* req;    // this wave's 64 request slots
-    double* rsp;    // this wave's 64 response slots (same storage)
-    int lane;
-    int stride;     // doubles per slot (compile-time constant after inlining)
-};
-
-// Model table: every lane may own one request (need, cell, w); returns the 6 interpolated columns
-// of the lane's own sample in v (NaN if !need).  Must be called by all 64 lanes of the wave.
-__device__ __forceinline__ void coop_star(const FastArgs& A, const CoopLds& L, bool need, uint32_t cell, const W3& w,
-                                          double* __restrict__ v)
-{
-    double* mine = L.req + L.lane * L.stride;
-    mine[0] = __hiloint2double(need ? 1 : 0, (int)cell);
-    mine[1] = w.t0;
-    mine[2] = w.t1;
-    mine[3] = w.t2;
-    __builtin_amdgcn_wave_barrier();
-    const unsigned long long m = __ballot(need);
-    const int j = L.lane & 3, grp = L.lane >> 2;
-    // two batches of two iterations: the 12 loads of a batch are in flight before the first use
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        if (((m >> (32 * half)) & 0xFFFFFFFFull) == 0) continue;          // wave-uniform
-        double2 u[2][6];
-        double wlo[2], whi[2];
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int src = 16 * (2 * half + k) + grp;
-            const double* rq = L.req + src * L.stride;
-            const double hdr = rq[0];
-            const double t0 = rq[1], t1 = rq[2], t2 = rq[3];
-            const bool nd = __double2hiint(hdr) != 0;
-            const uint32_t c = nd ? (uint32_t)__double2loint(hdr) : 0u;      // cell 0 is always readable
-            const double2* __restrict__ pc = reinterpret_cast<const double2*>(A.hotq + (size_t)c * PACK_ENTRY) + j;
-#pragma unroll
-            for (int e = 0; e < 6; ++e) u[k][e] = pc[4 * e];
-            const double g = ((j & 2) ? t1 : (1 - t1)) * ((j & 1) ? t2 : (1 - t2));
-            wlo[k] = nd ? (1 - t0) * g : 0.0;     // corners 0..3 (axis-0 offset 0)
-            whi[k] = nd ? t0 * g : 0.0;           // corners 4..7
-        }
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int src = 16 * (2 * half + k) + grp;
-            double part[6];
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                part[2 * q] = quad_sum(u[k][q].x * wlo[k] + u[k][3 + q].x * whi[k]);
-                part[2 * q + 1] = quad_sum(u[k][q].y * wlo[k] + u[k][3 + q].y * whi[k]);
-            }
-            double* rs = L.rsp + src * L.stride;
-            // spread the six stores over the quad: lane j writes values j and j+4
-            const double a0 = (j == 0) ? part[0] : (j == 1) ? part[1] : (j == 2) ? part[2] : part[3];
-            rs[j] = a0;
-            if (j < 2) rs[4 + j] = (j == 0) ? part[4] : part[5];
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-    const double* rs = L.rsp + L.lane * L.stride;
-#pragma unroll
-    for (int q = 0; q < 6; ++q) v[q] = need ? rs[q] : f_nan();
-    __builtin_amdgcn_wave_barrier();
-}
-
-// One column pair of the model table on its own corner-packed array ([cell][8 corners][2], 128 B per cell:
-// the asteroseismic (nu_max, delta_nu) pair): same protocol as coop_star with two 16-B loads per lane.
-__device__ __forceinline__ void coop_pair(const double* __restrict__ tab, const CoopLds& L, bool need, uint32_t cell,
-                                          const W3& w, double* __restrict__ v)
-{
-    double* mine = L.req + L.lane * L.stride;
-    mine[0] = __hiloint2double(need ? 1 : 0, (int)cell);
-    mine[1] = w.t0;
-    mine[2] = w.t1;
-    mine[3] = w.t2;
-    __builtin_amdgcn_wave_barrier();
-    const unsigned long long m = __ballot(need);
-    const int j = L.lane & 3, grp = L.lane >> 2;
-    double2 lo[4], hi[4];
-    double wlo[4], whi[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const double* rq = L.req + (16 * k + grp) * L.stride;
-        const double hdr = rq[0];
-        const double t0 = rq[1], t1 = rq[2], t2 = rq[3];
-        const bool nd = __double2hiint(hdr) != 0;
-        const uint32_t c = nd ? (uint32_t)__double2loint(hdr) : 0u;
-        const double2* __restrict__ pc = reinterpret_cast<const double2*>(tab + (size_t)c * 16) + j;
-        lo[k] = pc[0];
-        hi[k] = pc[4];
-        const double g = ((j & 2) ? t1 : (1 - t1)) * ((j & 1) ? t2 : (1 - t2));
-        wlo[k] = nd ? (1 - t0) * g : 0.0;
-        whi[k] = nd ? t0 * g : 0.0;
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        if (((m >> (16 * k)) & 0xFFFFull) == 0) continue;                      // wave-uniform
-        const double a = quad_sum(lo[k].x * wlo[k] + hi[k].x * whi[k]);
-        const double b = quad_sum(lo[k].y * wlo[k] + hi[k].y * whi[k]);
-        double* rs = L.rsp + (16 * k + grp) * L.stride;
-        if (j == 0) rs[0] = a;
-        if (j == 1) rs[1] = b;
-    }
-    __builtin_amdgcn_wave_barrier();
-    const double* rs = L.rsp + L.lane * L.stride;
-    v[0] = need ? rs[0] : f_nan();
-    v[1] = need ? rs[1] : f_nan();
-    __builtin_amdgcn_wave_barrier();
-}
-
-// BC table: lane j of a quad handles the corners whose (axis-1, axis-2) offsets are the bits of j
-template <int NB>
-__device__ __forceinline__ void coop_bc(const FastArgs& A, const CoopLds& L, bool need, uint32_t cell, const W4& w,
-                                        double* __restrict__ v)
-{
-    double* mine = L.req + L.lane * L.stride;
-    mine[0] = __hiloint2double(need ? 1 : 0, (int)cell);
-    mine[1] = w.t0;
-    mine[2] = w.t1;
-    mine[3] = w.t2;
-    mine[4] = w.t3;
-    __builtin_amdgcn_wave_barrier();
-    const unsigned long long m = __ballot(need);
-    const int j = L.lane & 3, grp = L.lane >> 2;
-    // batches sized so that <= 12 x 16-B loads per lane are in flight before the first use
-    constexpr int BATCH = (NB <= 1) ? 4 : (NB <= 3) ? 2 : 1;
-#pragma unroll
-    for (int r0 = 0; r0 < 4; r0 += BATCH) {
-        if (((m >> (16 * r0)) & ((BATCH == 4) ? ~0ull : ((1ull << (16 * BATCH)) - 1ull))) == 0) continue;   // wave-uniform
-        double2 x[BATCH][2 * NB];
-        double wa[BATCH][2], wb[BATCH][2];
-#pragma unroll
-        for (int k = 0; k < BATCH; ++k) {
-            const int src = 16 * (r0 + k) + grp;
-            const double* rq = L.req + src * L.stride;
-            const double hdr = rq[0];
-            const double t0 = rq[1], t1 = rq[2], t2 = rq[3], t3 = rq[4];
-            const bool nd = __double2hiint(hdr) != 0;
-            const uint32_t c = nd ? (uint32_t)__double2loint(hdr) : 0u;
-            const double2* __restrict__ pc = reinterpret_cast<const double2*>(A.bcq + (size_t)c * (16 * NB)) + j;
-#pragma unroll
-            for (int e = 0; e < 2 * NB; ++e) x[k][e] = pc[4 * e];           // e = kk*NB + band
-            const double g = nd ? ((j & 2) ? t1 : (1 - t1)) * ((j & 1) ? t2 : (1 - t2)) : 0.0;
-            wa[k][0] = (1 - t0) * g * (1 - t3);
-            wb[k][0] = (1 - t0) * g * t3;
-            wa[k][1] = t0 * g * (1 - t3);
-            wb[k][1] = t0 * g * t3;
-        }
-#pragma unroll
-        for (int k = 0; k < BATCH; ++k) {
-            const int src = 16 * (r0 + k) + grp;
-            double* rs = L.rsp + src * L.stride;
-#pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                const double part = quad_sum(x[k][b].x * wa[k][0] + x[k][b].y * wb[k][0] +
-                                             x[k][NB + b].x * wa[k][1] + x[k][NB + b].y * wb[k][1]);
-                if (j == (b & 3)) rs[b] = part;
-            }
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-    const double* rs = L.rsp + L.lane * L.stride;
-#pragma unroll
-    for (int b = 0; b < NB; ++b) v[b] = need ? rs[b] : f_nan();
-    __builtin_amdgcn_wave_barrier();
-}
-
-// lnpost of the lane's sample (p = its NS+4 parameters).  Shared by the batch kernel and the
-// sampler kernel.  With PACKED every gather is wave-cooperative, so ALL 64 lanes of the wave must
-// call this function together; `active` = the lane really has a sample (inactive lanes only help).
-template <int KIND, int NS, int NB, bool PACKED, bool ASTERO = false>
-__device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* lds, const CoopLds& L, bool active,
-                                              const DevModel& M, const double* __restrict__ p, bool want_parts,
-                                              double& lnp_out, double& lnl_out)
-{
-    const double q1 = p[NS], feh_par = p[NS + 1], dist = p[NS + 2], AV = p[NS + 3];
-
-    // ---- model table: axes 0/1 are shared by all components of an isochrone system ----
-    const double x0 = (KIND == ISO_KIND_TRACK) ? p[2] : q1;        // feh | age
-    const double x1 = (KIND == ISO_KIND_TRACK) ? p[0] : feh_par;   // mass | feh
-    const bool ok01 = active && !(x0 != x0) && !(x1 != x1) && !lds_oob(lds, A.m0, x0) && !lds_oob(lds, A.m1, x1);
-    int i0 = 0, i1 = 0;
-    W3 w;
-    w.t0 = w.t1 = w.t2 = 0.0;
-    if (ok01) {
-        lds_bracket2(lds, A.m0, A.m1, x0, x1, i0, i1, w.t0, w.t1);
-    }
-    double star[NS][6];
-    double astero[2] = {0.0, 0.0};
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        const double eep = (KIND == ISO_KIND_TRACK) ? p[1] : p[s];
-        const bool ok = ok01 && !(eep != eep) && !eep_oob(A, eep);
-        int i2 = 0;
-        if (ok) eep_bracket(A, eep, i2, w.t2);
-        if (PACKED) {
-            const uint32_t cell = (uint32_t)((int64_t)i0 * A.s0 + (int64_t)i1 * A.s1 + i2);
-            coop_star(A, L, ok, cell, w, star[s]);
-            // asteroseismic pair of the primary (reference starmodel.py:1603-1612); a separate instantiation,
-            // because even a never-taken branch here costs the common kernel registers (measured: +29 %)
-            if (ASTERO && s == 0) coop_pair(A.astq, L, ok && M.has_numax, cell, w, astero);
-        } else if (ok) {
-            gather_star<false>(A, i0, i1, i2, w, star[s]);
-        } else {
-#pragma unroll
-            for (int q = 0; q < 6; ++q) star[s][q] = f_nan();
-        }
-    }
-
-    // ---- lnprior ----
-    const double ld = log(dist);
-    double lnp = 0.0;
-    bool rejected = false;
-    if (NS == 2) rejected = p[1] > p[0];
-    if (NS == 3) rejected = !(p[0] > p[1]) && (p[1] > p[2]);
-    if (KIND == ISO_KIND_TRACK) lnp += ln_pdf<false>(M.prior_mass, p[0], 0.0);
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        const double eep = (KIND == ISO_KIND_TRACK) ? p[1] : p[s];
-        lnp += eep_term(M, (KIND == ISO_KIND_TRACK) ? M.prior_age : M.prior_mass, eep, star[s][4], star[s][5]);
-    }
-    if (KIND == ISO_KIND_ISO) lnp += ln_pdf<false>(M.prior_age, q1, 0.0);
-    lnp += ln_pdf<false>(M.prior_feh, feh_par, 0.0);
-    lnp += ln_pdf<true>(M.prior_distance, dist, ld);
-    lnp += ln_pdf<false>(M.prior_AV, AV, 0.0);
-    if (rejected) lnp = -f_inf();
-    const bool prior_ok = active && isfinite(lnp);
-    const bool go = active && (prior_ok || want_parts);     // evaluate the likelihood for this lane
-    lnp_out = lnp;
-    lnl_out = f_nan();
-    if (!PACKED && !go) return -f_inf();            // lane-wise path: nothing cooperative follows
-
-    // ---- lnlike ----
-    double lnl = 0.0;
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-        const double val = M.spec_val[q];
-        if (val == val) {
-            const double r = val - star[0][q];
-            lnl += M.spec_g0[q] - r * r * M.spec_hinv[q];
-        }
-    }
-    const double dm = fma(ld, 5.0 * kInvLn10, -5.0);   // 5*log10(d/10)
-    if constexpr (NB > 0) {          // NB = 0: spectroscopy / parallax only, the BC table is never touched
-        double tot[NB];
-        const bool okA = go && !(AV != AV) && !lds_oob(lds, A.b3, AV);
-    #pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const double T = star[s][0], g = star[s][1], f = star[s][2];
-            const bool ok = okA && !(T != T) && !(g != g) && !(f != f) && !lds_oob(lds, A.b0, T) &&
-                            !lds_oob(lds, A.b1, g) && !lds_oob(lds, A.b2, f);
-            double bc[NB];
-            int j0 = 0, j1 = 0, j2 = 0, j3 = 0;
-            W4 w4v;
-            w4v.t0 = w4v.t1 = w4v.t2 = w4v.t3 = 0.0;
-            if (ok) {
-                lds_bracket4(lds, A.b0, A.b1, A.b2, A.b3, T, g, f, AV, j0, j1, j2, j3, w4v.t0, w4v.t1, w4v.t2, w4v.t3);
-            }
-            if (PACKED) {
-                const uint32_t cell = (uint32_t)((int64_t)j0 * A.bs0 + (int64_t)j1 * A.bs1 + (int64_t)j2 * A.bs2 + j3);
-                coop_bc<NB>(A, L, ok, cell, w4v, bc);
-            } else if (ok) {
-                gather_bc<NB, false>(A, j0, j1, j2, j3, w4v, bc);
-            } else {
-    #pragma unroll
-                for (int b = 0; b < NB; ++b) bc[b] = f_nan();
-            }
-    #pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                const double mag = star[s][3] + dm - bc[b];
-                if (NS == 1) tot[b] = mag;
-                else tot[b] = (s == 0 ? 0.0 : tot[b]) + exp10(-0.4 * mag);
-            }
-        }
-    #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const double mag = (NS == 1) ? tot[b] : -2.5 * log10(tot[b]);
-            const double r = M.mag_val[b] - mag;
-            lnl += M.mag_g0[b] - r * r * M.mag_hinv[b];
-        }
-    }
-    if (M.has_parallax) {
-        const double r = M.plx_val - 1000.0 / dist;
-        lnl += M.plx_g0 - r * r * M.plx_hinv;
-    }
-    if (ASTERO && M.has_numax) {
-        const double r = M.numax_val - astero[0];
-        lnl += M.numax_g0 - r * r * M.numax_hinv;
-        if (M.has_dnu) {
-            const double r2 = M.dnu_val - astero[1];
-            lnl += M.dnu_g0 - r2 * r2 * M.dnu_hinv;
-        }
-    }
-    lnl_out = go ? lnl : f_nan();
-    return prior_ok ? lnp + lnl : -f_inf();
-}
-
-// LDS layout of the fast kernels: [axes blob, rounded to an even count][request slots][response slots]
-template <int NB>
-__device__ __forceinline__ CoopLds coop_lds(double* lds, int axes_len)
-{
-    constexpr int REQ_STRIDE = slot_stride(NB);
-    const int base = (axes_len + 1) & ~1;
-    const int wave = threadIdx.x >> 6;
-    CoopLds L;
-    L.req = lds + base + wave * 64 * REQ_STRIDE;
-    L.rsp = L.req;
-    L.stride = REQ_STRIDE;
-    L.lane = threadIdx.x & 63;
-    return L;
-}
-
-// waves per SIMD the register allocator must leave room for: 6 for the small single-star kernels
-// (88 -> 80 VGPR, a few dwords of scratch; measured +2 %), otherwise whatever the kernel needs
-constexpr int fast_min_waves(int ns, int nb) { return (ns == 1 && nb <= 2) ? 6 : 4; }
-
-template <int KIND, int NS, int NB, bool PACKED, bool MULTI, bool ASTERO = false>
-__global__ __launch_bounds__(BLOCK, fast_min_waves(NS, NB)) void k_lnpost_fast(const FastArgs A)
-{
-    extern __shared__ double lds[];
-    for (int j = threadIdx.x; j < A.axes_len; j += BLOCK) lds[j] = A.axes_blob[j];
-    __syncthreads();
-    const CoopLds L = coop_lds<NB>(lds, A.axes_len);
-    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    const bool active = i < A.n;
-    const int64_t ii = active ? i : (A.n - 1);         // inactive lanes shadow the last sample
-    const DevModel& M = A.m[MULTI ? A.star_id[ii] : 0];
-    constexpr int NP = NS + 4;
-    double p[NP];
-    {
-        const double* __restrict__ src = A.pars + ii * A.stride_n;
-#pragma unroll
-        for (int j = 0; j < NP; ++j) p[j] = src[j * A.stride_p];
-    }
-    double lnp, lnl;
-    const double r = lnpost_wave<KIND, NS, NB, PACKED, ASTERO>(A, lds, L, active, M, p, A.lnlike != nullptr, lnp, lnl);
-    if (active) {
-        if (A.lnpost) A.lnpost[i] = r;
-        if (A.lnprior) A.lnprior[i] = lnp;
-        if (A.lnlike) A.lnlike[i] = lnl;
-    }
-}
-
-// -------------------------------------------------------------------------------------------
-// Fused stretch-move half-step ("next" row f3: device-resident ensemble sampler).
-// One lane = one walker of the active half of one star's ensemble: draw a partner from the
-// complementary half (Philox4x32-10 counter RNG, keyed by seed, counter = (step, half, row)),
-// propose y = x_j + z (x_k - x_j), evaluate lnpost(y) with the same device function as the batch
-// kernel, accept / reject in place.  The active half only *reads* the other half, so a half-step
-// is race-free; two launches make one emcee-style iteration (Goodman & Weare 2010; the reference
-// drives emcee.EnsembleSampler with one Python lnpost call per walker, starmodel.py:951-969).
-// -------------------------------------------------------------------------------------------
-__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
-                                              uint32_t k1, uint32_t* out)
-{
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
-        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
-    }
-    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-}
-
-// One stretch move of walker k of the active half of one star's ensemble.  `pos` / `lnp` / `acc_cnt` are
-// that star's [W][NP] / [W] / [W] arrays (global memory in the step-wise kernel, LDS in the persistent
-// one), `chain_pos` / `chain_lnp` its slab of the stored chain for this step (or null).  The Philox
-// counter is (step, half, global row): both kernels draw identical numbers for a given move.
-template <int KIND, int NS, int NB>
-__device__ __forceinline__ void stretch_move(const FastArgs& A, const StretchArgs& S, double* lds, const CoopLds& L,
-                                             bool active, int64_t star, int k, int half, uint32_t step,
-                                             double* __restrict__ pos, double* __restrict__ lnp, int32_t* acc_cnt,
-                                             double* __restrict__ chain_pos, double* __restrict__ chain_lnp)
-{
-    constexpr int NP = NS + 4;
-    const int h = S.W >> 1;
-    const int lr = (half ? h : 0) + k;                  // row within the star's ensemble
-    const int64_t row = star * S.W + lr;
-    uint32_t rnd[4];
-    philox4x32_10((uint32_t)(2u * step + (uint32_t)half), (uint32_t)row, (uint32_t)((uint64_t)row >> 32), 0x51u,
-                  (uint32_t)S.seed, (uint32_t)(S.seed >> 32), rnd);
-    const int j = (int)(((uint64_t)rnd[0] * (uint64_t)h) >> 32);          // uniform in [0, h)
-    const int lp = (half ? 0 : h) + j;
-    const double u1 = ((double)rnd[1] + (double)(rnd[2] & 0xFFFFu) * (1.0 / 65536.0)) * (1.0 / 4294967296.0);
-    const double u2 = ((double)rnd[3] + (double)(rnd[2] >> 16) * (1.0 / 65536.0) + 0.5 / 65536.0) * (1.0 / 4294967296.0);
-    const double zr = (S.a - 1.0) * u1 + 1.0;
-    const double z = zr * zr / S.a;
-    // helper lanes (no walker of their own) only read the complementary half, which nobody writes in this
-    // half-step: they evaluate the partner's position and discard the result
-    const int lsrc = active ? lr : lp;
-    double xk[NP], y[NP];
-#pragma unroll
-    for (int q = 0; q < NP; ++q) {
-        xk[q] = pos[lsrc * NP + q];
-        const double xj = pos[lp * NP + q];
-        y[q] = xj + z * (xk[q] - xj);
-    }
-    const double lold = lnp[lsrc];
-    const DevModel& M = A.m[S.multi ? star : 0];
-    double lnp_unused, lnl_unused;
-    const double lnew = lnpost_wave<KIND, NS, NB, true>(A, lds, L, active, M, y, false, lnp_unused, lnl_unused);
-    const double lnq = (NP - 1) * log(z) + lnew - lold;
-    const bool acc = active && isfinite(lnew) && (log(u2) < lnq);
-    if (acc) {
-#pragma unroll
-        for (int q = 0; q < NP; ++q) pos[lr * NP + q] = y[q];
-        lnp[lr] = lnew;
-        if (acc_cnt) acc_cnt[lr] += 1;
-    }
-    // chain recording: every move stores the row it owns (its value for this step)
-    if (active && chain_pos) {
-#pragma unroll
-        for (int q = 0; q < NP; ++q) chain_pos[lr * NP + q] = acc ? y[q] : xk[q];
-    }
-    if (active && chain_lnp) chain_lnp[lr] = acc ? lnew : lold;
-}
-
-// step-wise form: one launch = one half-step of every ensemble (grid over stars x W/2 walkers);
-// the throughput form for catalogs large enough to fill the chip
-template <int KIND, int NS, int NB>
-__global__ __launch_bounds__(BLOCK) void k_stretch_half(const FastArgs A, const StretchArgs S)
-{
-    extern __shared__ double lds[];
-    for (int j = threadIdx.x; j < A.axes_len; j += BLOCK) lds[j] = A.axes_blob[j];
-    __syncthreads();
-    const CoopLds L = coop_lds<NB>(lds, A.axes_len);
-    const int64_t t0 = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    const bool active = t0 < S.n_active;
-    const int64_t t = active ? t0 : (S.n_active - 1);
-    constexpr int NP = NS + 4;
-    const int h = S.W >> 1;
-    const int64_t star = t / h;
-    const int k = (int)(t - star * h);
-    const int64_t r0 = star * S.W;
-    stretch_move<KIND, NS, NB>(A, S, lds, L, active, star, k, S.half, S.step, S.pos + r0 * NP, S.lnp + r0,
-                               S.accepted ? S.accepted + r0 : nullptr, S.chain_pos ? S.chain_pos + r0 * NP : nullptr,
-                               S.chain_lnp ? S.chain_lnp + r0 : nullptr);
-}
-
-// persistent form: ALL S.nsteps iterations in a single launch.  A workgroup owns G = max(1, BLOCK / (W/2))
-// whole ensembles (one lane per walker of the active half, so a 32-walker catalog packs 16 stars into a
-// workgroup; a large ensemble is walked in chunks of BLOCK).  Positions, lnpost values and acceptance
-// counters live in LDS; the two half-steps of an iteration are separated by workgroup barriers instead
-// of kernel boundaries, so an iteration costs two dependent evaluation chains instead of two launches.
-// Same moves, same random numbers, bit-identical chains as the step-wise form.
-// LDS: [axes][request/response slots][pos R*NP][lnp R][acc R (int32)],  R = G * W rows
-__host__ __device__ constexpr int persist_group(int W) { return (W >> 1) >= BLOCK ? 1 : BLOCK / (W >> 1); }
-__host__ __device__ constexpr int persist_extra_doubles(int W, int np)
-{
-    return persist_group(W) * W * (np + 1) + (persist_group(W) * W + 1) / 2;
-}
-
-template <int KIND, int NS, int NB>
-__global__ __launch_bounds__(BLOCK) void k_stretch_persist(const FastArgs A, const StretchArgs S)
-{
-    extern __shared__ double lds[];
-    for (int j = threadIdx.x; j < A.axes_len; j += BLOCK) lds[j] = A.axes_blob[j];
-    const CoopLds L = coop_lds<NB>(lds, A.axes_len);
-    constexpr int NP = NS + 4;
-    const int W = S.W, h = W >> 1;
-    const int G = persist_group(W);
-    const int per = h < BLOCK ? h : BLOCK;               // lanes one ensemble occupies per chunk
-    const int64_t n_ens = S.n_active / h;
-    const int64_t star0 = (int64_t)blockIdx.x * G;
-    const int here = (int)((n_ens - star0) < G ? (n_ens - star0) : G);   // ensembles this workgroup owns
-    const int R = here * W;
-    const int64_t r0 = star0 * W;
-    double* lpos = lds + ((A.axes_len + 1) & ~1) + coop_lds_doubles(NB);
-    double* llnp = lpos + G * W * NP;
-    int32_t* lacc = reinterpret_cast<int32_t*>(llnp + G * W);
-    for (int j = threadIdx.x; j < R * NP; j += BLOCK) lpos[j] = S.pos[r0 * NP + j];
-    for (int j = threadIdx.x; j < R; j += BLOCK) {
-        llnp[j] = S.lnp[r0 + j];
-        lacc[j] = 0;
-    }
-    __syncthreads();
-    const int64_t rows_total = n_ens * W;
-    const int g = (int)threadIdx.x / per, kk = (int)threadIdx.x - g * per;
-    const bool mine = g < here;
-    const int gs = mine ? g : 0;                          // idle lanes shadow a move of the first ensemble
-    for (int it = 0; it < S.nsteps; ++it) {
-        double* cp = S.chain_pos ? S.chain_pos + ((int64_t)it * rows_total + r0 + gs * W) * NP : nullptr;
-        double* cl = S.chain_lnp ? S.chain_lnp + (int64_t)it * rows_total + r0 + gs * W : nullptr;
-        for (int half = 0; half < 2; ++half) {
-            for (int k0 = 0; k0 < h; k0 += per) {
-                const int k = k0 + kk;
-                const bool active = mine && k < h;
-                if (__any(active))                        // wave-uniform: idle waves go straight to the barrier
-                    stretch_move<KIND, NS, NB>(A, S, lds, L, active, star0 + gs, active ? k : h - 1, half,
-                                               S.step + (uint32_t)it, lpos + gs * W * NP, llnp + gs * W,
-                                               lacc + gs * W, cp, cl);
-            }
-            __syncthreads();
-        }
-    }
-    for (int j = threadIdx.x; j < R * NP; j += BLOCK) S.pos[r0 * NP + j] = lpos[j];
-    for (int j = threadIdx.x; j < R; j += BLOCK) {
-        S.lnp[r0 + j] = llnp[j];
-        if (S.accepted) S.accepted[r0 + j] += lacc[j];
-    }
-}
-
-// dynamic LDS of the persistent form; the host uses it to decide whether an ensemble fits
-inline size_t stretch_persist_lds_bytes(int axes_len, int nb, int W, int np)
-{
-    return (size_t)(((axes_len + 1) & ~1) + coop_lds_doubles(nb) + persist_extra_doubles(W, np)) * sizeof(double);
-}
-
-template <int KIND, int NS>
-inline bool launch_stretch_nb(int nb, const FastArgs& A, const StretchArgs& S, hipStream_t s)
-{
-    const dim3 b(BLOCK);
-    if (S.nsteps > 0) {                                       // persistent: workgroups own whole ensembles
-        const int64_t n_ens = S.n_active / (S.W >> 1);
-        const int G = persist_group(S.W);
-        const dim3 gp((unsigned)((n_ens + G - 1) / G));
-        auto shp = [&](int n) { return stretch_persist_lds_bytes(A.axes_len, n, S.W, NS + 4); };
-        switch (nb) {
-        // with S.occupancy_query set: report resident workgroups per CU of this instantiation, launch nothing
-#define ISO_PERSIST_CASE(N)                                                                               \
-        case N:                                                                                           \
-            if (S.occupancy_query)                                                                        \
-                return hipOccupancyMaxActiveBlocksPerMultiprocessor(S.occupancy_query,                    \
-                                                                    k_stretch_persist<KIND, NS, N>, BLOCK, \
-                                                                    shp(N)) == hipSuccess;                \
-            hipLaunchKernelGGL((k_stretch_persist<KIND, NS, N>), gp, b, shp(N), s, A, S);                 \
-            return true;
-            ISO_PERSIST_CASE(0) ISO_PERSIST_CASE(1) ISO_PERSIST_CASE(2) ISO_PERSIST_CASE(3) ISO_PERSIST_CASE(4) ISO_PERSIST_CASE(5)
-            ISO_PERSIST_CASE(6) ISO_PERSIST_CASE(7) ISO_PERSIST_CASE(8) ISO_PERSIST_CASE(9) ISO_PERSIST_CASE(10)
-            ISO_PERSIST_CASE(11) ISO_PERSIST_CASE(12)
-#undef ISO_PERSIST_CASE
-        default: return false;
-        }
-    }
-    const dim3 g((unsigned)((S.n_active + BLOCK - 1) / BLOCK));
-    auto sh = [&](int n) { return (size_t)(((A.axes_len + 1) & ~1) + coop_lds_doubles(n)) * sizeof(double); };
-    switch (nb) {
-    case 0: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 0>), g, b, sh(0), s, A, S); return true;
-    case 1: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 1>), g, b, sh(1), s, A, S); return true;
-    case 2: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 2>), g, b, sh(2), s, A, S); return true;
-    case 3: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 3>), g, b, sh(3), s, A, S); return true;
-    case 4: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 4>), g, b, sh(4), s, A, S); return true;
-    case 5: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 5>), g, b, sh(5), s, A, S); return true;
-    case 6: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 6>), g, b, sh(6), s, A, S); return true;
-    case 7: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 7>), g, b, sh(7), s, A, S); return true;
-    case 8: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 8>), g, b, sh(8), s, A, S); return true;
-    case 9: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 9>), g, b, sh(9), s, A, S); return true;
-    case 10: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 10>), g, b, sh(10), s, A, S); return true;
-    case 11: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 11>), g, b, sh(11), s, A, S); return true;
-    case 12: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 12>), g, b, sh(12), s, A, S); return true;
-    default: return false;
-    }
-}
-
-template <int KIND, int NS, bool PACKED, bool MULTI, bool ASTERO = false>
-inline bool launch_nb(int nb, const FastArgs& A, hipStream_t s)
-{
-    const dim3 g((unsigned)((A.n + BLOCK - 1) / BLOCK)), b(BLOCK);
-    auto sh = [&](int n) { return (size_t)(((A.axes_len + 1) & ~1) + (PACKED ? coop_lds_doubles(n) : 0)) * sizeof(double); };
-    switch (nb) {
-    case 0: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 0, PACKED, MULTI, ASTERO>), g, b, sh(0), s, A); return true;
-    case 1: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 1, PACKED, MULTI, ASTERO>), g, b, sh(1), s, A); return true;
-    case 2: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 2, PACKED, MULTI, ASTERO>), g, b, sh(2), s, A); return true;
-    case 3: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 3, PACKED, MULTI, ASTERO>), g, b, sh(3), s, A); return true;
-    case 4: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 4, PACKED, MULTI, ASTERO>), g, b, sh(4), s, A); return true;
-    case 5: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 5, PACKED, MULTI, ASTERO>), g, b, sh(5), s, A); return true;
-    case 6: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 6, PACKED, MULTI, ASTERO>), g, b, sh(6), s, A); return true;
-    case 7: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 7, PACKED, MULTI, ASTERO>), g, b, sh(7), s, A); return true;
-    case 8: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 8, PACKED, MULTI, ASTERO>), g, b, sh(8), s, A); return true;
-    case 9: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 9, PACKED, MULTI, ASTERO>), g, b, sh(9), s, A); return true;
-    case 10: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 10, PACKED, MULTI, ASTERO>), g, b, sh(10), s, A); return true;
-    case 11: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 11, PACKED, MULTI, ASTERO>), g, b, sh(11), s, A); return true;
-    case 12: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 12, PACKED, MULTI, ASTERO>), g, b, sh(12), s, A); return true;
-    default: return false;
-    }
-}
+#include "fast/brackets.h"
+#include "fast/gather_lane.h"
+#include "fast/priors_log.h"
+#include "fast/coop_gather.h"
+#include "fast/lnpost_wave.h"
+#include "fast/sampler.h"
+#include "fast/launch.h"
 
 }  // namespace fastk
 
