@@ -510,3 +510,31 @@ def test_sample_from_prior_reference_semantics():
     assert isinstance(arr, np.ndarray) and arr.shape == (7, 5)
     assert len(mod.sample_from_prior(0)) == 0
     assert mod.emcee_p0(16, rng=np.random.default_rng(3)).shape == (16, 5)
+
+
+@pytest.mark.parametrize("N", [2, 3])
+def test_fit_catalog_multiple_star_models(N):
+    """Catalog fits with binary / triple models (reference: StarCatalog.iter_models(ic, N=2|3)): the MULTI kernels
+    for NS = 2, 3 under the batched sampler recover the distance of synthetic unresolved binaries."""
+    import pandas as pd
+    ages = ia.grids.mist_log_ages()[60::2]
+    ic = ia.synthetic_isochrone(bands=("J", "H", "K"), ages=ages, fehs=[-1.0, -0.5, 0.0, 0.5], eeps=np.arange(150.0, 700.0),
+                                eep_bounds=(150, 699), limits=dict(age=(ages[0], ages[-1]), feh=(-1.0, 0.5)))
+    rng = np.random.default_rng(3)
+    rows = []
+    for i in range(16):
+        e0 = rng.uniform(300, 450); e1 = rng.uniform(250, e0); age = rng.uniform(9.2, 9.9); feh = rng.uniform(-0.5, 0.3)
+        d = rng.uniform(100, 600)
+        m0 = ic.interp_mag([e0, age, feh, d, 0.1], ["J", "H", "K"])[3]
+        m1 = ic.interp_mag([e1, age, feh, d, 0.1], ["J", "H", "K"])[3]
+        mags = -2.5 * np.log10(10 ** (-0.4 * m0) + 10 ** (-0.4 * m1))
+        rows.append({"J_mag": mags[0], "J_mag_unc": 0.02, "H_mag": mags[1], "H_mag_unc": 0.02, "K_mag": mags[2],
+                     "K_mag_unc": 0.02, "parallax": 1000 / d, "parallax_unc": 0.05, "true_d": d})
+    df = pd.DataFrame(rows)
+    cat = ia.StarCatalog(df.drop(columns=["true_d"]), props=["parallax"])
+    res = fit_catalog(cat, ic, N=N, nwalkers=32, nburn=150, niter=60, seed=1)
+    assert list(res.columns[:3]) == ["eep_0_median", "eep_0_p16", "eep_0_p84"] and res.shape == (16, 3 * (N + 4) + 3)
+    assert res["ok"].mean() == 1.0
+    assert np.all(res["eep_0_median"] >= res["eep_%d_median" % (N - 1)])
+    rel = np.abs(res["distance_median"].values - df["true_d"].values) / df["true_d"].values
+    assert np.median(rel) < 0.02
