@@ -136,7 +136,14 @@ class CatalogPosterior:
         idx = np.arange(len(catalog)) if indices is None else np.asarray(indices, dtype=int)
         if idx.size == 0:
             raise ValueError("no stars")
-        template = catalog.model(int(idx[0]), ic, N=N, **model_kwargs)
+        # template = the first star that has every band (stars lacking some get NaN entries below)
+        sub = catalog.df.iloc[idx]
+        complete = np.ones(idx.size, dtype=bool)
+        for b in catalog.bands:
+            complete &= sub["{}_mag".format(b)].notna().to_numpy() & sub["{}_mag_unc".format(b)].notna().to_numpy()
+        if not complete.any():
+            raise ValueError("no star of the batch has all of the catalog's bands")
+        template = catalog.model(int(idx[int(np.argmax(complete))]), ic, N=N, **model_kwargs)
         d0 = template.model_desc()
         dt = np.dtype(_cabi.IsoModelDesc)
         arr = np.empty(idx.size, dtype=dt)
@@ -148,10 +155,11 @@ class CatalogPosterior:
         for j, b in enumerate(bands):
             v = df["{}_mag".format(b)].to_numpy(float)
             u = df["{}_mag_unc".format(b)].to_numpy(float)
-            if np.isnan(v).any() or np.isnan(u).any():
-                raise ValueError("band %s has missing values; a batched catalog needs every band for every star" % b)
-            arr["mag_val"][:, j] = v
-            arr["mag_unc"][:, j] = u
+            # a star without a measurement in this band: NaN value = "skip this term" for the catalog kernels
+            # (the reference drops NaN measurements when it builds that star's model, starmodel.py:1427-1433)
+            missing = np.isnan(v) | np.isnan(u)
+            arr["mag_val"][:, j] = np.where(missing, np.nan, v)
+            arr["mag_unc"][:, j] = np.where(missing, 1.0, u)
         for q, name in enumerate(("Teff", "logg", "feh")):
             if name in catalog.props:
                 v = df[name].to_numpy(float)

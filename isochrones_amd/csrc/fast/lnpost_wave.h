@@ -5,7 +5,10 @@
 // lnpost of the lane's sample (p = its NS+4 parameters).  Shared by the batch kernel and the
 // sampler kernel.  With PACKED every gather is wave-cooperative, so ALL 64 lanes of the wave must
 // call this function together; `active` = the lane really has a sample (inactive lanes only help).
-template <int KIND, int NS, int NB, bool PACKED, bool ASTERO = false>
+// MASKED (catalog rows and the sampler kernels): a band whose observed magnitude is NaN is a band this star
+// was not observed in - its term is skipped, as the reference drops NaN measurements when it builds a model
+// (starmodel.py:1427-1433).
+template <int KIND, int NS, int NB, bool PACKED, bool ASTERO = false, bool MASKED = false>
 __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* lds, const CoopLds& L, bool active,
                                               const DevModel& M, const double* __restrict__ p, bool want_parts,
                                               double& lnp_out, double& lnl_out)
@@ -113,7 +116,7 @@ __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* l
         for (int b = 0; b < NB; ++b) {
             const double mag = (NS == 1) ? tot[b] : -2.5 * log10(tot[b]);
             const double r = M.mag_val[b] - mag;
-            lnl += M.mag_g0[b] - r * r * M.mag_hinv[b];
+            if (!MASKED || M.mag_val[b] == M.mag_val[b]) lnl += M.mag_g0[b] - r * r * M.mag_hinv[b];
         }
     }
     if (M.has_parallax) {
@@ -170,7 +173,7 @@ __global__ __launch_bounds__(BLOCK, fast_min_waves(NS, NB)) void k_lnpost_fast(c
         for (int j = 0; j < NP; ++j) p[j] = src[j * A.stride_p];
     }
     double lnp, lnl;
-    const double r = lnpost_wave<KIND, NS, NB, PACKED, ASTERO>(A, lds, L, active, M, p, A.lnlike != nullptr, lnp, lnl);
+    const double r = lnpost_wave<KIND, NS, NB, PACKED, ASTERO, MULTI>(A, lds, L, active, M, p, A.lnlike != nullptr, lnp, lnl);
     if (active) {
         if (A.lnpost) A.lnpost[i] = r;
         if (A.lnprior) A.lnprior[i] = lnp;

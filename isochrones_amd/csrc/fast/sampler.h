@@ -62,7 +62,7 @@ __device__ __forceinline__ void stretch_move(const FastArgs& A, const StretchArg
     const double lold = lnp[lsrc];
     const DevModel& M = A.m[S.multi ? star : 0];
     double lnp_unused, lnl_unused;
-    const double lnew = lnpost_wave<KIND, NS, NB, true>(A, lds, L, active, M, y, false, lnp_unused, lnl_unused);
+    const double lnew = lnpost_wave<KIND, NS, NB, true, false, true>(A, lds, L, active, M, y, false, lnp_unused, lnl_unused);
     const double lnq = (NP - 1) * log(z) + lnew - lold;
     const bool acc = active && isfinite(lnew) && (log(u2) < lnq);
     if (acc) {

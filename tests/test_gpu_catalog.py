@@ -538,3 +538,30 @@ def test_fit_catalog_multiple_star_models(N):
     assert np.all(res["eep_0_median"] >= res["eep_%d_median" % (N - 1)])
     rel = np.abs(res["distance_median"].values - df["true_d"].values) / df["true_d"].values
     assert np.median(rel) < 0.02
+
+
+def test_catalog_rows_with_missing_bands():
+    """A star without a measurement in some band: the catalog kernels skip that term (NaN observed magnitude),
+    which is the posterior of the per-star model the reference would build without that band."""
+    import torch
+    ic = _small_track(("G", "BP", "RP"))
+    cat, truth = synthetic_catalog(ic, 12, bands=["G", "BP", "RP"], seed=8, mag_unc=0.01)
+    df = cat.df.copy()
+    df.loc[df.index[0], "BP_mag"] = np.nan                     # also the first row: the template must skip it
+    df.loc[df.index[4], "RP_mag_unc"] = np.nan
+    df.loc[df.index[7], ["G_mag", "BP_mag"]] = np.nan
+    cat2 = ia.StarCatalog(df, bands=["G", "BP", "RP"], props=list(cat.props))
+    post = CatalogPosterior.from_catalog(cat2, ic, N=1)
+    rng = np.random.default_rng(2)
+    n = 4000
+    lo = np.array([ic.model_grid.masses[0], 150, -1.0, 20.0, 0.0]); hi = np.array([ic.model_grid.masses[-1], 699, 0.5, 1500.0, 1.0])
+    x = torch.as_tensor(rng.uniform(lo, hi, size=(n, 5)), device="cuda")
+    models = list(cat2.iter_models(ic))
+    assert models[0].bands == ["G", "RP"] and models[4].bands == ["G", "BP"] and models[7].bands == ["RP"]
+    for s in (0, 4, 7, 2):
+        sid = torch.full((n,), s, dtype=torch.int32, device="cuda")
+        got = post.lnpost(x, sid).cpu().numpy()
+        want = models[s].lnpost(x).cpu().numpy()
+        fx.assert_close(got, want, 1e-11, atol=1e-11, what="star %d" % s)
+    res = fit_catalog(cat2, ic, nwalkers=32, nburn=100, niter=50, seed=1)
+    assert res["ok"].mean() == 1.0
