@@ -332,7 +332,7 @@ def result_columns(param_names):
 
 
 def fit_stars_gpu(catalog: StarCatalog, ic, indices, N=1, nwalkers=32, nburn=150, niter=100, seed=0,
-                  model_kwargs=None, fused=True, timings=None):
+                  model_kwargs=None, fused=True, timings=None, max_stars_per_batch=200_000):
     """Fit the stars ``indices`` of the catalog on the current GPU; returns [len(indices), 3*D+3]
     float64 numpy rows (result_columns order)."""
     import torch
@@ -347,6 +347,13 @@ def fit_stars_gpu(catalog: StarCatalog, ic, indices, N=1, nwalkers=32, nburn=150
 
     if len(indices) == 0:
         return np.empty((0, 3 * (N + 4) + 3))
+    if len(indices) > max_stars_per_batch:
+        # bound the device memory of the stored chains (S x W x niter x D doubles): fit the shard in slices
+        parts = [fit_stars_gpu(catalog, ic, indices[k:k + max_stars_per_batch], N=N, nwalkers=nwalkers, nburn=nburn,
+                               niter=niter, seed=seed + 7919 * (k // max_stars_per_batch), model_kwargs=model_kwargs,
+                               fused=fused, timings=timings, max_stars_per_batch=max_stars_per_batch)
+                 for k in range(0, len(indices), max_stars_per_batch)]
+        return np.concatenate(parts, axis=0)
     post = CatalogPosterior.from_catalog(catalog, ic, N=N, indices=indices, **(model_kwargs or {}))
     _mark("build_posteriors")
     D = post.n_params

@@ -565,3 +565,6 @@ def test_catalog_rows_with_missing_bands():
         fx.assert_close(got, want, 1e-11, atol=1e-11, what="star %d" % s)
     res = fit_catalog(cat2, ic, nwalkers=32, nburn=100, niter=50, seed=1)
     assert res["ok"].mean() == 1.0
+    sliced = fit_catalog(cat2, ic, nwalkers=32, nburn=100, niter=50, seed=1, max_stars_per_batch=5)   # 5 + 5 + 2 stars
+    assert sliced.shape == res.shape and sliced["ok"].mean() == 1.0
+    assert np.allclose(sliced["distance_median"], res["distance_median"], rtol=0.2)
