@@ -226,6 +226,15 @@ int  iso_interp_eep(iso_eep_table* t, const double* x, const double* x0, const d
  * them over processes).  iso_catalog_lnpost evaluates a batch of rows where row i belongs to
  * star star_id[i] (DEVICE int32 array): S stars x W walkers in one launch.  Needs 1-12 bands. */
 int  iso_catalog_create(iso_ic* ic, const iso_model_desc* descs, int64_t n_models, iso_catalog** out);
+/* The same catalog from one template descriptor (priors, bands, flags, bounds: identical for every star) plus
+ * plain HOST columns of what differs per star: magnitudes [n][n_bands] (NaN value = band not observed),
+ * spectroscopic values [n][3] (NaN = absent), parallaxes (has_plx[n] 0/1) and the upper distance bound [n]
+ * (NULL = the template's).  The per-star constant blocks are filled by a kernel on the device, so the
+ * host moves ~20 doubles per star instead of building n descriptors. */
+int  iso_catalog_create_columns(iso_ic* ic, const iso_model_desc* tmpl, int64_t n_models, const double* mag_val,
+                                const double* mag_unc, const double* spec_val, const double* spec_unc,
+                                const int32_t* has_plx, const double* plx_val, const double* plx_unc,
+                                const double* dist_hi, iso_catalog** out);
 void iso_catalog_destroy(iso_catalog* c);
 int  iso_catalog_lnpost(iso_catalog* c, const int32_t* star_id, const double* pars, int64_t stride_n,
                         int64_t stride_p, int64_t n, double* lnpost_out, void* stream);

@@ -97,7 +97,7 @@ EXPORTED_SYMBOLS = (
     "iso_ic_create", "iso_ic_destroy", "iso_interp_mag",
     "iso_model_create", "iso_model_destroy", "iso_model_n_params",
     "iso_lnpost", "iso_lnpost_host", "iso_unit_cube", "iso_time_lnpost",
-    "iso_catalog_create", "iso_catalog_destroy", "iso_catalog_lnpost",
+    "iso_catalog_create", "iso_catalog_create_columns", "iso_catalog_destroy", "iso_catalog_lnpost",
     "iso_eep_table_create", "iso_eep_table_destroy", "iso_interp_eep",
     "iso_sampler_create_model", "iso_sampler_create_catalog", "iso_sampler_destroy", "iso_sampler_run",
     "iso_chain_quantiles",
@@ -163,6 +163,9 @@ def lib():
     L.iso_unit_cube.argtypes = [vp, pd, i64, i64, i64, vp]
     L.iso_time_lnpost.argtypes = [vp, pd, i64, i64, i64, pd, C.c_int, vp, C.POINTER(dbl)]
     L.iso_catalog_create.argtypes = [vp, C.POINTER(IsoModelDesc), i64, C.POINTER(vp)]
+    hd = C.POINTER(dbl)
+    L.iso_catalog_create_columns.argtypes = [vp, C.POINTER(IsoModelDesc), i64, hd, hd, hd, hd, C.POINTER(C.c_int32), hd, hd,
+                                             hd, C.POINTER(vp)]
     L.iso_catalog_destroy.argtypes = [vp]
     L.iso_catalog_destroy.restype = None
     L.iso_catalog_lnpost.argtypes = [vp, pd, pd, i64, i64, i64, pd, vp]

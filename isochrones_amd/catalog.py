@@ -92,40 +92,126 @@ class CatalogPosterior:
     Build it from a list of models, or — without creating one Python object per star — from a
     :class:`StarCatalog` with :meth:`from_catalog` (descriptor records filled column-wise)."""
 
-    def __init__(self, ic, models=None, device=None, _descs=None, _template=None):
+    def __init__(self, ic, models=None, device=None, _descs=None, _template=None, _columns=None):
         self.ic = ic
         self.device = dev.current_device() if device is None else device
-        if _descs is None:
-            if not models:
-                raise ValueError("no models")
-            self.models = list(models)
-            template = self.models[0]
-            descs = (_cabi.IsoModelDesc * len(self.models))(*[m.model_desc() for m in self.models])
-            arr = np.frombuffer(descs, dtype=np.dtype(_cabi.IsoModelDesc))
-        else:
+        h = C.c_void_p()
+        if _columns is not None:
+            # template descriptor + plain per-star columns; the device fills the per-star constant blocks
             self.models = None
             template = _template
-            arr = _descs
-            descs = (_cabi.IsoModelDesc * arr.shape[0]).from_buffer(arr)
+            col = _columns
+            n = int(col["mag_val"].shape[0])
+            D = template.n_params
+            d0 = template.model_desc()
+            self.bounds_lo = np.tile(np.array([d0.bound_lo[j] for j in range(D)]), (n, 1))
+            self.bounds_hi = np.tile(np.array([d0.bound_hi[j] for j in range(D)]), (n, 1))
+            if col["dist_hi"] is not None:
+                self.bounds_hi[:, list(template.param_names).index("distance")] = col["dist_hi"]
+            has = col["has_plx"] != 0
+            self.parallax = np.where(has, col["plx_val"], np.nan)
+            self.parallax_unc = np.where(has, col["plx_unc"], np.nan)
+            self._desc_array = None
+            dp = C.POINTER(C.c_double)
+            ptr = lambda a: a.ctypes.data_as(dp)
+            _cabi.check(_cabi.lib().iso_catalog_create_columns(
+                ic.handle(self.device), C.byref(d0), n, ptr(col["mag_val"]), ptr(col["mag_unc"]), ptr(col["spec_val"]),
+                ptr(col["spec_unc"]), col["has_plx"].ctypes.data_as(C.POINTER(C.c_int32)), ptr(col["plx_val"]),
+                ptr(col["plx_unc"]), ptr(col["dist_hi"]) if col["dist_hi"] is not None else None, C.byref(h)))
+            self.n_models = n
+        else:
+            if _descs is None:
+                if not models:
+                    raise ValueError("no models")
+                self.models = list(models)
+                template = self.models[0]
+                descs = (_cabi.IsoModelDesc * len(self.models))(*[m.model_desc() for m in self.models])
+                arr = np.frombuffer(descs, dtype=np.dtype(_cabi.IsoModelDesc))
+            else:
+                self.models = None
+                template = _template
+                arr = _descs
+                descs = (_cabi.IsoModelDesc * arr.shape[0]).from_buffer(arr)
+            self.n_models = int(arr.shape[0])
+            D = template.n_params
+            self.bounds_lo = np.array(arr["bound_lo"][:, :D])
+            self.bounds_hi = np.array(arr["bound_hi"][:, :D])
+            has = arr["has_parallax"] != 0
+            self.parallax = np.where(has, arr["plx_val"], np.nan)
+            self.parallax_unc = np.where(has, arr["plx_unc"], np.nan)
+            self._desc_array = arr
+            _cabi.check(_cabi.lib().iso_catalog_create(ic.handle(self.device), descs, self.n_models, C.byref(h)))
         self.template = template
-        self.n_models = int(arr.shape[0])
         self.n_params = template.n_params
         self.param_names = template.param_names
-        D = self.n_params
-        self.bounds_lo = np.array(arr["bound_lo"][:, :D])
-        self.bounds_hi = np.array(arr["bound_hi"][:, :D])
-        has = arr["has_parallax"] != 0
-        self.parallax = np.where(has, arr["plx_val"], np.nan)
-        self.parallax_unc = np.where(has, arr["plx_unc"], np.nan)
-        self._desc_array = arr
-        h = C.c_void_p()
-        _cabi.check(_cabi.lib().iso_catalog_create(ic.handle(self.device), descs, self.n_models, C.byref(h)))
         self._h = h
 
     @classmethod
     def from_catalog(cls, catalog, ic, N=1, indices=None, device=None, **model_kwargs):
-        arr, template = cls.build_descs(catalog, ic, N=N, indices=indices, **model_kwargs)
-        return cls(ic, device=device, _descs=arr, _template=template)
+        """One template model + per-star columns straight from the DataFrame (no per-star Python objects and no
+        per-star descriptors on the host: ``iso_catalog_create_columns`` builds the constant blocks on the device)."""
+        cols, template = cls.build_columns(catalog, ic, N=N, indices=indices, **model_kwargs)
+        return cls(ic, device=device, _columns=cols, _template=template)
+
+    @staticmethod
+    def _template_and_rows(catalog, ic, N, indices, model_kwargs):
+        idx = np.arange(len(catalog)) if indices is None else np.asarray(indices, dtype=int)
+        if idx.size == 0:
+            raise ValueError("no stars")
+        # template = the first star that has every band (stars lacking some get NaN entries)
+        sub = catalog.df.iloc[idx]
+        complete = np.ones(idx.size, dtype=bool)
+        for b in catalog.bands:
+            complete &= sub["{}_mag".format(b)].notna().to_numpy() & sub["{}_mag_unc".format(b)].notna().to_numpy()
+        if not complete.any():
+            raise ValueError("no star of the batch has all of the catalog's bands")
+        template = catalog.model(int(idx[int(np.argmax(complete))]), ic, N=N, **model_kwargs)
+        if len(template.bands) != len([b for b in catalog.bands if b in ic.bc_grid.bands]):
+            raise ValueError("template star lacks some of the catalog's bands")
+        if "nu_max" in catalog.props or "delta_nu" in catalog.props:
+            raise ValueError("asteroseismic terms are not batched")
+        return idx, sub, template
+
+    @staticmethod
+    def build_columns(catalog, ic, N=1, indices=None, **model_kwargs):
+        """Per-star columns for ``iso_catalog_create_columns`` (host only, numpy): magnitudes [n, nb] (NaN =
+        band not observed), spectroscopic values [n, 3] (NaN = absent), parallax flags / values, and the
+        parallax-dependent upper distance bound (reference: starmodel.py:1465-1475)."""
+        idx, df, template = CatalogPosterior._template_and_rows(catalog, ic, N, indices, model_kwargs)
+        n, bands = idx.size, template.bands
+        mag_val = np.empty((n, len(bands))); mag_unc = np.empty((n, len(bands)))
+        for j, b in enumerate(bands):
+            v = df["{}_mag".format(b)].to_numpy(float)
+            u = df["{}_mag_unc".format(b)].to_numpy(float)
+            missing = np.isnan(v) | np.isnan(u)
+            mag_val[:, j] = np.where(missing, np.nan, v)
+            mag_unc[:, j] = np.where(missing, 1.0, u)
+        spec_val = np.full((n, 3), np.nan); spec_unc = np.full((n, 3), np.nan)
+        for q, name in enumerate(("Teff", "logg", "feh")):
+            if name in catalog.props:
+                v = df[name].to_numpy(float)
+                u = df[name + "_unc"].to_numpy(float)
+                missing = np.isnan(v) | np.isnan(u)
+                spec_val[:, q] = np.where(missing, np.nan, v)
+                spec_unc[:, q] = np.where(missing, np.nan, u)
+        has = np.zeros(n, dtype=np.int32); plx_val = np.zeros(n); plx_unc = np.ones(n)
+        dist_hi = None
+        if "parallax" in catalog.props:
+            v = df["parallax"].to_numpy(float)
+            u = df["parallax_unc"].to_numpy(float)
+            ok = ~(np.isnan(v) | np.isnan(u))
+            has = ok.astype(np.int32)
+            plx_val = np.where(ok, v, 0.0)
+            plx_unc = np.where(ok, u, 1.0)
+            if "max_distance" not in model_kwargs and "distance" not in catalog._prior_settings:
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    dist_hi = np.ascontiguousarray(np.where(ok & (v > 0), 1.0 / v * 2000,
+                                                            np.where(ok & (v < 0), 1.0 / np.abs(u) * 2000, 10000.0)))
+        cols = dict(mag_val=np.ascontiguousarray(mag_val), mag_unc=np.ascontiguousarray(mag_unc),
+                    spec_val=np.ascontiguousarray(spec_val), spec_unc=np.ascontiguousarray(spec_unc),
+                    has_plx=np.ascontiguousarray(has), plx_val=np.ascontiguousarray(plx_val),
+                    plx_unc=np.ascontiguousarray(plx_unc), dist_hi=dist_hi)
+        return cols, template
 
     @staticmethod
     def build_descs(catalog, ic, N=1, indices=None, **model_kwargs):

@@ -1153,6 +1153,97 @@ int iso_catalog_create(iso_ic* ic, const iso_model_desc* descs, int64_t n_models
     return ISO_OK;
 }
 
+int iso_catalog_create_columns(iso_ic* ic, const iso_model_desc* tmpl, int64_t n_models, const double* mag_val,
+                               const double* mag_unc, const double* spec_val, const double* spec_unc,
+                               const int32_t* has_plx, const double* plx_val, const double* plx_unc,
+                               const double* dist_hi, iso_catalog** out)
+{
+    if (!ic || !tmpl || !out || n_models < 1 || !mag_val || !mag_unc || !spec_val || !spec_unc || !has_plx || !plx_val ||
+        !plx_unc)
+        return fail(ISO_ERR_INVALID, "iso_catalog_create_columns: bad argument");
+    const int rc = validate_desc(ic, tmpl, "iso_catalog_create_columns");
+    if (rc != ISO_OK) return rc;
+    if (tmpl->has_numax) return fail(ISO_ERR_INVALID, "iso_catalog_create_columns: asteroseismic terms are not batched");
+    if (!fast_eligible(ic, tmpl) || !ic->d_hotq || tmpl->n_bands < 1)
+        return fail(ISO_ERR_INVALID, "iso_catalog_create_columns: needs 1-12 bands, a uniform EEP axis and the "
+                                     "corner-packed tables (ISOCHRONES_AMD_PATH=auto)");
+    DeviceGuard guard(ic->device);
+    iso_catalog* c = new (std::nothrow) iso_catalog();
+    if (!c) return fail(ISO_ERR_NOMEM, "iso_catalog_create_columns: out of host memory");
+    c->device = ic->device;
+    c->ic = ic;
+    c->n_models = n_models;
+    c->n_stars = tmpl->n_stars;
+    c->n_bands = tmpl->n_bands;
+    c->d_models = nullptr;
+    c->d_bc_hot = c->d_bcq = c->d_axes_blob = nullptr;
+    const int nb = tmpl->n_bands;
+    DevModel H;
+    fill_dev_model(tmpl, ic->kind, H);
+    // one staging allocation: template block | columns
+    const size_t n = (size_t)n_models;
+    const size_t col_doubles = n * (2 * (size_t)nb + 6 + 2 + (dist_hi ? 1 : 0));
+    DevModel* d_tmpl = nullptr;
+    double* d_cols = nullptr;
+    int32_t* d_has = nullptr;
+    hipError_t e = hipMalloc(&c->d_models, sizeof(DevModel) * n);
+    if (e == hipSuccess) e = hipMalloc(&d_tmpl, sizeof(DevModel));
+    if (e == hipSuccess) e = hipMalloc(&d_cols, col_doubles * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&d_has, n * sizeof(int32_t));
+    FillCatalogArgs F;
+    std::memset(&F, 0, sizeof(F));
+    if (e == hipSuccess) {
+        double* p = d_cols;
+        auto up = [&](const double* src, size_t count, const double** slot) {
+            *slot = p;
+            hipError_t r = hipMemcpy(p, src, count * sizeof(double), hipMemcpyHostToDevice);
+            p += count;
+            return r;
+        };
+        e = hipMemcpy(d_tmpl, &H, sizeof(DevModel), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = up(mag_val, n * nb, &F.mag_val);
+        if (e == hipSuccess) e = up(mag_unc, n * nb, &F.mag_unc);
+        if (e == hipSuccess) e = up(spec_val, n * 3, &F.spec_val);
+        if (e == hipSuccess) e = up(spec_unc, n * 3, &F.spec_unc);
+        if (e == hipSuccess) e = up(plx_val, n, &F.plx_val);
+        if (e == hipSuccess) e = up(plx_unc, n, &F.plx_unc);
+        if (e == hipSuccess && dist_hi) e = up(dist_hi, n, &F.dist_hi);
+        if (e == hipSuccess) e = hipMemcpy(d_has, has_plx, n * sizeof(int32_t), hipMemcpyHostToDevice);
+    }
+    if (e == hipSuccess) {
+        F.models = c->d_models;
+        F.tmpl = d_tmpl;
+        F.n = n_models;
+        F.nb = nb;
+        F.i_dist = tmpl->n_stars + 2;
+        F.has_plx = d_has;
+        hipLaunchKernelGGL(k_catalog_copy_template, dim3(grid_blocks(n_models * (int64_t)(sizeof(DevModel) / 8))), dim3(BLOCK),
+                           0, 0, F);
+        hipLaunchKernelGGL(k_catalog_fill, dim3(grid_blocks(n_models)), dim3(BLOCK), 0, 0, F);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+    }
+    if (d_tmpl) (void)hipFree(d_tmpl);
+    if (d_cols) (void)hipFree(d_cols);
+    if (d_has) (void)hipFree(d_has);
+    if (e == hipSuccess) e = pack_bands(ic, tmpl->bc_cols, nb, &c->d_bc_hot);
+    bool ok = false;
+    if (e == hipSuccess) e = build_fast(ic, nb, c->d_bc_hot, &c->d_axes_blob, &c->d_bcq, c->fast, &ok);
+    if (e == hipSuccess && (!ok || !c->d_bcq)) {
+        iso_catalog_destroy(c);
+        return fail(ISO_ERR_INVALID, "iso_catalog_create_columns: tables not representable on the fast path");
+    }
+    if (e != hipSuccess) {
+        std::string msg = std::string("iso_catalog_create_columns: ") + hipGetErrorString(e);
+        iso_catalog_destroy(c);
+        return fail(e == hipErrorOutOfMemory ? ISO_ERR_NOMEM : ISO_ERR_HIP, msg);
+    }
+    c->fast.m = c->d_models;
+    c->packed = true;
+    *out = c;
+    return ISO_OK;
+}
+
 void iso_catalog_destroy(iso_catalog* c)
 {
     if (!c) return;

@@ -103,3 +103,70 @@ __global__ __launch_bounds__(BLOCK) void k_pack_corners(const PackCornersArgs A)
         A.out[e] = A.src[src_cell * A.ncol + col];
     }
 }
+
+// -------------------------------------------------------------------------------------------
+// catalog: per-star constant blocks built on the device from a template block + per-star columns
+// -------------------------------------------------------------------------------------------
+struct FillCatalogArgs {
+    DevModel* models;          // [n]
+    const DevModel* tmpl;
+    int64_t n;
+    int nb, i_dist;            // bands; index of the distance parameter (n_stars + 2)
+    const double *mag_val, *mag_unc;      // [n][nb]
+    const double *spec_val, *spec_unc;    // [n][3]
+    const int32_t* has_plx;               // [n]
+    const double *plx_val, *plx_unc;      // [n]
+    const double* dist_hi;                // [n] or null
+};
+
+__global__ __launch_bounds__(BLOCK) void k_catalog_copy_template(const FillCatalogArgs A)
+{
+    constexpr int64_t WORDS = sizeof(DevModel) / sizeof(double);
+    static_assert(sizeof(DevModel) % sizeof(double) == 0, "DevModel must be a whole number of doubles");
+    const double* __restrict__ src = reinterpret_cast<const double*>(A.tmpl);
+    double* __restrict__ dst = reinterpret_cast<double*>(A.models);
+    const int64_t total = A.n * WORDS;
+    for (int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x; e < total; e += (int64_t)gridDim.x * BLOCK)
+        dst[e] = src[e % WORDS];
+}
+
+__device__ __forceinline__ void dev_gauss_consts(double unc, double& g0, double& unc2, double& hinv)
+{
+    g0 = log(1.0 / sqrt(2 * M_PI)) + log(unc);
+    unc2 = unc * unc;
+    hinv = 0.5 / unc2;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_catalog_fill(const FillCatalogArgs A)
+{
+    for (int64_t s = (int64_t)blockIdx.x * BLOCK + threadIdx.x; s < A.n; s += (int64_t)gridDim.x * BLOCK) {
+        DevModel& M = A.models[s];
+        for (int b = 0; b < A.nb; ++b) {
+            M.mag_val[b] = A.mag_val[s * A.nb + b];
+            dev_gauss_consts(A.mag_unc[s * A.nb + b], M.mag_g0[b], M.mag_unc2[b], M.mag_hinv[b]);
+        }
+        for (int q = 0; q < 3; ++q) {
+            M.spec_val[q] = A.spec_val[s * 3 + q];
+            dev_gauss_consts(A.spec_unc[s * 3 + q], M.spec_g0[q], M.spec_unc2[q], M.spec_hinv[q]);
+        }
+        M.has_parallax = A.has_plx[s];
+        M.plx_val = A.plx_val[s];
+        dev_gauss_consts(A.plx_unc[s], M.plx_g0, M.plx_unc2, M.plx_hinv);
+        if (A.dist_hi) {
+            const double hi = A.dist_hi[s];
+            DevPrior& P = M.prior_distance;
+            P.hi = hi;
+            if (P.kind == ISO_PRIOR_FLAT) {
+                P.k0 = 1.0 / (hi - P.lo);
+                P.k1 = log(P.k0);
+            } else if (P.kind == ISO_PRIOR_FLATLOG) {
+                P.k0 = pow(10.0, hi) - pow(10.0, P.lo);
+                P.k1 = log(log(10.0) / P.k0);
+            } else if (P.kind == ISO_PRIOR_POWERLAW) {
+                P.k0 = (1 + P.a) / (pow(hi, 1 + P.a) - pow(P.lo, 1 + P.a));
+                P.k1 = log(P.k0);
+            }
+            M.bound_hi[A.i_dist] = hi;
+        }
+    }
+}

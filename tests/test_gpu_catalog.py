@@ -568,3 +568,38 @@ def test_catalog_rows_with_missing_bands():
     sliced = fit_catalog(cat2, ic, nwalkers=32, nburn=100, niter=50, seed=1, max_stars_per_batch=5)   # 5 + 5 + 2 stars
     assert sliced.shape == res.shape and sliced["ok"].mean() == 1.0
     assert np.allclose(sliced["distance_median"], res["distance_median"], rtol=0.2)
+
+
+def test_catalog_columns_path_equals_descriptor_path():
+    """iso_catalog_create_columns (template + per-star columns, constant blocks filled by a kernel) against
+    iso_catalog_create (one host descriptor per star): same lnpost for every star, incl. stars without a
+    parallax / with a negative one / without Teff, and a catalog-wide custom prior."""
+    import pandas as pd
+    import torch
+    from isochrones_amd import priors as P
+    rng = np.random.default_rng(12)
+    ic = _small_track(("G", "RP"))
+    n = 30
+    df = pd.DataFrame({"G_mag": 10 + rng.random(n), "G_mag_unc": 0.01 + 0.01 * rng.random(n),
+                       "RP_mag": 9.5 + rng.random(n), "RP_mag_unc": 0.02,
+                       "parallax": 1 + 5 * rng.random(n), "parallax_unc": 0.05,
+                       "Teff": 5000 + 1000 * rng.random(n), "Teff_unc": 80.0})
+    df.loc[3, "parallax"] = np.nan
+    df.loc[5, "parallax"] = -0.2
+    df.loc[7, "Teff"] = np.nan
+    for custom in (False, True):
+        cat = ia.StarCatalog(df, bands=["G", "RP"], props=["parallax", "Teff"])
+        if custom:
+            cat.set_prior(feh=P.FlatPrior((-0.8, 0.3)), AV=P.PowerLawPrior(0.5, (0.0, 1.0)))
+        a = CatalogPosterior.from_catalog(cat, ic)                                      # columns
+        arr, template = CatalogPosterior.build_descs(cat, ic)
+        b = CatalogPosterior(ic, _descs=arr, _template=template)                        # descriptors
+        assert np.array_equal(a.bounds_hi, b.bounds_hi) and np.array_equal(a.bounds_lo, b.bounds_lo)
+        assert np.array_equal(a.parallax, b.parallax, equal_nan=True)
+        m = 3000
+        lo = np.array([ic.model_grid.masses[0], 150, -1.0, 20.0, 0.0]); hi = np.array([ic.model_grid.masses[-1], 699, 0.5, 2500.0, 1.0])
+        x = torch.as_tensor(rng.uniform(lo, hi, size=(m * n, 5)), device="cuda")
+        sid = torch.arange(n, dtype=torch.int32, device="cuda").repeat_interleave(m)
+        fx.assert_close(a.lnpost(x, sid).cpu().numpy(), b.lnpost(x, sid).cpu().numpy(), 1e-13, atol=1e-13, what="columns vs descs")
+        assert np.isfinite(a.lnpost(x, sid).cpu().numpy()).sum() > m
+        a.close(); b.close()
