@@ -34,15 +34,16 @@ __global__ __launch_bounds__(BLOCK) void k_chain_quantiles(const QuantArgs A)
     __syncthreads();
     for (int k = 2; k <= A.P; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < A.P; i += BLOCK) {
-                const int x = i ^ j;
-                if (x > i) {
-                    const double a = lds[i], b = lds[x];
-                    const bool asc = (i & k) == 0;
-                    if ((a > b) == asc) {
-                        lds[i] = b;
-                        lds[x] = a;
-                    }
+            // every thread takes whole compare-exchange pairs: pair p -> lower index i (a zero inserted at bit
+            // log2 j of p), partner i | j
+            for (int p = threadIdx.x; p < (A.P >> 1); p += BLOCK) {
+                const int i = ((p & ~(j - 1)) << 1) | (p & (j - 1));
+                const int x = i | j;
+                const double a = lds[i], b = lds[x];
+                const bool asc = (i & k) == 0;
+                if ((a > b) == asc) {
+                    lds[i] = b;
+                    lds[x] = a;
                 }
             }
             __syncthreads();
