@@ -21,11 +21,18 @@ inline bool launch_stretch_nb(int nb, const FastArgs& A, const StretchArgs& S, h
         // with S.occupancy_query set: report resident workgroups per CU of this instantiation, launch nothing
 #define ISO_PERSIST_CASE(N)                                                                               \
         case N:                                                                                           \
-            if (S.occupancy_query)                                                                        \
-                return hipOccupancyMaxActiveBlocksPerMultiprocessor(S.occupancy_query,                    \
-                                                                    k_stretch_persist<KIND, NS, N>, BLOCK, \
-                                                                    shp(N)) == hipSuccess;                \
-            hipLaunchKernelGGL((k_stretch_persist<KIND, NS, N>), gp, b, shp(N), s, A, S);                 \
+            if (S.occupancy_query) {                                                                      \
+                const hipError_t qe = S.dense                                                             \
+                    ? hipOccupancyMaxActiveBlocksPerMultiprocessor(S.occupancy_query,                     \
+                                                                   k_stretch_persist<KIND, NS, N, true>,  \
+                                                                   BLOCK, shp(N))                         \
+                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(S.occupancy_query,                     \
+                                                                   k_stretch_persist<KIND, NS, N, false>, \
+                                                                   BLOCK, shp(N));                        \
+                return qe == hipSuccess;                                                                  \
+            }                                                                                             \
+            if (S.dense) hipLaunchKernelGGL((k_stretch_persist<KIND, NS, N, true>), gp, b, shp(N), s, A, S);   \
+            else hipLaunchKernelGGL((k_stretch_persist<KIND, NS, N, false>), gp, b, shp(N), s, A, S);     \
             return true;
             ISO_PERSIST_CASE(0) ISO_PERSIST_CASE(1) ISO_PERSIST_CASE(2) ISO_PERSIST_CASE(3) ISO_PERSIST_CASE(4) ISO_PERSIST_CASE(5)
             ISO_PERSIST_CASE(6) ISO_PERSIST_CASE(7) ISO_PERSIST_CASE(8) ISO_PERSIST_CASE(9) ISO_PERSIST_CASE(10)

@@ -1501,6 +1501,7 @@ int iso_sampler_run(iso_sampler* sp, double* pos, double* lnp, int nsteps, doubl
     const int64_t rows = sp->n_ensembles * sp->W;
     StretchArgs S;
     S.occupancy_query = nullptr;
+    S.dense = 0;
     S.pos = pos;
     S.lnp = lnp;
     S.accepted = accepted;
@@ -1513,7 +1514,9 @@ int iso_sampler_run(iso_sampler* sp, double* pos, double* lnp, int nsteps, doubl
     // ensemble, all iterations in one launch) wins while the catalog is too small for a half-step launch
     // to fill the chip; both forms produce bit-identical chains.
     const char* env = getenv("ISOCHRONES_AMD_SAMPLER");
-    const std::string mode = env ? env : "auto";
+    std::string mode = env ? env : "auto";
+    const bool force_dense = mode == "persistent-dense";          // test hook: the register-capped instantiation
+    if (force_dense) mode = "persistent";
     if (mode != "auto" && mode != "persistent" && mode != "stepwise")
         return fail(ISO_ERR_INVALID, "ISOCHRONES_AMD_SAMPLER must be auto, persistent or stepwise");
     int group = 1;
@@ -1527,12 +1530,22 @@ int iso_sampler_run(iso_sampler* sp, double* pos, double* lnp, int nsteps, doubl
     int cus = 0, per_cu = 0;
     HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, sp->device));
     const int64_t blocks = (sp->n_ensembles + group - 1) / group;
-    if (fits && mode == "auto") {
+    // two instantiations: uncapped registers (2 workgroups per CU, fastest per iteration) and "dense"
+    // (3 per CU); persistent is chosen while one of them keeps every workgroup resident
+    int dense = 0;
+    if (fits && mode != "stepwise") {
         S.nsteps = 1;
-        S.occupancy_query = &per_cu;
-        if (!launch_stretch(sp->kind, sp->n_stars, sp->n_bands, sp->fast, S, s)) per_cu = 0;
-        S.occupancy_query = nullptr;
+        for (int dn = force_dense ? 1 : 0; dn < 2; ++dn) {
+            S.dense = dn;
+            S.occupancy_query = &per_cu;
+            per_cu = 0;
+            if (!launch_stretch(sp->kind, sp->n_stars, sp->n_bands, sp->fast, S, s)) per_cu = 0;
+            S.occupancy_query = nullptr;
+            dense = dn;
+            if (blocks <= (int64_t)cus * per_cu) break;
+        }
     }
+    S.dense = dense;
     const int64_t resident = (int64_t)cus * per_cu;
     const bool persistent = nsteps > 0 && fits && (mode == "persistent" || (mode == "auto" && blocks <= resident));
     if (persistent) {

@@ -130,6 +130,7 @@ struct StretchArgs {
     double* chain_pos;    // optional: this step's [n_rows][n_params] slab of the stored chain
     double* chain_lnp;    // optional: this step's [n_rows] slab
     int* occupancy_query; // host side only, persistent form: non-null = report workgroups/CU, do not launch
+    int dense;            // host side only, persistent form: 1 = the register-capped (3 waves/SIMD) instantiation
 };
 
 }  // namespace iso

@@ -189,9 +189,10 @@ def test_persistent_sampler_kernel_bit_identical_to_stepwise(W, monkeypatch):
     pos, lnp, failed = initial_positions(post, W, rng_seed=2)
     assert not bool(failed.any())
     a = _run_fused(post, pos, lnp, W, 40, "stepwise", monkeypatch)
-    b = _run_fused(post, pos, lnp, W, 40, "persistent", monkeypatch)
-    for x, y in zip(a, b):
-        assert torch.equal(x, y)
+    for mode in ("persistent", "persistent-dense"):        # uncapped and register-capped instantiations
+        b = _run_fused(post, pos, lnp, W, 40, mode, monkeypatch)
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
     assert int(a[4].sum()) > 0
     # single-model form
     a = _run_fused(models[2], pos[2], lnp[2], W, 25, "stepwise", monkeypatch)
