@@ -188,6 +188,16 @@ def test_vectorised_catalog_descriptors_equal_per_model_descriptors():
             a, b = np.asarray(arr2[i][name]), np.asarray(w[name])
             assert a.tobytes() == b.tobytes() or (name in ("plx_val", "plx_unc") and not w["has_parallax"]), (i, name, a, b)
     assert arr2["prior_distance"]["hi"][5] == 900.0 and arr2["prior_distance"]["kind"][0] == _cabi.PRIOR_GAUSS
+    # the column form (what from_catalog sends to iso_catalog_create_columns) carries the same per-star numbers
+    cat0 = ia.StarCatalog(df, bands=["G", "RP"], props=["parallax", "Teff"])
+    cols, tmpl = CatalogPosterior.build_columns(cat0, ic)
+    assert np.array_equal(cols["mag_val"], arr["mag_val"][:, :2]) and np.array_equal(cols["mag_unc"], arr["mag_unc"][:, :2])
+    assert np.array_equal(cols["spec_val"], arr["spec_val"], equal_nan=True)
+    assert np.array_equal(cols["has_plx"], arr["has_parallax"]) and np.array_equal(cols["dist_hi"], arr["prior_distance"]["hi"])
+    has = cols["has_plx"] != 0
+    assert np.array_equal(cols["plx_val"][has], arr["plx_val"][has]) and tmpl.bands == ["G", "RP"]
+    cols2, _ = CatalogPosterior.build_columns(cat, ic)            # catalog-wide distance prior: its own bounds stay
+    assert cols2["dist_hi"] is None
 
 
 def test_fit_catalog_checkpoint_resume(tmp_path):
