@@ -492,7 +492,10 @@ def fit_stars_gpu(catalog: StarCatalog, ic, indices, N=1, nwalkers=32, nburn=150
         q = srt[:, :, i0] * (1 - frac) + srt[:, :, i1] * frac                                   # [S, D, 3] (linear, as np.percentile)
     rows = torch.empty(post.n_models, 3 * D + 3, dtype=torch.float64, device=q.device)
     rows[:, : 3 * D] = q.reshape(post.n_models, 3 * D)
-    rows[:, 3 * D] = lnps.reshape(post.n_models, -1).max(dim=1).values
+    if fused:       # storage order is [step][star * W + walker]: reduce over steps first (coalesced), then walkers
+        rows[:, 3 * D] = sampler._lnprob.amax(dim=0).view(post.n_models, nwalkers).amax(dim=1)
+    else:
+        rows[:, 3 * D] = lnps.amax(dim=(1, 2))
     rows[:, 3 * D + 1] = acc_frac
     rows[:, 3 * D + 2] = good.to(torch.float64)
     rows[failed, : 3 * D + 2] = float("nan")

@@ -1600,8 +1600,17 @@ int iso_chain_quantiles(iso_ctx* ctx, const double* chain, int64_t nsteps, int64
     }
     A.out = out;
     DeviceGuard guard(ctx->device);
-    hipLaunchKernelGGL(k_chain_quantiles, dim3((unsigned)(n_ens * n_params)), dim3(BLOCK), (size_t)A.P * sizeof(double),
-                       as_stream(stream), A);
+    // selection kernel (3 passes + tiny lists); ISOCHRONES_AMD_QUANTILES=sort forces the full LDS sort (tests / A-B)
+    const char* qm = getenv("ISOCHRONES_AMD_QUANTILES");
+    const size_t sel_bytes = (size_t)QSEL_RANKS * QSEL_CAP * sizeof(double) + QSEL_BINS * sizeof(int) + QSEL_BINS +
+                             4 * QSEL_RANKS * sizeof(int) + 8 * sizeof(double) + 2 * sizeof(int) + 8 +
+                             QSEL_RANKS * sizeof(double);
+    const size_t sort_bytes = (size_t)A.P * sizeof(double);
+    const dim3 g((unsigned)(n_ens * n_params)), b(BLOCK);
+    if (qm && !std::strcmp(qm, "sort"))
+        hipLaunchKernelGGL(k_chain_quantiles, g, b, sort_bytes, as_stream(stream), A);
+    else
+        hipLaunchKernelGGL(k_chain_quantiles_select, g, b, std::max(sel_bytes, sort_bytes), as_stream(stream), A);
     HIP_TRY(hipGetLastError());
     return ISO_OK;
 }

@@ -15,22 +15,35 @@ struct QuantArgs {
     double* out;             // [n_ens][D][nq]
 };
 
-__global__ __launch_bounds__(BLOCK) void k_chain_quantiles(const QuantArgs A)
+// numpy.percentile(method="linear") position of quantile level qq among m sorted values: lower index + fraction
+__device__ __forceinline__ void quantile_position(double qq, int m, int& i0, int& i1, double& f)
 {
-    extern __shared__ double lds[];
-    const int64_t e = blockIdx.x / A.D;
-    const int d = (int)(blockIdx.x - e * A.D);
-    const int m = (int)(A.nsteps * A.W);
-    const int64_t rows = A.n_ens * A.W;
-    for (int i = threadIdx.x; i < A.P; i += BLOCK) {
-        double v = d_inf();
-        if (i < m) {
-            const int t = i / A.W, w = i - t * A.W;
-            v = A.chain[((int64_t)t * rows + e * A.W + w) * A.D + d];
-            if (v != v) v = d_inf();                 // NaN sorts last (cannot occur in an accepted chain)
-        }
-        lds[i] = v;
-    }
+#pragma clang fp contract(off)   // pos must be rounded before the fraction is taken (no fma(m-1, q, -i0))
+    const double pos = (double)(m - 1) * qq;        // numpy's virtual index for method="linear": (n - 1) q
+    i0 = (int)floor(pos);
+    i0 = max(0, min(i0, m - 1));
+    i1 = min(i0 + 1, m - 1);
+    f = pos - (double)i0;
+}
+
+__device__ __forceinline__ double quantile_lerp(double a, double b, double f)
+{
+#pragma clang fp contract(off)   // numpy's _lerp, unfused: a + (b-a)t, from the upper end for t >= 0.5
+    const double diff = b - a;
+    return (f >= 0.5) ? b - diff * (1 - f) : a + diff * f;
+}
+
+__device__ __forceinline__ double chain_value(const QuantArgs& A, int64_t e, int d, int64_t rows, int i)
+{
+    const int t = i / A.W, w = i - t * A.W;
+    const double v = A.chain[((int64_t)t * rows + e * A.W + w) * A.D + d];
+    return (v != v) ? d_inf() : v;                   // NaN sorts last (cannot occur in an accepted chain)
+}
+
+// full sort of the (ensemble, parameter) values in LDS; all threads of the workgroup
+__device__ __forceinline__ void bitonic_sort_chain(const QuantArgs& A, int64_t e, int d, int64_t rows, int m, double* lds)
+{
+    for (int i = threadIdx.x; i < A.P; i += BLOCK) lds[i] = (i < m) ? chain_value(A, e, d, rows, i) : d_inf();
     __syncthreads();
     for (int k = 2; k <= A.P; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
@@ -49,24 +62,199 @@ __global__ __launch_bounds__(BLOCK) void k_chain_quantiles(const QuantArgs A)
             __syncthreads();
         }
     }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_chain_quantiles(const QuantArgs A)
+{
+    extern __shared__ double lds[];
+    const int64_t e = blockIdx.x / A.D;
+    const int d = (int)(blockIdx.x - e * A.D);
+    const int m = (int)(A.nsteps * A.W);
+    bitonic_sort_chain(A, e, d, A.n_ens * A.W, m, lds);
     if ((int)threadIdx.x < A.nq) {
-        double pos;
-        {
-#pragma clang fp contract(off)   // numpy's virtual index for method="linear": n q + (1 + q (1 - 1 - 1)) - 1
-            const double qq = A.q[threadIdx.x];
-            pos = ((double)m * qq + (1.0 + qq * -1.0)) - 1.0;
+        int i0, i1;
+        double f;
+        quantile_position(A.q[threadIdx.x], m, i0, i1, f);
+        A.out[(e * A.D + d) * A.nq + threadIdx.x] = quantile_lerp(lds[i0], lds[i1], f);
+    }
+}
+
+// -------------------------------------------------------------------------------------------
+// The same quantiles by SELECTION instead of a full sort: only 2 x nq order statistics are needed.
+//   pass 1  min / max of the values
+//   pass 2  histogram over QSEL_BINS equal-width value bins (monotone binning: every element of a lower bin is
+//           <= every element of a higher bin), prefix sum -> the bin and the rank inside it of each target
+//   pass 3  the elements of the (at most 2 nq) target bins are gathered into small LDS lists; inside a list the
+//           order statistic is found by counting (an element's rank = number of elements that precede it in
+//           (value, position) order)
+// Three coalesced passes over the chain (L2-resident after the first) and a few dozen LDS operations, against
+// 78 compare-exchange passes of the bitonic network.  A target bin that holds more than QSEL_CAP elements
+// (a chain with hundreds of identical values, or NaN / inf) sends the workgroup to the full sort above.
+// -------------------------------------------------------------------------------------------
+constexpr int QSEL_BINS = 1024;
+constexpr int QSEL_CAP = 128;      // elements per gathered list
+constexpr int QSEL_RANKS = 16;     // 2 x nq, nq <= 8
+
+__global__ __launch_bounds__(BLOCK) void k_chain_quantiles_select(const QuantArgs A)
+{
+    extern __shared__ double lds[];
+    // LDS map (the bitonic fallback reuses the whole area from offset 0):
+    //   [0, QSEL_RANKS * QSEL_CAP) doubles   gathered lists
+    //   then QSEL_BINS ints                  histogram -> exclusive prefix
+    //   then QSEL_BINS bytes                 list slot of a bin (0xFF = not a target)
+    //   then small per-rank records
+    double* lists = lds;
+    int* hist = reinterpret_cast<int*>(lds + QSEL_RANKS * QSEL_CAP);
+    unsigned char* slot_of_bin = reinterpret_cast<unsigned char*>(hist + QSEL_BINS);
+    int* rank_bin = reinterpret_cast<int*>(slot_of_bin + QSEL_BINS);      // [QSEL_RANKS]
+    int* rank_local = rank_bin + QSEL_RANKS;                               // [QSEL_RANKS]
+    int* rank_slot = rank_local + QSEL_RANKS;                              // [QSEL_RANKS]
+    int* list_count = rank_slot + QSEL_RANKS;                              // [QSEL_RANKS]
+    double* red = reinterpret_cast<double*>(list_count + QSEL_RANKS);      // [2 * waves] min / max partials
+    int* flags = reinterpret_cast<int*>(red + 8);                          // [0] fallback, [1] number of lists
+    double* result = reinterpret_cast<double*>(flags + 2);                 // [QSEL_RANKS]
+
+    const int64_t e = blockIdx.x / A.D;
+    const int d = (int)(blockIdx.x - e * A.D);
+    const int m = (int)(A.nsteps * A.W);
+    const int64_t rows = A.n_ens * A.W;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_ranks = 2 * A.nq;
+
+    // ---- pass 1: min / max ----
+    double mn = d_inf(), mx = -d_inf();
+    for (int i = tid; i < m; i += BLOCK) {
+        const double v = chain_value(A, e, d, rows, i);
+        mn = fmin(mn, v);
+        mx = fmax(mx, v);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        mn = fmin(mn, __shfl_xor(mn, off));
+        mx = fmax(mx, __shfl_xor(mx, off));
+    }
+    if (lane == 0) {
+        red[wave] = mn;
+        red[4 + wave] = mx;
+    }
+    for (int i = tid; i < QSEL_BINS; i += BLOCK) {
+        hist[i] = 0;
+        slot_of_bin[i] = 0xFF;
+    }
+    if (tid == 0) flags[0] = flags[1] = 0;
+    __syncthreads();
+    mn = fmin(fmin(red[0], red[1]), fmin(red[2], red[3]));
+    mx = fmax(fmax(red[4], red[5]), fmax(red[6], red[7]));
+    const double inv = (double)QSEL_BINS / (mx - mn);
+    const bool degenerate = !(mx > mn) || !isfinite(inv) || !isfinite(mn);      // constant chain, inf, NaN
+    auto bin_of = [&](double v) { return min(QSEL_BINS - 1, (int)((v - mn) * inv)); };
+    if (!degenerate) {
+        // ---- pass 2: histogram + exclusive prefix ----
+        for (int i = tid; i < m; i += BLOCK) atomicAdd(&hist[bin_of(chain_value(A, e, d, rows, i))], 1);
+        __syncthreads();
+        {   // 1024 bins, 4 per thread: thread-local sum, wave scan of the sums, cross-wave offsets
+            int c[QSEL_BINS / BLOCK];
+            int tot = 0;
+#pragma unroll
+            for (int r = 0; r < QSEL_BINS / BLOCK; ++r) {
+                c[r] = hist[tid * (QSEL_BINS / BLOCK) + r];
+                tot += c[r];
+            }
+            int incl = tot;
+            for (int off = 1; off < 64; off <<= 1) {
+                const int up = __shfl_up(incl, off);
+                if (lane >= off) incl += up;
+            }
+            int* wsum = reinterpret_cast<int*>(red);      // min / max partials are no longer needed
+            __syncthreads();
+            if (lane == 63) wsum[wave] = incl;
+            __syncthreads();
+            int base = incl - tot;
+            for (int w = 0; w < wave; ++w) base += wsum[w];
+#pragma unroll
+            for (int r = 0; r < QSEL_BINS / BLOCK; ++r) {
+                hist[tid * (QSEL_BINS / BLOCK) + r] = base;     // exclusive prefix
+                base += c[r];
+            }
         }
-        int i0 = (int)floor(pos);
-        i0 = max(0, min(i0, m - 1));
-        const int i1 = min(i0 + 1, m - 1);
-        const double f = pos - (double)i0;
-        const double a = lds[i0], b = lds[i1];
-        double r;
-        {
-#pragma clang fp contract(off)   // numpy's _lerp, unfused: a + (b-a)t, from the upper end for t >= 0.5
-            const double diff = b - a;
-            r = (f >= 0.5) ? b - diff * (1 - f) : a + diff * f;
+        __syncthreads();
+        // ---- the target ranks: which bin, which rank inside it ----
+        if (tid < n_ranks) {
+            int i0, i1;
+            double f;
+            quantile_position(A.q[tid >> 1], m, i0, i1, f);
+            const int r = (tid & 1) ? i1 : i0;
+            int lo = 0, hi = QSEL_BINS - 1;                      // last bin whose exclusive prefix is <= r
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (hist[mid] <= r) lo = mid;
+                else hi = mid - 1;
+            }
+            rank_bin[tid] = lo;
+            rank_local[tid] = r - hist[lo];
         }
-        A.out[(e * A.D + d) * A.nq + threadIdx.x] = r;
+        __syncthreads();
+        if (tid == 0) {                                          // distinct target bins -> list slots
+            int n_lists = 0;
+            for (int k = 0; k < n_ranks; ++k) {
+                const int b = rank_bin[k];
+                if (slot_of_bin[b] == 0xFF) {
+                    slot_of_bin[b] = (unsigned char)n_lists;
+                    list_count[n_lists] = 0;
+                    const int cnt = ((b + 1 < QSEL_BINS) ? hist[b + 1] : m) - hist[b];
+                    if (cnt > QSEL_CAP) flags[0] = 1;
+                    ++n_lists;
+                }
+                rank_slot[k] = slot_of_bin[b];
+            }
+            flags[1] = n_lists;
+        }
+        __syncthreads();
+    }
+    const bool fallback = degenerate ? (mx > mn || !isfinite(mn) || !isfinite(mx)) : (flags[0] != 0);
+    if (degenerate && !fallback) {                               // every value equal
+        if (tid < A.nq) A.out[(e * A.D + d) * A.nq + tid] = mn;
+        return;
+    }
+    if (fallback) {                                              // workgroup-uniform
+        __syncthreads();
+        bitonic_sort_chain(A, e, d, rows, m, lds);
+        if (tid < A.nq) {
+            int i0, i1;
+            double f;
+            quantile_position(A.q[tid], m, i0, i1, f);
+            A.out[(e * A.D + d) * A.nq + tid] = quantile_lerp(lds[i0], lds[i1], f);
+        }
+        return;
+    }
+    // ---- pass 3: gather the target bins ----
+    for (int i = tid; i < m; i += BLOCK) {
+        const double v = chain_value(A, e, d, rows, i);
+        const int sl = slot_of_bin[bin_of(v)];
+        if (sl != 0xFF) {
+            const int pos = atomicAdd(&list_count[sl], 1);
+            lists[sl * QSEL_CAP + pos] = v;
+        }
+    }
+    __syncthreads();
+    // ---- order statistic inside a list by counting; rank k of the workgroup's targets handled by wave k % 4 ----
+    for (int k = wave; k < n_ranks; k += BLOCK / 64) {
+        const int sl = rank_slot[k], cnt = list_count[sl], want = rank_local[k];
+        const double* L = lists + sl * QSEL_CAP;
+        for (int j = lane; j < cnt; j += 64) {
+            const double x = L[j];
+            int before = 0;
+            for (int i = 0; i < cnt; ++i) {
+                const double y = L[i];
+                before += (y < x || (y == x && i < j)) ? 1 : 0;
+            }
+            if (before == want) result[k] = x;
+        }
+    }
+    __syncthreads();
+    if (tid < A.nq) {
+        int i0, i1;
+        double f;
+        quantile_position(A.q[tid], m, i0, i1, f);
+        A.out[(e * A.D + d) * A.nq + tid] = quantile_lerp(result[2 * tid], result[2 * tid + 1], f);
     }
 }

@@ -604,3 +604,41 @@ def test_catalog_columns_path_equals_descriptor_path():
         fx.assert_close(a.lnpost(x, sid).cpu().numpy(), b.lnpost(x, sid).cpu().numpy(), 1e-13, atol=1e-13, what="columns vs descs")
         assert np.isfinite(a.lnpost(x, sid).cpu().numpy()).sum() > m
         a.close(); b.close()
+
+
+@pytest.mark.parametrize("mode", ["select", "sort"])
+def test_chain_quantiles_adversarial_inputs(mode, monkeypatch):
+    """iso_chain_quantiles on hand-made chains (both the selection kernel and the full LDS sort): smooth data,
+    constant chains, heavy ties (falls back to the sort inside the selection kernel), tiny and odd sample counts,
+    infinities; always numpy.percentile's numbers."""
+    import ctypes as C
+    import torch
+    from isochrones_amd import _cabi, device as dev
+    if mode == "sort":
+        monkeypatch.setenv("ISOCHRONES_AMD_QUANTILES", "sort")
+    lib, ctx = _cabi.lib(), dev.context(0)
+    rng = np.random.default_rng(21)
+    qs = np.array([0.5, 0.16, 0.84, 0.0, 1.0, 0.999, 0.3333])
+    for nsteps, S, W, D in ((100, 9, 32, 5), (37, 4, 16, 3), (1, 3, 2, 2), (255, 2, 32, 6), (3, 5, 1, 1)):
+        x = rng.standard_normal((nsteps, S * W, D))
+        x[:, :W, 0] = 3.25                                        # ensemble 0, parameter 0: constant
+        if D > 1:
+            x[:, :W, 1] = rng.integers(0, 3, size=(nsteps, W))   # heavy ties
+        if S > 1 and D > 2:
+            x[:, W:2 * W, 2] = np.round(x[:, W:2 * W, 2], 1)      # moderate ties
+        if S > 2:
+            x[0, 2 * W, 0] = np.inf                               # one infinite sample
+            x[-1, 2 * W, 0] = -1e300
+        chain = torch.as_tensor(x, device="cuda")
+        out = torch.zeros(S, D, qs.size, dtype=torch.float64, device="cuda")
+        rc = lib.iso_chain_quantiles(ctx, dev.ptr(chain), nsteps, S, W, D, qs.ctypes.data_as(C.POINTER(C.c_double)), qs.size,
+                                     dev.ptr(out), None)
+        assert rc == 0
+        got = out.cpu().numpy()
+        flat = x.reshape(nsteps, S, W, D).transpose(1, 3, 0, 2).reshape(S, D, nsteps * W)
+        with np.errstate(invalid="ignore"):
+            want = np.moveaxis(np.quantile(flat, qs, axis=2), 0, 2)          # same levels, no x100/100 round trip
+        fin = np.isfinite(want)
+        assert np.array_equal(np.isfinite(got), fin), (nsteps, S, W, D)
+        assert np.array_equal(got[fin], want[fin]), (nsteps, S, W, D, np.abs(got[fin] - want[fin]).max())      # bit for bit
+        assert np.array_equal(got[~fin & ~np.isnan(want)], want[~fin & ~np.isnan(want)])
