@@ -169,7 +169,9 @@ int  iso_table_create(iso_ctx* ctx, int ndim, const int64_t* shape, const double
 void iso_table_destroy(iso_table* t);
 
 /* out[i*k + c] = multilinear interpolation of column icols[c] at (x[0][i],..,x[ndim-1][i]).
- * x = HOST array of ndim DEVICE pointers; icols = HOST array.  (interp_values_{2,3,4}d) */
+ * x = HOST array of ndim DEVICE pointers; icols = HOST array.  Replaces interp_values_2d/3d/4d and the
+ * scalar interp_value_*d (isochrones/interp.py:208-392); 3-D tables switch to a [cell][column][corner] pack for
+ * batches of >= 32768 rows. */
 int  iso_interp(iso_table* t, const double* const* x, int64_t n, const int32_t* icols, int k,
                 double* out, void* stream);
 
@@ -182,12 +184,15 @@ int  iso_ic_create(iso_ctx* ctx, iso_table* model_grid, iso_table* bc_grid, int 
                    iso_ic** out);
 void iso_ic_destroy(iso_ic* ic);
 
-/* interp_mags: pars = 5 parameters per sample in the ic's parametrisation (strided, see top).
+/* interp_mags / interp_mag (isochrones/mags.py:8-124): pars = 5 parameters per sample in the ic's parametrisation
+ * (strided, see top).
  * Teff/logg/feh [n], mags [n, nb] row-major; any output pointer may be NULL. */
 int  iso_interp_mag(iso_ic* ic, const double* pars, int64_t stride_n, int64_t stride_p, int64_t n,
                     const int32_t* bc_cols, int nb,
                     double* Teff, double* logg, double* feh, double* mags, void* stream);
 
+/* One 1-3 star system: observations + prior constants (BasicStarModel.__init__, isochrones/starmodel.py:1370-1484;
+ * the descriptor is what isochrones_amd/starmodel.py:model_desc packs). */
 int  iso_model_create(iso_ic* ic, const iso_model_desc* desc, iso_model** out);
 void iso_model_destroy(iso_model* m);
 int  iso_model_n_params(const iso_model* m);
