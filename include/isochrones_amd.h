@@ -226,6 +226,17 @@ void iso_eep_table_destroy(iso_eep_table* t);
 int  iso_interp_eep(iso_eep_table* t, const double* x, const double* x0, const double* x1, int64_t n, double* out,
                     void* stream);
 
+/* HOST-array forms of the three interpolation entry points for scalar calls and small batches — how the reference's
+ * API is used interactively (mist.interp_value(pars, props), mist.interp_mag(pars, bands), mist.get_eep(m, a, f):
+ * isochrones/models.py:390-445, 501-542).  Inputs and outputs are host arrays; they travel through a pinned,
+ * device-mapped staging buffer owned by the context: one launch + one synchronise per call (per 1 MiB chunk).
+ * x [n][ndim] and pars [n][5] row-major; out [n][k]; mags [n][nb]; any of Teff / logg / feh / mags may be NULL. */
+int  iso_interp_host(iso_table* t, const double* x, int64_t n, const int32_t* icols, int k, double* out);
+int  iso_interp_mag_host(iso_ic* ic, const double* pars, int64_t n, const int32_t* bc_cols, int nb, double* Teff,
+                         double* logg, double* feh, double* mags);
+int  iso_interp_eep_host(iso_eep_table* t, const double* age, const double* feh, const double* mass, int64_t n,
+                         double* out);
+
 /* A catalog = many independent systems observed in the same bands with the same multiplicity
  * (reference: isochrones/catalog.py:19-139 StarCatalog.iter_models; scripts/batch_starfit shards
  * them over processes).  iso_catalog_lnpost evaluates a batch of rows where row i belongs to

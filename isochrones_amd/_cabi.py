@@ -93,12 +93,12 @@ class IsoTreeDesc(C.Structure):
 #: every symbol include/isochrones_amd.h declares (tests check the .so exports all of them)
 EXPORTED_SYMBOLS = (
     "iso_last_error", "iso_version", "iso_ctx_create", "iso_ctx_destroy",
-    "iso_table_create", "iso_table_destroy", "iso_interp",
-    "iso_ic_create", "iso_ic_destroy", "iso_interp_mag",
+    "iso_table_create", "iso_table_destroy", "iso_interp", "iso_interp_host",
+    "iso_ic_create", "iso_ic_destroy", "iso_interp_mag", "iso_interp_mag_host",
     "iso_model_create", "iso_model_destroy", "iso_model_n_params",
     "iso_lnpost", "iso_lnpost_host", "iso_unit_cube", "iso_time_lnpost",
     "iso_catalog_create", "iso_catalog_create_columns", "iso_catalog_destroy", "iso_catalog_lnpost",
-    "iso_eep_table_create", "iso_eep_table_destroy", "iso_interp_eep",
+    "iso_eep_table_create", "iso_eep_table_destroy", "iso_interp_eep", "iso_interp_eep_host",
     "iso_sampler_create_model", "iso_sampler_create_catalog", "iso_sampler_destroy", "iso_sampler_run",
     "iso_chain_quantiles",
     "iso_tree_model_create", "iso_tree_model_destroy", "iso_tree_lnpost",
@@ -174,6 +174,10 @@ def lib():
     L.iso_eep_table_destroy.argtypes = [vp]
     L.iso_eep_table_destroy.restype = None
     L.iso_interp_eep.argtypes = [vp, pd, pd, pd, i64, pd, vp]
+    hdp = C.POINTER(dbl)
+    L.iso_interp_host.argtypes = [vp, hdp, i64, C.POINTER(C.c_int32), C.c_int, hdp]
+    L.iso_interp_mag_host.argtypes = [vp, hdp, i64, C.POINTER(C.c_int32), C.c_int, hdp, hdp, hdp, hdp]
+    L.iso_interp_eep_host.argtypes = [vp, hdp, hdp, hdp, i64, hdp]
     L.iso_sampler_create_model.argtypes = [vp, C.c_int, dbl, C.c_uint64, C.POINTER(vp)]
     L.iso_sampler_create_catalog.argtypes = [vp, C.c_int, dbl, C.c_uint64, C.POINTER(vp)]
     L.iso_sampler_destroy.argtypes = [vp]

@@ -267,6 +267,7 @@ struct iso_tree_model {
 
 struct iso_eep_table {
     int device;
+    iso_ctx* ctx;
     int64_t n0, n1, n_eep;
     double eep0;
     double *d_ages, *d_ax0, *d_ax1;
@@ -335,11 +336,20 @@ int iso_ctx_create(iso_ctx** out, int device)
     iso_ctx* c = new (std::nothrow) iso_ctx;
     if (!c) return fail(ISO_ERR_NOMEM, "iso_ctx_create: out of host memory");
     c->device = device;
+    c->h_stage = nullptr;
     *out = c;
     return ISO_OK;
 }
 
-void iso_ctx_destroy(iso_ctx* ctx) { delete ctx; }
+void iso_ctx_destroy(iso_ctx* ctx)
+{
+    if (!ctx) return;
+    if (ctx->h_stage) {
+        DeviceGuard guard(ctx->device);
+        (void)hipHostFree(ctx->h_stage);
+    }
+    delete ctx;
+}
 
 int iso_table_create(iso_ctx* ctx, int ndim, const int64_t* shape, const double* grid, const double* const* axes,
                      iso_table** out)
@@ -1045,6 +1055,7 @@ int iso_eep_table_create(iso_ctx* ctx, const double* ages, const int64_t* length
     iso_eep_table* t = new (std::nothrow) iso_eep_table();
     if (!t) return fail(ISO_ERR_NOMEM, "iso_eep_table_create: out of host memory");
     t->device = ctx->device;
+    t->ctx = ctx;
     t->n0 = n0; t->n1 = n1; t->n_eep = n_eep; t->eep0 = eep0;
     t->d_ages = t->d_ax0 = t->d_ax1 = nullptr;
     t->d_lengths = nullptr;
@@ -1103,6 +1114,99 @@ int iso_interp_eep(iso_eep_table* t, const double* x, const double* x0, const do
     DeviceGuard guard(t->device);
     hipLaunchKernelGGL(k_interp_eep, dim3(grid_blocks(n)), dim3(BLOCK), (size_t)lds * sizeof(double), as_stream(stream), A);
     HIP_TRY(hipGetLastError());
+    return ISO_OK;
+}
+
+namespace {
+// the context's pinned, device-mapped staging area (host view + device view); caller holds ctx->stage_mu
+int ctx_stage(iso_ctx* ctx, double** host, double** dev)
+{
+    if (!ctx->h_stage)
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_stage), sizeof(double) * ISO_CTX_STAGE_DOUBLES,
+                              hipHostMallocMapped));
+    *host = ctx->h_stage;
+    HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(dev), ctx->h_stage, 0));
+    return ISO_OK;
+}
+}  // namespace
+
+int iso_interp_host(iso_table* t, const double* x, int64_t n, const int32_t* icols, int k, double* out)
+{
+    if (!t || !icols || ((!x || !out) && n > 0)) return fail(ISO_ERR_INVALID, "iso_interp_host: NULL argument");
+    if (k < 1 || k > ISO_MAX_COLS) return fail(ISO_ERR_INVALID, "iso_interp_host: k out of range");
+    if (n < 0) return fail(ISO_ERR_INVALID, "iso_interp_host: n < 0");
+    if (n == 0) return ISO_OK;
+    DeviceGuard guard(t->device);
+    std::lock_guard<std::mutex> lock(t->ctx->stage_mu);
+    double *h = nullptr, *d = nullptr;
+    int rc = ctx_stage(t->ctx, &h, &d);
+    if (rc != ISO_OK) return rc;
+    const int nd = t->ndim;
+    const int64_t cap = ISO_CTX_STAGE_DOUBLES / (nd + k);
+    for (int64_t done = 0; done < n; done += cap) {
+        const int64_t c = std::min<int64_t>(cap, n - done);
+        const double* xp[ISO_MAX_DIM];
+        for (int dd = 0; dd < nd; ++dd) {                       // row-major host rows -> one contiguous vector per axis
+            for (int64_t i = 0; i < c; ++i) h[dd * c + i] = x[(done + i) * nd + dd];
+            xp[dd] = d + dd * c;
+        }
+        rc = iso_interp(t, xp, c, icols, k, d + nd * c, nullptr);
+        if (rc != ISO_OK) return rc;
+        HIP_TRY(hipStreamSynchronize(nullptr));
+        std::memcpy(out + done * k, h + nd * c, sizeof(double) * c * k);
+    }
+    return ISO_OK;
+}
+
+int iso_interp_mag_host(iso_ic* ic, const double* pars, int64_t n, const int32_t* bc_cols, int nb, double* Teff,
+                        double* logg, double* feh, double* mags)
+{
+    if (!ic || (!pars && n > 0)) return fail(ISO_ERR_INVALID, "iso_interp_mag_host: NULL argument");
+    if (nb < 0 || nb > ISO_MAX_BANDS) return fail(ISO_ERR_INVALID, "iso_interp_mag_host: nb out of range");
+    if (n < 0) return fail(ISO_ERR_INVALID, "iso_interp_mag_host: n < 0");
+    if (n == 0) return ISO_OK;
+    DeviceGuard guard(ic->device);
+    std::lock_guard<std::mutex> lock(ic->ctx->stage_mu);
+    double *h = nullptr, *d = nullptr;
+    int rc = ctx_stage(ic->ctx, &h, &d);
+    if (rc != ISO_OK) return rc;
+    const int64_t cap = ISO_CTX_STAGE_DOUBLES / (5 + 3 + (nb > 0 ? nb : 1));
+    for (int64_t done = 0; done < n; done += cap) {
+        const int64_t c = std::min<int64_t>(cap, n - done);
+        std::memcpy(h, pars + done * 5, sizeof(double) * c * 5);
+        double *dT = d + 5 * c, *dg = dT + c, *df = dg + c, *dm = df + c;
+        rc = iso_interp_mag(ic, d, 5, 1, c, bc_cols, nb, dT, dg, df, (mags && nb > 0) ? dm : nullptr, nullptr);
+        if (rc != ISO_OK) return rc;
+        HIP_TRY(hipStreamSynchronize(nullptr));
+        if (Teff) std::memcpy(Teff + done, h + 5 * c, sizeof(double) * c);
+        if (logg) std::memcpy(logg + done, h + 6 * c, sizeof(double) * c);
+        if (feh) std::memcpy(feh + done, h + 7 * c, sizeof(double) * c);
+        if (mags && nb > 0) std::memcpy(mags + done * nb, h + 8 * c, sizeof(double) * c * nb);
+    }
+    return ISO_OK;
+}
+
+int iso_interp_eep_host(iso_eep_table* t, const double* age, const double* feh, const double* mass, int64_t n, double* out)
+{
+    if (!t || ((!age || !feh || !mass || !out) && n > 0)) return fail(ISO_ERR_INVALID, "iso_interp_eep_host: NULL argument");
+    if (n < 0) return fail(ISO_ERR_INVALID, "iso_interp_eep_host: n < 0");
+    if (n == 0) return ISO_OK;
+    DeviceGuard guard(t->device);
+    std::lock_guard<std::mutex> lock(t->ctx->stage_mu);
+    double *h = nullptr, *d = nullptr;
+    int rc = ctx_stage(t->ctx, &h, &d);
+    if (rc != ISO_OK) return rc;
+    const int64_t cap = ISO_CTX_STAGE_DOUBLES / 4;
+    for (int64_t done = 0; done < n; done += cap) {
+        const int64_t c = std::min<int64_t>(cap, n - done);
+        std::memcpy(h, age + done, sizeof(double) * c);
+        std::memcpy(h + c, feh + done, sizeof(double) * c);
+        std::memcpy(h + 2 * c, mass + done, sizeof(double) * c);
+        rc = iso_interp_eep(t, d, d + c, d + 2 * c, c, d + 3 * c, nullptr);
+        if (rc != ISO_OK) return rc;
+        HIP_TRY(hipStreamSynchronize(nullptr));
+        std::memcpy(out + done, h + 3 * c, sizeof(double) * c);
+    }
     return ISO_OK;
 }
 

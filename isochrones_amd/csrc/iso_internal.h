@@ -137,7 +137,12 @@ struct StretchArgs {
 
 struct iso_ctx {
     int device;
+    // pinned, device-mapped staging for the *_host entry points (scalar / small-batch calls from Python: one launch
+    // + one synchronise per call, kernels read and write host memory through PCIe); lazily allocated
+    double* h_stage;
+    std::mutex stage_mu;
 };
+constexpr int64_t ISO_CTX_STAGE_DOUBLES = 1 << 17;      // 1 MiB
 
 struct iso_table {
     int device;

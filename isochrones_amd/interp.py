@@ -17,6 +17,9 @@ import numpy as np
 from . import _cabi, device as dev
 
 
+HOST_CALL_ROWS = 4096     # host inputs up to this many rows use the *_host entry points (one launch + one sync)
+
+
 def _is_scalar(v):
     return isinstance(v, (float, int)) and not isinstance(v, bool)
 
@@ -155,9 +158,21 @@ class DFInterpolator:
             xs = [x.reshape(-1).contiguous() for x in xs]
             return self.interp_device(xs, icols, device)
         device = dev.current_device()
-        if all(_is_scalar(x) for x in p):
-            xs = [dev.to_device_f64([float(x)], device) for x in p]
-            return self.interp_device(xs, icols, device).cpu().numpy()[0]
-        b = np.broadcast(*p)
-        xs = [dev.to_device_f64(np.atleast_1d(np.resize(x, b.shape)).astype(float).ravel(), device) for x in p]
+        scalar = all(_is_scalar(x) for x in p)
+        if scalar:
+            rows = np.array([[float(x) for x in p]])
+        else:
+            b = np.broadcast(*p)
+            rows = np.column_stack([np.atleast_1d(np.resize(x, b.shape)).astype(float).ravel() for x in p])
+        n = rows.shape[0]
+        if n <= HOST_CALL_ROWS and icols.size <= _cabi.ISO_MAX_COLS:
+            # scalar calls / small batches: host arrays through the context's pinned staging buffer
+            rows = np.ascontiguousarray(rows)
+            out = np.empty((n, icols.size))
+            dp = C.POINTER(C.c_double)
+            _cabi.check(_cabi.lib().iso_interp_host(self.handle(device), rows.ctypes.data_as(dp), n,
+                                                    icols.ctypes.data_as(C.POINTER(C.c_int32)), icols.size,
+                                                    out.ctypes.data_as(dp)))
+            return out[0] if scalar else out
+        xs = [dev.to_device_f64(np.ascontiguousarray(rows[:, d]), device) for d in range(self.ndim)]
         return self.interp_device(xs, icols, device).cpu().numpy()

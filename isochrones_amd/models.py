@@ -19,6 +19,9 @@ from . import _cabi, device as dev, grids
 from .interp import DFInterpolator
 
 
+from .interp import HOST_CALL_ROWS
+
+
 class TableGrid:
     """Holder of one dense table — the slice of the reference's ``Grid`` API
     (isochrones/grid.py:10-144) that the numeric path reads."""
@@ -242,8 +245,19 @@ class ModelGridInterpolator:
                 raise ValueError("interp_mag needs the five parameters %s" % (self.param_names,))
             b = np.broadcast(*pars)
             p = np.array([np.resize(x, b.shape).astype(float).ravel() for x in pars])
-        Teff, logg, feh, mags = self.interp_mag_device(dev.to_device_f64(p, device), bands, device)
-        Teff, logg, feh, mags = (t.cpu().numpy() for t in (Teff, logg, feh, mags))
+        n = p.shape[1]
+        if n <= HOST_CALL_ROWS and len(bands) <= _cabi.ISO_MAX_BANDS:
+            rows = np.ascontiguousarray(p.T)
+            Teff, logg, feh = np.empty(n), np.empty(n), np.empty(n)
+            mags = np.empty((n, len(bands)))
+            dp = C.POINTER(C.c_double)
+            bc_cols, bcp = dev.i32_array(self._band_cols(bands))
+            _cabi.check(_cabi.lib().iso_interp_mag_host(self.handle(device), rows.ctypes.data_as(dp), n, bcp, len(bands),
+                                                        Teff.ctypes.data_as(dp), logg.ctypes.data_as(dp),
+                                                        feh.ctypes.data_as(dp), mags.ctypes.data_as(dp)))
+        else:
+            Teff, logg, feh, mags = self.interp_mag_device(dev.to_device_f64(p, device), bands, device)
+            Teff, logg, feh, mags = (t.cpu().numpy() for t in (Teff, logg, feh, mags))
         if scalar:
             return Teff[0], logg[0], feh[0], mags[0]
         return Teff, logg, feh, mags
@@ -348,7 +362,14 @@ class ModelGridInterpolator:
         device = dev.current_device()
         scalar = all(isinstance(x, (float, int, np.floating, np.integer)) for x in args)
         b = np.broadcast(*args)
-        m, a, f = [dev.to_device_f64(np.atleast_1d(np.resize(x, b.shape)).astype(float).ravel(), device) for x in args]
+        hm, ha, hf = [np.ascontiguousarray(np.atleast_1d(np.resize(x, b.shape)).astype(float).ravel()) for x in args]
+        if hm.size <= HOST_CALL_ROWS:
+            res = np.empty(hm.size)
+            dp = C.POINTER(C.c_double)
+            _cabi.check(_cabi.lib().iso_interp_eep_host(self._eep_handle(device), ha.ctypes.data_as(dp), hf.ctypes.data_as(dp),
+                                                        hm.ctypes.data_as(dp), hm.size, res.ctypes.data_as(dp)))
+            return float(res[0]) if scalar else res
+        m, a, f = [dev.to_device_f64(x, device) for x in (hm, ha, hf)]
         out = dev.empty_f64((m.numel(),), device)
         _cabi.check(_cabi.lib().iso_interp_eep(self._eep_handle(device), dev.ptr(a), dev.ptr(f), dev.ptr(m),
                                                m.numel(), dev.ptr(out), dev.stream_ptr(device)))
