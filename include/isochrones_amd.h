@@ -263,6 +263,9 @@ int  iso_tree_model_create(iso_ic* ic, const iso_tree_desc* desc, iso_tree_model
 void iso_tree_model_destroy(iso_tree_model* m);
 int  iso_tree_lnpost(iso_tree_model* m, const double* pars, int64_t stride_n, int64_t stride_p, int64_t n,
                      double* lnpost_out, double* lnprior_out, double* lnlike_out, void* stream);
+/* The same for HOST arrays (pars [n][n_params] row-major), as iso_lnpost_host: the sampler-callback form. */
+int  iso_tree_lnpost_host(iso_tree_model* m, const double* pars, int64_t n, double* lnpost_out, double* lnprior_out,
+                          double* lnlike_out);
 
 /* Device-resident affine-invariant ensemble sampler (stretch move, Goodman & Weare 2010) — what the
  * reference obtains from emcee.EnsembleSampler(nwalkers, npars, self.lnpost).run_mcmc(...)

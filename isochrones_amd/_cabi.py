@@ -101,7 +101,7 @@ EXPORTED_SYMBOLS = (
     "iso_eep_table_create", "iso_eep_table_destroy", "iso_interp_eep", "iso_interp_eep_host",
     "iso_sampler_create_model", "iso_sampler_create_catalog", "iso_sampler_destroy", "iso_sampler_run",
     "iso_chain_quantiles",
-    "iso_tree_model_create", "iso_tree_model_destroy", "iso_tree_lnpost",
+    "iso_tree_model_create", "iso_tree_model_destroy", "iso_tree_lnpost", "iso_tree_lnpost_host",
 )
 
 _LIB = None
@@ -188,6 +188,7 @@ def lib():
     L.iso_tree_model_destroy.argtypes = [vp]
     L.iso_tree_model_destroy.restype = None
     L.iso_tree_lnpost.argtypes = [vp, pd, i64, i64, i64, pd, pd, pd, vp]
+    L.iso_tree_lnpost_host.argtypes = [vp, C.POINTER(dbl), i64, C.POINTER(dbl), C.POINTER(dbl), C.POINTER(dbl)]
     for name in EXPORTED_SYMBOLS:
         fn = getattr(L, name)
         if fn.restype is C.c_int:

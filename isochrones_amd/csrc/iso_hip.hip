@@ -1547,6 +1547,37 @@ int iso_tree_lnpost(iso_tree_model* m, const double* pars, int64_t stride_n, int
     return ISO_OK;
 }
 
+int iso_tree_lnpost_host(iso_tree_model* m, const double* pars, int64_t n, double* lnpost_out, double* lnprior_out,
+                         double* lnlike_out)
+{
+    if (!m || (!pars && n > 0)) return fail(ISO_ERR_INVALID, "iso_tree_lnpost_host: NULL argument");
+    if (n < 0) return fail(ISO_ERR_INVALID, "iso_tree_lnpost_host: n < 0");
+    if (!lnpost_out && !lnprior_out && !lnlike_out) return fail(ISO_ERR_INVALID, "iso_tree_lnpost_host: no output requested");
+    if (n == 0) return ISO_OK;
+    DeviceGuard guard(m->device);
+    iso_ctx* ctx = m->ic->ctx;
+    std::lock_guard<std::mutex> lock(ctx->stage_mu);
+    double *h = nullptr, *d = nullptr;
+    int rc = ctx_stage(ctx, &h, &d);
+    if (rc != ISO_OK) return rc;
+    const int np_ = m->n_params;
+    const int64_t cap = ISO_CTX_STAGE_DOUBLES / (np_ + 3);
+    for (int64_t done = 0; done < n; done += cap) {
+        const int64_t c = std::min<int64_t>(cap, n - done);
+        std::memcpy(h, pars + done * np_, sizeof(double) * c * np_);
+        double *dpost = d + c * np_, *dprior = dpost + c, *dlike = dprior + c;
+        rc = iso_tree_lnpost(m, d, np_, 1, c, lnpost_out ? dpost : nullptr, lnprior_out ? dprior : nullptr,
+                             lnlike_out ? dlike : nullptr, nullptr);
+        if (rc != ISO_OK) return rc;
+        HIP_TRY(hipStreamSynchronize(nullptr));
+        const double* hp = h + c * np_;
+        if (lnpost_out) std::memcpy(lnpost_out + done, hp, sizeof(double) * c);
+        if (lnprior_out) std::memcpy(lnprior_out + done, hp + c, sizeof(double) * c);
+        if (lnlike_out) std::memcpy(lnlike_out + done, hp + 2 * c, sizeof(double) * c);
+    }
+    return ISO_OK;
+}
+
 namespace {
 int sampler_common(iso_sampler* sp, int device, int kind, int n_stars, int n_bands, int64_t n_ens, const FastArgs& F,
                    int multi, int nwalkers, double a, uint64_t seed)

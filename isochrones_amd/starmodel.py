@@ -787,10 +787,22 @@ class TreeStarModel(_NestedFitMixin):
             out = self.evaluate_device(p.double()[None, :] if single else p.double(), parts=which != 0)
             out = out if which == 0 else out[which]
             return out[0] if single else out
-        arr = np.asarray(p, dtype=float)
+        arr = np.ascontiguousarray(p, dtype=np.float64)
         single = arr.ndim == 1
+        a2 = arr[None, :] if single else arr
         device = dev.current_device()
-        out = self.evaluate_device(dev.to_device_f64(arr[None, :] if single else arr, device), parts=which != 0)
+        if a2.ndim == 2 and a2.shape[0] <= 65536:
+            # host arrays of sampler-callback size: one C call through the context's pinned staging buffer
+            if a2.shape[1] != self.n_params:
+                raise ValueError("expected [N, %d]" % self.n_params)
+            n = a2.shape[0]
+            out = np.empty(n)
+            dp = C.POINTER(C.c_double)
+            ptrs = [None, None, None]
+            ptrs[which] = out.ctypes.data_as(dp)
+            _cabi.check(_cabi.lib().iso_tree_lnpost_host(self.handle(device), a2.ctypes.data_as(dp), n, *ptrs))
+            return float(out[0]) if single else out
+        out = self.evaluate_device(dev.to_device_f64(a2, device), parts=which != 0)
         out = (out if which == 0 else out[which]).cpu().numpy()
         return float(out[0]) if single else out
 
