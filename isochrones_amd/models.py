@@ -191,8 +191,12 @@ class ModelGridInterpolator:
         return self.model_grid.interp(p, props)
 
     def _band_cols(self, bands):
-        cols = self.bc_grid.interp.columns
-        return np.array([cols.index(b) for b in bands], dtype=np.int32)
+        key = tuple(bands)
+        cache = self.__dict__.setdefault("_band_col_cache", {})
+        if key not in cache:
+            cols = self.bc_grid.interp.columns
+            cache[key] = np.array([cols.index(b) for b in bands], dtype=np.int32)
+        return cache[key]
 
     def interp_mag_device(self, pars, bands=None, device=None):
         """pars: CUDA float64 tensor [5, N] (SoA) -> (Teff[N], logg[N], feh[N], mags[N, nb]) tensors."""
