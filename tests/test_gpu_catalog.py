@@ -642,3 +642,24 @@ def test_chain_quantiles_adversarial_inputs(mode, monkeypatch):
         assert np.array_equal(np.isfinite(got), fin), (nsteps, S, W, D)
         assert np.array_equal(got[fin], want[fin]), (nsteps, S, W, D, np.abs(got[fin] - want[fin]).max())      # bit for bit
         assert np.array_equal(got[~fin & ~np.isnan(want)], want[~fin & ~np.isnan(want)])
+
+
+def test_fit_multinest_binary_model_respects_ordering():
+    """Nested fit of a BinaryStarModel: the flat-box prior covers both orderings of the two EEPs, lnpost is -inf
+    for eep_1 > eep_0 (starmodel.py:1618-1620), so every posterior sample must be ordered and about half of the
+    box has no support."""
+    ages = ia.grids.mist_log_ages()[60::2]
+    ic = ia.synthetic_isochrone(bands=("J", "H", "K"), ages=ages, fehs=[-1.0, -0.5, 0.0, 0.5], eeps=np.arange(150.0, 700.0),
+                                eep_bounds=(150, 699), limits=dict(age=(ages[0], ages[-1]), feh=(-1.0, 0.5)))
+    truth = np.array([380.0, 330.0, 9.6, -0.1, 300.0, 0.1])
+    m0 = ic.interp_mag([truth[0], *truth[2:]], ["J", "H", "K"])[3]
+    m1 = ic.interp_mag([truth[1], *truth[2:]], ["J", "H", "K"])[3]
+    mags = -2.5 * np.log10(10 ** (-0.4 * m0) + 10 ** (-0.4 * m1))
+    mod = ia.BinaryStarModel(ic, J=(mags[0], 0.02), H=(mags[1], 0.02), K=(mags[2], 0.02), parallax=(1000 / 300.0, 0.05))
+    res = mod.fit_multinest(n_live_points=300, seed=4)
+    s = mod.samples
+    assert np.isfinite(res.logz) and res.prior_fraction < 0.6
+    assert np.all(s["eep_0"] >= s["eep_1"]) and np.isfinite(s["lnprob"]).all()
+    assert abs(np.median(s["distance"]) - 300.0) < 30.0
+    d = mod.derived_samples
+    assert {"mass_0", "mass_1", "J_mag"} <= set(d.columns)
