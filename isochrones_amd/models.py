@@ -182,6 +182,25 @@ class ModelGridInterpolator:
             pass
 
     # -- hot path ---------------------------------------------------------------------------
+    def initialize(self, pars=None):
+        """Make the interpolator ready for use (reference: models.py:349-358 triggers the numba compilation with one
+        call; here: upload / pack the tables on the current device and run one evaluation)."""
+        if pars is None:
+            lo_e, hi_e = self.eep_bounds
+            mid = 0.5 * (lo_e + hi_e)
+            if self.eep_replaces == "age":
+                m = self.model_grid.masses
+                pars = [float(m[len(m) // 2]), mid, float(self.fehs[len(self.fehs) // 2]), 100.0, 0.1]
+            else:
+                a = self.model_grid.ages
+                pars = [mid, float(a[len(a) // 2]), float(self.fehs[len(self.fehs) // 2]), 100.0, 0.1]
+        self.handle()
+        return self.interp_mag(pars, self.bands)
+
+    @property
+    def name(self):
+        return type(self).__name__
+
     def interp_value(self, pars, props):
         """Interpolate model-table columns ``props`` at ``pars`` (in ``param_names`` order; only
         the first three are used).  reference: isochrones/models.py:390-400"""
