@@ -584,6 +584,8 @@ def test_docs_grid_interpolator_notebook_flow():
     import pandas as pd
     from isochrones_amd.mist import MIST_EvolutionTrack, MIST_Isochrone
     mist = MIST_Isochrone()
+    T0, g0, f0, m0 = mist.initialize()                          # tables on the device + one evaluation
+    assert np.isfinite(T0) and m0.shape == (len(mist.bands),) and mist.name == "IsochroneInterpolator"
     pars = [353, 9.78, -1.24]                                    # eep, log(age), feh
     v = mist.interp_value(pars, ["mass", "radius", "Teff"])
     assert v.shape == (3,) and np.all(np.isfinite(v))
