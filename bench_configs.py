@@ -211,7 +211,10 @@ def nested(nlive=1000):
     t = time.perf_counter()
     res = mod.fit_multinest(n_live_points=nlive, seed=1)
     wall = time.perf_counter() - t
-    return {"config": "nested", "metric": "wall-clock of fit_multinest, %d live points, cfg-2 star" % nlive,
+    t = time.perf_counter()
+    res_c = mod.fit_multinest(n_live_points=nlive, seed=1, batched=False)
+    wall_classic = time.perf_counter() - t
+    return {"config": "nested", "wall_s_classic_loop": wall_classic, "logz_classic_loop": res_c.logz, "metric": "wall-clock of fit_multinest, %d live points, cfg-2 star" % nlive,
             "wall_s": wall, "lnpost_evaluations": res.ncall, "iterations": res.niter, "efficiency": res.efficiency,
             "logz": res.logz, "logz_err": res.logz_err, "prior_fraction_with_support": res.prior_fraction,
             "reference_published_estimate_s": [69e-6 * res.ncall, 719e-6 * res.ncall]}

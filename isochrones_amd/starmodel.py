@@ -73,17 +73,21 @@ class _NestedFitMixin:
     sampler in isochrones_amd/nested.py, every proposal batch being one fused lnpost launch."""
 
     def fit_multinest(self, n_live_points=1000, basename=None, verbose=False, refit=False, overwrite=False,
-                      test=False, evidence_tolerance=0.5, seed=0, **kwargs):
-        from .nested import nested_sample
+                      test=False, evidence_tolerance=0.5, seed=0, batched=True, **kwargs):
+        """``batched=True`` (default) retires n_live_points // 10 live points per macro-step with a vectorised host
+        loop; ``batched=False`` is the classic one-point-per-iteration loop.  Same integral, same result object."""
+        from .nested import nested_sample, nested_sample_batched
         names = list(self.param_names)
         lo = np.array([self.bounds(nm)[0] for nm in names], dtype=float)
         hi = np.array([self.bounds(nm)[1] for nm in names], dtype=float)
         run_kwargs = dict(nlive=int(n_live_points), tol=float(evidence_tolerance), seed=seed)
-        run_kwargs.update({k: v for k, v in kwargs.items() if k in ("enlarge", "batch", "max_batch", "max_calls", "max_iter")})
+        allowed = ("enlarge", "max_batch", "max_calls", "max_iter") + (("remove",) if batched else ("batch",))
+        run_kwargs.update({k: v for k, v in kwargs.items() if k in allowed})
         if test:
             print("nested_sample() with the following kwargs: {}".format(run_kwargs))
             return None
-        res = nested_sample(lambda th: self.lnpost(np.ascontiguousarray(th)), lo, hi, **run_kwargs)
+        run = nested_sample_batched if batched else nested_sample
+        res = run(lambda th: self.lnpost(np.ascontiguousarray(th)), lo, hi, **run_kwargs)
         self._nested = res
         self._samples = None
         self._fit_kind = "nested"

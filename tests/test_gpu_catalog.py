@@ -245,7 +245,7 @@ def test_fit_multinest_native_matches_mcmc_posterior(tmp_path):
     assert post.shape[1] == 6 and post.shape[0] > 200
     s_nest = mod.samples
     assert {"mass", "eep", "feh", "distance", "AV", "lnprob", "Teff", "G_mag"} <= set(s_nest.columns)
-    res2 = mod.fit_multinest(n_live_points=600, seed=2)
+    res2 = mod.fit_multinest(n_live_points=600, seed=2, batched=False)          # classic loop: same integral
     assert abs(res2.logz - logz) < 4 * np.hypot(err, res2.logz_err) + 0.05
     # brute force: Z = mean over the prior box of exp(lnpost)
     names = mod.param_names
@@ -451,7 +451,7 @@ def test_tree_model_fits_and_quantile_errors():
     s = mod.samples
     assert len(s) == 400 and list(s.columns[:-1]) == list(mod.param_names) and np.isfinite(s["lnprob"]).all()
     res = mod.fit_multinest(n_live_points=60, max_iter=400, seed=3)
-    assert np.isfinite(res.logz) and res.niter <= 400
+    assert np.isfinite(res.logz) and res.niter < 400 + 6          # a macro-step retires n_live // 10 points at a time
     lz, err = mod.evidence
     assert lz == res.logz and err > 0 and len(mod.samples) >= 1
     # iso_chain_quantiles refuses what it cannot sort in LDS / bad levels
