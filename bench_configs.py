@@ -202,6 +202,50 @@ def astero(n=1_000_000, reps=50):
     return {"config": "astero", "metric": "lnpost evals/s with nu_max + delta_nu terms, 1e6 batch", "bytes_per_eval": 560 + 128, **out}
 
 
+def published():
+    """The timings the reference records in its notebooks (laptop CPU, numba), repeated here through the same
+    Python calls on the MIST-shaped synthetic tables."""
+    import isochrones_amd as ia
+    from isochrones_amd.mist import MIST_EvolutionTrack, MIST_Isochrone
+    out = {}
+
+    def tm(f, n=1, warm=1):
+        for _ in range(warm):
+            f()
+        t = time.perf_counter()
+        for _ in range(n):
+            r = f()
+        return (time.perf_counter() - t) / n, r
+
+    trk = MIST_EvolutionTrack()
+    iso = MIST_Isochrone(bands=["J", "H", "K", "BP", "RP", "G"])
+    rng = np.random.default_rng(0)
+    x = [rng.uniform(-1, 0.4, 10000), rng.uniform(0.5, 2.0, 10000), rng.uniform(200, 600, 10000)]
+    out["track_grid.interp 10000 3-D points, 1 column (host arrays) [s]"] = \
+        {"here": tm(lambda: trk.model_grid.interp(x, ["radius"]), 50)[0], "reference": 4.01e-3}
+    out["track_grid.interp single 3-D point, 1 column [s]"] = \
+        {"here": tm(lambda: trk.model_grid.interp([-0.12, 1.01, 353.1], ["radius"]), 2000)[0], "reference": 12.5e-6}
+    N = 10000
+    mass, age, feh = np.ones(N) * 1.01, np.ones(N) * 9.82, np.ones(N) * 0.02
+    out["mist_track.generate(mass, age, feh), N = 10000 [s]"] = {"here": tm(lambda: trk.generate(mass, age, feh), 10)[0],
+                                                                "reference": 112e-3}
+    out["get_eep single [s]"] = {"here": tm(lambda: trk.get_eep(1.01, 9.51, 0.01), 2000)[0], "reference": 4.26e-6}
+    out["get_eep single, accurate=True [s]"] = {"here": tm(lambda: trk.get_eep(1.01, 9.51, 0.01, accurate=True), 20)[0],
+                                               "reference": 4.56e-3}
+    single = ia.SingleStarModel(iso, Teff=(5770, 80), feh=(0.0, 0.1), logg=(4.44, 0.08), J=(9.0, 0.02), H=(8.7, 0.02), K=(8.6, 0.02))
+    out["StarModel.lnpost(p), single star, spectroscopy + J, H, K [s]"] = \
+        {"here": tm(lambda: single.lnpost([355.0, 9.6, 0.0, 100.0, 0.1]), 2000)[0], "reference": 69e-6}
+    binary = ia.BinaryStarModel(iso, J=(9.3, 0.02), H=(9.0, 0.02), K=(8.95, 0.02), BP=(10.7, 0.002), RP=(9.8, 0.002),
+                                G=(10.3, 0.001), parallax=(2.0, 0.05))
+    pb = [350.0, 300.0, 9.7, 0.0, 500.0, 0.2]
+    out["BinaryStarModel.lnpost(pars), 6 bands + parallax [s]"] = {"here": tm(lambda: binary.lnpost(pb), 2000)[0],
+                                                                  "reference": 719e-6}
+    dt, res = tm(lambda: binary.fit_multinest(n_live_points=2000, seed=1), 1, warm=0)
+    out["binary nested fit, 2000 live points [s]"] = {"here": dt, "reference": 14 * 60.0, "lnpost_evaluations": res.ncall,
+                                                     "logz": res.logz}
+    return {"config": "published", "metric": "the reference's notebook timings (SURVEY 6) vs the same calls here", **out}
+
+
 def nested(nlive=1000):
     """fit_multinest on the cfg-2 star (full-size tables): batched nested sampling, one fused lnpost
     launch per proposal batch.  The reference runs MultiNest with one Python lnpost call per point."""
@@ -358,7 +402,7 @@ def main():
     args = ap.parse_args()
     for name in args.configs.split(","):
         fn = {"cfg1": cfg1, "cfg3": cfg3, "cfg4": cfg4, "cfg5": lambda: cfg5(args.stars),
-              "primitives": primitives, "tree": tree, "nested": nested, "astero": astero}[name.strip()]
+              "primitives": primitives, "tree": tree, "nested": nested, "astero": astero, "published": published}[name.strip()]
         r = fn()
         if r is not None:
             print(json.dumps(r), flush=True)

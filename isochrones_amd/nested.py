@@ -73,13 +73,19 @@ def _draw_in_ellipsoid(rng, mean, A, m):
 
 
 def nested_sample_batched(loglike, lo, hi, nlive=1000, tol=0.5, enlarge=1.5, remove=None, max_batch=1 << 20,
-                          max_calls=int(2e9), seed=0, max_iter=None):
+                          max_calls=int(2e9), seed=0, max_iter=None, propose=None):
     """The same integral with the K = ``remove`` lowest live points retired per macro-step (default nlive // 10) and
     all K replacements drawn above the highest of their thresholds — nested sampling with a live-point count that
     drops from nlive to nlive - K + 1 inside a macro-step (shrinkage exp(-1 / n_live) per retired point, as in
     dynamic nested sampling / the final live-point sweep).  Everything inside a macro-step is vectorised, so the
     host loop is ~nlive / K times shorter than in :func:`nested_sample`; the price is a slightly lower proposal
-    efficiency (every replacement must beat the batch's highest threshold).  Same result object."""
+    efficiency (every replacement must beat the batch's highest threshold).  Same result object.
+
+    ``propose(mean, A, want, threshold) -> (u [k, d], logl [k], n_evaluated)``, optional: draws ``want`` points
+    uniformly in the ellipsoid ``{mean + A z, |z| <= 1}`` of the unit cube, evaluates them and returns the ones
+    inside the cube with logl > threshold (``mean is None``: uniform in the cube).  Models pass a device-resident
+    implementation (random numbers, transform, lnpost and the threshold test on the GPU; only the accepted points
+    come back), which is what keeps hard posteriors - proposal efficiencies of 1e-3 and below - cheap."""
     lo = np.asarray(lo, dtype=float)
     hi = np.asarray(hi, dtype=float)
     d = lo.size
@@ -103,11 +109,16 @@ def nested_sample_batched(loglike, lo, hi, nlive=1000, tol=0.5, enlarge=1.5, rem
     tried = 0
     m = max(4 * nlive, 4096)
     while live_l.size < nlive:
-        u = rng.random((m, d))
-        ll = evaluate(u)
-        ok = ll > -np.inf
-        live_u = np.vstack([live_u, u[ok]])
-        live_l = np.concatenate([live_l, ll[ok]])
+        if propose is not None:
+            u_ok, l_ok, n_ev = propose(None, None, m, -np.inf)
+            ncall += n_ev
+        else:
+            u = rng.random((m, d))
+            ll = evaluate(u)
+            ok = ll > -np.inf
+            u_ok, l_ok = u[ok], ll[ok]
+        live_u = np.vstack([live_u, u_ok])
+        live_l = np.concatenate([live_l, l_ok])
         tried += m
         if tried > max_calls or (tried >= 64 * m and live_l.size == 0):
             raise RuntimeError("nested_sample: no point of the prior box has a finite log-likelihood")
@@ -142,15 +153,20 @@ def nested_sample_batched(loglike, lo, hi, nlive=1000, tol=0.5, enlarge=1.5, rem
         mean, A = _bounding_ellipsoid(live_u[keep], enlarge)
         new_u, new_l = np.empty((0, d)), np.empty(0)
         while new_l.size < K:
-            want = int(np.clip((K - new_l.size) / max(eff, 1e-6) * 1.3, 256, max_batch))
-            cand = _draw_in_ellipsoid(rng, mean, A, want)
-            if cand.shape[0] == 0:
-                continue
-            cl = evaluate(cand)
-            okc = cl > thr[-1]
-            eff = 0.5 * eff + 0.5 * max(okc.sum(), 1) / want
-            new_u = np.vstack([new_u, cand[okc]])
-            new_l = np.concatenate([new_l, cl[okc]])
+            want = int(np.clip((K - new_l.size) / max(eff, 1e-7) * 1.3, 256, max_batch))
+            if propose is not None:
+                u_ok, l_ok, n_ev = propose(mean, A, want, float(thr[-1]))
+                ncall += n_ev
+            else:
+                cand = _draw_in_ellipsoid(rng, mean, A, want)
+                if cand.shape[0] == 0:
+                    continue
+                cl = evaluate(cand)
+                okc = cl > thr[-1]
+                u_ok, l_ok = cand[okc], cl[okc]
+            eff = 0.5 * eff + 0.5 * max(l_ok.size, 1) / want
+            new_u = np.vstack([new_u, u_ok])
+            new_l = np.concatenate([new_l, l_ok])
             if ncall > max_calls:
                 raise RuntimeError("nested_sample: max_calls exceeded (efficiency %.2e)" % eff)
         live_u[idx] = new_u[:K]

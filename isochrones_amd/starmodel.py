@@ -87,6 +87,8 @@ class _NestedFitMixin:
             print("nested_sample() with the following kwargs: {}".format(run_kwargs))
             return None
         run = nested_sample_batched if batched else nested_sample
+        if batched:
+            run_kwargs["propose"] = self._device_proposer(lo, hi, seed)
         res = run(lambda th: self.lnpost(np.ascontiguousarray(th)), lo, hi, **run_kwargs)
         self._nested = res
         self._samples = None
@@ -101,6 +103,35 @@ class _NestedFitMixin:
             x, ll = res.equal_weight_samples(rng=np.random.default_rng(seed))
             np.savetxt("{}post_equal_weights.dat".format(basename), np.column_stack([x, ll]))
         return res
+
+    def _device_proposer(self, lo, hi, seed):
+        """Proposals of the nested sampler on the device: uniform draws in the bounding ellipsoid (or the unit
+        cube), the flat-box transform, lnpost and the likelihood-threshold test all stay in HBM; only the
+        accepted points travel back."""
+        import torch
+        device = torch.device("cuda", dev.current_device())
+        lo_t = torch.as_tensor(lo, dtype=torch.float64, device=device)
+        span_t = torch.as_tensor(np.asarray(hi) - np.asarray(lo), dtype=torch.float64, device=device)
+        gen = torch.Generator(device=device)
+        gen.manual_seed(int(seed) + 0x5EED)
+        d = len(lo)
+
+        def propose(mean, A, want, threshold):
+            if mean is None:
+                u = torch.rand(want, d, generator=gen, device=device, dtype=torch.float64)
+            else:
+                z = torch.randn(want, d, generator=gen, device=device, dtype=torch.float64)
+                r = torch.rand(want, generator=gen, device=device, dtype=torch.float64) ** (1.0 / d)
+                z = z * (r / z.norm(dim=1))[:, None]
+                u = torch.as_tensor(mean, device=device) + z @ torch.as_tensor(A, device=device).T
+                u = u[((u >= 0.0) & (u <= 1.0)).all(dim=1)]
+            if u.shape[0] == 0:
+                return np.empty((0, d)), np.empty(0), want
+            ll = self.lnpost(lo_t + u * span_t)
+            ok = torch.isfinite(ll) & (ll > threshold)
+            return u[ok].cpu().numpy(), ll[ok].cpu().numpy(), want
+
+        return propose
 
     @property
     def evidence(self):
