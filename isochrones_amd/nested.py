@@ -195,8 +195,11 @@ def nested_sample_batched(loglike, lo, hi, nlive=1000, tol=0.5, enlarge=1.5, rem
 
 
 def nested_sample(loglike, lo, hi, nlive=1000, tol=0.5, enlarge=1.5, batch=None, max_batch=1 << 20, max_calls=int(2e9),
-                  seed=0, max_iter=None):
+                  seed=0, max_iter=None, propose=None):
     """Nested sampling of ``exp(loglike(theta))`` under the flat prior on the box [lo, hi].
+
+    ``propose``: optional device-side proposal hook, see :func:`nested_sample_batched` (only the draws above
+    the current threshold are queued).
 
     loglike : callable, [n, ndim] float64 array -> [n] (NaN / -inf = zero likelihood)
     tol     : stop when the live points could add less than ``tol`` to logZ (MultiNest's
@@ -273,11 +276,18 @@ def nested_sample(loglike, lo, hi, nlive=1000, tol=0.5, enlarge=1.5, batch=None,
             eff = max(accepted_since_refill, 1) / max(drawn_since_refill, 1)
             want = int(np.clip((nlive // 4) / max(eff, 1e-6), 1024, max_batch)) if batch is None else int(batch)
             mean, A = _bounding_ellipsoid(live_u, enlarge)
-            cand = _draw_in_ellipsoid(rng, mean, A, want)
             accepted_since_refill, drawn_since_refill = 0, want
-            if cand.shape[0] == 0:
-                continue
-            queue_u, queue_l, qpos = cand, evaluate(cand), 0
+            if propose is not None:
+                queue_u, queue_l, n_ev = propose(mean, A, want, float(lmin))
+                ncall += n_ev
+                qpos = 0
+                if queue_l.size == 0:
+                    continue
+            else:
+                cand = _draw_in_ellipsoid(rng, mean, A, want)
+                if cand.shape[0] == 0:
+                    continue
+                queue_u, queue_l, qpos = cand, evaluate(cand), 0
             if ncall > max_calls:
                 raise RuntimeError("nested_sample: max_calls exceeded (efficiency %.2e)" % eff)
         live_u[i] = queue_u[qpos]

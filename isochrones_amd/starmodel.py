@@ -87,8 +87,7 @@ class _NestedFitMixin:
             print("nested_sample() with the following kwargs: {}".format(run_kwargs))
             return None
         run = nested_sample_batched if batched else nested_sample
-        if batched:
-            run_kwargs["propose"] = self._device_proposer(lo, hi, seed)
+        run_kwargs["propose"] = self._device_proposer(lo, hi, seed)
         res = run(lambda th: self.lnpost(np.ascontiguousarray(th)), lo, hi, **run_kwargs)
         self._nested = res
         self._samples = None
