@@ -191,10 +191,14 @@ class GaussianPrior(Prior):
         else:
             self.bounded = 0
             self.norm = 1.0
-        self.lognorm = math.log(self.norm)
+        # a truncation window that holds no probability mass gives norm = 0: -inf, as numpy's log in the reference
+        # (priors.py:246-247), not an exception
+        self.lognorm = math.log(self.norm) if self.norm > 0 else -math.inf
 
     def _raw(self, x):
         z = (x - self.mean) / self.sigma
+        if self.norm == 0:
+            return math.inf
         return math.exp(-(z * z) / 2.0) / _ROOT_2PI / self.sigma / self.norm
 
     def lnpdf(self, x):
