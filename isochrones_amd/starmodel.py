@@ -464,28 +464,42 @@ class BasicStarModel(_NestedFitMixin):
     def emcee_p0(self, nwalkers, rng=None):
         return self.sample_from_prior(nwalkers, values=True, rng=rng, require_valid=True)
 
-    def fit_mcmc(self, nwalkers=300, nburn=200, niter=100, p0=None, seed=None, fused=None, **kwargs):
-        """Burn in, reset, sample (reference: fit_mcmc_old).  ``fused`` selects the single-kernel
-        sampler (default: used whenever the model is on the corner-packed fast path, else the
-        framework-op sampler, which evaluates lnpost through the same HIP kernels)."""
+    def fit_mcmc(self, nwalkers=300, nburn=200, niter=100, p0=None, initial_burn=None, ninitial=50, seed=None,
+                 fused=None, **kwargs):
+        """Burn in, reset, sample (reference: fit_mcmc_old, starmodel.py:889-972).  ``initial_burn``: run
+        ``ninitial`` iterations from the prior draws first and restart every walker in a 0.1 % ball around the best
+        point found (the reference's re-initialisation).  ``fused`` selects the single-kernel sampler (default: used
+        whenever the model is on the corner-packed fast path, else the framework-op sampler, which evaluates lnpost
+        through the same HIP kernels)."""
         import torch
         from .sampler import EnsembleSampler, FusedEnsembleSampler
         rng = np.random.default_rng(seed)
         npars = self.n_params
+        device = torch.device("cuda", dev.current_device())
+
+        def make_sampler():
+            if fused is None or fused:
+                try:
+                    return FusedEnsembleSampler(self, nwalkers, seed=int(rng.integers(2 ** 62)))
+                except _cabi.IsoError:
+                    if fused:
+                        raise
+            return EnsembleSampler(nwalkers, npars, self.lnpost, seed=int(rng.integers(2 ** 62)), device=device)
+
         if p0 is None:
             p0 = self.emcee_p0(nwalkers, rng=rng)
+            if initial_burn:
+                first = make_sampler()
+                first.run_mcmc(p0, ninitial)
+                flat = first.flatlnprobability
+                best = first.flatchain[int(torch.argmax(flat))].cpu().numpy()
+                ball = best * (1 + rng.normal(size=p0.shape) * 0.001)
+                bad = ~np.isfinite(self.lnpost(ball))
+                ball[bad] = best                       # a perturbed walker that left the support restarts on the point
+                p0 = ball
         else:
             p0 = rng.normal(size=(nwalkers, npars)) * 0.01 + np.asarray(p0, dtype=float)[None, :]
-        device = torch.device("cuda", dev.current_device())
-        sampler = None
-        if fused is None or fused:
-            try:
-                sampler = FusedEnsembleSampler(self, nwalkers, seed=int(rng.integers(2 ** 62)))
-            except _cabi.IsoError:
-                if fused:
-                    raise
-        if sampler is None:
-            sampler = EnsembleSampler(nwalkers, npars, self.lnpost, seed=int(rng.integers(2 ** 62)), device=device)
+        sampler = make_sampler()
         pos, prob = sampler.run_mcmc(p0, nburn, store=False)
         sampler.reset()
         sampler.run_mcmc(pos, niter, lnprob0=prob)

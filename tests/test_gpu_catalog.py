@@ -275,6 +275,9 @@ def test_reference_test_fits_flow(tmp_path):
     mod = ia.StarModel(ic, **props)
     mod.fit_mcmc(nburn=20, niter=20, ninitial=20, seed=3)
     s = mod.samples
+    mod.fit_mcmc(nburn=20, niter=20, ninitial=20, initial_burn=True, seed=3)      # the reference's re-initialisation
+    s2 = mod.samples
+    assert len(s2) == len(s) and np.isfinite(s2["lnprob"]).all() and s2["lnprob"].max() >= s["lnprob"].max() - 5
     assert len(s) == 300 * 20 and np.isfinite(s["lnprob"]).all()
     assert {"eep", "age", "feh", "distance", "AV", "Teff", "logg", "J_mag", "K_mag"} <= set(s.columns)
     base = str(tmp_path / "chains" / "123456-")
