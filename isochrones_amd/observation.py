@@ -142,6 +142,36 @@ class ObservationTree:
             tree.add_observation(Observation(n, b, g.resolution.mean(), sources=sources, relative=g.relative.any()))
         return tree
 
+    def to_df(self):
+        """The photometry as a DataFrame that :meth:`from_df` reads back (reference: observation.py:796-835)."""
+        import pandas as pd
+        rows = [dict(name=o.name, band=o.band, resolution=o.resolution, mag=s.mag, e_mag=s.e_mag,
+                     separation=s.separation, pa=s.pa, relative=s.relative)
+                for o in self._observations for s in o.sources]
+        return pd.DataFrame(rows, columns=["name", "band", "resolution", "mag", "e_mag", "separation", "pa", "relative"])
+
+    def print_ascii(self, fout=None, p=None):
+        """The tree as indented text, one node per line (the reference draws the same hierarchy with asciitree,
+        observation.py:167-172, 1175-1179); with a parameter vector ``p`` the model leaves show their parameters."""
+        pardict = self.p2pardict(p) if p is not None else None
+        lines = []
+
+        def emit(node, prefix, last):
+            text = self.name if node.kind == "root" and getattr(self, "name", None) else node.label
+            if pardict is not None and node.kind == "model" and node.label in pardict:
+                text += " = " + ", ".join("%.4g" % v for v in pardict[node.label])
+            lines.append(prefix + ("" if node.kind == "root" else ("+-- " if last else "|-- ")) + str(text))
+            kids = node.children
+            for k, c in enumerate(kids):
+                emit(c, prefix + ("" if node.kind == "root" else ("    " if last else "|   ")), k == len(kids) - 1)
+
+        emit(self.root, "", True)
+        out = "\n".join(lines) + "\n"
+        if fout is None:
+            print(out, end="")
+        else:
+            fout.write(out)
+
     def add_observation(self, obs):
         k = 0
         for o in self._observations:          # keep coarsest resolution first

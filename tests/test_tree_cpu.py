@@ -139,3 +139,17 @@ def test_isotrack_oracle_composition_vs_reference():
     fx.assert_close(prior, g["lnprior"], 1e-11, atol=1e-12, what="lnprior")
     fx.assert_close(like, g["lnlike"], 1e-11, atol=1e-11, what="lnlike")
     fx.assert_close(post, g["lnpost"], 1e-11, atol=1e-11, what="lnpost")
+
+
+def test_tree_to_df_round_trip_and_print_ascii(capsys):
+    """to_df / from_df round trip (reference observation.py:796-835) and the text rendering of the hierarchy."""
+    tree = build_notebook_tree("t")
+    df = tree.to_df()
+    assert list(df.columns) == ["name", "band", "resolution", "mag", "e_mag", "separation", "pa", "relative"]
+    assert len(df) == sum(len(o.sources) for o in tree.observations)
+    again = ia.ObservationTree.from_df(df, name="t")
+    assert again.to_df().sort_values(list(df.columns)).reset_index(drop=True).equals(
+        df.sort_values(list(df.columns)).reset_index(drop=True))
+    tree.print_ascii()
+    out = capsys.readouterr().out
+    assert out.count("\n") >= len(df) and ("|-- " in out or "+-- " in out)
