@@ -863,6 +863,7 @@ class TreeStarModel(_NestedFitMixin):
     def lnlike(self, p):
         return self._evaluate(p, 2)
 
+
     def prior_transform(self, cube):
         """Unit cube -> parameters (reference: starmodel.py:615-627)."""
         cube = np.asarray(cube, dtype=float)
@@ -958,7 +959,7 @@ def StarModel(ic, obs=None, **kwargs):
     return BasicStarModel(ic, **kwargs)
 
 
-class IsoTrackModel:
+class IsoTrackModel(_NestedFitMixin):
     """The reference's experimental model that asks one star to agree with *both* grids
     (isochrones/starmodel.py:2010-2104): parameters (eep, mass, age, feh, distance, AV); the
     likelihood is the sum of the isochrone-grid likelihood at (eep, age, feh, d, AV) and the
@@ -1023,3 +1024,51 @@ class IsoTrackModel:
 
     def lnlike(self, p):
         return self._evaluate(p, 2)
+
+    # -- fits: the same drivers as the other models (fit_multinest / evidence come from the mixin) ----
+    def sample_from_prior(self, n, rng=None, max_tries=200):
+        """[n, 6] uniform draws from the parameter box with a finite lnpost."""
+        rng = rng or np.random.default_rng()
+        lo = np.array([self.bounds(nm)[0] for nm in self.param_names], dtype=float)
+        hi = np.array([self.bounds(nm)[1] for nm in self.param_names], dtype=float)
+        out = rng.uniform(lo, hi, size=(n, 6))
+        for _ in range(max_tries):
+            bad = ~np.isfinite(self.lnpost(out))
+            if not bad.any():
+                return out
+            out[bad] = rng.uniform(lo, hi, size=(int(bad.sum()), 6))
+        raise RuntimeError("could not find %d starting points with a finite lnpost" % n)
+
+    emcee_p0 = sample_from_prior
+
+    def fit_mcmc(self, nwalkers=300, nburn=200, niter=100, p0=None, seed=None, **kwargs):
+        import torch
+        from .sampler import EnsembleSampler
+        rng = np.random.default_rng(seed)
+        if p0 is None:
+            p0 = self.sample_from_prior(nwalkers, rng=rng)
+        else:
+            p0 = rng.normal(size=(nwalkers, 6)) * 0.01 + np.asarray(p0, dtype=float)[None, :]
+        sampler = EnsembleSampler(nwalkers, 6, self.lnpost, seed=int(rng.integers(2 ** 62)),
+                                  device=torch.device("cuda", dev.current_device()))
+        pos, prob = sampler.run_mcmc(p0, nburn, store=False)
+        sampler.reset()
+        sampler.run_mcmc(pos, niter, lnprob0=prob)
+        self._sampler, self._samples, self._fit_kind = sampler, None, "mcmc"
+        return sampler
+
+    fit = fit_mcmc
+
+    @property
+    def samples(self):
+        import pandas as pd
+        if getattr(self, "_samples", None) is None:
+            if getattr(self, "_fit_kind", "mcmc") == "nested":
+                self._samples = self._nested_frame()
+            else:
+                if getattr(self, "_sampler", None) is None:
+                    raise AttributeError("a fit must be run to access samples")
+                df = pd.DataFrame(self._sampler.flatchain.cpu().numpy(), columns=list(self.param_names))
+                df["lnprob"] = self._sampler.flatlnprobability.cpu().numpy()
+                self._samples = df
+        return self._samples

@@ -436,6 +436,13 @@ def test_isotrack_model_vs_reference_golden():
     k = int(np.flatnonzero(np.isfinite(g["lnpost"]))[0])
     assert np.isclose(mod.lnpost(p[k]), g["lnpost"][k], rtol=RTOL)
     assert mod.lnpost(torch.as_tensor(p, device="cuda")).is_cuda
+    # the fit drivers work on the composed model too
+    good = p[np.isfinite(g["lnpost"])]
+    if len(good):
+        mod.fit_mcmc(nwalkers=24, nburn=5, niter=5, p0=good[0], seed=1)
+        assert len(mod.samples) == 120 and list(mod.samples.columns[:-1]) == list(mod.param_names)
+    res = mod.fit_multinest(n_live_points=60, max_iter=200, seed=2)
+    assert np.isfinite(res.logz) and len(mod.samples) >= 1 and np.isfinite(mod.evidence[0])
 
 
 def test_tree_model_fits_and_quantile_errors():
