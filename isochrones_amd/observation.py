@@ -298,6 +298,14 @@ class ObservationTree:
             i += N[s] + 4
         return d
 
+    def pardict2p(self, pardict):
+        """The inverse of :meth:`p2pardict` (reference: observation.py:1132-1143)."""
+        pars, N = [], self.Nstars
+        for s in self.systems:
+            pars += [pardict["{}_{}".format(s, j)][0] for j in range(N[s])]
+            pars += list(pardict["{}_0".format(s)][1:])
+        return pars
+
     def obs_nodes(self):
         return [n for n in self.root.walk() if n.kind == "obs"]
 

@@ -196,6 +196,50 @@ class BasicStarModel(_NestedFitMixin):
             self._priors["feh"] = FehPrior(halo_fraction=halo_fraction)
         self._handles, self._handle_ic, self._handle_state = {}, {}, {}
 
+    # -- star.ini files (reference: StarModel.from_ini, starmodel.py:248-436; write_ini, 1485-1499) ------
+    @classmethod
+    def from_ini(cls, ic, folder=".", ini_file="star.ini", **kwargs):
+        """A model from a ``star.ini`` file: every ``key = value, uncertainty`` line becomes a measurement
+        keyword.  Sections of plain, unresolved photometry (``[twomass]`` holding only bands) are read as
+        keywords too; sections describing resolved companions need :class:`TreeStarModel`."""
+        import os
+        from . import ini
+        path = ini_file if os.path.isabs(ini_file) else os.path.join(folder, ini_file)
+        scalars, sections = ini.read_ini(path)
+        kw = {}
+        for k, v in scalars.items():
+            kw[k] = ini.parse_value(v)
+        rows = ini.observation_rows(sections)
+        for r in rows:
+            if r["relative"] or r["separation"] != 0.0:
+                raise ValueError("%s describes resolved companions ([%s]); use TreeStarModel.from_ini"
+                                 % (path, r["name"]))
+            kw[r["band"]] = (r["mag"], r["e_mag"])
+        ra, dec = kw.pop("RA", kw.pop("ra", None)), kw.pop("dec", kw.pop("Dec", None))
+        for k in ("N",):
+            if k in kw:
+                kw[k] = int(kw[k])
+        kw.update(kwargs)
+        if kw.get("N") is None:
+            kw.pop("N", None)
+        kw.setdefault("name", os.path.basename(os.path.abspath(folder)))
+        new = cls(ic, ra=ra, dec=dec, directory=os.path.abspath(folder), **kw)
+        return new
+
+    def write_ini(self, root="."):
+        """``<root>/<name>/star.ini`` holding the measurements (and ra/dec), readable by :meth:`from_ini`."""
+        import os
+        from . import ini
+        path = os.path.join(root, self.name)
+        os.makedirs(path, exist_ok=True)
+        scalars = {}
+        if self.ra is not None and self.dec is not None:
+            scalars["ra"], scalars["dec"] = self.ra, self.dec
+        for k, v in self.kwargs.items():
+            scalars[k] = (float(v[0]), float(v[1]))
+        ini.write_ini(os.path.join(path, "star.ini"), scalars)
+        return os.path.join(path, "star.ini")
+
     # -- description ------------------------------------------------------------------------
     @property
     def ic(self):
@@ -692,6 +736,62 @@ class TreeStarModel(_NestedFitMixin):
         self._handles, self._handle_ic, self._handle_state = {}, {}, {}
 
     ic = property(lambda self: self._ic)
+
+    # -- star.ini files (reference: starmodel.py:229-436) ---------------------------------------
+    @staticmethod
+    def get_bands(inifile):
+        from . import ini
+        return ini.get_bands(inifile)
+
+    @classmethod
+    def from_ini(cls, ic, folder=".", ini_file="star.ini", **kwargs):
+        """A model from a ``star.ini`` file (format: the reference's docstring, starmodel.py:249-314).
+        Top-level lines are measurement keywords (``Teff = 5770, 80``), ``maxAV``, ``N``, ``index`` or
+        ``obsfile`` (a csv with the columns of :meth:`ObservationTree.from_df`); every ``[section]`` is one
+        instrument's photometry, resolved companions carrying ``separation_<tag>`` / ``PA_<tag>`` /
+        ``<band>_<tag>``.  Without sections the bands apply to all model stars together."""
+        import os
+        import pandas as pd
+        from . import ini
+        from .observation import ObservationTree
+        path = ini_file if os.path.isabs(ini_file) else os.path.join(folder, ini_file)
+        scalars, sections = ini.read_ini(path)
+        kw = {k: ini.parse_value(v) for k, v in scalars.items()}
+        for k in ("RA", "dec", "ra", "Dec"):
+            kw.pop(k, None)
+        obs = None
+        if sections:
+            rows = ini.observation_rows(sections)
+            obs = ObservationTree.from_df(pd.DataFrame(rows, columns=["name", "band", "resolution", "relative",
+                                                                       "separation", "pa", "mag", "e_mag"]))
+        obsfile = kw.pop("obsfile", None)
+        if obsfile is not None:
+            obsfile = obsfile if os.path.isabs(obsfile) else os.path.join(folder, obsfile)
+            obs = ObservationTree.from_df(pd.read_csv(obsfile))
+        for k in ("N", "index"):
+            if k in kw:
+                kw[k] = [int(x) for x in kw[k]] if isinstance(kw[k], list) else int(kw[k])
+        for k, v in list(kw.items()):
+            if isinstance(v, list) and k not in ("N", "index"):
+                kw[k] = tuple(v)
+        kw.update(kwargs)
+        if kw.get("N") is None:
+            kw.pop("N", None)
+        kw.setdefault("name", os.path.basename(os.path.abspath(folder)))
+        new = cls(ic, obs=obs, **kw)
+        new._directory = os.path.abspath(folder)
+        return new
+
+    def print_ascii(self, fout=None, p=None):
+        return self.obs.print_ascii(fout=fout, p=p)
+
+    def convert_pars_to_eep(self, pars):
+        """A mass-based parameter vector (pre-2.0 layout: masses where the EEPs go) with every mass replaced
+        by the EEP that reaches it at that age and [Fe/H] (reference: starmodel.py:443-454)."""
+        pardict = self.obs.p2pardict(list(pars))
+        for star, sp in pardict.items():
+            sp[0] = float(self.ic.get_eep(sp[0], sp[1], sp[2], accurate=True))
+        return self.obs.pardict2p(pardict)
 
     @property
     def param_names(self):

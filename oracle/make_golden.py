@@ -353,6 +353,11 @@ def run_tree_cases():
         kw = dict(kw)
         obs = build(name) if build is not None else None
         mod = sm.StarModel(ic, obs=obs, **kw)
+        _emit_tree_case(name, mod, kw, build is not None, rng, axes, limits, obs_mod)
+
+
+def _emit_tree_case(name, mod, kw, built, rng, axes, limits, obs_mod, extra_meta=None):
+    if True:
         names = list(mod.param_names)
         N = mod.obs.Nstars
         # parameter samples: per system descending eeps near the table's middle, some violations
@@ -388,13 +393,114 @@ def run_tree_cases():
         meta = dict(param_names=names, leaf_labels=labels, nodes=nodes, kwargs={k: (list(v) if isinstance(v, (tuple, list)) else v)
                                                                                for k, v in kw.items()},
                     limits={k: list(map(float, v)) for k, v in limits.items()}, eep_bounds=[float(axes[2][0]), float(axes[2][-1])],
-                    bands=list(BANDS), built=build is not None, systems=[int(s) for s in mod.obs.systems],
+                    bands=list(BANDS), built=built, systems=[int(s) for s in mod.obs.systems],
                     Nstars={str(k): int(v) for k, v in N.items()})
+        meta.update(extra_meta or {})
         np.savez_compressed(os.path.join(OUT, name + ".npz"), meta=json.dumps(meta), pars=pars, lnprior=lnprior,
                             lnlike=lnlike, lnpost=lnpost, cube_in=cube,
                             cube_out=np.array([mod.prior_transform(c) for c in cube]))
         print("%-24s n=%d npar=%d finite lnpost=%d -inf=%d nan=%d leaves=%s" % (
             name, n, len(names), np.isfinite(lnpost).sum(), np.isneginf(lnpost).sum(), np.isnan(lnpost).sum(), labels))
+
+
+# The photometry rows of tests/golden/ini/<case>/star.ini, written out the way the reference's
+# StarModel.from_ini assembles them (starmodel.py:336-424: per section, per band, the tagged companions
+# in order, then the (0, 0.01) reference row of a relative section) before ObservationTree.from_df.
+# (from_ini itself needs configobj, which is not installed, so the rows are spelled out here and the
+# reference takes over from from_df on.)
+def _rows(instrument, resolution, relative, bands):
+    out = []
+    for band, entries in bands:
+        for sep, pa, mag, e in entries:
+            out.append(dict(name=instrument, band=band, resolution=resolution, relative=relative, separation=sep,
+                            pa=pa, mag=mag, e_mag=e))
+        if relative:
+            out.append(dict(name=instrument, band=band, resolution=resolution, relative=relative, separation=0.0,
+                            pa=0.0, mag=0.0, e_mag=0.01))
+    return out
+
+
+INI_CASES = {
+    "single": dict(
+        kwargs=dict(Teff=(5750, 98.0), feh=(-0.06, 0.16), logg=(4.41, 0.1)),
+        rows=_rows("twomass", 4.0, False, [("J", [(0, 0, 13.413, 0.02)]), ("H", [(0, 0, 13.045, 0.02)]),
+                                           ("K", [(0, 0, 12.993, 0.02)])])
+        + _rows("Gaia", 4.0, False, [("G", [(0, 0, 14.6, 0.05)]), ("RP", [(0, 0, 14.1, 0.05)])]),
+        variants={"": {}}),
+    "binary": dict(
+        kwargs={},
+        rows=_rows("twomass", 4.0, False, [("J", [(10, 100, 14.513, 0.02), (0, 0, 13.513, 0.02)]),
+                                           ("H", [(10, 100, 14.045, 0.02), (0, 0, 13.145, 0.02)]),
+                                           ("K", [(10, 100, 13.993, 0.02), (0, 0, 13.093, 0.02)])])
+        + _rows("Gaia", 4.0, False, [("G", [(10, 100, 15.9, 0.02), (0, 0, 14.7, 0.02)]),
+                                     ("BP", [(10, 100, 16.4, 0.02), (0, 0, 15.1, 0.02)]),
+                                     ("RP", [(10, 100, 15.3, 0.02), (0, 0, 14.2, 0.02)])]),
+        variants={"": {}, "_unassoc": dict(index=[0, 1])}),
+    "triple": dict(
+        kwargs=dict(maxAV=0.9, Teff=(5700, 98.0), feh=(-0.1, 0.16), logg=(4.45, 0.1)),
+        rows=_rows("twomass", 4.0, False, [("J", [(0, 0, 13.313, 0.02)]), ("H", [(0, 0, 12.945, 0.02)]),
+                                           ("K", [(0, 0, 12.893, 0.02)])])
+        + _rows("NIRC2", 0.1, True, [("K", [(0.6, 100, 1.66, 0.05), (1.2, 200, 2.1, 0.1)]),
+                                     ("H", [(0.6, 100, 1.77, 0.03), (1.2, 200, 2.2, 0.1)]),
+                                     ("J", [(0.6, 100, 1.84, 0.05), (1.2, 200, 2.35, 0.1)])]),
+        variants={"": {}, "_unassoc1": dict(index=[0, 0, 1]), "_unassoc2": dict(index=[0, 1, 1])}),
+    "triple_b": dict(
+        kwargs=dict(maxAV=0.8, Teff=(5765, 109), feh=(0.020, 0.150), logg=(4.449, 0.085)),
+        rows=_rows("twomass", 4.0, False, [("J", [(0, 0, 13.252, 0.021)]), ("H", [(0, 0, 12.910, 0.019)]),
+                                           ("K", [(0, 0, 12.871, 0.013)])])
+        + _rows("Lick", 0.5, True, [("H", [(3.842, 53.056, 1.343, 0.01), (12.073, 256.378, 2.488, 0.01)]),
+                                    ("K", [(3.842, 53.056, 1.305, 0.055)])]),
+        variants={"": {}, "_unassoc2": dict(index=[0, 1, 1])}),
+    "flat": dict(
+        kwargs=dict(J=(13.3, 0.05), H=(12.95, 0.05), K=(12.9, 0.05), Teff=(5800, 150), parallax=(2.0, 0.1)),
+        rows=None, variants={"": {}, "_N2": dict(N=2)}),
+}
+
+
+class _stable_argsort:
+    """The reference picks a new node's parent with ``np.argsort(distances)`` (observation.py:1260) and takes
+    the first candidate; coincident sources tie at distance 0.  numpy's default sort is not stable (the
+    AVX-512 kernels of numpy 2 reorder ties even in 8-element arrays), which makes the reference's tree depend
+    on the numpy build — on this machine the two-star, six-band file even yields a tree it then cannot
+    evaluate.  The goldens are generated with ties kept in iteration order (the result of the reference on any
+    numpy whose small-array sort is insertion sort), which is also what isochrones_amd.observation does."""
+
+    def __enter__(self):
+        self._orig = np.argsort
+        orig = self._orig
+
+        def argsort(a, *args, **kw):
+            if not args and "kind" not in kw:
+                kw["kind"] = "stable"
+            return orig(a, *args, **kw)
+        np.argsort = argsort
+
+    def __exit__(self, *exc):
+        np.argsort = self._orig
+
+
+def run_ini_cases():
+    """The star.ini fixtures (tests/golden/ini/) as the reference's generic StarModel sees them."""
+    import pandas as pd
+    sm = rh.ref("starmodel")
+    obs_mod = rh.ref("observation")
+    rng = np.random.default_rng(4242)
+    iso, bc = small_iso(), small_bc()
+    axes = iso[1]
+    limits = limits_of("iso", axes)
+    for case, spec in INI_CASES.items():
+        for suffix, extra in spec["variants"].items():
+            ic = rh.make_ref_ic("iso", iso, bc, limits, (axes[2][0], axes[2][-1]))
+            obs = None
+            kw = dict(spec["kwargs"], **extra)
+            with _stable_argsort():
+                if spec["rows"] is not None:
+                    df = pd.DataFrame(spec["rows"], columns=["name", "band", "resolution", "relative", "separation",
+                                                             "pa", "mag", "e_mag"])
+                    obs = obs_mod.ObservationTree.from_df(df)
+                mod = sm.StarModel(ic, obs=obs, **kw)
+            _emit_tree_case("ini_" + case + suffix, mod, kw, False, rng, axes, limits, obs_mod,
+                            extra_meta=dict(ini=case, from_ini_kwargs=extra))
 
 
 def run_isotrack_case():
@@ -468,6 +574,9 @@ def main():
     if "--only-tree" in sys.argv:
         run_tree_cases()
         return
+    if "--only-ini" in sys.argv:
+        run_ini_cases()
+        return
     if "--only-eep" in sys.argv:
         run_eep_case()
         return
@@ -494,6 +603,7 @@ def main():
     run_model_case("iso_triple_phot6", "iso", 3, "phot6_plx", iso, bc, rng, 250, 250)
     run_eep_case()
     run_tree_cases()
+    run_ini_cases()
     run_isotrack_case()
     run_prior_cases()
 

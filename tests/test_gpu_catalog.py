@@ -336,7 +336,7 @@ def test_fit_catalog_two_ranks_on_the_gpu(tmp_path):
 
 
 # ---- "next" row f4: generic StarModel over an ObservationTree ---------------------------------
-from tests.test_tree_cpu import TREE_CASES, make_tree_model  # noqa: E402
+from tests.test_tree_cpu import INI_CASES, INI_DIR, TREE_CASES, make_tree_model  # noqa: E402
 
 
 @pytest.fixture(params=["auto", "auto-runtime-leaves", "generic"])
@@ -349,7 +349,7 @@ def tree_kernel_path(request, monkeypatch):
     return request.param
 
 
-@pytest.mark.parametrize("case", TREE_CASES)
+@pytest.mark.parametrize("case", TREE_CASES + INI_CASES)
 def test_tree_model_vs_reference_golden(case, tree_kernel_path):
     import torch
     g = fx.load(case)
@@ -363,6 +363,57 @@ def test_tree_model_vs_reference_golden(case, tree_kernel_path):
     assert isinstance(v, float) and np.isclose(v, g["lnpost"][k], rtol=RTOL)
     dev_out = mod.lnpost(torch.as_tensor(pars, device="cuda"))
     fx.assert_close(dev_out.cpu().numpy(), g["lnpost"], RTOL, atol=1e-9, what="lnpost device")
+
+
+def test_reference_test_ini_checks(tmp_path):
+    """reference tests/test_ini.py (IniCheck.check_asserts / check_p0) on the star.ini fixtures: mass-based
+    parameter vectors convert to EEPs, lnlike is finite there, every emcee_p0 draw has a finite lnpost;
+    plus BasicStarModel's from_ini / write_ini round trip."""
+    import os
+    checks = {"ini_single": [1.0, 9.4, 0.0, 300, 0.2], "ini_binary": [1.0, 0.7, 9.4, 0.0, 300, 0.2],
+              "ini_binary_unassoc": [1.0, 9.4, 0.0, 300, 0.2, 0.8, 9.7, 0.1, 500, 0.3],
+              "ini_triple": [1.0, 0.8, 0.7, 9.4, 0.0, 300, 0.2],
+              "ini_triple_unassoc1": [1.0, 0.8, 9.4, 0.0, 300, 0.2, 1.0, 9.7, 0.0, 400, 0.5],
+              "ini_triple_unassoc2": [1.0, 9.4, 0.0, 300, 0.2, 1.0, 0.8, 9.7, 0.0, 400, 0.5]}
+    mist = ia.get_ichrone("mist", bands=["J", "H", "K", "G", "BP", "RP"])      # get_eep needs the companion track grid
+    for case, pars in checks.items():
+        meta = fx.load(case)["meta"]
+        mod = ia.TreeStarModel.from_ini(mist, folder=os.path.join(INI_DIR, meta["ini"]), **meta["from_ini_kwargs"])
+        ic = mist
+        eep_pars = mod.convert_pars_to_eep(pars)
+        assert len(eep_pars) == mod.n_params
+        pd_ = mod.obs.p2pardict(eep_pars)
+        pm = mod.obs.p2pardict(pars)
+        for star, sp in pd_.items():                               # the EEP reproduces the mass asked for
+            got = ic.interp_value([sp[0], sp[1], sp[2]], ["mass"])
+            assert abs(float(np.ravel(got)[0]) - pm[star][0]) < 0.02
+        assert np.isfinite(mod.lnlike(eep_pars)), case
+        p0 = mod.emcee_p0(10, rng=np.random.default_rng(3))
+        assert p0.shape == (10, mod.n_params) and np.all(np.isfinite(mod.lnpost(p0)))
+    # BasicStarModel: flat file, sectioned unresolved file, refusal of resolved companions, round trip
+    ic = fx.make_ic(dict(kind="iso", limits=fx.load("ini_flat")["meta"]["limits"],
+                         eep_bounds=fx.load("ini_flat")["meta"]["eep_bounds"]))
+    flat = ia.BasicStarModel.from_ini(ic, folder=os.path.join(INI_DIR, "flat"))
+    assert flat.name == "flat" and set(flat.kwargs) == {"J", "H", "K", "Teff", "parallax"} and flat.N == 1
+    assert flat.kwargs["Teff"] == (5800.0, 150.0)
+    b2 = ia.BasicStarModel.from_ini(ic, folder=os.path.join(INI_DIR, "flat"), N=2)
+    assert b2.N == 2 and len(b2.param_names) == 6
+    single = ia.SingleStarModel.from_ini(ic, folder=os.path.join(INI_DIR, "single"))
+    assert set(single.bands) == {"J", "H", "K", "G", "RP"} and single.ra == 299.268036
+    with pytest.raises(ValueError, match="resolved companions"):
+        ia.BasicStarModel.from_ini(ic, folder=os.path.join(INI_DIR, "triple"))
+    path = single.write_ini(str(tmp_path))
+    again = ia.SingleStarModel.from_ini(ic, folder=os.path.dirname(path))
+    assert again.kwargs == single.kwargs and again.ra == single.ra and again.name == single.name
+    p = fx.load("ini_single")["pars"][:64]
+    assert np.array_equal(again.lnpost(p), single.lnpost(p), equal_nan=True)
+    # the basic and the tree model of the same unresolved file agree once they share priors
+    tree = ia.TreeStarModel.from_ini(ic, folder=os.path.join(INI_DIR, "single"))
+    for k in ["mass", "feh", "age", "distance", "AV", "eep"]:
+        single.set_prior(**{k: tree._priors[k]})
+    a, b = tree.lnpost(p), single.lnpost(p)
+    fin = np.isfinite(b)
+    assert fin.sum() > 20 and np.array_equal(np.isfinite(a), fin) and np.allclose(a[fin], b[fin], rtol=1e-10, atol=1e-9)
 
 
 @pytest.mark.parametrize("which", ["all", "spec", "phot"])

@@ -1,6 +1,8 @@
 """CPU: the host-side observation-tree builder (isochrones_amd/observation.py) and the oracle's
 generic-model restatement against golden data produced by the reference's own
 ObservationTree + StarModel (docs/multiple.ipynb configurations + keyword form)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -11,6 +13,11 @@ from tests import _fixtures as fx
 
 TREE_CASES = ["tree_resolved", "tree_resolved_unassoc", "tree_triple1", "tree_triple2", "tree_double_binary",
               "tree_kwargs_single", "tree_kwargs_binary", "tree_kwargs_triple"]
+# star.ini fixtures (tests/golden/ini/, layouts of the reference's tests/star1..star4) with the N / index
+# variants of the reference's tests/test_ini.py
+INI_CASES = ["ini_single", "ini_binary", "ini_binary_unassoc", "ini_triple", "ini_triple_unassoc1",
+             "ini_triple_unassoc2", "ini_triple_b", "ini_triple_b_unassoc2", "ini_flat", "ini_flat_N2"]
+INI_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ini")
 
 
 def build_notebook_tree(name):
@@ -30,12 +37,14 @@ def build_notebook_tree(name):
 def make_tree_model(meta):
     iso_meta = dict(kind="iso", limits=meta["limits"], eep_bounds=meta["eep_bounds"])
     ic = fx.make_ic(iso_meta)
+    if meta.get("ini"):
+        return ic, ia.TreeStarModel.from_ini(ic, folder=os.path.join(INI_DIR, meta["ini"]), **meta["from_ini_kwargs"])
     kw = {k: (tuple(v) if isinstance(v, list) and k not in ("N", "index") else v) for k, v in meta["kwargs"].items()}
     obs = build_notebook_tree("t") if meta["built"] else None
     return ic, ia.TreeStarModel(ic, obs=obs, **kw)
 
 
-@pytest.mark.parametrize("case", TREE_CASES)
+@pytest.mark.parametrize("case", TREE_CASES + INI_CASES)
 def test_tree_structure_and_oracle_vs_reference(case):
     g = fx.load(case)
     meta = g["meta"]
@@ -153,3 +162,39 @@ def test_tree_to_df_round_trip_and_print_ascii(capsys):
     tree.print_ascii()
     out = capsys.readouterr().out
     assert out.count("\n") >= len(df) and ("|-- " in out or "+-- " in out)
+
+
+def test_ini_reader_and_checks_of_reference_test_ini(tmp_path):
+    """reference tests/test_ini.py: n_params / systems / Nstars of every fixture + variant, and the
+    reader's handling of comments, quoting, lists and malformed lines."""
+    from isochrones_amd import ini
+    expect = {"ini_single": (5, [0], {0: 1}), "ini_binary": (6, [0], {0: 2}), "ini_binary_unassoc": (10, [0, 1], {0: 1, 1: 1}),
+              "ini_triple": (7, [0], {0: 3}), "ini_triple_unassoc1": (11, [0, 1], {0: 2, 1: 1}),
+              "ini_triple_unassoc2": (11, [0, 1], {0: 1, 1: 2}), "ini_triple_b": (7, [0], {0: 3}),
+              "ini_triple_b_unassoc2": (11, [0, 1], {0: 1, 1: 2})}
+    for case, (npar, systems, nstars) in expect.items():
+        meta = fx.load(case)["meta"]
+        ic, mod = make_tree_model(meta)
+        assert len(mod.param_names) == npar and mod.n_params == npar
+        assert mod.obs.systems == systems and mod.obs.Nstars == nstars
+        assert mod.name == meta["ini"]
+    assert ia.TreeStarModel.get_bands(os.path.join(INI_DIR, "binary", "star.ini")) == ["J", "H", "K", "G", "BP", "RP"]
+    _, tri = make_tree_model(fx.load("ini_triple")["meta"])
+    assert tri.bounds("AV") == (0, 0.9)
+    # the reader
+    f = tmp_path / "star.ini"
+    f.write_text("# c\nname = 'a # b'  # trailing\nTeff = 5000, 100,\nN = 2\n\n[ s1 ]\nK = 1, 0.1\nlist = a, 'b c'\n")
+    scalars, sections = ini.read_ini(str(f))
+    assert scalars == {"name": "a # b", "Teff": ["5000", "100"], "N": "2"}
+    assert sections == {"s1": {"K": ["1", "0.1"], "list": ["a", "b c"]}}
+    assert ini.parse_value(scalars["Teff"]) == [5000.0, 100.0] and ini.parse_value("x") == "x"
+    f.write_text("Teff 5000\n")
+    with pytest.raises(ValueError, match="expected 'key = value'"):
+        ini.read_ini(str(f))
+    f.write_text("[s]\nK = 12\n")
+    with pytest.raises(ValueError, match="magnitude, uncertainty"):
+        ini.observation_rows(ini.read_ini(str(f))[1])
+    # pardict round trip
+    p = list(np.arange(11.0))
+    _, m = make_tree_model(fx.load("ini_triple_unassoc1")["meta"])
+    assert m.obs.pardict2p(m.obs.p2pardict(p)) == p
