@@ -66,6 +66,64 @@ class EEPPrior:
             owner._dirty()
 
 
+class _ConvenienceMixin:
+    """Small helpers of the reference's StarModel that only touch results or delegate to lnpost:
+    ``prior`` (starmodel.py:634), ``maxlike`` (:821-833), ``random_samples`` (:1055-1069), persistence
+    (:1205-1317, 1843-1959; container format in isochrones_amd/persist.py)."""
+
+    def prior(self, prop, val, **kwargs):
+        return self._priors[prop](val, **kwargs)
+
+    @property
+    def directory(self):
+        return getattr(self, "_directory", None) or "."
+
+    def maxlike(self, p0=None, n_starts=4096, seed=0, **kwargs):
+        """A (local) optimum of lnpost: Nelder-Mead on -lnpost like the reference, started from ``p0`` or —
+        the batched evaluation makes this cheap — from the best of ``n_starts`` prior draws."""
+        import scipy.optimize
+        if p0 is None:
+            cand = self.sample_from_prior(int(n_starts), rng=np.random.default_rng(seed))
+            if hasattr(cand, "columns"):
+                cand = cand[list(self.param_names)].values
+            cand = np.ascontiguousarray(cand, dtype=float)
+            lp = np.asarray(self.lnpost(cand))
+            p0 = cand[int(np.nanargmax(np.where(np.isfinite(lp), lp, -np.inf)))]
+        kwargs.setdefault("method", "Nelder-Mead")
+
+        def fn(p):
+            v = -self.lnpost(p)
+            return v if np.isfinite(v) else 1e300
+        return scipy.optimize.minimize(fn, np.asarray(p0, dtype=float), **kwargs)
+
+    def random_samples(self, n, rng=None):
+        """``n`` rows drawn (with replacement) from the posterior samples."""
+        rng = rng or np.random.default_rng()
+        samples = self.samples
+        return samples.iloc[rng.integers(len(samples), size=int(n))].reset_index(drop=True)
+
+    def save(self, filename, overwrite=True):
+        from . import persist
+        return persist.save_model(self, filename, overwrite=overwrite)
+
+    @classmethod
+    def load(cls, filename, ic=None, name=None):
+        from . import persist
+        return persist.load_model(cls, filename, ic=ic, name=name)
+
+    def save_hdf(self, filename, path="", overwrite=False, append=False):
+        from . import persist
+        return persist.save_hdf(self, filename, path=path, overwrite=overwrite, append=append)
+
+    @classmethod
+    def load_hdf(cls, filename, path="", name=None, ic=None):
+        from . import persist
+        if not str(filename).endswith(".npz"):
+            raise ImportError("reading the reference's HDF5 layout needs pytables, which is not installed; "
+                              "models saved here are .npz containers")
+        return persist.load_model(cls, filename, ic=ic, name=name)
+
+
 class _NestedFitMixin:
     """``fit_multinest`` / ``evidence`` for any model with ``param_names``, ``bounds(par)`` and a
     batched ``lnpost``: the reference hands ``mnest_loglike`` (= lnpost) and the flat-box ``mnest_prior``
@@ -103,6 +161,15 @@ class _NestedFitMixin:
             np.savetxt("{}post_equal_weights.dat".format(basename), np.column_stack([x, ll]))
         return res
 
+    use_emcee = False
+
+    def fit(self, **kwargs):
+        """``fit_mcmc`` if the model was built with ``use_emcee=True``, else ``fit_multinest`` (reference:
+        starmodel.py:667-671)."""
+        if self.use_emcee:
+            return self.fit_mcmc(**kwargs)
+        return self.fit_multinest(**kwargs)
+
     def _device_proposer(self, lo, hi, seed):
         """Proposals of the nested sampler on the device: uniform draws in the bounding ellipsoid (or the unit
         cube), the flat-box transform, lnpost and the likelihood-threshold test all stay in HBM; only the
@@ -136,6 +203,8 @@ class _NestedFitMixin:
     def evidence(self):
         """(log evidence, its error) of the last nested fit (reference starmodel.py:813-819)."""
         if getattr(self, "_nested", None) is None:
+            if getattr(self, "_loaded_evidence", None) is not None:
+                return self._loaded_evidence
             raise AttributeError("fit_multinest must be run to access the evidence")
         return (self._nested.logz, self._nested.logz_err)
 
@@ -147,12 +216,14 @@ class _NestedFitMixin:
         return df
 
 
-class BasicStarModel(_NestedFitMixin):
+class BasicStarModel(_NestedFitMixin, _ConvenienceMixin):
     def __init__(self, ic, eep_bounds=None, name="", directory=".", N=1, maxAV=None, max_distance=None,
                  halo_fraction=None, ra=None, dec=None, obs=None, use_emcee=False, **kwargs):
         self._ic = ic
         self.eep_bounds = tuple(eep_bounds) if eep_bounds is not None else tuple(ic.eep_bounds)
         self.name = str(name)
+        self._directory = str(directory)
+        self.use_emcee = bool(use_emcee)
         self.ra, self.dec = ra, dec
         if N not in (1, 2, 3):
             raise ValueError("N must be 1, 2 or 3")
@@ -267,6 +338,19 @@ class BasicStarModel(_NestedFitMixin):
     @property
     def props(self):
         return [k for k in self.kwargs if k in _NOT_A_BAND]
+
+    @property
+    def mags(self):
+        return {b: self.kwargs[b][0] for b in self.bands}
+
+    param_description = property(lambda self: self.param_names)
+
+    def prior_transform(self, cube):
+        """Unit cube -> parameters, out of place (reference: StarModel.prior_transform, starmodel.py:615-627)."""
+        cube = np.asarray(cube, dtype=float)
+        lo = np.array([self.bounds(p)[0] for p in self.param_names])
+        hi = np.array([self.bounds(p)[1] for p in self.param_names])
+        return (hi - lo) * cube + lo
 
     @property
     def spec_props(self):
@@ -552,7 +636,7 @@ class BasicStarModel(_NestedFitMixin):
         self._fit_kind = "mcmc"
         return sampler
 
-    fit = fit_mcmc
+    fit_mcmc_old = fit_mcmc
 
     @property
     def sampler(self):
@@ -674,7 +758,7 @@ class TripleStarModel(BasicStarModel):
 # ==========================================================================================
 # generic (observation-tree) model — "next" row f4
 # ==========================================================================================
-class TreeStarModel(_NestedFitMixin):
+class TreeStarModel(_NestedFitMixin, _ConvenienceMixin):
     """The reference's generic ``StarModel`` (isochrones/starmodel.py:63-661): photometry organised
     in an :class:`~isochrones_amd.observation.ObservationTree` (resolved and blended sources,
     relative photometry, several physical systems), evaluated on the device from the flattened
@@ -686,13 +770,14 @@ class TreeStarModel(_NestedFitMixin):
     keyword of the form ``Teff_1=(v, e)`` addresses leaf ``0_1``."""
 
     def __init__(self, ic, obs=None, N=1, index=0, name="", eep_bounds=None, maxAV=None, max_distance=None,
-                 **kwargs):
+                 use_emcee=False, **kwargs):
         import re
         from .observation import Observation, ObservationTree, Source
         if ic.eep_replaces != "mass":
             raise NotImplementedError("Prior not implemented for evolution track grids")
         self._ic = ic
         self.name = name
+        self.use_emcee = bool(use_emcee)
         if obs is None:
             obs = ObservationTree()
             for k, v in kwargs.items():
@@ -798,6 +883,32 @@ class TreeStarModel(_NestedFitMixin):
         return tuple(self.obs.param_description)
 
     param_description = param_names
+
+    @property
+    def labelstring(self):
+        """'single' / 'binary' / 'triple' for one system, joined by '-' for several (reference: starmodel.py:163-177)."""
+        names = {1: "single", 2: "binary", 3: "triple"}
+        N = self.obs.Nstars
+        return "-".join(names.get(N[s], "{}stars".format(N[s])) for s in self.obs.systems)
+
+    @property
+    def mags(self):
+        return {n.observation.band: n.source.mag for n in self.obs.obs_nodes()}
+
+    @property
+    def props(self):
+        """Measured properties beyond Teff / logg / feh (reference: starmodel.py:201-206)."""
+        found = {k for v in self.obs.spectroscopy.values() for k in v}
+        return sorted(found - {"Teff", "logg", "feh"})
+
+    def mnest_prior(self, cube, ndim=None, nparams=None):
+        """Unit cube -> parameters, in place (reference: starmodel.py:615-627 through pymultinest's callback)."""
+        out = self.prior_transform(np.array([cube[i] for i in range(self.n_params)], dtype=float))
+        for i in range(self.n_params):
+            cube[i] = out[i]
+
+    def mnest_loglike(self, cube, ndim=None, nparams=None):
+        return self.lnpost(np.array([cube[i] for i in range(self.n_params)], dtype=float))
 
     @property
     def n_params(self):
@@ -1027,7 +1138,7 @@ class TreeStarModel(_NestedFitMixin):
         self._fit_kind = "mcmc"
         return sampler
 
-    fit = fit_mcmc
+    fit_mcmc_old = fit_mcmc
 
     @property
     def sampler(self):
@@ -1079,9 +1190,30 @@ class IsoTrackModel(_NestedFitMixin):
 
     ic = property(lambda self: self.track)
     n_params = 6
+    labelstring = "single"
+    name = property(lambda self: self._track_model.name)
+    bands = property(lambda self: self._track_model.bands)
+    props = property(lambda self: self._track_model.props)
+    spec_props = property(lambda self: self._track_model.spec_props)
+    mags = property(lambda self: self._track_model.mags)
+    param_description = param_names
 
     def bounds(self, prop):
         return self._track_model.bounds(prop)
+
+    def set_bounds(self, **kwargs):
+        self._track_model.set_bounds(**kwargs)
+        self._iso_model.set_bounds(**kwargs)
+
+    def set_prior(self, **kwargs):
+        """Priors live in the track-grid model (mass through its EEP term, feh, distance, AV); the age prior is
+        evaluated here and has to stay an :class:`AgePrior` (its bounds may change)."""
+        if "age" in kwargs and not isinstance(kwargs["age"], AgePrior):
+            raise NotImplementedError("IsoTrackModel evaluates the age prior in closed form: pass an AgePrior")
+        self._track_model.set_prior(**kwargs)
+
+    def prior(self, prop, val, **kwargs):
+        return self._priors[prop](val, **kwargs)
 
     def _split(self, p):
         import torch
@@ -1157,7 +1289,7 @@ class IsoTrackModel(_NestedFitMixin):
         self._sampler, self._samples, self._fit_kind = sampler, None, "mcmc"
         return sampler
 
-    fit = fit_mcmc
+    fit_mcmc_old = fit_mcmc
 
     @property
     def samples(self):

@@ -494,6 +494,21 @@ def test_isotrack_model_vs_reference_golden():
         assert len(mod.samples) == 120 and list(mod.samples.columns[:-1]) == list(mod.param_names)
     res = mod.fit_multinest(n_live_points=60, max_iter=200, seed=2)
     assert np.isfinite(res.logz) and len(mod.samples) >= 1 and np.isfinite(mod.evidence[0])
+    # bounds / priors reach the two grid models; the closed-form age prior follows its bounds
+    from isochrones_amd import priors
+    before = mod.lnprior(good[:8])
+    d0, (a_lo, a_hi) = mod.bounds("distance")[1], mod.bounds("age")
+    mod.set_bounds(distance=(0, 3000))
+    assert mod.bounds("distance") == (0, 3000) and mod._iso_model.bounds("distance") == (0, 3000)
+    with pytest.raises(NotImplementedError):
+        mod.set_prior(age=priors.FlatPrior((9, 10)))
+    lo = float(np.min(good[:8, 2])) - 0.5
+    mod.set_prior(age=priors.AgePrior(bounds=(lo, 10.15)))
+    after = mod.lnprior(good[:8])
+    want = np.log(np.log(10) / (10 ** 10.15 - 10 ** lo)) - np.log(np.log(10) / (10 ** a_hi - 10 ** a_lo))
+    want += 3 * np.log(d0 / 3000.0)                 # the d^2 prior renormalises: 3 / hi^3
+    assert np.allclose(after - before, want, rtol=1e-9, atol=1e-9)
+    assert mod.bands == mod._track_model.bands and mod.labelstring == "single"
 
 
 def test_tree_model_fits_and_quantile_errors():
@@ -724,3 +739,61 @@ def test_fit_multinest_binary_model_respects_ordering():
     assert abs(np.median(s["distance"]) - 300.0) < 30.0
     d = mod.derived_samples
     assert {"mass_0", "mass_1", "J_mag"} <= set(d.columns)
+
+
+def test_save_load_round_trip_and_convenience_helpers(tmp_path):
+    """reference StarModel.save_hdf / load_hdf (starmodel.py:1205-1317, 1843-1959), maxlike (:821-833),
+    random_samples (:1055-1069), fit dispatch (:667-671): a fitted basic model and a fitted tree model come
+    back from disk with the same measurements, priors, bounds, samples and lnpost."""
+    import os
+    from isochrones_amd import priors
+    from tests.test_tree_cpu import build_notebook_tree
+    ic = ia.get_ichrone("mist", bands=["J", "H", "K"])
+    mod = ia.BinaryStarModel(ic, J=(9.6, 0.03), H=(9.2, 0.03), K=(9.1, 0.03), parallax=(8.0, 0.1), name="pair",
+                             use_emcee=True)
+    mod.set_prior(feh=priors.FlatPrior((-1.0, 0.4)), AV=priors.GaussianPrior(0.1, 0.05, bounds=(0, 1)))
+    mod.set_bounds(eep=(200, 500))
+    mod.fit(nwalkers=32, nburn=20, niter=10, seed=4)                        # use_emcee -> fit_mcmc
+    f = str(tmp_path / "pair.npz")
+    assert mod.save_hdf(f) == f and os.path.exists(f)
+    with pytest.raises(IOError):
+        mod.save_hdf(f)
+    with pytest.raises(ImportError, match="pytables"):
+        mod.save_hdf(str(tmp_path / "pair.h5"))
+    back = ia.BinaryStarModel.load_hdf(f, ic=ic)
+    assert type(back) is ia.BinaryStarModel and back.name == "pair" and back.kwargs == mod.kwargs
+    assert back._bounds == mod._bounds and back.bounds("eep") == (200, 500)
+    assert type(back._priors["feh"]) is priors.FlatPrior and back._priors["AV"].bounds == (0, 1)
+    assert list(back.samples.columns) == list(mod.samples.columns)
+    assert np.array_equal(back.samples.values, mod.samples.values)
+    assert np.array_equal(back.derived_samples.values, mod.derived_samples.values, equal_nan=True)
+    p = mod.samples[list(mod.param_names)].values[:50]
+    assert np.array_equal(back.lnpost(p), mod.lnpost(p))
+    assert len(back.random_samples(17, rng=np.random.default_rng(0))) == 17
+    also = ia.BasicStarModel.load(f)                                        # grid rebuilt from the stored bands
+    assert also.N == 2 and np.array_equal(also.lnpost(p), mod.lnpost(p))
+    with pytest.raises(TypeError):
+        ia.TreeStarModel.load(f, ic=ic)
+    # maxlike: Nelder-Mead from the best prior draw does at least as well as that draw and every sample
+    best = mod.maxlike(n_starts=2048, seed=1, options=dict(maxiter=400))
+    assert np.isfinite(best.fun) and -best.fun >= np.max(mod.samples["lnprob"].values) - 5.0
+    assert mod.prior("AV", 0.1) == mod._priors["AV"](0.1) and mod.mags["J"] == 9.6 and mod.directory == "."
+    # tree model: nested fit (fit() without use_emcee), evidence survives the round trip
+    tree = ia.TreeStarModel(ic, obs=build_notebook_tree("nb"), parallax=(2.0, 0.05), Teff=(5834.0, 100), name="nb")
+    tree.set_prior(AV=priors.FlatPrior((0, 0.5)))
+    tree.fit(n_live_points=60, max_iter=150, seed=2)
+    g = str(tmp_path / "tree.npz")
+    tree.save(g)
+    tb = ia.TreeStarModel.load(g, ic=ic)
+    assert tb.param_names == tree.param_names and tb.obs.leaf_labels == tree.obs.leaf_labels
+    assert tb.evidence == tree.evidence and tb.labelstring == "binary" and tb.props == []
+    q = tree.samples[list(tree.param_names)].values[:40]
+    assert np.array_equal(tb.lnpost(q), tree.lnpost(q))
+    assert np.array_equal(tb.samples.values, tree.samples.values)
+    cube = [0.5] * tree.n_params
+    tree.mnest_prior(cube)
+    assert np.allclose(cube, tree.prior_transform(np.full(tree.n_params, 0.5)))
+    assert np.isclose(tree.mnest_loglike(cube), tree.lnpost(np.array(cube)))
+    unfit = ia.SingleStarModel(ic, J=(9.6, 0.03))
+    unfit.save(str(tmp_path / "unfit.npz"))
+    assert ia.SingleStarModel.load(str(tmp_path / "unfit.npz"), ic=ic)._samples is None
