@@ -13,6 +13,7 @@ from ._cabi import IsoError
 from .sampler import EnsembleSampler, FusedEnsembleSampler
 from .catalog import (StarCatalog, CatalogPosterior, fit_catalog, synthetic_catalog, shard_of, shard_indices,
                       broadcast_interpolator)
-from . import priors, grids, ingest, mist, nested
+from . import priors, grids, ingest, mist, nested, ini, persist
+from .starfit import starfit
 
 __version__ = "0.1.0"

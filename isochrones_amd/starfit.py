@@ -1,0 +1,53 @@
+"""``starfit``: fit the star described by a folder's ``star.ini`` and keep the result next to it
+(reference: isochrones/starfit.py:14-175, the function behind ``scripts/starfit``).
+
+For every requested multiplicity the fitted model is stored as ``<models>_starmodel_<mult>.npz`` in the
+folder; an existing file is loaded instead of refitting unless ``overwrite`` is set.  Plots and the
+command-line wrapper of the reference are not provided.
+"""
+from __future__ import annotations
+
+import logging
+import os
+import time
+
+from . import ini
+from .models import get_ichrone
+from .priors import FlatPrior
+from .starmodel import BasicStarModel
+
+NSTARS = {"single": 1, "binary": 2, "triple": 3}
+
+
+def starfit(folder, multiplicities=("single",), models="mist", use_emcee=False, overwrite=False, verbose=False,
+            starmodel_type=None, ini_file="star.ini", bands=None, feh_prior=None, ichrone=None, logger=None,
+            **fit_kwargs):
+    """-> the model of the last multiplicity fitted (or loaded).  ``fit_kwargs`` go to ``mod.fit``
+    (``fit_multinest`` by default, ``fit_mcmc`` with ``use_emcee=True``)."""
+    Mod = BasicStarModel if starmodel_type is None else starmodel_type
+    logger = logger or logging.getLogger("isochrones_amd.starfit")
+    folder = os.path.abspath(folder)
+    name = os.path.basename(folder)
+    ini_path = ini_file if os.path.isabs(ini_file) else os.path.join(folder, ini_file)
+    mod = None
+    for mult in multiplicities:
+        if mult not in NSTARS:
+            raise ValueError("multiplicity must be one of {}, got {!r}".format(sorted(NSTARS), mult))
+        filename = os.path.join(folder, "{}_starmodel_{}.npz".format(models, mult))
+        start = time.time()
+        if os.path.exists(filename) and not overwrite:
+            mod = Mod.load_hdf(filename, name=name, ic=ichrone)
+            logger.info("%s exists.  Use overwrite=True to refit.", os.path.basename(filename))
+            continue
+        if ichrone is None:
+            found = ini.get_bands(ini_path)
+            ichrone = get_ichrone(models, bands=list(dict.fromkeys(list(bands or []) + found)))
+        scalars, _ = ini.read_ini(ini_path)
+        extra = {} if "N" in scalars else dict(N=NSTARS[mult])
+        mod = Mod.from_ini(ichrone, folder, ini_file=ini_file, use_emcee=use_emcee, name=name, **extra)
+        if feh_prior == "flat":
+            mod.set_prior(feh=FlatPrior(tuple(mod.ic.model_grid.get_limits("feh"))))
+        mod.fit(verbose=verbose, **fit_kwargs)
+        mod.save_hdf(filename, overwrite=True)
+        logger.info("%s starfit successful for %s in %.1f s.", mult, name, time.time() - start)
+    return mod

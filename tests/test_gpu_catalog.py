@@ -797,3 +797,27 @@ def test_save_load_round_trip_and_convenience_helpers(tmp_path):
     unfit = ia.SingleStarModel(ic, J=(9.6, 0.03))
     unfit.save(str(tmp_path / "unfit.npz"))
     assert ia.SingleStarModel.load(str(tmp_path / "unfit.npz"), ic=ic)._samples is None
+
+
+def test_starfit_driver_on_an_ini_folder(tmp_path):
+    """reference isochrones/starfit.py: star.ini folder -> model per multiplicity, fitted and stored next to
+    the ini; a second call loads instead of refitting."""
+    import os
+    import shutil
+    folder = tmp_path / "KOI-1"
+    shutil.copytree(os.path.join(INI_DIR, "flat"), str(folder))
+    mod = ia.starfit(str(folder), multiplicities=["single", "binary"], n_live_points=80, max_iter=120, seed=5,
+                     feh_prior="flat")
+    assert mod.N == 2 and mod.name == "KOI-1" and isinstance(mod._priors["feh"], ia.priors.FlatPrior)
+    assert sorted(f for f in os.listdir(str(folder)) if f.endswith(".npz")) == \
+        ["mist_starmodel_binary.npz", "mist_starmodel_single.npz"]
+    logz = mod.evidence
+    again = ia.starfit(str(folder), multiplicities=["binary"])
+    assert again.evidence == logz and np.array_equal(again.samples.values, mod.samples.values)
+    single = ia.SingleStarModel.load(str(folder / "mist_starmodel_single.npz"))
+    assert single.N == 1 and set(single.kwargs) == {"J", "H", "K", "Teff", "parallax"}
+    em = ia.starfit(str(folder), multiplicities=["single"], use_emcee=True, overwrite=True, nwalkers=24, nburn=10,
+                    niter=5, seed=1)
+    assert len(em.samples) == 120 and em.use_emcee
+    with pytest.raises(ValueError, match="multiplicity"):
+        ia.starfit(str(folder), multiplicities=["quadruple"])
