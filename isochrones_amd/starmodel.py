@@ -1160,14 +1160,34 @@ class TreeStarModel(_NestedFitMixin, _ConvenienceMixin):
         return self._samples
 
 
-def StarModel(ic, obs=None, **kwargs):
-    """Factory with the reference's name: an :class:`ObservationTree` (or ``N``/keywords on an
-    isochrone grid that describe blended multi-system photometry) gives the generic tree model;
-    plain keyword measurements of one unresolved 1-3 star system give :class:`BasicStarModel`
-    (the reference pins both to the same numbers, tests/test_likelihood.py)."""
-    if obs is not None:
-        return TreeStarModel(ic, obs=obs, **kwargs)
-    return BasicStarModel(ic, **kwargs)
+class _StarModelMeta(type):
+    def __instancecheck__(cls, obj):
+        return isinstance(obj, (BasicStarModel, TreeStarModel))
+
+    def __subclasscheck__(cls, sub):
+        return issubclass(sub, (BasicStarModel, TreeStarModel))
+
+
+class StarModel(metaclass=_StarModelMeta):
+    """The reference's name.  Called, it is a factory: an :class:`ObservationTree` (or a ``star.ini`` with
+    sections) gives the generic tree model, plain keyword measurements of one unresolved 1-3 star system give
+    :class:`BasicStarModel` (the reference pins both to the same numbers, tests/test_likelihood.py).  The class
+    methods of the reference's ``StarModel`` hang off it too (``from_ini``, ``get_bands``, ``load_hdf``)."""
+
+    def __new__(cls, ic, obs=None, **kwargs):
+        if obs is not None:
+            return TreeStarModel(ic, obs=obs, **kwargs)
+        return BasicStarModel(ic, **kwargs)
+
+    from_ini = TreeStarModel.from_ini
+    get_bands = staticmethod(TreeStarModel.get_bands)
+
+    @staticmethod
+    def load_hdf(filename, path="", name=None, ic=None):
+        from . import persist
+        return persist.load_model(None, filename, ic=ic, name=name)
+
+    load = load_hdf
 
 
 class IsoTrackModel(_NestedFitMixin):

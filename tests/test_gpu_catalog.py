@@ -821,3 +821,20 @@ def test_starfit_driver_on_an_ini_folder(tmp_path):
     assert len(em.samples) == 120 and em.use_emcee
     with pytest.raises(ValueError, match="multiplicity"):
         ia.starfit(str(folder), multiplicities=["quadruple"])
+
+
+def test_readme_quick_tour_runs(tmp_path, monkeypatch):
+    """The README's quick tour, executed verbatim (stars/ = a copy of the ini fixtures)."""
+    import os
+    import re
+    import shutil
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "README.md")).read()
+    code = re.search(r"## Quick tour.*?```python\n(.*?)```", text, re.S).group(1)
+    shutil.copytree(INI_DIR, str(tmp_path / "stars"))
+    monkeypatch.chdir(tmp_path)
+    ns = {}
+    exec(compile(code, "README.md quick tour", "exec"), ns)
+    assert len(ns["res"]) == 10_000 and np.isfinite(ns["mod"].evidence[0])
+    assert ns["again"].kwargs == ns["mod"].kwargs and ns["lp"].is_cuda and ns["tree"].n_params == 11
+    assert os.path.exists(str(tmp_path / "stars" / "flat" / "mist_starmodel_binary.npz"))
