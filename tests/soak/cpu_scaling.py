@@ -1,7 +1,7 @@
 """How does the CPU oracle (C port, OpenMP) scale on this host?  Prints evals/s per thread count."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import bench
 ic, mod = bench.build_model()
 oic = bench.oracle_view(ic)[1]

@@ -1,8 +1,8 @@
 """Randomised differential soak: many model configurations x sample mixes, GPU (every kernel path) vs the
-CPU oracle.  Usage on the GPU box: python tools/soak.py [seconds] [seed].  Exit code 1 on any mismatch."""
+CPU oracle.  Usage on the GPU box: python tests/soak/soak.py [seconds] [seed].  Exit code 1 on any mismatch."""
 import os, sys, time, json
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import isochrones_amd as ia
 from isochrones_amd import priors as P

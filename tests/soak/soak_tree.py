@@ -2,11 +2,12 @@
 reference tree configurations of tests/golden (docs/multiple.ipynb shapes) x wide, special-value-laden samples."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
-from oracle import oracle as orc          # tools/ = test infrastructure
+from oracle import oracle as orc          # tests/ = the only place the oracle is used as a checker
 from tests import _fixtures as fx
 from tests.test_tree_cpu import TREE_CASES, make_tree_model
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import soak
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 30.0

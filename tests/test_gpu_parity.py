@@ -567,13 +567,13 @@ def test_special_value_fuzz_vs_oracle(kind, n_stars, kernel_path):
 
 
 def test_randomised_soak_short(monkeypatch):
-    """tools/soak.py for a few seconds: random model configurations (bands, stars, observables, prior
+    """tests/soak/soak.py for a few seconds: random model configurations (bands, stars, observables, prior
     families, bounds) x special-value-laden samples on all three kernel paths against the oracle
     (the long runs are recorded in profiles/r01/soak.txt)."""
     import runpy
     monkeypatch.setattr(sys, "argv", ["soak.py", "6", "11"])
     with pytest.raises(SystemExit) as e:
-        runpy.run_path(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "soak.py"),
+        runpy.run_path(os.path.join(os.path.dirname(os.path.abspath(__file__)), "soak", "soak.py"),
                        run_name="__main__")
     assert e.value.code == 0
 
