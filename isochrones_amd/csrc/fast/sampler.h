@@ -142,8 +142,22 @@ __global__ __launch_bounds__(BLOCK, DENSE ? 3 : 1) void k_stretch_persist(const 
     }
     __syncthreads();
     const int64_t rows_total = n_ens * W;
-    const int g = (int)threadIdx.x / per, kk = (int)threadIdx.x - g * per;
-    const bool mine = g < here;
+    // lane -> (ensemble g, walker kk of its active half).  A workgroup that its ensembles do not fill (a single
+    // star's fit: 256 walkers = 128 moves per half-step) spreads the moves evenly over its four waves in
+    // multiples of 16: the cooperative gathers serve 16 samples per round and skip empty rounds, and a wave
+    // issues alone on its SIMD, so 4 x 32 moves finish sooner than 2 x 64.  The random numbers are keyed by
+    // (step, half, row), not by the lane, so the chain does not depend on this mapping.
+    int g = (int)threadIdx.x / per, kk = (int)threadIdx.x - g * per;
+    bool mine = g < here;
+    if (h < BLOCK && here * h < BLOCK) {
+        const int total = here * h;
+        int pw = (((total + 3) >> 2) + 15) & ~15;
+        pw = pw < 16 ? 16 : pw;
+        const int a = ((int)threadIdx.x >> 6) * pw + ((int)threadIdx.x & 63);
+        mine = ((int)threadIdx.x & 63) < pw && a < total;
+        g = mine ? a / h : 0;
+        kk = mine ? a - g * h : 0;
+    }
     const int gs = mine ? g : 0;                          // idle lanes shadow a move of the first ensemble
     for (int it = 0; it < S.nsteps; ++it) {
         double* cp = S.chain_pos ? S.chain_pos + ((int64_t)it * rows_total + r0 + gs * W) * NP : nullptr;
