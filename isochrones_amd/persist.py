@@ -155,6 +155,9 @@ def load_model(cls, filename, ic=None, name=None):
     if eep_orig is not None:
         mod._priors["eep"].orig_prior = eep_orig
     mod.set_bounds(**{k: tuple(v) for k, v in meta["bounds"].items() if v is not None})
+    for k, v in meta["bounds"].items():               # bounds never asked for stay unset, as they were
+        if v is None and k in mod._bounds:
+            mod._bounds[k] = None
     mod._samples = samples
     if samples is not None:
         mod._fit_kind = "loaded"

@@ -198,3 +198,43 @@ def test_ini_reader_and_checks_of_reference_test_ini(tmp_path):
     p = list(np.arange(11.0))
     _, m = make_tree_model(fx.load("ini_triple_unassoc1")["meta"])
     assert m.obs.pardict2p(m.obs.p2pardict(p)) == p
+
+
+def test_saved_models_describe_the_same_device_program(tmp_path):
+    """persist.py on the host side only: an (unfitted) basic model and the ini-built tree models come back with
+    the same measurements, priors, bounds and — what the kernels actually see — the same flattened descriptors."""
+    import ctypes as C
+    from isochrones_amd import priors
+
+    def raw(desc):
+        return bytes(C.string_at(C.addressof(desc), C.sizeof(desc)))
+
+    meta = fx.load("ini_flat")["meta"]
+    ic = fx.make_ic(dict(kind="iso", limits=meta["limits"], eep_bounds=meta["eep_bounds"]))
+    b = ia.BinaryStarModel.from_ini(ic, folder=os.path.join(INI_DIR, "flat"))
+    b.set_prior(AV=priors.GaussianPrior(0.2, 0.1, bounds=(0, 1)), distance=priors.PowerLawPrior(2.0, (1.0, 800.0)))
+    b.set_bounds(eep=(210, 600))
+    b._priors["eep"].orig_prior = priors.LogNormalPrior(0.0, 0.5)
+    f = str(tmp_path / "b.npz")
+    b.save(f)
+    back = ia.StarModel.load_hdf(f, ic=ic)
+    assert type(back) is ia.BinaryStarModel and back.kwargs == b.kwargs and back._bounds == b._bounds
+    assert type(back._priors["eep"].orig_prior) is priors.LogNormalPrior
+    assert raw(back.model_desc()) == raw(b.model_desc())
+    for case in ("ini_triple_unassoc1", "ini_binary", "ini_single"):
+        _, t = make_tree_model(fx.load(case)["meta"])
+        t.set_prior(feh=priors.FlatPrior((-0.5, 0.3)))
+        g = str(tmp_path / (case + ".npz"))
+        t.save(g)
+        tb = ia.TreeStarModel.load(g, ic=t.ic)
+        assert tb.param_names == t.param_names and tb.obs.leaf_labels == t.obs.leaf_labels
+        assert tb._bounds == t._bounds and tb.obs.spectroscopy == t.obs.spectroscopy
+        d0, d1 = t.tree_desc(), tb.tree_desc()
+        pars = fx.load(case)["pars"].T.copy()
+        oic = fx.make_oracle_ic(t.ic)
+        a, b_ = orc.tree_lnpost(oic, d0, pars)[0], orc.tree_lnpost(oic, d1, pars)[0]
+        assert np.array_equal(a, b_, equal_nan=True) and np.isfinite(a).sum() > 20
+    with pytest.raises(IOError):
+        ia.StarModel.load_hdf(str(tmp_path / "missing.npz"))
+    with pytest.raises(IOError):
+        t.save_hdf(g)                                  # exists, no overwrite / append
