@@ -119,6 +119,39 @@ class _Node:
             return "{} {}".format(self.observation, self.source)
         return self.kind
 
+    @property
+    def reference_label(self):
+        """The label the reference gives an observation node (observation.py:341-352):
+        ``<instrument> <band>=(<mag>, <unc>) @(<separation>, <pa> [<resolution>])``."""
+        if self.kind != "obs":
+            return self.label
+        o, s = self.observation, self.source
+        return "{} {}=({:.2f}, {:.2f}) @({:.2f}, {:.0f} [{:.2f}])".format(o.name, o.band, s.mag, s.e_mag, s.separation,
+                                                                          s.pa, o.resolution)
+
+    def select_leaves(self, pattern):
+        """All finest-level nodes below every node whose label matches ``pattern`` (a regular expression; this
+        build's label or the reference's spelling of it), reference observation.py:234-249."""
+        import re
+
+        def bottom(node):                         # finest observation level: model stars do not count
+            kids = [c for c in node.children if c.kind != "model"]
+            if not kids:
+                return [node]
+            out = []
+            for c in kids:
+                out += bottom(c)
+            return out
+
+        hit = self.kind != "root" and (re.search(pattern, self.label) or re.search(pattern, self.reference_label))
+        kids = [c for c in self.children if c.kind != "model"]
+        if hit or not kids:
+            return bottom(self) if hit else []
+        out = []
+        for c in kids:
+            out += c.select_leaves(pattern)
+        return out
+
 
 class ObservationTree:
     spec_props = ["Teff", "logg", "feh", "density"]
@@ -224,13 +257,18 @@ class ObservationTree:
     def define_models(self, ic=None, leaves=None, N=1, index=0):
         """Hang N model stars of physical system `index` below every finest-level node
         (scalars or one entry per node; an entry of `index` may itself be a list of length N)."""
-        if leaves is not None:
-            raise NotImplementedError("leaf selection by pattern is not provided")
         self._model_spec = None
         for n in list(self.root.walk()):
             if n.kind == "model":
                 n.parent.children.remove(n)
-        hosts = self.root.leaves()
+        if leaves is None:
+            hosts = self.root.leaves()
+        elif isinstance(leaves, str):             # a pattern: the finest-level nodes below every matching node
+            hosts = self.root.select_leaves(leaves)
+            if not hosts:
+                raise ValueError("no observation node matches {!r}".format(leaves))
+        else:
+            hosts = list(leaves)
         Ns = [int(N)] * len(hosts) if np.isscalar(N) else [int(x) for x in N]
         idx = [index] * len(hosts) if np.isscalar(index) else list(index)
         if len(Ns) != len(hosts) or len(idx) != len(hosts):
@@ -243,7 +281,7 @@ class ObservationTree:
                 tag = len([l for l in self.root.leaves() if l.kind == "model" and l.index == int(sysid)])
                 host.add_child(_Node("model", index=int(sysid), tag=tag))
         self._fix_labels()
-        self._model_spec = (ic, None, N, index)
+        self._model_spec = (ic, leaves if isinstance(leaves, str) else None, N, index)
 
     def _fix_labels(self):
         """Within each system the star below the brightest source carries tag 0."""

@@ -79,7 +79,7 @@ def save_model(mod, filename, overwrite=False):
         obs = mod.obs
         df = obs.to_df()
         spec = obs._model_spec
-        meta.update(kind="tree", N=_plain(spec[2]), index=_plain(spec[3]),
+        meta.update(kind="tree", N=_plain(spec[2]), index=_plain(spec[3]), leaves=spec[1],
                     spectroscopy={k: {p: _plain(v) for p, v in d.items()} for k, d in obs.spectroscopy.items()},
                     limits={k: {p: _plain(v) for p, v in d.items()} for k, d in obs.limits.items()},
                     parallax={str(k): _plain(v) for k, v in obs.parallax.items()},
@@ -140,7 +140,7 @@ def load_model(cls, filename, ic=None, name=None):
             obs = ObservationTree.from_df(df, name=meta.get("obs_name"))
         else:
             obs = ObservationTree(name=meta.get("obs_name"))
-        obs.define_models(ic, N=meta["N"], index=meta["index"])
+        obs.define_models(ic, leaves=meta.get("leaves"), N=meta["N"], index=meta["index"])
         for label, props in meta["spectroscopy"].items():
             obs.add_spectroscopy(label=label, **as_pair(props))
         for label, props in meta.get("limits", {}).items():

@@ -238,3 +238,19 @@ def test_saved_models_describe_the_same_device_program(tmp_path):
         ia.StarModel.load_hdf(str(tmp_path / "missing.npz"))
     with pytest.raises(IOError):
         t.save_hdf(g)                                  # exists, no overwrite / append
+
+
+def test_define_models_on_leaves_selected_by_pattern():
+    """reference ObservationTree.define_models(leaves=<pattern>) / select_leaves (observation.py:234-249, 1020-1023)."""
+    a, b, c = build_notebook_tree("a"), build_notebook_tree("b"), build_notebook_tree("c")
+    a.define_models(N=[1, 2], index=[0, 1])
+    b.define_models(leaves="AO", N=[1, 2], index=[0, 1])                 # the resolved image's two sources
+    c.define_models(leaves=r"K=\(.*\[0\.10\]", N=[1, 2], index=[0, 1])    # the reference's spelling of a node label
+    assert a.leaf_labels == b.leaf_labels == c.leaf_labels == ["0_0", "1_0", "1_1"]
+    assert [n.label for n in a.root.select_leaves("2MASS")] == [n.label for n in a.root.select_leaves("AO")]
+    assert a.root.select_leaves("nothing") == []
+    with pytest.raises(ValueError, match="no observation node"):
+        a.define_models(leaves="nothing")
+    one = build_notebook_tree("d").root.select_leaves(r"@\(0\.20, 100")
+    assert len(one) == 1 and one[0].source.separation == 0.2
+    assert one[0].reference_label == "AO K=(2.43, 0.02) @(0.20, 100 [0.10])"
