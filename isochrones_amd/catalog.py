@@ -85,6 +85,26 @@ class StarCatalog:
         for i in (range(len(self.df)) if indices is None else indices):
             yield self.model(i, ic, N=N, **kwargs)
 
+    def write_ini(self, ic=None, root=".", N=1, nest_directories=True, clobber=True):
+        """One ``<name>/star.ini`` folder per star — the layout ``starfit`` / ``batch_starfit`` walk (reference:
+        catalog.py:141-158; with ``nest_directories`` the folders are grouped by the first log_100(len) characters
+        of the star's name).  Returns the list of folders."""
+        import os
+        import shutil
+        if ic is None:
+            from .models import get_ichrone
+            ic = get_ichrone("mist", bands=self.bands)
+        n_pre = int(np.log10(max(len(self), 1)) // 2)
+        dirs = []
+        for mod in self.iter_models(ic, N=N):
+            path = os.path.join(root, str(mod.name)[:n_pre]) if nest_directories else root
+            mod_path = os.path.abspath(os.path.join(path, mod.name))
+            if os.path.exists(mod_path) and clobber:
+                shutil.rmtree(mod_path)
+            mod.write_ini(root=path)
+            dirs.append(mod_path)
+        return dirs
+
 
 class CatalogPosterior:
     """Device-resident posteriors of many stars sharing bands and multiplicity.

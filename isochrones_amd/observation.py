@@ -297,6 +297,52 @@ class ObservationTree:
                 other.tag, best.tag = best.tag, 0
 
     # -- queries ----------------------------------------------------------------------------
+    # the reference's spellings (observation.py:234-300, 1088-1098)
+    def select_leaves(self, pattern):
+        return self.root.select_leaves(pattern)
+
+    def select_observations(self, name):
+        """Observation nodes of one instrument-band, named like the reference's ``obsname`` (``'2MASS-K'``)."""
+        return [n for n in self.obs_nodes() if "{}-{}".format(n.observation.name, n.observation.band) == name]
+
+    def get_obs_nodes(self):
+        return self.obs_nodes()
+
+    def get_model_nodes(self):
+        return self.model_nodes()
+
+    def get_leaf(self, label):
+        for n in self.root.leaves():
+            if n.label == label:
+                return n
+        return None
+
+    def get_obs_leaves(self):
+        """The finest-level observation nodes (the ones model stars hang below)."""
+        seen, out = set(), []
+        for n in self.root.leaves():
+            host = n.parent if n.kind == "model" else n
+            if host.kind == "obs" and id(host) not in seen:
+                seen.add(id(host))
+                out.append(host)
+        return out
+
+    obs_leaf_nodes = property(get_obs_leaves)
+
+    @property
+    def N_model_nodes(self):
+        return len(self.model_nodes())
+
+    def clear_models(self):
+        self._model_spec = None
+        for n in list(self.root.walk()):
+            if n.kind == "model":
+                n.parent.children.remove(n)
+
+    def trim(self):
+        """No-op, as in the reference (observation.py:1100-1107 returns before doing anything)."""
+        return None
+
     def model_nodes(self):
         return [l for l in self.root.leaves() if l.kind == "model"]
 

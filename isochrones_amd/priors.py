@@ -429,5 +429,15 @@ class SalpeterPrior(PowerLawPrior):
         super().__init__(alpha=-2.35, bounds=bounds)
 
 
+BoundedPrior = Prior        # the reference splits Prior / BoundedPrior (priors.py:107-141); one class covers both here
+
+
+def __getattr__(name):      # priors.EEP_prior (reference priors.py:384-463) lives with the models that own it
+    if name in ("EEP_prior", "EEPPrior"):
+        from .starmodel import EEPPrior
+        return EEPPrior
+    raise AttributeError("module {!r} has no attribute {!r}".format(__name__, name))
+
+
 DEVICE_PRIOR_TYPES = (FlatPrior, FlatLogPrior, PowerLawPrior, GaussianPrior, LogNormalPrior,
                       ChabrierPrior, FehPrior)

@@ -838,3 +838,23 @@ def test_readme_quick_tour_runs(tmp_path, monkeypatch):
     assert len(ns["res"]) == 10_000 and np.isfinite(ns["mod"].evidence[0])
     assert ns["again"].kwargs == ns["mod"].kwargs and ns["lp"].is_cuda and ns["tree"].n_params == 11
     assert os.path.exists(str(tmp_path / "stars" / "flat" / "mist_starmodel_binary.npz"))
+
+
+def test_catalog_write_ini_then_starfit_per_folder(tmp_path):
+    """reference StarCatalog.write_ini (catalog.py:141-158) + scripts/batch_starfit: a catalog written as one ini
+    folder per star, each folder fitted by starfit(); the per-folder models see the catalog's measurements."""
+    import os
+    ic = ia.get_ichrone("mist", bands=["G", "BP", "RP"], tracks=True)
+    cat, truth = ia.synthetic_catalog(ic, 4, bands=["G", "BP", "RP"], seed=3)
+    dirs = cat.write_ini(ic, root=str(tmp_path), nest_directories=False)
+    assert len(dirs) == 4 and all(os.path.exists(os.path.join(d, "star.ini")) for d in dirs)
+    for i, d in enumerate(dirs):
+        want = cat.model(i, ic)
+        mod = ia.starfit(d, multiplicities=["single"], ichrone=ic, n_live_points=60, max_iter=100, seed=i)
+        assert mod.kwargs.keys() == want.kwargs.keys() and mod.name == os.path.basename(d)
+        for k in want.kwargs:
+            assert np.allclose(mod.kwargs[k], want.kwargs[k], rtol=0, atol=0)
+        p = mod.samples[list(mod.param_names)].values[:16]
+        assert np.array_equal(mod.lnpost(p), want.lnpost(p))
+    again = cat.write_ini(ic, root=str(tmp_path), nest_directories=False)      # clobbers the folders (and their fits)
+    assert again == dirs and not os.path.exists(os.path.join(dirs[0], "mist_starmodel_single.npz"))

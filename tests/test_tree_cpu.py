@@ -254,3 +254,18 @@ def test_define_models_on_leaves_selected_by_pattern():
     one = build_notebook_tree("d").root.select_leaves(r"@\(0\.20, 100")
     assert len(one) == 1 and one[0].source.separation == 0.2
     assert one[0].reference_label == "AO K=(2.43, 0.02) @(0.20, 100 [0.10])"
+
+
+def test_reference_spellings_of_tree_queries_and_prior_names():
+    from isochrones_amd import priors
+    t = build_notebook_tree("x")
+    t.define_models(N=1, index=[0, 1])
+    assert t.N_model_nodes == 2 and len(t.get_obs_leaves()) == 2 and t.get_leaf("1_0").label == "1_0"
+    assert len(t.select_observations("AO-K")) == 2 and len(t.select_observations("2MASS-J")) == 1
+    assert len(t.get_obs_nodes()) == 5 and [n.label for n in t.get_model_nodes()] == ["0_0", "1_0"]
+    assert [n.label for n in t.select_leaves("AO")] == [n.label for n in t.obs_leaf_nodes] and t.trim() is None
+    t.clear_models()
+    assert t.N_model_nodes == 0 and t.get_leaf("0_0") is None
+    assert priors.BoundedPrior is priors.Prior and priors.EEP_prior.__name__ == "EEPPrior"
+    with pytest.raises(AttributeError):
+        priors.NoSuchPrior
