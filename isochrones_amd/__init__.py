@@ -14,6 +14,6 @@ from .sampler import EnsembleSampler, FusedEnsembleSampler
 from .catalog import (StarCatalog, CatalogPosterior, fit_catalog, synthetic_catalog, shard_of, shard_indices,
                       broadcast_interpolator)
 from . import priors, grids, ingest, mist, nested, ini, persist
-from .starfit import starfit
+from .starfit import starfit, batch_starfit
 
 __version__ = "0.1.0"

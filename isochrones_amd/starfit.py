@@ -51,3 +51,38 @@ def starfit(folder, multiplicities=("single",), models="mist", use_emcee=False, 
         mod.save_hdf(filename, overwrite=True)
         logger.info("%s starfit successful for %s in %.1f s.", mult, name, time.time() - start)
     return mod
+
+
+def batch_starfit(folders, rank=None, world=None, **kwargs):
+    """``starfit`` over many folders, split over the ranks of the job the way the reference's
+    ``scripts/batch_starfit`` splits a list file over SLURM tasks (line NR, 1-based, goes to task NR % P,
+    scripts/batch_starfit:60-62).  ``folders``: a list of folders or the path of a file with one folder per
+    line.  ``rank`` / ``world`` default to the default ``torch.distributed`` group (one process per GPU), or
+    to a single process.  Returns ``{folder: model or the exception that stopped its fit}`` for this rank's share;
+    a failing folder is logged and does not stop the rest (the reference logs and carries on, starfit.py:165-169)."""
+    from .catalog import shard_of
+    if isinstance(folders, (str, os.PathLike)):
+        base = os.path.dirname(os.path.abspath(folders))
+        with open(folders) as f:
+            folders = [ln.strip() for ln in f if ln.strip() and not ln.lstrip().startswith("#")]
+        folders = [p if os.path.isabs(p) else os.path.join(base, p) for p in folders]
+    if rank is None or world is None:
+        try:
+            import torch.distributed as dist
+            on = dist.is_available() and dist.is_initialized()
+        except ImportError:          # pragma: no cover
+            on = False
+        rank, world = (dist.get_rank(), dist.get_world_size()) if on else (0, 1)
+    logger = kwargs.get("logger") or logging.getLogger("isochrones_amd.starfit")
+    out = {}
+    for i, folder in enumerate(folders):
+        if shard_of(i, world) != rank:
+            continue
+        try:
+            out[folder] = starfit(folder, **kwargs)
+        except KeyboardInterrupt:
+            raise
+        except Exception as e:       # noqa: BLE001 - one bad star must not end the batch
+            logger.error("starfit calculation failed for %s: %s", folder, e)
+            out[folder] = e
+    return out

@@ -856,5 +856,14 @@ def test_catalog_write_ini_then_starfit_per_folder(tmp_path):
             assert np.allclose(mod.kwargs[k], want.kwargs[k], rtol=0, atol=0)
         p = mod.samples[list(mod.param_names)].values[:16]
         assert np.array_equal(mod.lnpost(p), want.lnpost(p))
+    # the list-file form, split like scripts/batch_starfit: line NR (1-based) -> task NR % P
+    listfile = tmp_path / "stars.list"
+    listfile.write_text("\n".join(os.path.basename(d) for d in dirs) + "\n# comment\nnot_a_folder\n")
+    r0 = ia.batch_starfit(str(listfile), rank=0, world=2, multiplicities=["single"], ichrone=ic)
+    r1 = ia.batch_starfit(str(listfile), rank=1, world=2, multiplicities=["single"], ichrone=ic)
+    assert sorted(map(os.path.basename, r0)) == sorted([os.path.basename(dirs[1]), os.path.basename(dirs[3])])
+    assert sorted(map(os.path.basename, r1)) == sorted([os.path.basename(dirs[0]), os.path.basename(dirs[2]), "not_a_folder"])
+    assert isinstance(r1[os.path.join(str(tmp_path), "not_a_folder")], Exception)          # logged, batch carried on
+    assert all(m.name == os.path.basename(f) for f, m in r0.items())
     again = cat.write_ini(ic, root=str(tmp_path), nest_directories=False)      # clobbers the folders (and their fits)
     assert again == dirs and not os.path.exists(os.path.join(dirs[0], "mist_starmodel_single.npz"))
