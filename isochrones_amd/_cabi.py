@@ -175,8 +175,8 @@ def lib():
     L.iso_eep_table_destroy.restype = None
     L.iso_interp_eep.argtypes = [vp, pd, pd, pd, i64, pd, vp]
     hdp = C.POINTER(dbl)
-    L.iso_interp_host.argtypes = [vp, hdp, i64, C.POINTER(C.c_int32), C.c_int, hdp]
-    L.iso_interp_mag_host.argtypes = [vp, hdp, i64, C.POINTER(C.c_int32), C.c_int, hdp, hdp, hdp, hdp]
+    L.iso_interp_host.argtypes = [vp, vp, i64, C.POINTER(C.c_int32), C.c_int, vp]           # host double* as void*: plain ints pass
+    L.iso_interp_mag_host.argtypes = [vp, vp, i64, C.POINTER(C.c_int32), C.c_int, vp, vp, vp, vp]
     L.iso_interp_eep_host.argtypes = [vp, hdp, hdp, hdp, i64, hdp]
     L.iso_sampler_create_model.argtypes = [vp, C.c_int, dbl, C.c_uint64, C.POINTER(vp)]
     L.iso_sampler_create_catalog.argtypes = [vp, C.c_int, dbl, C.c_uint64, C.POINTER(vp)]

@@ -257,6 +257,22 @@ class ModelGridInterpolator:
             return self.interp_mag_device(p, bands, device)
         device = dev.current_device()
         scalar = False
+        nb = len(bands)
+        if (nb <= _cabi.ISO_MAX_BANDS and isinstance(pars, (list, tuple)) and len(pars) == 5
+                and all(isinstance(x, (float, int, np.floating, np.integer)) for x in pars)):
+            # five plain numbers (the reference's scalar form): one buffer [pars | Teff logg feh | mags], one C call
+            buf = np.empty(8 + nb)
+            buf[:5] = pars
+            base = buf.ctypes.data
+            key = tuple(bands)
+            cached = self._band_ptr_cache.get(key) if hasattr(self, "_band_ptr_cache") else None
+            if cached is None:
+                if not hasattr(self, "_band_ptr_cache"):
+                    self._band_ptr_cache = {}
+                cached = self._band_ptr_cache[key] = dev.i32_array(self._band_cols(bands))
+            _cabi.check(_cabi.lib().iso_interp_mag_host(self.handle(device), base, 1, cached[1], nb, base + 40, base + 48,
+                                                        base + 56, base + 64))
+            return buf[5], buf[6], buf[7], buf[8:]
         try:
             arr = np.atleast_1d(pars).astype(float).squeeze()
             if arr.ndim > 1 or arr.shape != (5,):
@@ -384,6 +400,11 @@ class ModelGridInterpolator:
             return out
         device = dev.current_device()
         scalar = all(isinstance(x, (float, int, np.floating, np.integer)) for x in args)
+        if scalar:                                 # the call form of the reference's notebooks: no array machinery
+            one = C.c_double * 1
+            out1 = one()
+            _cabi.check(_cabi.lib().iso_interp_eep_host(self._eep_handle(device), one(age), one(feh), one(mass), 1, out1))
+            return out1[0]
         b = np.broadcast(*args)
         hm, ha, hf = [np.ascontiguousarray(np.atleast_1d(np.resize(x, b.shape)).astype(float).ravel()) for x in args]
         if hm.size <= HOST_CALL_ROWS:
