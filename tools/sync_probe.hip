@@ -22,7 +22,7 @@ __global__ void k_work(const double* in, double* out, volatile uint64_t* flag, u
 }
 __global__ void k_signal(volatile uint64_t* flag, uint64_t seq) { __threadfence_system(); *flag = seq; }
 
-int main()
+int main(int argc, char** argv)
 {
     double* h; CK(hipHostMalloc(reinterpret_cast<void**>(&h), 4096, hipHostMallocMapped));
     double* d; CK(hipHostGetDevicePointer(reinterpret_cast<void**>(&d), h, 0));
@@ -30,6 +30,9 @@ int main()
     volatile uint64_t* dflag = reinterpret_cast<volatile uint64_t*>(d + 256);
     for (int i = 0; i < 64; ++i) h[i] = i;
     hipStream_t s = nullptr;
+    if (argc > 1 && argv[1][0] == 'n') CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));   // "n": own non-blocking stream
+    if (argc > 1 && argv[1][0] == 'b') CK(hipStreamCreate(&s));                                  // "b": own blocking stream
+    printf("stream: %s\n", s ? (argv[1][0] == 'n' ? "non-blocking" : "blocking") : "null (legacy default)");
     hipEvent_t ev; CK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     const int N = 5000;
     uint64_t seq = 0;
