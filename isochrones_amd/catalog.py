@@ -438,9 +438,10 @@ def result_columns(param_names):
 
 
 def fit_stars_gpu(catalog: StarCatalog, ic, indices, N=1, nwalkers=32, nburn=150, niter=100, seed=0,
-                  model_kwargs=None, fused=True, timings=None, max_stars_per_batch=200_000):
+                  model_kwargs=None, fused=True, timings=None, max_stars_per_batch=200_000, return_chains=False):
     """Fit the stars ``indices`` of the catalog on the current GPU; returns [len(indices), 3*D+3]
-    float64 numpy rows (result_columns order)."""
+    float64 numpy rows (result_columns order).  ``return_chains=True`` (fused sampler, one batch): also the
+    stored chain [S, W, niter, D] and its lnpost values [S, W, niter] as CUDA tensors."""
     import torch
     import time as _time
 
@@ -453,6 +454,8 @@ def fit_stars_gpu(catalog: StarCatalog, ic, indices, N=1, nwalkers=32, nburn=150
 
     if len(indices) == 0:
         return np.empty((0, 3 * (N + 4) + 3))
+    if return_chains and (not fused or len(indices) > max_stars_per_batch):
+        raise ValueError("return_chains needs the fused sampler and at most max_stars_per_batch stars")
     if len(indices) > max_stars_per_batch:
         # bound the device memory of the stored chains (S x W x niter x D doubles): fit the shard in slices
         parts = [fit_stars_gpu(catalog, ic, indices[k:k + max_stars_per_batch], N=N, nwalkers=nwalkers, nburn=nburn,
@@ -521,6 +524,10 @@ def fit_stars_gpu(catalog: StarCatalog, ic, indices, N=1, nwalkers=32, nburn=150
     rows[failed, : 3 * D + 2] = float("nan")
     out = rows.cpu().numpy()
     _mark("summaries")
+    if return_chains:
+        kept = (chain.clone(), lnps.clone())
+        post.close()
+        return out, kept[0], kept[1]
     post.close()
     return out
 

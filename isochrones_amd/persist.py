@@ -97,7 +97,7 @@ def save_model(mod, filename, overwrite=False):
     arrays["priors"] = np.frombuffer(pickle.dumps(priors, protocol=4), dtype=np.uint8)
     arrays["meta"] = np.array(json.dumps(meta))
     tmp = filename + ".tmp.npz"
-    np.savez_compressed(tmp, **arrays)
+    np.savez(tmp, **arrays)          # uncompressed: zlib on ~1.5 MB of float64 noise costs 20-60 ms per model for nothing
     os.replace(tmp, filename)
     return filename
 

@@ -268,34 +268,42 @@ class BasicStarModel(_NestedFitMixin, _ConvenienceMixin):
         self._handles, self._handle_ic, self._handle_state = {}, {}, {}
 
     # -- star.ini files (reference: StarModel.from_ini, starmodel.py:248-436; write_ini, 1485-1499) ------
+    @staticmethod
+    def ini_keywords(path):
+        """The constructor keywords a ``star.ini`` file describes (measurements, ``ra`` / ``dec``, ``N``, ``maxAV`` ...)."""
+        from . import ini
+        scalars, sections = ini.read_ini(path)
+        kw = {}
+        for k, v in scalars.items():
+            kw[k] = ini.parse_value(v)
+        for r in ini.observation_rows(sections):
+            if r["relative"] or r["separation"] != 0.0:
+                raise ValueError("%s describes resolved companions ([%s]); use TreeStarModel.from_ini"
+                                 % (path, r["name"]))
+            kw[r["band"]] = (r["mag"], r["e_mag"])
+        ra = kw.pop("RA", kw.pop("ra", None))
+        dec = kw.pop("dec", kw.pop("Dec", None))
+        if ra is not None:
+            kw["ra"] = ra
+        if dec is not None:
+            kw["dec"] = dec
+        if "N" in kw:
+            kw["N"] = int(kw["N"])
+        return kw
+
     @classmethod
     def from_ini(cls, ic, folder=".", ini_file="star.ini", **kwargs):
         """A model from a ``star.ini`` file: every ``key = value, uncertainty`` line becomes a measurement
         keyword.  Sections of plain, unresolved photometry (``[twomass]`` holding only bands) are read as
         keywords too; sections describing resolved companions need :class:`TreeStarModel`."""
         import os
-        from . import ini
         path = ini_file if os.path.isabs(ini_file) else os.path.join(folder, ini_file)
-        scalars, sections = ini.read_ini(path)
-        kw = {}
-        for k, v in scalars.items():
-            kw[k] = ini.parse_value(v)
-        rows = ini.observation_rows(sections)
-        for r in rows:
-            if r["relative"] or r["separation"] != 0.0:
-                raise ValueError("%s describes resolved companions ([%s]); use TreeStarModel.from_ini"
-                                 % (path, r["name"]))
-            kw[r["band"]] = (r["mag"], r["e_mag"])
-        ra, dec = kw.pop("RA", kw.pop("ra", None)), kw.pop("dec", kw.pop("Dec", None))
-        for k in ("N",):
-            if k in kw:
-                kw[k] = int(kw[k])
+        kw = cls.ini_keywords(path)
         kw.update(kwargs)
         if kw.get("N") is None:
             kw.pop("N", None)
         kw.setdefault("name", os.path.basename(os.path.abspath(folder)))
-        new = cls(ic, ra=ra, dec=dec, directory=os.path.abspath(folder), **kw)
-        return new
+        return cls(ic, directory=os.path.abspath(folder), **kw)
 
     def write_ini(self, root="."):
         """``<root>/<name>/star.ini`` holding the measurements (and ra/dec), readable by :meth:`from_ini`."""
