@@ -13,7 +13,16 @@ struct QuantArgs {
     int W, D, nq, P;         // P = power of two >= nsteps*W
     double q[8];
     double* out;             // [n_ens][D][nq]
+    int only_flagged;        // workgroup kernels: handle only the (ensemble, parameter) pairs the wave kernel flagged
 };
+
+// what k_chain_quantiles_wave leaves in out[..][0] of a pair it cannot select in its small per-wave storage
+// (a NaN with a payload no arithmetic produces); the workgroup kernel launched after it picks those pairs up
+constexpr unsigned long long QUANT_FLAG = 0x7ff8dead00000001ULL;
+__device__ __forceinline__ bool quant_flagged(const QuantArgs& A, int64_t pair)
+{
+    return (unsigned long long)__double_as_longlong(A.out[pair * A.nq]) == QUANT_FLAG;
+}
 
 // numpy.percentile(method="linear") position of quantile level qq among m sorted values: lower index + fraction
 __device__ __forceinline__ void quantile_position(double qq, int m, int& i0, int& i1, double& f)
@@ -67,6 +76,7 @@ __device__ __forceinline__ void bitonic_sort_chain(const QuantArgs& A, int64_t e
 __global__ __launch_bounds__(BLOCK) void k_chain_quantiles(const QuantArgs A)
 {
     extern __shared__ double lds[];
+    if (A.only_flagged && !quant_flagged(A, blockIdx.x)) return;      // workgroup-uniform
     const int64_t e = blockIdx.x / A.D;
     const int d = (int)(blockIdx.x - e * A.D);
     const int m = (int)(A.nsteps * A.W);
@@ -114,6 +124,7 @@ __global__ __launch_bounds__(BLOCK) void k_chain_quantiles_select(const QuantArg
     int* flags = reinterpret_cast<int*>(red + 8);                          // [0] fallback, [1] number of lists
     double* result = reinterpret_cast<double*>(flags + 2);                 // [QSEL_RANKS]
 
+    if (A.only_flagged && !quant_flagged(A, blockIdx.x)) return;          // workgroup-uniform
     const int64_t e = blockIdx.x / A.D;
     const int d = (int)(blockIdx.x - e * A.D);
     const int m = (int)(A.nsteps * A.W);
@@ -256,5 +267,206 @@ __global__ __launch_bounds__(BLOCK) void k_chain_quantiles_select(const QuantArg
         double f;
         quantile_position(A.q[tid], m, i0, i1, f);
         A.out[(e * A.D + d) * A.nq + tid] = quantile_lerp(result[2 * tid], result[2 * tid + 1], f);
+    }
+}
+
+
+// -------------------------------------------------------------------------------------------
+// Selection with ONE WAVEFRONT per (ensemble, parameter) pair, the values held in registers.
+// The workgroup kernel above spends its time in barriers between short phases (~60 us per pair for 3 200
+// values, 1 280 pairs in flight): a wave needs no barrier at all, keeps its <= 64 x IPL values in VGPRs after a
+// single pass over the chain, and 16 waves per CU are in flight.  Same algorithm: min / max, 1 024-bin
+// histogram in the wave's own LDS, prefix, the (at most 2 nq) target bins gathered into one small pool, rank by
+// counting.  A pair whose target bins overflow the pool (hundreds of identical values) or whose values are
+// not finite is flagged in `out` and left to the workgroup kernel, launched right after with only_flagged = 1.
+// -------------------------------------------------------------------------------------------
+constexpr int QW_IPL = 52;          // values per lane: up to 3 328 per pair (32 walkers x 100 steps = 3 200)
+constexpr int QW_POOL = 448;        // doubles of gathered target-bin elements per wave
+constexpr int QW_WAVES = BLOCK / 64;
+// per-wave LDS: histogram / slot map, pool, 16 x {bin, local rank, slot}, 16 x {offset, count, fill}, 16 results
+constexpr int QW_LDS_PER_WAVE = QSEL_BINS * 4 + QW_POOL * 8 + 6 * QSEL_RANKS * 4 + QSEL_RANKS * 8;
+
+__device__ __forceinline__ void qw_sync()
+{
+    __threadfence_block();
+    __builtin_amdgcn_wave_barrier();
+}
+
+// (capping the registers at 128 for a fourth wave per SIMD spills 106 of them: measured 22 instead of 16.5 ns per pair)
+__global__ __launch_bounds__(BLOCK) void k_chain_quantiles_wave(const QuantArgs A)
+{
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t pair = (int64_t)blockIdx.x * QW_WAVES + wave;
+    if (pair >= A.n_ens * A.D) return;                              // wave-uniform; no workgroup barrier below
+    char* base = reinterpret_cast<char*>(lds) + (size_t)wave * QW_LDS_PER_WAVE;
+    double* pool = reinterpret_cast<double*>(base);
+    double* result = pool + QW_POOL;
+    int* hist = reinterpret_cast<int*>(result + QSEL_RANKS);
+    int* rank_bin = hist + QSEL_BINS;
+    int* rank_local = rank_bin + QSEL_RANKS;
+    int* rank_slot = rank_local + QSEL_RANKS;
+    int* list_off = rank_slot + QSEL_RANKS;
+    int* list_cnt = list_off + QSEL_RANKS;
+    int* list_fill = list_cnt + QSEL_RANKS;
+
+    const int64_t e = pair / A.D;
+    const int d = (int)(pair - e * A.D);
+    const int m = (int)(A.nsteps * A.W);
+    const int64_t rows = A.n_ens * A.W;
+    const int n_ranks = 2 * A.nq;
+
+    // ---- the only pass over the chain: value i of the pair lives in lane i % 64, register i / 64 ----
+    double v[QW_IPL];
+    double mn = d_inf(), mx = -d_inf();
+    {
+        // i = t W + w advances by 64 per register: (t, w) += (64 / W, 64 % W) with a carry, no division in the loop
+        const int dq = 64 / A.W, dr = 64 - dq * A.W;
+        int t = lane / A.W, w = lane - t * A.W;
+        const double* __restrict__ src = A.chain + (e * A.W) * A.D + d;
+        const int64_t step_stride = rows * A.D;
+#pragma unroll
+        for (int k = 0; k < QW_IPL; ++k) {
+            const bool have = k * 64 + lane < m;
+            // unconditional load (element 0 of the pair for the padding lanes): the 52 loads issue back to back
+            double x = src[have ? (int64_t)t * step_stride + w * A.D : 0];
+            x = (have && x == x) ? x : d_inf();                     // NaN sorts last, as chain_value
+            v[k] = x;
+            mn = fmin(mn, x);
+            mx = have ? fmax(mx, x) : mx;
+            t += dq;
+            w += dr;
+            if (w >= A.W) {
+                w -= A.W;
+                ++t;
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        mn = fmin(mn, __shfl_xor(mn, off));
+        mx = fmax(mx, __shfl_xor(mx, off));
+    }
+    const double inv = (double)QSEL_BINS / (mx - mn);
+    const bool degenerate = !(mx > mn) || !isfinite(inv) || !isfinite(mn);
+    if (degenerate) {
+        const bool flat = !(mx > mn) && isfinite(mn) && isfinite(mx);        // every value equal
+        if (lane < A.nq) A.out[pair * A.nq + lane] = flat ? mn : __longlong_as_double((long long)QUANT_FLAG);
+        return;
+    }
+    auto bin_of = [&](double x) { return min(QSEL_BINS - 1, (int)((x - mn) * inv)); };
+
+    // ---- histogram in the wave's LDS, exclusive prefix (16 bins per lane) ----
+#pragma unroll
+    for (int r = 0; r < QSEL_BINS / 64; ++r) hist[r * 64 + lane] = 0;
+    if (lane < QSEL_RANKS) list_fill[lane] = 0;
+    qw_sync();
+#pragma unroll
+    for (int k = 0; k < QW_IPL; ++k)
+        if (k * 64 + lane < m) atomicAdd(&hist[bin_of(v[k])], 1);
+    qw_sync();
+    {
+        constexpr int PER = QSEL_BINS / 64;
+        int c[PER];
+        int tot = 0;
+#pragma unroll
+        for (int r = 0; r < PER; ++r) {
+            c[r] = hist[lane * PER + r];
+            tot += c[r];
+        }
+        int incl = tot;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int up = __shfl_up(incl, off);
+            if (lane >= off) incl += up;
+        }
+        int run = incl - tot;
+        qw_sync();
+#pragma unroll
+        for (int r = 0; r < PER; ++r) {
+            hist[lane * PER + r] = run;                            // exclusive prefix
+            run += c[r];
+        }
+    }
+    qw_sync();
+    // ---- target ranks -> bin and rank inside the bin ----
+    if (lane < n_ranks) {
+        int i0, i1;
+        double f;
+        quantile_position(A.q[lane >> 1], m, i0, i1, f);
+        const int r = (lane & 1) ? i1 : i0;
+        int lo = 0, hi = QSEL_BINS - 1;                            // last bin whose exclusive prefix is <= r
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (hist[mid] <= r) lo = mid;
+            else hi = mid - 1;
+        }
+        rank_bin[lane] = lo;
+        rank_local[lane] = r - hist[lo];
+    }
+    qw_sync();
+    // ---- distinct target bins -> slots of the pool (lane 0; at most 16 short iterations) ----
+    int overflow = 0, n_lists = 0;
+    if (lane == 0) {
+        int used = 0;
+        for (int k = 0; k < n_ranks; ++k) {
+            const int b = rank_bin[k];
+            int sl = -1;
+            for (int j = 0; j < k; ++j)
+                if (rank_bin[j] == b) { sl = rank_slot[j]; break; }
+            if (sl < 0) {
+                const int cnt = ((b + 1 < QSEL_BINS) ? hist[b + 1] : m) - hist[b];
+                sl = n_lists++;
+                list_off[sl] = used;
+                list_cnt[sl] = cnt;
+                used += cnt;
+            }
+            rank_slot[k] = sl;
+        }
+        overflow = used > QW_POOL;
+    }
+    overflow = __shfl(overflow, 0);
+    n_lists = __shfl(n_lists, 0);
+    if (overflow) {                                                  // wave-uniform
+        if (lane < A.nq) A.out[pair * A.nq + lane] = __longlong_as_double((long long)QUANT_FLAG);
+        return;
+    }
+    qw_sync();
+    // ---- the histogram area becomes the bin -> slot map ----
+#pragma unroll
+    for (int r = 0; r < QSEL_BINS / 64; ++r) hist[r * 64 + lane] = -1;
+    qw_sync();
+    if (lane < n_ranks) hist[rank_bin[lane]] = rank_slot[lane];      // equal bins write equal slots
+    qw_sync();
+    // ---- gather the target bins' elements into the pool ----
+#pragma unroll
+    for (int k = 0; k < QW_IPL; ++k) {
+        if (k * 64 + lane < m) {
+            const int sl = hist[bin_of(v[k])];
+            if (sl >= 0) {
+                const int pos = atomicAdd(&list_fill[sl], 1);
+                pool[list_off[sl] + pos] = v[k];
+            }
+        }
+    }
+    qw_sync();
+    // ---- order statistic inside a list by counting ----
+    for (int k = 0; k < n_ranks; ++k) {
+        const int sl = rank_slot[k], cnt = list_cnt[sl], want = rank_local[k];
+        const double* L = pool + list_off[sl];
+        for (int j = lane; j < cnt; j += 64) {
+            const double x = L[j];
+            int before = 0;
+            for (int i = 0; i < cnt; ++i) {
+                const double y = L[i];
+                before += (y < x || (y == x && i < j)) ? 1 : 0;
+            }
+            if (before == want) result[k] = x;
+        }
+    }
+    qw_sync();
+    if (lane < A.nq) {
+        int i0, i1;
+        double f;
+        quantile_position(A.q[lane], m, i0, i1, f);
+        A.out[pair * A.nq + lane] = quantile_lerp(result[2 * lane], result[2 * lane + 1], f);
     }
 }

@@ -682,21 +682,25 @@ def test_catalog_columns_path_equals_descriptor_path():
         a.close(); b.close()
 
 
-@pytest.mark.parametrize("mode", ["select", "sort"])
+@pytest.mark.parametrize("mode", ["wave", "workgroup", "sort"])
 def test_chain_quantiles_adversarial_inputs(mode, monkeypatch):
-    """iso_chain_quantiles on hand-made chains (both the selection kernel and the full LDS sort): smooth data,
-    constant chains, heavy ties (falls back to the sort inside the selection kernel), tiny and odd sample counts,
-    infinities; always numpy.percentile's numbers."""
+    """iso_chain_quantiles on hand-made chains (the wave-per-pair selection kernel with its flagged hand-over, the
+    workgroup selection kernel, and the full LDS sort): smooth data, constant chains, heavy ties (overflow the
+    selection lists: handed to the workgroup kernel / its sort), tiny and odd sample counts, more values than the
+    wave kernel holds, infinities; always numpy.quantile's numbers, bit for bit."""
     import ctypes as C
     import torch
     from isochrones_amd import _cabi, device as dev
-    if mode == "sort":
-        monkeypatch.setenv("ISOCHRONES_AMD_QUANTILES", "sort")
+    if mode != "wave":
+        monkeypatch.setenv("ISOCHRONES_AMD_QUANTILES", mode)
     lib, ctx = _cabi.lib(), dev.context(0)
     rng = np.random.default_rng(21)
     qs = np.array([0.5, 0.16, 0.84, 0.0, 1.0, 0.999, 0.3333])
-    for nsteps, S, W, D in ((100, 9, 32, 5), (37, 4, 16, 3), (1, 3, 2, 2), (255, 2, 32, 6), (3, 5, 1, 1)):
+    for nsteps, S, W, D in ((100, 9, 32, 5), (37, 4, 16, 3), (1, 3, 2, 2), (255, 2, 32, 6), (3, 5, 1, 1), (104, 3, 32, 2),
+                            (100, 1031, 32, 5)):
         x = rng.standard_normal((nsteps, S * W, D))
+        if S > 1000:
+            x[:, 5 * W:6 * W, 3] = np.exp(3 * x[:, 5 * W:6 * W, 3])      # long tail: most values share the first bins
         x[:, :W, 0] = 3.25                                        # ensemble 0, parameter 0: constant
         if D > 1:
             x[:, :W, 1] = rng.integers(0, 3, size=(nsteps, W))   # heavy ties
