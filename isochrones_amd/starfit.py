@@ -107,6 +107,9 @@ def _batch_starfit_device(folders, multiplicities=("single",), models="mist", in
     from .catalog import StarCatalog, fit_stars_gpu
     from .starmodel import BasicStarModel
     logger = logger or logging.getLogger("isochrones_amd.starfit")
+    if unused:
+        logger.warning("batch_starfit(batched=True) samples with the ensemble sampler; ignored keywords: %s",
+                       ", ".join(sorted(unused)))
     out = {}
     # ---- read every ini once; anything the batch cannot express is fitted on its own afterwards ----
     recs, alone = [], []
