@@ -288,7 +288,7 @@ int  iso_sampler_run(iso_sampler* s, double* pos, double* lnp, int nsteps, doubl
  * star (the reference takes them from the pandas samples of every star, isochrones/starfit.py + catalog
  * drivers).  chain is iso_sampler_run's chain output [nsteps][n_ens*W][n_params]; for every ensemble e and
  * parameter d the order statistics of the nsteps*W values are selected (one wavefront per pair with the values
- * in registers; a workgroup selection / LDS sort for more than 3328 values or heavy ties) and
+ * in registers; a workgroup selection / LDS sort for more than 6656 values or heavy ties) and
  * out[(e*n_params + d)*nq + k] receives the q[k] quantile with linear interpolation between order statistics
  * (numpy.percentile's default, bit for bit).  q is a HOST array of nq <= 8 levels in [0, 1]; nsteps*W <= 8192.
  * ISOCHRONES_AMD_QUANTILES=workgroup|sort forces the older forms (tests, A/B runs). */

@@ -1745,12 +1745,15 @@ int iso_chain_quantiles(iso_ctx* ctx, const double* chain, int64_t nsteps, int64
     A.only_flagged = 0;
     if (qm && !std::strcmp(qm, "sort")) {
         hipLaunchKernelGGL(k_chain_quantiles, g, b, sort_bytes, as_stream(stream), A);
-    } else if (m <= 64 * QW_IPL && !(qm && !std::strcmp(qm, "workgroup"))) {
+    } else if (m <= 64 * QW_IPL_BIG && !(qm && !std::strcmp(qm, "workgroup"))) {
         // one wave per pair, values in registers; the few pairs it flags (heavy ties, non-finite values) go to the
         // workgroup kernel, which exits at once everywhere else
         const int64_t pairs = n_ens * n_params;
         const dim3 gw((unsigned)((pairs + QW_WAVES - 1) / QW_WAVES));
-        hipLaunchKernelGGL(k_chain_quantiles_wave, gw, b, (size_t)QW_WAVES * QW_LDS_PER_WAVE, as_stream(stream), A);
+        if (m <= 64 * QW_IPL)
+            hipLaunchKernelGGL(k_chain_quantiles_wave<QW_IPL>, gw, b, (size_t)QW_WAVES * QW_LDS_PER_WAVE, as_stream(stream), A);
+        else
+            hipLaunchKernelGGL(k_chain_quantiles_wave<QW_IPL_BIG>, gw, b, (size_t)QW_WAVES * QW_LDS_PER_WAVE, as_stream(stream), A);
         HIP_TRY(hipGetLastError());
         A.only_flagged = 1;
         hipLaunchKernelGGL(k_chain_quantiles_select, g, b, std::max(sel_bytes, sort_bytes), as_stream(stream), A);

@@ -281,6 +281,7 @@ __global__ __launch_bounds__(BLOCK) void k_chain_quantiles_select(const QuantArg
 // not finite is flagged in `out` and left to the workgroup kernel, launched right after with only_flagged = 1.
 // -------------------------------------------------------------------------------------------
 constexpr int QW_IPL = 52;          // values per lane: up to 3 328 per pair (32 walkers x 100 steps = 3 200)
+constexpr int QW_IPL_BIG = 104;     // second instantiation: up to 6 656 per pair at two waves per SIMD
 constexpr int QW_POOL = 448;        // doubles of gathered target-bin elements per wave
 constexpr int QW_WAVES = BLOCK / 64;
 // per-wave LDS: histogram / slot map, pool, 16 x {bin, local rank, slot}, 16 x {offset, count, fill}, 16 results
@@ -293,6 +294,7 @@ __device__ __forceinline__ void qw_sync()
 }
 
 // (capping the registers at 128 for a fourth wave per SIMD spills 106 of them: measured 22 instead of 16.5 ns per pair)
+template <int IPL>
 __global__ __launch_bounds__(BLOCK) void k_chain_quantiles_wave(const QuantArgs A)
 {
     extern __shared__ double lds[];
@@ -317,7 +319,7 @@ __global__ __launch_bounds__(BLOCK) void k_chain_quantiles_wave(const QuantArgs 
     const int n_ranks = 2 * A.nq;
 
     // ---- the only pass over the chain: value i of the pair lives in lane i % 64, register i / 64 ----
-    double v[QW_IPL];
+    double v[IPL];
     double mn = d_inf(), mx = -d_inf();
     {
         // i = t W + w advances by 64 per register: (t, w) += (64 / W, 64 % W) with a carry, no division in the loop
@@ -326,7 +328,7 @@ __global__ __launch_bounds__(BLOCK) void k_chain_quantiles_wave(const QuantArgs 
         const double* __restrict__ src = A.chain + (e * A.W) * A.D + d;
         const int64_t step_stride = rows * A.D;
 #pragma unroll
-        for (int k = 0; k < QW_IPL; ++k) {
+        for (int k = 0; k < IPL; ++k) {
             const bool have = k * 64 + lane < m;
             // unconditional load (element 0 of the pair for the padding lanes): the 52 loads issue back to back
             double x = src[have ? (int64_t)t * step_stride + w * A.D : 0];
@@ -361,7 +363,7 @@ __global__ __launch_bounds__(BLOCK) void k_chain_quantiles_wave(const QuantArgs 
     if (lane < QSEL_RANKS) list_fill[lane] = 0;
     qw_sync();
 #pragma unroll
-    for (int k = 0; k < QW_IPL; ++k)
+    for (int k = 0; k < IPL; ++k)
         if (k * 64 + lane < m) atomicAdd(&hist[bin_of(v[k])], 1);
     qw_sync();
     {
@@ -438,7 +440,7 @@ __global__ __launch_bounds__(BLOCK) void k_chain_quantiles_wave(const QuantArgs 
     qw_sync();
     // ---- gather the target bins' elements into the pool ----
 #pragma unroll
-    for (int k = 0; k < QW_IPL; ++k) {
+    for (int k = 0; k < IPL; ++k) {
         if (k * 64 + lane < m) {
             const int sl = hist[bin_of(v[k])];
             if (sl >= 0) {

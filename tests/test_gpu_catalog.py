@@ -697,7 +697,8 @@ def test_chain_quantiles_adversarial_inputs(mode, monkeypatch):
     rng = np.random.default_rng(21)
     qs = np.array([0.5, 0.16, 0.84, 0.0, 1.0, 0.999, 0.3333])
     for nsteps, S, W, D in ((100, 9, 32, 5), (37, 4, 16, 3), (1, 3, 2, 2), (255, 2, 32, 6), (3, 5, 1, 1), (104, 3, 32, 2),
-                            (60, 3, 48, 2), (30, 2, 100, 3), (7, 2, 65, 2), (100, 1031, 32, 5)):
+                            (60, 3, 48, 2), (30, 2, 100, 3), (7, 2, 65, 2), (200, 5, 32, 3), (208, 2, 32, 2), (209, 2, 32, 2),
+                            (100, 1031, 32, 5)):
         x = rng.standard_normal((nsteps, S * W, D))
         if S > 1000:
             x[:, 5 * W:6 * W, 3] = np.exp(3 * x[:, 5 * W:6 * W, 3])      # long tail: most values share the first bins
