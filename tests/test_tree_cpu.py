@@ -269,3 +269,23 @@ def test_reference_spellings_of_tree_queries_and_prior_names():
     assert priors.BoundedPrior is priors.Prior and priors.EEP_prior.__name__ == "EEPPrior"
     with pytest.raises(AttributeError):
         priors.NoSuchPrior
+
+
+def test_from_ini_with_an_obsfile(tmp_path):
+    """star.ini with ``obsfile = obs.csv`` (reference starmodel.py:262-275, 427-428): the photometry table
+    comes from the csv, spectroscopy / N / index from the ini."""
+    meta = fx.load("tree_resolved_unassoc")["meta"]
+    ic, direct = make_tree_model(meta)
+    folder = tmp_path / "KOI-7"
+    folder.mkdir()
+    build_notebook_tree("x").to_df().to_csv(folder / "obs.csv", index=False)
+    kw = meta["kwargs"]
+    lines = ["obsfile = obs.csv", "index = 0, 1"]
+    lines += ["%s = %r, %r" % (k, v[0], v[1]) for k, v in kw.items() if k not in ("N", "index")]
+    (folder / "star.ini").write_text("\n".join(lines) + "\n")
+    mod = ia.StarModel.from_ini(ic, folder=str(folder))
+    assert mod.name == "KOI-7" and mod.param_names == direct.param_names and mod.obs.leaf_labels == direct.obs.leaf_labels
+    g = fx.load("tree_resolved_unassoc")
+    oic = fx.make_oracle_ic(ic)
+    a = orc.tree_lnpost(oic, mod.tree_desc(), g["pars"].T.copy())[0]
+    fx.assert_close(a, g["lnpost"], 1e-11, atol=1e-11, what="lnpost of the obsfile model vs the reference golden")
