@@ -13,7 +13,7 @@ from ._cabi import IsoError
 from .sampler import EnsembleSampler, FusedEnsembleSampler
 from .catalog import (StarCatalog, CatalogPosterior, fit_catalog, synthetic_catalog, shard_of, shard_indices,
                       broadcast_interpolator)
-from . import priors, grids, ingest, mist, nested, ini, persist
+from . import priors, grids, ingest, mist, nested, ini, persist, utils
 from .starfit import starfit, batch_starfit
 
 __version__ = "0.1.0"

@@ -195,3 +195,17 @@ def test_table_files_round_trip(tmp_path):
     d1 = ia.SingleStarModel(ic, G=(10.0, 0.02), Teff=(5700, 100)).model_desc()
     d2 = ia.SingleStarModel(ic2, G=(10.0, 0.02), Teff=(5700, 100)).model_desc()
     assert d1.n_bands == d2.n_bands == 1 and d1.bc_cols[0] == d2.bc_cols[0] == 1
+
+
+def test_utils_known_answers():
+    """isochrones_amd.utils against values computed with the reference's isochrones.utils in the authoring
+    container (addmags with and without uncertainties, distance, band_pairs)."""
+    from isochrones_amd import utils
+    assert utils.addmags(10.0, 11.5) == 9.756693015728262
+    assert utils.addmags(10.0, 11.5, 12.25) == 9.652601139068326
+    m, u = utils.addmags((10.0, 0.02), (11.0, 0.05))
+    assert (m, u) == (9.636148842226767, 0.02004642829733418)
+    assert utils.addmags((10.0, 0.02), 11.0)[1] == 0.01426743937691573
+    assert utils.distance((0.6, 100), (1.2, 200)) == 1.4318007458582984
+    assert utils.fast_addmags([10.0, 11.0]) == 9.636148842226767
+    assert utils.band_pairs("JHK") == [("J", "K"), ("H", "K")]
