@@ -429,6 +429,20 @@ class SalpeterPrior(PowerLawPrior):
         super().__init__(alpha=-2.35, bounds=bounds)
 
 
+def BrokenPrior(components, breakpoints, bounds=None):
+    """The reference's stitched-together prior (priors.py:143-232).  The device evaluates one such composition,
+    the one the reference itself uses: a log-normal below a single breakpoint and a power law above it — with
+    any parameters — so that is what this builds (a :class:`ChabrierPrior` with those parameters)."""
+    comps = list(components)
+    if (len(comps) == 2 and len(breakpoints) == 1 and isinstance(comps[0], LogNormalPrior)
+            and isinstance(comps[1], PowerLawPrior)):
+        lo_hi = bounds if bounds is not None else (0.0, float(comps[1].bounds[1]))
+        return ChabrierPrior(bounds=lo_hi, mu=comps[0].mu, sigma=comps[0].sigma, alpha=comps[1].alpha,
+                             breakpoint=float(breakpoints[0]), powerlaw_bounds=tuple(comps[1].bounds))
+    raise NotImplementedError("the device evaluates broken priors of the form [LogNormalPrior, PowerLawPrior] with one "
+                              "breakpoint (the Chabrier composition); got %s" % [type(c).__name__ for c in comps])
+
+
 BoundedPrior = Prior        # the reference splits Prior / BoundedPrior (priors.py:107-141); one class covers both here
 
 

@@ -617,3 +617,28 @@ def test_docs_grid_interpolator_notebook_flow():
     assert isinstance(d, dict) and d["A_G"][0] > 0 and d["A_K"][0] > 0        # toy BC tables: no band ordering
     big = mist_track.generate(np.ones(10000) * 1.01, np.ones(10000) * 9.82, np.ones(10000) * 0.02)
     assert len(big) == 10000
+
+
+def test_broken_prior_with_custom_parameters_on_the_device():
+    """priors.BrokenPrior([LogNormal, PowerLaw], [bp]) (reference priors.py:143-232) with non-Chabrier numbers as
+    the mass prior of a track model: the kernel's lnprior moves by exactly log(custom(m)) - log(default(m)), and
+    the oracle agrees with the kernel on the whole batch."""
+    from isochrones_amd import priors as P
+    g = fx.load("track_single_spec_phot")
+    mod = fx.make_model(g["meta"])
+    ic = mod.ic
+    pars = g["pars"]
+    base = mod.lnprior(pars)
+    custom = P.BrokenPrior([P.LogNormalPrior(np.log(0.2), 0.6), P.PowerLawPrior(-2.0, (0.8, 50.0))], [0.8], bounds=(0.05, 50.0))
+    default = mod._priors["mass"]
+    mod.set_prior(mass=custom)
+    got = mod.lnprior(pars)
+    fin = np.isfinite(base) & np.isfinite(got)
+    assert fin.sum() > 50
+    want = np.array([custom.lnpdf(m) - default.lnpdf(m) for m in pars[fin, 0]])
+    assert np.allclose(got[fin] - base[fin], want, rtol=1e-10, atol=1e-10)
+    oic = fx.make_oracle_ic(ic)
+    ref = oic.lnpost(mod.model_desc(), np.ascontiguousarray(pars.T))
+    fx.assert_close(mod.lnpost(pars), ref[0], RTOL, atol=ATOL, what="lnpost with a custom broken prior")
+    with pytest.raises(NotImplementedError):
+        P.BrokenPrior([P.FlatPrior((0, 1)), P.PowerLawPrior(-2.0, (1.0, 50.0))], [1.0])
