@@ -16,3 +16,8 @@ def MIST_Isochrone(bands=None, **kwargs):
 def MIST_EvolutionTrack(bands=None, **kwargs):
     """(mass, eep, feh, distance, AV) interpolator over the [15, 196, 1710] evolution-track grid."""
     return get_ichrone("mist", bands=bands, tracks=True, **kwargs)
+
+
+# the reference's "Basic" variants skip the companion grid; here both forms are the same object
+MIST_BasicIsochrone = MIST_Isochrone
+MIST_BasicEvolutionTrack = MIST_EvolutionTrack

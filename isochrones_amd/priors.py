@@ -429,6 +429,21 @@ class SalpeterPrior(PowerLawPrior):
         super().__init__(alpha=-2.35, bounds=bounds)
 
 
+ONE_OVER_ROOT_2PI = 1.0 / _ROOT_2PI
+LOG_ONE_OVER_ROOT_2PI = float(np.log(ONE_OVER_ROOT_2PI))
+
+
+def powerlaw_pdf(x, alpha, lo, hi):
+    """Normalised x^alpha on (lo, hi) (reference: priors.py:470-473)."""
+    a1 = alpha + 1
+    return a1 / (hi ** a1 - lo ** a1) * x ** alpha
+
+
+def powerlaw_lnpdf(x, alpha, lo, hi):
+    a1 = alpha + 1
+    return np.log(a1 / (hi ** a1 - lo ** a1)) + alpha * np.log(x)
+
+
 def BrokenPrior(components, breakpoints, bounds=None):
     """The reference's stitched-together prior (priors.py:143-232).  The device evaluates one such composition,
     the one the reference itself uses: a log-normal below a single breakpoint and a power law above it — with
