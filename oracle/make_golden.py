@@ -423,33 +423,33 @@ def _rows(instrument, resolution, relative, bands):
 INI_CASES = {
     "single": dict(
         kwargs=dict(Teff=(5750, 98.0), feh=(-0.06, 0.16), logg=(4.41, 0.1)),
-        rows=_rows("twomass", 4.0, False, [("J", [(0, 0, 13.413, 0.02)]), ("H", [(0, 0, 13.045, 0.02)]),
-                                           ("K", [(0, 0, 12.993, 0.02)])])
-        + _rows("Gaia", 4.0, False, [("G", [(0, 0, 14.6, 0.05)]), ("RP", [(0, 0, 14.1, 0.05)])]),
+        rows=_rows("2MASS", 4.0, False, [("J", [(0, 0, 13.413, 0.02)]), ("H", [(0, 0, 13.045, 0.02)]),
+                                         ("K", [(0, 0, 12.993, 0.02)])])
+        + _rows("GaiaDR3", 4.0, False, [("G", [(0, 0, 14.6, 0.05)]), ("RP", [(0, 0, 14.1, 0.05)])]),
         variants={"": {}}),
     "binary": dict(
         kwargs={},
-        rows=_rows("twomass", 4.0, False, [("J", [(10, 100, 14.513, 0.02), (0, 0, 13.513, 0.02)]),
-                                           ("H", [(10, 100, 14.045, 0.02), (0, 0, 13.145, 0.02)]),
-                                           ("K", [(10, 100, 13.993, 0.02), (0, 0, 13.093, 0.02)])])
-        + _rows("Gaia", 4.0, False, [("G", [(10, 100, 15.9, 0.02), (0, 0, 14.7, 0.02)]),
-                                     ("BP", [(10, 100, 16.4, 0.02), (0, 0, 15.1, 0.02)]),
-                                     ("RP", [(10, 100, 15.3, 0.02), (0, 0, 14.2, 0.02)])]),
+        rows=_rows("GaiaDR3", 4.0, False, [("G", [(10, 100, 15.9, 0.02), (0, 0, 14.7, 0.02)]),
+                                           ("BP", [(10, 100, 16.4, 0.02), (0, 0, 15.1, 0.02)]),
+                                           ("RP", [(10, 100, 15.3, 0.02), (0, 0, 14.2, 0.02)])])
+        + _rows("2MASS", 4.0, False, [("J", [(10, 100, 14.513, 0.02), (0, 0, 13.513, 0.02)]),
+                                      ("H", [(10, 100, 14.045, 0.02), (0, 0, 13.145, 0.02)]),
+                                      ("K", [(10, 100, 13.993, 0.02), (0, 0, 13.093, 0.02)])]),
         variants={"": {}, "_unassoc": dict(index=[0, 1])}),
     "triple": dict(
         kwargs=dict(maxAV=0.9, Teff=(5700, 98.0), feh=(-0.1, 0.16), logg=(4.45, 0.1)),
-        rows=_rows("twomass", 4.0, False, [("J", [(0, 0, 13.313, 0.02)]), ("H", [(0, 0, 12.945, 0.02)]),
-                                           ("K", [(0, 0, 12.893, 0.02)])])
-        + _rows("NIRC2", 0.1, True, [("K", [(0.6, 100, 1.66, 0.05), (1.2, 200, 2.1, 0.1)]),
-                                     ("H", [(0.6, 100, 1.77, 0.03), (1.2, 200, 2.2, 0.1)]),
-                                     ("J", [(0.6, 100, 1.84, 0.05), (1.2, 200, 2.35, 0.1)])]),
+        rows=_rows("2MASS", 4.0, False, [("J", [(0, 0, 13.313, 0.02)]), ("H", [(0, 0, 12.945, 0.02)]),
+                                         ("K", [(0, 0, 12.893, 0.02)])])
+        + _rows("KeckAO", 0.1, True, [("K", [(0.6, 100, 1.66, 0.05), (1.2, 200, 2.1, 0.1)]),
+                                      ("H", [(0.6, 100, 1.77, 0.03), (1.2, 200, 2.2, 0.1)]),
+                                      ("J", [(0.6, 100, 1.84, 0.05), (1.2, 200, 2.35, 0.1)])]),
         variants={"": {}, "_unassoc1": dict(index=[0, 0, 1]), "_unassoc2": dict(index=[0, 1, 1])}),
     "triple_b": dict(
-        kwargs=dict(maxAV=0.8, Teff=(5765, 109), feh=(0.020, 0.150), logg=(4.449, 0.085)),
-        rows=_rows("twomass", 4.0, False, [("J", [(0, 0, 13.252, 0.021)]), ("H", [(0, 0, 12.910, 0.019)]),
-                                           ("K", [(0, 0, 12.871, 0.013)])])
-        + _rows("Lick", 0.5, True, [("H", [(3.842, 53.056, 1.343, 0.01), (12.073, 256.378, 2.488, 0.01)]),
-                                    ("K", [(3.842, 53.056, 1.305, 0.055)])]),
+        kwargs=dict(maxAV=0.7, Teff=(5810, 90), feh=(0.05, 0.12), logg=(4.40, 0.09)),
+        rows=_rows("2MASS", 4.0, False, [("J", [(0, 0, 13.31, 0.02)]), ("H", [(0, 0, 12.96, 0.02)]),
+                                         ("K", [(0, 0, 12.91, 0.015)])])
+        + _rows("ShaneAO", 0.5, True, [("H", [(2.95, 41.5, 1.41, 0.01), (9.4, 230.0, 2.55, 0.01)]),
+                                       ("K", [(2.95, 41.5, 1.36, 0.05)])]),
         variants={"": {}, "_unassoc2": dict(index=[0, 1, 1])}),
     "flat": dict(
         kwargs=dict(J=(13.3, 0.05), H=(12.95, 0.05), K=(12.9, 0.05), Teff=(5800, 150), parallax=(2.0, 0.1)),

@@ -178,7 +178,7 @@ def test_ini_reader_and_checks_of_reference_test_ini(tmp_path):
         assert len(mod.param_names) == npar and mod.n_params == npar
         assert mod.obs.systems == systems and mod.obs.Nstars == nstars
         assert mod.name == meta["ini"]
-    assert ia.TreeStarModel.get_bands(os.path.join(INI_DIR, "binary", "star.ini")) == ["J", "H", "K", "G", "BP", "RP"]
+    assert ia.TreeStarModel.get_bands(os.path.join(INI_DIR, "binary", "star.ini")) == ["G", "BP", "RP", "J", "H", "K"]
     _, tri = make_tree_model(fx.load("ini_triple")["meta"])
     assert tri.bounds("AV") == (0, 0.9)
     # the reader
