@@ -642,3 +642,33 @@ def test_broken_prior_with_custom_parameters_on_the_device():
     fx.assert_close(mod.lnpost(pars), ref[0], RTOL, atol=ATOL, what="lnpost with a custom broken prior")
     with pytest.raises(NotImplementedError):
         P.BrokenPrior([P.FlatPrior((0, 1)), P.PowerLawPrior(-2.0, (1.0, 50.0))], [1.0])
+
+
+def test_lnpost_on_mass_age_feh_distance_av_samples():
+    """BASELINE north star, literally: samples given as (mass, age, feh, distance, AV) -> EEP by get_eep on the device
+    -> fused lnpost on the device, against the same two steps on the CPU oracle (interp_eep + lnpost), <= 1e-9
+    (north star: 1e-6), identical NaN / -inf patterns; all of it on device tensors without a host round trip."""
+    import torch
+    from oracle import oracle as orc
+    ic = ia.synthetic_track(bands=("V",), fehs=np.array([-1.0, -0.5, -0.25, 0.0, 0.25, 0.5]),
+                            masses=ia.grids.mist_masses()[30:120:2], eeps=np.arange(150.0, 900.0), eep_bounds=(150, 899))
+    mod = ia.SingleStarModel(ic, Teff=(5770, 100), logg=(4.5, 0.1), feh=(0.0, 0.15), V=(10.0, 0.05), parallax=(10.0, 0.2))
+    rng = np.random.default_rng(99)
+    n = 200_000
+    lim = ic.model_grid.get_limits
+    mass = rng.uniform(lim("mass")[0] - 0.02, min(lim("mass")[1], 2.5), n)
+    age = rng.uniform(8.0, 10.2, n)
+    feh = rng.uniform(-1.05, 0.55, n)
+    dist, AV = rng.uniform(50.0, 200.0, n), rng.uniform(-0.01, 0.8, n)
+    t = lambda x: torch.as_tensor(x, device="cuda")
+    eep_dev = ic.get_eep(t(mass), t(age), t(feh))                                        # CUDA tensor
+    pars_dev = torch.stack([t(mass), eep_dev, t(feh), t(dist), t(AV)], dim=1).contiguous()
+    got = mod.lnpost(pars_dev).cpu().numpy()
+    ic._eep_handle(0)                                                                   # makes the ragged age arrays available
+    fehs, masses, _ = ic.model_grid.interp.index_columns
+    # the reference's interp_eeps returns 1 + the fractional row index (its EEP axis starts at 1); this table's starts at 150
+    eep_cpu = orc.interp_eep(age, feh, mass, fehs, masses, ic._age_grid, ic._array_lengths) + (150.0 - 1.0)
+    fx.assert_close(eep_dev.cpu().numpy(), eep_cpu, 1e-12, what="EEP of the (mass, age, feh) samples")
+    want = fx.make_oracle_ic(ic).lnpost(mod.model_desc(), np.ascontiguousarray(np.stack([mass, eep_cpu, feh, dist, AV])))[0]
+    fx.assert_close(got, want, RTOL, atol=ATOL, what="lnpost of (mass, age, feh, distance, AV) samples")
+    assert np.isfinite(want).sum() > 20_000 and np.isneginf(want).sum() > 1000
