@@ -17,6 +17,9 @@ star's batch — independent posteriors, no data-path collective (weak scaling);
 collectives are the timing barrier and the max-over-ranks reduction.
 
 Prints ONE JSON line (rank 0) with the driver's contract keys plus `roofline` and `cpu_baseline`.
+After the timed region (never part of `value`) the same ranks run BASELINE configs[4], the catalog path: a fixed
+synthetic catalog split over the ranks with batch_starfit's rule and fitted by the device-resident sampler, reported
+as `catalog` (stars/s at this N; strong scaling).  `--no-catalog` / `--no-extras` skip it.
 """
 from __future__ import annotations
 
@@ -144,6 +147,37 @@ def cpu_baseline(ic, mod, pars_host, wall_budget_s=4.0):
                 value_1thread=p1 * n1 / dt1), out
 
 
+def catalog_leg(rank, world, barrier, dist, reduce_device, sizes=(10_000, 400_000), nwalkers=32, nburn=150, niter=100):
+    """Strong scaling of the catalog path: the whole catalog has a fixed size, rank r fits the stars
+    scripts/batch_starfit would give task r (NR % P), and the wall-clock is the slowest rank's."""
+    import torch
+    import isochrones_amd as ia
+    from isochrones_amd.catalog import fit_stars_gpu, shard_indices
+    bands = ["G", "BP", "RP"]
+    ic = ia.synthetic_track(bands=bands)
+    warm, _ = ia.synthetic_catalog(ic, 64, bands=bands, seed=1, mag_unc=0.01)
+    fit_stars_gpu(warm, ic, np.arange(64), nwalkers=nwalkers, nburn=5, niter=5)          # framework-kernel warm-up
+    out = {"rule": "star i -> rank (i + 1) % P, no collective in the fit", "walkers": nwalkers, "steps": nburn + niter,
+           "bands": bands}
+    for n_stars in sizes:
+        cat, _truth = ia.synthetic_catalog(ic, n_stars, bands=bands, seed=7, mag_unc=0.01)
+        idx = shard_indices(n_stars, rank, world)
+        barrier()
+        t0 = time.perf_counter()
+        rows = fit_stars_gpu(cat, ic, idx, nwalkers=nwalkers, nburn=nburn, niter=niter, seed=11 + rank)
+        barrier()
+        wall = time.perf_counter() - t0
+        ok = float(np.mean(rows[:, -1] == 1)) if len(rows) else 1.0
+        stats = torch.tensor([wall, -ok], dtype=torch.float64, device=reduce_device)
+        if dist is not None:
+            dist.all_reduce(stats, op=dist.ReduceOp.MAX)
+        wall, ok_min = float(stats[0]), -float(stats[1])
+        out["%d_stars" % n_stars] = {"wall_s": wall, "stars_per_s": n_stars / wall, "stars_per_rank": int(len(idx)),
+                                     "lnpost_evals": int(n_stars) * nwalkers * (nburn + niter), "ok_fraction_min": ok_min}
+        del cat, rows
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -157,6 +191,7 @@ def main():
                          "posterior: MCMC-like Gaussian ball (cache resident)")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary workloads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-catalog", action="store_true", help="skip the catalog-sharding leg (BASELINE configs[4])")
     ap.add_argument("--path", default=None, choices=["auto", "compact", "generic"],
                     help="kernel/table-layout selection (default: library default = auto)")
     args = ap.parse_args()
@@ -285,6 +320,15 @@ def main():
         dt_h = (time.perf_counter() - t_h) / 3
         result["host_array_path"] = {"ms": dt_h * 1e3, "evals_per_s": args.n / dt_h,
                                      "note": "mod.lnpost(numpy [N,5]) -> numpy [N], PCIe transfers included"}
+    if not args.no_extras and not args.no_catalog:
+        # BASELINE configs[4] on the same ranks: a synthetic catalog split over the GPUs with the reference's
+        # batch_starfit rule, every rank fitting its stars with the device-resident sampler.  No data-path
+        # collective; the same barrier + max-over-ranks timing as above.  Reported next to the metric, never `value`.
+        try:
+            result["catalog"] = catalog_leg(rank, world, barrier, dist if distributed else None,
+                                            "cuda" if backend == "nccl" else "cpu")
+        except Exception as e:       # noqa: BLE001 - the extra leg must not take the benchmark line down
+            result["catalog"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             base, ref = cpu_baseline(ic, mod, pars_host)
