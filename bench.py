@@ -149,32 +149,50 @@ def cpu_baseline(ic, mod, pars_host, wall_budget_s=4.0):
 
 def catalog_leg(rank, world, barrier, dist, reduce_device, sizes=(10_000, 400_000), nwalkers=32, nburn=150, niter=100):
     """Strong scaling of the catalog path: the whole catalog has a fixed size, rank r fits the stars
-    scripts/batch_starfit would give task r (NR % P), and the wall-clock is the slowest rank's."""
+    scripts/batch_starfit would give task r (NR % P), and the wall-clock is the slowest rank's.
+    Every rank reaches every barrier / reduction whatever happens to its own work (a local failure is recorded
+    and reported, it never leaves the other ranks waiting)."""
     import torch
     import isochrones_amd as ia
     from isochrones_amd.catalog import fit_stars_gpu, shard_indices
     bands = ["G", "BP", "RP"]
-    ic = ia.synthetic_track(bands=bands)
-    warm, _ = ia.synthetic_catalog(ic, 64, bands=bands, seed=1, mag_unc=0.01)
-    fit_stars_gpu(warm, ic, np.arange(64), nwalkers=nwalkers, nburn=5, niter=5)          # framework-kernel warm-up
+    err, ic = None, None
+    try:
+        ic = ia.synthetic_track(bands=bands)
+        warm, _ = ia.synthetic_catalog(ic, 64, bands=bands, seed=1, mag_unc=0.01)
+        fit_stars_gpu(warm, ic, np.arange(64), nwalkers=nwalkers, nburn=5, niter=5)      # framework-kernel warm-up
+    except Exception as e:           # noqa: BLE001
+        err = "%s: %s" % (type(e).__name__, e)
     out = {"rule": "star i -> rank (i + 1) % P, no collective in the fit", "walkers": nwalkers, "steps": nburn + niter,
            "bands": bands}
     for n_stars in sizes:
-        cat, _truth = ia.synthetic_catalog(ic, n_stars, bands=bands, seed=7, mag_unc=0.01)
-        idx = shard_indices(n_stars, rank, world)
+        cat, idx, ok = None, np.empty(0, dtype=int), 0.0
+        try:
+            if err is None:
+                cat, _truth = ia.synthetic_catalog(ic, n_stars, bands=bands, seed=7, mag_unc=0.01)
+                idx = shard_indices(n_stars, rank, world)
+        except Exception as e:       # noqa: BLE001
+            err = "%s: %s" % (type(e).__name__, e)
         barrier()
         t0 = time.perf_counter()
-        rows = fit_stars_gpu(cat, ic, idx, nwalkers=nwalkers, nburn=nburn, niter=niter, seed=11 + rank)
+        try:
+            if err is None:
+                rows = fit_stars_gpu(cat, ic, idx, nwalkers=nwalkers, nburn=nburn, niter=niter, seed=11 + rank)
+                ok = float(np.mean(rows[:, -1] == 1)) if len(rows) else 1.0
+        except Exception as e:       # noqa: BLE001
+            err = "%s: %s" % (type(e).__name__, e)
         barrier()
         wall = time.perf_counter() - t0
-        ok = float(np.mean(rows[:, -1] == 1)) if len(rows) else 1.0
-        stats = torch.tensor([wall, -ok], dtype=torch.float64, device=reduce_device)
+        stats = torch.tensor([wall, -ok, 1.0 if err is not None else 0.0], dtype=torch.float64, device=reduce_device)
         if dist is not None:
             dist.all_reduce(stats, op=dist.ReduceOp.MAX)
-        wall, ok_min = float(stats[0]), -float(stats[1])
-        out["%d_stars" % n_stars] = {"wall_s": wall, "stars_per_s": n_stars / wall, "stars_per_rank": int(len(idx)),
-                                     "lnpost_evals": int(n_stars) * nwalkers * (nburn + niter), "ok_fraction_min": ok_min}
-        del cat, rows
+        wall, ok_min, failed = float(stats[0]), -float(stats[1]), bool(stats[2] > 0)
+        if failed:
+            out["%d_stars" % n_stars] = {"error": err or "a rank other than 0 failed"}
+        else:
+            out["%d_stars" % n_stars] = {"wall_s": wall, "stars_per_s": n_stars / wall, "stars_per_rank": int(len(idx)),
+                                         "lnpost_evals": int(n_stars) * nwalkers * (nburn + niter), "ok_fraction_min": ok_min}
+        cat = None
     return out
 
 
