@@ -10,6 +10,9 @@ here into one ``.npz`` container (numpy only: pytables / h5py are optional and a
 * ``meta``        — JSON: class, name, N / index, measurements, bounds, grid type and bands, evidence,
 * ``priors``      — the prior objects, pickled (as the reference does through HDF5 attributes).
 
+The prior objects are pickled, exactly as pandas pickles them into the reference's HDF5 attributes: load only
+files you wrote yourself (unpickling runs code).
+
 ``save_hdf`` / ``load_hdf`` keep the reference's names: they write / read this container when the file
 name ends in ``.npz`` and otherwise need pytables (pandas ``HDFStore``) for the reference's own layout.
 """
