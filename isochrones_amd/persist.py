@@ -10,8 +10,8 @@ here into one ``.npz`` container (numpy only: pytables / h5py are optional and a
 * ``meta``        — JSON: class, name, N / index, measurements, bounds, grid type and bands, evidence,
 * ``priors``      — the prior objects, pickled (as the reference does through HDF5 attributes).
 
-The prior objects are pickled, exactly as pandas pickles them into the reference's HDF5 attributes: load only
-files you wrote yourself (unpickling runs code).
+The prior objects are pickled, as pandas pickles them into the reference's HDF5 attributes; on loading, only this
+package's prior classes (and the numpy arrays inside them) are accepted — anything else in the stream is refused.
 
 ``save_hdf`` / ``load_hdf`` keep the reference's names: they write / read this container when the file
 name ends in ``.npz`` and otherwise need pytables (pandas ``HDFStore``) for the reference's own layout.
@@ -25,6 +25,23 @@ import pickle
 import numpy as np
 
 FORMAT_VERSION = 1
+
+
+class _PriorUnpickler(pickle.Unpickler):
+    """Only this package's prior classes and the numpy array machinery they hold may be rebuilt from a file."""
+    _NUMPY_OK = ("_reconstruct", "ndarray", "dtype", "scalar")
+
+    def find_class(self, module, name):
+        if module == "isochrones_amd.priors" and not name.startswith("_"):
+            return super().find_class(module, name)
+        if module.split(".")[0] == "numpy" and name in self._NUMPY_OK:
+            return super().find_class(module, name)
+        raise pickle.UnpicklingError("refusing to load {}.{} from a saved model".format(module, name))
+
+
+def _load_priors(buf):
+    import io
+    return _PriorUnpickler(io.BytesIO(buf)).load()
 
 
 def _frame_arrays(df):
@@ -117,7 +134,7 @@ def load_model(cls, filename, ic=None, name=None):
             raise ValueError("{}: unknown container version {!r}".format(filename, meta.get("format")))
         samples = _frame(z["samples"], z["samples_columns"])
         derived = _frame(z["derived"], z["derived_columns"])
-        priors = pickle.loads(z["priors"].tobytes())
+        priors = _load_priors(z["priors"].tobytes())
         obs_arrays = {k: z[k] for k in z.files if k.startswith("obs_")}
     if ic is None:
         ic = _rebuild_ic(meta)

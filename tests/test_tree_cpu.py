@@ -289,3 +289,21 @@ def test_from_ini_with_an_obsfile(tmp_path):
     oic = fx.make_oracle_ic(ic)
     a = orc.tree_lnpost(oic, mod.tree_desc(), g["pars"].T.copy())[0]
     fx.assert_close(a, g["lnpost"], 1e-11, atol=1e-11, what="lnpost of the obsfile model vs the reference golden")
+
+
+def test_saved_model_refuses_foreign_pickles(tmp_path):
+    """The priors entry of a saved model may only rebuild this package's prior classes."""
+    import pickle
+    from isochrones_amd import persist
+    meta = fx.load("ini_flat")["meta"]
+    ic = fx.make_ic(dict(kind="iso", limits=meta["limits"], eep_bounds=meta["eep_bounds"]))
+    mod = ia.BasicStarModel.from_ini(ic, folder=os.path.join(INI_DIR, "flat"))
+    f = str(tmp_path / "m.npz")
+    mod.save(f)
+    with np.load(f) as z:
+        arrays = {k: z[k] for k in z.files}
+    arrays["priors"] = np.frombuffer(pickle.dumps({"mass": os.getcwd, "x": os.system}), dtype=np.uint8)
+    np.savez(str(tmp_path / "evil.npz"), **arrays)
+    with pytest.raises(pickle.UnpicklingError, match="refusing to load"):
+        ia.BasicStarModel.load(str(tmp_path / "evil.npz"), ic=ic)
+    assert ia.BasicStarModel.load(f, ic=ic).kwargs == mod.kwargs          # the genuine file still loads
