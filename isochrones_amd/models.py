@@ -579,8 +579,12 @@ def synthetic_isochrone(bands=grids.DEFAULT_BANDS, ages=None, fehs=None, eeps=No
     return ic
 
 
-def get_ichrone(models="mist", bands=None, tracks=False, **kwargs):
-    """Reference-style factory (isochrones/isochrone.py:48-78) over the synthetic tables."""
+def get_ichrone(models="mist", bands=None, default=False, tracks=False, basic=False, **kwargs):
+    """Reference-style factory (isochrones/isochrone.py:48-78) over the synthetic tables.  An interpolator
+    object passed as ``models`` is returned as it is; ``default`` / ``basic`` select variants of the reference's
+    grids that coincide here."""
+    if isinstance(models, ModelGridInterpolator):
+        return models
     if models not in ("mist", "synthetic"):
         raise ValueError("only the MIST-shaped synthetic tables are available offline")
     bands = grids.DEFAULT_BANDS if bands is None else tuple(bands)
