@@ -587,5 +587,5 @@ def get_ichrone(models="mist", bands=None, default=False, tracks=False, basic=Fa
         return models
     if models not in ("mist", "synthetic"):
         raise ValueError("only the MIST-shaped synthetic tables are available offline")
-    bands = grids.DEFAULT_BANDS if bands is None else tuple(bands)
+    bands = grids.DEFAULT_BANDS if not bands else tuple(bands)
     return synthetic_track(bands, **kwargs) if tracks else synthetic_isochrone(bands, **kwargs)
