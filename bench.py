@@ -184,13 +184,17 @@ def catalog_leg(rank, world, barrier, dist, reduce_device, sizes=(10_000, 400_00
         barrier()
         wall = time.perf_counter() - t0
         stats = torch.tensor([wall, -ok, 1.0 if err is not None else 0.0], dtype=torch.float64, device=reduce_device)
+        share = torch.zeros(world, dtype=torch.float64, device=reduce_device)
+        share[rank] = float(len(idx))
         if dist is not None:
             dist.all_reduce(stats, op=dist.ReduceOp.MAX)
+            dist.all_reduce(share, op=dist.ReduceOp.SUM)
         wall, ok_min, failed = float(stats[0]), -float(stats[1]), bool(stats[2] > 0)
         if failed:
             out["%d_stars" % n_stars] = {"error": err or "a rank other than 0 failed"}
         else:
             out["%d_stars" % n_stars] = {"wall_s": wall, "stars_per_s": n_stars / wall, "stars_per_rank": int(len(idx)),
+                                         "stars_per_rank_all": [int(x) for x in share.tolist()],
                                          "lnpost_evals": int(n_stars) * nwalkers * (nburn + niter), "ok_fraction_min": ok_min}
         cat = None
     return out
@@ -311,6 +315,9 @@ def main():
                    "kernel_path": os.environ.get("ISOCHRONES_AMD_PATH", "auto")},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "traffic_source": ("static: profiles/pmc_traffic.json (rocprofv3 --pmc passes of this command, "
+                                        "FETCH_SIZE/WRITE_SIZE with the gfx950 corrections; not measured in this run)"
+                                        if traffic is not None else None),
                      "kernel_ms": kernel_ms, "bytes_per_eval": BYTES_PER_EVAL_SINGLE_1BAND},
     }
     if world == 1 and not args.no_extras:

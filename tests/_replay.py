@@ -1,0 +1,132 @@
+"""TEST INFRASTRUCTURE - teacher-forced replay of the device-resident stretch-move sampler on the CPU.
+
+The fused sampler kernels (isochrones_amd/csrc/fast/sampler.h) draw every move's random numbers from
+Philox4x32-10 with counter (2*step + half, row_lo, row_hi, 0x51) and key = seed, so a stored chain can be
+checked move by move without running a second sampler: for every stored step the proposal is rebuilt on the
+host from the *stored* previous state (teacher forcing - an accept/reject flip cannot snowball), evaluated
+with the CPU oracle, and the oracle's accept/reject decision and lnpost are compared with what the GPU
+stored.  This replaces "the sampler's lnprob equals the HIP batch kernel's lnpost" (HIP vs HIP) by
+"the sampler's every move equals the reference algorithm's" (HIP vs oracle).
+
+What the reference does at this point: emcee's stretch move around `StarModel.lnpost`
+(isochrones/starmodel.py:951-969; Goodman & Weare 2010: z ~ g(z) on [1/a, a], y = x_j + z (x_k - x_j),
+accept with probability min(1, z^(D-1) p(y)/p(x_k))).
+"""
+import numpy as np
+
+M0, M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
+W0, W1 = 0x9E3779B9, 0xBB67AE85
+MASK32 = np.uint64(0xFFFFFFFF)
+
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Vectorised Philox4x32-10 (Salmon et al. 2011): uint32 counter arrays, scalar key -> 4 uint32 arrays."""
+    c0, c1, c2, c3 = (np.asarray(c, dtype=np.uint64) & MASK32 for c in (c0, c1, c2, c3))
+    k0, k1 = int(k0) & 0xFFFFFFFF, int(k1) & 0xFFFFFFFF
+    for _ in range(10):
+        p0 = M0 * c0
+        p1 = M1 * c2
+        n0 = (p1 >> np.uint64(32)) ^ c1 ^ np.uint64(k0)
+        n1 = p1 & MASK32
+        n2 = (p0 >> np.uint64(32)) ^ c3 ^ np.uint64(k1)
+        n3 = p0 & MASK32
+        c0, c1, c2, c3 = n0, n1, n2, n3
+        k0 = (k0 + W0) & 0xFFFFFFFF
+        k1 = (k1 + W1) & 0xFFFFFFFF
+    return c0, c1, c2, c3
+
+
+def philox_kat():
+    """Known-answer vectors of Philox4x32-10 from the Random123 distribution (kat_vectors)."""
+    out = philox4x32_10([0], [0], [0], [0], 0, 0)
+    assert [int(x[0]) for x in out] == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    f = 0xFFFFFFFF
+    out = philox4x32_10([f], [f], [f], [f], f, f)
+    assert [int(x[0]) for x in out] == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    out = philox4x32_10([0x243f6a88], [0x85a308d3], [0x13198a2e], [0x03707344], 0xa4093822, 0x299f31d0)
+    assert [int(x[0]) for x in out] == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def moves(step, half, rows, h, a, seed):
+    """Random numbers of the moves of global rows `rows` at (step, half): partner index j in [0, h),
+    stretch factor z, acceptance uniform u2 - the same arithmetic as stretch_move()."""
+    rows = np.asarray(rows, dtype=np.uint64)
+    step = np.asarray(step, dtype=np.uint64)
+    r0, r1, r2, r3 = philox4x32_10(np.uint64(2) * step + np.uint64(half), rows & MASK32, rows >> np.uint64(32),
+                                   np.full(rows.shape, 0x51, dtype=np.uint64), seed & 0xFFFFFFFF, seed >> 32)
+    j = ((r0 * np.uint64(h)) >> np.uint64(32)).astype(np.int64)
+    u1 = (r1.astype(np.float64) + (r2 & np.uint64(0xFFFF)).astype(np.float64) * (1.0 / 65536.0)) * (1.0 / 4294967296.0)
+    u2 = (r3.astype(np.float64) + (r2 >> np.uint64(16)).astype(np.float64) * (1.0 / 65536.0) + 0.5 / 65536.0) * (
+        1.0 / 4294967296.0)
+    zr = (a - 1.0) * u1 + 1.0
+    return j, zr * zr / a, u2
+
+
+def replay(p0, lnp0, chain, chain_lnp, W, a, seed, step0, lnpost_fn, star_of_block=None, margin=1e-9,
+           lnp_rtol=1e-9, lnp_atol=1e-11):
+    """Check a stored chain move by move.
+
+    p0 [R, D], lnp0 [R]: state before the first stored step; chain [T, R, D], chain_lnp [T, R]: as
+    iso_sampler_run stores them; R = B * W rows = B whole ensembles.  `star_of_block` [B] = the global
+    ensemble index of each block (row = star * W + walker keys the random numbers; default 0..B-1).
+    lnpost_fn(block_index [n], pars [n, D]) -> oracle lnpost [n].
+
+    Returns a dict of counts; raises AssertionError on any disagreement beyond the tolerances:
+      * rejected move: position and lnprob carried over bit for bit;
+      * accepted move: stored position == rebuilt proposal (1e-13 relative: FMA contraction), stored
+        lnprob == oracle lnpost of it (lnp_rtol / lnp_atol), and that lnpost is finite;
+      * the oracle's own decision (log u < (D-1) log z + lnpost(y) - lnpost(x)) equals the GPU's, except
+        where |log u - lnq| < margin * (1 + |lnpost(y)| + |lnpost(x)|) (counted as `near_ties`).
+    """
+    p0, lnp0, chain, chain_lnp = (np.asarray(x, dtype=np.float64) for x in (p0, lnp0, chain, chain_lnp))
+    T, R, D = chain.shape
+    assert R % W == 0 and p0.shape == (R, D) and lnp0.shape == (R,) and chain_lnp.shape == (T, R)
+    B, h = R // W, W // 2
+    star_of_block = np.arange(B) if star_of_block is None else np.asarray(star_of_block)
+    prev = np.concatenate([p0[None], chain[:-1]], axis=0).reshape(T, B, W, D)        # state before step t
+    prev_lnp = np.concatenate([lnp0[None], chain_lnp[:-1]], axis=0).reshape(T, B, W)
+    cur = chain.reshape(T, B, W, D)
+    cur_lnp = chain_lnp.reshape(T, B, W)
+    steps = (step0 + np.arange(T, dtype=np.int64))[:, None, None]
+    grow = (star_of_block[:, None] * W + np.arange(W)[None, :])[None]                # global row [1, B, W]
+    stats = dict(moves=0, accepted=0, near_ties=0, max_lnp_rel=0.0)
+    for half in (0, 1):
+        lo = half * h
+        rows = np.broadcast_to(grow[:, :, lo:lo + h], (T, B, h))
+        j, z, u2 = moves(np.broadcast_to(steps, (T, B, h)), half, rows, h, a, int(seed))
+        x = prev[:, :, lo:lo + h, :]
+        lold = prev_lnp[:, :, lo:lo + h]
+        # half 0 reads the second half as it was before the step; half 1 reads the first half after its update
+        other = prev[:, :, h:, :] if half == 0 else cur[:, :, :h, :]
+        xj = np.take_along_axis(other, j[..., None], axis=2)
+        y = xj + z[..., None] * (x - xj)
+        got = cur[:, :, lo:lo + h, :]
+        got_lnp = cur_lnp[:, :, lo:lo + h]
+        moved = np.any(got != x, axis=-1) | (got_lnp != lold)
+        blk = np.broadcast_to(np.arange(B)[None, :, None], (T, B, h))
+        lnew = lnpost_fn(blk.reshape(-1), y.reshape(-1, D)).reshape(T, B, h)
+        # --- GPU bookkeeping -------------------------------------------------------------------
+        assert np.array_equal(got[~moved], x[~moved]) and np.array_equal(got_lnp[~moved], lold[~moved])
+        ym, gm = y[moved], got[moved]
+        assert np.all(np.abs(gm - ym) <= 1e-13 * np.maximum(1.0, np.abs(ym))), "accepted position is not the proposal"
+        lm, sm = lnew[moved], got_lnp[moved]
+        assert np.isfinite(sm).all(), "a non-finite proposal was accepted"
+        assert np.isfinite(lm).all(), "the oracle rejects (non-finite lnpost) a proposal the GPU accepted"
+        err = np.abs(sm - lm)
+        tol = lnp_atol + lnp_rtol * np.abs(lm)
+        assert np.all(err <= tol), "stored lnprob differs from the oracle: max %g" % float((err - tol).max())
+        if lm.size:
+            stats["max_lnp_rel"] = max(stats["max_lnp_rel"], float(np.max(err / np.maximum(1.0, np.abs(lm)))))
+        # --- the oracle's decision -----------------------------------------------------------------
+        with np.errstate(invalid="ignore", divide="ignore"):
+            lnq = (D - 1) * np.log(z) + lnew - lold
+            logu = np.log(u2)
+            acc_o = np.isfinite(lnew) & (logu < lnq)
+            near = np.isfinite(lnew) & (np.abs(logu - lnq) < margin * (1.0 + np.abs(lnew) + np.abs(lold)))
+        flips = (acc_o != moved) & ~near
+        assert not flips.any(), "%d accept/reject decisions differ from the oracle's (first at %s)" % (
+            int(flips.sum()), np.argwhere(flips)[0])
+        stats["moves"] += int(moved.size)
+        stats["accepted"] += int(moved.sum())
+        stats["near_ties"] += int(((acc_o != moved) & near).sum())
+    return stats

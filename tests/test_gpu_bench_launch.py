@@ -1,0 +1,76 @@
+"""bench.py under torch.distributed.run, as the driver launches it for the multi-GPU scaling runs:
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py
+--gpus N --steps K --warmup W`.  The GPU box of the test suite has one GPU, so the two ranks share it
+(ISO_BENCH_SHARE_GPU=1) and the timing collectives use gloo (ISO_BENCH_BACKEND=gloo); everything else - rank
+plumbing, per-rank batches, the barrier + max-over-ranks timing, the catalog leg's sharding rule - is the code path
+the 8-GPU run takes."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _launch(nproc, extra):
+    env = dict(os.environ, ISO_BENCH_SHARE_GPU="1", ISO_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
+           "--gpus", str(nproc)] + extra
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-4000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]         # exactly one JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_prints_one_valid_line():
+    r = _launch(2, ["--steps", "5", "--warmup", "2"])
+    assert r["n_gpus"] == 2 and r["steps"] == 5 and r["warmup"] == 2
+    assert r["scaling"] == "weak" and r["unit"] == "evals/s" and r["dtype"] == "f64" and r["vs_baseline"] is None
+    assert r["value"] > 0 and r["ms_per_step"] > 0
+    # value = the evaluations of BOTH ranks over the max-over-ranks time
+    assert abs(r["value"] - 2 * r["config"]["batch"] * r["steps"] / (r["ms_per_step"] * 1e-3 * r["steps"])) < 1e-6 * r["value"]
+    assert r["roofline"]["bound"] == "hbm" and 0 < r["roofline"]["frac"] <= 1.0
+    assert r["cpu_baseline"] is None                 # rank 0 at N = 1 only
+    cat = r["catalog"]
+    assert "error" not in cat
+    for key, n in (("10000_stars", 10_000), ("400000_stars", 400_000)):
+        leg = cat[key]
+        assert "error" not in leg, leg
+        assert leg["stars_per_s"] > 0 and leg["ok_fraction_min"] > 0.99
+        # star i -> rank (i + 1) % 2: rank 0 owns the odd indices = n // 2 stars, and the shares add up to the catalog
+        assert leg["stars_per_rank"] == n // 2
+        assert sum(leg["stars_per_rank_all"]) == n and len(leg["stars_per_rank_all"]) == 2
+
+
+def test_bench_single_rank_default_line_has_roofline_and_cpu_baseline():
+    env = dict(os.environ)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--no-catalog"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-4000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 1 and r["config"]["workload"].startswith("cfg2")
+    rf = r["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and 0.3 < rf["frac"] <= 1.0
+    assert rf["traffic"] is None or (rf["traffic"] > 0 and "traffic_source" in rf)
+    cb = r["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["parity_pattern_ok"]
+    assert cb["parity_max_rel_err"] < 1e-9
+    for wl in r["other_workloads"].values():
+        if "roofline" in wl:
+            assert 0 < wl["roofline"]["frac"] <= 1.0
