@@ -73,7 +73,7 @@ def _draw_in_ellipsoid(rng, mean, A, m):
 
 
 def nested_sample_batched(loglike, lo, hi, nlive=1000, tol=0.5, enlarge=1.5, remove=None, max_batch=1 << 20,
-                          max_calls=int(2e9), seed=0, max_iter=None, propose=None):
+                          max_calls=int(2e9), seed=0, max_iter=None, propose=None, transform=None):
     """The same integral with the K = ``remove`` lowest live points retired per macro-step (default nlive // 10) and
     all K replacements drawn above the highest of their thresholds — nested sampling with a live-point count that
     drops from nlive to nlive - K + 1 inside a macro-step (shrinkage exp(-1 / n_live) per retired point, as in
@@ -85,23 +85,28 @@ def nested_sample_batched(loglike, lo, hi, nlive=1000, tol=0.5, enlarge=1.5, rem
     uniformly in the ellipsoid ``{mean + A z, |z| <= 1}`` of the unit cube, evaluates them and returns the ones
     inside the cube with logl > threshold (``mean is None``: uniform in the cube).  Models pass a device-resident
     implementation (random numbers, transform, lnpost and the threshold test on the GPU; only the accepted points
-    come back), which is what keeps hard posteriors - proposal efficiencies of 1e-3 and below - cheap."""
+    come back), which is what keeps hard posteriors - proposal efficiencies of 1e-3 and below - cheap.
+
+    ``transform(u [n, d]) -> theta [n, d]``, optional: the unit cube -> parameter map when it is not the plain box
+    ``lo + u (hi - lo)`` (the reference's generic ``mnest_prior`` also sorts each system's EEPs, starmodel.py:644-656);
+    a ``propose`` hook must apply the same map."""
     lo = np.asarray(lo, dtype=float)
     hi = np.asarray(hi, dtype=float)
     d = lo.size
     if nlive < max(20, 4 * (d + 1)):                   # too few points for a macro-step and a sane ellipsoid
         return nested_sample(loglike, lo, hi, nlive=nlive, tol=tol, enlarge=enlarge, max_batch=max_batch,
-                             max_calls=max_calls, seed=seed, max_iter=max_iter)
+                             max_calls=max_calls, seed=seed, max_iter=max_iter, transform=transform)
     rng = np.random.default_rng(seed)
     span = hi - lo
     K = max(1, int(nlive // 10 if remove is None else remove))
     K = min(K, nlive - 2 * (d + 1))                    # keep enough points for the bounding ellipsoid
     ncall = 0
+    to_pars = transform if transform is not None else (lambda u: lo + u * span)
 
     def evaluate(u):
         nonlocal ncall
         ncall += u.shape[0]
-        ll = np.asarray(loglike(lo + u * span), dtype=float).reshape(-1)
+        ll = np.asarray(loglike(to_pars(u)), dtype=float).reshape(-1)
         return np.where(np.isfinite(ll), ll, -np.inf)
 
     live_u = np.empty((0, d))
@@ -185,7 +190,7 @@ def nested_sample_batched(loglike, lo, hi, nlive=1000, tol=0.5, enlarge=1.5, rem
         dead_l.append(live_l[order])
         dead_logw.append(logw + live_l[order])
         logz = np.logaddexp(logz, np.logaddexp.reduce(logw + live_l[order]))
-    samples = lo + np.vstack(dead_u) * span
+    samples = to_pars(np.vstack(dead_u))
     logl = np.concatenate(dead_l)
     logwt = np.concatenate(dead_logw) - logz
     w = np.exp(logwt)
@@ -195,7 +200,7 @@ def nested_sample_batched(loglike, lo, hi, nlive=1000, tol=0.5, enlarge=1.5, rem
 
 
 def nested_sample(loglike, lo, hi, nlive=1000, tol=0.5, enlarge=1.5, batch=None, max_batch=1 << 20, max_calls=int(2e9),
-                  seed=0, max_iter=None, propose=None):
+                  seed=0, max_iter=None, propose=None, transform=None):
     """Nested sampling of ``exp(loglike(theta))`` under the flat prior on the box [lo, hi].
 
     ``propose``: optional device-side proposal hook, see :func:`nested_sample_batched` (only the draws above
@@ -212,11 +217,12 @@ def nested_sample(loglike, lo, hi, nlive=1000, tol=0.5, enlarge=1.5, batch=None,
     d = lo.size
     span = hi - lo
     ncall = 0
+    to_pars = transform if transform is not None else (lambda u: lo + u * span)
 
     def evaluate(u):
         nonlocal ncall
         ncall += u.shape[0]
-        ll = np.asarray(loglike(lo + u * span), dtype=float).reshape(-1)
+        ll = np.asarray(loglike(to_pars(u)), dtype=float).reshape(-1)
         return np.where(np.isfinite(ll), ll, -np.inf)
 
     # live points: prior draws with non-zero likelihood; the zero-likelihood part of the box only rescales Z
@@ -308,7 +314,7 @@ def nested_sample(loglike, lo, hi, nlive=1000, tol=0.5, enlarge=1.5, batch=None,
         dead_u.append(live_u[j].copy())
         dead_l.append(live_l[j])
         dead_logw.append(logw_live + live_l[j])
-    samples = lo + np.array(dead_u) * span
+    samples = to_pars(np.array(dead_u))
     logl = np.array(dead_l)
     logwt = np.array(dead_logw) - logz
     info = max(float(h_acc), 0.0)

@@ -146,6 +146,8 @@ class _NestedFitMixin:
             return None
         run = nested_sample_batched if batched else nested_sample
         run_kwargs["propose"] = self._device_proposer(lo, hi, seed)
+        if getattr(self, "mnest_transform", None) is not None:
+            run_kwargs["transform"] = self.mnest_transform     # the cube -> parameter map is not the plain box
         res = run(lambda th: self.lnpost(np.ascontiguousarray(th)), lo, hi, **run_kwargs)
         self._nested = res
         self._samples = None
@@ -193,11 +195,16 @@ class _NestedFitMixin:
                 u = u[((u >= 0.0) & (u <= 1.0)).all(dim=1)]
             if u.shape[0] == 0:
                 return np.empty((0, d)), np.empty(0), want
-            ll = self.lnpost(lo_t + u * span_t)
+            ll = self.lnpost(self._cube_to_pars_device(u, lo_t, span_t))
             ok = torch.isfinite(ll) & (ll > threshold)
             return u[ok].cpu().numpy(), ll[ok].cpu().numpy(), want
 
         return propose
+
+    def _cube_to_pars_device(self, u, lo_t, span_t):
+        """mnest_prior on a CUDA batch; the flat box for models whose ``mnest_prior`` is one (BasicStarModel,
+        reference starmodel.py:1637-1640)."""
+        return lo_t + u * span_t
 
     @property
     def evidence(self):
@@ -909,9 +916,33 @@ class TreeStarModel(_NestedFitMixin, _ConvenienceMixin):
         found = {k for v in self.obs.spectroscopy.values() for k in v}
         return sorted(found - {"Teff", "logg", "feh"})
 
+    def mnest_transform(self, cube):
+        """Unit cube -> parameters as the reference's ``StarModel.mnest_prior`` maps them (starmodel.py:644-656): the
+        flat box of :meth:`prior_transform`, then every system's EEPs put in descending order, so that the whole
+        cube lands on the ordering ``lnprior`` accepts.  ``cube`` [..., n_params]; out of place."""
+        pars = self.prior_transform(cube)
+        i = 0
+        for s in self.obs.systems:
+            n = self.obs.Nstars[s]
+            if n > 1:
+                pars[..., i:i + n] = -np.sort(-pars[..., i:i + n], axis=-1)
+            i += 4 + n
+        return pars
+
+    def _cube_to_pars_device(self, u, lo_t, span_t):
+        import torch
+        pars = lo_t + u * span_t
+        i = 0
+        for s in self.obs.systems:
+            n = self.obs.Nstars[s]
+            if n > 1:
+                pars[:, i:i + n] = torch.sort(pars[:, i:i + n], dim=1, descending=True).values
+            i += 4 + n
+        return pars
+
     def mnest_prior(self, cube, ndim=None, nparams=None):
-        """Unit cube -> parameters, in place (reference: starmodel.py:615-627 through pymultinest's callback)."""
-        out = self.prior_transform(np.array([cube[i] for i in range(self.n_params)], dtype=float))
+        """Unit cube -> parameters, in place: pymultinest's prior callback (reference: starmodel.py:644-656)."""
+        out = self.mnest_transform(np.array([cube[i] for i in range(self.n_params)], dtype=float))
         for i in range(self.n_params):
             cube[i] = out[i]
 
@@ -1099,9 +1130,6 @@ class TreeStarModel(_NestedFitMixin, _ConvenienceMixin):
             i += 4 + n
         return pars
 
-    def mnest_loglike(self, cube, ndim=None, nparams=None):
-        return self.lnpost(cube)
-
     # -- fits (reference: StarModel.fit_mcmc / fit_multinest, starmodel.py:717-972) --------------
     def sample_from_prior(self, n, rng=None, max_tries=200):
         """[n, n_params] uniform draws from the parameter box with a finite lnpost (EEPs of a system
@@ -1109,13 +1137,7 @@ class TreeStarModel(_NestedFitMixin, _ConvenienceMixin):
         rng = rng or np.random.default_rng()
 
         def draw(m):
-            x = self.prior_transform(rng.random((m, self.n_params)))
-            i = 0
-            for sname in self.obs.systems:
-                k = self.obs.Nstars[sname]
-                x[:, i:i + k] = -np.sort(-x[:, i:i + k], axis=1)
-                i += 4 + k
-            return x
+            return self.mnest_transform(rng.random((m, self.n_params)))
 
         out = draw(n)
         for _ in range(max_tries):

@@ -396,9 +396,16 @@ def _emit_tree_case(name, mod, kw, built, rng, axes, limits, obs_mod, extra_meta
                     bands=list(BANDS), built=built, systems=[int(s) for s in mod.obs.systems],
                     Nstars={str(k): int(v) for k, v in N.items()})
         meta.update(extra_meta or {})
+        # StarModel.mnest_prior (starmodel.py:644-656) on non-degenerate cubes: unlike prior_transform it sorts every
+        # system's EEPs in descending order.  Own generator, so the arrays above keep their values.
+        import zlib
+        mcube = np.random.default_rng(zlib.crc32(name.encode())).random((32, len(names)))
+        mnest = mcube.copy()
+        for row in mnest:
+            mod.mnest_prior(row, len(names), len(names))
         np.savez_compressed(os.path.join(OUT, name + ".npz"), meta=json.dumps(meta), pars=pars, lnprior=lnprior,
                             lnlike=lnlike, lnpost=lnpost, cube_in=cube,
-                            cube_out=np.array([mod.prior_transform(c) for c in cube]))
+                            cube_out=np.array([mod.prior_transform(c) for c in cube]), mnest_in=mcube, mnest_out=mnest)
         print("%-24s n=%d npar=%d finite lnpost=%d -inf=%d nan=%d leaves=%s" % (
             name, n, len(names), np.isfinite(lnpost).sum(), np.isneginf(lnpost).sum(), np.isnan(lnpost).sum(), labels))
 

@@ -795,10 +795,14 @@ def test_save_load_round_trip_and_convenience_helpers(tmp_path):
     q = tree.samples[list(tree.param_names)].values[:40]
     assert np.array_equal(tb.lnpost(q), tree.lnpost(q))
     assert np.array_equal(tb.samples.values, tree.samples.values)
-    cube = [0.5] * tree.n_params
+    cube = [0.2, 0.7, 0.5, 0.4, 0.3, 0.1]                      # EEPs out of order: mnest_prior sorts them (starmodel.py:644-656)
     tree.mnest_prior(cube)
-    assert np.allclose(cube, tree.prior_transform(np.full(tree.n_params, 0.5)))
+    box = tree.prior_transform(np.array([0.7, 0.2, 0.5, 0.4, 0.3, 0.1]))
+    assert np.allclose(cube, box) and cube[0] > cube[1]
     assert np.isclose(tree.mnest_loglike(cube), tree.lnpost(np.array(cube)))
+    # the nested fit maps the cube the same way, so its samples are ordered and the whole cube carries prior mass
+    e = tree.samples[list(tree.param_names)].values
+    assert (e[:, 0] >= e[:, 1]).all()
     unfit = ia.SingleStarModel(ic, J=(9.6, 0.03))
     unfit.save(str(tmp_path / "unfit.npz"))
     assert ia.SingleStarModel.load(str(tmp_path / "unfit.npz"), ic=ic)._samples is None

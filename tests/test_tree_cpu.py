@@ -67,6 +67,15 @@ def test_tree_structure_and_oracle_vs_reference(case):
     fx.assert_close(like, g["lnlike"], 1e-11, atol=1e-11, what="lnlike")
     fx.assert_close(post, g["lnpost"], 1e-11, atol=1e-11, what="lnpost")
     fx.assert_close(mod.prior_transform(g["cube_in"]), g["cube_out"], 1e-15, what="prior_transform")
+    # mnest_prior (reference starmodel.py:644-656): the box transform, then every system's EEPs in descending
+    # order - 32 random (non-degenerate) cubes through the reference's own method
+    rows = g["mnest_in"].copy()
+    for r in rows:
+        mod.mnest_prior(r, len(r), len(r))
+    assert np.array_equal(rows, g["mnest_out"])
+    assert np.array_equal(mod.mnest_transform(g["mnest_in"]), g["mnest_out"])
+    if max(meta["Nstars"].values()) > 1:                       # the sort matters for these cases
+        assert not np.array_equal(mod.prior_transform(g["mnest_in"]), g["mnest_out"])
     assert np.isfinite(g["lnpost"]).sum() > 50
 
 
