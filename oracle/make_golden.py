@@ -571,6 +571,152 @@ def run_prior_cases(rng=None):
                    priors=dict(age=("FlatLog", 8.0, 10.0), distance=("PowerLaw", 2.0, 0.0, 500.0)))
 
 
+# ------------------------------------------------------------------------------------------------
+# table ingest ("next" row f1): the reference's own grid classes on small synthetic raw frames
+# ------------------------------------------------------------------------------------------------
+
+def _raw_mist_rows(rng, keys, key_names, eep_counts):
+    """Raw MIST-like rows (the column names of the .eep / .iso files the reference parses, mist/models.py:23-33)
+    for every key tuple; row counts differ, so the product grid is ragged."""
+    import pandas as pd
+    frames = []
+    for key, n in zip(keys, eep_counts):
+        eep = np.arange(1, n + 1, dtype=float)
+        m0 = key[key_names.index("initial_mass")] if "initial_mass" in key_names else 0.5 + 0.02 * eep + 0.1 * rng.random()
+        feh = key[0] if key_names[0] == "initial_feh" else key[1]
+        d = dict(zip(key_names, [np.full(n, k) for k in key]))
+        d["EEP"] = eep
+        d["initial_mass"] = m0 * np.ones(n)
+        d["star_mass"] = d["initial_mass"] * (1.0 - 2e-3 * eep / n)
+        d["star_age"] = 1e6 * 10 ** (3.4 * (eep / 40.0) ** 0.7) / np.mean(d["initial_mass"]) ** 2.5 * (1 + 0.01 * rng.random(n))
+        d["log_Teff"] = 3.76 + 0.12 * np.log10(d["initial_mass"]) - 1.5e-3 * eep + 0.002 * feh
+        d["log_g"] = 4.45 - 0.03 * eep
+        d["log_L"] = 3.5 * np.log10(d["initial_mass"]) + 0.012 * eep
+        d["log_R"] = 0.8 * np.log10(d["initial_mass"]) + 6e-3 * eep
+        d["log_surf_z"] = np.log10(0.0142 * 10.0 ** feh) - 1e-4 * eep
+        d["surface_h1"] = 0.715 - 2e-4 * eep
+        d["delta_nu"] = 135.0 * np.sqrt(d["initial_mass"]) / (1 + 0.02 * eep)
+        d["nu_max"] = 3090.0 * d["initial_mass"] / (1 + 0.04 * eep)
+        d["phase"] = np.floor(eep / 12.0)
+        d["interpolated"] = np.zeros(n)
+        frames.append(pd.DataFrame(d))
+    return pd.concat(frames, ignore_index=True)
+
+
+def run_ingest_cases():
+    """MISTEvolutionTrackGrid / MISTIsochroneGrid / MISTBolometricCorrectionGrid of the reference on synthetic raw
+    frames: column standardisation + derived columns (models.py:102-109, mist/models.py:81-85,219-223), dt_deep
+    (mist/models.py:403-435), dm_deep (models.py:126-153), the ragged age arrays (models.py:171-203), the
+    NaN-padded dense grids (interp.py:590-614), and the BC frame -> band columns -> Rv slice -> dense 4-D table
+    (bc.py:99-118, mist/bc.py:161-233).  Inputs and outputs are stored as plain arrays."""
+    import tempfile
+    import pandas as pd
+    mm = rh.ref("mist.models")
+    mbc = rh.ref("mist.bc")
+    rng = np.random.default_rng(4242)
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp, rh.memory_hdf() as hdf, warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        # ---- evolution tracks ----
+        fehs = np.array([-0.5, 0.0, 0.25])
+        masses = np.array([0.8, 1.0, 1.2, 1.5])
+        keys = list(itertools.product(fehs, masses))
+        counts = [int(c) for c in rng.integers(18, 36, len(keys))]
+        raw_t = _raw_mist_rows(rng, keys, ("initial_feh", "initial_mass"), counts)
+
+        class Tracks(mm.MISTEvolutionTrackGrid):
+            n_eep = max(counts)
+            datadir = os.path.join(tmp, "tracks")
+
+            def df_all(self):
+                df = raw_t.copy().sort_values(by=list(self.index_cols))
+                df.index = [df[c] for c in self.index_cols]
+                return df
+
+        Tracks.fehs = fehs
+        os.makedirs(Tracks.datadir)
+        g = Tracks()
+        df = g.df
+        age, dt, lengths = g.get_array_grids()
+        out.update(track_raw=raw_t.values, track_raw_columns=np.array(list(raw_t.columns)),
+                   track_columns=np.array(list(df.columns)), track_values=df.values,
+                   track_index=np.array([list(t) for t in df.index.values], dtype=float),
+                   track_grid=g.interp.grid, track_axes0=g.interp.index_columns[0], track_axes1=g.interp.index_columns[1],
+                   track_axes2=g.interp.index_columns[2], track_age_arrays=age, track_dt_deep_arrays=dt,
+                   track_lengths=lengths)
+        print("ingest tracks: %d rows, grid %s, %d NaN cells" % (len(df), g.interp.grid.shape,
+                                                                  int(np.isnan(g.interp.grid[..., 0]).sum())))
+        # ---- isochrones ----
+        ages = np.array([8.5, 9.0, 9.5, 10.0])
+        ifehs = np.array([-1.0, 0.0, 0.5])
+        keys = list(itertools.product(ages, ifehs))
+        counts = [int(c) for c in rng.integers(15, 30, len(keys))]
+        raw_i = _raw_mist_rows(rng, keys, ("log10_isochrone_age_yr", "feh"), counts)
+        # an isochrone's rows: initial mass grows along EEP (what dm_deep differentiates)
+        raw_i["initial_mass"] = 0.3 + 0.03 * raw_i["EEP"] ** 1.1 + 0.02 * raw_i["feh"]
+        raw_i["star_mass"] = raw_i["initial_mass"] * 0.999
+
+        class Isos(mm.MISTIsochroneGrid):
+            datadir = os.path.join(tmp, "isos")
+
+            def df_all(self):
+                df = raw_i.copy().sort_values(by=list(self.index_cols))
+                df.index = [df[c] for c in self.index_cols]
+                return df
+
+        os.makedirs(Isos.datadir)
+        gi = Isos()
+        dfi = gi.df
+        out.update(iso_raw=raw_i.values, iso_raw_columns=np.array(list(raw_i.columns)),
+                   iso_columns=np.array(list(dfi.columns)), iso_values=dfi.values,
+                   iso_index=np.array([list(t) for t in dfi.index.values], dtype=float),
+                   iso_grid=gi.interp.grid, iso_axes0=gi.interp.index_columns[0], iso_axes1=gi.interp.index_columns[1],
+                   iso_axes2=gi.interp.index_columns[2])
+        print("ingest isochrones: %d rows, grid %s" % (len(dfi), gi.interp.grid.shape))
+        # ---- bolometric corrections: two photometric systems, five index levels incl. Rv ----
+        lv = (np.array([3500.0, 5000.0, 6500.0, 8000.0]), np.array([3.0, 4.0, 5.0]), np.array([-1.0, 0.0, 0.5]),
+              np.array([0.0, 0.5, 1.0]), np.array([2.5, 3.1, 4.0]))
+        idx = pd.MultiIndex.from_product(lv, names=["Teff", "logg", "[Fe/H]", "Av", "Rv"])
+        bcdir = os.path.join(tmp, "BC", "mist")
+        os.makedirs(bcdir)
+
+        class BC(mbc.MISTBolometricCorrectionGrid):
+            datadir = bcdir
+
+        frames = {}
+        for phot, cols in (("UBVRIplus", ["Bessell_B", "Bessell_V", "2MASS_J", "2MASS_Ks", "Gaia_G_DR2Rev", "TESS",
+                                          "Kepler_Kp"]),
+                           ("WISE", ["WISE_W1", "WISE_W2"])):
+            frames[phot] = pd.DataFrame(rng.normal(size=(len(idx), len(cols))), index=idx, columns=cols)
+            hdf.preload(os.path.join(bcdir, "%s.h5" % phot), "df", frames[phot])
+        bands = ["J", "K", "G", "W1", "V", "Kepler", "TESS"]
+        gb = BC(bands=bands)
+        dfb = gb.df
+        out.update(bc_index=np.array([list(t) for t in idx.values], dtype=float), bc_bands=np.array(bands),
+                   bc_columns=np.array(list(dfb.columns)), bc_grid=gb.interp.grid,
+                   **{"bc_axes%d" % k: gb.interp.index_columns[k] for k in range(4)})
+        for phot, fr in frames.items():
+            out["bc_%s_values" % phot] = fr.values
+            out["bc_%s_columns" % phot] = np.array(list(fr.columns))
+        print("ingest BC: frame %s -> grid %s, columns %s" % (dfb.shape, gb.interp.grid.shape, list(dfb.columns)))
+        # band-name resolution (mist/bc.py:165-233)
+        names = ["J", "H", "K", "Ks", "G", "BP", "RP", "Bp", "Rp", "U", "B", "V", "R", "I", "u", "g", "r", "i", "z", "W1", "W2",
+                 "W3", "W4", "Kepler", "kep", "Kp", "TESS", "Tycho_B", "Hipparcos_Hp", "WFPC2_F555W", "UKIRT_K", "UK_J",
+                 "HST_WFPC2_F555W", "Gaia_G_MAW", "UBVRIplus_Bessell_V"]
+        names += ["nonsense", "PanSTARRS_g", "SDSS_g"]
+
+        def resolve(b):
+            try:
+                return BC.get_band(b)
+            except ValueError:
+                return ("!unresolved", "!unresolved")
+
+        got = [resolve(b) for b in names]
+        out.update(band_names=np.array(names), band_phot=np.array([p for p, _ in got]), band_column=np.array([c for _, c in got]))
+    np.savez_compressed(os.path.join(OUT, "ingest.npz"), **out)
+
+
+
 def main():
     if "--only-priors" in sys.argv:
         run_prior_cases()
@@ -586,6 +732,9 @@ def main():
         return
     if "--only-eep" in sys.argv:
         run_eep_case()
+        return
+    if "--only-ingest" in sys.argv:
+        run_ingest_cases()
         return
     if not rh.reference_available():
         sys.exit("reference tree not found; goldens can only be regenerated in the authoring container")
@@ -613,6 +762,7 @@ def main():
     run_ini_cases()
     run_isotrack_case()
     run_prior_cases()
+    run_ingest_cases()
 
 
 if __name__ == "__main__":

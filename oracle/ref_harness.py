@@ -171,3 +171,56 @@ def make_ref_ic(kind, model_table, bc_table, limits, eep_bounds):
     ic.eep_bounds = tuple(eep_bounds)
     ic.grid = mg  # ``eep_replaces`` property of the base class reads self.grid
     return ic
+
+
+# --------------------------------------------------------------------------------------
+# in-memory stand-in for pandas' HDF5 I/O
+# --------------------------------------------------------------------------------------
+
+class memory_hdf:
+    """Context manager: ``DataFrame.to_hdf`` / ``Series.to_hdf`` / ``pd.read_hdf`` keep their objects in a dict
+    instead of an HDF5 file.  pytables is not installed, and the reference's grid classes cache every
+    intermediate frame through HDF5 (grid.py:103-118, models.py:126-153, mist/models.py:403-435, bc.py:99-118).
+    This replaces the *storage*, not any of the reference's arithmetic: what is written is what is read back.
+    ``preload(path, key, obj)`` plants a frame as if an earlier run had cached it (and touches the file, because
+    the reference tests ``os.path.exists`` before reading)."""
+
+    def __init__(self):
+        self.store = {}
+
+    def preload(self, path, key, obj):
+        path = os.path.abspath(path)
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        open(path, "a").close()
+        self.store[(path, key)] = obj.copy()
+
+    def __enter__(self):
+        import pandas as pd
+        self._saved = (pd.DataFrame.to_hdf, pd.Series.to_hdf, pd.read_hdf)
+        store = self.store
+
+        def to_hdf(obj, path, key=None, *args, **kwargs):
+            path = os.path.abspath(path)
+            open(path, "a").close()
+            store[(path, key)] = obj.copy()
+
+        def read_hdf(path, key=None, *args, **kwargs):
+            path = os.path.abspath(path)
+            if (path, key) in store:
+                return store[(path, key)].copy()
+            same_file = [v for (p, _), v in store.items() if p == path]
+            if key is None and len(same_file) == 1:
+                return same_file[0].copy()
+            if not same_file:
+                raise FileNotFoundError(path)
+            raise KeyError(key)
+
+        pd.DataFrame.to_hdf = to_hdf
+        pd.Series.to_hdf = to_hdf
+        pd.read_hdf = read_hdf
+        return self
+
+    def __exit__(self, *exc):
+        import pandas as pd
+        pd.DataFrame.to_hdf, pd.Series.to_hdf, pd.read_hdf = self._saved
+        return False

@@ -1,0 +1,111 @@
+"""Table ingest ("next" row f1) against the reference's own grid classes.
+
+tests/golden/ingest.npz was produced by oracle/make_golden.py:run_ingest_cases, which runs the reference's
+``MISTEvolutionTrackGrid`` / ``MISTIsochroneGrid`` / ``MISTBolometricCorrectionGrid`` on small synthetic raw
+frames (ragged tracks, two photometric systems, three Rv values) and stores inputs and outputs as plain arrays:
+the standardised frames (isochrones/models.py:102-124, mist/models.py:81-85,219-223), ``dt_deep``
+(mist/models.py:403-435), ``dm_deep`` (models.py:126-153), the ragged age arrays (models.py:171-203), the
+NaN-padded dense grids (interp.py:590-614) and the BC table (bc.py:99-118, mist/bc.py:161-233).
+Everything here is host-side numpy/pandas: bit-for-bit equality is required."""
+import numpy as np
+import pandas as pd
+import pytest
+
+from isochrones_amd import ingest
+from tests import _fixtures as fx
+
+
+@pytest.fixture(scope="module")
+def g():
+    return fx.load("ingest")
+
+
+def _raw(g, pre):
+    return pd.DataFrame(g[pre + "_raw"], columns=[str(c) for c in g[pre + "_raw_columns"]])
+
+
+def _same(a, b):
+    return np.array_equal(a, b, equal_nan=True)
+
+
+@pytest.mark.parametrize("pre,tracks,deriv", [("track", True, "dt_deep"), ("iso", False, "dm_deep")])
+def test_standard_columns_dense_grid_and_derivative(g, pre, tracks, deriv):
+    raw = _raw(g, pre)
+    raw = raw.sample(frac=1.0, random_state=3)                     # row order of the input must not matter
+    ref_cols = [str(c) for c in g[pre + "_columns"]]
+    df = ingest.standardize_mist_frame(raw, tracks)
+    assert set(df.columns) | {deriv} == set(ref_cols)              # the reference orders them through a set()
+    assert _same(np.array([list(t) for t in df.index.values]), g[pre + "_index"])
+    for c in df.columns:
+        assert _same(df[c].to_numpy(), g[pre + "_values"][:, ref_cols.index(c)]), c
+    dfi = ingest.model_table_from_raw(raw, tracks)
+    assert dfi.grid.shape == g[pre + "_grid"].shape
+    for k in range(3):
+        assert np.array_equal(dfi.index_columns[k], g[pre + "_axes%d" % k])
+    for c in dfi.columns:
+        assert _same(dfi.grid[..., dfi.column_index[c]], g[pre + "_grid"][..., ref_cols.index(c)]), c
+    d = dfi.grid[..., dfi.column_index[deriv]]
+    assert np.isfinite(d).sum() == len(raw) and np.isnan(d).sum() == d.size - len(raw)
+
+
+def test_ragged_age_arrays(g):
+    dfi = ingest.model_table_from_raw(_raw(g, "track"), True)
+    want_age, want_dt, want_len = g["track_age_arrays"], g["track_dt_deep_arrays"], g["track_lengths"]
+    age, dt, lengths = ingest.ragged_age_arrays(dfi, "age", n_eep=want_age.shape[1], with_dt_deep=True)
+    assert np.array_equal(lengths, want_len) and len(set(want_len.tolist())) > 3        # really ragged
+    assert _same(age, want_age) and _same(dt, want_dt)
+    age2, len2 = ingest.ragged_age_arrays(dfi, "age")
+    assert np.array_equal(len2, want_len) and _same(age2, want_age[:, : age2.shape[1]])
+
+
+def test_bc_frames_to_dense_table(g, tmp_path):
+    bands = [str(b) for b in g["bc_bands"]]
+    frames = [(g["bc_index"], g["bc_%s_values" % p], [str(c) for c in g["bc_%s_columns" % p]]) for p in ("UBVRIplus", "WISE")]
+    bc = ingest.bc_table_from_frames(frames, bands)
+    ref_cols = [str(c) for c in g["bc_columns"]]
+    assert sorted(bc.columns) == sorted(ref_cols) == sorted(bands)
+    assert bc.grid.shape == g["bc_grid"].shape and bc.index_names == ["Teff", "logg", "[Fe/H]", "Av"]
+    for k in range(4):
+        assert np.array_equal(bc.index_columns[k], g["bc_axes%d" % k])
+    for c in bands:
+        assert np.array_equal(bc.grid[..., bc.column_index[c]], g["bc_grid"][..., ref_cols.index(c)]), c
+    # shuffled rows, the export-file route, and a frame already sliced at Rv = 3.1
+    perm = np.random.default_rng(0).permutation(len(g["bc_index"]))
+    idx = pd.MultiIndex.from_arrays(g["bc_index"][perm].T, names=["Teff", "logg", "[Fe/H]", "Av", "Rv"])
+    files = []
+    for p in ("UBVRIplus", "WISE"):
+        fr = pd.DataFrame(g["bc_%s_values" % p][perm], index=idx, columns=[str(c) for c in g["bc_%s_columns" % p]])
+        files.append(str(tmp_path / (p + ".npz")))
+        ingest.export_frame_npz(fr, files[-1])
+    bc2 = ingest.bc_table_from_frames(files, bands)
+    assert bc2.columns == bc.columns and np.array_equal(bc2.grid, bc.grid)
+    keep = g["bc_index"][:, 4] == 3.1
+    bc3 = ingest.bc_table_from_frames([(g["bc_index"][keep, :4], f[1][keep], f[2]) for f in frames], bands)
+    assert np.array_equal(bc3.grid, bc.grid)
+    other = ingest.bc_table_from_frames(frames, bands, rv=2.5)
+    assert not np.array_equal(other.grid, bc.grid)
+    with pytest.raises(ValueError):
+        ingest.bc_table_from_frames(frames, ["J", "z"])            # SDSS frame not given
+    with pytest.raises(ValueError):
+        drop = np.arange(len(g["bc_index"])) != int(np.flatnonzero(keep)[5])
+        ingest.bc_table_from_frames([(f[0][drop], f[1][drop], f[2]) for f in frames], bands)   # not a full product
+
+
+def test_band_names(g):
+    """(system, column) of 35 band names as the reference's get_band resolves them (isochrones/mist/bc.py:165-233)."""
+    assert len(g["band_names"]) >= 35
+    for b, phot, col in zip(g["band_names"], g["band_phot"], g["band_column"]):
+        if str(phot) == "!unresolved":                           # the reference raises ValueError for these
+            with pytest.raises(ValueError):
+                ingest.mist_band(str(b), {"UBVRIplus": ["Tycho_B"]})
+        else:
+            # full column names are looked up in the tables at hand (the reference: in its static filter list)
+            known = {"UBVRIplus": ["Tycho_B", "Hipparcos_Hp", "Gaia_G_MAW"], "HST_WFPC2": ["WFPC2_F555W"],
+                     "SDSSugriz": ["SDSS_g"]}
+            assert ingest.mist_band(str(b), known) == (str(phot), str(col)), b
+    assert (g["band_phot"] == "!unresolved").sum() >= 2
+
+
+def test_unknown_band_is_an_error():
+    with pytest.raises(ValueError):
+        ingest.mist_band("nonsense")
