@@ -8,7 +8,7 @@ inline size_t stretch_persist_lds_bytes(int axes_len, int nb, int W, int np)
     return (size_t)(((axes_len + 1) & ~1) + coop_lds_doubles(nb) + persist_extra_doubles(W, np)) * sizeof(double);
 }
 
-template <int KIND, int NS>
+template <int KIND, int NS, bool ASTERO = false>
 inline bool launch_stretch_nb(int nb, const FastArgs& A, const StretchArgs& S, hipStream_t s)
 {
     const dim3 b(BLOCK);
@@ -24,15 +24,15 @@ inline bool launch_stretch_nb(int nb, const FastArgs& A, const StretchArgs& S, h
             if (S.occupancy_query) {                                                                      \
                 const hipError_t qe = S.dense                                                             \
                     ? hipOccupancyMaxActiveBlocksPerMultiprocessor(S.occupancy_query,                     \
-                                                                   k_stretch_persist<KIND, NS, N, true>,  \
+                                                                   k_stretch_persist<KIND, NS, N, true, ASTERO>,  \
                                                                    BLOCK, shp(N))                         \
                     : hipOccupancyMaxActiveBlocksPerMultiprocessor(S.occupancy_query,                     \
-                                                                   k_stretch_persist<KIND, NS, N, false>, \
+                                                                   k_stretch_persist<KIND, NS, N, false, ASTERO>, \
                                                                    BLOCK, shp(N));                        \
                 return qe == hipSuccess;                                                                  \
             }                                                                                             \
-            if (S.dense) hipLaunchKernelGGL((k_stretch_persist<KIND, NS, N, true>), gp, b, shp(N), s, A, S);   \
-            else hipLaunchKernelGGL((k_stretch_persist<KIND, NS, N, false>), gp, b, shp(N), s, A, S);     \
+            if (S.dense) hipLaunchKernelGGL((k_stretch_persist<KIND, NS, N, true, ASTERO>), gp, b, shp(N), s, A, S);   \
+            else hipLaunchKernelGGL((k_stretch_persist<KIND, NS, N, false, ASTERO>), gp, b, shp(N), s, A, S);     \
             return true;
             ISO_PERSIST_CASE(0) ISO_PERSIST_CASE(1) ISO_PERSIST_CASE(2) ISO_PERSIST_CASE(3) ISO_PERSIST_CASE(4) ISO_PERSIST_CASE(5)
             ISO_PERSIST_CASE(6) ISO_PERSIST_CASE(7) ISO_PERSIST_CASE(8) ISO_PERSIST_CASE(9) ISO_PERSIST_CASE(10)
@@ -44,19 +44,19 @@ inline bool launch_stretch_nb(int nb, const FastArgs& A, const StretchArgs& S, h
     const dim3 g((unsigned)((S.n_active + BLOCK - 1) / BLOCK));
     auto sh = [&](int n) { return (size_t)(((A.axes_len + 1) & ~1) + coop_lds_doubles(n)) * sizeof(double); };
     switch (nb) {
-    case 0: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 0>), g, b, sh(0), s, A, S); return true;
-    case 1: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 1>), g, b, sh(1), s, A, S); return true;
-    case 2: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 2>), g, b, sh(2), s, A, S); return true;
-    case 3: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 3>), g, b, sh(3), s, A, S); return true;
-    case 4: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 4>), g, b, sh(4), s, A, S); return true;
-    case 5: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 5>), g, b, sh(5), s, A, S); return true;
-    case 6: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 6>), g, b, sh(6), s, A, S); return true;
-    case 7: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 7>), g, b, sh(7), s, A, S); return true;
-    case 8: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 8>), g, b, sh(8), s, A, S); return true;
-    case 9: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 9>), g, b, sh(9), s, A, S); return true;
-    case 10: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 10>), g, b, sh(10), s, A, S); return true;
-    case 11: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 11>), g, b, sh(11), s, A, S); return true;
-    case 12: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 12>), g, b, sh(12), s, A, S); return true;
+    case 0: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 0, ASTERO>), g, b, sh(0), s, A, S); return true;
+    case 1: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 1, ASTERO>), g, b, sh(1), s, A, S); return true;
+    case 2: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 2, ASTERO>), g, b, sh(2), s, A, S); return true;
+    case 3: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 3, ASTERO>), g, b, sh(3), s, A, S); return true;
+    case 4: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 4, ASTERO>), g, b, sh(4), s, A, S); return true;
+    case 5: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 5, ASTERO>), g, b, sh(5), s, A, S); return true;
+    case 6: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 6, ASTERO>), g, b, sh(6), s, A, S); return true;
+    case 7: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 7, ASTERO>), g, b, sh(7), s, A, S); return true;
+    case 8: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 8, ASTERO>), g, b, sh(8), s, A, S); return true;
+    case 9: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 9, ASTERO>), g, b, sh(9), s, A, S); return true;
+    case 10: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 10, ASTERO>), g, b, sh(10), s, A, S); return true;
+    case 11: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 11, ASTERO>), g, b, sh(11), s, A, S); return true;
+    case 12: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 12, ASTERO>), g, b, sh(12), s, A, S); return true;
     default: return false;
     }
 }

@@ -7,7 +7,8 @@
 // One lane = one walker of the active half of one star's ensemble: draw a partner from the
 // complementary half (Philox4x32-10 counter RNG, keyed by seed, counter = (step, half, row)),
 // propose y = x_j + z (x_k - x_j), evaluate lnpost(y) with the same device function as the batch
-// kernel, accept / reject in place.  The active half only *reads* the other half, so a half-step
+// kernel, accept / reject in place.  ASTERO: the instantiation for models with nu_max / delta_nu terms
+// (reference starmodel.py:1603-1612), as in the batch kernel a template parameter, not a runtime branch.  The active half only *reads* the other half, so a half-step
 // is race-free; two launches make one emcee-style iteration (Goodman & Weare 2010; the reference
 // drives emcee.EnsembleSampler with one Python lnpost call per walker, starmodel.py:951-969).
 // -------------------------------------------------------------------------------------------
@@ -30,7 +31,7 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 // that star's [W][NP] / [W] / [W] arrays (global memory in the step-wise kernel, LDS in the persistent
 // one), `chain_pos` / `chain_lnp` its slab of the stored chain for this step (or null).  The Philox
 // counter is (step, half, global row): both kernels draw identical numbers for a given move.
-template <int KIND, int NS, int NB>
+template <int KIND, int NS, int NB, bool ASTERO>
 __device__ __forceinline__ void stretch_move(const FastArgs& A, const StretchArgs& S, double* lds, const CoopLds& L,
                                              bool active, int64_t star, int k, int half, uint32_t step,
                                              double* __restrict__ pos, double* __restrict__ lnp, int32_t* acc_cnt,
@@ -62,7 +63,7 @@ __device__ __forceinline__ void stretch_move(const FastArgs& A, const StretchArg
     const double lold = lnp[lsrc];
     const DevModel& M = A.m[S.multi ? star : 0];
     double lnp_unused, lnl_unused;
-    const double lnew = lnpost_wave<KIND, NS, NB, true, false, true>(A, lds, L, active, M, y, false, lnp_unused, lnl_unused);
+    const double lnew = lnpost_wave<KIND, NS, NB, true, ASTERO, true>(A, lds, L, active, M, y, false, lnp_unused, lnl_unused);
     const double lnq = (NP - 1) * log(z) + lnew - lold;
     const bool acc = active && isfinite(lnew) && (log(u2) < lnq);
     if (acc) {
@@ -81,7 +82,7 @@ __device__ __forceinline__ void stretch_move(const FastArgs& A, const StretchArg
 
 // step-wise form: one launch = one half-step of every ensemble (grid over stars x W/2 walkers);
 // the throughput form for catalogs large enough to fill the chip
-template <int KIND, int NS, int NB>
+template <int KIND, int NS, int NB, bool ASTERO = false>
 __global__ __launch_bounds__(BLOCK) void k_stretch_half(const FastArgs A, const StretchArgs S)
 {
     extern __shared__ double lds[];
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(BLOCK) void k_stretch_half(const FastArgs A, const 
     const int64_t star = t / h;
     const int k = (int)(t - star * h);
     const int64_t r0 = star * S.W;
-    stretch_move<KIND, NS, NB>(A, S, lds, L, active, star, k, S.half, S.step, S.pos + r0 * NP, S.lnp + r0,
+    stretch_move<KIND, NS, NB, ASTERO>(A, S, lds, L, active, star, k, S.half, S.step, S.pos + r0 * NP, S.lnp + r0,
                                S.accepted ? S.accepted + r0 : nullptr, S.chain_pos ? S.chain_pos + r0 * NP : nullptr,
                                S.chain_lnp ? S.chain_lnp + r0 : nullptr);
 }
@@ -117,7 +118,7 @@ __host__ __device__ constexpr int persist_extra_doubles(int W, int np)
 // DENSE: registers capped for 3 waves/SIMD, so that 3 workgroups share a CU (catalogs of 513-768 workgroups
 // stay resident in one round: 10^4 stars x 32 walkers 53 -> 42 us per iteration); the uncapped form (182 VGPR,
 // 2 workgroups per CU) is 10 % faster when latency is all that matters.
-template <int KIND, int NS, int NB, bool DENSE>
+template <int KIND, int NS, int NB, bool DENSE, bool ASTERO = false>
 __global__ __launch_bounds__(BLOCK, DENSE ? 3 : 1) void k_stretch_persist(const FastArgs A, const StretchArgs S)
 {
     extern __shared__ double lds[];
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(BLOCK, DENSE ? 3 : 1) void k_stretch_persist(const 
                 const int k = k0 + kk;
                 const bool active = mine && k < h;
                 if (__any(active))                        // wave-uniform: idle waves go straight to the barrier
-                    stretch_move<KIND, NS, NB>(A, S, lds, L, active, star0 + gs, active ? k : h - 1, half,
+                    stretch_move<KIND, NS, NB, ASTERO>(A, S, lds, L, active, star0 + gs, active ? k : h - 1, half,
                                                S.step + (uint32_t)it, lpos + gs * W * NP, llnp + gs * W,
                                                lacc + gs * W, cp, cl);
             }

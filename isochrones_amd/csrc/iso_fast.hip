@@ -17,6 +17,15 @@ bool launch_lnpost_fast(int kind, int n_stars, int n_bands, bool packed, bool mu
 
 bool launch_stretch(int kind, int n_stars, int n_bands, const FastArgs& A, const StretchArgs& S, hipStream_t s)
 {
+    if (A.astq) {                     // the model has nu_max / delta_nu terms: ASTERO instantiations
+        if (kind == ISO_KIND_TRACK) return n_stars == 1 && launch_stretch_ast_track1(n_bands, A, S, s);
+        switch (n_stars) {
+        case 1: return launch_stretch_ast_iso1(n_bands, A, S, s);
+        case 2: return launch_stretch_ast_iso2(n_bands, A, S, s);
+        case 3: return launch_stretch_ast_iso3(n_bands, A, S, s);
+        }
+        return false;
+    }
     if (kind == ISO_KIND_TRACK) return n_stars == 1 && launch_stretch_track1(n_bands, A, S, s);
     switch (n_stars) {
     case 1: return launch_stretch_iso1(n_bands, A, S, s);

@@ -55,6 +55,18 @@ constexpr double kInvLn10 = 0.43429448190325176;
         return fastk::launch_stretch_nb<KIND, NS>(nb, A, S, s);                               \
     }
 
+// the sampler kernels of models with asteroseismic terms live in their own translation units
+// (iso_fast_ast_<tag>.hip): they double the number of instantiations and would otherwise double the build time
+#define ISO_DEFINE_STRETCH_AST_LAUNCHER(NAME, KIND, NS)                                       \
+    bool NAME(int nb, const FastArgs& A, const StretchArgs& S, hipStream_t s)                 \
+    {                                                                                         \
+        return fastk::launch_stretch_nb<KIND, NS, true>(nb, A, S, s);                         \
+    }
+
+bool launch_stretch_ast_track1(int nb, const FastArgs& A, const StretchArgs& S, hipStream_t s);
+bool launch_stretch_ast_iso1(int nb, const FastArgs& A, const StretchArgs& S, hipStream_t s);
+bool launch_stretch_ast_iso2(int nb, const FastArgs& A, const StretchArgs& S, hipStream_t s);
+bool launch_stretch_ast_iso3(int nb, const FastArgs& A, const StretchArgs& S, hipStream_t s);
 bool launch_stretch_track1(int nb, const FastArgs& A, const StretchArgs& S, hipStream_t s);
 bool launch_stretch_iso1(int nb, const FastArgs& A, const StretchArgs& S, hipStream_t s);
 bool launch_stretch_iso2(int nb, const FastArgs& A, const StretchArgs& S, hipStream_t s);

@@ -1602,9 +1602,9 @@ int iso_sampler_create_model(iso_model* m, int nwalkers, double a, uint64_t seed
 {
     if (!m || !out) return fail(ISO_ERR_INVALID, "iso_sampler_create_model: NULL argument");
     if (nwalkers < 2 || (nwalkers & 1) || !(a > 1.0)) return fail(ISO_ERR_INVALID, "iso_sampler_create_model: need an even walker count and a > 1");
-    if (!m->fast_ok || !m->fast.hotq || (!m->fast.bcq && m->desc.n_bands > 0) || m->fast.astq)
+    if (!m->fast_ok || !m->fast.hotq || (!m->fast.bcq && m->desc.n_bands > 0))
         return fail(ISO_ERR_INVALID, "iso_sampler_create_model: the model is not on the corner-packed fast path "
-                                     "(needs <= 12 bands, uniform EEP axis, no asteroseismic terms, ISOCHRONES_AMD_PATH=auto)");
+                                     "(needs <= 12 bands, uniform EEP axis, ISOCHRONES_AMD_PATH=auto)");
     iso_sampler* sp = new (std::nothrow) iso_sampler();
     if (!sp) return fail(ISO_ERR_NOMEM, "iso_sampler_create_model: out of host memory");
     sampler_common(sp, m->device, m->ic->kind, m->desc.n_stars, m->desc.n_bands, 1, m->fast, 0, nwalkers, a, seed);

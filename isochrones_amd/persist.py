@@ -8,10 +8,8 @@ here into one ``.npz`` container (numpy only: pytables / h5py are optional and a
 * ``samples`` / ``samples_columns`` and ``derived`` / ``derived_columns``  — the two DataFrames,
 * ``obs_*``       — the observation tree's photometry rows (generic model only),
 * ``meta``        — JSON: class, name, N / index, measurements, bounds, grid type and bands, evidence,
-* ``priors``      — the prior objects, pickled (as the reference does through HDF5 attributes).
-
-The prior objects are pickled, as pandas pickles them into the reference's HDF5 attributes; on loading, only this
-package's prior classes (and the numpy arrays inside them) are accepted — anything else in the stream is refused.
+* ``priors``      — JSON records of the prior objects: class name + constructor parameters (the reference pickles
+  them into HDF5 attributes; nothing executable is stored or read here).
 
 ``save_hdf`` / ``load_hdf`` keep the reference's names: they write / read this container when the file
 name ends in ``.npz`` and otherwise need pytables (pandas ``HDFStore``) for the reference's own layout.
@@ -20,28 +18,23 @@ from __future__ import annotations
 
 import json
 import os
-import pickle
 
 import numpy as np
 
-FORMAT_VERSION = 1
+FORMAT_VERSION = 2
 
 
-class _PriorUnpickler(pickle.Unpickler):
-    """Only this package's prior classes and the numpy array machinery they hold may be rebuilt from a file."""
-    _NUMPY_OK = ("_reconstruct", "ndarray", "dtype", "scalar")
-
-    def find_class(self, module, name):
-        if module == "isochrones_amd.priors" and not name.startswith("_"):
-            return super().find_class(module, name)
-        if module.split(".")[0] == "numpy" and name in self._NUMPY_OK:
-            return super().find_class(module, name)
-        raise pickle.UnpicklingError("refusing to load {}.{} from a saved model".format(module, name))
+def _dump_priors(priors):
+    """Prior objects as JSON records (class name + constructor parameters).  Nothing executable is stored: earlier
+    containers pickled them, and an unpickler restricted by module name can still be steered to arbitrary callables
+    through dotted attribute paths, so that format is refused on load."""
+    from .priors import prior_to_spec
+    return json.dumps({k: (None if v is None else prior_to_spec(v)) for k, v in priors.items()})
 
 
-def _load_priors(buf):
-    import io
-    return _PriorUnpickler(io.BytesIO(buf)).load()
+def _load_priors(text):
+    from .priors import prior_from_spec
+    return {k: (None if v is None else prior_from_spec(v)) for k, v in json.loads(text).items()}
 
 
 def _frame_arrays(df):
@@ -114,7 +107,7 @@ def save_model(mod, filename, overwrite=False):
         raise TypeError("cannot save a {}".format(type(mod).__name__))
     arrays["samples"], arrays["samples_columns"] = _frame_arrays(samples)
     arrays["derived"], arrays["derived_columns"] = _frame_arrays(derived)
-    arrays["priors"] = np.frombuffer(pickle.dumps(priors, protocol=4), dtype=np.uint8)
+    arrays["priors"] = np.array(_dump_priors(priors))
     arrays["meta"] = np.array(json.dumps(meta))
     tmp = filename + ".tmp.npz"
     np.savez(tmp, **arrays)          # uncompressed: zlib on ~1.5 MB of float64 noise costs 20-60 ms per model for nothing
@@ -134,7 +127,10 @@ def load_model(cls, filename, ic=None, name=None):
             raise ValueError("{}: unknown container version {!r}".format(filename, meta.get("format")))
         samples = _frame(z["samples"], z["samples_columns"])
         derived = _frame(z["derived"], z["derived_columns"])
-        priors = _load_priors(z["priors"].tobytes())
+        if z["priors"].dtype.kind != "U":
+            raise ValueError("{}: priors are stored in the pickled form of an older container, which is no longer "
+                             "read; save the model again".format(filename))
+        priors = _load_priors(str(z["priors"]))
         obs_arrays = {k: z[k] for k in z.files if k.startswith("obs_")}
     if ic is None:
         ic = _rebuild_ic(meta)

@@ -183,17 +183,29 @@ class GaussianPrior(Prior):
 
     def __init__(self, mean, sigma, bounds=None):
         self.mean, self.sigma = float(mean), float(sigma)
+        self.bounded = 0
+        self.norm, self.lognorm = 1.0, 0.0
         if bounds is not None:
             self.bounded = 1
             self._bounds = (float(bounds[0]), float(bounds[1]))
-            a, b = (self._bounds[0] - mean) / sigma, (self._bounds[1] - mean) / sigma
-            self.norm = _ncdf(b) - _ncdf(a)
-        else:
-            self.bounded = 0
-            self.norm = 1.0
-        # a truncation window that holds no probability mass gives norm = 0: -inf, as numpy's log in the reference
-        # (priors.py:246-247), not an exception
-        self.lognorm = math.log(self.norm) if self.norm > 0 else -math.inf
+            self.norm = self._mass_inside()
+            # a truncation window that holds no probability mass gives norm = 0: -inf, as numpy's log in the reference
+            # (priors.py:246-247), not an exception
+            self.lognorm = math.log(self.norm) if self.norm > 0 else -math.inf
+
+    def _mass_inside(self):
+        a, b = (self._bounds[0] - self.mean) / self.sigma, (self._bounds[1] - self.mean) / self.sigma
+        return _ncdf(b) - _ncdf(a)
+
+    def _rebuild(self):
+        """Bounds assigned after construction (``prior.bounds = ...``, ``model.set_bounds``): the prior is bounded
+        from then on - lnpdf is -inf outside, on the host and in the device descriptor - as the reference's
+        ``BoundedPrior.lnpdf`` (priors.py:131-140).  The normalisation stays the one of the constructor, and, as the
+        reference's bounds setter does with its integral test (priors.py:123-129), bounds under which the density no
+        longer integrates to one are refused."""
+        self.bounded = 1
+        if not np.isclose(self._mass_inside() / self.norm if self.norm > 0 else np.inf, 1.0):
+            raise ValueError("Problem setting bounds to {}; integral test failed.".format(self._bounds))
 
     def _raw(self, x):
         z = (x - self.mean) / self.sigma
@@ -470,3 +482,64 @@ def __getattr__(name):      # priors.EEP_prior (reference priors.py:384-463) liv
 
 DEVICE_PRIOR_TYPES = (FlatPrior, FlatLogPrior, PowerLawPrior, GaussianPrior, LogNormalPrior,
                       ChabrierPrior, FehPrior)
+
+# ---- plain-data form of a prior (saved models) ----------------------------------------------------
+#: the only classes a saved model may name
+_SPEC_CLASSES = {c.__name__: c for c in (FlatPrior, FlatLogPrior, PowerLawPrior, GaussianPrior, LogNormalPrior,
+                                         ChabrierPrior, FehPrior, AgePrior, DistancePrior, AVPrior, QPrior,
+                                         SalpeterPrior)}
+
+
+def prior_to_spec(p):
+    """``{"cls": name, ...constructor parameters...}`` - numbers, booleans and lists only (JSON)."""
+    name = type(p).__name__
+    if name not in _SPEC_CLASSES:
+        raise TypeError("cannot serialise a {}".format(name))
+    lo, hi = (float(b) for b in p.bounds)
+    if isinstance(p, ChabrierPrior):
+        return dict(cls=name, bounds=[lo, hi], mu=p.low.mu, sigma=p.low.sigma, alpha=p.high.alpha,
+                    breakpoint=float(p.breakpoints[0]), powerlaw_bounds=[float(b) for b in p.high.bounds])
+    if isinstance(p, PowerLawPrior):
+        return dict(cls=name, alpha=p.alpha, bounds=[lo, hi])
+    if isinstance(p, (FlatPrior, FlatLogPrior)):
+        return dict(cls=name, bounds=[lo, hi])
+    if isinstance(p, GaussianPrior):
+        # the normalisation is a record of its own: bounds assigned after construction do not change it
+        return dict(cls=name, mean=p.mean, sigma=p.sigma, bounds=[lo, hi] if p.bounded else None, norm=p.norm)
+    if isinstance(p, LogNormalPrior):
+        return dict(cls=name, mu=p.mu, sigma=p.sigma)
+    if isinstance(p, FehPrior):
+        return dict(cls=name, halo_fraction=p.halo_fraction, local=p.local,
+                    bounds=[lo, hi] if np.isfinite(lo) and np.isfinite(hi) else None)
+    raise TypeError("cannot serialise a {}".format(name))
+
+
+def prior_from_spec(spec):
+    """Inverse of :func:`prior_to_spec`; the class is looked up in an explicit table, every parameter is coerced to
+    float / bool, nothing else in the record is interpreted."""
+    if not isinstance(spec, dict) or spec.get("cls") not in _SPEC_CLASSES:
+        raise ValueError("not a prior record: {!r}".format(spec))
+    cls = _SPEC_CLASSES[spec["cls"]]
+    num = lambda k: float(spec[k])
+    pair = lambda k: None if spec.get(k) is None else (float(spec[k][0]), float(spec[k][1]))
+    obj = cls.__new__(cls)                 # sub-classes (AgePrior, DistancePrior, ...) only differ in their defaults
+    if issubclass(cls, ChabrierPrior):
+        ChabrierPrior.__init__(obj, bounds=pair("bounds"), mu=num("mu"), sigma=num("sigma"), alpha=num("alpha"),
+                               breakpoint=num("breakpoint"), powerlaw_bounds=pair("powerlaw_bounds"))
+    elif issubclass(cls, PowerLawPrior):
+        PowerLawPrior.__init__(obj, num("alpha"), pair("bounds"))
+    elif issubclass(cls, FlatPrior):
+        FlatPrior.__init__(obj, pair("bounds"))
+    elif issubclass(cls, FlatLogPrior):
+        FlatLogPrior.__init__(obj, pair("bounds"))
+    elif issubclass(cls, GaussianPrior):
+        GaussianPrior.__init__(obj, num("mean"), num("sigma"))
+        if pair("bounds") is not None:
+            obj.bounded, obj._bounds = 1, pair("bounds")
+        obj.norm = num("norm")
+        obj.lognorm = math.log(obj.norm) if obj.norm > 0 else -math.inf
+    elif issubclass(cls, LogNormalPrior):
+        LogNormalPrior.__init__(obj, num("mu"), num("sigma"))
+    else:
+        FehPrior.__init__(obj, halo_fraction=num("halo_fraction"), local=bool(spec["local"]), bounds=pair("bounds"))
+    return obj

@@ -793,7 +793,9 @@ def test_save_load_round_trip_and_convenience_helpers(tmp_path):
     assert tb.param_names == tree.param_names and tb.obs.leaf_labels == tree.obs.leaf_labels
     assert tb.evidence == tree.evidence and tb.labelstring == "binary" and tb.props == []
     q = tree.samples[list(tree.param_names)].values[:40]
-    assert np.array_equal(tb.lnpost(q), tree.lnpost(q))
+    # the tree rebuilt from the stored rows may list same-resolution observations in another order: the same terms
+    # summed in a different order, so equal to rounding, not bit for bit
+    assert np.allclose(tb.lnpost(q), tree.lnpost(q), rtol=1e-12, atol=0)
     assert np.array_equal(tb.samples.values, tree.samples.values)
     cube = [0.2, 0.7, 0.5, 0.4, 0.3, 0.1]                      # EEPs out of order: mnest_prior sorts them (starmodel.py:644-656)
     tree.mnest_prior(cube)

@@ -115,6 +115,51 @@ def test_cfg3_binary_sampler_moves_against_the_oracle():
     assert st["near_ties"] <= 2
 
 
+@pytest.mark.parametrize("kind", ["track", "iso"])
+def test_asteroseismic_model_fits_on_the_fused_sampler_and_matches_the_oracle(kind, monkeypatch):
+    """nu_max / delta_nu terms (reference starmodel.py:1603-1612, delta_nu with sigma = its value): the ASTERO
+    instantiations of both sampler kernels, replayed move by move; fit_mcmc stays on the device path."""
+    from isochrones_amd.sampler import FusedEnsembleSampler
+    if kind == "track":
+        ic = ia.synthetic_track(bands=("V", "K"))
+        truth = np.array([1.0, 355.0, 0.0, 100.0, 0.1])
+        width = np.array([0.01, 2.0, 0.02, 1.0, 0.02])
+    else:
+        ic = ia.synthetic_isochrone(bands=("V", "K"))
+        truth = np.array([355.0, 9.6, 0.0, 100.0, 0.1])
+        width = np.array([2.0, 0.01, 0.02, 1.0, 0.02])
+    numax, dnu = (float(v) for v in ic.interp_value(truth, ["nu_max", "delta_nu"]))
+    T, g, f, mags = ic.interp_mag(truth, ["V", "K"])
+    mod = ia.SingleStarModel(ic, Teff=(float(T), 100), V=(float(mags[0]), 0.05), K=(float(mags[1]), 0.03),
+                             nu_max=(numax, 0.03 * numax), delta_nu=(dnu, 0.02 * dnu))
+    d = mod.model_desc()
+    assert d.has_numax == 1 and d.has_dnu == 1
+    W, seed = 64, 5
+    rng = np.random.default_rng(2)
+    p0 = truth + width * rng.standard_normal((W, 5))
+    p0[:, 4] = np.abs(p0[:, 4])
+    fn = _oracle_fn(ic, [d])
+    lnp0 = fn(np.zeros(W, dtype=int), p0)
+    assert np.isfinite(lnp0).all()
+    # the asteroseismic terms matter for this posterior
+    plain = ia.SingleStarModel(ic, Teff=(float(T), 100), V=(float(mags[0]), 0.05), K=(float(mags[1]), 0.03))
+    assert np.max(np.abs(fn(np.zeros(W, dtype=int), p0) - _oracle_fn(ic, [plain.model_desc()])(np.zeros(W, dtype=int), p0))) > 1.0
+    for mode, T_steps in (("persistent", 1200), ("stepwise", 300)):
+        monkeypatch.setenv("ISOCHRONES_AMD_SAMPLER", mode)
+        fs = FusedEnsembleSampler(mod, W, seed=seed)
+        fs.run_mcmc(p0, T_steps, lnprob0=lnp0, store=True)
+        st = _replay.replay(p0, lnp0, fs._chain.cpu().numpy(), fs._lnprob.cpu().numpy(), W, 2.0, seed, 0, fn)
+        assert st["moves"] == W * T_steps and st["accepted"] > 0.1 * st["moves"] and st["near_ties"] <= 2
+        fs.close()
+    monkeypatch.delenv("ISOCHRONES_AMD_SAMPLER")
+    sampler = mod.fit_mcmc(nwalkers=64, nburn=200, niter=100, p0=truth, seed=3, fused=True)     # fused=True: no fallback
+    assert isinstance(sampler, FusedEnsembleSampler) and sampler.chain.shape == (64, 100, 5)
+    assert isinstance(mod.fit_mcmc(nwalkers=64, nburn=20, niter=20, p0=truth, seed=3), FusedEnsembleSampler)   # and by default
+    lp = sampler.flatlnprobability.cpu().numpy()
+    want = fn(np.zeros(lp.size, dtype=int), sampler.flatchain.cpu().numpy())
+    fx.assert_close(lp, want, 1e-9, atol=1e-10, what="astero chain lnprob")
+
+
 def _catalog(n_stars, seed=7):
     bands = ["G", "BP", "RP"]
     ic = ia.synthetic_track(bands=bands)            # full-size tables, as bench.py's catalog leg

@@ -300,19 +300,46 @@ def test_from_ini_with_an_obsfile(tmp_path):
     fx.assert_close(a, g["lnpost"], 1e-11, atol=1e-11, what="lnpost of the obsfile model vs the reference golden")
 
 
-def test_saved_model_refuses_foreign_pickles(tmp_path):
-    """The priors entry of a saved model may only rebuild this package's prior classes."""
+def test_saved_model_priors_are_plain_data(tmp_path):
+    """The priors entry of a saved model is JSON (class name + constructor parameters): every prior family round-trips,
+    nothing is unpickled, an older pickled entry or a record naming anything but a prior class is refused."""
+    import json
     import pickle
-    from isochrones_amd import persist
+    from isochrones_amd import persist, priors as P
     meta = fx.load("ini_flat")["meta"]
     ic = fx.make_ic(dict(kind="iso", limits=meta["limits"], eep_bounds=meta["eep_bounds"]))
     mod = ia.BasicStarModel.from_ini(ic, folder=os.path.join(INI_DIR, "flat"))
     f = str(tmp_path / "m.npz")
     mod.save(f)
-    with np.load(f) as z:
+    with np.load(f, allow_pickle=False) as z:
         arrays = {k: z[k] for k in z.files}
-    arrays["priors"] = np.frombuffer(pickle.dumps({"mass": os.getcwd, "x": os.system}), dtype=np.uint8)
+    assert arrays["priors"].dtype.kind == "U" and "cls" in str(arrays["priors"])
+    assert ia.BasicStarModel.load(f, ic=ic).kwargs == mod.kwargs
+    # every family, including bounds set after construction (GaussianPrior: bounds truncate, reference priors.py:131-140)
+    g = P.GaussianPrior(0.0, 0.1)
+    g.bounds = (-1.0, 0.5)
+    assert g.bounded == 1 and g.lnpdf(2.0) == -np.inf and g.pdf(2.0) == 0.0 and g.desc().bounded == 1
+    assert g.norm == 1.0 and np.isclose(P.GaussianPrior(0.0, 0.1, bounds=(0.0, 5.0)).norm, 0.5)
+    with pytest.raises(ValueError, match="integral test failed"):           # reference bounds setter, priors.py:123-129
+        P.GaussianPrior(0.0, 0.1).bounds = (0.0, 5.0)
+    fam = [P.FlatPrior((0, 2)), P.FlatLogPrior((1, 3)), P.PowerLawPrior(-2.35, (1, 100)), g, P.GaussianPrior(1.0, 2.0),
+           P.LogNormalPrior(0.1, 0.5), P.ChabrierPrior(bounds=(0.1, 300)), P.FehPrior(halo_fraction=0.05, bounds=(-4, 0.5)),
+           P.FehPrior(local=False), P.AgePrior(), P.DistancePrior(3000), P.AVPrior((0, 0.5)), P.QPrior(), P.SalpeterPrior()]
+    for p in fam:
+        spec = json.loads(json.dumps(P.prior_to_spec(p)))
+        q = P.prior_from_spec(spec)
+        assert type(q) is type(p) and q.bounds == p.bounds and q.bounded == p.bounded
+        a, b = p.desc(), q.desc()
+        assert all(getattr(a, k) == getattr(b, k) or (np.isnan(getattr(a, k)) and np.isnan(getattr(b, k)))
+                   for k, _ in a._fields_), type(p).__name__
+    # refused: the pickled form of older containers (whatever it holds), unknown classes, dotted names
+    arrays["priors"] = np.frombuffer(pickle.dumps({"mass": os.getcwd, "x": os.system}, protocol=4), dtype=np.uint8)
     np.savez(str(tmp_path / "evil.npz"), **arrays)
-    with pytest.raises(pickle.UnpicklingError, match="refusing to load"):
+    with pytest.raises(ValueError, match="pickled form"):
         ia.BasicStarModel.load(str(tmp_path / "evil.npz"), ic=ic)
-    assert ia.BasicStarModel.load(f, ic=ic).kwargs == mod.kwargs          # the genuine file still loads
+    for bad in ({"cls": "np.ctypeslib.os.system"}, {"cls": "Prior"}, {"cls": "EEP_prior"}, "FlatPrior", {"bounds": [0, 1]}):
+        arrays["priors"] = np.array(json.dumps({"mass": bad}))
+        np.savez(str(tmp_path / "evil2.npz"), **arrays)
+        with pytest.raises(ValueError, match="not a prior record"):
+            ia.BasicStarModel.load(str(tmp_path / "evil2.npz"), ic=ic)
+    assert not hasattr(persist, "pickle")
