@@ -36,44 +36,65 @@ def shard_indices(n: int, rank: int, world: int) -> np.ndarray:
 
 
 class StarCatalog:
+    """Measurements of many stars, held column-wise.
+
+    The reference's ``StarCatalog`` (isochrones/catalog.py:19-139) wraps a DataFrame whose columns follow the
+    ``<band>_mag`` / ``<band>_mag_unc`` and ``<prop>`` / ``<prop>_unc`` naming and yields one star model per row.
+    The same frame, names and accessors are accepted here, but the object is organised around what the batched
+    device path consumes: every measurement is pulled out once as a (values, uncertainties) pair of float arrays
+    (``measurements``), so building the per-star columns of :class:`CatalogPosterior` never touches a row object;
+    per-row models are only made on request (``model(i)`` / ``iter_models``).
+
+    df        frame with one row per star (index = star names)
+    bands     photometric bands; default: every ``X`` with an ``X_mag`` column
+    props     further measured quantities (``Teff``, ``logg``, ``feh``, ``parallax``, ...)
+    no_uncs   accept a frame without uncertainty columns (uncertainties are then NaN)"""
+
+    _MAG = re.compile(r"(.+)_mag$")
+
     def __init__(self, df, bands=None, props=None, no_uncs=False):
         self.df = df
-        if bands is None:
-            bands = [m.group(1) for m in (re.search("(.+)_mag$", c) for c in df.columns) if m]
-        self.bands = tuple(bands)
-        self.band_cols = tuple("{}_mag".format(b) for b in self.bands)
-        self.props = tuple() if props is None else tuple(props)
-        if not no_uncs:
-            for c in self.band_cols + self.props:
-                if c not in df.columns:
-                    raise ValueError("{} not in DataFrame!".format(c))
-                if "{}_unc".format(c) not in df.columns:
-                    raise ValueError("{0} uncertainty ({0}_unc) not in DataFrame!".format(c))
+        names = [str(c) for c in df.columns]
+        self.bands = tuple(bands) if bands is not None else tuple(m.group(1) for m in map(self._MAG.match, names) if m)
+        self.props = tuple(props or ())
         self._prior_settings = {}
+        self.measurements = {}
+        for key, column in [(b, b + "_mag") for b in self.bands] + [(q, q) for q in self.props]:
+            missing = [c for c in (column, column + "_unc") if c not in names]
+            if missing and not no_uncs:
+                what = ("{} not in DataFrame!" if missing[0] == column else "{0} uncertainty ({0}_unc) not in DataFrame!")
+                raise ValueError(what.format(column))
+            val = df[column].to_numpy(dtype=float) if column in names else np.full(len(df), np.nan)
+            unc = df[column + "_unc"].to_numpy(dtype=float) if column + "_unc" in names else np.full(len(df), np.nan)
+            self.measurements[key] = (val, unc)
+
+    @property
+    def band_cols(self):
+        return tuple(b + "_mag" for b in self.bands)
 
     def __len__(self):
         return len(self.df)
 
     def get_measurement(self, prop, values=False):
-        return self.df[prop].values, self.df[prop + "_unc"].values
+        """(values, uncertainties) of a band (``"J"`` or ``"J_mag"``) or property."""
+        m = self._MAG.match(prop)
+        key = m.group(1) if m and m.group(1) in self.measurements else prop
+        return self.measurements[key]
 
     def iter_bands(self, **kwargs):
-        for b, col in zip(self.bands, self.band_cols):
-            yield b, self.get_measurement(col, **kwargs)
+        return ((b, self.measurements[b]) for b in self.bands)
 
     def iter_props(self, **kwargs):
-        for p in self.props:
-            yield p, self.get_measurement(p, **kwargs)
+        return ((q, self.measurements[q]) for q in self.props)
 
     def set_prior(self, **kwargs):
-        """Prior objects applied to every model of the catalog (reference: catalog.py:117-124)."""
+        """Prior objects every model built from this catalog receives (reference: catalog.py:117-124)."""
         self._prior_settings.update(kwargs)
 
     def model(self, i, ic, N=1, **kwargs):
-        row = self.df.iloc[i]
-        mags = {b: (row["{}_mag".format(b)], row["{}_mag_unc".format(b)]) for b in self.bands}
-        props = {p: (row[p], row["{}_unc".format(p)]) for p in self.props}
-        mod = BasicStarModel(ic, N=N, name=row.name, **mags, **props, **kwargs)
+        """The 1-3 star model of row ``i`` (what the reference's ``iter_models`` yields for it)."""
+        obs = {key: (float(v[i]), float(u[i])) for key, (v, u) in self.measurements.items()}
+        mod = BasicStarModel(ic, N=N, name=self.df.index[i], **obs, **kwargs)
         if self._prior_settings:
             mod.set_prior(**self._prior_settings)
         return mod
@@ -82,28 +103,12 @@ class StarCatalog:
         if ic is None:
             from .models import get_ichrone
             ic = get_ichrone("mist", bands=self.bands)
-        for i in (range(len(self.df)) if indices is None else indices):
-            yield self.model(i, ic, N=N, **kwargs)
+        return (self.model(int(i), ic, N=N, **kwargs) for i in (range(len(self)) if indices is None else indices))
 
     def write_ini(self, ic=None, root=".", N=1, nest_directories=True, clobber=True):
-        """One ``<name>/star.ini`` folder per star — the layout ``starfit`` / ``batch_starfit`` walk (reference:
-        catalog.py:141-158; with ``nest_directories`` the folders are grouped by the first log_100(len) characters
-        of the star's name).  Returns the list of folders."""
-        import os
-        import shutil
-        if ic is None:
-            from .models import get_ichrone
-            ic = get_ichrone("mist", bands=self.bands)
-        n_pre = int(np.log10(max(len(self), 1)) // 2)
-        dirs = []
-        for mod in self.iter_models(ic, N=N):
-            path = os.path.join(root, str(mod.name)[:n_pre]) if nest_directories else root
-            mod_path = os.path.abspath(os.path.join(path, mod.name))
-            if os.path.exists(mod_path) and clobber:
-                shutil.rmtree(mod_path)
-            mod.write_ini(root=path)
-            dirs.append(mod_path)
-        return dirs
+        """One ``<name>/star.ini`` folder per star for the per-folder drivers (see starfit.write_catalog_ini)."""
+        from .starfit import write_catalog_ini
+        return write_catalog_ini(self, ic=ic, root=root, N=N, nest_directories=nest_directories, clobber=clobber)
 
 
 class CatalogPosterior:
@@ -469,6 +474,14 @@ def fit_stars_gpu(catalog: StarCatalog, ic, indices, N=1, nwalkers=32, nburn=150
     pos, lnp, failed = initial_positions(post, nwalkers, rng_seed=seed)
     _mark("initial_positions")
     good = ~failed
+    if not bool(good.any()):
+        # no star of the batch found a start point: nothing to sample, every row reports ok = 0
+        post.close()
+        out = np.full((post.n_models, 3 * D + 3), np.nan)
+        out[:, 3 * D + 2] = 0.0
+        if return_chains:
+            raise ValueError("no star of the batch has a start point with a finite lnpost")
+        return out
     # failed stars get a copy of a good star's walkers so the batch stays rectangular
     if bool(failed.any()) and bool(good.any()):
         src = int(torch.nonzero(good)[0])
@@ -532,14 +545,42 @@ def fit_stars_gpu(catalog: StarCatalog, ic, indices, N=1, nwalkers=32, nburn=150
     return out
 
 
-def fit_catalog(catalog: StarCatalog, ic, N=1, fit_fn=None, checkpoint_dir=None, **fit_kwargs):
+def _shard_fingerprint(catalog, mine, N, fit_kwargs):
+    """Digest of everything a stored shard depends on: the stars' names and measurements, the multiplicity and the
+    fit settings (walkers, steps, seed, model keywords, prior settings)."""
+    import hashlib
+    h = hashlib.sha256()
+    sub = catalog.df.iloc[mine]
+    h.update(repr([str(x) for x in sub.index]).encode())
+    for c in sorted(str(c) for c in catalog.df.columns):
+        col = sub[c]
+        try:
+            h.update(c.encode() + np.ascontiguousarray(col.to_numpy(dtype=float)).tobytes())
+        except (TypeError, ValueError):
+            h.update(c.encode() + repr(list(col)).encode())
+    h.update(repr((int(N), tuple(catalog.bands), tuple(catalog.props))).encode())
+    h.update(repr(sorted((k, repr(v)) for k, v in fit_kwargs.items() if k != "timings")).encode())
+    from .priors import prior_to_spec
+    h.update(repr(sorted((k, repr(prior_to_spec(v))) for k, v in catalog._prior_settings.items())).encode())
+    return h.hexdigest()
+
+
+def fit_catalog(catalog: StarCatalog, ic, N=1, fit_fn=None, checkpoint_dir=None, strict=False, **fit_kwargs):
     """Shard the catalog over the ranks of the default process group (star i -> rank (i+1) % P),
     fit every shard with ``fit_fn`` (default: :func:`fit_stars_gpu`) and all-gather the per-star
     result rows.  Returns a DataFrame indexed like ``catalog.df`` on every rank.
 
+    Failure isolation: a rank whose shard cannot be fitted (an exception in ``fit_fn``) contributes NaN rows with
+    ``ok = 0`` and still takes part in every collective, so the other ranks' stars are not lost and nobody waits for
+    a rank that has left; the error texts come back in ``result.attrs["shard_errors"]`` ({rank: message}) with a
+    RuntimeWarning on every rank - or, with ``strict=True``, as a RuntimeError raised on every rank after the
+    exchange.  (The reference wraps each star's fit in try/except, isochrones/starfit.py:155-159.)
+
     ``checkpoint_dir``: every rank stores its finished shard there (``shard_{rank}of{world}.npz``)
-    and a rerun with the same catalog and sharding loads it instead of refitting — the reference's
-    "skip stars whose results already exist" (isochrones/starfit.py:66-77)."""
+    and a rerun loads it instead of refitting - the reference's "skip stars whose results already exist"
+    (isochrones/starfit.py:66-77).  A stored shard is reused only if the stars, their measurements and the fit
+    settings are the ones it was made with (a digest of all of them is stored next to the rows)."""
+    import warnings
     import pandas as pd
     import torch
     import torch.distributed as dist
@@ -549,28 +590,35 @@ def fit_catalog(catalog: StarCatalog, ic, N=1, fit_fn=None, checkpoint_dir=None,
     n = len(catalog)
     mine = shard_indices(n, rank, world)
     fit_fn = fit_fn or fit_stars_gpu
-    rows = None
-    ckpt = None
-    if checkpoint_dir is not None:
-        import os
-        os.makedirs(checkpoint_dir, exist_ok=True)
-        ckpt = os.path.join(checkpoint_dir, "shard_%dof%d.npz" % (rank, world))
-        if os.path.exists(ckpt):
-            try:
-                z = np.load(ckpt, allow_pickle=False)
-                if (np.array_equal(z["indices"], mine) and int(z["N"]) == N
-                        and list(z["names"]) == [str(x) for x in catalog.df.index[mine]]):
-                    rows = z["rows"]
-            except Exception:
-                rows = None
-    if rows is None:
-        rows = np.asarray(fit_fn(catalog, ic, mine, N=N, **fit_kwargs), dtype=np.float64)
-        if ckpt is not None:
-            tmp = ckpt + ".tmp.npz"
-            np.savez(tmp, indices=mine, rows=rows, N=N, names=np.array([str(x) for x in catalog.df.index[mine]]))
-            os.replace(tmp, ckpt)
-    width = rows.shape[1] if rows.size else 3 * (N + 4) + 3
+    width = 3 * (N + 4) + 3
+    rows, ckpt, error = None, None, None
+    try:
+        if checkpoint_dir is not None:
+            import os
+            os.makedirs(checkpoint_dir, exist_ok=True)
+            ckpt = os.path.join(checkpoint_dir, "shard_%dof%d.npz" % (rank, world))
+            digest = _shard_fingerprint(catalog, mine, N, fit_kwargs)
+            if os.path.exists(ckpt):
+                try:
+                    with np.load(ckpt, allow_pickle=False) as z:
+                        if np.array_equal(z["indices"], mine) and str(z["digest"]) == digest:
+                            rows = z["rows"]
+                except Exception:
+                    rows = None
+        if rows is None:
+            rows = np.asarray(fit_fn(catalog, ic, mine, N=N, **fit_kwargs), dtype=np.float64)
+            if rows.shape != (len(mine), width):
+                raise ValueError("fit_fn returned rows of shape %s, expected %s" % (rows.shape, (len(mine), width)))
+            if ckpt is not None:
+                tmp = ckpt + ".tmp.npz"
+                np.savez(tmp, indices=mine, rows=rows, digest=np.array(digest))
+                os.replace(tmp, ckpt)
+    except Exception as e:           # noqa: BLE001 - this rank's stars are lost, the job is not
+        error = "%s: %s" % (type(e).__name__, e)
+        rows = np.full((len(mine), width), np.nan)
+        rows[:, -1] = 0.0
     full = np.full((n, width), np.nan)
+    errors = {}
     if distributed:
         cap = (n + world - 1) // world + 1                       # fixed-size exchange buffers
         backend = dist.get_backend()
@@ -584,10 +632,22 @@ def fit_catalog(catalog: StarCatalog, ic, N=1, fit_fn=None, checkpoint_dir=None,
             g = g.cpu().numpy()
             ok = np.isfinite(g[:, 0])
             full[g[ok, 0].astype(int)] = g[ok, 1:]
+        texts = [None] * world
+        dist.all_gather_object(texts, error)
+        errors = {r: t for r, t in enumerate(texts) if t is not None}
     else:
         full[mine] = rows
+        if error is not None:
+            errors = {0: error}
+    if errors:
+        msg = "fit_catalog: shard(s) failed - " + "; ".join("rank %d: %s" % kv for kv in sorted(errors.items()))
+        if strict:
+            raise RuntimeError(msg)
+        warnings.warn(msg, RuntimeWarning)
     names = (ic.param_names if N == 1 else tuple(["eep_%d" % i for i in range(N)] + list(ic.param_names[1:])))
-    return pd.DataFrame(full, index=catalog.df.index, columns=result_columns(names))
+    out = pd.DataFrame(full, index=catalog.df.index, columns=result_columns(names))
+    out.attrs["shard_errors"] = errors
+    return out
 
 
 def synthetic_catalog(ic, n_stars, bands=None, seed=0, mag_unc=0.02, with_parallax=True, device=None):

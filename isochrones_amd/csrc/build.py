@@ -37,12 +37,38 @@ def _newer(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+STAMP = os.path.join(HERE, "libiso_hip.stamp")
+
+
+def source_digest() -> str:
+    """sha256 over every source, header, the flags and this script: what the library was built from.  File times
+    are not trusted for the up-to-date test (a checkout or a snapshot copy resets them); the digest stored next to
+    the library is."""
+    import hashlib
+    h = hashlib.sha256()
+    h.update(repr(FLAGS).encode())
+    for path in sources() + HEADERS + [os.path.abspath(__file__)]:
+        h.update(os.path.basename(path).encode() + b"\0")
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def built_digest():
+    try:
+        return open(STAMP).read().strip()
+    except OSError:
+        return None
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
-    me = os.path.abspath(__file__)
-    if not force and not verbose and not _newer(OUT, sources() + HEADERS + [me]):
-        return OUT                       # library newer than every source: nothing to do
+    digest = source_digest()
+    if not force and not verbose and os.path.exists(OUT) and built_digest() == digest:
+        return OUT                       # the library was built from exactly these sources: nothing to do
     os.makedirs(OBJDIR, exist_ok=True)
     cc = hipcc()
+    me = os.path.abspath(__file__)
+    stale = built_digest() != digest     # objects of another source state are only reused when their times say so
     jobs = []
     objs = []
     for src in sources():
@@ -56,8 +82,10 @@ def build(force: bool = False, verbose: bool = False) -> str:
             for rc in ex.map(lambda c: subprocess.run(c, cwd=HERE).returncode, jobs):
                 if rc != 0:
                     raise RuntimeError("hipcc failed")
-    if force or jobs or _newer(OUT, objs):
+    if force or jobs or stale or _newer(OUT, objs):
         subprocess.check_call([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs, cwd=HERE)
+    with open(STAMP, "w") as f:
+        f.write(digest + "\n")
     return OUT
 
 

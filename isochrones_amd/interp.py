@@ -30,6 +30,8 @@ class DFInterpolator:
         self.filename = filename
         self.is_full = is_full
         self._handles = {}          # device index -> iso_table*
+        self._generation = 0        # bumped whenever device tables are freed: dependants compare generations, not
+                                    # pointer values (a new table often lands on the address of the freed one)
         if df is not None:
             self.columns = list(df.columns)
             self.index_columns = tuple(np.array(l, dtype=float) for l in df.index.levels)
@@ -109,6 +111,7 @@ class DFInterpolator:
         for h in self._handles.values():
             _cabi.lib().iso_table_destroy(h)
         self._handles = {}
+        self._generation += 1
 
     def __del__(self):
         try:

@@ -94,6 +94,7 @@ class ModelGridInterpolator:
             self.eep_bounds = tuple(eep_bounds)
         self._handles = {}
         self._handle_tables = {}
+        self._generation = 0        # bumped whenever an iso_ic is destroyed (models bound to it rebuild)
         ci = model_grid.interp.column_index
         missing = [c for c in ("Teff", "logg", "feh", "Mbol") if c not in ci]
         if missing:
@@ -152,8 +153,10 @@ class ModelGridInterpolator:
         mg = self.model_grid.interp.handle(device)
         bc = self.bc_grid.interp.handle(device)
         h = self._handles.get(device)
-        if h is not None and self._handle_tables.get(device) != (mg.value, bc.value):
+        tables = (self.model_grid.interp._generation, self.bc_grid.interp._generation)
+        if h is not None and self._handle_tables.get(device) != tables:
             _cabi.lib().iso_ic_destroy(h)      # a table was rebuilt (add_column): rebind
+            self._generation += 1
             h = None
         if h is None:
             ctx = dev.context(device)
@@ -163,7 +166,7 @@ class ModelGridInterpolator:
             h = C.c_void_p()
             _cabi.check(_cabi.lib().iso_ic_create(ctx, mg, bc, self.kind, cols, pcols, acols, C.byref(h)))
             self._handles[device] = h
-            self._handle_tables[device] = (mg.value, bc.value)
+            self._handle_tables[device] = tables
         return h
 
     def release(self):
@@ -171,6 +174,7 @@ class ModelGridInterpolator:
             _cabi.lib().iso_ic_destroy(h)
         self._handles = {}
         self._handle_tables = {}
+        self._generation = getattr(self, "_generation", 0) + 1
         for h in getattr(self, "_eep_handles", {}).values():
             _cabi.lib().iso_eep_table_destroy(h)
         self._eep_handles = {}

@@ -398,43 +398,46 @@ class ObservationTree:
         return list({n.observation.band for n in self.obs_nodes()})
 
     # -- extra measurements -----------------------------------------------------------------
-    def _check_label(self, label):
+    def _pair_for(self, what, label, name, value, second):
+        """Shared validation of the per-star constraints: a known model star, one of the spectroscopic
+        properties, and a 2-sequence."""
         if label not in self.leaf_labels:
-            raise ValueError("No model node named {} (must be in {}). Maybe define models first?".format(
+            raise ValueError("there is no model star {!r}; the tree's stars are {} (call define_models first)".format(
                 label, self.leaf_labels))
+        if name not in self.spec_props:
+            raise ValueError("{} takes {}, not {!r}".format(what, " / ".join(self.spec_props), name))
+        try:
+            first, other = value
+        except (TypeError, ValueError):
+            raise ValueError("{}: {} needs a (value, {}) pair, got {!r}".format(what, name, second, value)) from None
+        return first, other
 
     def add_spectroscopy(self, label="0_0", **props):
-        self._check_label(label)
-        for k, v in props.items():
-            if k not in self.spec_props:
-                raise ValueError("Illegal property {} (only {} allowed).".format(k, self.spec_props))
-            if len(v) != 2:
-                raise ValueError("Must provide (value, uncertainty) for {}.".format(k))
-        self.spectroscopy.setdefault(label, {}).update(props)
+        """Teff / logg / feh measurements ``(value, uncertainty)`` of one model star (reference: observation.py:1029-1053)."""
+        checked = {k: tuple(self._pair_for("add_spectroscopy", label, k, v, "uncertainty")) for k, v in props.items()}
+        self.spectroscopy.setdefault(label, {}).update(checked)
 
     def add_limit(self, label="0_0", **props):
-        self._check_label(label)
+        """Hard ``(min, max)`` limits on Teff / logg / feh of one model star; ``None`` leaves a side open
+        (reference: observation.py:1055-1078)."""
         for k, v in props.items():
-            if k not in self.spec_props:
-                raise ValueError("Illegal property {} (only {} allowed).".format(k, self.spec_props))
-            if len(v) != 2:
-                raise ValueError("Must provide (min, max) for {}. (`None` is allowed value)".format(k))
-            lo, hi = v
+            lo, hi = self._pair_for("add_limit", label, k, v, "maximum")
             self.limits.setdefault(label, {})[k] = (-np.inf if lo is None else lo, np.inf if hi is None else hi)
 
-    def add_parallax(self, plax, system=0):
-        if len(plax) != 2:
-            raise ValueError("Must enter (value,uncertainty).")
+    def _system_pair(self, what, value, system):
         if system not in self.systems:
-            raise ValueError("{} not in systems ({}).".format(system, self.systems))
-        self.parallax[system] = tuple(plax)
+            raise ValueError("{}: system {!r} is not one of {}".format(what, system, self.systems))
+        try:
+            val, unc = value
+        except (TypeError, ValueError):
+            raise ValueError("{} needs a (value, uncertainty) pair, got {!r}".format(what, value)) from None
+        return (val, unc)
+
+    def add_parallax(self, plax, system=0):
+        self.parallax[system] = self._system_pair("add_parallax", plax, system)
 
     def add_AV(self, AV, system=0):
-        if len(AV) != 2:
-            raise ValueError("Must enter (value,uncertainty).")
-        if system not in self.systems:
-            raise ValueError("{} not in systems ({}).".format(system, self.systems))
-        self.AV[system] = tuple(AV)
+        self.AV[system] = self._system_pair("add_AV", AV, system)
 
     # -- the flat program -------------------------------------------------------------------
     def program(self, bands=None):

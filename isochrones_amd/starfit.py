@@ -207,3 +207,28 @@ def _batch_starfit_device(folders, multiplicities=("single",), models="mist", in
             logger.error("starfit calculation failed for %s: %s", folder, e)
             out[folder] = e
     return out
+
+
+def write_catalog_ini(catalog, ic=None, root=".", N=1, nest_directories=True, clobber=True):
+    """Lay a catalog out as the folder tree ``starfit`` / ``batch_starfit`` walk: ``<root>/[<prefix>/]<star>/star.ini``
+    (reference: StarCatalog.write_ini, catalog.py:141-158).  With ``nest_directories`` the stars are grouped under the
+    leading characters of their names, one character per factor of 100 stars, so no directory grows beyond a few
+    hundred entries.  ``clobber`` removes a star's existing folder (and whatever was fitted in it) first.  Returns the
+    absolute star folders in catalog order."""
+    import shutil
+    prefix_len = 0
+    size = len(catalog)
+    while nest_directories and size >= 100:
+        size //= 100
+        prefix_len += 1
+    folders = []
+    for mod in catalog.iter_models(ic, N=N):
+        name = str(mod.name)
+        parent = os.path.join(root, name[:prefix_len]) if nest_directories else root
+        target = os.path.abspath(os.path.join(parent, name))
+        if clobber and os.path.isdir(target):
+            shutil.rmtree(target)
+        mod.write_ini(root=parent)
+        folders.append(target)
+    return folders
+

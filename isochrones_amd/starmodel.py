@@ -455,7 +455,7 @@ class BasicStarModel(_NestedFitMixin, _ConvenienceMixin):
         ich = self.ic.handle(device)
         h = self._handles.get(device)
         state = _prior_state(self._priors)
-        if h is not None and (self._handle_ic.get(device) != ich.value or self._handle_state.get(device) != state):
+        if h is not None and (self._handle_ic.get(device) != self.ic._generation or self._handle_state.get(device) != state):
             _cabi.lib().iso_model_destroy(h)   # the interpolator was rebound / a shared prior object changed: rebuild
             self._handles.pop(device, None)
             h = None
@@ -467,7 +467,7 @@ class BasicStarModel(_NestedFitMixin, _ConvenienceMixin):
             h = C.c_void_p()
             _cabi.check(_cabi.lib().iso_model_create(ich, C.byref(desc), C.byref(h)))
             self._handles[device] = h
-            self._handle_ic[device] = ich.value
+            self._handle_ic[device] = self.ic._generation
             self._handle_state[device] = _prior_state(self._priors)       # packing may have snapped bounds
         return h
 
@@ -1044,7 +1044,7 @@ class TreeStarModel(_NestedFitMixin, _ConvenienceMixin):
         ich = self.ic.handle(device)
         h = self._handles.get(device)
         state = _prior_state(self._priors)
-        if h is not None and (self._handle_ic.get(device) != ich.value or self._handle_state.get(device) != state):
+        if h is not None and (self._handle_ic.get(device) != self.ic._generation or self._handle_state.get(device) != state):
             _cabi.lib().iso_tree_model_destroy(h)
             self._handles.pop(device, None)
             h = None
@@ -1053,7 +1053,7 @@ class TreeStarModel(_NestedFitMixin, _ConvenienceMixin):
             h = C.c_void_p()
             _cabi.check(_cabi.lib().iso_tree_model_create(ich, C.byref(desc), C.byref(h)))
             self._handles[device] = h
-            self._handle_ic[device] = ich.value
+            self._handle_ic[device] = self.ic._generation
             self._handle_state[device] = _prior_state(self._priors)
         return h
 

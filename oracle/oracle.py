@@ -12,7 +12,8 @@ import numpy as np
 from isochrones_amd import _cabi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIBPATH = os.path.join(_HERE, "libiso_oracle.so")
+# ISO_ORACLE_LIB: load another build of the same sources (the sanitizer build of tests/test_oracle_sanitizers.py)
+_LIBPATH = os.environ.get("ISO_ORACLE_LIB") or os.path.join(_HERE, "libiso_oracle.so")
 _lib = None
 
 ORC_MAX_DIM = 4
@@ -41,7 +42,7 @@ class _IC(C.Structure):
 def build(force=False):
     src = os.path.join(_HERE, "iso_oracle.c")
     if force or not os.path.exists(_LIBPATH) or os.path.getmtime(_LIBPATH) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-s", "-C", _HERE, "-B", "libiso_oracle.so"])
+        subprocess.check_call(["make", "-s", "-C", _HERE, "-B", os.path.basename(_LIBPATH)])
     return _LIBPATH
 
 

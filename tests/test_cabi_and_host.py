@@ -31,6 +31,14 @@ def test_header_symbols_exported(built_lib):
     assert b"isochrones_amd" in lib.iso_version()
 
 
+def test_library_was_built_from_the_sources_in_the_tree(built_lib):
+    """The digest stored next to libiso_hip.so is the digest of the sources, headers and flags in the tree: a stale
+    prebuilt binary cannot pass for a fresh build (file times are not consulted)."""
+    from isochrones_amd.csrc import build as hip_build
+    assert hip_build.built_digest() == hip_build.source_digest()
+    assert os.path.getsize(built_lib) > 1 << 20
+
+
 def test_struct_layout_matches_header(built_lib):
     """ctypes mirror vs the C compiler's layout of iso_prior / iso_model_desc."""
     import subprocess, tempfile

@@ -672,3 +672,14 @@ def test_lnpost_on_mass_age_feh_distance_av_samples():
     want = fx.make_oracle_ic(ic).lnpost(mod.model_desc(), np.ascontiguousarray(np.stack([mass, eep_cpu, feh, dist, AV])))[0]
     fx.assert_close(got, want, RTOL, atol=ATOL, what="lnpost of (mass, age, feh, distance, AV) samples")
     assert np.isfinite(want).sum() > 20_000 and np.isneginf(want).sum() > 1000
+
+
+def test_gpu_box_runs_the_library_built_from_these_sources():
+    """The prebuilt libiso_hip.so that travelled to the GPU box carries the digest of exactly the sources next to
+    it (isochrones_amd/csrc/build.py: source_digest), and it is the file this process has mapped."""
+    from isochrones_amd import _cabi
+    from isochrones_amd.csrc import build as hip_build
+    assert hip_build.built_digest() == hip_build.source_digest()
+    _cabi.lib()
+    assert os.path.realpath(_cabi.library_path()) in {os.path.realpath(l.split()[-1]) for l in open("/proc/self/maps")
+                                                      if "libiso_hip.so" in l}

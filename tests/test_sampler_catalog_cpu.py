@@ -221,6 +221,85 @@ def test_fit_catalog_checkpoint_resume(tmp_path):
     assert calls == [9, 7]
 
 
+def test_fit_catalog_checkpoint_depends_on_settings_and_data(tmp_path):
+    """A stored shard is reused only for the same stars, measurements and fit settings."""
+    import pandas as pd
+    df = pd.DataFrame({"V_mag": np.linspace(8, 12, 6), "V_mag_unc": 0.02}, index=["s%d" % i for i in range(6)])
+    calls = []
+
+    def fake_fit(catalog, ic, indices, N=1, **kw):
+        calls.append(dict(kw))
+        return np.zeros((len(indices), 3 * (N + 4) + 3))
+
+    run = lambda frame, **kw: ia.fit_catalog(ia.StarCatalog(frame, bands=["V"]), ic=None_IC(), fit_fn=fake_fit,
+                                             checkpoint_dir=str(tmp_path), **kw)
+    run(df, nwalkers=32, niter=100, seed=1)
+    run(df, nwalkers=32, niter=100, seed=1)
+    assert len(calls) == 1                                    # reused
+    run(df, nwalkers=32, niter=100, seed=2)                   # other seed
+    run(df, nwalkers=64, niter=100, seed=2)                   # other walker count
+    df2 = df.copy()
+    df2.loc["s3", "V_mag"] += 0.01                            # a measurement changed
+    run(df2, nwalkers=64, niter=100, seed=2)
+    assert len(calls) == 4
+    run(df2, nwalkers=64, niter=100, seed=2)
+    assert len(calls) == 4
+
+
+def _failing_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import warnings
+    import pandas as pd
+    import torch.distributed as dist
+    import isochrones_amd as ia_
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n = 9
+    df = pd.DataFrame({"V_mag": np.linspace(8, 12, n), "V_mag_unc": 0.02}, index=["s%03d" % i for i in range(n)])
+    cat = ia_.StarCatalog(df, bands=["V"])
+
+    def fit(catalog, ic, indices, N=1, **kw):
+        if rank == 1:
+            raise ValueError("no star of the batch has all of the catalog's bands")
+        rows = np.ones((len(indices), 3 * (N + 4) + 3))
+        rows[:, 0] = np.asarray(indices)
+        return rows
+
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        res = ia_.fit_catalog(cat, ic=None_IC(), fit_fn=fit)
+    assert any("rank 1" in str(x.message) for x in w)
+    res.to_pickle(os.path.join(out_dir, "res%d.pkl" % rank))
+    with open(os.path.join(out_dir, "err%d.txt" % rank), "w") as f:
+        f.write(repr(res.attrs["shard_errors"]))
+    try:
+        ia_.fit_catalog(cat, ic=None_IC(), fit_fn=fit, strict=True)
+        raised = False
+    except RuntimeError as e:
+        raised = "rank 1" in str(e)
+    with open(os.path.join(out_dir, "strict%d.txt" % rank), "w") as f:
+        f.write(str(raised))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_fit_catalog_a_failing_rank_does_not_hang_the_others(tmp_path):
+    """One rank's fit raises: it still enters the all-gather with NaN / ok = 0 rows, the other rank's stars arrive,
+    every rank sees the error text; strict=True raises on every rank after the exchange."""
+    import pandas as pd
+    import torch.multiprocessing as mp
+    mp.spawn(_failing_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = pd.read_pickle(tmp_path / "res0.pkl"), pd.read_pickle(tmp_path / "res1.pkl")
+    assert r0.equals(r1)
+    owner = (np.arange(9) + 1) % 2
+    assert np.array_equal(r0["ok"].values, (owner == 0).astype(float))
+    assert np.isnan(r0.iloc[owner == 1, :-1].values).all() and np.array_equal(r0.iloc[owner == 0, 0].values, np.flatnonzero(owner == 0))
+    for r in (0, 1):
+        assert "no star of the batch" in open(tmp_path / ("err%d.txt" % r)).read()
+        assert open(tmp_path / ("strict%d.txt" % r)).read() == "True"
+
+
 def _bcast_worker(rank, world, port, out_dir):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
