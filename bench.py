@@ -41,6 +41,49 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BYTES_PER_EVAL_SINGLE_1BAND = 8 * 6 * 8 + 16 * 1 * 8 + 6 * 8
 
 
+_PMC = None
+
+
+def pmc_record(label, n):
+    """Per-launch PMC figures of a workload from profiles/pmc_traffic.json (measured beforehand with
+    tools/pmc_collect.sh; None if absent or taken at another batch size)."""
+    global _PMC
+    if _PMC is None:
+        try:
+            _PMC = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        except Exception:
+            _PMC = {}
+    rec = _PMC.get(label)
+    return rec if isinstance(rec, dict) and rec.get("n") == n else None
+
+
+def bounds(label, n, kernel_ms, algorithmic_bytes):
+    """What bounds a launch: the larger of (a) the memory side - L2-miss ("fabric") bytes per launch from the PMC passes
+    over the HBM peak - and (b) VALU issue - busy cycles per SIMD from the PMC passes over the cycles of this launch.
+    Kernel time is measured in this run; the counter values are static (separate rocprofv3 --pmc passes cannot run
+    inside a timed region) and say so.  `frac` is at most 1 by construction for the VALU bound (busy cycles cannot
+    exceed elapsed cycles) and for the memory bound as long as the misses are served by HBM; traffic served by the
+    Infinity Cache can exceed the HBM peak, which would show as frac > 1 and mean "cache-resident"."""
+    t = kernel_ms * 1e-3
+    out = {"algorithmic_GBs": algorithmic_bytes / t / 1e9, "kernel_ms": kernel_ms}
+    rec = pmc_record(label, n)
+    if rec is None:
+        out.update(bound=None, frac=None, note="no PMC record for this workload / batch size")
+        return out
+    hbm = rec["fabric_bytes"] / t / 1e9
+    valu = rec["valu_busy_cycles_per_simd"] / (t * rec["effective_clock_GHz"] * 1e9)
+    out.update(hbm={"achieved": hbm, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm / HBM_PEAK_GBS,
+                    "traffic": rec["fabric_bytes"], "traffic_over_algorithmic": rec["fabric_bytes"] / algorithmic_bytes,
+                    "l2_hit_rate": rec.get("l2_hit_rate")},
+               valu={"busy_cycles_per_simd": rec["valu_busy_cycles_per_simd"], "clock_GHz": rec["effective_clock_GHz"],
+                     "frac": valu, "insts_per_wave": rec.get("valu_insts_per_wave")},
+               source="static: profiles/pmc_traffic.json <- profiles/r02/pmc_summary.json (rocprofv3 --pmc passes, "
+                      "FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; SQ_ACTIVE_INST_VALU x4 / 1024 SIMDs); kernel time: this run")
+    out["bound"] = "hbm" if hbm / HBM_PEAK_GBS >= valu else "valu"
+    out["frac"] = max(hbm / HBM_PEAK_GBS, valu)
+    return out
+
+
 def make_samples(rng, n, workload):
     """[n, 5] float64 (mass, eep, feh, distance, AV) rows."""
     if workload == "prior":
@@ -284,15 +327,8 @@ def main():
     value = total_evals / elapsed
     bytes_per_launch = BYTES_PER_EVAL_SINGLE_1BAND * args.n
     achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
-    traffic = None
-    pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc_file):
-        try:
-            rec = json.load(open(pmc_file))
-            key = "%s_n%d" % (args.workload, args.n)
-            traffic = rec.get(key, {}).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+    rec = pmc_record("cfg2/%s" % args.workload, args.n)
+    traffic = rec["fabric_bytes"] if rec else None
 
     result = {
         "metric": "lnpost evals/sec over MIST grid (10^6-sample batch)",
@@ -318,7 +354,8 @@ def main():
                      "traffic_source": ("static: profiles/pmc_traffic.json (rocprofv3 --pmc passes of this command, "
                                         "FETCH_SIZE/WRITE_SIZE with the gfx950 corrections; not measured in this run)"
                                         if traffic is not None else None),
-                     "kernel_ms": kernel_ms, "bytes_per_eval": BYTES_PER_EVAL_SINGLE_1BAND},
+                     "kernel_ms": kernel_ms, "bytes_per_eval": BYTES_PER_EVAL_SINGLE_1BAND,
+                     "bounds": bounds("cfg2/%s" % args.workload, args.n, kernel_ms, bytes_per_launch)},
     }
     if world == 1 and not args.no_extras:
         # secondary workloads, same kernel, same launch count/3 (reported, never `value`)
@@ -333,9 +370,30 @@ def main():
                 _cabi.check(lib.iso_time_lnpost(handle, dev.ptr(pt), 1, args.n, args.n, dev.ptr(o2), reps, stream,
                                                 C.byref(ms)))
             extras[wl] = {"kernel_ms": ms.value, "evals_per_s": args.n / (ms.value * 1e-3),
-                          "algorithmic_GBs": BYTES_PER_EVAL_SINGLE_1BAND * args.n / (ms.value * 1e-3) / 1e9,
-                          "finite_fraction": float(torch.isfinite(o2).double().mean())}
+                          "finite_fraction": float(torch.isfinite(o2).double().mean()),
+                          "roofline": bounds("cfg2/" + wl, args.n, ms.value, BYTES_PER_EVAL_SINGLE_1BAND * args.n)}
+            del pt, o2
         result["other_workloads"] = extras
+        # BASELINE configs[2]: binary (two-component flux sum), 6 bands + parallax, isochrone parametrisation, full-size
+        # tables - kernel k_lnpost_fast<1, 2, 6, ...>, 2 360 algorithmic B/eval
+        try:
+            import bench_configs
+            ic3, mod3, sets3 = bench_configs.cfg3_model_and_samples(args.n)
+            h3 = mod3.handle(local_rank)
+            cfg3 = {"bytes_per_eval": 2360, "kernel": "k_lnpost_fast<ISO, 2 stars, 6 bands, packed>"}
+            for wl, ph in sets3.items():
+                pt = torch.as_tensor(np.ascontiguousarray(ph.T), device="cuda")
+                o3 = torch.empty(args.n, dtype=torch.float64, device="cuda")
+                for reps in (5, max(10, args.steps // 4)):
+                    _cabi.check(lib.iso_time_lnpost(h3, dev.ptr(pt), 1, args.n, args.n, dev.ptr(o3), reps, stream, C.byref(ms)))
+                cfg3[wl] = {"kernel_ms": ms.value, "evals_per_s": args.n / (ms.value * 1e-3),
+                            "finite_fraction": float(torch.isfinite(o3).double().mean()),
+                            "roofline": bounds("cfg3/" + wl, args.n, ms.value, 2360.0 * args.n)}
+                del pt, o3
+            result["cfg3_binary_6_bands"] = cfg3
+            del mod3, ic3, sets3
+        except Exception as e:       # noqa: BLE001 - a secondary leg must not take the benchmark line down
+            result["cfg3_binary_6_bands"] = {"error": "%s: %s" % (type(e).__name__, e)}
         # end to end through the host-array API (numpy in, numpy out: H2D of 40 B + D2H of 8 B per sample
         # around the same kernel) - reported for the record, never `value`
         mod.lnpost(pars_host[:1000])

@@ -67,15 +67,16 @@ def cfg1():
             "reference_published_us_per_call": 69.0, "note": "published: notebooks/Overview.ipynb:738 (laptop, numba)"}
 
 
-def cfg3(n=1_000_000, reps=100):
-    import torch
+def cfg3_model_and_samples(n=1_000_000, seed=3):
+    """BASELINE configs[2]: binary, 6 bands + parallax on the full-size isochrone table, and its three sample
+    distributions [n, 6] (eep_0, eep_1, age, feh, distance, AV)."""
     import isochrones_amd as ia
     bands = ("J", "H", "K", "BP", "RP", "G")
     ic = ia.synthetic_isochrone(bands=bands)
     mod = ia.BinaryStarModel(ic, J=(9.3, 0.02), H=(9.0, 0.02), K=(8.95, 0.02), BP=(10.7, 0.002), RP=(9.8, 0.002),
                              G=(10.3, 0.001), parallax=(2.0, 0.05))
-    rng = np.random.default_rng(3)
-    out = {}
+    rng = np.random.default_rng(seed)
+    sets = {}
     for workload in ("prior", "prior_valid", "posterior"):
         if workload == "prior_valid":
             # uniform over the populated part of the isochrone table: both components always reach
@@ -96,6 +97,15 @@ def cfg3(n=1_000_000, reps=100):
             w = np.array([10.0, 10.0, 0.1, 0.1, 10.0, 0.05])
             pars = c + w * rng.standard_normal((n, 6))
             pars[:, 5] = np.abs(pars[:, 5])
+        sets[workload] = pars
+    return ic, mod, sets
+
+
+def cfg3(n=1_000_000, reps=100):
+    import torch
+    ic, mod, sets = cfg3_model_and_samples(n)
+    out = {}
+    for workload, pars in sets.items():
         pt = torch.as_tensor(np.ascontiguousarray(pars.T), device="cuda")
         ms, res = _time_kernel(mod, pt, reps)
         oic = _oracle_ic(ic)
@@ -304,10 +314,9 @@ def primitives(n=1_000_000, reps=20):
     return {"config": "primitives", "metric": "batch API primitives, 1e6 samples (includes output allocation)", **out}
 
 
-def tree(n=1_000_000, reps=20):
-    """Generic observation-tree model (docs/multiple.ipynb resolved binary: 3 unresolved bands +
-    a resolved relative K image, 2 stars in one system); reference: 1.23 ms per lnpost call."""
-    import torch
+def tree_model_and_samples(n=1_000_000):
+    """Generic observation-tree model (docs/multiple.ipynb resolved binary: 3 unresolved bands + a resolved relative
+    K image, 2 stars in one system) and a posterior-like [n, 6] sample batch."""
     import isochrones_amd as ia
     from isochrones_amd.observation import Observation, ObservationTree, Source
     ic = ia.synthetic_isochrone(bands=("J", "H", "K"))
@@ -326,6 +335,14 @@ def tree(n=1_000_000, reps=20):
     pars = c + w * rng.standard_normal((n, 6))
     pars[:, :2] = -np.sort(-pars[:, :2], axis=1)
     pars[:, 5] = np.abs(pars[:, 5])
+    return mod, pars
+
+
+def tree(n=1_000_000, reps=20):
+    """Generic observation-tree model (docs/multiple.ipynb resolved binary); reference: 1.23 ms per lnpost call."""
+    import torch
+    mod, pars = tree_model_and_samples(n)
+    ic = mod.ic
     pt = torch.as_tensor(pars, device="cuda")
     out = mod.lnpost(pt); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -278,9 +278,16 @@ int  iso_tree_lnpost_host(iso_tree_model* m, const double* pars, int64_t n, doub
  * n_ens = 1 for a model, = n_models for a catalog (row = star*W + walker).  The model / catalog
  * handle must outlive the sampler. */
 typedef struct iso_sampler iso_sampler;
+/* layouts of a stored chain */
+#define ISO_CHAIN_ROW_MAJOR    0   /* chain [nsteps][n_ens*W][n_params] (the default; emcee's walker-major rows) */
+#define ISO_CHAIN_PARAM_MAJOR  1   /* chain [nsteps][n_params][n_ens*W]: consecutive walkers store consecutive doubles, and
+                                      the nsteps*W values of an (ensemble, parameter) pair are W contiguous doubles per
+                                      step - the summaries below then fetch every line of the chain once */
 int  iso_sampler_create_model(iso_model* m, int nwalkers, double a, uint64_t seed, iso_sampler** out);
 int  iso_sampler_create_catalog(iso_catalog* c, int nwalkers, double a, uint64_t seed, iso_sampler** out);
 void iso_sampler_destroy(iso_sampler* s);
+/* How iso_sampler_run lays out its `chain` output from now on (chain_lnp is [nsteps][n_ens*W] either way). */
+int  iso_sampler_set_chain_layout(iso_sampler* s, int layout);
 int  iso_sampler_run(iso_sampler* s, double* pos, double* lnp, int nsteps, double* chain, double* chain_lnp,
                      int32_t* accepted, void* stream);
 
@@ -294,6 +301,9 @@ int  iso_sampler_run(iso_sampler* s, double* pos, double* lnp, int nsteps, doubl
  * ISOCHRONES_AMD_QUANTILES=workgroup|sort forces the older forms (tests, A/B runs). */
 int  iso_chain_quantiles(iso_ctx* ctx, const double* chain, int64_t nsteps, int64_t n_ens, int W, int n_params,
                          const double* q, int nq, double* out, void* stream);
+/* The same for a chain stored in `layout` (ISO_CHAIN_ROW_MAJOR = the call above). */
+int  iso_chain_quantiles_layout(iso_ctx* ctx, const double* chain, int layout, int64_t nsteps, int64_t n_ens, int W,
+                                int n_params, const double* q, int nq, double* out, void* stream);
 
 /* Time `reps` back-to-back iso_lnpost launches with hipEvents on `stream`; returns the mean
  * milliseconds per launch in *ms_per_launch (measurement helper for bench.py). */

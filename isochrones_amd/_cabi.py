@@ -15,6 +15,8 @@ ISO_MAX_COLS = 64
 
 KIND_TRACK = 0
 KIND_ISO = 1
+CHAIN_ROW_MAJOR = 0
+CHAIN_PARAM_MAJOR = 1
 
 PRIOR_FLAT = 1
 PRIOR_FLATLOG = 2
@@ -100,7 +102,7 @@ EXPORTED_SYMBOLS = (
     "iso_catalog_create", "iso_catalog_create_columns", "iso_catalog_destroy", "iso_catalog_lnpost",
     "iso_eep_table_create", "iso_eep_table_destroy", "iso_interp_eep", "iso_interp_eep_host",
     "iso_sampler_create_model", "iso_sampler_create_catalog", "iso_sampler_destroy", "iso_sampler_run",
-    "iso_chain_quantiles",
+    "iso_sampler_set_chain_layout", "iso_chain_quantiles", "iso_chain_quantiles_layout",
     "iso_tree_model_create", "iso_tree_model_destroy", "iso_tree_lnpost", "iso_tree_lnpost_host",
 )
 
@@ -184,6 +186,8 @@ def lib():
     L.iso_sampler_destroy.restype = None
     L.iso_sampler_run.argtypes = [vp, pd, pd, C.c_int, pd, pd, pd, vp]
     L.iso_chain_quantiles.argtypes = [vp, pd, i64, i64, C.c_int, C.c_int, C.POINTER(dbl), C.c_int, pd, vp]
+    L.iso_chain_quantiles_layout.argtypes = [vp, pd, C.c_int, i64, i64, C.c_int, C.c_int, C.POINTER(dbl), C.c_int, pd, vp]
+    L.iso_sampler_set_chain_layout.argtypes = [vp, C.c_int]
     L.iso_tree_model_create.argtypes = [vp, C.POINTER(IsoTreeDesc), C.POINTER(vp)]
     L.iso_tree_model_destroy.argtypes = [vp]
     L.iso_tree_model_destroy.restype = None

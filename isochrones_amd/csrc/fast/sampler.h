@@ -29,7 +29,10 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 
 // One stretch move of walker k of the active half of one star's ensemble.  `pos` / `lnp` / `acc_cnt` are
 // that star's [W][NP] / [W] / [W] arrays (global memory in the step-wise kernel, LDS in the persistent
-// one), `chain_pos` / `chain_lnp` its slab of the stored chain for this step (or null).  The Philox
+// one), `chain_pos` / `chain_lnp` its slab of the stored chain for this step (or null): parameter q of its row
+// lr goes to chain_pos[lr * S.chain_rs + q * S.chain_ps] (row-major [rows][NP]: rs = NP, ps = 1; parameter-major
+// [NP][rows]: rs = 1, ps = rows - consecutive walkers then store consecutive doubles and a (star, parameter)
+// pair of the chain is contiguous per step, which is what the summaries read).  The Philox
 // counter is (step, half, global row): both kernels draw identical numbers for a given move.
 template <int KIND, int NS, int NB, bool ASTERO>
 __device__ __forceinline__ void stretch_move(const FastArgs& A, const StretchArgs& S, double* lds, const CoopLds& L,
@@ -75,7 +78,7 @@ __device__ __forceinline__ void stretch_move(const FastArgs& A, const StretchArg
     // chain recording: every move stores the row it owns (its value for this step)
     if (active && chain_pos) {
 #pragma unroll
-        for (int q = 0; q < NP; ++q) chain_pos[lr * NP + q] = acc ? y[q] : xk[q];
+        for (int q = 0; q < NP; ++q) chain_pos[lr * S.chain_rs + q * S.chain_ps] = acc ? y[q] : xk[q];
     }
     if (active && chain_lnp) chain_lnp[lr] = acc ? lnew : lold;
 }
@@ -98,7 +101,7 @@ __global__ __launch_bounds__(BLOCK) void k_stretch_half(const FastArgs A, const 
     const int k = (int)(t - star * h);
     const int64_t r0 = star * S.W;
     stretch_move<KIND, NS, NB, ASTERO>(A, S, lds, L, active, star, k, S.half, S.step, S.pos + r0 * NP, S.lnp + r0,
-                               S.accepted ? S.accepted + r0 : nullptr, S.chain_pos ? S.chain_pos + r0 * NP : nullptr,
+                               S.accepted ? S.accepted + r0 : nullptr, S.chain_pos ? S.chain_pos + r0 * S.chain_rs : nullptr,
                                S.chain_lnp ? S.chain_lnp + r0 : nullptr);
 }
 
@@ -161,7 +164,7 @@ __global__ __launch_bounds__(BLOCK, DENSE ? 3 : 1) void k_stretch_persist(const 
     }
     const int gs = mine ? g : 0;                          // idle lanes shadow a move of the first ensemble
     for (int it = 0; it < S.nsteps; ++it) {
-        double* cp = S.chain_pos ? S.chain_pos + ((int64_t)it * rows_total + r0 + gs * W) * NP : nullptr;
+        double* cp = S.chain_pos ? S.chain_pos + (int64_t)it * rows_total * NP + (r0 + gs * W) * S.chain_rs : nullptr;
         double* cl = S.chain_lnp ? S.chain_lnp + (int64_t)it * rows_total + r0 + gs * W : nullptr;
         for (int half = 0; half < 2; ++half) {
             for (int k0 = 0; k0 < h; k0 += per) {

@@ -549,8 +549,12 @@ int iso_ic_create(iso_ctx* ctx, iso_table* model_grid, iso_table* bc_grid, int k
     for (int d = 0; d < 4; ++d) ic->h_axes_bc[d] = bc_grid->h_axes[d];
     ic->d_hotq = nullptr;
     ic->d_astq = nullptr;
+    ic->g3.hotq = ic->g3.astq = nullptr;
+    ic->g4.tabq = nullptr;
     // (cell indices travel as 32-bit integers through the cooperative gather)
-    if (path_mode() == PATH_AUTO && model_grid->ax[2].uniform && model_grid->ncells < (int64_t(1) << 31) &&
+    // Built for every table the generic kernel can meet as well (non-uniform EEP axis, ISOCHRONES_AMD_PATH=generic):
+    // its lane-per-sample gathers read the same pack.  "compact" keeps every kernel on the compact tables.
+    if (path_mode() != PATH_COMPACT && model_grid->ncells < (int64_t(1) << 31) &&
         bc_grid->ncells < (int64_t(1) << 31)) {
         // corner-packed copy for the fast kernel: 8 corners x 6 columns per cell (384 B)
         e = pack_corners(ic->d_hot, HOT_COLS, PACK_COLS, 3, model_grid->shape, &ic->d_hotq);
@@ -601,7 +605,7 @@ int iso_interp_mag(iso_ic* ic, const double* pars, int64_t stride_n, int64_t str
     A.Teff = Teff; A.logg = logg; A.feh = feh;
     A.mags = nb > 0 ? mags : nullptr;
     DeviceGuard guard(ic->ctx->device);
-    if (nb >= 1 && nb <= 12 && mags && ic->d_hotq && path_mode() == PATH_AUTO) {
+    if (nb >= 1 && nb <= 12 && mags && ic->d_hotq && ic->model->ax[2].uniform && path_mode() == PATH_AUTO) {
         // large batches: corner-packed tables + wave-cooperative gathers (the pack for this band list
         // is built once and kept); small ones are not worth building a pack for
         FastArgs F;
@@ -876,6 +880,29 @@ int iso_model_create(iso_ic* ic, const iso_model_desc* desc, iso_model** out)
             if (!m->fast.astq || (!m->d_bcq && desc->n_bands > 0)) m->fast_ok = false;     // generic kernel
         }
     }
+    if (e == hipSuccess && !m->fast_ok && ic->d_hotq) {
+        // generic kernel: give its lane-per-sample gathers the corner-packed forms too (whole-line reads), whatever
+        // made the model miss the fast path (> 12 bands, non-uniform EEP axis, ISOCHRONES_AMD_PATH=generic)
+        const size_t bcq_bytes = (size_t)ic->bc->ncells * 16 * (size_t)std::max(desc->n_bands, 1) * sizeof(double);
+        if (desc->n_bands > 0 && !m->d_bcq && bcq_bytes <= (size_t(4) << 30)) {
+            hipError_t e2 = pack_corners(m->d_bc_hot, desc->n_bands, desc->n_bands, 4, ic->bc->shape, &m->d_bcq);
+            if (e2 != hipSuccess) {
+                m->d_bcq = nullptr;
+                (void)hipGetLastError();
+            }
+        }
+        if (desc->has_numax) {
+            std::lock_guard<std::mutex> lock(ic->mag_mu);
+            if (!ic->d_astq) {
+                hipError_t e2 = pack_corners(ic->d_hot, HOT_COLS, 2, 3, ic->model->shape, &ic->d_astq, 6);
+                if (e2 != hipSuccess) {
+                    ic->d_astq = nullptr;
+                    (void)hipGetLastError();
+                }
+            }
+        }
+    }
+    m->g4.tabq = (!m->fast_ok && ic->d_hotq) ? m->d_bcq : nullptr;
     if (e != hipSuccess) {
         std::string msg = std::string("iso_model_create: ") + hipGetErrorString(e);
         iso_model_destroy(m);
@@ -956,6 +983,8 @@ int enqueue_lnpost(iso_model* m, const double* pars, int64_t stride_n, int64_t s
     }
     PostArgs A;
     A.g3 = m->ic->g3;
+    A.g3.hotq = m->ic->d_hotq;
+    A.g3.astq = m->ic->d_astq;
     A.g4 = m->g4;
     A.m = m->d_model;
     A.pars = pars;
@@ -1593,6 +1622,7 @@ int sampler_common(iso_sampler* sp, int device, int kind, int n_stars, int n_ban
     sp->seed = seed;
     sp->step = 0;
     sp->multi = multi;
+    sp->chain_layout = ISO_CHAIN_ROW_MAJOR;
     sp->fast = F;
     return ISO_OK;
 }
@@ -1625,6 +1655,15 @@ int iso_sampler_create_catalog(iso_catalog* c, int nwalkers, double a, uint64_t 
 
 void iso_sampler_destroy(iso_sampler* s) { delete s; }
 
+int iso_sampler_set_chain_layout(iso_sampler* s, int layout)
+{
+    if (!s) return fail(ISO_ERR_INVALID, "iso_sampler_set_chain_layout: NULL argument");
+    if (layout != ISO_CHAIN_ROW_MAJOR && layout != ISO_CHAIN_PARAM_MAJOR)
+        return fail(ISO_ERR_INVALID, "iso_sampler_set_chain_layout: unknown layout");
+    s->chain_layout = layout;
+    return ISO_OK;
+}
+
 
 int iso_sampler_run(iso_sampler* sp, double* pos, double* lnp, int nsteps, double* chain, double* chain_lnp,
                     int32_t* accepted, void* stream)
@@ -1645,6 +1684,8 @@ int iso_sampler_run(iso_sampler* sp, double* pos, double* lnp, int nsteps, doubl
     S.n_active = sp->n_ensembles * (sp->W / 2);
     S.a = sp->a;
     S.seed = sp->seed;
+    S.chain_rs = sp->chain_layout == ISO_CHAIN_PARAM_MAJOR ? 1 : sp->n_params;
+    S.chain_ps = sp->chain_layout == ISO_CHAIN_PARAM_MAJOR ? rows : 1;
     // ISOCHRONES_AMD_SAMPLER = auto | persistent | stepwise.  The persistent kernel (one workgroup per
     // ensemble, all iterations in one launch) wins while the catalog is too small for a half-step launch
     // to fill the chip; both forms produce bit-identical chains.
@@ -1713,7 +1754,15 @@ int iso_sampler_run(iso_sampler* sp, double* pos, double* lnp, int nsteps, doubl
 int iso_chain_quantiles(iso_ctx* ctx, const double* chain, int64_t nsteps, int64_t n_ens, int W, int n_params,
                         const double* q, int nq, double* out, void* stream)
 {
+    return iso_chain_quantiles_layout(ctx, chain, ISO_CHAIN_ROW_MAJOR, nsteps, n_ens, W, n_params, q, nq, out, stream);
+}
+
+int iso_chain_quantiles_layout(iso_ctx* ctx, const double* chain, int layout, int64_t nsteps, int64_t n_ens, int W,
+                               int n_params, const double* q, int nq, double* out, void* stream)
+{
     if (!ctx || !chain || !q || !out) return fail(ISO_ERR_INVALID, "iso_chain_quantiles: NULL argument");
+    if (layout != ISO_CHAIN_ROW_MAJOR && layout != ISO_CHAIN_PARAM_MAJOR)
+        return fail(ISO_ERR_INVALID, "iso_chain_quantiles: unknown chain layout");
     if (nsteps < 1 || n_ens < 1 || W < 1 || n_params < 1 || nq < 1 || nq > 8)
         return fail(ISO_ERR_INVALID, "iso_chain_quantiles: counts out of range");
     const int64_t m = nsteps * W;
@@ -1721,6 +1770,9 @@ int iso_chain_quantiles(iso_ctx* ctx, const double* chain, int64_t nsteps, int64
     if (n_ens * n_params > 0x7fffffff) return fail(ISO_ERR_INVALID, "iso_chain_quantiles: too many ensembles");
     QuantArgs A;
     A.chain = chain;
+    A.ss = n_ens * W * n_params;
+    A.rs = layout == ISO_CHAIN_PARAM_MAJOR ? 1 : n_params;
+    A.ps = layout == ISO_CHAIN_PARAM_MAJOR ? n_ens * W : 1;
     A.nsteps = nsteps;
     A.n_ens = n_ens;
     A.W = W;

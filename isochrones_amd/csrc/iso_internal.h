@@ -32,12 +32,15 @@ struct AxisD {
 struct Grid3V {           // packed hot-column model table
     AxisD ax[3];
     const double* hot;    // [n0][n1][n2][HOT_COLS]
+    const double* hotq;   // corner-packed [cell][8 corners x PACK_COLS] (k_pack_corners order), or null
+    const double* astq;   // corner-packed (nu_max, delta_nu) [cell][8 corners x 2], or null
     int64_t s0, s1;       // cell strides of axes 0, 1 (axis 2 stride = 1)
 };
 
 struct Grid4V {           // BC table (all columns, or packed to the model's bands)
     AxisD ax[4];
     const double* tab;    // [nT][ng][nf][nA][ncol]
+    const double* tabq;   // corner-packed [cell][16 corners x ncol] (k_pack_corners order) of the same columns, or null
     int ncol;
     int64_t s0, s1, s2;   // cell strides of axes 0..2 (axis 3 stride = 1)
 };
@@ -127,7 +130,8 @@ struct StretchArgs {
     uint32_t step;
     int nsteps;           // 0: step-wise kernel (one half-step per launch); > 0: persistent kernel, all
                           // iterations in one launch (chain slabs then advance by n_rows per iteration)
-    double* chain_pos;    // optional: this step's [n_rows][n_params] slab of the stored chain
+    int64_t chain_rs, chain_ps;   // element strides of the stored chain between rows / between parameters of a step
+    double* chain_pos;    // optional: this step's [n_rows][n_params] (or [n_params][n_rows]) slab of the stored chain
     double* chain_lnp;    // optional: this step's [n_rows] slab
     int* occupancy_query; // host side only, persistent form: non-null = report workgroups/CU, do not launch
     int dense;            // host side only, persistent form: 1 = the register-capped (3 waves/SIMD) instantiation
@@ -226,6 +230,7 @@ struct iso_sampler {
     uint64_t seed;
     uint32_t step;           // running step counter (keeps the RNG stream moving across runs)
     int multi;
+    int chain_layout;        // ISO_CHAIN_ROW_MAJOR / ISO_CHAIN_PARAM_MAJOR
     iso::FastArgs fast;      // tables + model(s); copied at create time (owner must outlive the sampler)
 };
 

@@ -51,6 +51,56 @@ __device__ __forceinline__ void gather3(const Grid3V& G, const Cell3& c, double*
     }
 }
 
+// The same sums on the corner-packed table (k_pack_corners, ndim 3, P column pairs): the 16-byte piece holding the
+// column pair pr of corner j sits at piece index 4 * ((j >> 2) * P + pr) + (j & 3) of the cell.  One lane reads its
+// cell's 384 contiguous bytes (three whole 128-B lines) instead of eight scattered 64-B rows.
+__device__ __forceinline__ void gather3q(const Grid3V& G, const Cell3& c, double* __restrict__ v)
+{
+#pragma unroll
+    for (int q = 0; q < 6; ++q) v[q] = 0.0;
+    const double2* __restrict__ p = reinterpret_cast<const double2*>(G.hotq + c.base * PACK_ENTRY);
+    double2 u[24];
+#pragma unroll
+    for (int k = 0; k < 24; ++k) u[k] = p[k];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        double w = 1.0;
+        w *= ((j >> 2) & 1) ? c.t0 : (1 - c.t0);
+        w *= ((j >> 1) & 1) ? c.t1 : (1 - c.t1);
+        w *= (j & 1) ? c.t2 : (1 - c.t2);
+#pragma unroll
+        for (int pr = 0; pr < 3; ++pr) {
+            const double2 x = u[4 * ((j >> 2) * 3 + pr) + (j & 3)];
+            v[2 * pr] += x.x * w;
+            v[2 * pr + 1] += x.y * w;
+        }
+    }
+}
+
+// (nu_max, delta_nu) of a located cell: corner-packed pair table when there is one, else hot columns 6, 7
+__device__ __forceinline__ void gather3_astero(const Grid3V& G, const Cell3& c, double* __restrict__ v)
+{
+    if (G.astq) {
+        v[0] = v[1] = 0.0;
+        const double2* __restrict__ p = reinterpret_cast<const double2*>(G.astq + c.base * 16);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            double w = 1.0;
+            w *= ((j >> 2) & 1) ? c.t0 : (1 - c.t0);
+            w *= ((j >> 1) & 1) ? c.t1 : (1 - c.t1);
+            w *= (j & 1) ? c.t2 : (1 - c.t2);
+            const double2 x = p[j];
+            v[0] += x.x * w;
+            v[1] += x.y * w;
+        }
+    } else {
+        double a[8];
+        gather3<8>(G, c, a);
+        v[0] = a[6];
+        v[1] = a[7];
+    }
+}
+
 struct Cell4 {
     int64_t base;
     double t0, t1, t2, t3;
@@ -109,6 +159,40 @@ __device__ __forceinline__ void gather4_packed(const Grid4V& G, const Cell4& c, 
         const double* __restrict__ p = G.tab + corner4(G, c, j) * NB;
 #pragma unroll
         for (int b = 0; b < NB; ++b) v[b] += p[b] * w;
+    }
+}
+
+// The BC sums on the corner-packed table (k_pack_corners, ndim 4, nb bands): the 16-byte piece with the axis-3 pair
+// (o3 = 0, 1) of corner (o0, o1, o2) and band b sits at piece index (o0 * nb + b) * 4 + (o1 * 2 + o2) of the cell;
+// a cell is 128 * nb contiguous bytes.
+__device__ __forceinline__ double gather4q_col(const Grid4V& G, const Cell4& c, int col)
+{
+    const double2* __restrict__ p = reinterpret_cast<const double2*>(G.tabq + c.base * (16 * (int64_t)G.ncol));
+    double v = 0.0;
+#pragma unroll
+    for (int j = 0; j < 16; j += 2) {
+        const double2 x = p[((j >> 3) * G.ncol + col) * 4 + ((j >> 1) & 3)];
+        v += x.x * weight4(c, j);
+        v += x.y * weight4(c, j + 1);
+    }
+    return v;
+}
+
+template <int NB>
+__device__ __forceinline__ void gather4q_packed(const Grid4V& G, const Cell4& c, double* __restrict__ v)
+{
+#pragma unroll
+    for (int b = 0; b < NB; ++b) v[b] = 0.0;
+    const double2* __restrict__ p = reinterpret_cast<const double2*>(G.tabq + c.base * (16 * NB));
+#pragma unroll
+    for (int j = 0; j < 16; j += 2) {
+        const double w0 = weight4(c, j), w1 = weight4(c, j + 1);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const double2 x = p[((j >> 3) * NB + b) * 4 + ((j >> 1) & 3)];
+            v[b] += x.x * w0;
+            v[b] += x.y * w1;
+        }
     }
 }
 

@@ -8,7 +8,8 @@
 // and writes the requested quantiles (linear interpolation between order statistics)
 // -------------------------------------------------------------------------------------------
 struct QuantArgs {
-    const double* chain;     // [nsteps][n_ens*W][D]
+    const double* chain;     // element (step t, row r, parameter d) at chain[t * ss + r * rs + d * ps]
+    int64_t ss, rs, ps;      // row-major [nsteps][n_ens*W][D]: (rows*D, D, 1); parameter-major [nsteps][D][rows]: (rows*D, 1, rows)
     int64_t nsteps, n_ens;
     int W, D, nq, P;         // P = power of two >= nsteps*W
     double q[8];
@@ -45,7 +46,7 @@ __device__ __forceinline__ double quantile_lerp(double a, double b, double f)
 __device__ __forceinline__ double chain_value(const QuantArgs& A, int64_t e, int d, int64_t rows, int i)
 {
     const int t = i / A.W, w = i - t * A.W;
-    const double v = A.chain[((int64_t)t * rows + e * A.W + w) * A.D + d];
+    const double v = A.chain[(int64_t)t * A.ss + (e * A.W + w) * A.rs + d * A.ps];
     return (v != v) ? d_inf() : v;                   // NaN sorts last (cannot occur in an accepted chain)
 }
 
@@ -315,7 +316,6 @@ __global__ __launch_bounds__(BLOCK) void k_chain_quantiles_wave(const QuantArgs 
     const int64_t e = pair / A.D;
     const int d = (int)(pair - e * A.D);
     const int m = (int)(A.nsteps * A.W);
-    const int64_t rows = A.n_ens * A.W;
     const int n_ranks = 2 * A.nq;
 
     // ---- the only pass over the chain: value i of the pair lives in lane i % 64, register i / 64 ----
@@ -325,13 +325,13 @@ __global__ __launch_bounds__(BLOCK) void k_chain_quantiles_wave(const QuantArgs 
         // i = t W + w advances by 64 per register: (t, w) += (64 / W, 64 % W) with a carry, no division in the loop
         const int dq = 64 / A.W, dr = 64 - dq * A.W;
         int t = lane / A.W, w = lane - t * A.W;
-        const double* __restrict__ src = A.chain + (e * A.W) * A.D + d;
-        const int64_t step_stride = rows * A.D;
+        const double* __restrict__ src = A.chain + (e * A.W) * A.rs + d * A.ps;
+        const int64_t step_stride = A.ss;
 #pragma unroll
         for (int k = 0; k < IPL; ++k) {
             const bool have = k * 64 + lane < m;
             // unconditional load (element 0 of the pair for the padding lanes): the 52 loads issue back to back
-            double x = src[have ? (int64_t)t * step_stride + w * A.D : 0];
+            double x = src[have ? (int64_t)t * step_stride + w * A.rs : 0];
             x = (have && x == x) ? x : d_inf();                     // NaN sorts last, as chain_value
             v[k] = x;
             mn = fmin(mn, x);

@@ -1,4 +1,6 @@
-// K1+K2 generic fused lnpost kernel
+// K1+K2 generic fused lnpost kernel (any axis kind, any band count).  One lane = one sample; when the interpolator /
+// model carry corner-packed tables (Grid3V::hotq, Grid4V::tabq) every gather reads its cell's contiguous block -
+// 384 B + 128 B per band, whole 128-B lines - instead of 8 + 16 scattered rows of the compact tables.
 // (textually included by iso_hip.hip inside its anonymous namespace: one translation unit, device code only)
 #pragma once
 
@@ -49,7 +51,8 @@ __global__ __launch_bounds__(BLOCK) void k_lnpost(const PostArgs A)
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             if (ok3[s]) {
-                gather3<6>(A.g3, c3[s], star[s]);
+                if (A.g3.hotq) gather3q(A.g3, c3[s], star[s]);      // corner-packed: whole lines
+                else gather3<6>(A.g3, c3[s], star[s]);
             } else {
 #pragma unroll
                 for (int q = 0; q < 6; ++q) star[s][q] = d_nan();
@@ -102,7 +105,8 @@ __global__ __launch_bounds__(BLOCK) void k_lnpost(const PostArgs A)
                 for (int s = 0; s < NS; ++s) {
                     double bc[NB > 0 ? NB : 1];
                     if (ok4[s]) {
-                        gather4_packed<(NB > 0 ? NB : 1)>(A.g4, c4[s], bc);
+                        if (A.g4.tabq) gather4q_packed<(NB > 0 ? NB : 1)>(A.g4, c4[s], bc);
+                        else gather4_packed<(NB > 0 ? NB : 1)>(A.g4, c4[s], bc);
                     } else {
 #pragma unroll
                         for (int b = 0; b < NB; ++b) bc[b] = d_nan();
@@ -124,7 +128,8 @@ __global__ __launch_bounds__(BLOCK) void k_lnpost(const PostArgs A)
                     double tot = 0.0;
 #pragma unroll
                     for (int s = 0; s < NS; ++s) {
-                        const double bc = ok4[s] ? gather4_col(A.g4, c4[s], b) : d_nan();
+                        const double bc = !ok4[s] ? d_nan()
+                                          : (A.g4.tabq ? gather4q_col(A.g4, c4[s], b) : gather4_col(A.g4, c4[s], b));
                         const double mag = star[s][3] + dm - bc;
                         if (NS == 1) tot = mag;
                         else tot += exp10(-0.4 * mag);
@@ -135,14 +140,14 @@ __global__ __launch_bounds__(BLOCK) void k_lnpost(const PostArgs A)
             }
             if (M.has_parallax) lnl += gauss_term(M.plx_val, M.plx_g0, M.plx_unc2, 1000.0 / dist);
             if (M.has_numax) {
-                double a2[8];
+                double a2[2];
                 if (ok3[0]) {
-                    gather3<8>(A.g3, c3[0], a2);
+                    gather3_astero(A.g3, c3[0], a2);
                 } else {
-                    a2[6] = a2[7] = d_nan();
+                    a2[0] = a2[1] = d_nan();
                 }
-                lnl += gauss_term(M.numax_val, M.numax_g0, M.numax_unc2, a2[6]);
-                if (M.has_dnu) lnl += gauss_term(M.dnu_val, M.dnu_g0, M.dnu_unc2, a2[7]);
+                lnl += gauss_term(M.numax_val, M.numax_g0, M.numax_unc2, a2[0]);
+                if (M.has_dnu) lnl += gauss_term(M.dnu_val, M.dnu_g0, M.dnu_unc2, a2[1]);
             }
         }
         if (A.lnpost) A.lnpost[i] = prior_ok ? lnp + lnl : -d_inf();

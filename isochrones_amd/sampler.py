@@ -147,6 +147,9 @@ class FusedEnsembleSampler:
             _cabi.check(lib.iso_sampler_create_model(target.handle(self.device_index), self.nwalkers, float(a),
                                                      int(seed), C.byref(h)))
         self._h = h
+        # the chain is stored parameter-major, [nsteps][ndim][rows]: coalesced stores in the sampler kernels, and the
+        # per-(star, parameter) summaries read contiguous runs (every line of the chain is fetched once)
+        _cabi.check(lib.iso_sampler_set_chain_layout(h, _cabi.CHAIN_PARAM_MAJOR))
         self.reset()
 
     def close(self):
@@ -185,7 +188,7 @@ class FusedEnsembleSampler:
                torch.as_tensor(lnprob0, dtype=torch.float64, device=self.device).reshape(rows)).contiguous().clone()
         if not bool(torch.isfinite(lnp).all()):
             raise ValueError("initial positions must have finite lnpost")
-        chain = torch.empty(nsteps, rows, self.ndim, dtype=torch.float64, device=self.device) if store else None
+        chain = torch.empty(nsteps, self.ndim, rows, dtype=torch.float64, device=self.device) if store else None
         clnp = torch.empty(nsteps, rows, dtype=torch.float64, device=self.device) if store else None
         _cabi.check(_cabi.lib().iso_sampler_run(self._h, dev.ptr(pos), dev.ptr(lnp), int(nsteps), dev.ptr(chain),
                                                 dev.ptr(clnp), dev.ptr(self.accepted),
@@ -197,13 +200,22 @@ class FusedEnsembleSampler:
         shape = (self.n_ensembles, self.nwalkers) if self.is_catalog else (self.nwalkers,)
         return pos.view(*shape, self.ndim), lnp.view(*shape)
 
+    @property
+    def chain_steps(self):
+        """The stored chain as [nsteps, n_ens * W, ndim] (row = star * W + walker): a strided view of the
+        parameter-major storage ``_chain`` [nsteps, ndim, n_ens * W]."""
+        import torch
+        if self._chain is None:
+            return torch.empty(0, self.n_ensembles * self.nwalkers, self.ndim, dtype=torch.float64, device=self.device)
+        return self._chain.permute(0, 2, 1)
+
     # emcee-v2 style views: [W, nsteps, ndim] for a model, [S, W, nsteps, ndim] for a catalog
     @property
     def chain(self):
         import torch
         if self._chain is None:
             return torch.empty(self.nwalkers, 0, self.ndim, dtype=torch.float64, device=self.device)
-        c = self._chain.view(-1, self.n_ensembles, self.nwalkers, self.ndim).permute(1, 2, 0, 3)
+        c = self._chain.view(-1, self.ndim, self.n_ensembles, self.nwalkers).permute(2, 3, 0, 1)
         return c if self.is_catalog else c[0]
 
     @property
@@ -239,12 +251,13 @@ class FusedEnsembleSampler:
         if nsteps * self.nwalkers <= 8192 and q.size <= 8:
             out = torch.empty(self.n_ensembles, self.ndim, q.size, dtype=torch.float64, device=self.device)
             chain = self._chain.contiguous()
-            _cabi.check(_cabi.lib().iso_chain_quantiles(dev.context(self.device_index), dev.ptr(chain), nsteps,
-                                                        self.n_ensembles, self.nwalkers, self.ndim,
-                                                        q.ctypes.data_as(C.POINTER(C.c_double)), q.size, dev.ptr(out),
-                                                        dev.stream_ptr(self.device_index)))
+            _cabi.check(_cabi.lib().iso_chain_quantiles_layout(dev.context(self.device_index), dev.ptr(chain),
+                                                               _cabi.CHAIN_PARAM_MAJOR, nsteps, self.n_ensembles,
+                                                               self.nwalkers, self.ndim,
+                                                               q.ctypes.data_as(C.POINTER(C.c_double)), q.size,
+                                                               dev.ptr(out), dev.stream_ptr(self.device_index)))
         else:
-            flat = self._chain.view(nsteps, self.n_ensembles, self.nwalkers, self.ndim).permute(1, 3, 0, 2)
+            flat = self._chain.view(nsteps, self.ndim, self.n_ensembles, self.nwalkers).permute(2, 1, 0, 3)
             srt = torch.sort(flat.reshape(self.n_ensembles, self.ndim, -1), dim=2).values
             m = srt.shape[2]
             pick = torch.as_tensor(q, device=self.device) * (m - 1)

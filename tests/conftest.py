@@ -27,3 +27,21 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+_SWITCHES = ("ISOCHRONES_AMD_PATH", "ISOCHRONES_AMD_SAMPLER", "ISOCHRONES_AMD_QUANTILES")
+
+
+@pytest.fixture(autouse=True)
+def _kernel_switches_do_not_leak():
+    """The library reads its kernel-selection switches from the environment at call time: a test that leaves one
+    set changes what every later test measures.  Restore them, and say which test leaked."""
+    before = {k: os.environ.get(k) for k in _SWITCHES}
+    yield
+    leaked = {k: os.environ.get(k) for k in _SWITCHES if os.environ.get(k) != before[k]}
+    for k, v in before.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
+    assert not leaked, "test left kernel switches set: %r" % leaked

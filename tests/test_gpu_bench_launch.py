@@ -71,6 +71,12 @@ def test_bench_single_rank_default_line_has_roofline_and_cpu_baseline():
     cb = r["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["parity_pattern_ok"]
     assert cb["parity_max_rel_err"] < 1e-9
-    for wl in r["other_workloads"].values():
-        if "roofline" in wl:
-            assert 0 < wl["roofline"]["frac"] <= 1.0
+    # every secondary line carries what bounds it (memory side or VALU issue), as a fraction that cannot exceed 1
+    legs = list(r["other_workloads"].values()) + [r["cfg3_binary_6_bands"][w] for w in ("prior", "prior_valid", "posterior")]
+    assert "error" not in r["cfg3_binary_6_bands"]
+    for leg in legs + [{"roofline": rf["bounds"]}]:
+        b = leg["roofline"]
+        assert b["bound"] in ("hbm", "valu") and 0.3 < b["frac"] <= 1.0, b
+        assert b["source"].startswith("static") and 0 < b["hbm"]["frac"] <= 1.0 and 0 < b["valu"]["frac"] <= 1.0
+    assert r["cfg3_binary_6_bands"]["posterior"]["roofline"]["bound"] == "valu"          # cache-resident batch
+    assert r["cfg3_binary_6_bands"]["prior_valid"]["roofline"]["bound"] == "hbm"

@@ -541,6 +541,66 @@ def test_tree_model_fits_and_quantile_errors():
     assert lib.iso_chain_quantiles(ctx, None, 4, 1, 8, 3, q, 1, dev.ptr(out), None) != 0
 
 
+def test_chain_layouts_row_major_and_parameter_major(monkeypatch):
+    """iso_sampler_set_chain_layout / iso_chain_quantiles_layout: the sampler makes the same moves whichever way the
+    chain is stored (row-major [step][row][param] = the C ABI's default, parameter-major [step][param][row] = what
+    FusedEnsembleSampler uses), and the summaries of both layouts are bit-identical, in every kernel form."""
+    import ctypes as C
+    import torch
+    from isochrones_amd import _cabi, device as dev
+    from isochrones_amd.catalog import initial_positions
+    ic = _small_track(("G", "BP", "RP"))
+    cat, _ = synthetic_catalog(ic, 40, bands=["G", "BP", "RP"], seed=3, mag_unc=0.01)
+    post = CatalogPosterior.from_catalog(cat, ic)
+    W, T, D, S = 32, 60, 5, 40
+    pos0, lnp0, failed = initial_positions(post, W, rng_seed=1)
+    assert not bool(failed.any())
+    lib = _cabi.lib()
+    rows = S * W
+    q = np.array([0.5, 0.16, 0.84])
+    qp = q.ctypes.data_as(C.POINTER(C.c_double))
+    res = {}
+    for mode in ("stepwise", "persistent"):
+        monkeypatch.setenv("ISOCHRONES_AMD_SAMPLER", mode)
+        for layout in (_cabi.CHAIN_ROW_MAJOR, _cabi.CHAIN_PARAM_MAJOR):
+            h = C.c_void_p()
+            _cabi.check(lib.iso_sampler_create_catalog(post._h, W, 2.0, 77, C.byref(h)))
+            _cabi.check(lib.iso_sampler_set_chain_layout(h, layout))
+            pos, lnp = pos0.reshape(rows, D).clone(), lnp0.reshape(rows).clone()
+            chain = torch.full((T, rows, D) if layout == _cabi.CHAIN_ROW_MAJOR else (T, D, rows), float("nan"),
+                               dtype=torch.float64, device="cuda")
+            clnp = torch.empty(T, rows, dtype=torch.float64, device="cuda")
+            acc = torch.zeros(rows, dtype=torch.int32, device="cuda")
+            _cabi.check(lib.iso_sampler_run(h, dev.ptr(pos), dev.ptr(lnp), T, dev.ptr(chain), dev.ptr(clnp), dev.ptr(acc), None))
+            out = torch.empty(S, D, 3, dtype=torch.float64, device="cuda")
+            _cabi.check(lib.iso_chain_quantiles_layout(dev.context(0), dev.ptr(chain), layout, T, S, W, D, qp, 3, dev.ptr(out), None))
+            torch.cuda.synchronize()
+            lib.iso_sampler_destroy(h)
+            as_rows = chain if layout == _cabi.CHAIN_ROW_MAJOR else chain.permute(0, 2, 1)
+            res[(mode, layout)] = (as_rows.cpu().numpy(), clnp.cpu().numpy(), acc.cpu().numpy(), out.cpu().numpy())
+        assert lib.iso_sampler_set_chain_layout(None, 0) != 0
+    ref = res[("stepwise", _cabi.CHAIN_ROW_MAJOR)]
+    assert np.isfinite(ref[0]).all() and ref[2].sum() > 0.1 * rows * T
+    for key, got in res.items():
+        for a, b in zip(ref, got):
+            assert np.array_equal(a, b), key
+    want = np.percentile(ref[0].reshape(T, S, W, D).transpose(1, 0, 2, 3).reshape(S, T * W, D), [50, 16, 84], axis=1)
+    assert np.array_equal(ref[3], want.transpose(1, 2, 0))
+    for mode_q in ("workgroup", "sort"):                       # the older summary kernels read both layouts too
+        monkeypatch.setenv("ISOCHRONES_AMD_QUANTILES", mode_q)
+        for layout in (_cabi.CHAIN_ROW_MAJOR, _cabi.CHAIN_PARAM_MAJOR):
+            c = torch.as_tensor(ref[0] if layout == _cabi.CHAIN_ROW_MAJOR else np.ascontiguousarray(ref[0].transpose(0, 2, 1)),
+                                device="cuda")
+            out = torch.empty(S, D, 3, dtype=torch.float64, device="cuda")
+            _cabi.check(lib.iso_chain_quantiles_layout(dev.context(0), dev.ptr(c), layout, T, S, W, D, qp, 3, dev.ptr(out), None))
+            assert np.array_equal(out.cpu().numpy(), ref[3])
+    h = C.c_void_p()
+    _cabi.check(lib.iso_sampler_create_catalog(post._h, W, 2.0, 77, C.byref(h)))
+    assert lib.iso_sampler_set_chain_layout(h, 7) != 0
+    lib.iso_sampler_destroy(h)
+    post.close()
+
+
 def test_derived_samples_single_and_binary():
     """reference _make_samples (starmodel.py:1653-1707): per-component columns and combined magnitudes."""
     ages = ia.grids.mist_log_ages()[60::2]

@@ -572,6 +572,8 @@ def test_randomised_soak_short(monkeypatch):
     (the long runs are recorded in profiles/r01/soak.txt)."""
     import runpy
     monkeypatch.setattr(sys, "argv", ["soak.py", "6", "11"])
+    monkeypatch.setenv("ISOCHRONES_AMD_PATH", "auto")          # the soak switches kernel paths through this variable:
+                                                               # monkeypatch puts it back for the tests that follow
     with pytest.raises(SystemExit) as e:
         runpy.run_path(os.path.join(os.path.dirname(os.path.abspath(__file__)), "soak", "soak.py"),
                        run_name="__main__")

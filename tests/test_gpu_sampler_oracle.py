@@ -63,7 +63,7 @@ def test_cfg4_every_move_of_the_fit_against_the_oracle(mode, nsteps, monkeypatch
     assert np.isfinite(lnp0).all()
     fs = FusedEnsembleSampler(mod, W, seed=seed)
     pos, lnp = fs.run_mcmc(p0, nsteps, lnprob0=lnp0, store=True)
-    chain = fs._chain.cpu().numpy()                 # [T, W, 5] in the kernel's storage order
+    chain = fs.chain_steps.cpu().numpy()            # [T, W, 5]
     clnp = fs._lnprob.cpu().numpy()
     assert chain.shape == (nsteps, W, 5)
     st = _replay.replay(p0, lnp0, chain, clnp, W, 2.0, seed, 0, fn)
@@ -81,7 +81,7 @@ def test_cfg4_every_move_of_the_fit_against_the_oracle(mode, nsteps, monkeypatch
     assert (moved.sum(axis=0) > 0.1 * nsteps).all()
     # a second run_mcmc continues the counter stream (step0 = nsteps)
     pos2, lnp2 = fs.run_mcmc(pos, 40, lnprob0=lnp, store=True)
-    c2, l2 = fs._chain.cpu().numpy()[nsteps:], fs._lnprob.cpu().numpy()[nsteps:]
+    c2, l2 = fs.chain_steps.cpu().numpy()[nsteps:], fs._lnprob.cpu().numpy()[nsteps:]
     st2 = _replay.replay(chain[-1], clnp[-1], c2, l2, W, 2.0, seed, nsteps, fn)
     assert st2["moves"] == 40 * W
 
@@ -109,7 +109,7 @@ def test_cfg3_binary_sampler_moves_against_the_oracle():
     fs.run_mcmc(p0, T, lnprob0=lnp0, store=True)
     # lnlike reaches 1e5..1e7 here (sigma = 0.001 mag): 1e-9 relative, plus the absolute floor that a 1e-14 mag
     # rounding difference times (residual / sigma^2 ~ 1e6) produces
-    st = _replay.replay(p0, lnp0, fs._chain.cpu().numpy(), fs._lnprob.cpu().numpy(), W, 2.0, seed, 0, fn, lnp_atol=1e-7,
+    st = _replay.replay(p0, lnp0, fs.chain_steps.cpu().numpy(), fs._lnprob.cpu().numpy(), W, 2.0, seed, 0, fn, lnp_atol=1e-7,
                         margin=1e-8)
     assert st["moves"] == W * T and st["accepted"] > 0.02 * st["moves"]
     assert st["near_ties"] <= 2
@@ -148,7 +148,7 @@ def test_asteroseismic_model_fits_on_the_fused_sampler_and_matches_the_oracle(ki
         monkeypatch.setenv("ISOCHRONES_AMD_SAMPLER", mode)
         fs = FusedEnsembleSampler(mod, W, seed=seed)
         fs.run_mcmc(p0, T_steps, lnprob0=lnp0, store=True)
-        st = _replay.replay(p0, lnp0, fs._chain.cpu().numpy(), fs._lnprob.cpu().numpy(), W, 2.0, seed, 0, fn)
+        st = _replay.replay(p0, lnp0, fs.chain_steps.cpu().numpy(), fs._lnprob.cpu().numpy(), W, 2.0, seed, 0, fn)
         assert st["moves"] == W * T_steps and st["accepted"] > 0.1 * st["moves"] and st["near_ties"] <= 2
         fs.close()
     monkeypatch.delenv("ISOCHRONES_AMD_SAMPLER")
@@ -239,7 +239,7 @@ def test_cfg5_catalog_sampler_moves_against_the_oracle(monkeypatch):
         monkeypatch.setenv("ISOCHRONES_AMD_SAMPLER", mode)
         fs = FusedEnsembleSampler(post, W, seed=21)
         fs.run_mcmc(pos, T, lnprob0=lnp, store=True)
-        ch = fs._chain.view(T, n_stars, W, 5)[:, sel].reshape(T, -1, 5).cpu().numpy()
+        ch = fs.chain_steps.reshape(T, n_stars, W, 5)[:, sel].reshape(T, -1, 5).cpu().numpy()
         cl = fs._lnprob.view(T, n_stars, W)[:, sel].reshape(T, -1).cpu().numpy()
         st = _replay.replay(p_sel, l_sel, ch, cl, W, 2.0, 21, 0, fn, star_of_block=pick, lnp_atol=1e-10)
         assert st["moves"] == 300 * W * T and st["accepted"] > 0.1 * st["moves"]

@@ -1,0 +1,123 @@
+#!/usr/bin/env python
+"""Launch the library kernels of the benchmark workloads in a fixed order, `--launches` times each, and write
+the order as a manifest - so that a rocprofv3 --pmc pass over this script can be split per workload even though
+several workloads run the same kernel (tools/pmc_summarize.py walks the dispatches of a kernel in order).
+
+    python tools/pmc_workload.py --manifest out.json [--launches 6] [--cases cfg2,cfg3,...]
+
+cases: cfg2 (single star, 1 band: prior / prior_valid / posterior samples), cfg3 (binary, 6 bands + parallax: the same
+three), generic (cfg2 model on the generic kernel), astero, tree (resolved binary, fast tree kernel),
+quantiles (chain summaries of a 10^4-star catalog, 32 walkers x 100 steps), sampler (cfg 4 persistent kernel).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--manifest", required=True)
+    ap.add_argument("--launches", type=int, default=12)
+    ap.add_argument("--cases", default="cfg2,cfg3,generic,astero,tree,quantiles")
+    ap.add_argument("--n", type=int, default=1_000_000)
+    args = ap.parse_args()
+    import torch
+    import bench
+    import bench_configs
+    import isochrones_amd as ia
+    from isochrones_amd import _cabi, device as dev
+    lib = _cabi.lib()
+    manifest = []
+    L, n = args.launches, args.n
+    cases = args.cases.split(",")
+
+    def lnpost_launches(label, kernel, mod, pars, bytes_per_eval):
+        pt = torch.as_tensor(np.ascontiguousarray(pars.T), device="cuda")
+        out = torch.empty(pars.shape[0], dtype=torch.float64, device="cuda")
+        ms = C.c_double()
+        h = mod.handle(torch.cuda.current_device())
+        torch.cuda.synchronize()
+        _cabi.check(lib.iso_time_lnpost(h, dev.ptr(pt), 1, pars.shape[0], pars.shape[0], dev.ptr(out), L, dev.stream_ptr(),
+                                        C.byref(ms)))
+        torch.cuda.synchronize()
+        manifest.append(dict(label=label, kernel=kernel, launches=L, skip=2, n=int(pars.shape[0]), ms_per_launch_profiled=ms.value,
+                             algorithmic_bytes_per_launch=float(bytes_per_eval) * pars.shape[0],
+                             finite_fraction=float(torch.isfinite(out).double().mean())))
+
+    if "cfg2" in cases or "generic" in cases:
+        ic, mod = bench.build_model()
+        samples = {wl: bench.make_samples(np.random.default_rng(12345 if wl == "prior_valid" else 999), n, wl)
+                   for wl in ("prior", "prior_valid", "posterior")}
+        if "cfg2" in cases:
+            mod.lnpost(samples["prior"][:4096])                         # builds the packs outside the counted launches
+            for wl, pars in samples.items():
+                lnpost_launches("cfg2/" + wl, "k_lnpost_fast<0, 1, 1, true, false, false>", mod, pars, 560)
+        if "generic" in cases:
+            os.environ["ISOCHRONES_AMD_PATH"] = "generic"
+            ic_g, mod_g = bench.build_model()
+            mod_g.lnpost(samples["prior"][:4096])
+            for wl in ("prior_valid", "posterior"):
+                lnpost_launches("generic/" + wl, "k_lnpost<0, 1, 1", mod_g, samples[wl], 560)
+            os.environ.pop("ISOCHRONES_AMD_PATH")
+            del mod_g, ic_g
+        del mod, ic
+    if "cfg3" in cases:
+        ic3, mod3, sets = bench_configs.cfg3_model_and_samples(n)
+        mod3.lnpost(sets["prior"][:4096])
+        for wl, pars in sets.items():
+            lnpost_launches("cfg3/" + wl, "k_lnpost_fast<1, 2, 6, true, false, false>", mod3, pars, 2360)
+        del mod3, ic3
+    if "astero" in cases:
+        ic = ia.synthetic_track(bands=("V",))
+        mod = ia.SingleStarModel(ic, Teff=(5770, 100), logg=(4.5, 0.1), feh=(0.0, 0.15), V=(10.0, 0.05),
+                                 nu_max=(3000.0, 100.0), delta_nu=(135.0, 3.0))
+        pars = bench.make_samples(np.random.default_rng(12345), n, "prior_valid")
+        mod.lnpost(pars[:4096])
+        lnpost_launches("astero/prior_valid", "k_lnpost_fast<0, 1, 1, true, false, true>", mod, pars, 688)
+        del mod, ic
+    if "tree" in cases:
+        mod, pars = bench_configs.tree_model_and_samples(n)
+        pt = torch.as_tensor(pars, device="cuda")
+        mod.lnpost(pt[:4096])
+        torch.cuda.synchronize()
+        for _ in range(L):
+            mod.lnpost(pt)
+        torch.cuda.synchronize()
+        manifest.append(dict(label="tree/posterior", kernel="k_lnpost_tree_fast", launches=L + 1, skip=2, n=n,
+                             algorithmic_bytes_per_launch=float(2 * 384 + 2 * 3 * 128 + 56) * n))
+        del mod
+    if "quantiles" in cases:
+        from isochrones_amd.catalog import CatalogPosterior, initial_positions
+        from isochrones_amd.sampler import FusedEnsembleSampler
+        bands = ["G", "BP", "RP"]
+        ic = ia.synthetic_track(bands=bands)
+        S, W, T = 100_000, 32, 100
+        cat, _ = ia.synthetic_catalog(ic, S, bands=bands, seed=7, mag_unc=0.01)
+        post = CatalogPosterior.from_catalog(cat, ic)
+        pos, lnp, failed = initial_positions(post, W, rng_seed=0)
+        if bool(failed.any()):
+            good = int(torch.nonzero(~failed)[0])
+            pos[failed] = pos[good]
+            lnp[failed] = 0.0
+        fs = FusedEnsembleSampler(post, W, seed=1)
+        fs.run_mcmc(pos, T, lnprob0=lnp, store=True)
+        fs.quantiles()
+        torch.cuda.synchronize()
+        for _ in range(L):
+            fs.quantiles()
+        torch.cuda.synchronize()
+        manifest.append(dict(label="quantiles/100000x32x100", kernel="k_chain_quantiles_wave", launches=L + 1, skip=1,
+                             n=S * 5, algorithmic_bytes_per_launch=float(S) * W * T * 5 * 8))
+    json.dump(manifest, open(args.manifest, "w"), indent=1)
+    print("manifest:", args.manifest, [m["label"] for m in manifest])
+
+
+if __name__ == "__main__":
+    main()

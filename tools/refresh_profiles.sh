@@ -1,9 +1,18 @@
+# Regenerate the files under profiles/<round>/ on the GPU box:  bash tools/refresh_profiles.sh r02
 set -x
-mkdir -p gpurun_out/final
-python bench.py > gpurun_out/final/bench_cfg2_1gpu.json 2> gpurun_out/final/bench.err
-python bench_configs.py --configs cfg1,cfg3,cfg4,cfg5,tree,primitives,astero,nested,published > gpurun_out/final/bench_configs_1gpu.jsonl 2> gpurun_out/final/bench_configs.err
+R=${1:-r02}
+OUT=gpurun_out/$R
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+mkdir -p $OUT
+python bench.py > $OUT/bench_cfg2_1gpu.json 2> $OUT/bench.err
+python bench_configs.py --configs cfg1,cfg3,cfg4,cfg5,tree,primitives,astero,nested,published > $OUT/bench_configs_1gpu.jsonl 2> $OUT/bench_configs.err
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/final/prof -- python $GRAFT_REPO_ROOT/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-extras > $GRAFT_REPO_ROOT/gpurun_out/final/prof_bench.json 2> $GRAFT_REPO_ROOT/gpurun_out/final/prof.err
-cd $GRAFT_REPO_ROOT
-find gpurun_out/final/prof -name "*kernel_stats.csv" | head
-tail -c 600 gpurun_out/final/bench_cfg2_1gpu.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/prof -- python $ROOT/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-catalog > $ROOT/$OUT/prof_bench.json 2> $ROOT/$OUT/prof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/prof_all -- python $ROOT/bench_configs.py --configs cfg3,cfg4,cfg5,tree,primitives,astero > $ROOT/$OUT/prof_all.jsonl 2> $ROOT/$OUT/prof_all.err
+cd $ROOT
+for d in prof prof_all; do
+  f=$(find $OUT/$d -name "*kernel_stats.csv" | head -1)
+  [ -n "$f" ] && cp "$f" $OUT/kernel_stats_$d.csv
+  find $OUT/$d -name "*.csv" -size +1M -delete
+done
+tail -c 1500 $OUT/bench_cfg2_1gpu.json
