@@ -206,8 +206,13 @@ int  iso_lnpost(iso_model* m, const double* pars, int64_t stride_n, int64_t stri
 
 /* The same for HOST arrays (pars [n][n_params] row-major): the sampler-callback form — what emcee /
  * MultiNest do when they call StarModel.lnpost(p) with one parameter vector (starmodel.py:952,966,
- * 1642-1645).  Parameters and results go through a pinned, device-mapped staging buffer owned by
- * the model: one launch + one synchronise per call.  Not re-entrant per model. */
+ * 1642-1645) — and the vectorised form for host batches of any size.  Up to 32768 rows travel through a pinned,
+ * device-mapped staging buffer owned by the model, one launch per 8192 rows; a call that fits one workgroup (<= 256
+ * rows on the fused kernel) is completed by a flag the kernel raises in mapped memory, which the host spins on
+ * (ISOCHRONES_AMD_HOST_SYNC=1: synchronise the stream instead).  Larger batches are cut into 131072-row chunks: the
+ * calling thread uploads and launches chunk k (results land in pinned host memory) while a helper thread copies the
+ * results of the chunks before it into the caller's arrays.
+ * Not re-entrant per model. */
 int  iso_lnpost_host(iso_model* m, const double* pars, int64_t n, double* lnpost_out, double* lnprior_out,
                      double* lnlike_out);
 

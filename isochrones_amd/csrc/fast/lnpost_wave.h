@@ -179,4 +179,12 @@ __global__ __launch_bounds__(BLOCK, fast_min_waves(NS, NB)) void k_lnpost_fast(c
         if (A.lnprior) A.lnprior[i] = lnp;
         if (A.lnlike) A.lnlike[i] = lnl;
     }
+    if (A.done_flag) {               // single-workgroup host-callback launch: results first, then the flag
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            *reinterpret_cast<volatile unsigned long long*>(A.done_flag) = A.done_seq;
+            __threadfence_system();
+        }
+    }
 }

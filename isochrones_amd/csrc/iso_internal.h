@@ -8,6 +8,8 @@
 #include <string>
 #include <mutex>
 #include <vector>
+#include <atomic>
+#include <thread>
 
 #include "../../include/isochrones_amd.h"
 
@@ -98,6 +100,11 @@ struct FastArgs {
     double* lnpost;
     double* lnprior;                 // optional: BasicStarModel.lnprior / .lnlike of every sample
     double* lnlike;                  // (lnlike is then evaluated even where the prior is not finite)
+    // host-callback launches of a single workgroup (iso_lnpost_host): after its results are out the kernel
+    // stores done_seq to done_flag (pinned, device-mapped) - the host spins on it instead of paying a
+    // hipStreamSynchronize (13 -> 8 us per round trip, tools/sync_probe.hip); null for every other launch
+    unsigned long long* done_flag;
+    unsigned long long done_seq;
 };
 
 // flattened observation tree of a generic StarModel (constants pre-evaluated on the host)
@@ -219,6 +226,12 @@ struct iso_model {
     iso::FastArgs fast;      // template filled at create time (pars/outputs set per call)
     double* h_stage;         // pinned, device-mapped staging for iso_lnpost_host (lazy)
     int64_t stage_rows;
+    unsigned long long stage_seq;   // sequence number of the completion flag at the end of h_stage
+    // large host batches (iso_lnpost_host beyond the staging buffer): device rows + two streams, kept between calls
+    double* d_pipe;          // device: the uploaded parameter rows
+    double* h_pipe;          // pinned, device-mapped: the kernels write their results straight into host memory
+    int64_t pipe_rows;
+    hipStream_t pipe_stream[2];
 };
 
 struct iso_sampler {

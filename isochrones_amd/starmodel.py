@@ -514,8 +514,9 @@ class BasicStarModel(_NestedFitMixin, _ConvenienceMixin):
         single = arr.ndim == 1
         a2 = arr[None, :] if single else arr
         device = dev.current_device()
-        if a2.shape[0] <= 65536 and not (soa and not single):
-            # host arrays of sampler-callback size: one C call (pinned, device-mapped staging)
+        if not (soa and not single):
+            # host arrays: one C call.  Sampler-callback sizes go through the pinned, device-mapped staging buffer (one
+            # launch, completion flag), large batches through the chunked upload / download pipeline of iso_lnpost_host
             if a2.shape[1] != self.n_params:
                 raise ValueError("expected [N, %d]" % self.n_params)
             n = a2.shape[0]

@@ -29,7 +29,7 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
-_SWITCHES = ("ISOCHRONES_AMD_PATH", "ISOCHRONES_AMD_SAMPLER", "ISOCHRONES_AMD_QUANTILES")
+_SWITCHES = ("ISOCHRONES_AMD_PATH", "ISOCHRONES_AMD_SAMPLER", "ISOCHRONES_AMD_QUANTILES", "ISOCHRONES_AMD_HOST_SYNC")
 
 
 @pytest.fixture(autouse=True)

@@ -685,3 +685,44 @@ def test_gpu_box_runs_the_library_built_from_these_sources():
     _cabi.lib()
     assert os.path.realpath(_cabi.library_path()) in {os.path.realpath(l.split()[-1]) for l in open("/proc/self/maps")
                                                       if "libiso_hip.so" in l}
+
+
+@pytest.mark.parametrize("n", [1, 2, 100, 256, 257, 8192, 8193, 32768, 32769, 131072 + 5, 1_000_003])
+def test_host_array_entry_point_every_size_regime(n, monkeypatch):
+    """iso_lnpost_host: the flag-completed single-workgroup call (<= 256 rows), the staged loop (<= 32768 rows) and the
+    chunked upload / download pipeline with its helper thread (beyond) all return what the device-pointer entry point
+    returns for the same rows, bit for bit - lnpost, and lnprior / lnlike on request."""
+    import torch
+    import bench
+    ic = _ic_for_host_test()
+    mod = ia.SingleStarModel(ic, Teff=(5770, 100), logg=(4.5, 0.1), feh=(0.0, 0.15), V=(10.0, 0.05), parallax=(10.0, 0.1))
+    rng = np.random.default_rng(n)
+    lo = np.array([0.65, 295.0, -1.1, 50.0, 0.0])
+    hi = np.array([2.1, 425.0, 0.6, 150.0, 1.0])
+    pars = rng.uniform(lo, hi, size=(n, 5))
+    if n >= 100:
+        pars[rng.integers(0, n, n // 50), rng.integers(0, 5, n // 50)] = np.nan
+    dv = torch.as_tensor(pars, device="cuda")
+    want, want_prior, want_like = (t.cpu().numpy() for t in mod.evaluate_device(dv, parts=True))
+    same = lambda a, b: np.array_equal(a, b, equal_nan=True)
+    got = mod.lnpost(pars)
+    assert got.shape == (n,) and same(got, want) and np.isfinite(want).sum() > 0
+    assert same(mod.lnprior(pars), want_prior) and same(mod.lnlike(pars), want_like)
+    assert same(mod.lnpost(pars), want)                                       # again: staging buffers are reused
+    if n <= 256:
+        monkeypatch.setenv("ISOCHRONES_AMD_HOST_SYNC", "1")                   # the stream-synchronise completion
+        assert same(mod.lnpost(pars), want)
+    if n > 1:
+        assert mod.lnpost(list(pars[1])) == want[1] or (np.isnan(want[1]) and np.isnan(mod.lnpost(list(pars[1]))))
+
+
+_HOST_IC = []
+
+
+def _ic_for_host_test():
+    if not _HOST_IC:
+        fehs = np.array([-1.0, -0.5, 0.0, 0.5])
+        masses = np.array([0.7, 0.9, 1.0, 1.1, 1.3, 2.0])
+        _HOST_IC.append(ia.synthetic_track(bands=("V", "J", "K"), fehs=fehs, masses=masses, eeps=np.arange(300.0, 420.0),
+                                           limits=dict(mass=(0.7, 2.0), feh=(-1.0, 0.5), age=(5, 10.13)), eep_bounds=(300, 419)))
+    return _HOST_IC[0]

@@ -18,3 +18,28 @@ t("ic.interp_mag(p, ['V'])", lambda: ic.interp_mag(p, ["V"]))
 t("ic.model_grid.interp([0.0,1.0,355.0], ['Teff'])", lambda: ic.model_grid.interp([0.0, 1.0, 355.0], ["Teff"]))
 t("ic.get_eep(1.0, 9.6, 0.0)", lambda: ic.get_eep(1.0, 9.6, 0.0))
 t("ic.mass(*p[:3])", lambda: ic.mass(*p[:3]))
+half = np.tile(np.array(p), (128, 1)) * (1 + 1e-3 * np.random.default_rng(0).standard_normal((128, 5)))
+t("mod.lnpost(half ensemble [128, 5])", lambda: mod.lnpost(half))
+os.environ["ISOCHRONES_AMD_HOST_SYNC"] = "1"          # A/B: the stream-synchronise completion of round 1
+t("mod.lnpost(p), hipStreamSynchronize", lambda: mod.lnpost(p))
+t("mod.lnpost(half), hipStreamSynchronize", lambda: mod.lnpost(half))
+os.environ.pop("ISOCHRONES_AMD_HOST_SYNC")
+assert mod.lnpost(p) == float(mod.lnpost(np.array([p]))[0])
+# host-array path at benchmark size: where the time goes
+import torch
+big = bench.make_samples(np.random.default_rng(1), 1_000_000, "prior_valid")
+def tm(label, f, n=5):
+    f(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n): f()
+    torch.cuda.synchronize()
+    print("%-46s %.3f ms" % (label, (time.perf_counter() - t0) / n * 1e3), flush=True)
+tm("mod.lnpost(numpy [1e6, 5]) -> numpy", lambda: mod.lnpost(big))
+dv = torch.as_tensor(big, device="cuda")
+tm("  H2D 40 MB pageable (torch.as_tensor)", lambda: torch.as_tensor(big, device="cuda"))
+tm("  kernel on resident rows", lambda: mod.lnpost(dv))
+res = mod.lnpost(dv)
+tm("  D2H 8 MB (.cpu().numpy())", lambda: res.cpu().numpy())
+pin = torch.empty(big.shape, dtype=torch.float64).pin_memory()
+tm("  memcpy numpy -> pinned (1 thread)", lambda: pin.numpy().__setitem__(slice(None), big))
+tm("  H2D 40 MB from pinned", lambda: dv.copy_(pin, non_blocking=True))
