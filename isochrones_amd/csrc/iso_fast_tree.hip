@@ -11,13 +11,35 @@ namespace iso {
 namespace fastk {
 
 // NL > 0: the tree has exactly NL model stars, every per-leaf array is indexed at compile time and lives
-// in registers (the common 1-4 star trees); NL = 0: runtime leaf count, arrays in per-lane scratch.
+// in registers (the common 1-4 star trees).  NL = 0: runtime leaf count (5-8 stars, or more than 8 bands): the
+// per-leaf values live in LDS, [slot][lane] so that the lanes of a wave touch consecutive addresses - one wave per
+// workgroup, n_leaves * (6 + NB) * 64 doubles (5 stars x 3 bands: 23 KB).  (Per-lane scratch arrays, the first form,
+// cost 456-1160 B of scratch per lane: 200 MB of write traffic per 10^6 samples.)
 template <int NB, int NL>
 struct TreeLeaves {
     static constexpr bool STATIC = NL > 0;
-    static constexpr int ML = STATIC ? NL : ISO_TREE_MAX_LEAVES;
-    double star[ML][6];
-    double flux[ML][NB];
+    static constexpr int ML = STATIC ? NL : 1;
+    static constexpr int PER = 6 + NB;
+    double star_[ML][6];
+    double flux_[ML][NB];
+    double* lds_;          // NL = 0: this lane's column of the [slot][lane] block
+    int stride_;           // lanes per workgroup
+
+    __device__ __forceinline__ void set_star(int l, int q, double v)
+    {
+        if constexpr (STATIC) star_[l][q] = v;
+        else lds_[(l * PER + q) * stride_] = v;
+    }
+    __device__ __forceinline__ void set_flux(int l, int b, double v)
+    {
+        if constexpr (STATIC) flux_[l][b] = v;
+        else lds_[(l * PER + 6 + b) * stride_] = v;
+    }
+    __device__ __forceinline__ double star(int l, int q) const
+    {
+        if constexpr (STATIC) return star_[l][q];
+        else return lds_[(l * PER + q) * stride_];
+    }
 
     __device__ __forceinline__ double addmags(uint32_t mask, int band, int n_leaves) const
     {
@@ -26,10 +48,10 @@ struct TreeLeaves {
 #pragma unroll
             for (int l = 0; l < NL; ++l)
 #pragma unroll
-                for (int b = 0; b < NB; ++b) tot += (((mask >> l) & 1u) && b == band) ? flux[l][b] : 0.0;
+                for (int b = 0; b < NB; ++b) tot += (((mask >> l) & 1u) && b == band) ? flux_[l][b] : 0.0;
         } else {
             for (int l = 0; l < n_leaves; ++l)
-                if (mask & (1u << l)) tot += flux[l][band];
+                if (mask & (1u << l)) tot += lds_[(l * PER + 6 + band) * stride_];
         }
         return -2.5 * log10(tot);
     }
@@ -41,29 +63,36 @@ struct TreeLeaves {
 #pragma unroll
             for (int l = 0; l < NL; ++l)
 #pragma unroll
-                for (int k = 0; k < 6; ++k) v = (l == leaf && k == q) ? star[l][k] : v;
+                for (int k = 0; k < 6; ++k) v = (l == leaf && k == q) ? star_[l][k] : v;
             return v;
         } else {
-            return star[leaf][q];
+            return lds_[(leaf * PER + q) * stride_];
         }
     }
 };
 
+// threads per workgroup: four waves for the register form, one wave for the LDS-resident runtime form
+template <int NL>
+constexpr int tree_block() { return NL > 0 ? BLOCK : 64; }
+
 template <int NB, int NL>
-__global__ __launch_bounds__(BLOCK) void k_lnpost_tree_fast(const FastArgs A, const DevTree* __restrict__ Tp)
+__global__ __launch_bounds__(tree_block<NL>()) void k_lnpost_tree_fast(const FastArgs A, const DevTree* __restrict__ Tp)
 {
+    constexpr int TB = tree_block<NL>();
     extern __shared__ double lds[];
-    for (int j = threadIdx.x; j < A.axes_len; j += BLOCK) lds[j] = A.axes_blob[j];
+    for (int j = threadIdx.x; j < A.axes_len; j += TB) lds[j] = A.axes_blob[j];
     __syncthreads();
     const CoopLds L = coop_lds<NB>(lds, A.axes_len);
     const DevTree& T = *Tp;
-    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x;
     const bool active = i < A.n;
     const int64_t ii = active ? i : (A.n - 1);
     const double* __restrict__ src = A.pars + ii * A.stride_n;
     auto par = [&](int j) { return src[j * A.stride_p]; };        // parameters stay in memory (L1/L2 hits)
     const int n_leaves = (NL > 0) ? NL : T.n_leaves;
     TreeLeaves<NB, NL> S;
+    S.lds_ = lds + ((A.axes_len + 1) & ~1) + coop_lds_doubles(NB) + threadIdx.x;     // (unused by the register form)
+    S.stride_ = TB;
     // ---- every model star: model-table gather, then magnitudes as fluxes ----
     auto leaf = [&](int l) {
         const int s = T.leaf_system[l];
@@ -82,7 +111,7 @@ __global__ __launch_bounds__(BLOCK) void k_lnpost_tree_fast(const FastArgs A, co
         double v[6];
         coop_star(A, L, ok3, (uint32_t)((int64_t)i0 * A.s0 + (int64_t)i1 * A.s1 + i2), w, v);
 #pragma unroll
-        for (int q = 0; q < 6; ++q) S.star[l][q] = v[q];
+        for (int q = 0; q < 6; ++q) S.set_star(l, q, v[q]);
         const double Tf = v[0], g = v[1], f = v[2];
         const bool ok4 = ok3 && !(AV != AV) && !(Tf != Tf) && !(g != g) && !(f != f) && !lds_oob(lds, A.b0, Tf) &&
                          !lds_oob(lds, A.b1, g) && !lds_oob(lds, A.b2, f) && !lds_oob(lds, A.b3, AV);
@@ -94,7 +123,7 @@ __global__ __launch_bounds__(BLOCK) void k_lnpost_tree_fast(const FastArgs A, co
         coop_bc<NB>(A, L, ok4, (uint32_t)((int64_t)j0 * A.bs0 + (int64_t)j1 * A.bs1 + (int64_t)j2 * A.bs2 + j3), w4v, bc);
         const double dm = 5 * log10(dist / 10.0);
 #pragma unroll
-        for (int b = 0; b < NB; ++b) S.flux[l][b] = exp10(-0.4 * (v[3] + dm - bc[b]));
+        for (int b = 0; b < NB; ++b) S.set_flux(l, b, exp10(-0.4 * (v[3] + dm - bc[b])));
     };
     if constexpr (NL > 0) {
 #pragma unroll
@@ -125,7 +154,7 @@ __global__ __launch_bounds__(BLOCK) void k_lnpost_tree_fast(const FastArgs A, co
             if (eep < T.eep_lo || eep > T.eep_hi) {
                 term = -f_inf();
             } else {
-                const double lc = ln_call(T.prior_mass, S.star[l][4]), deriv = S.star[l][5];
+                const double lc = ln_call(T.prior_mass, S.star(l, 4)), deriv = S.star(l, 5);
                 term = (lc == -f_inf()) ? ((deriv != deriv) ? f_nan() : -f_inf()) : lc + log(deriv);
             }
             lnp += term;
@@ -190,11 +219,16 @@ __global__ __launch_bounds__(BLOCK) void k_lnpost_tree_fast(const FastArgs A, co
 }  // namespace fastk
 
 template <int NL>
-static bool launch_tree_nl(int nb, const FastArgs& A, const DevTree* T, hipStream_t s)
+static bool launch_tree_nl(int nb, int n_leaves, const FastArgs& A, const DevTree* T, hipStream_t s)
 {
     using namespace fastk;
-    const dim3 g((unsigned)((A.n + BLOCK - 1) / BLOCK)), b(BLOCK);
-    auto sh = [&](int n) { return (size_t)(((A.axes_len + 1) & ~1) + coop_lds_doubles(n)) * sizeof(double); };
+    constexpr int TB = tree_block<NL>();
+    const dim3 g((unsigned)((A.n + TB - 1) / TB)), b(TB);
+    // the runtime-leaf form keeps n_leaves * (6 + bands) values per lane in LDS behind the staged axes and gather slots
+    auto sh = [&](int n) {
+        return (size_t)(((A.axes_len + 1) & ~1) + coop_lds_doubles(n) + (NL > 0 ? 0 : n_leaves * (6 + n) * TB)) * sizeof(double);
+    };
+    if (sh(nb) > 64 * 1024) return false;      // (7-8 stars x 10-12 bands: the generic tree kernel takes those)
     switch (nb) {
 #define ISO_TREE_CASE(N) \
     case N: hipLaunchKernelGGL((k_lnpost_tree_fast<N, NL>), g, b, sh(N), s, A, T); return true;
@@ -218,13 +252,13 @@ bool launch_tree_fast(int nb, int n_leaves, const FastArgs& A, const DevTree* T,
     const char* rt = getenv("ISOCHRONES_AMD_TREE_RUNTIME_LEAVES");
     if (nb <= 8 && !(rt && rt[0] == '1')) {
         switch (n_leaves) {
-        case 1: return launch_tree_nl<1>(nb, A, T, s);
-        case 2: return launch_tree_nl<2>(nb, A, T, s);
-        case 3: return launch_tree_nl<3>(nb, A, T, s);
-        case 4: return launch_tree_nl<4>(nb, A, T, s);
+        case 1: return launch_tree_nl<1>(nb, n_leaves, A, T, s);
+        case 2: return launch_tree_nl<2>(nb, n_leaves, A, T, s);
+        case 3: return launch_tree_nl<3>(nb, n_leaves, A, T, s);
+        case 4: return launch_tree_nl<4>(nb, n_leaves, A, T, s);
         }
     }
-    return launch_tree_nl<0>(nb, A, T, s);
+    return launch_tree_nl<0>(nb, n_leaves, A, T, s);
 }
 
 }  // namespace iso

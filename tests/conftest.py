@@ -29,7 +29,8 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
-_SWITCHES = ("ISOCHRONES_AMD_PATH", "ISOCHRONES_AMD_SAMPLER", "ISOCHRONES_AMD_QUANTILES", "ISOCHRONES_AMD_HOST_SYNC")
+_SWITCHES = ("ISOCHRONES_AMD_PATH", "ISOCHRONES_AMD_SAMPLER", "ISOCHRONES_AMD_QUANTILES", "ISOCHRONES_AMD_HOST_SYNC",
+             "ISOCHRONES_AMD_TREE_RUNTIME_LEAVES")
 
 
 @pytest.fixture(autouse=True)

@@ -90,7 +90,17 @@ def main():
         for _ in range(L):
             mod.lnpost(pt)
         torch.cuda.synchronize()
-        manifest.append(dict(label="tree/posterior", kernel="k_lnpost_tree_fast", launches=L + 1, skip=2, n=n,
+        manifest.append(dict(label="tree/posterior", kernel="k_lnpost_tree_fast<3, 2>", launches=L + 1, skip=2, n=n,
+                             algorithmic_bytes_per_launch=float(2 * 384 + 2 * 3 * 128 + 56) * n))
+        # the runtime-leaf-count form of the same kernel (what trees of 5-8 stars run): per-leaf values in LDS
+        os.environ["ISOCHRONES_AMD_TREE_RUNTIME_LEAVES"] = "1"
+        mod.lnpost(pt[:4096])
+        torch.cuda.synchronize()
+        for _ in range(L):
+            mod.lnpost(pt)
+        torch.cuda.synchronize()
+        os.environ.pop("ISOCHRONES_AMD_TREE_RUNTIME_LEAVES")
+        manifest.append(dict(label="tree_runtime_leaves/posterior", kernel="k_lnpost_tree_fast<3, 0>", launches=L + 1, skip=2, n=n,
                              algorithmic_bytes_per_launch=float(2 * 384 + 2 * 3 * 128 + 56) * n))
         del mod
     if "quantiles" in cases:
