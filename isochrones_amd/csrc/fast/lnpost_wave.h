@@ -48,7 +48,7 @@ __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* l
     }
 
     // ---- lnprior ----
-    const double ld = log(dist);
+    const double ld = fast_log(dist);
     double lnp = 0.0;
     bool rejected = false;
     if (NS == 2) rejected = p[1] > p[0];
@@ -82,7 +82,7 @@ __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* l
     }
     const double dm = fma(ld, 5.0 * kInvLn10, -5.0);   // 5*log10(d/10)
     if constexpr (NB > 0) {          // NB = 0: spectroscopy / parallax only, the BC table is never touched
-        double tot[NB];
+        double tot[NB], rel[NS > 1 ? NB : 1];
         const bool okA = go && !(AV != AV) && !lds_oob(lds, A.b3, AV);
     #pragma unroll
         for (int s = 0; s < NS; ++s) {
@@ -105,16 +105,30 @@ __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* l
     #pragma unroll
                 for (int b = 0; b < NB; ++b) bc[b] = f_nan();
             }
+            // total magnitude of an unresolved system (reference utils.py:67-75: -2.5 log10 sum_c 10^(-0.4 m_c)) written
+            // relative to the primary, m_0 - 2.5 log10(1 + sum_{c>0} 10^(-0.4 (m_c - m_0))): the same number to a few ulp
+            // with one exponential less per band.  Beyond |m_0| = 700 mag (distances below 1e-140 pc or above 1e140 pc)
+            // the reference's fluxes leave the double range - they overflow to inf or fade through the subnormals to 0,
+            // and its result with them; there the sum is taken about 0 instead of m_0, i.e. exactly as the reference
+            // writes it, so that even those values and their +-inf pattern are reproduced.
     #pragma unroll
             for (int b = 0; b < NB; ++b) {
                 const double mag = star[s][3] + dm - bc[b];
-                if (NS == 1) tot[b] = mag;
-                else tot[b] = (s == 0 ? 0.0 : tot[b]) + exp10(-0.4 * mag);
+                if (NS == 1) {
+                    tot[b] = mag;
+                } else if (s == 0) {
+                    const bool far = fabs(mag) > 700.0;              // false for NaN
+                    tot[b] = far ? 0.0 : mag;
+                    rel[b] = 1.0;
+                    if (__ballot(far)) rel[b] = far ? exp10(-0.4 * mag) : 1.0;     // wave-uniform branch, never taken in practice
+                } else {
+                    rel[b] += exp10(-0.4 * (mag - tot[b]));
+                }
             }
         }
     #pragma unroll
         for (int b = 0; b < NB; ++b) {
-            const double mag = (NS == 1) ? tot[b] : -2.5 * log10(tot[b]);
+            const double mag = (NS == 1) ? tot[b] : fma(-2.5, fast_log10(rel[b]), tot[b]);
             const double r = M.mag_val[b] - mag;
             if (!MASKED || M.mag_val[b] == M.mag_val[b]) lnl += M.mag_g0[b] - r * r * M.mag_hinv[b];
         }

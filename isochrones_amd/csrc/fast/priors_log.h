@@ -40,7 +40,7 @@ __device__ __forceinline__ double ln_pdf(const DevPrior& P, double x, double lx)
     case ISO_PRIOR_FLATLOG: return outside ? -f_inf() : fma(x, kLn10, P.k1);
     case ISO_PRIOR_POWERLAW: {
         if (P.bounded && outside) return -f_inf();
-        const double l = HAS_LX ? lx : log(x);
+        const double l = HAS_LX ? lx : fast_log(x);
         return fma(P.a, l, P.k1);
     }
     case ISO_PRIOR_GAUSS: {
@@ -48,9 +48,9 @@ __device__ __forceinline__ double ln_pdf(const DevPrior& P, double x, double lx)
         const double z = (x - P.a) * P.r0;
         return (-0.5 * (z * z) + kLogInvRoot2Pi) - P.k1 - P.c;
     }
-    case ISO_PRIOR_LOGNORMAL: return lognormal_ln(P, HAS_LX ? lx : log(x));
+    case ISO_PRIOR_LOGNORMAL: return lognormal_ln(P, HAS_LX ? lx : fast_log(x));
     case ISO_PRIOR_CHABRIER: {
-        const double l = HAS_LX ? lx : log(x);
+        const double l = HAS_LX ? lx : fast_log(x);
         if (x < P.d) return lognormal_ln(P, l) - P.k3;
         if (x < P.g || x > P.h) return -f_inf();
         return fma(P.c, l, P.k5) - P.k4;
@@ -58,7 +58,7 @@ __device__ __forceinline__ double ln_pdf(const DevPrior& P, double x, double lx)
     case ISO_PRIOR_FEH: {
         if (outside) return -f_inf();
         const double pdf = feh_pdf(P, x);
-        return pdf != 0 ? log(pdf) : -f_inf();
+        return pdf != 0 ? fast_log(pdf) : -f_inf();
     }
     }
     return f_nan();
@@ -71,23 +71,23 @@ __device__ __forceinline__ double ln_call(const DevPrior& P, double x)
     switch (P.kind) {
     case ISO_PRIOR_FLAT: return outside ? -f_inf() : P.k1;
     case ISO_PRIOR_FLATLOG: return outside ? -f_inf() : fma(x, kLn10, P.k1);
-    case ISO_PRIOR_POWERLAW: return outside ? -f_inf() : fma(P.a, log(x), P.k1);
+    case ISO_PRIOR_POWERLAW: return outside ? -f_inf() : fma(P.a, fast_log(x), P.k1);
     case ISO_PRIOR_GAUSS: {
         if (outside) return -f_inf();
         const double z = (x - P.a) * P.r0;
         return (-0.5 * (z * z) + kLogInvRoot2Pi) - P.k1 - P.c;
     }
-    case ISO_PRIOR_LOGNORMAL: return (x < 0) ? -f_inf() : lognormal_ln(P, log(x));
+    case ISO_PRIOR_LOGNORMAL: return (x < 0) ? -f_inf() : lognormal_ln(P, fast_log(x));
     case ISO_PRIOR_CHABRIER: {
         if (outside) return -f_inf();
-        if (x < P.d) return (x < 0) ? -f_inf() : lognormal_ln(P, log(x)) - P.k3;
+        if (x < P.d) return (x < 0) ? -f_inf() : lognormal_ln(P, fast_log(x)) - P.k3;
         if (x < P.g || x > P.h) return -f_inf();
-        return fma(P.c, log(x), P.k5) - P.k4;
+        return fma(P.c, fast_log(x), P.k5) - P.k4;
     }
     case ISO_PRIOR_FEH: {
         if (outside) return -f_inf();
         const double pdf = feh_pdf(P, x);
-        return pdf != 0 ? log(pdf) : -f_inf();
+        return pdf != 0 ? fast_log(pdf) : -f_inf();
     }
     }
     return f_nan();
@@ -100,5 +100,5 @@ __device__ __forceinline__ double eep_term(const DevModel& M, const DevPrior& or
     if (eep < M.eep_lo || eep > M.eep_hi) return -f_inf();
     const double lc = ln_call(orig, value);
     if (lc == -f_inf()) return (deriv != deriv) ? f_nan() : -f_inf();   // 0 * deriv
-    return lc + log(deriv);   // deriv == 0 -> -inf, deriv < 0 -> NaN, NaN -> NaN
+    return lc + fast_log(deriv);   // deriv == 0 -> -inf, deriv < 0 -> NaN, NaN -> NaN
 }

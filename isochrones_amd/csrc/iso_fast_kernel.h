@@ -28,6 +28,40 @@ constexpr double kInvRoot2Pi = 0.3989422804014327;
 constexpr double kLn10 = 2.302585092994046;
 constexpr double kInvLn10 = 0.43429448190325176;
 
+// Natural logarithm for the fused kernels.  The device library's log() is correctly rounded at the price of ~100 VALU
+// instructions (76 of them fp64); a sample of the single-star model takes four logarithms, a binary with six bands twelve
+// - a fifth to a quarter of the arithmetic of a kernel that is VALU-issue bound whenever its tables are cache-resident
+// (profiles/r02: MCMC-like batches, the sampler).  This is the classic reduction x = 2^k m, m in [sqrt(1/2), sqrt(2)),
+// s = (m - 1) / (m + 1), log m = 2 s + s^3 (2/3 + ...) with the degree-14 minimax polynomial of the fdlibm family and a
+// split ln 2: ~35 instructions, error < 0.8 ulp over 2 x 10^7 arguments (tools/fast_log_check.c runs the same
+// arithmetic on the host).  Zero, negative, infinite, NaN and subnormal arguments behave as log() does.
+__device__ __forceinline__ double fast_log(double x)
+{
+    double m = __builtin_amdgcn_frexp_mant(x);            // [0.5, 1), exact (subnormals included)
+    int e = __builtin_amdgcn_frexp_exp(x);
+    const bool low = m < 0.70710678118654752440;
+    m = low ? m * 2.0 : m;
+    e = low ? e - 1 : e;
+    const double f = m - 1.0, d = 2.0 + f;
+    double r = __builtin_amdgcn_rcp(d);                   // reciprocal seed, two Newton steps, one residual correction
+    double t = fma(-d, r, 1.0);
+    r = fma(r, t, r);
+    t = fma(-d, r, 1.0);
+    r = fma(r, t, r);
+    double sq = f * r;
+    sq = fma(r, fma(-d, sq, f), sq);
+    const double z = sq * sq, w = z * z;
+    const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+    const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01), 2.857142874366239149e-01),
+                              6.666666666666735130e-01);
+    const double R = t2 + t1, hfsq = 0.5 * f * f, dk = (double)e;
+    const double v = dk * 6.93147180369123816490e-01 - ((hfsq - fma(sq, hfsq + R, dk * 1.90821492927058770002e-10)) - f);
+    const double special = (x == 0.0) ? -f_inf() : ((x > 0.0) ? x : f_nan());       // 0 -> -inf, +inf -> +inf, else NaN
+    return (x > 0.0 && x < f_inf()) ? v : special;
+}
+
+__device__ __forceinline__ double fast_log10(double x) { return fast_log(x) * kInvLn10; }
+
 #include "fast/brackets.h"
 #include "fast/gather_lane.h"
 #include "fast/priors_log.h"

@@ -53,7 +53,7 @@ struct TreeLeaves {
             for (int l = 0; l < n_leaves; ++l)
                 if (mask & (1u << l)) tot += lds_[(l * PER + 6 + band) * stride_];
         }
-        return -2.5 * log10(tot);
+        return -2.5 * fast_log10(tot);
     }
 
     __device__ __forceinline__ double prop(int leaf, int q) const
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(tree_block<NL>()) void k_lnpost_tree_fast(const Fas
                 term = -f_inf();
             } else {
                 const double lc = ln_call(T.prior_mass, S.star(l, 4)), deriv = S.star(l, 5);
-                term = (lc == -f_inf()) ? ((deriv != deriv) ? f_nan() : -f_inf()) : lc + log(deriv);
+                term = (lc == -f_inf()) ? ((deriv != deriv) ? f_nan() : -f_inf()) : lc + fast_log(deriv);
             }
             lnp += term;
         };
