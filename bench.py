@@ -165,29 +165,43 @@ def cpu_baseline(ic, mod, pars_host, wall_budget_s=4.0):
             time.sleep(0.2)                                            # let the quota period roll over
     dt = time.perf_counter() - t0
     passes = len(times)
-    n1 = min(n, 200_000)
-    s1 = np.ascontiguousarray(soa[:, :n1])
-    p1, t1 = 0, time.perf_counter()
-    while time.perf_counter() - t1 < wall_budget_s:
-        oic.lnpost(desc, s1, nthreads=1, parts=False)
-        p1 += 1
+    # B2: one thread, the reference's serial interp_mags-style loop without Python overhead, at 10^4
+    # samples (BASELINE configs[0]'s size) and over the whole batch; median of 5 / 3 passes
+    def one_thread(m, reps):
+        sm = np.ascontiguousarray(soa[:, :m])
+        oic.lnpost(desc, sm, nthreads=1, parts=False)
+        ts = []
+        for _ in range(reps):
+            t = time.perf_counter()
+            oic.lnpost(desc, sm, nthreads=1, parts=False)
+            ts.append(time.perf_counter() - t)
+        return m / float(np.median(ts))
+
+    t1 = time.perf_counter()
+    b2_small = one_thread(min(n, 10_000), 5)
+    b2_full = one_thread(n, 3)
     dt1 = time.perf_counter() - t1
-    # scalar-call mode: one sample per call through the oracle's C ABI from a Python loop - how the reference
-    # is actually driven by its samplers (published there: 69 us per call single star, numba)
-    one = np.ascontiguousarray(soa[:, :1])
-    for _ in range(200):
-        oic.lnpost(desc, one, nthreads=1, parts=False)
+    # B1, scalar-call mode: one sample per call through the oracle's C ABI from a Python loop - how the reference
+    # is actually driven by its samplers (published there: 69 us per call single star, numba); 10^4 calls
+    one = [np.ascontiguousarray(soa[:, k:k + 1]) for k in range(min(n, 10_000))]
+    for k in range(200):
+        oic.lnpost(desc, one[k % len(one)], nthreads=1, parts=False)
     tc = time.perf_counter()
-    for k in range(3000):
-        oic.lnpost(desc, one, nthreads=1, parts=False)
-    scalar_us = (time.perf_counter() - tc) / 3000 * 1e6
+    for col in one:
+        oic.lnpost(desc, col, nthreads=1, parts=False)
+    scalar_us = (time.perf_counter() - tc) / len(one) * 1e6
+    p1, n1 = 3, n
     return dict(value=n / min(times), unit="evals/s", cores=cores, kind="port", scalar_call_us=scalar_us,
                 sample="best of %d passes over the same %d-sample batch (%.1f s wall), C restatement of the reference "
                        "(oracle/iso_oracle.c), OpenMP static over %d threads; container CPU quota: %s; 1-thread "
                        "figure: %d passes over the first %d samples (%.1f s)"
                        % (passes, n, dt, cores, ("%.1f CPUs" % quota) if quota else "none", p1, n1, dt1),
                 value_median_pass=n / float(np.median(times)), cpu_quota_cores=quota,
-                value_1thread=p1 * n1 / dt1), out
+                value_1thread=b2_full,
+                modes={"B1_scalar_call": {"us_per_call": scalar_us, "calls": len(one), "evals_per_s": 1e6 / scalar_us},
+                       "B2_one_thread_1e4": {"evals_per_s": b2_small}, "B2_one_thread_full_batch": {"evals_per_s": b2_full},
+                       "B3_all_cores_full_batch": {"evals_per_s": n / min(times), "median_pass": n / float(np.median(times)),
+                                                   "threads": cores}}), out
 
 
 def catalog_leg(rank, world, barrier, dist, reduce_device, sizes=(10_000, 400_000), nwalkers=32, nburn=150, niter=100):
@@ -401,6 +415,29 @@ def main():
             del mod3, ic3, sets3
         except Exception as e:       # noqa: BLE001 - a secondary leg must not take the benchmark line down
             result["cfg3_binary_6_bands"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        # BASELINE configs[3]: ensemble MCMC, 256 walkers x 5000 steps on the cfg-2 star with the device-resident sampler
+        # (proposal + fused lnpost + accept in one persistent kernel; chain stored)
+        try:
+            from isochrones_amd.sampler import FusedEnsembleSampler
+            truth = np.array([1.0, 355.0, 0.0, 100.0, 0.1])
+            p0 = truth + np.array([0.01, 2.0, 0.02, 1.0, 0.02]) * np.random.default_rng(1).standard_normal((256, 5))
+            p0[:, 4] = np.abs(p0[:, 4])
+            fs = FusedEnsembleSampler(mod, 256, seed=2)
+            fs.run_mcmc(p0, 50, store=False)
+            walls = []
+            for _ in range(3):
+                fs.reset()
+                torch.cuda.synchronize()
+                t_s = time.perf_counter()
+                fs.run_mcmc(p0, 5000, store=True)
+                torch.cuda.synchronize()
+                walls.append(time.perf_counter() - t_s)
+            result["cfg4_mcmc_256x5000"] = {"gpu_wall_s": min(walls), "us_per_step": min(walls) / 5000 * 1e6,
+                                            "lnpost_evals": 256 * 5000, "acceptance": float(fs.acceptance_fraction.mean()),
+                                            "finite_chain": bool(torch.isfinite(fs._lnprob).all())}
+            fs.close()
+        except Exception as e:       # noqa: BLE001
+            result["cfg4_mcmc_256x5000"] = {"error": "%s: %s" % (type(e).__name__, e)}
         # end to end through the host-array API (numpy in, numpy out: H2D of 40 B + D2H of 8 B per sample
         # around the same kernel) - reported for the record, never `value`
         mod.lnpost(pars_host)                        # first call of a size allocates the pinned / device staging
@@ -431,6 +468,11 @@ def main():
             base["finite_fraction"] = float(fin.mean())
             result["cpu_baseline"] = base
             result["speedup_vs_cpu_all_cores"] = value / base["value"]
+            if "gpu_wall_s" in result.get("cfg4_mcmc_256x5000", {}):
+                # the same 1.28 x 10^6 evaluations as one-sample-per-call host calls (how emcee drives the reference)
+                c4 = result["cfg4_mcmc_256x5000"]
+                c4["cpu_scalar_calls_estimated_s"] = base["scalar_call_us"] * 1e-6 * c4["lnpost_evals"]
+                c4["reference_published_estimate_s"] = 69e-6 * c4["lnpost_evals"]
         else:
             result["cpu_baseline"] = None
         print(json.dumps(result))

@@ -78,5 +78,9 @@ def test_bench_single_rank_default_line_has_roofline_and_cpu_baseline():
         b = leg["roofline"]
         assert b["bound"] in ("hbm", "valu") and 0.3 < b["frac"] <= 1.0, b
         assert b["source"].startswith("static") and 0 < b["hbm"]["frac"] <= 1.0 and 0 < b["valu"]["frac"] <= 1.0
+    c4 = r["cfg4_mcmc_256x5000"]
+    assert "error" not in c4 and c4["finite_chain"] and 0.1 < c4["acceptance"] < 0.8 and c4["gpu_wall_s"] < 2.0
+    assert c4["cpu_scalar_calls_estimated_s"] > c4["gpu_wall_s"]
+    assert set(cb["modes"]) == {"B1_scalar_call", "B2_one_thread_1e4", "B2_one_thread_full_batch", "B3_all_cores_full_batch"}
     assert r["cfg3_binary_6_bands"]["posterior"]["roofline"]["bound"] == "valu"          # cache-resident batch
     assert r["cfg3_binary_6_bands"]["prior_valid"]["roofline"]["bound"] == "hbm"

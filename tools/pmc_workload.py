@@ -25,7 +25,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--manifest", required=True)
     ap.add_argument("--launches", type=int, default=12)
-    ap.add_argument("--cases", default="cfg2,cfg3,generic,astero,tree,quantiles")
+    ap.add_argument("--cases", default="cfg2,cfg3,generic,astero,tree,quantiles,sampler")
     ap.add_argument("--n", type=int, default=1_000_000)
     args = ap.parse_args()
     import torch
@@ -125,6 +125,30 @@ def main():
         torch.cuda.synchronize()
         manifest.append(dict(label="quantiles/100000x32x100", kernel="k_chain_quantiles_wave", launches=L + 1, skip=1,
                              n=S * 5, algorithmic_bytes_per_launch=float(S) * W * T * 5 * 8))
+    if "sampler" in cases:
+        # the catalog sampler in its throughput form: one launch per half-step over 2 x 10^5 stars x 16 moves
+        from isochrones_amd.catalog import CatalogPosterior, initial_positions
+        from isochrones_amd.sampler import FusedEnsembleSampler
+        bands = ["G", "BP", "RP"]
+        ic = ia.synthetic_track(bands=bands)
+        S, W = 200_000, 32
+        cat, _ = ia.synthetic_catalog(ic, S, bands=bands, seed=7, mag_unc=0.01)
+        post = CatalogPosterior.from_catalog(cat, ic)
+        pos, lnp, failed = initial_positions(post, W, rng_seed=0)
+        if bool(failed.any()):
+            good = int(torch.nonzero(~failed)[0])
+            pos[failed] = pos[good]
+            lnp[failed] = 0.0
+        os.environ["ISOCHRONES_AMD_SAMPLER"] = "stepwise"
+        fs = FusedEnsembleSampler(post, W, seed=1)
+        pos, lnp = fs.run_mcmc(pos, 100, lnprob0=lnp, store=False)          # burn in: walkers settle on their posteriors
+        torch.cuda.synchronize()
+        fs.run_mcmc(pos, L // 2, lnprob0=lnp, store=False)
+        torch.cuda.synchronize()
+        os.environ.pop("ISOCHRONES_AMD_SAMPLER")
+        # 816 B per move: 384 (model cell) + 3 x 128 (BC) + position in/out
+        manifest.append(dict(label="sampler_stepwise/200000x32", kernel="k_stretch_half<0, 1, 3", launches=2 * (100 + L // 2),
+                             skip=200, n=S * W // 2, algorithmic_bytes_per_launch=float(S * W // 2) * (384 + 3 * 128 + 2 * 48)))
     json.dump(manifest, open(args.manifest, "w"), indent=1)
     print("manifest:", args.manifest, [m["label"] for m in manifest])
 

@@ -20,3 +20,7 @@ if "host_array_path" in r:
 for k, v in (r.get("catalog") or {}).items():
     if isinstance(v, dict) and "stars_per_s" in v:
         print("catalog %s: %.4f s = %.3g stars/s (first call %.3f s)" % (k, v["wall_s"], v["stars_per_s"], v.get("first_call_wall_s") or 0))
+if "cfg4_mcmc_256x5000" in r:
+    print("cfg4", r["cfg4_mcmc_256x5000"])
+if r.get("cpu_baseline"):
+    print("cpu modes", {k: {kk: (round(vv, 3) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in r["cpu_baseline"]["modes"].items()})
