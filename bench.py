@@ -378,6 +378,15 @@ def main():
                      "kernel_ms": kernel_ms, "bytes_per_eval": BYTES_PER_EVAL_SINGLE_1BAND,
                      "bounds": bounds("cfg2/%s" % args.workload, args.n, kernel_ms, bytes_per_launch)},
     }
+    if not args.no_extras and not args.no_catalog:
+        # BASELINE configs[4] on the same ranks: a synthetic catalog split over the GPUs with the reference's
+        # batch_starfit rule, every rank fitting its stars with the device-resident sampler.  No data-path
+        # collective; the same barrier + max-over-ranks timing as above.  Reported next to the metric, never `value`.
+        try:
+            result["catalog"] = catalog_leg(rank, world, barrier, dist if distributed else None,
+                                            "cuda" if backend == "nccl" else "cpu")
+        except Exception as e:       # noqa: BLE001 - the extra leg must not take the benchmark line down
+            result["catalog"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if world == 1 and not args.no_extras:
         # secondary workloads, same kernel, same launch count/3 (reported, never `value`)
         extras = {}
@@ -447,15 +456,6 @@ def main():
         dt_h = (time.perf_counter() - t_h) / 5
         result["host_array_path"] = {"ms": dt_h * 1e3, "evals_per_s": args.n / dt_h,
                                      "note": "mod.lnpost(numpy [N,5]) -> numpy [N], PCIe transfers included"}
-    if not args.no_extras and not args.no_catalog:
-        # BASELINE configs[4] on the same ranks: a synthetic catalog split over the GPUs with the reference's
-        # batch_starfit rule, every rank fitting its stars with the device-resident sampler.  No data-path
-        # collective; the same barrier + max-over-ranks timing as above.  Reported next to the metric, never `value`.
-        try:
-            result["catalog"] = catalog_leg(rank, world, barrier, dist if distributed else None,
-                                            "cuda" if backend == "nccl" else "cpu")
-        except Exception as e:       # noqa: BLE001 - the extra leg must not take the benchmark line down
-            result["catalog"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             base, ref = cpu_baseline(ic, mod, pars_host)

@@ -7,7 +7,7 @@ mkdir -p $OUT
 python bench.py > $OUT/bench_cfg2_1gpu.json 2> $OUT/bench.err
 python bench_configs.py --configs cfg1,cfg3,cfg4,cfg5,tree,primitives,astero,nested,published > $OUT/bench_configs_1gpu.jsonl 2> $OUT/bench_configs.err
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/prof -- python $ROOT/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-catalog > $ROOT/$OUT/prof_bench.json 2> $ROOT/$OUT/prof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/prof -- python $ROOT/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-extras > $ROOT/$OUT/prof_bench.json 2> $ROOT/$OUT/prof.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/prof_all -- python $ROOT/bench_configs.py --configs cfg3,cfg4,cfg5,tree,primitives,astero > $ROOT/$OUT/prof_all.jsonl 2> $ROOT/$OUT/prof_all.err
 cd $ROOT
 for d in prof prof_all; do
