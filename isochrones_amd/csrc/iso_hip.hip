@@ -1264,11 +1264,45 @@ namespace {
 // the context's pinned, device-mapped staging area (host view + device view); caller holds ctx->stage_mu
 int ctx_stage(iso_ctx* ctx, double** host, double** dev)
 {
-    if (!ctx->h_stage)
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_stage), sizeof(double) * ISO_CTX_STAGE_DOUBLES,
+    if (!ctx->h_stage) {
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_stage), sizeof(double) * (ISO_CTX_STAGE_DOUBLES + 8),
                               hipHostMallocMapped));
+        ctx->h_stage[ISO_CTX_STAGE_DOUBLES] = 0.0;
+        ctx->stage_seq = 0;
+    }
     *host = ctx->h_stage;
     HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(dev), ctx->h_stage, 0));
+    return ISO_OK;
+}
+
+// Completion of the launches a *_host entry point has put on the default stream: a one-thread kernel behind them
+// stores a sequence number into the mapped staging area and the host spins on it - 10 us instead of the 13 us of a
+// hipStreamSynchronize per round trip (tools/sync_probe.hip).  After 2 ms without the flag (a fault, a very large
+// batch) the stream is synchronised, which also surfaces the error.
+__global__ void k_signal_done(volatile unsigned long long* flag, unsigned long long seq)
+{
+    __threadfence_system();
+    *flag = seq;
+    __threadfence_system();
+}
+
+int ctx_wait(iso_ctx* ctx, double* h, double* d)
+{
+    if (getenv("ISOCHRONES_AMD_HOST_SYNC")) {
+        HIP_TRY(hipStreamSynchronize(nullptr));
+        return ISO_OK;
+    }
+    const unsigned long long seq = ++ctx->stage_seq;
+    volatile unsigned long long* h_flag = reinterpret_cast<volatile unsigned long long*>(h + ISO_CTX_STAGE_DOUBLES);
+    hipLaunchKernelGGL(k_signal_done, dim3(1), dim3(1), 0, nullptr,
+                       reinterpret_cast<volatile unsigned long long*>(d + ISO_CTX_STAGE_DOUBLES), seq);
+    HIP_TRY(hipGetLastError());
+    const auto t0 = std::chrono::steady_clock::now();
+    bool seen = false;
+    for (uint64_t spins = 0; !(seen = (*h_flag == seq)); ++spins)
+        if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+    std::atomic_thread_fence(std::memory_order_acquire);
+    if (!seen) HIP_TRY(hipStreamSynchronize(nullptr));
     return ISO_OK;
 }
 }  // namespace
@@ -1295,7 +1329,8 @@ int iso_interp_host(iso_table* t, const double* x, int64_t n, const int32_t* ico
         }
         rc = iso_interp(t, xp, c, icols, k, d + nd * c, nullptr);
         if (rc != ISO_OK) return rc;
-        HIP_TRY(hipStreamSynchronize(nullptr));
+        rc = ctx_wait(t->ctx, h, d);
+        if (rc != ISO_OK) return rc;
         std::memcpy(out + done * k, h + nd * c, sizeof(double) * c * k);
     }
     return ISO_OK;
@@ -1320,7 +1355,8 @@ int iso_interp_mag_host(iso_ic* ic, const double* pars, int64_t n, const int32_t
         double *dT = d + 5 * c, *dg = dT + c, *df = dg + c, *dm = df + c;
         rc = iso_interp_mag(ic, d, 5, 1, c, bc_cols, nb, dT, dg, df, (mags && nb > 0) ? dm : nullptr, nullptr);
         if (rc != ISO_OK) return rc;
-        HIP_TRY(hipStreamSynchronize(nullptr));
+        rc = ctx_wait(ic->ctx, h, d);
+        if (rc != ISO_OK) return rc;
         if (Teff) std::memcpy(Teff + done, h + 5 * c, sizeof(double) * c);
         if (logg) std::memcpy(logg + done, h + 6 * c, sizeof(double) * c);
         if (feh) std::memcpy(feh + done, h + 7 * c, sizeof(double) * c);
@@ -1347,7 +1383,8 @@ int iso_interp_eep_host(iso_eep_table* t, const double* age, const double* feh, 
         std::memcpy(h + 2 * c, mass + done, sizeof(double) * c);
         rc = iso_interp_eep(t, d, d + c, d + 2 * c, c, d + 3 * c, nullptr);
         if (rc != ISO_OK) return rc;
-        HIP_TRY(hipStreamSynchronize(nullptr));
+        rc = ctx_wait(t->ctx, h, d);
+        if (rc != ISO_OK) return rc;
         std::memcpy(out + done, h + 3 * c, sizeof(double) * c);
     }
     return ISO_OK;
@@ -1712,7 +1749,8 @@ int iso_tree_lnpost_host(iso_tree_model* m, const double* pars, int64_t n, doubl
         rc = iso_tree_lnpost(m, d, np_, 1, c, lnpost_out ? dpost : nullptr, lnprior_out ? dprior : nullptr,
                              lnlike_out ? dlike : nullptr, nullptr);
         if (rc != ISO_OK) return rc;
-        HIP_TRY(hipStreamSynchronize(nullptr));
+        rc = ctx_wait(ctx, h, d);
+        if (rc != ISO_OK) return rc;
         const double* hp = h + c * np_;
         if (lnpost_out) std::memcpy(lnpost_out + done, hp, sizeof(double) * c);
         if (lnprior_out) std::memcpy(lnprior_out + done, hp + c, sizeof(double) * c);

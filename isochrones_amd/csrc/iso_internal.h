@@ -152,8 +152,9 @@ struct iso_ctx {
     // + one synchronise per call, kernels read and write host memory through PCIe); lazily allocated
     double* h_stage;
     std::mutex stage_mu;
+    unsigned long long stage_seq;    // sequence number of the completion flag kept behind the staging area
 };
-constexpr int64_t ISO_CTX_STAGE_DOUBLES = 1 << 17;      // 1 MiB
+constexpr int64_t ISO_CTX_STAGE_DOUBLES = 1 << 17;      // 1 MiB (+ 8 doubles for the completion flag)
 
 struct iso_table {
     int device;
