@@ -726,3 +726,48 @@ def _ic_for_host_test():
         _HOST_IC.append(ia.synthetic_track(bands=("V", "J", "K"), fehs=fehs, masses=masses, eeps=np.arange(300.0, 420.0),
                                            limits=dict(mass=(0.7, 2.0), feh=(-1.0, 0.5), age=(5, 10.13)), eep_bounds=(300, 419)))
     return _HOST_IC[0]
+
+
+def test_tables_built_by_the_ingest_route_drive_the_kernels():
+    """Row f1 end to end: raw MIST-like frames -> ingest (bit-identical to the reference's grid classes, CPU test
+    test_ingest_golden.py) -> device interpolator -> interp_value / interp_mag / lnpost, against the oracle on the
+    dense tables the *reference* built from the same frames (tests/golden/ingest.npz: track_grid, bc_grid)."""
+    import pandas as pd
+    from isochrones_amd import ingest
+    from isochrones_amd.models import BolometricCorrectionGrid, EvolutionTrackGrid, EvolutionTrackInterpolator
+    from oracle import oracle as orc
+    g = fx.load("ingest")
+    raw = pd.DataFrame(g["track_raw"], columns=[str(c) for c in g["track_raw_columns"]])
+    model = ingest.model_table_from_raw(raw, tracks=True)
+    bands = [str(b) for b in g["bc_bands"]]
+    frames = [(g["bc_index"], g["bc_%s_values" % p], [str(c) for c in g["bc_%s_columns" % p]]) for p in ("UBVRIplus", "WISE")]
+    bc = ingest.bc_table_from_frames(frames, bands)
+    ax = model.index_columns
+    ic = EvolutionTrackInterpolator(EvolutionTrackGrid(model, limits=dict(mass=(ax[1][0], ax[1][-1]), feh=(ax[0][0], ax[0][-1]),
+                                                                         age=(5, 10.13))),
+                                    BolometricCorrectionGrid(bc, bands=bands), bands=bands, eep_bounds=(1, ax[2][-1]))
+    # the oracle sees the reference's own arrays (column order of the reference's frames)
+    ref_cols = [str(c) for c in g["track_columns"]]
+    ref_bands = [str(c) for c in g["bc_columns"]]
+    ci = {c: i for i, c in enumerate(ref_cols)}
+    oic = orc.OracleIC(0, orc.OracleTable(g["track_grid"], [g["track_axes%d" % k] for k in range(3)]),
+                       orc.OracleTable(g["bc_grid"], [g["bc_axes%d" % k] for k in range(4)]),
+                       [ci["Teff"], ci["logg"], ci["feh"], ci["Mbol"]], [ci["age"], ci["dt_deep"]], [ci["nu_max"], ci["delta_nu"]])
+    rng = np.random.default_rng(5)
+    n = 20_000
+    pars = np.column_stack([rng.uniform(ax[1][0] - 0.05, ax[1][-1] + 0.05, n), rng.uniform(0.5, ax[2][-1] + 1, n),
+                            rng.uniform(ax[0][0] - 0.05, ax[0][-1] + 0.05, n), rng.uniform(5, 500, n), rng.uniform(-0.02, 1.02, n)])
+    want_T, want_g, want_f, want_m = oic.interp_mag(pars.T.copy(), [ref_bands.index(b) for b in ("J", "G", "W1")], nthreads=8)
+    T, gg, f, m = ic.interp_mag([pars[:, j] for j in range(5)], ["J", "G", "W1"])
+    fx.assert_close(T, want_T, 1e-12, what="Teff")
+    fx.assert_close(m, want_m, 1e-11, atol=1e-12, what="mags")
+    assert np.isfinite(want_m).all(axis=1).sum() > n // 10 and np.isnan(want_T).sum() > n // 50        # ragged: both occur
+    mod = ia.SingleStarModel(ic, Teff=(5700, 100), J=(9.0, 0.03), W1=(8.5, 0.05), parallax=(8.0, 0.2))
+    desc = mod.model_desc()
+    # the descriptor's band columns index this build's BC table; the oracle's table is in the reference's column order
+    for k in range(desc.n_bands):
+        desc.bc_cols[k] = ref_bands.index(bc.columns[desc.bc_cols[k]])
+    want = oic.lnpost(desc, pars.T.copy(), nthreads=8)
+    fx.assert_close(mod.lnpost(pars), want[0], RTOL, atol=ATOL, what="lnpost")
+    fx.assert_close(mod.lnprior(pars), want[1], RTOL, atol=ATOL, what="lnprior")
+    assert np.isfinite(want[0]).sum() > 200
