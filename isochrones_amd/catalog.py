@@ -561,7 +561,14 @@ def _shard_fingerprint(catalog, mine, N, fit_kwargs):
     h.update(repr((int(N), tuple(catalog.bands), tuple(catalog.props))).encode())
     h.update(repr(sorted((k, repr(v)) for k, v in fit_kwargs.items() if k != "timings")).encode())
     from .priors import prior_to_spec
-    h.update(repr(sorted((k, repr(prior_to_spec(v))) for k, v in catalog._prior_settings.items())).encode())
+
+    def spec(v):
+        try:
+            return repr(prior_to_spec(v))
+        except TypeError:            # a prior class without a plain-data form: its own repr has to do
+            return repr(v)
+
+    h.update(repr(sorted((k, spec(v)) for k, v in catalog._prior_settings.items())).encode())
     return h.hexdigest()
 
 

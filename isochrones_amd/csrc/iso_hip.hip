@@ -25,6 +25,8 @@
 #include <hip/hip_runtime.h>
 #include <atomic>
 #include <chrono>
+#include <exception>
+#include <thread>
 
 #include <cmath>
 #include <cstdint>
@@ -973,10 +975,13 @@ void launch_lnpost(const iso_model* m, dim3 g, dim3 b, size_t shmem, hipStream_t
 }
 
 int enqueue_lnpost(iso_model* m, const double* pars, int64_t stride_n, int64_t stride_p, int64_t n,
-                   double* lnpost_out, double* lnprior_out, double* lnlike_out, hipStream_t s)
+                   double* lnpost_out, double* lnprior_out, double* lnlike_out, hipStream_t s,
+                   unsigned long long* done_flag = nullptr, unsigned long long done_seq = 0)
 {
     if (m->fast_ok) {
         FastArgs F = m->fast;
+        F.done_flag = done_flag;        // single-workgroup host callbacks only (iso_lnpost_host)
+        F.done_seq = done_seq;
         F.pars = pars;
         F.stride_n = stride_n;
         F.stride_p = stride_p;
@@ -1057,12 +1062,20 @@ static int lnpost_host_pipelined(iso_model* m, const double* pars, int64_t n, do
     double* h_out[3] = {lnpost_out, lnprior_out, lnlike_out};
     const int64_t nchunks = (n + CH - 1) / CH;
     std::vector<hipEvent_t> ev((size_t)nchunks, nullptr);
-    for (hipEvent_t& e : ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (hipEvent_t& e : ev) {
+        const hipError_t ce = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+        if (ce != hipSuccess) {
+            for (hipEvent_t& made : ev)
+                if (made) (void)hipEventDestroy(made);
+            return fail(ISO_ERR_HIP, std::string("iso_lnpost_host: hipEventCreate: ") + hipGetErrorString(ce));
+        }
+    }
     std::atomic<int64_t> issued{0};
     std::atomic<int> worker_err{(int)hipSuccess};
     std::atomic<bool> abort_flag{false};
     const int device = m->device;
-    std::thread worker([&] {
+    std::thread worker;
+    auto copy_out = [&] {
         (void)hipSetDevice(device);
         for (int64_t k = 0; k < nchunks; ++k) {
             while (issued.load(std::memory_order_acquire) <= k) {
@@ -1078,7 +1091,13 @@ static int lnpost_host_pipelined(iso_model* m, const double* pars, int64_t n, do
             for (int o = 0; o < 3; ++o)
                 if (h_out[o]) std::memcpy(h_out[o] + off, staged[o] + off, sizeof(double) * c);
         }
-    });
+    };
+    try {
+        worker = std::thread(copy_out);
+    } catch (const std::exception& ex) {                   // no thread to be had: nothing crosses the C ABI as an exception
+        for (hipEvent_t& ev_k : ev) (void)hipEventDestroy(ev_k);
+        return fail(ISO_ERR_NOMEM, std::string("iso_lnpost_host: cannot start the copy-out thread: ") + ex.what());
+    }
     int rc = ISO_OK;
     hipError_t e = hipSuccess;
     for (int64_t k = 0; k < nchunks && rc == ISO_OK && e == hipSuccess; ++k) {
@@ -1140,18 +1159,8 @@ int iso_lnpost_host(iso_model* m, const double* pars, int64_t n, double* lnpost_
         // mapped memory after its results and the host spins on it; everything else synchronises the stream
         const bool flagged = m->fast_ok && c <= BLOCK && !getenv("ISOCHRONES_AMD_HOST_SYNC");
         const unsigned long long seq = ++m->stage_seq;
-        int rc;
-        if (flagged) {
-            const FastArgs keep = m->fast;
-            m->fast.done_flag = d_flag;
-            m->fast.done_seq = seq;
-            rc = enqueue_lnpost(m, d_pars, np_, 1, c, lnpost_out ? d_post : nullptr, lnprior_out ? d_prior : nullptr,
-                                lnlike_out ? d_like : nullptr, nullptr);
-            m->fast = keep;
-        } else {
-            rc = enqueue_lnpost(m, d_pars, np_, 1, c, lnpost_out ? d_post : nullptr, lnprior_out ? d_prior : nullptr,
-                                lnlike_out ? d_like : nullptr, nullptr);
-        }
+        const int rc = enqueue_lnpost(m, d_pars, np_, 1, c, lnpost_out ? d_post : nullptr, lnprior_out ? d_prior : nullptr,
+                                      lnlike_out ? d_like : nullptr, nullptr, flagged ? d_flag : nullptr, seq);
         if (rc != ISO_OK) return rc;
         bool seen = false;
         if (flagged) {
