@@ -61,7 +61,7 @@ __device__ __forceinline__ void stretch_move(const FastArgs& A, const StretchArg
     for (int q = 0; q < NP; ++q) {
         xk[q] = pos[lsrc * NP + q];
         const double xj = pos[lp * NP + q];
-        y[q] = xj + z * (xk[q] - xj);
+        y[q] = fma(z, xk[q] - xj, xj);
     }
     const double lold = lnp[lsrc];
     const DevModel& M = A.m[S.multi ? star : 0];
@@ -84,25 +84,105 @@ __device__ __forceinline__ void stretch_move(const FastArgs& A, const StretchArg
 }
 
 // step-wise form: one launch = one half-step of every ensemble (grid over stars x W/2 walkers);
-// the throughput form for catalogs large enough to fill the chip
+// the throughput form for catalogs large enough to fill the chip.
+//
+// Its occupancy is bound by registers, and what a move carries across the evaluation of its proposal - the walker's
+// own position, the stretch factor, the acceptance uniform, the old lnpost, five array addresses - costs 32 of them
+// (124 against the 92 of the batch kernel on the same model: 4 instead of 5 waves per SIMD, and the kernel is
+// latency-bound: profiles/r02).  So the move is built twice from the thread index: once to form the proposal, and
+// again after the evaluation (the index passes through an empty asm statement there, so nothing derived from it can
+// be kept) to decide and store.  Same instructions on the same inputs both times: the chain is bit-identical to the
+// persistent form's.
+struct MoveIds {
+    bool active;
+    int64_t star;
+    int lr, lp;          // own row / partner row inside the ensemble
+    double z, u2;
+};
+
+__device__ __forceinline__ MoveIds move_ids(const StretchArgs& S, int tid)
+{
+    MoveIds m;
+    const int64_t t0 = (int64_t)blockIdx.x * BLOCK + tid;
+    m.active = t0 < S.n_active;
+    const uint32_t t = (uint32_t)(m.active ? t0 : (S.n_active - 1));       // the host keeps n_active below 2^31 here
+    const uint32_t h = (uint32_t)(S.W >> 1);
+    const uint32_t star = t / h;
+    const int k = (int)(t - star * h);
+    m.star = star;
+    m.lr = (S.half ? (int)h : 0) + k;
+    const int64_t row = (int64_t)star * S.W + m.lr;
+    uint32_t rnd[4];
+    philox4x32_10((uint32_t)(2u * S.step + (uint32_t)S.half), (uint32_t)row, (uint32_t)((uint64_t)row >> 32), 0x51u,
+                  (uint32_t)S.seed, (uint32_t)(S.seed >> 32), rnd);
+    const int j = (int)(((uint64_t)rnd[0] * (uint64_t)h) >> 32);
+    m.lp = (S.half ? 0 : (int)h) + j;
+    const double u1 = ((double)rnd[1] + (double)(rnd[2] & 0xFFFFu) * (1.0 / 65536.0)) * (1.0 / 4294967296.0);
+    m.u2 = ((double)rnd[3] + (double)(rnd[2] >> 16) * (1.0 / 65536.0) + 0.5 / 65536.0) * (1.0 / 4294967296.0);
+    const double zr = (S.a - 1.0) * u1 + 1.0;
+    m.z = zr * zr / S.a;
+    return m;
+}
+
+// five waves per SIMD up to 7 bands (93-96 registers, at most 12 B of scratch); beyond that the evaluation itself
+// needs 138-168 registers and the cap would only spill
+constexpr int stretch_half_waves(int nb) { return nb <= 7 ? 5 : 1; }
+
 template <int KIND, int NS, int NB, bool ASTERO = false>
-__global__ __launch_bounds__(BLOCK) void k_stretch_half(const FastArgs A, const StretchArgs S)
+__global__ __launch_bounds__(BLOCK, stretch_half_waves(NB)) void k_stretch_half(const FastArgs A, const StretchArgs S)
 {
     extern __shared__ double lds[];
     for (int j = threadIdx.x; j < A.axes_len; j += BLOCK) lds[j] = A.axes_blob[j];
     __syncthreads();
     const CoopLds L = coop_lds<NB>(lds, A.axes_len);
-    const int64_t t0 = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    const bool active = t0 < S.n_active;
-    const int64_t t = active ? t0 : (S.n_active - 1);
     constexpr int NP = NS + 4;
-    const int h = S.W >> 1;
-    const int64_t star = t / h;
-    const int k = (int)(t - star * h);
-    const int64_t r0 = star * S.W;
-    stretch_move<KIND, NS, NB, ASTERO>(A, S, lds, L, active, star, k, S.half, S.step, S.pos + r0 * NP, S.lnp + r0,
-                               S.accepted ? S.accepted + r0 : nullptr, S.chain_pos ? S.chain_pos + r0 * S.chain_rs : nullptr,
-                               S.chain_lnp ? S.chain_lnp + r0 : nullptr);
+    // ---- the proposal ----
+    double y[NP];
+    bool active;
+    const DevModel* Mp;
+    {
+        const MoveIds m = move_ids(S, (int)threadIdx.x);
+        const double* __restrict__ pos = S.pos + m.star * S.W * NP;
+        const int lsrc = m.active ? m.lr : m.lp;      // helper lanes evaluate the partner's position and discard it
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            const double xk = pos[lsrc * NP + q], xj = pos[m.lp * NP + q];
+            y[q] = fma(m.z, xk - xj, xj);
+        }
+        active = m.active;
+        Mp = A.m + (S.multi ? m.star : 0);
+    }
+    double lnp_unused, lnl_unused;
+    const double lnew = lnpost_wave<KIND, NS, NB, true, ASTERO, true>(A, lds, L, active, *Mp, y, false, lnp_unused, lnl_unused);
+    // ---- decide and store: everything about the move is rebuilt from the thread index ----
+    int tid = (int)threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const MoveIds m = move_ids(S, tid);
+    if (!m.active) return;
+    double* __restrict__ pos = S.pos + m.star * S.W * NP;
+    double* __restrict__ lnp = S.lnp + m.star * S.W;
+    double xk[NP], yy[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        xk[q] = pos[m.lr * NP + q];
+        const double xj = pos[m.lp * NP + q];
+        yy[q] = fma(m.z, xk[q] - xj, xj);
+    }
+    const double lold = lnp[m.lr];
+    const double lnq = (NP - 1) * log(m.z) + lnew - lold;
+    const bool acc = isfinite(lnew) && (log(m.u2) < lnq);
+    if (acc) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) pos[m.lr * NP + q] = yy[q];
+        lnp[m.lr] = lnew;
+        if (S.accepted) S.accepted[m.star * S.W + m.lr] += 1;
+    }
+    if (S.chain_pos) {
+        double* __restrict__ cp = S.chain_pos + (m.star * S.W + m.lr) * S.chain_rs;
+#pragma unroll
+        for (int q = 0; q < NP; ++q) cp[q * S.chain_ps] = acc ? yy[q] : xk[q];
+    }
+    if (S.chain_lnp) S.chain_lnp[m.star * S.W + m.lr] = acc ? lnew : lold;
 }
 
 // persistent form: ALL S.nsteps iterations in a single launch.  A workgroup owns G = max(1, BLOCK / (W/2))

@@ -1843,6 +1843,7 @@ int iso_sampler_run(iso_sampler* sp, double* pos, double* lnp, int nsteps, doubl
     S.W = sp->W;
     S.multi = sp->multi;
     S.n_active = sp->n_ensembles * (sp->W / 2);
+    if (S.n_active >= (int64_t(1) << 31)) return fail(ISO_ERR_INVALID, "iso_sampler_run: more than 2^31 moves per half-step");
     S.a = sp->a;
     S.seed = sp->seed;
     S.chain_rs = sp->chain_layout == ISO_CHAIN_PARAM_MAJOR ? 1 : sp->n_params;
