@@ -713,6 +713,15 @@ def run_ingest_cases():
 
         got = [resolve(b) for b in names]
         out.update(band_names=np.array(names), band_phot=np.array([p for p, _ in got]), band_column=np.array([c for _, c in got]))
+    # the reference orders the track columns through a set() and joins the BC frames in set order, both of which depend on
+    # the interpreter's string hash seed: store every table with its columns sorted by name, so that regenerating this
+    # file gives the same bytes
+    for pre, grid_keys in (("track", ("track_values", "track_grid")), ("iso", ("iso_values", "iso_grid")), ("bc", ("bc_grid",))):
+        names = [str(c) for c in out[pre + "_columns"]]
+        order = np.argsort(names)
+        out[pre + "_columns"] = np.array([names[k] for k in order])
+        for key in grid_keys:
+            out[key] = np.ascontiguousarray(out[key][..., order])
     np.savez_compressed(os.path.join(OUT, "ingest.npz"), **out)
 
 
