@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 from oracle import ref_harness as rh          # noqa: E402
 from isochrones_amd import grids as G         # noqa: E402
 
-OUT = os.path.join(ROOT, "tests", "golden")
+OUT = os.environ.get("ISO_GOLDEN_OUT") or os.path.join(ROOT, "tests", "golden")     # (override: tests/test_goldens_reproducible.py)
 BANDS = ("J", "H", "K", "G", "BP", "RP", "V")
 
 
