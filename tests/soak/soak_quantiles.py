@@ -33,9 +33,12 @@ while time.time() - t0 < budget:
         x[rng.random(x.shape) < 0.01] = -np.inf
     nq = int(rng.integers(1, 9))
     qs = np.ascontiguousarray(rng.choice([0.0, 1.0, 0.5, 0.16, 0.84, 0.025, 0.975, 1 / 3, 0.999, rng.random()], size=nq))
-    chain = torch.as_tensor(x, device="cuda")
+    # both chain layouts: row-major [step][row][param] and parameter-major [step][param][row]
+    layout = int(rng.integers(0, 2))
+    chain = torch.as_tensor(x if layout == _cabi.CHAIN_ROW_MAJOR else np.ascontiguousarray(x.transpose(0, 2, 1)), device="cuda")
     out = torch.zeros(S, D, nq, dtype=torch.float64, device="cuda")
-    rc = lib.iso_chain_quantiles(ctx, dev.ptr(chain), T, S, W, D, qs.ctypes.data_as(C.POINTER(C.c_double)), nq, dev.ptr(out), None)
+    rc = lib.iso_chain_quantiles_layout(ctx, dev.ptr(chain), layout, T, S, W, D, qs.ctypes.data_as(C.POINTER(C.c_double)), nq,
+                                        dev.ptr(out), None)
     assert rc == 0
     got = out.cpu().numpy()
     flat = x.reshape(T, S, W, D).transpose(1, 3, 0, 2).reshape(S, D, T * W)
