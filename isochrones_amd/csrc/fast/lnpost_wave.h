@@ -40,7 +40,7 @@ __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* l
             // because even a never-taken branch here costs the common kernel registers (measured: +29 %)
             if (ASTERO && s == 0) coop_pair(A.astq, L, ok && M.has_numax, cell, w, astero);
         } else if (ok) {
-            gather_star<false>(A, i0, i1, i2, w, star[s]);
+            gather_star(A, i0, i1, i2, w, star[s]);
         } else {
 #pragma unroll
             for (int q = 0; q < 6; ++q) star[s][q] = f_nan();
@@ -100,7 +100,7 @@ __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* l
                 const uint32_t cell = (uint32_t)((int64_t)j0 * A.bs0 + (int64_t)j1 * A.bs1 + (int64_t)j2 * A.bs2 + j3);
                 coop_bc<NB>(A, L, ok, cell, w4v, bc);
             } else if (ok) {
-                gather_bc<NB, false>(A, j0, j1, j2, j3, w4v, bc);
+                gather_bc<NB>(A, j0, j1, j2, j3, w4v, bc);
             } else {
     #pragma unroll
                 for (int b = 0; b < NB; ++b) bc[b] = f_nan();
