@@ -74,6 +74,11 @@ class _ConvenienceMixin:
     def prior(self, prop, val, **kwargs):
         return self._priors[prop](val, **kwargs)
 
+    def lnpost_polychord(self, theta):
+        """PolyChord's callback form of ``lnpost``: (log-posterior, derived parameters) with no derived parameters
+        (reference: starmodel.py:703-705).  ``theta`` may also be a batch [N, n_params]."""
+        return self.lnpost(theta), [0.0]
+
     @property
     def directory(self):
         return getattr(self, "_directory", None) or "."

@@ -181,7 +181,7 @@ def test_reference_style_entry_points_exist():
         assert hasattr(ia, name), name
     for name in ("interp_value", "interp_mag", "get_eep", "generate", "isochrone", "model_value", "model_mag", "mass", "radius"):
         assert hasattr(ia.ModelGridInterpolator, name), name
-    for name in ("lnpost", "lnlike", "lnprior", "mnest_prior", "mnest_loglike", "fit_mcmc", "fit_multinest", "evidence",
+    for name in ("lnpost", "lnlike", "lnprior", "lnpost_polychord", "mnest_prior", "mnest_loglike", "fit_mcmc", "fit_multinest", "evidence",
                  "samples", "derived_samples", "sample_from_prior", "emcee_p0", "set_prior", "set_bounds", "bounds"):
         assert hasattr(ia.BasicStarModel, name), name
 
