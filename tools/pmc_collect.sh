@@ -3,7 +3,7 @@
 # then the per-workload summary.   usage (on the GPU box):  bash tools/pmc_collect.sh <outdir> [cases]
 set -u
 OUT=${1:-gpurun_out/pmc}
-CASES=${2:-cfg2,cfg3,generic,astero,tree,quantiles,sampler}
+CASES=${2:-cfg2,cfg3,generic,astero,tree,quantiles,primitives,sampler}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p "$ROOT/$OUT"
 cd /tmp && export TMPDIR=/tmp

@@ -25,7 +25,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--manifest", required=True)
     ap.add_argument("--launches", type=int, default=12)
-    ap.add_argument("--cases", default="cfg2,cfg3,generic,astero,tree,quantiles,sampler")
+    ap.add_argument("--cases", default="cfg2,cfg3,generic,astero,tree,quantiles,primitives,sampler")
     ap.add_argument("--n", type=int, default=1_000_000)
     args = ap.parse_args()
     import torch
@@ -125,6 +125,36 @@ def main():
         torch.cuda.synchronize()
         manifest.append(dict(label="quantiles/100000x32x100", kernel="k_chain_quantiles_wave", launches=L + 1, skip=1,
                              n=S * 5, algorithmic_bytes_per_launch=float(S) * W * T * 5 * 8))
+    if "primitives" in cases:
+        # the batch API primitives (rows a3-a8): interp_mag on the corner-packed tables, interp_value on the wide pack
+        ic = ia.synthetic_track()                                    # 11 default bands
+        rng = np.random.default_rng(5)
+        lo = np.array([0.1, 1.0, -4.0, 1.0, 0.0]); hi = np.array([10.0, 1710.0, 0.5, 3000.0, 1.0])
+        pars = torch.as_tensor(np.ascontiguousarray(rng.uniform(lo, hi, size=(n, 5)).T), device="cuda")
+        ci = ic.model_grid.interp.column_index
+        todo = [("interp_mag/1_band", "k_interp_mag_fast<0, 1>", lambda: ic.interp_mag_device(pars, list(ic.bands)[:1]),
+                 8 * 4 * 8 + 16 * 1 * 8 + 40 + 8 * 4),
+                ("interp_mag/11_bands", "k_interp_mag_fast<0, 11>", lambda: ic.interp_mag_device(pars, list(ic.bands)),
+                 8 * 4 * 8 + 16 * 11 * 8 + 40 + 8 * 14),
+                ("interp_value/18_cols", "k_interp3_wide", lambda: ic.model_grid.interp.interp_device([pars[2], pars[0], pars[1]], np.arange(18)),
+                 8 * 18 * 8 + 24 + 18 * 8)]
+        for label, kernel, fn, nbytes in todo:
+            fn(); fn()
+            torch.cuda.synchronize()
+            for _ in range(L):
+                fn()
+            torch.cuda.synchronize()
+            manifest.append(dict(label=label, kernel=kernel, launches=L + 2, skip=2, n=n, algorithmic_bytes_per_launch=float(nbytes) * n))
+        # the single-column interp_value also runs k_interp3_wide: after the 18-column launches in dispatch order
+        one = np.array([ci["radius"]])
+        f1 = lambda: ic.model_grid.interp.interp_device([pars[2], pars[0], pars[1]], one)
+        f1(); torch.cuda.synchronize()
+        for _ in range(L):
+            f1()
+        torch.cuda.synchronize()
+        manifest.append(dict(label="interp_value/1_col", kernel="k_interp3_wide", launches=L + 1, skip=1, n=n,
+                             algorithmic_bytes_per_launch=float(8 * 8 + 24 + 8) * n))
+        del ic
     if "sampler" in cases:
         # the catalog sampler in its throughput form: one launch per half-step over 2 x 10^5 stars x 16 moves
         from isochrones_amd.catalog import CatalogPosterior, initial_positions
