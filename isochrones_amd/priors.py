@@ -65,6 +65,18 @@ class Prior:
 
     __call__ = pdf
 
+    def pdf_array(self, x):
+        """``pdf`` of every element of an array (what start-point generation evaluates by the thousand); the same values
+        as ``pdf`` element by element: 0 outside the bounds, NaN for NaN."""
+        x = np.asarray(x, dtype=float)
+        lo, hi = self.bounds
+        with np.errstate(all="ignore"):
+            raw = np.asarray(self._raw_array(x), dtype=float)
+        return np.where((x < lo) | (x > hi), 0.0, raw)
+
+    def _raw_array(self, x):
+        return np.array([self._raw(float(v)) for v in x.ravel()]).reshape(x.shape)
+
     def lnpdf(self, x):
         if self.bounded:
             lo, hi = self.bounds
@@ -120,6 +132,9 @@ class FlatPrior(Prior):
         lo, hi = self.bounds
         return 1.0 / (hi - lo)
 
+    def _raw_array(self, x):
+        return np.full(x.shape, self._raw(0.0))
+
     def sample(self, n, rng=None):
         rng = rng or np.random.default_rng()
         lo, hi = self.bounds
@@ -137,6 +152,8 @@ class FlatLogPrior(Prior):
     def _raw(self, x):
         lo, hi = self.bounds
         return _LN10 * 10 ** x / (10 ** hi - 10 ** lo)
+
+    _raw_array = _raw
 
     def sample(self, n, rng=None):
         rng = rng or np.random.default_rng()
@@ -159,6 +176,8 @@ class PowerLawPrior(Prior):
 
     def _raw(self, x):
         return self._C() * x ** self.alpha
+
+    _raw_array = _raw
 
     def lnpdf(self, x):
         lo, hi = self.bounds
@@ -213,6 +232,12 @@ class GaussianPrior(Prior):
             return math.inf
         return math.exp(-(z * z) / 2.0) / _ROOT_2PI / self.sigma / self.norm
 
+    def _raw_array(self, x):
+        z = (x - self.mean) / self.sigma
+        if self.norm == 0:
+            return np.full(x.shape, np.inf)
+        return np.exp(-(z * z) / 2.0) / _ROOT_2PI / self.sigma / self.norm
+
     def lnpdf(self, x):
         if self.bounded and (x < self._bounds[0] or x > self._bounds[1]):
             return -np.inf
@@ -244,8 +269,11 @@ class LogNormalPrior(Prior):
 
     def _raw(self, x):
         s = self.sigma
-        y = x / self.scale
-        return (1.0 / _ROOT_2PI) / (s * y) * np.exp(-0.5 * (np.log(y) / s) ** 2) / self.scale
+        with np.errstate(all="ignore"):          # x = 0: inf * 0 = nan, as numpy gives the reference - not an exception
+            y = np.float64(x) / self.scale if np.isscalar(x) else x / self.scale
+            return (1.0 / _ROOT_2PI) / (s * y) * np.exp(-0.5 * (np.log(y) / s) ** 2) / self.scale
+
+    _raw_array = _raw
 
     def lnpdf(self, x):
         s = self.sigma
@@ -312,6 +340,9 @@ class ChabrierPrior(Prior):
             return self.low(x) / self.norms[0]
         return self.high(x) / self.norms[1]
 
+    def _raw_array(self, x):
+        return np.where(x < self.breakpoint, self.low.pdf_array(x) / self.norms[0], self.high.pdf_array(x) / self.norms[1])
+
     def lnpdf(self, x):
         # no bounds test on this path in the reference (BrokenPrior._lnpdf)
         if x < self.breakpoint:
@@ -324,11 +355,12 @@ class ChabrierPrior(Prior):
         out = np.empty(n)
         filled = 0
         # rejection from a log-uniform proposal — adequate for start-point generation
-        pmax = max(self.pdf(x) * x for x in np.geomspace(max(lo, 1e-3), hi, 400))
+        grid = np.geomspace(max(lo, 1e-3), hi, 400)
+        pmax = float(np.max(self.pdf_array(grid) * grid))
         while filled < n:
             m = max(2 * (n - filled), 64)
             x = np.exp(rng.uniform(np.log(max(lo, 1e-3)), np.log(hi), m))
-            keep = rng.random(m) * pmax * 1.05 < np.array([self.pdf(v) * v for v in x])
+            keep = rng.random(m) * pmax * 1.05 < self.pdf_array(x) * x
             take = x[keep][: n - filled]
             out[filled:filled + take.size] = take
             filled += take.size
@@ -388,6 +420,8 @@ class FehPrior(Prior):
 
     def _raw(self, x):
         return self._shape(x) / self._norm
+
+    _raw_array = _raw
 
     def sample(self, n, rng=None):
         rng = rng or np.random.default_rng()

@@ -590,7 +590,8 @@ class BasicStarModel(_NestedFitMixin, _ConvenienceMixin):
                 pars = [cols["mass"], cand, cols["feh"]] if orig_par == "age" else [cand, cols["age"], cols["feh"]]
                 v = np.atleast_2d(self.ic.interp_value(pars, [deriv, orig_par]))
                 op = self._priors["eep"].orig_prior
-                w = np.array([op(x) if np.isfinite(x) else 0.0 for x in v[:, 1]]) * v[:, 0]
+                fin = np.isfinite(v[:, 1])
+                w = np.where(fin, op.pdf_array(np.where(fin, v[:, 1], 0.0)), 0.0) * v[:, 0]
                 w = np.where(np.isfinite(w) & (w > 0), w, 0.0)
                 cols[nm] = cand[rng.choice(m, size=m, p=w / w.sum())] if w.sum() > 0 else cand
             x = np.column_stack([cols[nm] for nm in names])

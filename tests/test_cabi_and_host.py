@@ -217,3 +217,22 @@ def test_utils_known_answers():
     assert utils.distance((0.6, 100), (1.2, 200)) == 1.4318007458582984
     assert utils.fast_addmags([10.0, 11.0]) == 9.636148842226767
     assert utils.band_pairs("JHK") == [("J", "K"), ("H", "K")]
+
+
+def test_pdf_array_is_pdf_element_by_element():
+    """Prior.pdf_array (the vectorised form start-point generation uses) returns exactly what pdf returns per element,
+    bounds, NaN and the break of the Chabrier prior included."""
+    fam = [priors.FlatPrior((0, 2)), priors.FlatLogPrior((1, 3)), priors.PowerLawPrior(-2.35, (1, 100)),
+           priors.GaussianPrior(0.3, 0.2), priors.GaussianPrior(0.3, 0.2, bounds=(0.0, 1.0)), priors.LogNormalPrior(0.1, 0.5),
+           priors.ChabrierPrior(bounds=(0.1, 300)), priors.FehPrior(halo_fraction=0.05, bounds=(-4, 0.5)), priors.FehPrior(local=False),
+           priors.AgePrior(), priors.DistancePrior(3000), priors.AVPrior((0, 0.5))]
+    rng = np.random.default_rng(3)
+    x = np.concatenate([rng.uniform(-5, 320, 400), [0.0, 1.0, 100.0, 0.1, 300.0, 0.5, -4.0, 2.0, 3.0, np.nan, 5.0, 10.15]])
+    for p in fam:
+        with np.errstate(all="ignore"):
+            want = np.array([p.pdf(float(v)) for v in x], dtype=float)
+        got = p.pdf_array(x)
+        # (numpy's array pow and Python's float pow may differ in the last bit)
+        assert np.array_equal(np.isnan(got), np.isnan(want)) and np.allclose(got, want, rtol=1e-14, atol=0, equal_nan=True), type(p).__name__
+    s = priors.ChabrierPrior(bounds=(0.1, 300)).sample(5000, rng)
+    assert s.min() >= 0.1 and s.max() <= 300 and 0.2 < np.median(s) < 0.7
