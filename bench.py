@@ -334,6 +334,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if distributed:
+        # untimed, with the warm-up steps: the first collectives of a communicator build its channels (RCCL: lazily,
+        # per operation kind), which would otherwise land inside the K-step bracket's closing barrier
+        warm = torch.zeros(2, dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        for _ in range(2):
+            barrier()
+            dist.all_reduce(warm, op=dist.ReduceOp.MAX)
     barrier()
     t0 = time.perf_counter()
     kernel_ms = run(args.steps)            # K launches bracketed by HIP events on this stream

@@ -1130,6 +1130,7 @@ int iso_lnpost_host(iso_model* m, const double* pars, int64_t n, double* lnpost_
     if (!lnpost_out && !lnprior_out && !lnlike_out) return fail(ISO_ERR_INVALID, "iso_lnpost_host: no output requested");
     if (n == 0) return ISO_OK;
     DeviceGuard guard(m->device);
+    std::lock_guard<std::mutex> lock(m->host_mu);       // ctypes drops the GIL: two Python threads may call one model
     const int np_ = m->desc.n_stars + 4;
     constexpr int64_t CAP = 8192;
     if (n > 4 * CAP) return lnpost_host_pipelined(m, pars, n, lnpost_out, lnprior_out, lnlike_out);

@@ -233,6 +233,7 @@ struct iso_model {
     double* h_pipe;          // pinned, device-mapped: the kernels write their results straight into host memory
     int64_t pipe_rows;
     hipStream_t pipe_stream[2];
+    std::mutex host_mu;      // iso_lnpost_host: one caller at a time per model (the staging areas are the model's)
 };
 
 struct iso_sampler {

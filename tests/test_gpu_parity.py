@@ -716,6 +716,39 @@ def test_host_array_entry_point_every_size_regime(n, monkeypatch):
         assert mod.lnpost(list(pars[1])) == want[1] or (np.isnan(want[1]) and np.isnan(mod.lnpost(list(pars[1]))))
 
 
+def test_host_array_entry_point_from_two_threads_at_once():
+    """ctypes releases the GIL for the call, so two Python threads can be inside iso_lnpost_host of ONE model at the same
+    time (its staging areas belong to the model): every call must still return its own rows' values, in all three size
+    regimes."""
+    import threading
+    import torch
+    ic = _ic_for_host_test()
+    mod = ia.SingleStarModel(ic, Teff=(5770, 100), logg=(4.5, 0.1), feh=(0.0, 0.15), V=(10.0, 0.05), parallax=(10.0, 0.1))
+    lo = np.array([0.65, 295.0, -1.1, 50.0, 0.0])
+    hi = np.array([2.1, 425.0, 0.6, 150.0, 1.0])
+    sizes = [1, 64, 300, 9000, 40_000]
+    jobs = []
+    for t in range(2):
+        rng = np.random.default_rng(100 + t)
+        batches = [rng.uniform(lo, hi, size=(n, 5)) for n in sizes]
+        want = [mod.evaluate_device(torch.as_tensor(b, device="cuda")).cpu().numpy() for b in batches]
+        jobs.append((batches, want))
+    bad = []
+
+    def work(t):
+        batches, want = jobs[t]
+        for rep in range(40):
+            for b, w in zip(batches, want):
+                if not np.array_equal(mod.lnpost(b), w, equal_nan=True):
+                    bad.append((t, rep, len(b)))
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not bad, bad[:5]
+
+
 _HOST_IC = []
 
 
