@@ -65,15 +65,105 @@ def diagnose(p0, chain, clnp, lnp0, W, a, seed):
     return shown
 
 
+def catalog_run(rng):
+    """One random catalog through the catalog (MULTI) instantiation of the sampler kernels: random band lists, bands a
+    star was not observed in (NaN -> masked term), spectroscopic columns, with / without parallax, 1-2 stars per system,
+    random ensemble size / scale / kernel form; a subset of the stars replayed with each star's own oracle model.
+    Returns (stats or None if skipped, cfg)."""
+    import pandas as pd
+    import torch
+    from isochrones_amd.catalog import CatalogPosterior, StarCatalog, initial_positions
+    kind = str(rng.choice(["track", "iso"]))
+    N = 1 if kind == "track" else int(rng.choice([1, 1, 2]))
+    nb = int(rng.integers(1, 9))
+    bands = list(ia.grids.DEFAULT_BANDS[:nb])
+    S = int(rng.integers(20, 400))
+    W = int(rng.choice([8, 16, 32, 64]))
+    a = float(rng.choice([1.3, 2.0, 3.0]))
+    mode = str(rng.choice(["auto", "stepwise", "persistent-dense"]))
+    T = int(rng.integers(8, 40))
+    sseed = int(rng.integers(0, 2 ** 40))
+    plx = bool(rng.random() < 0.7)
+    cfg = dict(catalog=True, kind=kind, N=N, nb=nb, S=S, W=W, a=a, mode=mode, T=T, seed=sseed, parallax=plx)
+    ic = ia.synthetic_track(bands=bands) if kind == "track" else ia.synthetic_isochrone(bands=bands)
+    cat, _ = ia.synthetic_catalog(ic, S, bands=bands, seed=int(rng.integers(0, 2 ** 31)), mag_unc=float(rng.choice([0.005, 0.02, 0.1])),
+                                  with_parallax=plx)
+    df = cat.df.copy()
+    props = list(cat.props)
+    if nb > 1:                       # bands some stars were not observed in
+        for b in bands[1:]:
+            if rng.random() < 0.5:
+                df.loc[df.index[rng.random(S) < 0.3], b + "_mag"] = np.nan
+    if rng.random() < 0.4:
+        df["logg"] = 4.4 + 0.1 * rng.standard_normal(S); df["logg_unc"] = 0.2
+        props.append("logg")
+    cat = StarCatalog(df, bands=bands, props=props)
+    os.environ["ISOCHRONES_AMD_SAMPLER"] = mode
+    try:
+        post = CatalogPosterior.from_catalog(cat, ic, N=N)
+    except IsoError:
+        ic.release()
+        return None, cfg
+    pos, lnp, failed = initial_positions(post, W, rng_seed=int(rng.integers(0, 2 ** 31)))
+    good = np.flatnonzero(~failed.cpu().numpy())
+    if good.size < 5:
+        post.close(); ic.release()
+        return None, cfg
+    if bool(failed.any()):
+        pos[failed] = pos[int(good[0])]
+        lnp[failed] = 0.0
+    D = post.n_params
+    pick = np.sort(rng.choice(good, min(40, good.size), replace=False))
+    descs = [cat.model(int(k), ic, N=N).model_desc() for k in pick]
+    oic = fx.make_oracle_ic(ic)
+
+    def fn(blk, pars):
+        out = np.empty(pars.shape[0])
+        for b in range(len(descs)):
+            sel = np.flatnonzero(blk == b)
+            if sel.size:
+                out[sel] = oic.lnpost(descs[b], np.ascontiguousarray(pars[sel].T), nthreads=4, parts=False)
+        return out
+    sel = torch.as_tensor(pick, device=pos.device)
+    p_sel = pos[sel].reshape(-1, D).cpu().numpy()
+    l_sel = lnp[sel].reshape(-1).cpu().numpy()
+    want0 = fn(np.repeat(np.arange(len(pick)), W), p_sel)
+    if not np.allclose(l_sel, want0, rtol=1e-9, atol=1e-9):
+        raise AssertionError("catalog start lnpost differs from the oracle: %g" % float(np.max(np.abs(l_sel - want0))))
+    fs = FusedEnsembleSampler(post, W, a=a, seed=sseed)
+    fs.run_mcmc(pos, T, lnprob0=lnp, store=True)
+    ch = fs.chain_steps.reshape(T, S, W, D)[:, sel].reshape(T, -1, D).cpu().numpy()
+    cl = fs._lnprob.view(T, S, W)[:, sel].reshape(T, -1).cpu().numpy()
+    try:
+        st = _replay.replay(p_sel, l_sel, ch, cl, W, a, sseed, 0, fn, star_of_block=pick, lnp_atol=1e-7, margin=1e-8)
+    finally:
+        fs.close(); post.close(); ic.release()
+    return st, cfg
+
+
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     rng = np.random.default_rng(seed)
     os.environ["ISOCHRONES_AMD_PATH"] = "auto"
     t0 = time.time()
-    runs = skipped = fails = moves = accepted = ties = 0
+    runs = cat_runs = skipped = fails = moves = accepted = ties = 0
     worst = 0.0
     while time.time() - t0 < budget:
+        if rng.random() < float(os.environ.get("SOAK_CATALOG_FRACTION", 0.15)):
+            cfg = {}
+            try:
+                st, cfg = catalog_run(rng)
+                if st is None:
+                    skipped += 1
+                    continue
+                moves += st["moves"]; accepted += st["accepted"]; ties += st["near_ties"]
+                worst = max(worst, st["max_lnp_rel"])
+                cat_runs += 1
+            except AssertionError as e:
+                print("MISMATCH", e, json.dumps(cfg), flush=True)
+                fails += 1
+            continue
         cfg, ic, mod, axes, lo, hi = soak.build(rng)
         W = int(rng.choice([4, 8, 16, 30, 64, 100, 256]))
         a = float(rng.choice([1.3, 2.0, 3.0]))
@@ -127,9 +217,9 @@ def main():
         runs += 1
         del fs
         ic.release()
-    print("sampler soak: %d runs (%d configurations skipped), %.3g moves replayed against the oracle, %.3g accepted, "
+    print("sampler soak: %d single-model runs + %d catalog runs (%d configurations skipped), %.3g moves replayed against the oracle, %.3g accepted, "
           "%d near ties, %d disagreements, largest stored-lnprob difference %.2e (relative), %.0f s"
-          % (runs, skipped, moves, accepted, ties, fails, worst, time.time() - t0))
+          % (runs, cat_runs, skipped, moves, accepted, ties, fails, worst, time.time() - t0))
     sys.exit(1 if fails else 0)
 
 
