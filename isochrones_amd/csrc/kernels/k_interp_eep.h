@@ -18,17 +18,21 @@ struct EepArgs {
     double* out;
 };
 
-// number of elements of arr[0..N) that are < x  (== the reference's searchsorted L)
-__device__ __forceinline__ int64_t count_less(const double* __restrict__ arr, double x, int64_t N)
+// The reference's searchsorted (isochrones/interp.py:10-35) step for step: the index of the first element > x when no
+// element equals x; on an exact hit the index of the equal element its bisection lands on - which, inside a run of
+// repeated ages, is not the first of the run, so the probe sequence itself has to be the reference's.
+__device__ __forceinline__ int64_t ref_searchsorted(const double* __restrict__ arr, double x, int64_t N)
 {
-    int64_t base = 0, len = N;
-    if (N <= 0) return 0;
-    while (len > 1) {                       // base = largest index with arr[base] < x, or 0
-        const int64_t half = len >> 1;
-        base = (arr[base + half] < x) ? base + half : base;
-        len -= half;
+    int64_t L = 0, R = N - 1;
+    while (L <= R) {
+        const int64_t m = (L + R) >> 1;
+        const double xm = arr[m];
+        if (xm < x) L = m + 1;
+        else if (xm > x) R = m - 1;
+        else if (xm == x) return m;
+        else break;                         // NaN inside the track's length: the reference would spin; tables have none
     }
-    return (arr[base] < x) ? base + 1 : base;
+    return L;
 }
 
 __global__ __launch_bounds__(BLOCK) void k_interp_eep(const EepArgs A)
@@ -52,7 +56,7 @@ __global__ __launch_bounds__(BLOCK) void k_interp_eep(const EepArgs A)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 len[k] = A.lengths[ind[k]];
-                ie[k] = count_less(A.ages + ind[k] * A.n_eep, x, len[k]);
+                ie[k] = ref_searchsorted(A.ages + ind[k] * A.n_eep, x, len[k]);
                 bad |= ie[k] > A.n_eep - 1;
             }
             if (!bad) {

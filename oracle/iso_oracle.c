@@ -559,7 +559,7 @@ int orc_max_threads(void)
  * The reference reads, but never uses, the dt_deep weights; the substitution chain for tracks
  * that end before `x` is sequential, exactly as written there.
  * ------------------------------------------------------------------------------------- */
-static int64_t orc_count_less(const double* arr, double x, int64_t N)
+static int64_t orc_eep_index(const double* arr, double x, int64_t N)
 {
     int eq;
     if (N <= 0) return 0;
@@ -582,7 +582,7 @@ double orc_interp_eep1(double x, double x0, double x1, const double* ax0, int64_
     const int64_t i0 = idx[0], i1 = idx[1];
     const int64_t ind[4] = {i0 * n1 + i1, i0 * n1 + (i1 + 1), (i0 + 1) * n1 + i1, (i0 + 1) * n1 + (i1 + 1)};
     int64_t ie[4];
-    for (int k = 0; k < 4; ++k) ie[k] = orc_count_less(ages + ind[k] * n_eep, x, lengths[ind[k]]);
+    for (int k = 0; k < 4; ++k) ie[k] = orc_eep_index(ages + ind[k] * n_eep, x, lengths[ind[k]]);
     const int64_t max_i = n_eep - 1;
     for (int k = 0; k < 4; ++k)
         if (ie[k] > max_i) return NAN;

@@ -309,6 +309,32 @@ def run_eep_case():
     np.savez_compressed(os.path.join(OUT, "interp_eep.npz"), fehs=fehs, masses=masses, ages=ages, lengths=lengths,
                         age=x, feh=x0, mass=x1, eep=want)
     print("interp_eep: n=%d finite=%d nan=%d" % (n, np.isfinite(want).sum(), np.isnan(want).sum()))
+    # second fixture: repeated ages inside tracks and many exact hits.  The reference's searchsorted returns the
+    # index of the equal element its bisection lands on (interp.py:26-29), which inside a run of equal ages is
+    # neither the first nor the last of the run - the probe sequence itself is part of the behaviour.
+    ages2 = ages.copy()
+    for t in rng.choice(ages2.shape[0], 24, replace=False):
+        L = int(lengths[t])
+        for _ in range(6):
+            if L > 12:
+                a0 = int(rng.integers(1, L - 8))
+                ages2[t, a0:a0 + int(rng.integers(2, 8))] = ages2[t, a0]
+    n = 6000
+    x1 = rng.uniform(0.5, 7.0, n)
+    x0 = rng.uniform(-1.0, 0.5, n)
+    x = rng.uniform(4.8, 11.0, n)
+    fin = ages2[np.isfinite(ages2)]
+    x[:3000] = rng.choice(fin, 3000)                                  # ages that are in the table
+    for k in range(3000, 3600):                                       # ... queried on the very track they come from
+        i, j = int(rng.integers(0, fehs.size - 1)), int(rng.integers(0, masses.size - 1))    # (the upper edge is undefined in the reference)
+        L = int(lengths[i * masses.size + j])
+        if L:
+            x[k], x0[k], x1[k] = ages2[i * masses.size + j, int(rng.integers(0, L))], fehs[i], masses[j]
+    with np.errstate(all="ignore"):
+        want2 = interp.interp_eeps(x, x0, x1, fehs, masses, len(masses), ages2, dt, lengths)
+    np.savez_compressed(os.path.join(OUT, "interp_eep_plateaus.npz"), fehs=fehs, masses=masses, ages=ages2,
+                        lengths=lengths, age=x, feh=x0, mass=x1, eep=want2)
+    print("interp_eep_plateaus: n=%d finite=%d nan=%d" % (n, np.isfinite(want2).sum(), np.isnan(want2).sum()))
 
 
 def _tree_cases(obs_mod, ic):

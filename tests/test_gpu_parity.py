@@ -398,6 +398,34 @@ def test_get_eep_and_generate():
         ic.ages
 
 
+def test_get_eep_exact_age_hits_and_repeated_ages():
+    """Reference fixture with runs of equal ages inside tracks and 3600 queries that hit table ages exactly: which of
+    the equal elements the reference's bisection returns (interp.py:26-29) decides the EEP, so the kernel walks the
+    same probe sequence.  Host-array, device-tensor and scalar forms."""
+    import torch
+    from isochrones_amd.models import EvolutionTrackGrid, EvolutionTrackInterpolator, BolometricCorrectionGrid
+    g = fx.load("interp_eep_plateaus")
+    fehs, masses = g["fehs"], g["masses"]
+    n_eep = g["ages"].shape[1]
+    grid, ax, cols = ia.grids.synthetic_track_grid(fehs, masses, np.arange(1.0, n_eep + 1.0))
+    grid[..., cols.index("age")] = g["ages"].reshape(fehs.size, masses.size, n_eep)
+    bcg, bax, bands = ia.grids.synthetic_bc_grid(("G",))
+    ic = EvolutionTrackInterpolator(EvolutionTrackGrid(DFInterpolator.from_arrays(grid, ax, cols)),
+                                    BolometricCorrectionGrid(DFInterpolator.from_arrays(bcg, bax, bands), bands=bands),
+                                    bands=bands)
+    want = g["eep"]
+    fx.assert_close(ic.get_eep(g["mass"], g["age"], g["feh"]), want, 1e-13, what="get_eep, repeated ages")
+    dev_out = ic.get_eep(*(torch.as_tensor(g[k], device="cuda") for k in ("mass", "age", "feh")))
+    fx.assert_close(dev_out.cpu().numpy(), want, 1e-13, what="get_eep device, repeated ages")
+    for k in range(3000, 3040):
+        v = ic.get_eep(float(g["mass"][k]), float(g["age"][k]), float(g["feh"][k]))
+        assert (np.isnan(v) and np.isnan(want[k])) or np.isclose(v, want[k], rtol=1e-13)
+    # the fixture does exercise the difference: "first index with age >= x" is not the reference's answer everywhere
+    from oracle import oracle as orc
+    assert np.array_equal(orc.interp_eep(g["age"], g["feh"], g["mass"], fehs, masses, g["ages"], g["lengths"]), want,
+                          equal_nan=True)
+
+
 def test_ingest_derived_columns():
     """'next' row f1: dt_deep / dm_deep as np.gradient over the populated points of each track."""
     from isochrones_amd import ingest

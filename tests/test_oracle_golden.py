@@ -96,9 +96,12 @@ def test_threads_agree():
     assert np.array_equal(a, b, equal_nan=True)
 
 
-def test_interp_eep_vs_reference():
-    """'next' row f2: the oracle's interp_eep against the reference's interp_eeps."""
-    g = fx.load("interp_eep")
+@pytest.mark.parametrize("fixture", ["interp_eep", "interp_eep_plateaus"])
+def test_interp_eep_vs_reference(fixture):
+    """'next' row f2: the oracle's interp_eep against the reference's interp_eeps.  The second fixture has runs of
+    repeated ages inside tracks and 3600 queries that hit table ages exactly: the reference's searchsorted returns
+    the equal element its bisection lands on (interp.py:26-29), and the index decides the EEP."""
+    g = fx.load(fixture)
     got = orc.interp_eep(g["age"], g["feh"], g["mass"], g["fehs"], g["masses"], g["ages"], g["lengths"])
-    fx.assert_close(got, g["eep"], 1e-13, what="interp_eep")
+    fx.assert_close(got, g["eep"], 1e-13, what=fixture)
     assert np.isnan(g["eep"]).any() and np.isfinite(g["eep"]).sum() > 1000
