@@ -212,7 +212,8 @@ int  iso_lnpost(iso_model* m, const double* pars, int64_t stride_n, int64_t stri
  * (ISOCHRONES_AMD_HOST_SYNC=1: synchronise the stream instead).  Larger batches are cut into 131072-row chunks: the
  * calling thread uploads and launches chunk k (results land in pinned host memory) while a helper thread copies the
  * results of the chunks before it into the caller's arrays.
- * Not re-entrant per model. */
+ * Calls on one model are serialised by the library (the staging areas are the model's); different models run
+ * concurrently. */
 int  iso_lnpost_host(iso_model* m, const double* pars, int64_t n, double* lnpost_out, double* lnprior_out,
                      double* lnlike_out);
 
