@@ -629,7 +629,7 @@ def _raw_mist_rows(rng, keys, key_names, eep_counts):
     return pd.concat(frames, ignore_index=True)
 
 
-def run_ingest_cases():
+def run_ingest_cases(seed=4242, save=True):
     """MISTEvolutionTrackGrid / MISTIsochroneGrid / MISTBolometricCorrectionGrid of the reference on synthetic raw
     frames: column standardisation + derived columns (models.py:102-109, mist/models.py:81-85,219-223), dt_deep
     (mist/models.py:403-435), dm_deep (models.py:126-153), the ragged age arrays (models.py:171-203), the
@@ -639,13 +639,22 @@ def run_ingest_cases():
     import pandas as pd
     mm = rh.ref("mist.models")
     mbc = rh.ref("mist.bc")
-    rng = np.random.default_rng(4242)
+    rng = np.random.default_rng(seed)
     out = {}
+    # the committed fixture is seed 4242 with the table shapes below; any other seed (tests/test_ingest_golden.py's
+    # container-only sweep) also draws the shapes
+    vary = np.random.default_rng(seed + 1) if seed != 4242 else None
+
+    def axis(default, lo, hi, step):
+        if vary is None:
+            return np.array(default)
+        n = int(vary.integers(2, 6))
+        return np.sort(vary.choice(np.arange(lo, hi, step), n, replace=False)).round(6)
     with tempfile.TemporaryDirectory() as tmp, rh.memory_hdf() as hdf, warnings.catch_warnings():
         warnings.simplefilter("ignore")
         # ---- evolution tracks ----
-        fehs = np.array([-0.5, 0.0, 0.25])
-        masses = np.array([0.8, 1.0, 1.2, 1.5])
+        fehs = axis([-0.5, 0.0, 0.25], -2.0, 0.6, 0.25)
+        masses = axis([0.8, 1.0, 1.2, 1.5], 0.3, 3.0, 0.1)
         keys = list(itertools.product(fehs, masses))
         counts = [int(c) for c in rng.integers(18, 36, len(keys))]
         raw_t = _raw_mist_rows(rng, keys, ("initial_feh", "initial_mass"), counts)
@@ -673,8 +682,8 @@ def run_ingest_cases():
         print("ingest tracks: %d rows, grid %s, %d NaN cells" % (len(df), g.interp.grid.shape,
                                                                   int(np.isnan(g.interp.grid[..., 0]).sum())))
         # ---- isochrones ----
-        ages = np.array([8.5, 9.0, 9.5, 10.0])
-        ifehs = np.array([-1.0, 0.0, 0.5])
+        ages = axis([8.5, 9.0, 9.5, 10.0], 7.0, 10.3, 0.05)
+        ifehs = axis([-1.0, 0.0, 0.5], -2.0, 0.6, 0.25)
         keys = list(itertools.product(ages, ifehs))
         counts = [int(c) for c in rng.integers(15, 30, len(keys))]
         raw_i = _raw_mist_rows(rng, keys, ("log10_isochrone_age_yr", "feh"), counts)
@@ -748,7 +757,9 @@ def run_ingest_cases():
         out[pre + "_columns"] = np.array([names[k] for k in order])
         for key in grid_keys:
             out[key] = np.ascontiguousarray(out[key][..., order])
-    np.savez_compressed(os.path.join(OUT, "ingest.npz"), **out)
+    if save:
+        np.savez_compressed(os.path.join(OUT, "ingest.npz"), **out)
+    return out
 
 
 

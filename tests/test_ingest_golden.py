@@ -109,3 +109,24 @@ def test_band_names(g):
 def test_unknown_band_is_an_error():
     with pytest.raises(ValueError):
         ingest.mist_band("nonsense")
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_other_seeds_and_table_shapes_against_the_reference_itself(seed, tmp_path, monkeypatch):
+    """Container-only (needs /root/reference): the reference's grid classes are run on freshly drawn raw frames -
+    other random values, other numbers of [Fe/H] / mass / age nodes, other ragged track lengths - and every check of
+    this file is repeated on them."""
+    import os
+    import sys
+    if not os.path.isdir("/root/reference/isochrones"):
+        pytest.skip("the reference tree is only present in the build container")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    monkeypatch.syspath_prepend(os.path.join(root, "oracle"))
+    monkeypatch.setenv("ISO_GOLDEN_OUT", str(tmp_path))
+    import make_golden
+    fresh = make_golden.run_ingest_cases(seed=seed, save=False)
+    fresh = {k: np.asarray(v) for k, v in fresh.items()}
+    for pre, tracks, deriv in (("track", True, "dt_deep"), ("iso", False, "dm_deep")):
+        test_standard_columns_dense_grid_and_derivative(fresh, pre, tracks, deriv)
+    test_ragged_age_arrays(fresh)
+    test_bc_frames_to_dense_table(fresh, tmp_path)
