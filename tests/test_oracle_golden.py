@@ -105,3 +105,54 @@ def test_interp_eep_vs_reference(fixture):
     got = orc.interp_eep(g["age"], g["feh"], g["mass"], g["fehs"], g["masses"], g["ages"], g["lengths"])
     fx.assert_close(got, g["eep"], 1e-13, what=fixture)
     assert np.isnan(g["eep"]).any() and np.isfinite(g["eep"]).sum() > 1000
+
+
+@pytest.mark.parametrize("seed", [101, 102, 103, 104, 105, 106])
+def test_model_case_on_fresh_draws_against_the_reference_itself(seed, tmp_path, monkeypatch):
+    """Container-only (needs /root/reference): instead of the committed vectors, the reference's StarModel classes are run
+    here on freshly drawn cases - parametrisation, multiplicity, observables and their values, bounds keywords, prior
+    families and sample points all random - and the oracle is put through the same checks as test_model_case."""
+    import os
+    if not os.path.isdir("/root/reference/isochrones"):
+        pytest.skip("the reference tree is only present in the build container")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    monkeypatch.syspath_prepend(os.path.join(root, "oracle"))
+    import make_golden as mg
+    fx.tables()                                            # the committed small tables = mg.small_*(): cache them first
+    monkeypatch.setattr(mg, "OUT", str(tmp_path))
+    monkeypatch.setattr(fx, "GOLDEN", str(tmp_path))
+    rng = np.random.default_rng(seed)
+    trk, iso, bc = mg.small_track(), mg.small_iso(), mg.small_bc()
+    for k in range(3):
+        kind = str(rng.choice(["track", "iso"]))
+        n_stars = 1 if kind == "track" else int(rng.choice([1, 2, 3]))
+        obs = {}
+        if rng.random() < 0.6: obs["Teff"] = (float(rng.uniform(4500, 6800)), 100.0)
+        if rng.random() < 0.5: obs["logg"] = (float(rng.uniform(3.8, 4.7)), 0.1)
+        if rng.random() < 0.5: obs["feh"] = (float(rng.uniform(-0.4, 0.3)), 0.15)
+        if rng.random() < 0.6: obs["parallax"] = (float(rng.choice([2.5, 10.0])), float(rng.choice([0.05, 0.5])))
+        if rng.random() < 0.3:
+            obs["nu_max"] = (float(rng.uniform(800, 3200)), 60.0)
+            if rng.random() < 0.6: obs["delta_nu"] = (float(rng.uniform(50, 150)), 2.0)
+        for b in rng.choice(list(mg.BANDS), int(rng.integers(0, len(mg.BANDS) + 1)), replace=False):
+            obs[str(b)] = (float(rng.uniform(8.5, 11.0)), float(rng.choice([0.002, 0.02, 0.1])))
+        if not obs:
+            obs["Teff"] = (5700.0, 100.0)
+        monkeypatch.setitem(mg.OBS, "fresh", obs)
+        kw = {}
+        if rng.random() < 0.4: kw["maxAV"] = float(rng.uniform(0.3, 1.2))
+        if rng.random() < 0.4: kw["max_distance"] = float(rng.uniform(300, 3000))
+        if rng.random() < 0.3: kw["halo_fraction"] = float(rng.uniform(0.0, 0.2))
+        pri = {}
+        if rng.random() < 0.3: pri["mass"] = [("LogNormal", 0.0, 0.4), ("PowerLaw", -2.35, 0.1, 10.0)][int(rng.integers(0, 2))]
+        if rng.random() < 0.3: pri["age"] = [("Gaussian", 9.6, 0.3, 8.0, 10.1), ("Flat", 8.5, 10.1), ("FlatLog", 8.0, 10.0)][int(rng.integers(0, 3))]
+        if rng.random() < 0.3: pri["feh"] = [("Flat", -1.5, 0.4), ("Gaussian", -0.2, 0.3, -1.0, 0.5)][int(rng.integers(0, 2))]
+        if rng.random() < 0.3: pri["distance"] = [("Gaussian", 150.0, 60.0, 1.0, 600.0), ("LogNormal", float(np.log(300.0)), 0.5), ("PowerLaw", 2.0, 0.0, 500.0)][int(rng.integers(0, 3))]
+        if rng.random() < 0.3: pri["AV"] = [("PowerLaw", 0.5, 0.0, 1.0), ("Gaussian", 0.2, 0.1, 0.0, 1.0)][int(rng.integers(0, 2))]
+        eep_orig = None
+        if rng.random() < 0.25:
+            eep_orig = ("Gaussian", 9.6, 0.3, 8.0, 10.1) if kind == "track" else ("LogNormal", float(np.log(0.9)), 0.5)
+        name = "fresh_%d_%d" % (seed, k)
+        mg.run_model_case(name, kind, n_stars, "fresh", trk if kind == "track" else iso, bc, rng, 90, 90, extra_kw=kw,
+                          priors=pri or None, eep_orig_prior=eep_orig)
+        test_model_case(name)
