@@ -151,8 +151,9 @@ class _NestedFitMixin:
             return None
         run = nested_sample_batched if batched else nested_sample
         run_kwargs["propose"] = self._device_proposer(lo, hi, seed)
-        if getattr(self, "mnest_transform", None) is not None:
-            run_kwargs["transform"] = self.mnest_transform     # the cube -> parameter map is not the plain box
+        transform = getattr(self, "_fit_transform", None) or getattr(self, "mnest_transform", None)
+        if transform is not None:
+            run_kwargs["transform"] = transform                # the cube -> parameter map is not the plain box
         res = run(lambda th: self.lnpost(np.ascontiguousarray(th)), lo, hi, **run_kwargs)
         self._nested = res
         self._samples = None
@@ -923,18 +924,42 @@ class TreeStarModel(_NestedFitMixin, _ConvenienceMixin):
         found = {k for v in self.obs.spectroscopy.values() for k in v}
         return sorted(found - {"Teff", "logg", "feh"})
 
-    def mnest_transform(self, cube):
-        """Unit cube -> parameters as the reference's ``StarModel.mnest_prior`` maps them (starmodel.py:644-656): the
-        flat box of :meth:`prior_transform`, then every system's EEPs put in descending order, so that the whole
-        cube lands on the ordering ``lnprior`` accepts.  ``cube`` [..., n_params]; out of place."""
-        pars = self.prior_transform(cube)
+    def _slots(self, reference_order):
+        """(system, number of stars) in the order the parameter slots are walked.  The parameter vector itself is laid
+        out by ascending system index (``param_names``, what ``lnpost`` reads: observation.py:1116-1130, :1146-1154).
+        The reference's ``prior_transform`` / ``mnest_prior`` walk ``obs.Nstars.items()`` instead (starmodel.py:618,
+        :646) - the order in which the tree first meets each system - which is a different slot layout whenever the
+        systems are met out of order AND hold different numbers of stars; there the reference scales slots with the
+        bounds of other parameters.  ``reference_order=True`` reproduces that walk."""
+        N = self.obs.Nstars
+        return list(N.items()) if reference_order else [(s, N[s]) for s in self.obs.systems]
+
+    def _box(self, cube, reference_order, sort_eeps):
+        cube = np.asarray(cube, dtype=float)
+        pars = cube * 0
         i = 0
-        for s in self.obs.systems:
-            n = self.obs.Nstars[s]
-            if n > 1:
+        lo_e, hi_e = self._bounds["eep"]
+        for _, n in self._slots(reference_order):
+            pars[..., i:i + n] = (hi_e - lo_e) * cube[..., i:i + n] + lo_e
+            if sort_eeps and n > 1:
                 pars[..., i:i + n] = -np.sort(-pars[..., i:i + n], axis=-1)
+            for j, par in enumerate(("age", "feh", "distance", "AV")):
+                lo, hi = self.bounds(par)
+                pars[..., i + n + j] = (hi - lo) * cube[..., i + n + j] + lo
             i += 4 + n
         return pars
+
+    def mnest_transform(self, cube):
+        """Unit cube -> parameters exactly as the reference's ``StarModel.mnest_prior`` maps them (starmodel.py:644-656):
+        the flat box, every system's EEPs put in descending order, slots walked as the reference walks them (see
+        :meth:`_slots`).  ``cube`` [..., n_params]; out of place."""
+        return self._box(cube, True, True)
+
+    def _fit_transform(self, cube):
+        """The same map on the parameter vector's own layout: what this build's nested sampler uses, so that a fit also
+        works for the trees on which the reference's slot walk goes astray (identical to :meth:`mnest_transform`
+        everywhere else)."""
+        return self._box(cube, False, True)
 
     def _cube_to_pars_device(self, u, lo_t, span_t):
         import torch
@@ -1122,20 +1147,8 @@ class TreeStarModel(_NestedFitMixin, _ConvenienceMixin):
 
 
     def prior_transform(self, cube):
-        """Unit cube -> parameters (reference: starmodel.py:615-627)."""
-        cube = np.asarray(cube, dtype=float)
-        pars = cube * 0
-        i = 0
-        N = self.obs.Nstars
-        lo_e, hi_e = self._bounds["eep"]
-        for s in self.obs.systems:
-            n = N[s]
-            pars[..., i:i + n] = (hi_e - lo_e) * cube[..., i:i + n] + lo_e
-            for j, par in enumerate(("age", "feh", "distance", "AV")):
-                lo, hi = self.bounds(par)
-                pars[..., i + n + j] = (hi - lo) * cube[..., i + n + j] + lo
-            i += 4 + n
-        return pars
+        """Unit cube -> parameters (reference: starmodel.py:615-627, its slot walk included: see :meth:`_slots`)."""
+        return self._box(cube, True, False)
 
     # -- fits (reference: StarModel.fit_mcmc / fit_multinest, starmodel.py:717-972) --------------
     def sample_from_prior(self, n, rng=None, max_tries=200):
@@ -1144,7 +1157,7 @@ class TreeStarModel(_NestedFitMixin, _ConvenienceMixin):
         rng = rng or np.random.default_rng()
 
         def draw(m):
-            return self.mnest_transform(rng.random((m, self.n_params)))
+            return self._fit_transform(rng.random((m, self.n_params)))
 
         out = draw(n)
         for _ in range(max_tries):

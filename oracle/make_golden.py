@@ -362,6 +362,10 @@ def _tree_cases(obs_mod, ic):
                                           parallax=(2.0, 0.1))),
         ("tree_kwargs_binary", None, dict(J=(13.3, 0.05), K=(12.9, 0.05), parallax=(2.0, 0.1), N=2)),
         ("tree_kwargs_triple", None, dict(Teff=(5800, 100), J=(13.3, 0.05), K=(12.9, 0.05), N=3, maxAV=0.6)),
+        # the tree meets system 1 (one star) before system 0 (two stars): prior_transform / mnest_prior walk
+        # obs.Nstars.items() (starmodel.py:618,646) while the parameter vector is laid out by ascending system index
+        # (observation.py:1116-1130), so the reference scales some slots with other parameters' bounds here
+        ("tree_out_of_order", build, dict(N=[1, 2], index=[1, 0], parallax=(2.0, 0.05))),
     ]
 
 

@@ -12,7 +12,7 @@ from oracle import oracle as orc
 from tests import _fixtures as fx
 
 TREE_CASES = ["tree_resolved", "tree_resolved_unassoc", "tree_triple1", "tree_triple2", "tree_double_binary",
-              "tree_kwargs_single", "tree_kwargs_binary", "tree_kwargs_triple"]
+              "tree_kwargs_single", "tree_kwargs_binary", "tree_kwargs_triple", "tree_out_of_order"]
 # star.ini fixtures (tests/golden/ini/, layouts of the reference's tests/star1..star4) with the N / index
 # variants of the reference's tests/test_ini.py
 INI_CASES = ["ini_single", "ini_binary", "ini_binary_unassoc", "ini_triple", "ini_triple_unassoc1",
@@ -47,8 +47,12 @@ def make_tree_model(meta):
 @pytest.mark.parametrize("case", TREE_CASES + INI_CASES)
 def test_tree_structure_and_oracle_vs_reference(case):
     g = fx.load(case)
+    ic, mod = make_tree_model(g["meta"])
+    _check_tree_case(g, ic, mod)
+
+
+def _check_tree_case(g, ic, mod):
     meta = g["meta"]
-    ic, mod = make_tree_model(meta)
     # --- structure: same parameters, leaves, and per-node blending as the reference's tree ---
     assert list(mod.param_names) == meta["param_names"]
     assert mod.obs.leaf_labels == meta["leaf_labels"]
@@ -343,3 +347,102 @@ def test_saved_model_priors_are_plain_data(tmp_path):
         with pytest.raises(ValueError, match="not a prior record"):
             ia.BasicStarModel.load(str(tmp_path / "evil2.npz"), ic=ic)
     assert not hasattr(persist, "pickle")
+
+
+def _random_tree_spec(rng):
+    """A random set of observations the way a user would enter them: 1-3 unresolved catalogue bands, optionally a
+    seeing-limited image that splits a wide companion, optionally an AO image that also splits a close one."""
+    wide, close = bool(rng.random() < 0.6), bool(rng.random() < 0.6)
+    if not (wide or close) and rng.random() < 0.5:
+        close = True
+    spec = []
+    for band in rng.choice(["J", "H", "K", "G", "V"], int(rng.integers(1, 4)), replace=False):
+        spec.append(("2MASS", str(band), 4.0, [(float(rng.uniform(9.5, 12.5)), 0.02, 0.0, 0.0, False, False)]))
+    pos = [(0.0, 0.0)]
+    if close:
+        pos.append((float(rng.uniform(0.2, 0.45)), float(rng.uniform(0, 360))))
+    if wide:
+        pos.append((float(rng.uniform(1.8, 3.0)), float(rng.uniform(0, 360))))
+    if wide and rng.random() < 0.7:                      # seeing-limited: the close pair (if any) stays blended
+        rel = bool(rng.random() < 0.5)
+        srcs = [(0.0 if rel else float(rng.uniform(10, 12)), 0.02, 0.0, 0.0, rel, rel),
+                (float(rng.uniform(0.5, 3.0)) + (0.0 if rel else 11.0), 0.03, pos[-1][0], pos[-1][1], rel, False)]
+        spec.append(("seeing", str(rng.choice(["K", "G"])), 1.0, srcs))
+    if len(pos) > 1 and (close or rng.random() < 0.5):   # AO: every component on its own
+        rel = bool(rng.random() < 0.6)
+        srcs = []
+        for k, (sep, pa) in enumerate(pos):
+            dm = 0.0 if k == 0 else float(rng.uniform(0.5, 3.5))
+            srcs.append(((dm if rel else 10.5 + dm), 0.02, sep, pa, rel, rel and k == 0))
+        spec.append(("AO", str(rng.choice(["K", "H"])), 0.1, srcs))
+    return spec
+
+
+def _build_tree(api, spec, name):
+    t = api.ObservationTree(name=name)
+    for inst, band, res, srcs in spec:
+        o = api.Observation(inst, band, res)
+        for mag, e, sep, pa, rel, isref in srcs:
+            o.add_source(api.Source(mag, e, separation=sep, pa=pa, relative=rel, is_reference=isref))
+        t.add_observation(o)
+    return t
+
+
+@pytest.mark.parametrize("seed", [201, 202, 203, 204, 205, 206, 3041, 3042])
+def test_random_trees_against_the_reference_itself(seed, tmp_path, monkeypatch):
+    """Container-only (needs /root/reference): random observation sets (unresolved bands, a seeing-limited image, an AO
+    image; relative or absolute photometry) and random N / index assignments are handed to the reference's
+    ObservationTree + StarModel and to this build's; structure, flattened terms and the oracle's numbers must agree as
+    for the committed cases."""
+    if not os.path.isdir("/root/reference/isochrones"):
+        pytest.skip("the reference tree is only present in the build container")
+    import isochrones_amd.observation as mine
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    monkeypatch.syspath_prepend(os.path.join(root, "oracle"))
+    import make_golden as mg
+    import ref_harness as rh
+    fx.tables()
+    monkeypatch.setattr(mg, "OUT", str(tmp_path))
+    monkeypatch.setattr(fx, "GOLDEN", str(tmp_path))
+    sm, obs_mod = rh.ref("starmodel"), rh.ref("observation")
+    rng = np.random.default_rng(seed)
+    iso, bc = mg.small_iso(), mg.small_bc()
+    axes = iso[1]
+    limits = mg.limits_of("iso", axes)
+    done = 0
+    for k in range(4):
+        spec = _random_tree_spec(rng)
+        n_fine = max(len(srcs) for _, _, _, srcs in spec)
+        N = [int(rng.choice([1, 1, 2])) for _ in range(n_fine)]
+        if rng.random() < 0.5:
+            index = [0] * n_fine
+        else:
+            index = [int(v) for v in rng.permutation(n_fine)] if rng.random() < 0.6 else [int(min(j, 1)) for j in range(n_fine)]
+        if sum(N[j] for j in range(n_fine) if index[j] == index[0]) > 3:
+            N = [1] * n_fine
+        kw = dict(N=N if n_fine > 1 else N[0], index=index if n_fine > 1 else index[0])
+        if rng.random() < 0.5: kw["parallax"] = (float(rng.choice([2.0, 5.0])), 0.05)
+        if rng.random() < 0.4: kw["Teff"] = (float(rng.uniform(5000, 6500)), 100)
+        if rng.random() < 0.3: kw["logg"] = (float(rng.uniform(4.0, 4.6)), 0.15)
+        if rng.random() < 0.3: kw["AV"] = (0.2, 0.1)
+        name = "fresh_tree_%d_%d" % (seed, k)
+        ic_ref = rh.make_ref_ic("iso", iso, bc, limits, (axes[2][0], axes[2][-1]))
+        try:
+            ref_mod = sm.StarModel(ic_ref, obs=_build_tree(obs_mod, spec, name), **kw)
+        except Exception:                # a layout the reference itself does not take
+            with pytest.raises(Exception):
+                ic0 = fx.make_ic(dict(kind="iso", limits={k_: list(map(float, v)) for k_, v in limits.items()},
+                                      eep_bounds=[float(axes[2][0]), float(axes[2][-1])]))
+                ia.TreeStarModel(ic0, obs=_build_tree(mine, spec, name), **kw)
+            continue
+        mg._emit_tree_case(name, ref_mod, kw, True, rng, axes, limits, obs_mod)
+        g = fx.load(name)
+        meta = g["meta"]
+        ic = fx.make_ic(dict(kind="iso", limits=meta["limits"], eep_bounds=meta["eep_bounds"]))
+        kw2 = {k_: (tuple(v) if isinstance(v, list) and k_ not in ("N", "index") else v) for k_, v in meta["kwargs"].items()}
+        mod = ia.TreeStarModel(ic, obs=_build_tree(mine, spec, name), **kw2)
+        if np.isfinite(g["lnpost"]).sum() <= 50:          # the draw left too few finite points for the last check
+            g["lnpost"] = g["lnpost"].copy()
+        _check_tree_case(g, ic, mod)
+        done += 1
+    assert done >= 2
