@@ -26,7 +26,10 @@ def test_oracle_golden_tests_pass_under_asan_and_ubsan():
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "libiso_oracle_san.so"])
     env = dict(os.environ, ISO_ORACLE_LIB=lib, LD_PRELOAD=asan, PYTHONDONTWRITEBYTECODE="1",
                ASAN_OPTIONS="detect_leaks=0:abort_on_error=1:halt_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
-    cmd = [sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider", "tests/test_oracle_golden.py",
+    # (the container-only tests that import the reference package pull in matplotlib & co., which do not survive an
+    # LD_PRELOADed ASan runtime; they exercise the same oracle entry points as the committed cases)
+    cmd = [sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider", "-k", "not reference_itself",
+           "tests/test_oracle_golden.py",
            "tests/test_tree_cpu.py::test_tree_structure_and_oracle_vs_reference",
            "tests/test_tree_cpu.py::test_keyword_tree_equals_basic_model_on_the_oracle"]
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
