@@ -34,15 +34,26 @@ def build(rng):
     n_stars = 1 if kind == "track" else int(rng.choice([1, 1, 2, 3]))
     nb = int(rng.choice([0, 1, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11]))
     bands = list(ia.grids.DEFAULT_BANDS[:max(nb, 1)])
+    all_fehs = np.array([-2.0, -1.5, -1.0, -0.75, -0.5, -0.25, 0.0, 0.25, 0.5])
+    # the [Fe/H] axis keeps its end points (the bounds below) and a random subset of the inner nodes
+    inner = np.sort(rng.choice(all_fehs[1:-1], int(rng.integers(2, 8)), replace=False))
+    def thin(eeps):
+        """now and then an EEP axis with missing nodes: not uniform, so no O(1) index and no fused kernels -
+        the generic kernel's bisection has to carry the whole model"""
+        if rng.random() < 0.12:
+            keep = np.ones(eeps.size, bool)
+            keep[rng.choice(np.arange(1, eeps.size - 1), int(rng.integers(1, 30)), replace=False)] = False
+            return eeps[keep]
+        return eeps
     if kind == "track":
-        fehs = np.array([-2.0, -1.0, -0.5, -0.25, 0.0, 0.25, 0.5]); masses = ia.grids.mist_masses()[20:150:int(rng.integers(2, 5))]
-        eeps = np.arange(200.0, 200.0 + int(rng.integers(300, 700)))
+        fehs = np.concatenate([[-2.0], inner, [0.5]]); masses = ia.grids.mist_masses()[20:150:int(rng.integers(2, 5))]
+        eeps = thin(np.arange(200.0, 200.0 + int(rng.integers(300, 700))))
         ic = ia.synthetic_track(bands=bands, fehs=fehs, masses=masses, eeps=eeps, eep_bounds=(eeps[0], eeps[-1]),
                                 limits=dict(mass=(masses[0], masses[-1]), feh=(-2.0, 0.5), age=(5, 10.13)))
         axes = [masses, eeps, fehs]; lo = np.array([masses[0], eeps[0], -2.0, 5.0, 0.0]); hi = np.array([masses[-1], eeps[-1], 0.5, 2000.0, 1.0])
     else:
-        ages = ia.grids.mist_log_ages()[40::int(rng.integers(2, 5))]; fehs = np.array([-2.0, -1.0, -0.5, -0.25, 0.0, 0.25, 0.5])
-        eeps = np.arange(150.0, 150.0 + int(rng.integers(300, 750)))
+        ages = ia.grids.mist_log_ages()[40::int(rng.integers(2, 5))]; fehs = np.concatenate([[-2.0], inner, [0.5]])
+        eeps = thin(np.arange(150.0, 150.0 + int(rng.integers(300, 750))))
         ic = ia.synthetic_isochrone(bands=bands, ages=ages, fehs=fehs, eeps=eeps, eep_bounds=(eeps[0], eeps[-1]),
                                     limits=dict(age=(ages[0], ages[-1]), feh=(-2.0, 0.5)))
         axes = [eeps] * n_stars + [ages, fehs]
@@ -71,7 +82,8 @@ def build(rng):
                 else:
                     mod.set_prior(**{name: pr})
                 desc_pri[name] = type(pr).__name__
-    return dict(kind=kind, n_stars=n_stars, nb=nb, obs=sorted(obs), kw=kw, priors=desc_pri), ic, mod, axes, lo, hi
+    return dict(kind=kind, n_stars=n_stars, nb=nb, obs=sorted(obs), kw=kw, priors=desc_pri, n_feh=int(fehs.size),
+                uniform_eep=bool(np.all(np.diff(eeps) == 1.0))), ic, mod, axes, lo, hi
 
 
 def samples(rng, axes, lo, hi, n):
