@@ -284,6 +284,9 @@ def main():
 
     if args.path:
         os.environ["ISOCHRONES_AMD_PATH"] = args.path
+    # the host driver only supports dmabuf IPC: RCCL between the ranks of one node needs this (already exported on the
+    # GPU boxes; set here as well so that a bare launch works)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import ctypes as C
     from isochrones_amd import _cabi, device as dev
