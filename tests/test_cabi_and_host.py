@@ -173,6 +173,8 @@ def test_synthetic_tables_shapes():
 
 def test_reference_style_entry_points_exist():
     """Names a user of the reference imports for this path (isochrones/__init__.py, mist/__init__.py)."""
+    from isochrones_amd.starmodel import EEPPrior
+    assert priors.EEP_prior is EEPPrior                      # isochrones/priors.py:394
     from isochrones_amd.mist import MIST_EvolutionTrack, MIST_Isochrone   # noqa: F401
     from isochrones_amd.interp import DFInterpolator                      # noqa: F401
     from isochrones_amd.starmodel import BasicStarModel, StarModel        # noqa: F401
