@@ -1849,9 +1849,13 @@ int iso_sampler_run(iso_sampler* sp, double* pos, double* lnp, int nsteps, doubl
     S.seed = sp->seed;
     S.chain_rs = sp->chain_layout == ISO_CHAIN_PARAM_MAJOR ? 1 : sp->n_params;
     S.chain_ps = sp->chain_layout == ISO_CHAIN_PARAM_MAJOR ? rows : 1;
-    // ISOCHRONES_AMD_SAMPLER = auto | persistent | stepwise.  The persistent kernel (one workgroup per
-    // ensemble, all iterations in one launch) wins while the catalog is too small for a half-step launch
-    // to fill the chip; both forms produce bit-identical chains.
+    // ISOCHRONES_AMD_SAMPLER = auto | persistent | stepwise.  Both forms produce bit-identical chains.  The persistent
+    // kernel (workgroups own their ensembles for all iterations of the call, positions in LDS) is the faster one
+    // at every catalog size measured (tools/sampler_mode_sweep.py: 7-25 % over 2 x 10^3 ... 4 x 10^5 stars, 1-8 bands,
+    // 1-3 stars per system, 16-64 walkers): beyond the chip's capacity its workgroups run in rounds, and the few
+    // thousand ensembles resident at a time re-read table lines that are still in L2 / Infinity Cache, where a
+    // half-step launch over the whole catalog streams everything from HBM.  The exception is a catalog just above
+    // one round (1 < rounds <= 1.4): the second, nearly empty round costs more than the step-wise form.
     const char* env = getenv("ISOCHRONES_AMD_SAMPLER");
     std::string mode = env ? env : "auto";
     const bool force_dense = mode == "persistent-dense";          // test hook: the register-capped instantiation
@@ -1863,9 +1867,7 @@ int iso_sampler_run(iso_sampler* sp, double* pos, double* lnp, int nsteps, doubl
     const bool fits = lds_bytes <= 64 * 1024;
     if (mode == "persistent" && !fits)
         return fail(ISO_ERR_INVALID, "iso_sampler_run: ensemble too large for the persistent kernel's LDS");
-    // auto: persistent while every workgroup of the launch is resident at once (occupancy of this kernel
-    // instantiation as the runtime reports it); beyond that its workgroups would run in rounds and the
-    // step-wise form has the better throughput
+    // resident = workgroups the chip holds at once (occupancy of this kernel instantiation as the runtime reports it)
     int cus = 0, per_cu = 0;
     HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, sp->device));
     const int64_t blocks = (sp->n_ensembles + group - 1) / group;
@@ -1886,7 +1888,8 @@ int iso_sampler_run(iso_sampler* sp, double* pos, double* lnp, int nsteps, doubl
     }
     S.dense = dense;
     const int64_t resident = (int64_t)cus * per_cu;
-    const bool persistent = nsteps > 0 && fits && (mode == "persistent" || (mode == "auto" && blocks <= resident));
+    const bool rounds_ok = blocks <= resident || (resident > 0 && 5 * blocks > 7 * resident);      // not in (1, 1.4] rounds
+    const bool persistent = nsteps > 0 && fits && (mode == "persistent" || (mode == "auto" && rounds_ok));
     if (persistent) {
         S.step = sp->step;
         S.nsteps = nsteps;

@@ -121,10 +121,11 @@ class FusedEnsembleSampler:
     per half-ensemble (``iso_sampler_*``; Philox counter RNG in-kernel).  ``target`` is a
     :class:`BasicStarModel` (one ensemble) or a :class:`CatalogPosterior` (one ensemble per star,
     all advanced in lock-step; row = star * nwalkers + walker).  A 256-walker half-step is a
-    single ~10 us launch instead of ~25 framework launches; while the whole catalog fits on the
-    chip at once the library runs ALL iterations of a ``run_mcmc`` call in one persistent launch
-    (workgroup-resident ensembles, positions in LDS), which produces bit-identical chains
-    (``ISOCHRONES_AMD_SAMPLER=auto|persistent|stepwise`` selects the form)."""
+    single ~10 us launch instead of ~25 framework launches; whenever an ensemble fits a workgroup's
+    LDS the library runs ALL iterations of a ``run_mcmc`` call in one persistent launch
+    (workgroup-resident ensembles, positions in LDS; catalogs larger than the chip run in rounds),
+    which produces bit-identical chains and is the faster form at every catalog size but those just
+    above one round (``ISOCHRONES_AMD_SAMPLER=auto|persistent|stepwise`` selects the form)."""
 
     def __init__(self, target, nwalkers, a=2.0, seed=0, device=None):
         import ctypes as C

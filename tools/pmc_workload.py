@@ -7,7 +7,8 @@ several workloads run the same kernel (tools/pmc_summarize.py walks the dispatch
 
 cases: cfg2 (single star, 1 band: prior / prior_valid / posterior samples), cfg3 (binary, 6 bands + parallax: the same
 three), generic (cfg2 model on the generic kernel), astero, tree (resolved binary, fast tree kernel),
-quantiles (chain summaries of a 10^4-star catalog, 32 walkers x 100 steps), sampler (cfg 4 persistent kernel).
+quantiles (chain summaries of a 10^4-star catalog, 32 walkers x 100 steps), sampler (the catalog sampler on 2 x 10^5 stars: step-wise and
+persistent kernels).
 """
 import argparse
 import ctypes as C
@@ -179,6 +180,18 @@ def main():
         # 816 B per move: 384 (model cell) + 3 x 128 (BC) + position in/out
         manifest.append(dict(label="sampler_stepwise/200000x32", kernel="k_stretch_half<0, 1, 3", launches=2 * (100 + L // 2),
                              skip=200, n=S * W // 2, algorithmic_bytes_per_launch=float(S * W // 2) * (384 + 3 * 128 + 2 * 48)))
+        # ... and as the library runs a catalog of this size since the auto rule changed: the persistent kernel, whose
+        # workgroups own 16 stars each for all iterations of the call and run in rounds (one launch = L // 2 iterations)
+        os.environ["ISOCHRONES_AMD_SAMPLER"] = "persistent"
+        fs2 = FusedEnsembleSampler(post, W, seed=1)
+        pos2, lnp2 = fs2.run_mcmc(pos, 10, lnprob0=lnp, store=False)
+        torch.cuda.synchronize()
+        fs2.run_mcmc(pos2, L // 2, lnprob0=lnp2, store=False)
+        torch.cuda.synchronize()
+        os.environ.pop("ISOCHRONES_AMD_SAMPLER")
+        manifest.append(dict(label="sampler_persistent/200000x32", kernel="k_stretch_persist<0, 1, 3", launches=2, skip=1,
+                             n=S * W * (L // 2), iterations=L // 2,
+                             algorithmic_bytes_per_launch=float(S * W * (L // 2)) * (384 + 3 * 128) + float(S * W) * 2 * 48))
     json.dump(manifest, open(args.manifest, "w"), indent=1)
     print("manifest:", args.manifest, [m["label"] for m in manifest])
 
