@@ -243,6 +243,11 @@ __global__ __launch_bounds__(BLOCK, DENSE ? 3 : 1) void k_stretch_persist(const 
         kk = mine ? a - g * h : 0;
     }
     const int gs = mine ? g : 0;                          // idle lanes shadow a move of the first ensemble
+    // When every ensemble of this workgroup lies inside one wavefront (W/2 divides 64 and the plain lane mapping is in
+    // use), a half-step only depends on LDS rows its own wave wrote: the waves then need no workgroup barrier between
+    // half-steps and run through the iterations independently - a wave that waits for memory no longer holds up the
+    // other three.  (LDS operations of one wave complete in order; the fence keeps the compiler from moving them.)
+    const bool wave_local = h <= 64 && (64 % h) == 0 && !(h < BLOCK && here * h < BLOCK);
     for (int it = 0; it < S.nsteps; ++it) {
         double* cp = S.chain_pos ? S.chain_pos + (int64_t)it * rows_total * NP + (r0 + gs * W) * S.chain_rs : nullptr;
         double* cl = S.chain_lnp ? S.chain_lnp + (int64_t)it * rows_total + r0 + gs * W : nullptr;
@@ -255,9 +260,15 @@ __global__ __launch_bounds__(BLOCK, DENSE ? 3 : 1) void k_stretch_persist(const 
                                                S.step + (uint32_t)it, lpos + gs * W * NP, llnp + gs * W,
                                                lacc + gs * W, cp, cl);
             }
-            __syncthreads();
+            if (wave_local) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            } else {
+                __syncthreads();
+            }
         }
     }
+    if (wave_local) __syncthreads();                      // the write-back below reads rows of the other waves
     for (int j = threadIdx.x; j < R * NP; j += BLOCK) S.pos[r0 * NP + j] = lpos[j];
     for (int j = threadIdx.x; j < R; j += BLOCK) {
         S.lnp[r0 + j] = llnp[j];
