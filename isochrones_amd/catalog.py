@@ -386,50 +386,73 @@ def initial_positions(post: CatalogPosterior, nwalkers, rng_seed=0, oversample=8
     the parameter bounds (distance centred on the parallax when there is one), evaluate them in
     one launch, keep each star's best W.  Stars that never reach W finite candidates are returned
     in ``failed`` (their rows hold NaN) — per-star failure isolation, as the reference's
-    try/except around each star (isochrones/starfit.py:155-159)."""
+    try/except around each star (isochrones/starfit.py:155-159).
+
+    The candidates are held parameter-major ([D, S, K]: one contiguous plane per parameter, drawn and transformed
+    in place; the catalog kernel reads them through its stride arguments), so a pass costs a few sweeps over
+    S x K doubles per parameter instead of a dozen over the interleaved [S, K, D] block."""
     import torch
     S, D, W = post.n_models, post.n_params, nwalkers
     device = torch.device("cuda", post.device)
     gen = torch.Generator(device=device)
     gen.manual_seed(int(rng_seed))
-    lo = torch.as_tensor(post.bounds_lo, dtype=torch.float64, device=device)
-    hi = torch.as_tensor(post.bounds_hi, dtype=torch.float64, device=device)
+    f64 = dict(dtype=torch.float64, device=device)
+    lo = torch.as_tensor(post.bounds_lo, **f64)
+    hi = torch.as_tensor(post.bounds_hi, **f64)
     names = list(post.param_names)
     i_d = names.index("distance")
-    plx = torch.as_tensor(post.parallax, dtype=torch.float64, device=device)
-    plx_e = torch.as_tensor(post.parallax_unc, dtype=torch.float64, device=device)
+    plx = torch.as_tensor(post.parallax, **f64)
+    plx_e = torch.as_tensor(post.parallax_unc, **f64)
     n_eep = sum(1 for n in names if n.startswith("eep"))
     K = oversample * W
-    best = torch.full((S, W, D), float("nan"), dtype=torch.float64, device=device)
-    best_lnp = torch.full((S, W), -float("inf"), dtype=torch.float64, device=device)
+    # per-star affine maps u -> a + b u of every parameter; mass and a prior-drawn distance are then exponentiated
+    a, b = lo.clone(), hi - lo
+    log_cols = torch.zeros(S, D, dtype=torch.bool, device=device)
+    if "mass" in names:                             # log-uniform in mass
+        j = names.index("mass")
+        a[:, j], b[:, j] = torch.log(lo[:, j]), torch.log(hi[:, j] / lo[:, j])
+        log_cols[:, j] = True
+    dlo = torch.clamp(lo[:, i_d], min=1.0)
+    d0 = 1000.0 / plx
+    rel = torch.clamp(plx_e / plx, min=1e-3, max=0.3)
+    use_plx = (plx > 0) & torch.isfinite(d0)
+    a[:, i_d] = torch.where(use_plx, d0 * (1.0 - 4.0 * rel), torch.log(dlo))         # d0 (1 + 4 rel (2u - 1)) | log-uniform
+    b[:, i_d] = torch.where(use_plx, 8.0 * rel * d0, torch.log(hi[:, i_d] / dlo))
+    log_cols[:, i_d] = ~use_plx
+    cand = torch.empty(D, S, K, **f64)
+    best = torch.full((S, W, D), float("nan"), **f64)
+    best_lnp = torch.full((S, W), -float("inf"), **f64)
     sid = torch.arange(S, device=device, dtype=torch.int32).repeat_interleave(K)
-    for _ in range(max_tries):
-        u = torch.rand(S, K, D, generator=gen, device=device, dtype=torch.float64)
-        cand = lo[:, None, :] + u * (hi - lo)[:, None, :]
-        if "mass" in names:                         # log-uniform in mass
-            j = names.index("mass")
-            cand[..., j] = torch.exp(torch.log(lo[:, None, j]) + u[..., j] * torch.log(hi / lo)[:, None, j])
-        dlo = torch.clamp(lo[:, i_d], min=1.0)
-        logd = torch.log(dlo)[:, None] + u[..., i_d] * torch.log(hi[:, i_d] / dlo)[:, None]
-        d_prior = torch.exp(logd)
-        d0 = 1000.0 / plx
-        rel = torch.clamp(plx_e / plx, min=1e-3, max=0.3)
-        d_plx = d0[:, None] * (1.0 + 4.0 * rel[:, None] * (2.0 * u[..., i_d] - 1.0))
-        use_plx = (plx > 0) & torch.isfinite(d0)
-        cand[..., i_d] = torch.where(use_plx[:, None], d_plx, d_prior)
+    out = dev.empty_f64((S * K,), post.device)
+    for attempt in range(max_tries):
+        for j in range(D):
+            plane = cand[j]
+            plane.uniform_(0.0, 1.0, generator=gen)
+            plane.mul_(b[:, j, None]).add_(a[:, j, None])
+            if bool(log_cols[:, j].all()):
+                plane.exp_()
+            elif bool(log_cols[:, j].any()):
+                rows = log_cols[:, j]
+                plane[rows] = torch.exp(plane[rows])
         if n_eep > 1:                               # eep_0 >= eep_1 >= eep_2
-            cand[..., :n_eep] = torch.sort(cand[..., :n_eep], dim=-1, descending=True).values
-        lnp = post.lnpost(cand.reshape(S * K, D), sid).view(S, K)
-        lnp = torch.where(torch.isfinite(lnp), lnp, torch.full_like(lnp, -float("inf")))
-        allp = torch.cat([best, cand], dim=1)
-        alll = torch.cat([best_lnp, lnp], dim=1)
-        top = torch.topk(alll, W, dim=1)
-        best_lnp = top.values
-        best = allp.gather(1, top.indices[..., None].expand(S, W, D))
+            cand[:n_eep] = torch.sort(cand[:n_eep], dim=0, descending=True).values
+        _cabi.check(_cabi.lib().iso_catalog_lnpost(post._h, dev.ptr(sid), dev.ptr(cand), 1, S * K, S * K, dev.ptr(out),
+                                                   dev.stream_ptr(post.device)))
+        lnp = out.view(S, K)
+        lnp.masked_fill_(~torch.isfinite(lnp), -float("inf"))
+        if attempt == 0:                            # nothing kept yet: the best W of the K new ones
+            top = torch.topk(lnp, W, dim=1)
+            best_lnp = top.values
+            best = torch.stack([cand[j].gather(1, top.indices) for j in range(D)], dim=-1)
+        else:
+            top = torch.topk(torch.cat([best_lnp, lnp], dim=1), W, dim=1)
+            best_lnp = top.values
+            best = torch.stack([torch.cat([best[..., j], cand[j]], dim=1).gather(1, top.indices) for j in range(D)], dim=-1)
         if bool(torch.isfinite(best_lnp).all()):
             break
     failed = ~torch.isfinite(best_lnp).all(dim=1)
-    return best, best_lnp, failed
+    best[failed] = float("nan")
+    return best.contiguous(), best_lnp.contiguous(), failed
 
 
 RESULT_STATS = ("median", "p16", "p84")
