@@ -183,11 +183,20 @@ class CatalogPosterior:
         idx = np.arange(len(catalog)) if indices is None else np.asarray(indices, dtype=int)
         if idx.size == 0:
             raise ValueError("no stars")
-        # template = the first star that has every band (stars lacking some get NaN entries)
-        sub = catalog.df.iloc[idx]
+        # template = the first star that has every band (stars lacking some get NaN entries).  The rows are taken from
+        # the catalog's column arrays (StarCatalog.measurements), not through a DataFrame copy
+        class _Rows:
+            def __init__(self, cat, rows):
+                self.cat, self.rows = cat, rows
+
+            def pair(self, key):
+                v, u = self.cat.measurements[key]
+                return v[self.rows], u[self.rows]
+        sub = _Rows(catalog, idx)
         complete = np.ones(idx.size, dtype=bool)
         for b in catalog.bands:
-            complete &= sub["{}_mag".format(b)].notna().to_numpy() & sub["{}_mag_unc".format(b)].notna().to_numpy()
+            v, u = sub.pair(b)
+            complete &= ~(np.isnan(v) | np.isnan(u))
         if not complete.any():
             raise ValueError("no star of the batch has all of the catalog's bands")
         template = catalog.model(int(idx[int(np.argmax(complete))]), ic, N=N, **model_kwargs)
@@ -206,24 +215,21 @@ class CatalogPosterior:
         n, bands = idx.size, template.bands
         mag_val = np.empty((n, len(bands))); mag_unc = np.empty((n, len(bands)))
         for j, b in enumerate(bands):
-            v = df["{}_mag".format(b)].to_numpy(float)
-            u = df["{}_mag_unc".format(b)].to_numpy(float)
+            v, u = df.pair(b)
             missing = np.isnan(v) | np.isnan(u)
             mag_val[:, j] = np.where(missing, np.nan, v)
             mag_unc[:, j] = np.where(missing, 1.0, u)
         spec_val = np.full((n, 3), np.nan); spec_unc = np.full((n, 3), np.nan)
         for q, name in enumerate(("Teff", "logg", "feh")):
             if name in catalog.props:
-                v = df[name].to_numpy(float)
-                u = df[name + "_unc"].to_numpy(float)
+                v, u = df.pair(name)
                 missing = np.isnan(v) | np.isnan(u)
                 spec_val[:, q] = np.where(missing, np.nan, v)
                 spec_unc[:, q] = np.where(missing, np.nan, u)
         has = np.zeros(n, dtype=np.int32); plx_val = np.zeros(n); plx_unc = np.ones(n)
         dist_hi = None
         if "parallax" in catalog.props:
-            v = df["parallax"].to_numpy(float)
-            u = df["parallax_unc"].to_numpy(float)
+            v, u = df.pair("parallax")
             ok = ~(np.isnan(v) | np.isnan(u))
             has = ok.astype(np.int32)
             plx_val = np.where(ok, v, 0.0)
