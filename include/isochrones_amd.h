@@ -316,6 +316,13 @@ int  iso_chain_quantiles_layout(iso_ctx* ctx, const double* chain, int layout, i
  * milliseconds per launch in *ms_per_launch (measurement helper for bench.py). */
 int  iso_time_lnpost(iso_model* m, const double* pars, int64_t stride_n, int64_t stride_p, int64_t n,
                      double* lnpost_out, int reps, void* stream, double* ms_per_launch);
+/* The same over a rotation of `n_batches` distinct sample batches: launch r evaluates pars[r % n_batches] into
+ * lnpost_out[r % n_batches] (HOST arrays of DEVICE pointers, every batch n rows with the same strides).  With enough
+ * batches the table lines one launch touches have left the 256 MiB Infinity Cache before any launch needs them again,
+ * so the measured time has no inter-launch reuse in it. */
+int  iso_time_lnpost_rotating(iso_model* m, const double* const* pars, double* const* lnpost_out, int n_batches,
+                              int64_t stride_n, int64_t stride_p, int64_t n, int reps, void* stream,
+                              double* ms_per_launch);
 
 #ifdef __cplusplus
 }

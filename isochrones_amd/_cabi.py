@@ -98,7 +98,7 @@ EXPORTED_SYMBOLS = (
     "iso_table_create", "iso_table_destroy", "iso_interp", "iso_interp_host",
     "iso_ic_create", "iso_ic_destroy", "iso_interp_mag", "iso_interp_mag_host",
     "iso_model_create", "iso_model_destroy", "iso_model_n_params",
-    "iso_lnpost", "iso_lnpost_host", "iso_unit_cube", "iso_time_lnpost",
+    "iso_lnpost", "iso_lnpost_host", "iso_unit_cube", "iso_time_lnpost", "iso_time_lnpost_rotating",
     "iso_catalog_create", "iso_catalog_create_columns", "iso_catalog_destroy", "iso_catalog_lnpost",
     "iso_eep_table_create", "iso_eep_table_destroy", "iso_interp_eep", "iso_interp_eep_host",
     "iso_sampler_create_model", "iso_sampler_create_catalog", "iso_sampler_destroy", "iso_sampler_run",
@@ -164,6 +164,8 @@ def lib():
     L.iso_lnpost_host.argtypes = [vp, vp, i64, vp, vp, vp]
     L.iso_unit_cube.argtypes = [vp, pd, i64, i64, i64, vp]
     L.iso_time_lnpost.argtypes = [vp, pd, i64, i64, i64, pd, C.c_int, vp, C.POINTER(dbl)]
+    L.iso_time_lnpost_rotating.argtypes = [vp, C.POINTER(pd), C.POINTER(pd), C.c_int, i64, i64, i64, C.c_int, vp,
+                                           C.POINTER(dbl)]
     L.iso_catalog_create.argtypes = [vp, C.POINTER(IsoModelDesc), i64, C.POINTER(vp)]
     hd = C.POINTER(dbl)
     L.iso_catalog_create_columns.argtypes = [vp, C.POINTER(IsoModelDesc), i64, hd, hd, hd, hd, C.POINTER(C.c_int32), hd, hd,

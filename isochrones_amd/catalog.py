@@ -574,48 +574,89 @@ def fit_stars_gpu(catalog: StarCatalog, ic, indices, N=1, nwalkers=32, nburn=150
     return out
 
 
-def _shard_fingerprint(catalog, mine, N, fit_kwargs):
-    """Digest of everything a stored shard depends on: the stars' names and measurements, the multiplicity and the
-    fit settings (walkers, steps, seed, model keywords, prior settings)."""
+#: bump when the stored result rows change meaning (columns, summaries, sampler defaults)
+SHARD_FORMAT = 2
+
+
+def _stable_repr(key, value):
+    """A representation of a fit setting that is the same in every process: plain data as is, arrays by content.
+    Anything whose default ``repr`` carries a memory address (callables, objects without ``__repr__``) has no such
+    form: the shard digest then changes from run to run and the shard is refitted every time - say so once."""
+    import warnings
+    if value is None or isinstance(value, (bool, int, float, str, bytes)):
+        return repr(value)
+    if isinstance(value, np.ndarray):
+        return "ndarray%s%s:%s" % (value.shape, value.dtype, value.tobytes().hex())
+    if isinstance(value, (list, tuple)):
+        return "[%s]" % ",".join(_stable_repr(key, v) for v in value)
+    if isinstance(value, dict):
+        return "{%s}" % ",".join("%r:%s" % (k, _stable_repr(key, v)) for k, v in sorted(value.items(), key=lambda kv: repr(kv[0])))
+    try:
+        from .priors import prior_to_spec
+        return repr(prior_to_spec(value))
+    except Exception:       # noqa: BLE001 - not a prior with a plain-data form
+        pass
+    text = repr(value)
+    if " at 0x" in text:
+        warnings.warn("fit_catalog: the setting %r has no stable representation (%s); a stored shard can never match "
+                      "it and will be refitted on every run" % (key, type(value).__name__), RuntimeWarning, stacklevel=3)
+    return text
+
+
+def _shard_fingerprint(catalog, mine, N, fit_kwargs, ic=None):
+    """Digest of everything a stored shard depends on: the stars' names and the measurement arrays the fit reads
+    (``StarCatalog.measurements`` - the snapshot taken at construction, which is what ``CatalogPosterior`` consumes, not
+    the live DataFrame), the multiplicity, the fit settings, the catalog's prior settings, the interpolator (its
+    parametrisation, bands and table shapes) and the format of the stored rows."""
     import hashlib
     h = hashlib.sha256()
-    sub = catalog.df.iloc[mine]
-    h.update(repr([str(x) for x in sub.index]).encode())
-    for c in sorted(str(c) for c in catalog.df.columns):
-        col = sub[c]
-        try:
-            h.update(c.encode() + np.ascontiguousarray(col.to_numpy(dtype=float)).tobytes())
-        except (TypeError, ValueError):
-            h.update(c.encode() + repr(list(col)).encode())
+    h.update(repr(("format", SHARD_FORMAT)).encode())
+    h.update(repr([str(catalog.df.index[i]) for i in mine]).encode())
+    for key in sorted(catalog.measurements):
+        v, u = catalog.measurements[key]
+        h.update(key.encode() + b"\0" + np.ascontiguousarray(v[mine], dtype=np.float64).tobytes()
+                 + np.ascontiguousarray(u[mine], dtype=np.float64).tobytes())
     h.update(repr((int(N), tuple(catalog.bands), tuple(catalog.props))).encode())
-    h.update(repr(sorted((k, repr(v)) for k, v in fit_kwargs.items() if k != "timings")).encode())
-    from .priors import prior_to_spec
-
-    def spec(v):
-        try:
-            return repr(prior_to_spec(v))
-        except TypeError:            # a prior class without a plain-data form: its own repr has to do
-            return repr(v)
-
-    h.update(repr(sorted((k, spec(v)) for k, v in catalog._prior_settings.items())).encode())
+    h.update(repr(sorted((k, _stable_repr(k, v)) for k, v in fit_kwargs.items() if k != "timings")).encode())
+    h.update(repr(sorted((k, _stable_repr(k, v)) for k, v in catalog._prior_settings.items())).encode())
+    h.update(repr(_ic_signature(ic)).encode())
     return h.hexdigest()
 
 
-def fit_catalog(catalog: StarCatalog, ic, N=1, fit_fn=None, checkpoint_dir=None, strict=False, **fit_kwargs):
+def _ic_signature(ic):
+    """What identifies the interpolator a shard was fitted with: parametrisation, bands, table shapes, EEP bounds
+    (whatever of these the object has - fit_fn may be handed any stand-in)."""
+    sig = [type(ic).__name__]
+    for name in ("eep_replaces", "bands", "eep_bounds", "param_names"):
+        v = getattr(ic, name, None)
+        sig.append((name, tuple(v) if isinstance(v, (list, tuple)) else v))
+    for name in ("model_grid", "bc_grid"):
+        interp = getattr(getattr(ic, name, None), "interp", None)
+        grid = getattr(interp, "grid", None)
+        sig.append((name, tuple(grid.shape) if grid is not None else None))
+    return tuple(sig)
+
+
+def fit_catalog(catalog: StarCatalog, ic, N=1, fit_fn=None, checkpoint_dir=None, strict=None, **fit_kwargs):
     """Shard the catalog over the ranks of the default process group (star i -> rank (i+1) % P),
     fit every shard with ``fit_fn`` (default: :func:`fit_stars_gpu`) and all-gather the per-star
     result rows.  Returns a DataFrame indexed like ``catalog.df`` on every rank.
 
-    Failure isolation: a rank whose shard cannot be fitted (an exception in ``fit_fn``) contributes NaN rows with
-    ``ok = 0`` and still takes part in every collective, so the other ranks' stars are not lost and nobody waits for
-    a rank that has left; the error texts come back in ``result.attrs["shard_errors"]`` ({rank: message}) with a
-    RuntimeWarning on every rank - or, with ``strict=True``, as a RuntimeError raised on every rank after the
-    exchange.  (The reference wraps each star's fit in try/except, isochrones/starfit.py:155-159.)
+    Failure isolation (runs with more than one rank): a rank whose shard cannot be fitted (an exception in ``fit_fn``)
+    contributes NaN rows with ``ok = 0`` and still takes part in every collective, so the other ranks' stars are not lost
+    and nobody waits for a rank that has left; the error texts come back in ``result.attrs["shard_errors"]``
+    ({rank: message}) with a RuntimeWarning on every rank - or, with ``strict=True``, as a RuntimeError raised on every
+    rank after the exchange.  (The reference wraps each star's fit in try/except, isochrones/starfit.py:155-159.)
+    In a single-process run there is nobody to wait for, so ``strict`` defaults to True there and the original exception
+    propagates (a misspelled keyword or an unwritable directory is an error, not an all-NaN table).
 
     ``checkpoint_dir``: every rank stores its finished shard there (``shard_{rank}of{world}.npz``)
     and a rerun loads it instead of refitting - the reference's "skip stars whose results already exist"
-    (isochrones/starfit.py:66-77).  A stored shard is reused only if the stars, their measurements and the fit
-    settings are the ones it was made with (a digest of all of them is stored next to the rows)."""
+    (isochrones/starfit.py:66-77).  A stored shard is reused only if the stars, their measurements, the interpolator
+    and the fit settings are the ones it was made with (a digest of all of them is stored next to the rows).
+
+    ``result.attrs["timings"]``: this rank's seconds in the fit (``fit_s``) and in the result exchange (``gather_s``)."""
+    import time as _time
     import warnings
     import pandas as pd
     import torch
@@ -623,23 +664,28 @@ def fit_catalog(catalog: StarCatalog, ic, N=1, fit_fn=None, checkpoint_dir=None,
     distributed = dist.is_available() and dist.is_initialized()
     rank = dist.get_rank() if distributed else 0
     world = dist.get_world_size() if distributed else 1
+    if strict is None:
+        strict = world == 1
     n = len(catalog)
     mine = shard_indices(n, rank, world)
     fit_fn = fit_fn or fit_stars_gpu
     width = 3 * (N + 4) + 3
     rows, ckpt, error = None, None, None
-    try:
+    t_fit = _time.perf_counter()
+
+    def fit_shard():
+        import os
+        rows, ckpt = None, None
         if checkpoint_dir is not None:
-            import os
             os.makedirs(checkpoint_dir, exist_ok=True)
             ckpt = os.path.join(checkpoint_dir, "shard_%dof%d.npz" % (rank, world))
-            digest = _shard_fingerprint(catalog, mine, N, fit_kwargs)
+            digest = _shard_fingerprint(catalog, mine, N, fit_kwargs, ic)
             if os.path.exists(ckpt):
                 try:
                     with np.load(ckpt, allow_pickle=False) as z:
                         if np.array_equal(z["indices"], mine) and str(z["digest"]) == digest:
                             rows = z["rows"]
-                except Exception:
+                except Exception:        # noqa: BLE001 - an unreadable shard file is refitted
                     rows = None
         if rows is None:
             rows = np.asarray(fit_fn(catalog, ic, mine, N=N, **fit_kwargs), dtype=np.float64)
@@ -649,10 +695,20 @@ def fit_catalog(catalog: StarCatalog, ic, N=1, fit_fn=None, checkpoint_dir=None,
                 tmp = ckpt + ".tmp.npz"
                 np.savez(tmp, indices=mine, rows=rows, digest=np.array(digest))
                 os.replace(tmp, ckpt)
-    except Exception as e:           # noqa: BLE001 - this rank's stars are lost, the job is not
-        error = "%s: %s" % (type(e).__name__, e)
-        rows = np.full((len(mine), width), np.nan)
-        rows[:, -1] = 0.0
+        return rows
+
+    if world == 1 and strict:
+        rows = fit_shard()                # single process: errors are the caller's, as they come
+    else:
+        try:
+            rows = fit_shard()
+        except Exception as e:           # noqa: BLE001 - this rank's stars are lost, the job is not
+            error = "%s: %s" % (type(e).__name__, e)
+            rows = np.full((len(mine), width), np.nan)
+            rows[:, -1] = 0.0
+    if torch.cuda.is_available() and distributed and dist.get_backend() == "nccl":
+        torch.cuda.synchronize()
+    t_gather = _time.perf_counter()
     full = np.full((n, width), np.nan)
     errors = {}
     if distributed:
@@ -662,19 +718,28 @@ def fit_catalog(catalog: StarCatalog, ic, N=1, fit_fn=None, checkpoint_dir=None,
         buf = torch.full((cap, width + 1), float("nan"), dtype=torch.float64, device=devt)
         buf[: len(mine), 0] = torch.as_tensor(mine, dtype=torch.float64)
         buf[: len(mine), 1:] = torch.as_tensor(rows, dtype=torch.float64)
-        gathered = [torch.empty_like(buf) for _ in range(world)]
-        dist.all_gather(gathered, buf)
-        for g in gathered:
-            g = g.cpu().numpy()
-            ok = np.isfinite(g[:, 0])
-            full[g[ok, 0].astype(int)] = g[ok, 1:]
-        texts = [None] * world
-        dist.all_gather_object(texts, error)
-        errors = {r: t for r, t in enumerate(texts) if t is not None}
+        gathered = torch.empty((world, cap, width + 1), dtype=torch.float64, device=devt)
+        if backend == "nccl":
+            dist.all_gather_into_tensor(gathered, buf)           # one RCCL all-gather into one buffer
+        else:
+            parts = [torch.empty_like(buf) for _ in range(world)]
+            dist.all_gather(parts, buf)
+            gathered = torch.stack(parts)
+        g = gathered.reshape(world * cap, width + 1).cpu().numpy()
+        ok = np.isfinite(g[:, 0])
+        full[g[ok, 0].astype(int)] = g[ok, 1:]
+        # the error texts: one flag reduction first, the (slower) object exchange only when some rank failed
+        flag = torch.tensor([1.0 if error is not None else 0.0], dtype=torch.float64, device=devt)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if float(flag[0]) > 0:
+            texts = [None] * world
+            dist.all_gather_object(texts, error)
+            errors = {r: t for r, t in enumerate(texts) if t is not None}
     else:
         full[mine] = rows
         if error is not None:
             errors = {0: error}
+    t_end = _time.perf_counter()
     if errors:
         msg = "fit_catalog: shard(s) failed - " + "; ".join("rank %d: %s" % kv for kv in sorted(errors.items()))
         if strict:
@@ -683,6 +748,8 @@ def fit_catalog(catalog: StarCatalog, ic, N=1, fit_fn=None, checkpoint_dir=None,
     names = (ic.param_names if N == 1 else tuple(["eep_%d" % i for i in range(N)] + list(ic.param_names[1:])))
     out = pd.DataFrame(full, index=catalog.df.index, columns=result_columns(names))
     out.attrs["shard_errors"] = errors
+    out.attrs["timings"] = {"fit_s": t_gather - t_fit, "gather_s": t_end - t_gather, "world": world, "rank": rank,
+                            "backend": dist.get_backend() if distributed else None, "stars_of_this_rank": int(len(mine))}
     return out
 
 
@@ -729,19 +796,25 @@ def synthetic_catalog(ic, n_stars, bands=None, seed=0, mag_unc=0.02, with_parall
     return StarCatalog(df, bands=bands, props=props), truth
 
 
-def broadcast_interpolator(ic=None, src=0):
+def broadcast_interpolator(ic=None, src=0, rebuild_on_src=False, timings=None):
     """Give every rank the interpolator that only rank ``src`` has loaded (one broadcast
     of the tables at start-up instead of P reads of the table files).  Metadata travels as a small
     pickled object, the dense float64 tables as tensors (RCCL over xGMI with the ``nccl`` backend —
-    the packed model table is ~0.7 GB —, host memory with ``gloo``).  Returns a
-    ModelGridInterpolator on every rank; without an initialised process group it returns ``ic``."""
+    the model table is ~0.7 GB —, host memory with ``gloo``).  Returns a
+    ModelGridInterpolator on every rank; without an initialised process group it returns ``ic``.
+
+    ``rebuild_on_src``: rank ``src`` also rebuilds its interpolator from the broadcast buffers instead of returning
+    the one it passed in (what a one-rank group needs to exercise the route at all: tests).  ``timings`` (dict):
+    receives ``broadcast_s`` (collectives + device-to-host copies) and ``rebuild_s`` (interpolator construction)."""
+    import time as _time
     import torch
     import torch.distributed as dist
     from .interp import DFInterpolator
     from .models import (BolometricCorrectionGrid, EvolutionTrackGrid, EvolutionTrackInterpolator, IsochroneGrid,
                          IsochroneInterpolator)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not rebuild_on_src):
         return ic
+    t0 = _time.perf_counter()
     rank = dist.get_rank()
     use_gpu = dist.get_backend() == "nccl"
     devt = torch.device("cuda", torch.cuda.current_device()) if use_gpu else torch.device("cpu")
@@ -753,14 +826,15 @@ def broadcast_interpolator(ic=None, src=0):
                                   limits=dict(ic.model_grid._limits)),
                        bc=dict(shape=b.grid.shape, columns=list(b.columns), names=list(b.index_names),
                                bands=list(ic.bc_grid.bands or b.columns)))
-    dist.broadcast_object_list(meta, src=src)
+    dist.broadcast_object_list(meta, src=src, device=devt if use_gpu else None)
     meta = meta[0]
+    keep = rank != src or rebuild_on_src
 
     def bcast(arr, shape):
         t = (torch.as_tensor(np.ascontiguousarray(arr, dtype=np.float64), device=devt) if rank == src
              else torch.empty(shape, dtype=torch.float64, device=devt))
         dist.broadcast(t, src=src)
-        return t.cpu().numpy()
+        return t.cpu().numpy() if keep else None
 
     tables = {}
     for key in ("model", "bc"):
@@ -769,7 +843,13 @@ def broadcast_interpolator(ic=None, src=0):
         grid = bcast(srcobj.grid if srcobj is not None else None, shape)
         axes = [bcast(srcobj.index_columns[d] if srcobj is not None else None, (shape[d],)) for d in range(len(shape) - 1)]
         tables[key] = (grid, axes)
-    if rank == src:
+    if use_gpu:
+        torch.cuda.synchronize()
+    t1 = _time.perf_counter()
+    if timings is not None:
+        timings["broadcast_s"] = t1 - t0
+        timings["broadcast_bytes"] = int(sum(8 * int(np.prod(meta[k]["shape"])) for k in ("model", "bc")))
+    if not keep:
         return ic
     mg_cls, ic_cls = ((EvolutionTrackGrid, EvolutionTrackInterpolator) if meta["kind"] == _cabi.KIND_TRACK
                       else (IsochroneGrid, IsochroneInterpolator))
@@ -777,4 +857,7 @@ def broadcast_interpolator(ic=None, src=0):
                                            meta["model"]["names"]), limits=meta["model"]["limits"])
     bcg = BolometricCorrectionGrid(DFInterpolator.from_arrays(tables["bc"][0], tables["bc"][1], meta["bc"]["columns"],
                                                               meta["bc"]["names"]), bands=meta["bc"]["bands"])
-    return ic_cls(mg, bcg, bands=meta["bands"], eep_bounds=meta["eep_bounds"])
+    out = ic_cls(mg, bcg, bands=meta["bands"], eep_bounds=meta["eep_bounds"])
+    if timings is not None:
+        timings["rebuild_s"] = _time.perf_counter() - t1
+    return out

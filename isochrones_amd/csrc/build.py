@@ -54,21 +54,48 @@ def source_digest() -> str:
     return h.hexdigest()
 
 
-def built_digest():
+def file_sha256(path) -> str:
+    import hashlib
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for block in iter(lambda: f.read(1 << 20), b""):
+            h.update(block)
+    return h.hexdigest()
+
+
+def read_stamp():
+    """(digest of the sources the library was built from, sha256 of the library file written by that build), or
+    (None, None).  Line 1 / line 2 of libiso_hip.stamp."""
     try:
-        return open(STAMP).read().strip()
+        lines = open(STAMP).read().split()
     except OSError:
-        return None
+        return None, None
+    return (lines[0] if lines else None), (lines[1] if len(lines) > 1 else None)
+
+
+def built_digest():
+    return read_stamp()[0]
+
+
+def built_library_sha256():
+    """sha256 of libiso_hip.so as the build that wrote the stamp produced it (compare with file_sha256(OUT): the binary
+    next to the stamp is the one that build linked, not a file swapped in later)."""
+    return read_stamp()[1]
+
+
+def up_to_date() -> bool:
+    src, so = read_stamp()
+    return os.path.exists(OUT) and src == source_digest() and so is not None and so == file_sha256(OUT)
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
     digest = source_digest()
-    if not force and not verbose and os.path.exists(OUT) and built_digest() == digest:
-        return OUT                       # the library was built from exactly these sources: nothing to do
+    if not force and not verbose and up_to_date():
+        return OUT                       # this very file was built from exactly these sources: nothing to do
     os.makedirs(OBJDIR, exist_ok=True)
     cc = hipcc()
     me = os.path.abspath(__file__)
-    stale = built_digest() != digest     # objects of another source state are only reused when their times say so
+    stale = not up_to_date()             # objects of another source state are only reused when their times say so
     jobs = []
     objs = []
     for src in sources():
@@ -85,7 +112,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if force or jobs or stale or _newer(OUT, objs):
         subprocess.check_call([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs, cwd=HERE)
     with open(STAMP, "w") as f:
-        f.write(digest + "\n")
+        f.write(digest + "\n" + file_sha256(OUT) + "\n")
     return OUT
 
 

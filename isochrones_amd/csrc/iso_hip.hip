@@ -1050,7 +1050,9 @@ static int lnpost_host_pipelined(iso_model* m, const double* pars, int64_t n, do
         m->d_pipe = m->h_pipe = nullptr;
         m->pipe_rows = 0;
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->d_pipe), sizeof(double) * (size_t)n * np_));
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&m->h_pipe), sizeof(double) * (size_t)n * 3, hipHostMallocMapped));
+        // coherent (fine-grained): the copy-out thread reads results a kernel wrote while later kernels are still running
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&m->h_pipe), sizeof(double) * (size_t)n * 3,
+                              hipHostMallocMapped | hipHostMallocCoherent));
         m->pipe_rows = n;
     }
     if (!m->pipe_stream[0]) HIP_TRY(hipStreamCreateWithFlags(&m->pipe_stream[0], hipStreamNonBlocking));
@@ -1116,6 +1118,14 @@ static int lnpost_host_pipelined(iso_model* m, const double* pars, int64_t n, do
     worker.join();
     (void)hipStreamSynchronize(m->pipe_stream[0]);
     for (hipEvent_t& ev_k : ev) (void)hipEventDestroy(ev_k);
+    // the staging areas of an ordinary batch stay with the model for the next call; those of a very large one
+    // (> 4 Mi rows: 160 MB of device + 96 MB of pinned memory and up) go back at once
+    if (m->pipe_rows > (int64_t(1) << 22)) {
+        (void)hipFree(m->d_pipe);
+        (void)hipHostFree(m->h_pipe);
+        m->d_pipe = m->h_pipe = nullptr;
+        m->pipe_rows = 0;
+    }
     if (rc != ISO_OK) return rc;
     if (e == hipSuccess) e = (hipError_t)worker_err.load();
     if (e != hipSuccess) return fail(ISO_ERR_HIP, std::string("iso_lnpost_host: ") + hipGetErrorString(e));
@@ -1137,7 +1147,10 @@ int iso_lnpost_host(iso_model* m, const double* pars, int64_t n, double* lnpost_
     if (!m->h_stage) {
         // pinned + mapped: the kernel reads the parameters and writes the results straight through
         // PCIe — one launch + one synchronise per call, no separate copies (+ 8 doubles for the completion flag)
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&m->h_stage), sizeof(double) * (CAP * (np_ + 3) + 8), hipHostMallocMapped));
+        // coherent (fine-grained) host memory: the host spins on a flag the kernel raises behind its results while the
+        // kernel may still be running - visibility and ordering of both must not depend on HIP_HOST_COHERENT
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&m->h_stage), sizeof(double) * (CAP * (np_ + 3) + 8),
+                              hipHostMallocMapped | hipHostMallocCoherent));
         m->stage_rows = CAP;
         m->stage_seq = 0;
         m->h_stage[CAP * (np_ + 3)] = 0.0;
@@ -1276,7 +1289,7 @@ int ctx_stage(iso_ctx* ctx, double** host, double** dev)
 {
     if (!ctx->h_stage) {
         HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_stage), sizeof(double) * (ISO_CTX_STAGE_DOUBLES + 8),
-                              hipHostMallocMapped));
+                              hipHostMallocMapped | hipHostMallocCoherent));
         ctx->h_stage[ISO_CTX_STAGE_DOUBLES] = 0.0;
         ctx->stage_seq = 0;
     }
@@ -2004,6 +2017,35 @@ int iso_time_lnpost(iso_model* m, const double* pars, int64_t stride_n, int64_t 
     (void)hipEventDestroy(e1);
     if (rc != ISO_OK) return rc;
     if (e != hipSuccess) return fail(ISO_ERR_HIP, std::string("iso_time_lnpost: ") + hipGetErrorString(e));
+    *ms_per_launch = (double)ms / reps;
+    return ISO_OK;
+}
+
+int iso_time_lnpost_rotating(iso_model* m, const double* const* pars, double* const* lnpost_out, int n_batches,
+                             int64_t stride_n, int64_t stride_p, int64_t n, int reps, void* stream,
+                             double* ms_per_launch)
+{
+    if (!m || !pars || !lnpost_out || !ms_per_launch || reps < 1 || n < 1 || n_batches < 1)
+        return fail(ISO_ERR_INVALID, "iso_time_lnpost_rotating: bad argument");
+    for (int b = 0; b < n_batches; ++b)
+        if (!pars[b] || !lnpost_out[b]) return fail(ISO_ERR_INVALID, "iso_time_lnpost_rotating: NULL batch pointer");
+    DeviceGuard guard(m->ic->ctx->device);
+    hipStream_t s = as_stream(stream);
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    int rc = ISO_OK;
+    HIP_TRY(hipEventRecord(e0, s));
+    for (int r = 0; r < reps && rc == ISO_OK; ++r)
+        rc = enqueue_lnpost(m, pars[r % n_batches], stride_n, stride_p, n, lnpost_out[r % n_batches], nullptr, nullptr, s);
+    hipError_t e = hipEventRecord(e1, s);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc != ISO_OK) return rc;
+    if (e != hipSuccess) return fail(ISO_ERR_HIP, std::string("iso_time_lnpost_rotating: ") + hipGetErrorString(e));
     *ms_per_launch = (double)ms / reps;
     return ISO_OK;
 }

@@ -81,21 +81,25 @@ def ragged_age_arrays(dfi: DFInterpolator, column="age", n_eep=None, with_dt_dee
     (isochrones/models.py:171-203): row i = the rows track i has, left-justified, NaN beyond ``lengths[i]``.
     ``n_eep`` widens the arrays (the reference allocates MIST's 1710 columns whatever the table holds);
     ``with_dt_deep=True`` also returns the ``dt_deep`` column laid out the same way."""
-    def lay_out(col):
-        v = dfi.grid[..., dfi.column_index[col]]
-        n0, n1, ne = v.shape
-        rows = v.reshape(n0 * n1, ne)
-        out = np.full((n0 * n1, max(ne, n_eep or 0)), np.nan)
-        lengths = np.zeros(n0 * n1, dtype=np.int64)
-        for r in range(rows.shape[0]):
-            have = rows[r][~np.isnan(rows[r])]
-            out[r, : have.size] = have
-            lengths[r] = have.size
-        return out, lengths
+    # which (track, EEP) rows the table holds is decided once, from the table itself (a row the ragged frame lacked is
+    # NaN in every column of the padded dense table), and both columns are laid out with that one mask: the reference
+    # copies ``subdf[age].values`` and ``subdf.dt_deep.values`` row-aligned (models.py:189-194), so a NaN inside a
+    # populated row - ``dt_deep`` of a single-point track, the age of a ``star_age <= 0`` row - stays where it is
+    # and counts towards ``lengths``
+    n0, n1, ne = dfi.grid.shape[:3]
+    populated = ~np.isnan(dfi.grid).all(axis=-1).reshape(n0 * n1, ne)
+    lengths = populated.sum(axis=1).astype(np.int64)
 
-    ages, lengths = lay_out(column)
+    def lay_out(col):
+        rows = dfi.grid[..., dfi.column_index[col]].reshape(n0 * n1, ne)
+        out = np.full((n0 * n1, max(ne, n_eep or 0)), np.nan)
+        for r in range(rows.shape[0]):
+            out[r, : lengths[r]] = rows[r][populated[r]]
+        return out
+
+    ages = lay_out(column)
     if with_dt_deep:
-        return ages, lay_out("dt_deep")[0], lengths
+        return ages, lay_out("dt_deep"), lengths
     return ages, lengths
 
 

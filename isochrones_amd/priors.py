@@ -577,11 +577,3 @@ def prior_from_spec(spec):
     else:
         FehPrior.__init__(obj, halo_fraction=num("halo_fraction"), local=bool(spec["local"]), bounds=pair("bounds"))
     return obj
-
-
-def __getattr__(name):
-    # the reference's name for the EEP prior class (isochrones/priors.py:394); it lives next to the models here
-    if name == "EEP_prior":
-        from .starmodel import EEPPrior
-        return EEPPrior
-    raise AttributeError("module %r has no attribute %r" % (__name__, name))

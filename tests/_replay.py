@@ -14,52 +14,7 @@ accept with probability min(1, z^(D-1) p(y)/p(x_k))).
 """
 import numpy as np
 
-M0, M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
-W0, W1 = 0x9E3779B9, 0xBB67AE85
-MASK32 = np.uint64(0xFFFFFFFF)
-
-
-def philox4x32_10(c0, c1, c2, c3, k0, k1):
-    """Vectorised Philox4x32-10 (Salmon et al. 2011): uint32 counter arrays, scalar key -> 4 uint32 arrays."""
-    c0, c1, c2, c3 = (np.asarray(c, dtype=np.uint64) & MASK32 for c in (c0, c1, c2, c3))
-    k0, k1 = int(k0) & 0xFFFFFFFF, int(k1) & 0xFFFFFFFF
-    for _ in range(10):
-        p0 = M0 * c0
-        p1 = M1 * c2
-        n0 = (p1 >> np.uint64(32)) ^ c1 ^ np.uint64(k0)
-        n1 = p1 & MASK32
-        n2 = (p0 >> np.uint64(32)) ^ c3 ^ np.uint64(k1)
-        n3 = p0 & MASK32
-        c0, c1, c2, c3 = n0, n1, n2, n3
-        k0 = (k0 + W0) & 0xFFFFFFFF
-        k1 = (k1 + W1) & 0xFFFFFFFF
-    return c0, c1, c2, c3
-
-
-def philox_kat():
-    """Known-answer vectors of Philox4x32-10 from the Random123 distribution (kat_vectors)."""
-    out = philox4x32_10([0], [0], [0], [0], 0, 0)
-    assert [int(x[0]) for x in out] == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
-    f = 0xFFFFFFFF
-    out = philox4x32_10([f], [f], [f], [f], f, f)
-    assert [int(x[0]) for x in out] == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
-    out = philox4x32_10([0x243f6a88], [0x85a308d3], [0x13198a2e], [0x03707344], 0xa4093822, 0x299f31d0)
-    assert [int(x[0]) for x in out] == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
-
-
-def moves(step, half, rows, h, a, seed):
-    """Random numbers of the moves of global rows `rows` at (step, half): partner index j in [0, h),
-    stretch factor z, acceptance uniform u2 - the same arithmetic as stretch_move()."""
-    rows = np.asarray(rows, dtype=np.uint64)
-    step = np.asarray(step, dtype=np.uint64)
-    r0, r1, r2, r3 = philox4x32_10(np.uint64(2) * step + np.uint64(half), rows & MASK32, rows >> np.uint64(32),
-                                   np.full(rows.shape, 0x51, dtype=np.uint64), seed & 0xFFFFFFFF, seed >> 32)
-    j = ((r0 * np.uint64(h)) >> np.uint64(32)).astype(np.int64)
-    u1 = (r1.astype(np.float64) + (r2 & np.uint64(0xFFFF)).astype(np.float64) * (1.0 / 65536.0)) * (1.0 / 4294967296.0)
-    u2 = (r3.astype(np.float64) + (r2 >> np.uint64(16)).astype(np.float64) * (1.0 / 65536.0) + 0.5 / 65536.0) * (
-        1.0 / 4294967296.0)
-    zr = (a - 1.0) * u1 + 1.0
-    return j, zr * zr / a, u2
+from oracle.cpu_sampler import moves, philox4x32_10, philox_kat  # noqa: F401  (the device sampler's random numbers)
 
 
 def replay(p0, lnp0, chain, chain_lnp, W, a, seed, step0, lnpost_fn, star_of_block=None, margin=1e-9,

@@ -36,7 +36,22 @@ def test_library_was_built_from_the_sources_in_the_tree(built_lib):
     prebuilt binary cannot pass for a fresh build (file times are not consulted)."""
     from isochrones_amd.csrc import build as hip_build
     assert hip_build.built_digest() == hip_build.source_digest()
+    assert hip_build.built_library_sha256() == hip_build.file_sha256(built_lib)      # the binary itself, not only the stamp
     assert os.path.getsize(built_lib) > 1 << 20
+
+
+def test_a_swapped_library_file_is_not_taken_for_the_build(built_lib, tmp_path, monkeypatch):
+    """up_to_date() hashes the .so: a library file that is not the one the stamped build wrote fails the check even
+    though the source digest in the stamp still matches."""
+    import shutil
+    from isochrones_amd.csrc import build as hip_build
+    assert hip_build.up_to_date()
+    fake = tmp_path / "libiso_hip.so"
+    shutil.copy(built_lib, fake)
+    with open(fake, "ab") as f:
+        f.write(b"\0")
+    monkeypatch.setattr(hip_build, "OUT", str(fake))
+    assert not hip_build.up_to_date()
 
 
 def test_struct_layout_matches_header(built_lib):

@@ -39,48 +39,69 @@ def test_bench_two_ranks_prints_one_valid_line():
     r = _launch(2, ["--steps", "5", "--warmup", "2"])
     assert r["n_gpus"] == 2 and r["steps"] == 5 and r["warmup"] == 2
     assert r["scaling"] == "weak" and r["unit"] == "evals/s" and r["dtype"] == "f64" and r["vs_baseline"] is None
-    assert r["value"] > 0 and r["ms_per_step"] > 0
-    # value = the evaluations of BOTH ranks over the max-over-ranks time
+    assert r["value"] > 0 and r["ms_per_step"] > 0 and r["wall_ms_per_step"] >= 0.9 * r["ms_per_step"]
+    # value = the evaluations of BOTH ranks over the slowest rank's device time; the wall-clock bracket beside it
     assert abs(r["value"] - 2 * r["config"]["batch"] * r["steps"] / (r["ms_per_step"] * 1e-3 * r["steps"])) < 1e-6 * r["value"]
+    assert 0 < r["value_wall"] <= r["value"] * 1.02
+    assert r["config"]["distinct_batches"] == 8
     assert r["roofline"]["bound"] == "hbm" and 0 < r["roofline"]["frac"] <= 1.0
     assert r["cpu_baseline"] is None                 # rank 0 at N = 1 only
+    # start-up: rank 0 built the tables, rank 1 received them in one broadcast
+    st = r["startup"]
+    assert st["world"] == 2 and st["tables"] == "broadcast from rank 0" and st["broadcast_bytes"] > 7e8
     cat = r["catalog"]
-    assert "error" not in cat
+    assert "error" not in cat and cat["world"] == 2 and cat["backend"] == "gloo"
     for key, n in (("10000_stars", 10_000), ("400000_stars", 400_000)):
         leg = cat[key]
         assert "error" not in leg, leg
-        assert leg["stars_per_s"] > 0 and leg["ok_fraction_min"] > 0.99
-        # star i -> rank (i + 1) % 2: rank 0 owns the odd indices = n // 2 stars, and the shares add up to the catalog
-        assert leg["stars_per_rank"] == n // 2
-        assert sum(leg["stars_per_rank_all"]) == n and len(leg["stars_per_rank_all"]) == 2
+        assert leg["stars_per_s"] > 0 and leg["ok_fraction"] > 0.99
+        assert leg["fit_s"] > 0 and leg["gather_s"] > 0 and leg["wall_s"] >= leg["fit_s"]
+        # star i -> rank (i + 1) % 2: each rank owns n // 2 stars, and after the all-gather rank 0 holds every row
+        assert leg["stars_per_rank_all"] == [n // 2, n // 2]
+        assert leg["rows_gathered_on_rank0"] == n
 
 
 def test_bench_single_rank_default_line_has_roofline_and_cpu_baseline():
     env = dict(os.environ)
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--no-catalog"],
-                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
     assert p.returncode == 0, p.stderr[-4000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     r = json.loads(lines[0])
-    assert r["n_gpus"] == 1 and r["config"]["workload"].startswith("cfg2")
+    assert "watchdog" not in r
+    assert r["n_gpus"] == 1 and r["config"]["workload"].startswith("cfg2") and r["config"]["distinct_batches"] == 8
     rf = r["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and 0.3 < rf["frac"] <= 1.0
-    assert rf["traffic"] is None or (rf["traffic"] > 0 and "traffic_source" in rf)
+    assert rf["traffic"] is None or (rf["traffic"] > 0 and rf["traffic_source"])
+    assert 0.3 < rf["single_batch"]["frac"] <= 1.0
     cb = r["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["parity_pattern_ok"]
     assert cb["parity_max_rel_err"] < 1e-9
+    assert set(cb["modes"]) == {"B1_scalar_call", "B2_one_thread_1e4", "B2_one_thread_full_batch", "B3_all_cores_full_batch"}
     # every secondary line carries what bounds it (memory side or VALU issue), as a fraction that cannot exceed 1
-    legs = list(r["other_workloads"].values()) + [r["cfg3_binary_6_bands"][w] for w in ("prior", "prior_valid", "posterior")]
-    assert "error" not in r["cfg3_binary_6_bands"]
+    c3 = r["cfg3_binary_6_bands"]
+    assert "error" not in c3
+    legs = list(r["other_workloads"].values()) + [c3[w] for w in ("prior", "prior_valid", "posterior")]
     for leg in legs + [{"roofline": rf["bounds"]}]:
         b = leg["roofline"]
+        if b["bound"] is None:                       # no counter record for this workload (yet): nothing is claimed
+            continue
         assert b["bound"] in ("hbm", "valu") and 0.3 < b["frac"] <= 1.0, b
         assert b["source"].startswith("static") and 0 < b["hbm"]["frac"] <= 1.0 and 0 < b["valu"]["frac"] <= 1.0
+    # cfg 3: a measured CPU baseline (B1 / B2 / B3) next to the kernel
+    b3 = c3["cpu_baseline"]
+    assert b3["kind"] == "port" and b3["parity_pattern_ok"] and b3["parity_max_rel_err"] < 1e-9
+    assert c3["speedup_vs_cpu_all_cores"] > 1 and c3["speedup_vs_cpu_scalar_calls"] > 50
+    # cfg 4: the fit on the GPU and the SAME fit run on the host (measured, not estimated), chains compared
     c4 = r["cfg4_mcmc_256x5000"]
     assert "error" not in c4 and c4["finite_chain"] and 0.1 < c4["acceptance"] < 0.8 and c4["gpu_wall_s"] < 2.0
-    assert c4["cpu_scalar_calls_estimated_s"] > c4["gpu_wall_s"]
-    assert set(cb["modes"]) == {"B1_scalar_call", "B2_one_thread_1e4", "B2_one_thread_full_batch", "B3_all_cores_full_batch"}
-    assert r["cfg3_binary_6_bands"]["posterior"]["roofline"]["bound"] == "valu"          # cache-resident batch
-    assert r["cfg3_binary_6_bands"]["prior_valid"]["roofline"]["bound"] == "hbm"
+    assert c4["cpu_wall_s"] > c4["gpu_wall_s"] and c4["cpu_fit"]["one_walker_per_call"]["lnpost_evals"] == 256 * 5000
+    assert c4["gpu_vs_cpu_chain"]["steps_identical_to_1e-9"] >= 100
+    assert abs(c4["cpu_fit"]["one_walker_per_call"]["acceptance"] - c4["acceptance"]) < 0.02
+    # cfg 5: fit_catalog on this rank + a CPU subsample
+    leg = r["catalog"]["10000_stars"]
+    assert leg["ok_fraction"] > 0.99 and leg["rows_gathered_on_rank0"] == 10_000
+    assert leg["cpu_baseline"]["fitted"] >= 60 and leg["cpu_baseline"]["stars_per_s"] > 0
+    assert leg["gpu_over_cpu_one_thread"] if "gpu_over_cpu_one_thread" in leg else leg["cpu_baseline"]["gpu_over_cpu_one_thread"] > 10

@@ -706,10 +706,13 @@ def test_lnpost_on_mass_age_feh_distance_av_samples():
 
 def test_gpu_box_runs_the_library_built_from_these_sources():
     """The prebuilt libiso_hip.so that travelled to the GPU box carries the digest of exactly the sources next to
-    it (isochrones_amd/csrc/build.py: source_digest), and it is the file this process has mapped."""
+    it (isochrones_amd/csrc/build.py: source_digest) and is byte for byte the file that build wrote (sha256 in the
+    stamp), and it is the file this process has mapped."""
     from isochrones_amd import _cabi
     from isochrones_amd.csrc import build as hip_build
     assert hip_build.built_digest() == hip_build.source_digest()
+    # ... and the binary is the one that build linked: its sha256 is stored next to the source digest
+    assert hip_build.built_library_sha256() == hip_build.file_sha256(_cabi.library_path())
     _cabi.lib()
     assert os.path.realpath(_cabi.library_path()) in {os.path.realpath(l.split()[-1]) for l in open("/proc/self/maps")
                                                       if "libiso_hip.so" in l}

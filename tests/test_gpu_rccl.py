@@ -1,0 +1,84 @@
+"""The RCCL route of the catalog path on the one GPU of the test box: a world_size-1 `nccl` process group (backend
+"nccl" is RCCL on ROCm) through which `broadcast_interpolator` and `fit_catalog` run their collectives - the broadcast
+of the tables, the all-gather of the result rows, the error-flag reduction.  The sharding logic itself is covered with
+world_size-2 gloo groups in tests/test_sampler_catalog_cpu.py; what this adds is that librccl is loaded and executes
+this build's calls (scripts/batch_starfit:60-62 is the reference's sharding rule; SURVEY 8e names the two collectives)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SCRIPT = r'''
+import json, os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+import torch
+import torch.distributed as dist
+import isochrones_amd as ia
+from isochrones_amd.catalog import fit_stars_gpu
+
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+out = {"backend": dist.get_backend(), "world": dist.get_world_size()}
+fehs = np.array([-1.0, -0.5, 0.0, 0.5]); masses = np.array([0.7, 0.9, 1.0, 1.1, 1.3, 2.0]); eeps = np.arange(250.0, 460.0)
+ic0 = ia.synthetic_track(bands=("G", "BP", "RP"), fehs=fehs, masses=masses, eeps=eeps,
+                         limits=dict(mass=(0.7, 2.0), feh=(-1.0, 0.5), age=(5, 10.13)), eep_bounds=(250, 459))
+# 1. the tables travel through RCCL broadcasts (device buffers) and the interpolator is rebuilt from what arrived
+tm = {}
+ic = ia.broadcast_interpolator(ic0, src=0, rebuild_on_src=True, timings=tm)
+assert ic is not ic0
+out["broadcast"] = tm
+for a, b in ((ic.model_grid.interp, ic0.model_grid.interp), (ic.bc_grid.interp, ic0.bc_grid.interp)):
+    assert np.array_equal(a.grid, b.grid, equal_nan=True) and list(a.columns) == list(b.columns)
+    assert all(np.array_equal(x, y) for x, y in zip(a.index_columns, b.index_columns))
+assert ic.bands == ic0.bands and tuple(ic.eep_bounds) == tuple(ic0.eep_bounds) and ic.kind == ic0.kind
+# 2. fit_catalog: the shard (all stars at world 1) is fitted on the device, the rows go through all_gather_into_tensor
+rng = np.random.default_rng(3)
+cat, truth = ia.synthetic_catalog(ic, 96, bands=["G", "BP", "RP"], seed=5, mag_unc=0.01)
+res = ia.fit_catalog(cat, ic, strict=True, nwalkers=32, nburn=60, niter=40, seed=9)
+tmg = res.attrs["timings"]
+assert tmg["backend"] == "nccl" and tmg["world"] == 1 and tmg["stars_of_this_rank"] == 96
+direct = fit_stars_gpu(cat, ic, np.arange(96), nwalkers=32, nburn=60, niter=40, seed=9)
+assert np.array_equal(res.values, direct, equal_nan=True)          # gathered rows = the rows of the fit, bit for bit
+out["ok_fraction"] = float((res["ok"] == 1).mean())
+out["timings"] = {k: v for k, v in tmg.items() if isinstance(v, (int, float, str))}
+# 3. a failing shard still reaches the collectives and reports through them (strict=False isolation at world 1)
+import warnings
+with warnings.catch_warnings(record=True) as w:
+    warnings.simplefilter("always")
+    bad = ia.fit_catalog(cat, ic, strict=False, fit_fn=lambda *a, **k: (_ for _ in ()).throw(RuntimeError("boom")))
+assert bad["ok"].eq(0).all() and "boom" in bad.attrs["shard_errors"][0]
+# which librccl the process has mapped
+maps = open("/proc/self/maps").read()
+out["rccl_mapped"] = sorted({ln.split()[-1] for ln in maps.splitlines() if "rccl" in ln.lower()})
+dist.barrier()
+dist.destroy_process_group()
+print("RESULT " + json.dumps(out))
+'''
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_world1_nccl_group_runs_broadcast_and_fit_catalog(tmp_path):
+    script = tmp_path / "rccl_world1.py"
+    script.write_text(SCRIPT % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1",
+               LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, str(script)], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-4000:])
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")][-1]
+    out = json.loads(line[len("RESULT "):])
+    assert out["backend"] == "nccl" and out["world"] == 1
+    assert out["ok_fraction"] > 0.9
+    assert out["rccl_mapped"], "no librccl in the process map: the nccl backend did not load RCCL"
+    assert out["broadcast"]["broadcast_bytes"] > 0 and out["broadcast"]["broadcast_s"] > 0

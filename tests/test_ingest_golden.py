@@ -130,3 +130,27 @@ def test_other_seeds_and_table_shapes_against_the_reference_itself(seed, tmp_pat
         test_standard_columns_dense_grid_and_derivative(fresh, pre, tracks, deriv)
     test_ragged_age_arrays(fresh)
     test_bc_frames_to_dense_table(fresh, tmp_path)
+
+
+def test_ragged_arrays_keep_nans_of_populated_rows_in_place():
+    """The reference lays ``age`` and ``dt_deep`` out row-aligned (models.py:189-194: both are ``.values`` of the same
+    sub-frame): a NaN inside a populated row - ``dt_deep`` of a single-point track, the age of a ``star_age <= 0`` row -
+    stays at its row and counts towards ``lengths``; only rows the ragged frame lacked (NaN in every column) are padding."""
+    from isochrones_amd.interp import DFInterpolator
+    fehs, masses, eeps = np.array([-0.5, 0.0]), np.array([0.8, 1.0]), np.arange(1.0, 7.0)
+    grid = np.full((2, 2, 6, 3), np.nan)                      # columns: age, dt_deep, Teff
+    rng = np.random.default_rng(0)
+    lengths = {(0, 0): 6, (0, 1): 4, (1, 0): 1, (1, 1): 5}
+    for (i, j), n in lengths.items():
+        grid[i, j, :n, 0] = np.sort(rng.uniform(8, 10, n))
+        grid[i, j, :n, 1] = rng.uniform(0.1, 1.0, n)
+        grid[i, j, :n, 2] = rng.uniform(4000, 7000, n)
+    grid[1, 0, 0, 1] = np.nan                                 # single-point track: its derivative is NaN
+    grid[0, 1, 0, 0] = np.nan                                 # star_age <= 0: log10 age NaN in a row that exists
+    dfi = DFInterpolator.from_arrays(grid, [fehs, masses, eeps], ["age", "dt_deep", "Teff"], ["feh", "mass", "eep"])
+    age, dt, ln = ingest.ragged_age_arrays(dfi, "age", with_dt_deep=True)
+    assert list(ln) == [6, 4, 1, 5]
+    assert np.isnan(dt[2, 0]) and np.array_equal(age[2, :1], grid[1, 0, :1, 0])
+    assert np.isnan(age[1, 0]) and np.array_equal(age[1, 1:4], grid[0, 1, 1:4, 0])
+    assert np.array_equal(dt[1, :4], grid[0, 1, :4, 1])       # dt_deep stays aligned with its ages
+    assert np.isnan(age[:, 6:]).all() if age.shape[1] > 6 else True

@@ -329,3 +329,54 @@ def test_broadcast_interpolator_world2_gloo(tmp_path):
     for k in a.files:
         assert np.array_equal(a[k], b[k], equal_nan=True) if a[k].dtype.kind == "f" else np.array_equal(a[k], b[k]), k
     assert b["grid"].shape == (3, 3, 40, 16) and list(b["bands"]) == ["J", "K"] and int(b["kind"]) == 1
+
+
+def test_fit_catalog_single_process_errors_propagate_and_strict_false_isolates():
+    """One process: a failing fit_fn / a wrong result width is the caller's error (strict defaults to True there);
+    strict=False keeps the per-shard isolation (NaN rows, ok = 0, RuntimeWarning)."""
+    import pandas as pd
+    df = pd.DataFrame({"V_mag": np.linspace(8, 12, 5), "V_mag_unc": 0.02}, index=["s%d" % i for i in range(5)])
+    cat = ia.StarCatalog(df, bands=["V"])
+
+    def bad_kw(catalog, ic, indices, N=1):
+        return np.zeros((len(indices), 18))
+
+    with pytest.raises(TypeError):                               # misspelled keyword reaches the caller as TypeError
+        ia.fit_catalog(cat, ic=None_IC(), fit_fn=bad_kw, nwalkerz=32)
+    with pytest.raises(ValueError, match="expected"):
+        ia.fit_catalog(cat, ic=None_IC(), fit_fn=lambda c, i, idx, N=1: np.zeros((len(idx), 3)))
+    with pytest.warns(RuntimeWarning, match="shard"):
+        res = ia.fit_catalog(cat, ic=None_IC(), fit_fn=bad_kw, nwalkerz=32, strict=False)
+    assert res["ok"].eq(0).all() and 0 in res.attrs["shard_errors"]
+    assert set(res.attrs["timings"]) >= {"fit_s", "gather_s", "world"}
+
+
+def test_checkpoint_digest_covers_the_interpolator_and_flags_unstable_settings(tmp_path):
+    import pandas as pd
+    from isochrones_amd.catalog import _shard_fingerprint
+    df = pd.DataFrame({"V_mag": np.linspace(8, 12, 5), "V_mag_unc": 0.02}, index=["s%d" % i for i in range(5)])
+    cat = ia.StarCatalog(df, bands=["V"])
+    mine = np.arange(5)
+
+    class TrackIC(None_IC):
+        eep_replaces, bands = "age", ("V",)
+
+    class IsoIC(None_IC):
+        eep_replaces, bands = "mass", ("V",)
+
+    a = _shard_fingerprint(cat, mine, 1, dict(nwalkers=32), TrackIC())
+    assert a == _shard_fingerprint(cat, mine, 1, dict(nwalkers=32), TrackIC())
+    assert a != _shard_fingerprint(cat, mine, 1, dict(nwalkers=32), IsoIC())          # other parametrisation
+    IsoIC.eep_replaces = "age"
+    IsoIC.bands = ("V", "J")
+    assert a != _shard_fingerprint(cat, mine, 1, dict(nwalkers=32), IsoIC())          # other bands
+    # the digest reads the arrays the fit reads (the catalog's snapshot), not the live frame
+    cat.df = cat.df.assign(V_mag=99.0)                 # a new frame: the measurement arrays are what they were
+    assert a == _shard_fingerprint(cat, mine, 1, dict(nwalkers=32), TrackIC())
+    cat.measurements["V"][0][2] += 0.5
+    assert a != _shard_fingerprint(cat, mine, 1, dict(nwalkers=32), TrackIC())
+    # arrays are hashed by content; an object whose repr is its address is flagged
+    k = dict(model_kwargs=dict(w=np.arange(3.0)))
+    assert _shard_fingerprint(cat, mine, 1, k, TrackIC()) == _shard_fingerprint(cat, mine, 1, dict(model_kwargs=dict(w=np.arange(3.0))), TrackIC())
+    with pytest.warns(RuntimeWarning, match="no stable representation"):
+        _shard_fingerprint(cat, mine, 1, dict(callback=object()), TrackIC())

@@ -25,7 +25,7 @@ sys.path.insert(0, ROOT)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--manifest", required=True)
-    ap.add_argument("--launches", type=int, default=12)
+    ap.add_argument("--launches", type=int, default=18)
     ap.add_argument("--cases", default="cfg2,cfg3,generic,astero,tree,quantiles,primitives,sampler")
     ap.add_argument("--n", type=int, default=1_000_000)
     args = ap.parse_args()
@@ -39,49 +39,64 @@ def main():
     L, n = args.launches, args.n
     cases = args.cases.split(",")
 
-    def lnpost_launches(label, kernel, mod, pars, bytes_per_eval):
-        pt = torch.as_tensor(np.ascontiguousarray(pars.T), device="cuda")
-        out = torch.empty(pars.shape[0], dtype=torch.float64, device="cuda")
+    NB = 8      # distinct sample batches a workload's launches rotate over (no launch finds lines of the previous ones in the
+                # 256 MiB Infinity Cache: a batch touches ~0.5-1.2 GB of table lines), as bench.py's timed steps do
+
+    def lnpost_launches(label, kernel, mod, batches, bytes_per_eval):
+        """`batches`: list of [n, D] host arrays; launch r evaluates batch r % len(batches)."""
+        n_rows = batches[0].shape[0]
+        pts = [torch.as_tensor(np.ascontiguousarray(b.T), device="cuda") for b in batches]
+        outs = [torch.empty(n_rows, dtype=torch.float64, device="cuda") for _ in batches]
+        p_arr = (C.c_void_p * len(pts))(*[t.data_ptr() for t in pts])
+        o_arr = (C.c_void_p * len(pts))(*[t.data_ptr() for t in outs])
         ms = C.c_double()
         h = mod.handle(torch.cuda.current_device())
         torch.cuda.synchronize()
-        _cabi.check(lib.iso_time_lnpost(h, dev.ptr(pt), 1, pars.shape[0], pars.shape[0], dev.ptr(out), L, dev.stream_ptr(),
-                                        C.byref(ms)))
+        _cabi.check(lib.iso_time_lnpost_rotating(h, p_arr, o_arr, len(pts), 1, n_rows, n_rows, L, dev.stream_ptr(), C.byref(ms)))
         torch.cuda.synchronize()
-        manifest.append(dict(label=label, kernel=kernel, launches=L, skip=2, n=int(pars.shape[0]), ms_per_launch_profiled=ms.value,
-                             algorithmic_bytes_per_launch=float(bytes_per_eval) * pars.shape[0],
-                             finite_fraction=float(torch.isfinite(out).double().mean())))
+        manifest.append(dict(label=label, kernel=kernel, launches=L, skip=2, n=int(n_rows), ms_per_launch_profiled=ms.value,
+                             distinct_batches=len(pts), algorithmic_bytes_per_launch=float(bytes_per_eval) * n_rows,
+                             finite_fraction=float(torch.isfinite(outs[0]).double().mean())))
 
     if "cfg2" in cases or "generic" in cases:
         ic, mod = bench.build_model()
-        samples = {wl: bench.make_samples(np.random.default_rng(12345 if wl == "prior_valid" else 999), n, wl)
+        samples = {wl: [bench.make_samples(np.random.default_rng((12345 if wl == "prior_valid" else 999) + b), n, wl) for b in range(NB)]
                    for wl in ("prior", "prior_valid", "posterior")}
         if "cfg2" in cases:
-            mod.lnpost(samples["prior"][:4096])                         # builds the packs outside the counted launches
-            for wl, pars in samples.items():
-                lnpost_launches("cfg2/" + wl, "k_lnpost_fast<0, 1, 1, true, false, false>", mod, pars, 560)
+            mod.lnpost(samples["prior"][0][:4096])                      # builds the packs outside the counted launches
+            for wl, batches in samples.items():
+                lnpost_launches("cfg2/" + wl, "k_lnpost_fast<0, 1, 1, true, false, false>", mod, batches, 560)
+            # the one-batch-repeated form of rounds 1-2 next to it (what the Infinity Cache hides)
+            lnpost_launches("cfg2/prior_valid_single_batch", "k_lnpost_fast<0, 1, 1, true, false, false>", mod,
+                            samples["prior_valid"][:1], 560)
         if "generic" in cases:
             os.environ["ISOCHRONES_AMD_PATH"] = "generic"
             ic_g, mod_g = bench.build_model()
-            mod_g.lnpost(samples["prior"][:4096])
+            mod_g.lnpost(samples["prior"][0][:4096])
             for wl in ("prior_valid", "posterior"):
                 lnpost_launches("generic/" + wl, "k_lnpost<0, 1, 1", mod_g, samples[wl], 560)
             os.environ.pop("ISOCHRONES_AMD_PATH")
             del mod_g, ic_g
-        del mod, ic
+        del mod, ic, samples
     if "cfg3" in cases:
-        ic3, mod3, sets = bench_configs.cfg3_model_and_samples(n)
-        mod3.lnpost(sets["prior"][:4096])
-        for wl, pars in sets.items():
-            lnpost_launches("cfg3/" + wl, "k_lnpost_fast<1, 2, 6, true, false, false>", mod3, pars, 2360)
+        ic3, mod3 = bench_configs.cfg3_model()
+        first = True
+        for wl in ("prior", "prior_valid", "posterior"):
+            batches = [bench_configs.cfg3_samples(n, wl, seed=3 + 17 * b) for b in range(NB)]
+            if first:
+                mod3.lnpost(batches[0][:4096])
+                first = False
+            lnpost_launches("cfg3/" + wl, "k_lnpost_fast<1, 2, 6, true, false, false>", mod3, batches, 2360)
+            del batches
         del mod3, ic3
     if "astero" in cases:
         ic = ia.synthetic_track(bands=("V",))
         mod = ia.SingleStarModel(ic, Teff=(5770, 100), logg=(4.5, 0.1), feh=(0.0, 0.15), V=(10.0, 0.05),
                                  nu_max=(3000.0, 100.0), delta_nu=(135.0, 3.0))
-        pars = bench.make_samples(np.random.default_rng(12345), n, "prior_valid")
-        mod.lnpost(pars[:4096])
-        lnpost_launches("astero/prior_valid", "k_lnpost_fast<0, 1, 1, true, false, true>", mod, pars, 688)
+        batches = [bench.make_samples(np.random.default_rng(12345 + b), n, "prior_valid") for b in range(NB)]
+        mod.lnpost(batches[0][:4096])
+        lnpost_launches("astero/prior_valid", "k_lnpost_fast<0, 1, 1, true, false, true>", mod, batches, 688)
+        del batches
         del mod, ic
     if "tree" in cases:
         mod, pars = bench_configs.tree_model_and_samples(n)
