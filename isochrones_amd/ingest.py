@@ -81,13 +81,13 @@ def ragged_age_arrays(dfi: DFInterpolator, column="age", n_eep=None, with_dt_dee
     (isochrones/models.py:171-203): row i = the rows track i has, left-justified, NaN beyond ``lengths[i]``.
     ``n_eep`` widens the arrays (the reference allocates MIST's 1710 columns whatever the table holds);
     ``with_dt_deep=True`` also returns the ``dt_deep`` column laid out the same way."""
-    # which (track, EEP) rows the table holds is decided once, from the table itself (a row the ragged frame lacked is
-    # NaN in every column of the padded dense table), and both columns are laid out with that one mask: the reference
-    # copies ``subdf[age].values`` and ``subdf.dt_deep.values`` row-aligned (models.py:189-194), so a NaN inside a
-    # populated row - ``dt_deep`` of a single-point track, the age of a ``star_age <= 0`` row - stays where it is
-    # and counts towards ``lengths``
+    # which (track, EEP) rows a track has is decided once, from the age column (a row the ragged frame lacked is NaN
+    # there in the padded dense table), and both columns are laid out with that one mask: the reference copies
+    # ``subdf[age].values`` and ``subdf.dt_deep.values`` row-aligned (models.py:189-194), so a NaN ``dt_deep`` at a
+    # populated age - a single-point track, whose derivative is undefined - stays next to its age instead of shifting
+    # the rest of the row
     n0, n1, ne = dfi.grid.shape[:3]
-    populated = ~np.isnan(dfi.grid).all(axis=-1).reshape(n0 * n1, ne)
+    populated = ~np.isnan(dfi.grid[..., dfi.column_index[column]]).reshape(n0 * n1, ne)
     lengths = populated.sum(axis=1).astype(np.int64)
 
     def lay_out(col):

@@ -132,10 +132,10 @@ def test_other_seeds_and_table_shapes_against_the_reference_itself(seed, tmp_pat
     test_bc_frames_to_dense_table(fresh, tmp_path)
 
 
-def test_ragged_arrays_keep_nans_of_populated_rows_in_place():
+def test_ragged_arrays_keep_dt_deep_aligned_with_its_ages():
     """The reference lays ``age`` and ``dt_deep`` out row-aligned (models.py:189-194: both are ``.values`` of the same
-    sub-frame): a NaN inside a populated row - ``dt_deep`` of a single-point track, the age of a ``star_age <= 0`` row -
-    stays at its row and counts towards ``lengths``; only rows the ragged frame lacked (NaN in every column) are padding."""
+    sub-frame): a NaN ``dt_deep`` at a populated age (a single-point track: no derivative) stays next to its age and the
+    values after it do not shift; ``lengths`` describes both arrays."""
     from isochrones_amd.interp import DFInterpolator
     fehs, masses, eeps = np.array([-0.5, 0.0]), np.array([0.8, 1.0]), np.arange(1.0, 7.0)
     grid = np.full((2, 2, 6, 3), np.nan)                      # columns: age, dt_deep, Teff
@@ -146,11 +146,12 @@ def test_ragged_arrays_keep_nans_of_populated_rows_in_place():
         grid[i, j, :n, 1] = rng.uniform(0.1, 1.0, n)
         grid[i, j, :n, 2] = rng.uniform(4000, 7000, n)
     grid[1, 0, 0, 1] = np.nan                                 # single-point track: its derivative is NaN
-    grid[0, 1, 0, 0] = np.nan                                 # star_age <= 0: log10 age NaN in a row that exists
+    grid[0, 1, 1, 1] = np.nan                                 # a NaN derivative in the middle of a track
     dfi = DFInterpolator.from_arrays(grid, [fehs, masses, eeps], ["age", "dt_deep", "Teff"], ["feh", "mass", "eep"])
     age, dt, ln = ingest.ragged_age_arrays(dfi, "age", with_dt_deep=True)
     assert list(ln) == [6, 4, 1, 5]
     assert np.isnan(dt[2, 0]) and np.array_equal(age[2, :1], grid[1, 0, :1, 0])
-    assert np.isnan(age[1, 0]) and np.array_equal(age[1, 1:4], grid[0, 1, 1:4, 0])
-    assert np.array_equal(dt[1, :4], grid[0, 1, :4, 1])       # dt_deep stays aligned with its ages
-    assert np.isnan(age[:, 6:]).all() if age.shape[1] > 6 else True
+    assert np.array_equal(age[1, :4], grid[0, 1, :4, 0])
+    assert np.array_equal(dt[1, :4], grid[0, 1, :4, 1], equal_nan=True) and np.isnan(dt[1, 1]) and not np.isnan(dt[1, 2])
+    for r, n in enumerate(ln):
+        assert np.isnan(age[r, n:]).all() and np.isnan(dt[r, n:]).all()

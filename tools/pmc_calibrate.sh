@@ -15,10 +15,11 @@ grep -i -E "^\s*(Name|counter)?.*(TCC_EA|MALL|HBM|DRAM|FETCH|WRITE_SIZE|TCC_REQ|
 CGROUPS=(
  "FETCH_SIZE"
  "WRITE_SIZE"
- "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum"
+ "TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum"
  "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"
  "TCC_HIT_sum TCC_MISS_sum"
  "TCC_EA0_RDREQ_DRAM_sum TCC_EA0_WRREQ_DRAM_sum"
+ "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_LEVEL_sum GRBM_GUI_ACTIVE"
 )
 i=0
 for g in "${CGROUPS[@]}"; do

@@ -13,6 +13,8 @@ CGROUPS=(
  "TCC_HIT_sum TCC_MISS_sum"
  "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE"
  "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES"
+ "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"
+ "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_LEVEL_sum"
 )
 i=0
 for g in "${CGROUPS[@]}"; do

@@ -91,6 +91,16 @@ def main():
             d["wave_wait_fraction"] = c("SQ_WAIT_ANY") / c("SQ_WAVE_CYCLES")
         if c("SQ_LDS_BANK_CONFLICT") is not None and c("SQ_LDS_IDX_ACTIVE"):
             d["lds_conflict_fraction"] = c("SQ_LDS_BANK_CONFLICT") / c("SQ_LDS_IDX_ACTIVE")
+        # memory-side request mix: write requests by size, and the mean time a read request spends outstanding at the
+        # fabric interface (LEVEL = outstanding requests summed over TCC cycles; / requests = cycles per request): HBM
+        # misses and Infinity-Cache hits differ in that latency, the byte counters do not separate them
+        if c("TCC_EA0_WRREQ_sum") is not None and c("TCC_EA0_WRREQ_64B_sum") is not None:
+            d["write_requests"] = c("TCC_EA0_WRREQ_sum")
+            d["write_requests_64B"] = c("TCC_EA0_WRREQ_64B_sum")
+            d["write_bytes_from_requests"] = 64.0 * c("TCC_EA0_WRREQ_64B_sum") + 32.0 * (c("TCC_EA0_WRREQ_sum") - c("TCC_EA0_WRREQ_64B_sum"))
+        if c("TCC_EA0_RDREQ_sum") and c("TCC_EA0_RDREQ_LEVEL_sum") is not None:
+            d["read_requests"] = c("TCC_EA0_RDREQ_sum")
+            d["read_request_mean_outstanding_cycles"] = c("TCC_EA0_RDREQ_LEVEL_sum") / c("TCC_EA0_RDREQ_sum")
         entry["derived"] = d
         result.append(entry)
     json.dump(result, open(sys.argv[3], "w"), indent=1)
