@@ -1,20 +1,209 @@
-"""Reference-style entry points for the MIST grids (isochrones/mist/__init__.py: ``MIST_Isochrone``,
-``MIST_EvolutionTrack``; isochrones/isochrone.py:48-78 ``get_ichrone``).  The real MIST tables need the
-network and HDF5 support this image lacks, so these build the MIST-shaped synthetic tables of
-``isochrones_amd.grids`` (same axes, columns and ragged structure); with real tables, construct the
-interpolators from ``DFInterpolator(df)`` / ``ingest.load_full_grid_npz`` instead."""
+"""The MIST grids from the reference's own data directory (``$ISOCHRONES``, default ``~/.isochrones``).
+
+The reference builds its interpolators from caches it keeps there (isochrones/config.py:5;
+isochrones/isochrone.py:48-78 ``get_ichrone`` -> isochrones/mist ``MIST_Isochrone`` / ``MIST_EvolutionTrack``):
+
+    $ISOCHRONES/mist/full_grid_v1.2_vvcrit0.4_full_isos.npz      isochrone table  (keys ``grid``, ``columns``;
+    $ISOCHRONES/mist/tracks/full_grid_v1.2_vvcrit0.4.npz         track table       interp.py:590-614, models.py:163-165)
+    $ISOCHRONES/mist/tracks/array_grid_v1.2_vvcrit0.4.npz        ragged age arrays (models.py:171-203)
+    $ISOCHRONES/BC/mist/<phot>.h5                                one frame per photometric system (bc.py:89-118)
+
+``full_grid*.npz`` is the dense NaN-padded table including the derivative column (``dt_deep`` / ``dm_deep``: the
+reference appends it to ``df`` before it builds the interpolator, mist/models.py:395-401, models.py:155-161), but it
+does not hold the axis vectors - the reference takes those from the HDF5 frame's index.  Here they are recovered from
+the table itself where it carries them (tracks: the ``initial_mass`` and ``eep`` columns; isochrones: ``age`` and
+``eep``) and, for [Fe/H], from an axes file next to the cache if there is one (``full_grid<tag>_axes.npz``, written by
+:func:`export_axes` on a machine that can read the HDF5 store) or else from MIST's metallicity list when the table has
+its 15 nodes (the reference's class attribute, mist/models.py:39-58).
+
+The BC frames exist only as HDF5 in the reference's layout.  They are read with pandas where pytables is installed;
+otherwise from ``$ISOCHRONES/BC/mist/<phot>.npz``, the same frame exported once with
+``isochrones_amd.ingest.export_frame_npz(pd.read_hdf(".../<phot>.h5"), ".../<phot>.npz")`` (numpy only from then on).
+
+:func:`isochrones_amd.models.get_ichrone` calls :func:`load_mist` for ``"mist"``; when the directory holds no MIST
+caches it says so with a ``UserWarning`` and returns the MIST-shaped *synthetic* tables of ``isochrones_amd.grids``
+(same axes, columns and ragged structure, invented physics) - never silently.
+"""
 from __future__ import annotations
 
-from .models import get_ichrone
+import os
+
+import numpy as np
+
+from . import grids, ingest
+from .interp import DFInterpolator
+
+#: the reference's default grid keywords (mist/models.py:34,98,165)
+DEFAULT_VERSION, DEFAULT_VVCRIT, DEFAULT_KIND = "1.2", 0.4, "full_isos"
+
+
+class MistDataNotFound(FileNotFoundError):
+    """The data directory has no MIST cache this build can read (the message says which file is missing)."""
+
+
+def data_root(root=None):
+    """``$ISOCHRONES`` or ``~/.isochrones`` (isochrones/config.py:5)."""
+    return os.path.expanduser(root or os.getenv("ISOCHRONES") or os.path.join("~", ".isochrones"))
+
+
+def kwarg_tag(tracks, version=DEFAULT_VERSION, vvcrit=DEFAULT_VVCRIT, kind=DEFAULT_KIND):
+    """File-name tag of a grid (mist/models.py:76-78,104-107,202-204)."""
+    tag = "_v{}_vvcrit{}".format(version, vvcrit)
+    return tag if tracks else "{}_{}".format(tag, kind)
+
+
+def mist_paths(root=None, tracks=False, **kw):
+    """Where the reference keeps the caches of one model grid: dict(datadir, full_grid, axes, array_grid, bc_dir)."""
+    root = data_root(root)
+    datadir = os.path.join(root, "mist", "tracks") if tracks else os.path.join(root, "mist")
+    tag = kwarg_tag(tracks, **kw)
+    return dict(root=root, datadir=datadir, tag=tag, full_grid=os.path.join(datadir, "full_grid%s.npz" % tag),
+                axes=os.path.join(datadir, "full_grid%s_axes.npz" % tag),
+                array_grid=os.path.join(datadir, "array_grid%s.npz" % tag), bc_dir=os.path.join(root, "BC", "mist"))
+
+
+def export_axes(df_or_levels, filename, index_names=None):
+    """Write the axis vectors of a model grid next to its ``full_grid*.npz``: pass the reference's frame
+    (``MISTEvolutionTrackGrid().df``: its index levels are the axes, interp.py:583) or the three level arrays."""
+    if hasattr(df_or_levels, "index"):
+        levels = [np.asarray(l, dtype=float) for l in df_or_levels.index.levels]
+        index_names = [str(n) for n in df_or_levels.index.names]
+    else:
+        levels = [np.asarray(l, dtype=float) for l in df_or_levels]
+    np.savez(filename, axis0=levels[0], axis1=levels[1], axis2=levels[2],
+             index_names=np.array([str(n) for n in (index_names or ("", "", ""))]))
+
+
+def _axis_from_column(values, along, what):
+    """The axis whose nodes a table column repeats (``initial_mass`` along the mass axis of a track table, ``eep`` along
+    the EEP axis, ``age`` along the age axis of an isochrone table): every populated cell of a slice holds the same
+    number, which is the node."""
+    v = np.moveaxis(values, along, 0).reshape(values.shape[along], -1)
+    with np.errstate(invalid="ignore"):
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)          # all-NaN slices
+            lo, hi = np.nanmin(v, axis=1), np.nanmax(v, axis=1)
+    if np.isnan(lo).any():
+        raise MistDataNotFound("the %s axis cannot be read off the table (a node without any populated cell); "
+                               "export the axes with isochrones_amd.mist.export_axes" % what)
+    if not np.array_equal(lo, hi):
+        raise MistDataNotFound("the table's %s column is not constant across a node of its axis; export the axes with "
+                               "isochrones_amd.mist.export_axes" % what)
+    if not np.all(np.diff(lo) > 0):
+        raise MistDataNotFound("recovered %s axis is not increasing" % what)
+    return lo
+
+
+def model_axes(grid, columns, tracks, axes_file=None):
+    """Axis vectors of a ``full_grid*.npz`` table.  Order of preference: the axes file; the table's own columns for the
+    axes it repeats; MIST's metallicity list for a 15-node [Fe/H] axis."""
+    names = (["initial_feh", "initial_mass", "EEP"] if tracks else ["log10_isochrone_age_yr", "feh", "EEP"])
+    if axes_file and os.path.exists(axes_file):
+        d = np.load(axes_file, allow_pickle=False)
+        axes = [np.asarray(d["axis%d" % k], dtype=float) for k in range(3)]
+        if tuple(a.size for a in axes) != tuple(grid.shape[:3]):
+            raise MistDataNotFound("%s does not match the table's shape %s" % (axes_file, grid.shape[:3]))
+        return axes, names
+    col = {c: j for j, c in enumerate(columns)}
+    feh_dim = 0 if tracks else 1
+    if grid.shape[feh_dim] != grids.MIST_FEHS.size:
+        raise MistDataNotFound("the [Fe/H] axis of a table with %d metallicities is not MIST's; put its axes next to the "
+                               "cache with isochrones_amd.mist.export_axes" % grid.shape[feh_dim])
+    fehs = np.array(grids.MIST_FEHS, dtype=float)
+    eeps = _axis_from_column(grid[..., col["eep"]], 2, "EEP")
+    if tracks:
+        return [fehs, _axis_from_column(grid[..., col["initial_mass"]], 1, "initial mass"), eeps], names
+    return [_axis_from_column(grid[..., col["age"]], 0, "age"), fehs, eeps], names
+
+
+def load_model_table(root=None, tracks=False, **kw):
+    """DFInterpolator over the reference's ``full_grid*.npz`` of one model grid."""
+    p = mist_paths(root, tracks, **kw)
+    if not os.path.exists(p["full_grid"]):
+        raise MistDataNotFound("no MIST %s cache at %s" % ("track" if tracks else "isochrone", p["full_grid"]))
+    d = np.load(p["full_grid"], allow_pickle=False)
+    grid = np.ascontiguousarray(d["grid"], dtype=float)
+    columns = [str(c) for c in d["columns"]]
+    need = ["Teff", "logg", "feh", "Mbol", "eep"] + (["age", "dt_deep", "initial_mass"] if tracks else ["mass", "dm_deep", "age"])
+    missing = [c for c in need if c not in columns]
+    if grid.ndim != 4 or missing:
+        raise MistDataNotFound("%s is not a MIST %s table (columns missing: %s)" % (p["full_grid"],
+                                                                                    "track" if tracks else "isochrone", missing))
+    axes, names = model_axes(grid, columns, tracks, p["axes"])
+    return DFInterpolator.from_arrays(grid, axes, columns, names)
+
+
+def _bc_frame(bc_dir, phot):
+    """(index [n, 4|5], values [n, k], columns) of one photometric system's frame."""
+    npz, h5 = os.path.join(bc_dir, phot + ".npz"), os.path.join(bc_dir, phot + ".h5")
+    if os.path.exists(npz):
+        d = np.load(npz, allow_pickle=False)
+        return d["index"], d["values"], [str(c) for c in d["columns"]]
+    if os.path.exists(h5):
+        try:
+            import tables  # noqa: F401
+            import pandas as pd
+        except Exception:
+            raise MistDataNotFound(
+                "%s is an HDF5 store and pytables is not installed: export it once where it is, "
+                "isochrones_amd.ingest.export_frame_npz(pandas.read_hdf(%r), %r)" % (h5, h5, npz)) from None
+        df = pd.read_hdf(h5)
+        return (np.array([list(t) for t in df.index.values], dtype=float), np.asarray(df.values, dtype=float),
+                [str(c) for c in df.columns])
+    raise MistDataNotFound("no bolometric-correction frame for the %s system in %s (%s.h5 / %s.npz)" % (phot, bc_dir, phot, phot))
+
+
+def load_bc_table(bands, root=None, rv=3.1):
+    """Dense BC table [nT, ng, nf, nA, n_bands] of ``bands`` from the per-system frames under ``$ISOCHRONES/BC/mist``
+    (reference: MISTBolometricCorrectionGrid.get_df -> Rv slice -> DFInterpolator, bc.py:99-118, mist/bc.py)."""
+    bc_dir = mist_paths(root)["bc_dir"]
+    systems = []
+    known = {}
+    if os.path.isdir(bc_dir):        # columns of the frames at hand, for band names that are table columns themselves
+        for f in sorted(os.listdir(bc_dir)):
+            if f.endswith(".npz"):
+                try:
+                    known[f[:-4]] = [str(c) for c in np.load(os.path.join(bc_dir, f), allow_pickle=False)["columns"]]
+                except Exception:        # noqa: BLE001 - not an exported frame
+                    pass
+    for b in bands:
+        phot = ingest.mist_band(b, known)[0]
+        if phot not in systems:
+            systems.append(phot)
+    frames = [_bc_frame(bc_dir, phot) for phot in systems]
+    return ingest.bc_table_from_frames(frames, list(bands), rv=rv)
+
+
+def load_mist(bands=None, tracks=False, root=None, companion=True, **kw):
+    """The MIST interpolator of the reference's ``get_ichrone('mist', bands, tracks=...)`` from the caches under
+    ``$ISOCHRONES``.  Raises :class:`MistDataNotFound` (naming the missing file and how to produce it) when they are
+    not there - the caller decides what to do then; nothing synthetic comes out of this function."""
+    bands = tuple(bands) if bands else tuple(grids.DEFAULT_BANDS)
+    model = load_model_table(root, tracks, **kw)
+    bc = load_bc_table(bands, root)
+    ic = ingest.interpolator_from_tables(model, bc, tracks, bands=bands)
+    ic.data_source = mist_paths(root, tracks, **kw)["full_grid"]
+    if companion:
+        # the other parametrisation of the same grids (IsochroneInterpolator.get_eep / generate go through the track
+        # grid, the reference's `ic.track`): built on first use, and only if its cache exists
+        ic._companion_factory = lambda: load_mist(bands, not tracks, root, companion=False, **kw)
+    return ic
+
+
+def available(root=None, tracks=False, **kw):
+    return os.path.exists(mist_paths(root, tracks, **kw)["full_grid"])
 
 
 def MIST_Isochrone(bands=None, **kwargs):
-    """(eep, age, feh, distance, AV) interpolator over the [107, 15, 1710] isochrone grid."""
+    """(eep, age, feh, distance, AV) interpolator over the [107, 15, 1710] isochrone grid (isochrones/mist)."""
+    from .models import get_ichrone
     return get_ichrone("mist", bands=bands, tracks=False, **kwargs)
 
 
 def MIST_EvolutionTrack(bands=None, **kwargs):
-    """(mass, eep, feh, distance, AV) interpolator over the [15, 196, 1710] evolution-track grid."""
+    """(mass, eep, feh, distance, AV) interpolator over the [15, 196, 1710] evolution-track grid (isochrones/mist)."""
+    from .models import get_ichrone
     return get_ichrone("mist", bands=bands, tracks=True, **kwargs)
 
 

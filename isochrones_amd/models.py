@@ -584,12 +584,29 @@ def synthetic_isochrone(bands=grids.DEFAULT_BANDS, ages=None, fehs=None, eeps=No
 
 
 def get_ichrone(models="mist", bands=None, default=False, tracks=False, basic=False, **kwargs):
-    """Reference-style factory (isochrones/isochrone.py:48-78) over the synthetic tables.  An interpolator
-    object passed as ``models`` is returned as it is; ``default`` / ``basic`` select variants of the reference's
-    grids that coincide here."""
+    """The reference's factory (isochrones/isochrone.py:48-78).  An interpolator object passed as ``models`` is returned
+    as it is.
+
+    ``"mist"``: the MIST grids from the reference's data directory, ``$ISOCHRONES`` (default ``~/.isochrones``): its
+    ``full_grid*.npz`` caches and BC frames, see :mod:`isochrones_amd.mist`.  When that directory holds no MIST caches
+    this build can read, a ``UserWarning`` says so (naming what is missing) and the MIST-shaped *synthetic* tables of
+    :mod:`isochrones_amd.grids` are returned: same axes, columns and ragged structure, invented physics - good for
+    exercising the path, not for astrophysics.  ``"synthetic"`` asks for those tables by name (no warning).
+    ``default`` / ``basic`` select variants of the reference's grids that coincide here."""
     if isinstance(models, ModelGridInterpolator):
         return models
     if models not in ("mist", "synthetic"):
-        raise ValueError("only the MIST-shaped synthetic tables are available offline")
+        raise ValueError("Unknown stellar models: {}".format(models))
     bands = grids.DEFAULT_BANDS if not bands else tuple(bands)
+    if models == "mist":
+        from . import mist
+        grid_kw = {k: kwargs[k] for k in ("version", "vvcrit", "kind") if k in kwargs}
+        try:
+            return mist.load_mist(bands, tracks=tracks, **grid_kw)
+        except mist.MistDataNotFound as e:
+            import warnings
+            warnings.warn("get_ichrone('mist'): no MIST tables under %s (%s) - using synthetic MIST-shaped tables "
+                          "(isochrones_amd.grids: same axes and columns, invented physics)" % (mist.data_root(), e),
+                          UserWarning, stacklevel=2)
+        kwargs = {k: v for k, v in kwargs.items() if k not in grid_kw}
     return synthetic_track(bands, **kwargs) if tracks else synthetic_isochrone(bands, **kwargs)

@@ -767,6 +767,141 @@ def run_ingest_cases(seed=4242, save=True):
 
 
 
+# ------------------------------------------------------------------------------------------------
+# the reference's data directory ($ISOCHRONES) as its own classes lay it out, on small synthetic frames
+# ------------------------------------------------------------------------------------------------
+
+def run_datadir_case(seed=777):
+    """A small ``$ISOCHRONES`` tree written by the reference's own code - ``MISTEvolutionTrackGrid().interp`` /
+    ``MISTIsochroneGrid().interp`` save ``full_grid<tag>.npz`` through ``DFInterpolator(df, filename=...)``
+    (grid.py:132-137, interp.py:590-614, models.py:163-165), ``get_array_grids()`` saves ``array_grid<tag>.npz``
+    (models.py:171-203) - plus what a user exports once where pytables exists: the BC frames
+    (``ingest.export_frame_npz`` of the frames behind ``BC/mist/<phot>.h5``) and the axis vectors of each model grid
+    (``mist.export_axes`` of the frame's index levels; the real MIST grids do not need them).  And, in
+    ``datadir.npz``, what the reference's MIST interpolators / star models built on these very grids return at seeded
+    sample points: ``interp_value``, ``interp_mag``, ``SingleStarModel.lnprior / lnlike / lnpost``.
+    tests/golden/isochrones_tree/ is then what ``get_ichrone('mist')`` of this build must load."""
+    import shutil
+    import pandas as pd
+    from isochrones_amd import ingest, mist as our_mist
+    mm = rh.ref("mist.models")
+    mbc = rh.ref("mist.bc")
+    miso = rh.ref("mist.isochrone")
+    sm = rh.ref("starmodel")
+    rng = np.random.default_rng(seed)
+    tree = os.path.join(OUT, "isochrones_tree")
+    shutil.rmtree(tree, ignore_errors=True)
+    tdir, idir, bcdir = os.path.join(tree, "mist", "tracks"), os.path.join(tree, "mist"), os.path.join(tree, "BC", "mist")
+    for d in (tdir, bcdir):
+        os.makedirs(d)
+    bands = ["J", "K", "G", "W1", "V"]
+    with rh.memory_hdf() as hdf, warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        fehs, masses = np.array([-0.5, 0.0, 0.25]), np.array([0.8, 1.0, 1.2, 1.5])
+        keys = list(itertools.product(fehs, masses))
+        counts = [int(c) for c in rng.integers(20, 34, len(keys))]
+        counts[5] = 34                                        # one track reaches the last EEP node
+        raw_t = _raw_mist_rows(rng, keys, ("initial_feh", "initial_mass"), counts)
+
+        class Tracks(mm.MISTEvolutionTrackGrid):
+            n_eep = max(counts)
+            datadir = tdir
+
+            def df_all(self):
+                df = raw_t.copy().sort_values(by=list(self.index_cols))
+                df.index = [df[c] for c in self.index_cols]
+                return df
+
+        Tracks.fehs = fehs
+        ages, ifehs = np.array([8.5, 9.0, 9.5, 10.0]), np.array([-0.5, 0.0, 0.25])
+        keys = list(itertools.product(ages, ifehs))
+        icounts = [int(c) for c in rng.integers(18, 30, len(keys))]
+        icounts[4] = 30
+        raw_i = _raw_mist_rows(rng, keys, ("log10_isochrone_age_yr", "feh"), icounts)
+        raw_i["initial_mass"] = 0.3 + 0.03 * raw_i["EEP"] ** 1.1 + 0.02 * raw_i["feh"]
+        raw_i["star_mass"] = raw_i["initial_mass"] * 0.999
+
+        class Isos(mm.MISTIsochroneGrid):
+            datadir = idir
+
+            def df_all(self):
+                df = raw_i.copy().sort_values(by=list(self.index_cols))
+                df.index = [df[c] for c in self.index_cols]
+                return df
+
+        lv = (np.array([3500.0, 5000.0, 6500.0, 8000.0]), np.array([2.5, 3.5, 4.0, 5.0]), np.array([-1.0, 0.0, 0.5]),
+              np.array([0.0, 0.5, 1.0]), np.array([2.5, 3.1, 4.0]))
+        idx = pd.MultiIndex.from_product(lv, names=["Teff", "logg", "[Fe/H]", "Av", "Rv"])
+
+        class BC(mbc.MISTBolometricCorrectionGrid):
+            datadir = bcdir
+
+        frames = {}
+        for phot, cols in (("UBVRIplus", ["Bessell_B", "Bessell_V", "2MASS_J", "2MASS_Ks", "Gaia_G_DR2Rev", "TESS", "Kepler_Kp"]),
+                           ("WISE", ["WISE_W1", "WISE_W2"])):
+            # smooth in (Teff, logg, feh, Av), so that magnitudes stay in a sane range
+            T, g, f, A, R = (idx.get_level_values(k).to_numpy(float) for k in range(5))
+            vals = np.column_stack([0.3 * j - 2.0 * np.log10(T / 5772.0) * (1 + 0.1 * j) + 0.02 * (g - 4.4) + 0.03 * f
+                                    - A * (0.3 + 0.1 * j) * (R / 3.1) ** 0.2 + 0.01 * rng.normal(size=len(idx))
+                                    for j in range(len(cols))])
+            frames[phot] = pd.DataFrame(vals, index=idx, columns=cols)
+            hdf.preload(os.path.join(bcdir, "%s.h5" % phot), "df", frames[phot])
+
+        class TrackIC(miso.MIST_EvolutionTrack):
+            grid_type, bc_type = Tracks, BC
+            eep_bounds = (1, max(counts))
+
+        class IsoIC(miso.MIST_Isochrone):
+            grid_type, bc_type = Isos, BC
+            eep_bounds = (1, max(icounts))
+
+        out = {}
+        for kind, ic_cls in (("track", TrackIC), ("iso", IsoIC)):
+            ic = ic_cls(bands=list(bands))
+            mg = ic.model_grid
+            interp = mg.interp                                 # the reference writes full_grid<tag>.npz here
+            if kind == "track":
+                age, dt, lengths = mg.get_array_grids()        # ... and array_grid<tag>.npz here
+                out.update(track_age_arrays=age, track_dt_deep_arrays=dt, track_lengths=lengths)
+            our_mist.export_axes(mg.df, os.path.join(mg.datadir, "full_grid%s_axes.npz" % mg.kwarg_tag))
+            n = 400
+            if kind == "track":
+                pars = np.column_stack([rng.uniform(0.75, 1.55, n), rng.uniform(0.5, 35.0, n), rng.uniform(-0.55, 0.3, n),
+                                        rng.uniform(50, 400, n), rng.uniform(-0.05, 1.05, n)])
+                pcols = ["Teff", "logg", "feh", "Mbol", "age", "dt_deep", "radius", "nu_max"]
+            else:
+                pars = np.column_stack([rng.uniform(0.5, 31.0, n), rng.uniform(8.4, 10.05, n), rng.uniform(-0.55, 0.3, n),
+                                        rng.uniform(50, 400, n), rng.uniform(-0.05, 1.05, n)])
+                pcols = ["Teff", "logg", "feh", "Mbol", "mass", "dm_deep", "radius", "nu_max"]
+            mod = sm.SingleStarModel(ic, Teff=(5600, 120), logg=(4.1, 0.2), J=(9.0, 0.05), K=(8.6, 0.05), G=(10.2, 0.02),
+                                     parallax=(5.0, 0.2))
+            lnprior, lnlike, lnpost = np.empty(n), np.empty(n), np.empty(n)
+            with np.errstate(all="ignore"):
+                vals = np.asarray(ic.interp_value([pars[:, 0], pars[:, 1], pars[:, 2]], pcols))
+                Teff, logg, feh, mags = ic.interp_mag([pars[:, j] for j in range(5)], list(bands))
+                for i in range(n):
+                    lnprior[i], lnlike[i], lnpost[i] = mod.lnprior(pars[i]), mod.lnlike(pars[i]), mod.lnpost(pars[i])
+            cols = [str(c) for c in interp.columns]
+            out.update({kind + "_pars": pars, kind + "_interp_value": vals, kind + "_Teff": Teff, kind + "_logg": logg,
+                        kind + "_feh": feh, kind + "_mags": mags, kind + "_lnprior": lnprior, kind + "_lnlike": lnlike,
+                        kind + "_lnpost": lnpost, kind + "_grid_shape": np.array(interp.grid.shape),
+                        kind + "_columns": np.array(cols), kind + "_interp_value_cols": np.array(pcols),
+                        kind + "_axis0": interp.index_columns[0], kind + "_axis1": interp.index_columns[1],
+                        kind + "_axis2": interp.index_columns[2]})
+            print("datadir %s: grid %s, finite lnpost %d / %d" % (kind, interp.grid.shape, np.isfinite(lnpost).sum(), n))
+        out["meta"] = json.dumps(dict(bands=bands, obs=dict(Teff=[5600, 120], logg=[4.1, 0.2], J=[9.0, 0.05], K=[8.6, 0.05],
+                                                               G=[10.2, 0.02], parallax=[5.0, 0.2]),
+                                      track_eep_bounds=[1, max(counts)], iso_eep_bounds=[1, max(icounts)]))
+        for phot, fr in frames.items():
+            ingest.export_frame_npz(fr, os.path.join(bcdir, phot + ".npz"))
+    # the HDF5 stand-in only touched empty placeholder files: they are not part of the fixture
+    for dirpath, _, files in os.walk(tree):
+        for f in files:
+            if not f.endswith(".npz"):
+                os.remove(os.path.join(dirpath, f))
+    np.savez_compressed(os.path.join(OUT, "datadir.npz"), **out)
+
+
 def main():
     if "--only-priors" in sys.argv:
         run_prior_cases()
@@ -785,6 +920,9 @@ def main():
         return
     if "--only-ingest" in sys.argv:
         run_ingest_cases()
+        return
+    if "--only-datadir" in sys.argv:
+        run_datadir_case()
         return
     if not rh.reference_available():
         sys.exit("reference tree not found; goldens can only be regenerated in the authoring container")
@@ -813,6 +951,7 @@ def main():
     run_isotrack_case()
     run_prior_cases()
     run_ingest_cases()
+    run_datadir_case()
 
 
 if __name__ == "__main__":

@@ -24,3 +24,10 @@ def test_make_golden_reproduces_the_committed_fixtures(tmp_path):
     assert made == kept
     match, mismatch, errors = filecmp.cmpfiles(str(tmp_path), os.path.join(ROOT, "tests", "golden"), made, shallow=False)
     assert not mismatch and not errors, (mismatch, errors)
+    # the $ISOCHRONES tree the reference's grid classes write (full_grid / array_grid caches) + the exported frames
+    def walk(top):
+        return sorted(os.path.relpath(os.path.join(d, f), top) for d, _, fs in os.walk(top) for f in fs)
+    a, b = os.path.join(str(tmp_path), "isochrones_tree"), os.path.join(ROOT, "tests", "golden", "isochrones_tree")
+    assert walk(a) == walk(b) and len(walk(a)) >= 7
+    match, mismatch, errors = filecmp.cmpfiles(a, b, walk(a), shallow=False)
+    assert not mismatch and not errors, (mismatch, errors)

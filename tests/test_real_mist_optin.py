@@ -1,7 +1,7 @@
-"""Opt-in known-answer checks that need the REAL MIST tables: they run only when
-$ISOCHRONES points at the reference's data directory *and* pandas can read its HDF5 stores
-(pytables).  Offline (this image) they are skipped; the recorded values are the reference's own:
-isochrones/tests/test_basic.py:16-18 and docs notebooks."""
+"""Opt-in known-answer checks that need the REAL MIST tables: they run only when $ISOCHRONES points at
+the reference's data directory with its isochrone cache (``mist/full_grid_v1.2_vvcrit0.4_full_isos.npz``, read with numpy
+alone: isochrones_amd/mist.py - no pytables).  Offline (this image) they are skipped; the recorded values are the
+reference's own: isochrones/tests/test_basic.py:16-18."""
 import os
 
 import numpy as np
@@ -13,27 +13,18 @@ KATS_LOGG = [((632, 7.55, -1.75), 2.4117770214014103, 0.0),       # exact grid p
 
 
 def _real_iso_table():
-    root = os.environ.get("ISOCHRONES")
-    if not root or not os.path.isdir(os.path.join(root, "mist")):
-        pytest.skip("real MIST tables not available ($ISOCHRONES)")
-    try:
-        import tables  # noqa: F401
-        import pandas as pd
-    except Exception:
-        pytest.skip("pytables not installed: cannot read the reference's HDF5 stores")
-    h5 = [f for f in os.listdir(os.path.join(root, "mist")) if f.endswith("full_isos.h5")]
-    if not h5:
-        pytest.skip("no isochrone HDF5 store found")
-    return pd.read_hdf(os.path.join(root, "mist", h5[0]))
+    from isochrones_amd import mist
+    if not mist.available(tracks=False):
+        pytest.skip("real MIST isochrone cache not available (%s)" % mist.mist_paths(tracks=False)["full_grid"])
+    dfi = mist.load_model_table(tracks=False)
+    if dfi.grid.shape[:3] != (107, 15, 1710):
+        pytest.skip("the cache under $ISOCHRONES is not the full MIST isochrone grid (shape %s)" % (dfi.grid.shape,))
+    return dfi
 
 
 @pytest.mark.gpu
 def test_reference_logg_kats_on_real_tables():
-    import isochrones_amd as ia
-    from isochrones_amd.interp import DFInterpolator
-    df = _real_iso_table()
-    dfi = DFInterpolator(df)
-    ci = dfi.column_index["logg"]
+    dfi = _real_iso_table()
     for (eep, age, feh), want, rtol in KATS_LOGG:
         got = dfi([age, feh, float(eep)], ["logg"])[0]
         assert np.isclose(got, want, rtol=max(rtol, 1e-13)), (eep, age, feh, got, want)
