@@ -196,6 +196,12 @@ int  iso_interp_mag(iso_ic* ic, const double* pars, int64_t stride_n, int64_t st
 int  iso_model_create(iso_ic* ic, const iso_model_desc* desc, iso_model** out);
 void iso_model_destroy(iso_model* m);
 int  iso_model_n_params(const iso_model* m);
+/* Which kernel family evaluates this model (measurement / test helper): the generic kernel (any table shape, any
+ * band count), the fused kernel on the compact tables, or the fused kernel on the corner-packed tables. */
+#define ISO_PATH_GENERIC        0
+#define ISO_PATH_FUSED_COMPACT  1
+#define ISO_PATH_FUSED_PACKED   2
+int  iso_model_kernel_path(const iso_model* m);
 
 /* lnpost = lnprior + lnlike, or -inf where lnprior is not finite (starmodel.py:538-542).
  * lnprior_out / lnlike_out are optional (NULL to skip); when requested they hold the values

@@ -80,14 +80,58 @@ __device__ __forceinline__ void lds_bracket4(const double* lds, const FastAxis a
     t3 = (x3 - a3[b3]) * a3[ax3.n + b3];
 }
 
+// Third model axis (EEP).  Exactly uniform (MIST's integer EEPs): O(1) index with an exact fix-up.  Anything else
+// (A.e_axis != null; the reference bisects every axis alike, interp.py:10-35): every 8th node is staged in LDS with the
+// other axes (A.ec), a branch-free bisection over those picks a window of 9 consecutive nodes, which come from the axis
+// itself (a few KB, L2-resident: five independent loads, one round trip) and are counted against x in registers:
+//   i = clamp(#{a_j <= x} - 1, 0, n - 2),  t = (x - a_i) / (a_{i+1} - a_i)        (a true division: no table of 1/spacing)
+// - the rule of the LDS axes, i.e. searchsorted + find_indices bit for bit.  The branch is wave-uniform (a kernel
+// argument), so the uniform case pays one scalar compare for it.
 __device__ __forceinline__ bool eep_oob(const FastArgs& A, double x)
 {
-    return (x < A.e_a0) || (x > fma((double)(A.e_n - 1), A.e_step, A.e_a0));
+    return (x < A.e_a0) || (x > A.e_last);
 }
 
-__device__ __forceinline__ void eep_bracket(const FastArgs& A, double x, int& i, double& t)
+__device__ __forceinline__ void eep_bracket(const FastArgs& A, const double* lds, double x, int& i, double& t)
 {
     const int n = A.e_n;
+    if (A.e_axis) {
+        const double* c = lds + A.ec.off;
+        int base = 0, len = A.ec.n;
+        while (len > 1) {
+            const int half = len >> 1;
+            base = (c[base + half] <= x) ? base + half : base;
+            len -= half;
+        }
+        base = min(base * 8, n - 9);                       // window [base, base + 8]; the host guarantees n >= 9
+        const double2* __restrict__ w2 = reinterpret_cast<const double2*>(A.e_axis + base);
+        double v[9];
+        if ((base & 1) == 0) {                              // 16-B aligned window: four 16-B loads + one 8-B load
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double2 u = w2[q];
+                v[2 * q] = u.x;
+                v[2 * q + 1] = u.y;
+            }
+            v[8] = A.e_axis[base + 8];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 9; ++q) v[q] = A.e_axis[base + q];
+        }
+        int cnt = 0;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) cnt += (v[q] <= x) ? 1 : 0;
+        const int k = max(0, min(cnt - 1, 7));
+        double lo = v[0], hi = v[1];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) {
+            lo = (k == q) ? v[q] : lo;
+            hi = (k == q) ? v[q + 1] : hi;
+        }
+        i = base + k;
+        t = (x - lo) / (hi - lo);
+        return;
+    }
     int k = (int)((x - A.e_a0) * A.e_inv);
     k = max(0, min(k, n - 2));
     const double lo = fma((double)k, A.e_step, A.e_a0);

@@ -208,3 +208,52 @@ __device__ __forceinline__ void coop_bc(const FastArgs& A, const CoopLds& L, boo
     for (int b = 0; b < NB; ++b) v[b] = need ? rs[b] : f_nan();
     __builtin_amdgcn_wave_barrier();
 }
+
+// A tile of TB bands [b0, b0 + TB) of a BC cell that holds `nbt` bands (the pack's piece index of band e at axis-0
+// offset kk is ((kk * nbt + e) * 4 + j)); bands beyond nbt - 1 repeat the last one (their terms are masked by the
+// caller).  One round per 16 samples, 2 * TB loads of 16 B per lane in flight.
+template <int TB>
+__device__ __forceinline__ void coop_bc_tile(const FastArgs& A, const CoopLds& L, bool need, uint32_t cell, const W4& w,
+                                             int nbt, int b0, double* __restrict__ v)
+{
+    double* mine = L.req + L.lane * L.stride;
+    mine[0] = __hiloint2double(need ? 1 : 0, (int)cell);
+    mine[1] = w.t0;
+    mine[2] = w.t1;
+    mine[3] = w.t2;
+    mine[4] = w.t3;
+    __builtin_amdgcn_wave_barrier();
+    const unsigned long long m = __ballot(need);
+    const int j = L.lane & 3, grp = L.lane >> 2;
+#pragma unroll
+    for (int r0 = 0; r0 < 4; ++r0) {
+        if (((m >> (16 * r0)) & 0xFFFFull) == 0) continue;                       // wave-uniform
+        const int src = 16 * r0 + grp;
+        const double* rq = L.req + src * L.stride;
+        const double hdr = rq[0];
+        const double t0 = rq[1], t1 = rq[2], t2 = rq[3], t3 = rq[4];
+        const bool nd = __double2hiint(hdr) != 0;
+        const uint32_t c = nd ? (uint32_t)__double2loint(hdr) : 0u;
+        const double2* __restrict__ pc = reinterpret_cast<const double2*>(A.bcq + (size_t)c * (size_t)(16 * nbt)) + j;
+        double2 x[2 * TB];
+#pragma unroll
+        for (int b = 0; b < TB; ++b) {
+            const int band = min(b0 + b, nbt - 1);
+            x[b] = pc[4 * band];
+            x[TB + b] = pc[4 * (nbt + band)];
+        }
+        const double g = nd ? ((j & 2) ? t1 : (1 - t1)) * ((j & 1) ? t2 : (1 - t2)) : 0.0;
+        const double wa0 = (1 - t0) * g * (1 - t3), wb0 = (1 - t0) * g * t3, wa1 = t0 * g * (1 - t3), wb1 = t0 * g * t3;
+        double* rs = L.rsp + src * L.stride;
+#pragma unroll
+        for (int b = 0; b < TB; ++b) {
+            const double part = quad_sum(x[b].x * wa0 + x[b].y * wb0 + x[TB + b].x * wa1 + x[TB + b].y * wb1);
+            if (j == (b & 3)) rs[b] = part;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const double* rs = L.rsp + L.lane * L.stride;
+#pragma unroll
+    for (int b = 0; b < TB; ++b) v[b] = need ? rs[b] : f_nan();
+    __builtin_amdgcn_wave_barrier();
+}

@@ -8,7 +8,9 @@
 // MASKED (catalog rows and the sampler kernels): a band whose observed magnitude is NaN is a band this star
 // was not observed in - its term is skipped, as the reference drops NaN measurements when it builds a model
 // (starmodel.py:1427-1433).
-template <int KIND, int NS, int NB, bool PACKED, bool ASTERO = false, bool MASKED = false>
+// TILED (batch kernels for 13-32 bands, k_lnpost_wide): NB is the width of a band tile and the photometric terms are
+// taken tile by tile over the A.nb_total bands of the corner-packed BC cell (each star's BC bracket is found once and kept).
+template <int KIND, int NS, int NB, bool PACKED, bool ASTERO = false, bool MASKED = false, bool TILED = false>
 __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* lds, const CoopLds& L, bool active,
                                               const DevModel& M, const double* __restrict__ p, bool want_parts,
                                               double& lnp_out, double& lnl_out)
@@ -32,7 +34,7 @@ __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* l
         const double eep = (KIND == ISO_KIND_TRACK) ? p[1] : p[s];
         const bool ok = ok01 && !(eep != eep) && !eep_oob(A, eep);
         int i2 = 0;
-        if (ok) eep_bracket(A, eep, i2, w.t2);
+        if (ok) eep_bracket(A, lds, eep, i2, w.t2);
         if (PACKED) {
             const uint32_t cell = (uint32_t)((int64_t)i0 * A.s0 + (int64_t)i1 * A.s1 + i2);
             coop_star(A, L, ok, cell, w, star[s]);
@@ -81,7 +83,56 @@ __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* l
         }
     }
     const double dm = fma(ld, 5.0 * kInvLn10, -5.0);   // 5*log10(d/10)
-    if constexpr (NB > 0) {          // NB = 0: spectroscopy / parallax only, the BC table is never touched
+    if constexpr (TILED) {
+        static_assert(PACKED && NB > 0, "band tiles run on the corner-packed tables");
+        const int nbt = A.nb_total;
+        const bool okA = go && !(AV != AV) && !lds_oob(lds, A.b3, AV);
+        bool okb[NS];
+        uint32_t cellb[NS];
+        W4 wb[NS];
+    #pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const double T = star[s][0], g = star[s][1], f = star[s][2];
+            okb[s] = okA && !(T != T) && !(g != g) && !(f != f) && !lds_oob(lds, A.b0, T) && !lds_oob(lds, A.b1, g) &&
+                     !lds_oob(lds, A.b2, f);
+            int j0 = 0, j1 = 0, j2 = 0, j3 = 0;
+            wb[s].t0 = wb[s].t1 = wb[s].t2 = wb[s].t3 = 0.0;
+            if (okb[s]) {
+                lds_bracket4(lds, A.b0, A.b1, A.b2, A.b3, T, g, f, AV, j0, j1, j2, j3, wb[s].t0, wb[s].t1, wb[s].t2, wb[s].t3);
+            }
+            cellb[s] = (uint32_t)((int64_t)j0 * A.bs0 + (int64_t)j1 * A.bs1 + (int64_t)j2 * A.bs2 + j3);
+        }
+        for (int b0 = 0; b0 < nbt; b0 += NB) {                   // wave-uniform
+            double tot[NB], rel[NS > 1 ? NB : 1];
+    #pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                double bc[NB];
+                coop_bc_tile<NB>(A, L, okb[s], cellb[s], wb[s], nbt, b0, bc);
+    #pragma unroll
+                for (int b = 0; b < NB; ++b) {                   // the flux sum of the untiled form below, band by band
+                    const double mag = star[s][3] + dm - bc[b];
+                    if (NS == 1) {
+                        tot[b] = mag;
+                    } else if (s == 0) {
+                        const bool far = fabs(mag) > 700.0;
+                        tot[b] = far ? 0.0 : mag;
+                        rel[b] = 1.0;
+                        if (__ballot(far)) rel[b] = far ? exp10(-0.4 * mag) : 1.0;
+                    } else {
+                        rel[b] += exp10(-0.4 * (mag - tot[b]));
+                    }
+                }
+            }
+    #pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const int band = min(b0 + b, nbt - 1);
+                const double mag = (NS == 1) ? tot[b] : fma(-2.5, fast_log10(rel[b]), tot[b]);
+                const double mv = M.mag_val[band];
+                const double r = mv - mag;
+                if (b0 + b < nbt && (!MASKED || mv == mv)) lnl += M.mag_g0[band] - r * r * M.mag_hinv[band];
+            }
+        }
+    } else if constexpr (NB > 0) {   // NB = 0: spectroscopy / parallax only, the BC table is never touched
         double tot[NB], rel[NS > 1 ? NB : 1];
         const bool okA = go && !(AV != AV) && !lds_oob(lds, A.b3, AV);
     #pragma unroll
@@ -167,6 +218,48 @@ __device__ __forceinline__ CoopLds coop_lds(double* lds, int axes_len)
 // waves per SIMD the register allocator must leave room for: 6 for the small single-star kernels
 // (88 -> 80 VGPR, a few dwords of scratch; measured +2 %), otherwise whatever the kernel needs
 constexpr int fast_min_waves(int ns, int nb) { return (ns == 1 && nb <= 2) ? 6 : 4; }
+
+// 13-32 bands: the same evaluation with the photometric terms taken in tiles of WIDE_TILE bands (the BC cell of a
+// 32-band model is 4 KB: registers hold one tile of it at a time).  Batch form only.
+constexpr int WIDE_TILE = 8;
+// tile width per multiplicity: a system of 2-3 stars keeps every component's BC bracket and a flux sum per band of the
+// tile alive, which at 8 bands spills (208-320 B of scratch per lane at 128 registers)
+constexpr int wide_tile(int ns) { return ns == 1 ? WIDE_TILE : 4; }
+
+template <int KIND, int NS>
+__global__ __launch_bounds__(BLOCK, 4) void k_lnpost_wide(const FastArgs A)
+{
+    extern __shared__ double lds[];
+    for (int j = threadIdx.x; j < A.axes_len; j += BLOCK) lds[j] = A.axes_blob[j];
+    __syncthreads();
+    const CoopLds L = coop_lds<WIDE_TILE>(lds, A.axes_len);
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const bool active = i < A.n;
+    const int64_t ii = active ? i : (A.n - 1);
+    const DevModel& M = A.m[0];
+    constexpr int NP = NS + 4;
+    double p[NP];
+    {
+        const double* __restrict__ src = A.pars + ii * A.stride_n;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) p[j] = src[j * A.stride_p];
+    }
+    double lnp, lnl;
+    const double r = lnpost_wave<KIND, NS, wide_tile(NS), true, false, false, true>(A, lds, L, active, M, p, A.lnlike != nullptr, lnp, lnl);
+    if (active) {
+        if (A.lnpost) A.lnpost[i] = r;
+        if (A.lnprior) A.lnprior[i] = lnp;
+        if (A.lnlike) A.lnlike[i] = lnl;
+    }
+    if (A.done_flag) {               // single-workgroup host-callback launch: results first, then the flag
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            *reinterpret_cast<volatile unsigned long long*>(A.done_flag) = A.done_seq;
+            __threadfence_system();
+        }
+    }
+}
 
 template <int KIND, int NS, int NB, bool PACKED, bool MULTI, bool ASTERO = false>
 __global__ __launch_bounds__(BLOCK, fast_min_waves(NS, NB)) void k_lnpost_fast(const FastArgs A)

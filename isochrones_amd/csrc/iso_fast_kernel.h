@@ -105,6 +105,7 @@ bool launch_stretch_track1(int nb, const FastArgs& A, const StretchArgs& S, hipS
 bool launch_stretch_iso1(int nb, const FastArgs& A, const StretchArgs& S, hipStream_t s);
 bool launch_stretch_iso2(int nb, const FastArgs& A, const StretchArgs& S, hipStream_t s);
 bool launch_stretch_iso3(int nb, const FastArgs& A, const StretchArgs& S, hipStream_t s);
+bool launch_fast_wide(int kind, int n_stars, const FastArgs& A, hipStream_t s);
 bool launch_fast_track1(int nb, bool packed, bool multi, const FastArgs& A, hipStream_t s);
 bool launch_fast_iso1(int nb, bool packed, bool multi, const FastArgs& A, hipStream_t s);
 bool launch_fast_iso2(int nb, bool packed, bool multi, const FastArgs& A, hipStream_t s);

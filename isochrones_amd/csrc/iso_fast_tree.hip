@@ -106,7 +106,7 @@ __global__ __launch_bounds__(tree_block<NL>()) void k_lnpost_tree_fast(const Fas
         w.t0 = w.t1 = w.t2 = 0.0;
         if (ok3) {
             lds_bracket2(lds, A.m0, A.m1, age, feh, i0, i1, w.t0, w.t1);
-            eep_bracket(A, eep, i2, w.t2);
+            eep_bracket(A, lds, eep, i2, w.t2);
         }
         double v[6];
         coop_star(A, L, ok3, (uint32_t)((int64_t)i0 * A.s0 + (int64_t)i1 * A.s1 + i2), w, v);

@@ -220,7 +220,13 @@ PathMode path_mode()
     return PATH_AUTO;
 }
 
+constexpr int FAST_NB_MAX = 12;        // band count up to which every fused form exists (batch, catalog, samplers)
 constexpr int FAST_MAX_BLOB = 4096;   // doubles (32 KiB of LDS) the fast kernel may stage
+
+// third model axis (EEP): exactly uniform -> O(1) index; otherwise the fused kernels bisect it (every 8th node in LDS, a
+// window of 9 nodes from the device copy of the axis), which needs at least 9 nodes
+bool third_axis_ok(const iso_ic* ic) { return ic->model->ax[2].uniform || ic->model->ax[2].n >= 9; }
+
 
 hipError_t pack_corners(const double* src, int ncol, int keep, int ndim, const int64_t* n, double** out, int col0 = 0)
 {
@@ -609,7 +615,7 @@ int iso_interp_mag(iso_ic* ic, const double* pars, int64_t stride_n, int64_t str
     A.Teff = Teff; A.logg = logg; A.feh = feh;
     A.mags = nb > 0 ? mags : nullptr;
     DeviceGuard guard(ic->ctx->device);
-    if (nb >= 1 && nb <= 12 && mags && ic->d_hotq && ic->model->ax[2].uniform && path_mode() == PATH_AUTO) {
+    if (nb >= 1 && nb <= 12 && mags && ic->d_hotq && third_axis_ok(ic) && path_mode() == PATH_AUTO) {
         // large batches: corner-packed tables + wave-cooperative gathers (the pack for this band list
         // is built once and kept); small ones are not worth building a pack for
         FastArgs F;
@@ -721,8 +727,11 @@ hipError_t pack_bands(const iso_ic* ic, const int32_t* bc_cols, int nb, double**
 bool fast_eligible(const iso_ic* ic, const iso_model_desc* desc)
 {
     // asteroseismic terms are only on the corner-packed form of the fast path
-    return path_mode() != PATH_GENERIC && desc->n_bands >= 0 && desc->n_bands <= 12 &&
-           (!desc->has_numax || (path_mode() == PATH_AUTO && ic->d_hotq)) && ic->model->ax[2].uniform;
+    // 13-32 bands: the band-tiled batch kernel, on the corner-packed tables only and without asteroseismic terms
+    const bool bands_ok = desc->n_bands >= 0 && (desc->n_bands <= FAST_NB_MAX ||
+                                                (desc->n_bands <= ISO_MAX_BANDS && path_mode() == PATH_AUTO && ic->d_hotq && !desc->has_numax));
+    return path_mode() != PATH_GENERIC && bands_ok &&
+           (!desc->has_numax || (path_mode() == PATH_AUTO && ic->d_hotq)) && third_axis_ok(ic);
 }
 
 // staged axes (+ reciprocal spacings) and, when the interpolator has a corner-packed model table,
@@ -743,6 +752,16 @@ hipError_t build_fast(const iso_ic* ic, int nb, const double* d_bc_hot, double**
         for (size_t j = 0; j + 1 < v.size(); ++j) blob.push_back(1.0 / (v[j + 1] - v[j]));
         blob.push_back(0.0);
     }
+    FastAxis coarse;
+    coarse.off = coarse.n = 0;
+    const bool e_uniform = ic->model->ax[2].uniform != 0;
+    if (!e_uniform) {
+        const std::vector<double>& v = ic->h_axes_model[2];
+        if (v.size() < 9) return hipSuccess;
+        coarse.off = (int)blob.size();
+        for (size_t j = 0; j < v.size(); j += 8) blob.push_back(v[j]);
+        coarse.n = (int)blob.size() - coarse.off;
+    }
     if ((int)blob.size() > FAST_MAX_BLOB) return hipSuccess;
     hipError_t e = hipMalloc(d_axes_blob, blob.size() * sizeof(double));
     if (e == hipSuccess) e = hipMemcpy(*d_axes_blob, blob.data(), blob.size() * sizeof(double), hipMemcpyHostToDevice);
@@ -757,10 +776,20 @@ hipError_t build_fast(const iso_ic* ic, int nb, const double* d_bc_hot, double**
     std::memset(&F, 0, sizeof(F));
     F.m0 = fa[0]; F.m1 = fa[1];
     F.b0 = fa[2]; F.b1 = fa[3]; F.b2 = fa[4]; F.b3 = fa[5];
-    F.e_a0 = ic->model->ax[2].a0;
-    F.e_step = ic->model->ax[2].step;
-    F.e_inv = 1.0 / F.e_step;
     F.e_n = ic->model->ax[2].n;
+    if (e_uniform) {
+        F.e_a0 = ic->model->ax[2].a0;
+        F.e_step = ic->model->ax[2].step;
+        F.e_inv = 1.0 / F.e_step;
+        F.e_last = std::fma((double)(F.e_n - 1), F.e_step, F.e_a0);
+        F.e_axis = nullptr;
+    } else {
+        F.e_a0 = ic->h_axes_model[2].front();
+        F.e_last = ic->h_axes_model[2].back();
+        F.e_step = F.e_inv = 0.0;
+        F.ec = coarse;
+        F.e_axis = ic->model->d_axes[2];
+    }
     F.axes_blob = *d_axes_blob;
     F.axes_len = (int)blob.size();
     F.hot = ic->d_hot;
@@ -769,6 +798,8 @@ hipError_t build_fast(const iso_ic* ic, int nb, const double* d_bc_hot, double**
     F.s0 = ic->g3.s0; F.s1 = ic->g3.s1;
     F.bc = d_bc_hot;
     F.bcq = *d_bcq;
+    F.nb_total = nb;
+    if (nb > FAST_NB_MAX && !*d_bcq) return hipSuccess;      // the band-tiled kernel exists on the packed tables only
     F.bs2 = ic->bc->shape[3];
     F.bs1 = ic->bc->shape[2] * ic->bc->shape[3];
     F.bs0 = ic->bc->shape[1] * ic->bc->shape[2] * ic->bc->shape[3];
@@ -891,7 +922,7 @@ int iso_model_create(iso_ic* ic, const iso_model_desc* desc, iso_model** out)
     }
     if (e == hipSuccess && !m->fast_ok && ic->d_hotq) {
         // generic kernel: give its lane-per-sample gathers the corner-packed forms too (whole-line reads), whatever
-        // made the model miss the fast path (> 12 bands, non-uniform EEP axis, ISOCHRONES_AMD_PATH=generic)
+        // made the model miss the fast path (> 12 bands, ISOCHRONES_AMD_PATH=generic)
         const size_t bcq_bytes = (size_t)ic->bc->ncells * 16 * (size_t)std::max(desc->n_bands, 1) * sizeof(double);
         if (desc->n_bands > 0 && !m->d_bcq && bcq_bytes <= (size_t(4) << 30)) {
             hipError_t e2 = pack_corners(m->d_bc_hot, desc->n_bands, desc->n_bands, 4, ic->bc->shape, &m->d_bcq);
@@ -938,6 +969,14 @@ void iso_model_destroy(iso_model* m)
 }
 
 int iso_model_n_params(const iso_model* m) { return m ? m->desc.n_stars + 4 : ISO_ERR_INVALID; }
+
+int iso_model_kernel_path(const iso_model* m)
+{
+    if (!m) return ISO_ERR_INVALID;
+    if (!m->fast_ok) return ISO_PATH_GENERIC;
+    const bool packed = m->fast.hotq != nullptr && (m->fast.bcq != nullptr || m->desc.n_bands == 0);
+    return packed ? ISO_PATH_FUSED_PACKED : ISO_PATH_FUSED_COMPACT;
+}
 
 }  // extern "C"
 
@@ -1425,8 +1464,8 @@ int iso_catalog_create(iso_ic* ic, const iso_model_desc* descs, int64_t n_models
             return fail(ISO_ERR_INVALID, "iso_catalog_create: every star needs the same multiplicity and bands");
         if (descs[k].has_numax) return fail(ISO_ERR_INVALID, "iso_catalog_create: asteroseismic terms are not batched");
     }
-    if (!fast_eligible(ic, &d0) || !ic->d_hotq || d0.n_bands < 1)
-        return fail(ISO_ERR_INVALID, "iso_catalog_create: needs 1-12 bands, a uniform EEP axis and the corner-packed "
+    if (!fast_eligible(ic, &d0) || !ic->d_hotq || d0.n_bands < 1 || d0.n_bands > FAST_NB_MAX)
+        return fail(ISO_ERR_INVALID, "iso_catalog_create: needs 1-12 bands, a third model axis of at least 9 nodes (or an exactly uniform one) and the corner-packed "
                                      "tables (ISOCHRONES_AMD_PATH=auto)");
     DeviceGuard guard(ic->device);
     iso_catalog* c = new (std::nothrow) iso_catalog();
@@ -1471,8 +1510,8 @@ int iso_catalog_create_columns(iso_ic* ic, const iso_model_desc* tmpl, int64_t n
     const int rc = validate_desc(ic, tmpl, "iso_catalog_create_columns");
     if (rc != ISO_OK) return rc;
     if (tmpl->has_numax) return fail(ISO_ERR_INVALID, "iso_catalog_create_columns: asteroseismic terms are not batched");
-    if (!fast_eligible(ic, tmpl) || !ic->d_hotq || tmpl->n_bands < 1)
-        return fail(ISO_ERR_INVALID, "iso_catalog_create_columns: needs 1-12 bands, a uniform EEP axis and the "
+    if (!fast_eligible(ic, tmpl) || !ic->d_hotq || tmpl->n_bands < 1 || tmpl->n_bands > FAST_NB_MAX)
+        return fail(ISO_ERR_INVALID, "iso_catalog_create_columns: needs 1-12 bands, a third model axis of at least 9 nodes (or an exactly uniform one) and the "
                                      "corner-packed tables (ISOCHRONES_AMD_PATH=auto)");
     DeviceGuard guard(ic->device);
     iso_catalog* c = new (std::nothrow) iso_catalog();
@@ -1685,7 +1724,7 @@ int iso_tree_model_create(iso_ic* ic, const iso_tree_desc* d, iso_tree_model** o
         m->g4.ncol = d->n_bands;
     }
     if (e == hipSuccess && path_mode() == PATH_AUTO && ic->d_hotq && d->n_bands >= 1 && d->n_bands <= 12 &&
-        ic->model->ax[2].uniform) {
+        third_axis_ok(ic)) {
         bool ok = false;
         e = build_fast(ic, d->n_bands, m->d_bc_hot, &m->d_axes_blob, &m->d_bcq, m->fast, &ok);
         m->fast_ok = ok && m->d_bcq != nullptr;
@@ -1807,9 +1846,9 @@ int iso_sampler_create_model(iso_model* m, int nwalkers, double a, uint64_t seed
 {
     if (!m || !out) return fail(ISO_ERR_INVALID, "iso_sampler_create_model: NULL argument");
     if (nwalkers < 2 || (nwalkers & 1) || !(a > 1.0)) return fail(ISO_ERR_INVALID, "iso_sampler_create_model: need an even walker count and a > 1");
-    if (!m->fast_ok || !m->fast.hotq || (!m->fast.bcq && m->desc.n_bands > 0))
+    if (!m->fast_ok || !m->fast.hotq || (!m->fast.bcq && m->desc.n_bands > 0) || m->desc.n_bands > FAST_NB_MAX)
         return fail(ISO_ERR_INVALID, "iso_sampler_create_model: the model is not on the corner-packed fast path "
-                                     "(needs <= 12 bands, uniform EEP axis, ISOCHRONES_AMD_PATH=auto)");
+                                     "(needs <= 12 bands, ISOCHRONES_AMD_PATH=auto)");
     iso_sampler* sp = new (std::nothrow) iso_sampler();
     if (!sp) return fail(ISO_ERR_NOMEM, "iso_sampler_create_model: out of host memory");
     sampler_common(sp, m->device, m->ic->kind, m->desc.n_stars, m->desc.n_bands, 1, m->fast, 0, nwalkers, a, seed);

@@ -80,8 +80,11 @@ struct FastAxis {
 
 struct FastArgs {
     FastAxis m0, m1;                 // model axes 0 and 1 (bisection in LDS)
-    double e_a0, e_step, e_inv;      // model axis 2 = EEP: exactly uniform, O(1) index
+    double e_a0, e_step, e_inv;      // model axis 2 = EEP: exactly uniform -> O(1) index (e_axis == null)
+    double e_last;                   // its last node (upper bound of the table)
     int e_n;
+    FastAxis ec;                     // ... or not uniform: every 8th node staged in LDS (off, n = ceil(e_n / 8))
+    const double* e_axis;            //     and the axis itself on the device (null for a uniform axis)
     FastAxis b0, b1, b2, b3;         // BC axes
     const double* axes_blob;         // [values | 1/spacing] of the six LDS axes, concatenated
     int axes_len;                    // doubles
@@ -92,6 +95,7 @@ struct FastArgs {
     int64_t s0, s1;
     const double* bc;                // BC restricted to the model's bands [..][nb]
     const double* bcq;               // corner-packed BC [cells][16 corners][nb] (or null)
+    int nb_total;                    // bands in a cell of bcq (the band-tiled kernels, 13-32 bands, read it)
     int64_t bs0, bs1, bs2;
     const DevModel* m;               // one model, or an array indexed by star_id (catalog kernels)
     const int32_t* star_id;          // per-row model index (catalog kernels only)

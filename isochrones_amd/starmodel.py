@@ -477,6 +477,10 @@ class BasicStarModel(_NestedFitMixin, _ConvenienceMixin):
             self._handle_state[device] = _prior_state(self._priors)       # packing may have snapped bounds
         return h
 
+    def kernel_path(self, device=None):
+        """'generic' | 'fused-compact' | 'fused-packed': the kernel family that evaluates this model on `device`."""
+        return ("generic", "fused-compact", "fused-packed")[_cabi.lib().iso_model_kernel_path(self.handle(device))]
+
     def __del__(self):
         try:
             self._dirty()
