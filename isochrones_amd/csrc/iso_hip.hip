@@ -2020,7 +2020,27 @@ int iso_chain_quantiles_layout(iso_ctx* ctx, const double* chain, int layout, in
         // workgroup kernel, which exits at once everywhere else
         const int64_t pairs = n_ens * n_params;
         const dim3 gw((unsigned)((pairs + QW_WAVES - 1) / QW_WAVES));
-        if (m <= 64 * QW_IPL)
+        // the common chain shapes (W divides 64; 12 / 25 / 50 / 100 full registers of 64 values, + a partial one): everything
+        // per-value decided at compile time (ISOCHRONES_AMD_QUANTILES=wave keeps the generic wave kernel for A/B runs)
+        const int full = m / 64;
+        const bool tail = (m % 64) != 0;
+        const size_t qsh = (size_t)QW_WAVES * QW_LDS_PER_WAVE;
+        bool exact = W <= 64 && (64 % W) == 0 && !(qm && !std::strcmp(qm, "wave"));
+        if (exact) {
+            hipStream_t st = as_stream(stream);
+#define ISO_QEXACT(F)                                                                                      \
+            case F:                                                                                        \
+                if (tail) hipLaunchKernelGGL((k_chain_quantiles_exact<F, true>), gw, b, qsh, st, A);       \
+                else hipLaunchKernelGGL((k_chain_quantiles_exact<F, false>), gw, b, qsh, st, A);           \
+                break;
+            switch (full) {
+                ISO_QEXACT(12) ISO_QEXACT(25) ISO_QEXACT(50) ISO_QEXACT(100)
+            default: exact = false;
+            }
+#undef ISO_QEXACT
+        }
+        if (exact) {
+        } else if (m <= 64 * QW_IPL)
             hipLaunchKernelGGL(k_chain_quantiles_wave<QW_IPL>, gw, b, (size_t)QW_WAVES * QW_LDS_PER_WAVE, as_stream(stream), A);
         else
             hipLaunchKernelGGL(k_chain_quantiles_wave<QW_IPL_BIG>, gw, b, (size_t)QW_WAVES * QW_LDS_PER_WAVE, as_stream(stream), A);

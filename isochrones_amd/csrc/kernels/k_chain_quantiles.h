@@ -472,3 +472,187 @@ __global__ __launch_bounds__(BLOCK) void k_chain_quantiles_wave(const QuantArgs 
         A.out[pair * A.nq + lane] = quantile_lerp(result[2 * lane], result[2 * lane + 1], f);
     }
 }
+
+
+// -------------------------------------------------------------------------------------------
+// The same wave-per-pair selection for the common chain shapes, with everything the generic form decides per value
+// decided at compile time.  FULL = floor(m / 64) registers are full in every lane (TAIL: one more register holds the
+// remaining m % 64 values), and W divides 64, so value (t, w) of register k is dq = 64 / W steps behind register k + 1's:
+// one per-lane pointer, a uniform advance per register, no predicate on the FULL registers anywhere.  The generic
+// kernel spends 24 of its ~73 vector instructions per value on 64-bit index arithmetic for the load alone
+// (profiles/r02: 3 806 per pair of 3 200 values, instruction-issue bound); this form needs ~20 per value in total.
+// A NaN in the chain (cannot occur in an accepted chain) flags the pair for the workgroup kernel instead of being
+// replaced value by value.  Host dispatch: iso_chain_quantiles_layout, sizes 12 / 25 / 50 / 100 x 64 (+ tail).
+// -------------------------------------------------------------------------------------------
+template <int FULL, bool TAIL>
+__global__ __launch_bounds__(BLOCK) void k_chain_quantiles_exact(const QuantArgs A)
+{
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t pair = (int64_t)blockIdx.x * QW_WAVES + wave;
+    if (pair >= A.n_ens * A.D) return;                              // wave-uniform; no workgroup barrier below
+    char* base = reinterpret_cast<char*>(lds) + (size_t)wave * QW_LDS_PER_WAVE;
+    double* pool = reinterpret_cast<double*>(base);
+    double* result = pool + QW_POOL;
+    int* hist = reinterpret_cast<int*>(result + QSEL_RANKS);
+    int* rank_bin = hist + QSEL_BINS;
+    int* rank_local = rank_bin + QSEL_RANKS;
+    int* rank_slot = rank_local + QSEL_RANKS;
+    int* list_off = rank_slot + QSEL_RANKS;
+    int* list_cnt = list_off + QSEL_RANKS;
+    int* list_fill = list_cnt + QSEL_RANKS;
+
+    const int64_t e = pair / A.D;
+    const int d = (int)(pair - e * A.D);
+    const int m = (int)(A.nsteps * A.W);                            // FULL * 64 (+ m % 64 with TAIL)
+    const int n_ranks = 2 * A.nq;
+    const int tail = m - FULL * 64;
+
+    // ---- the only pass over the chain ----
+    double v[FULL], vt = d_inf();
+    double mn = d_inf(), mx = -d_inf();
+    bool any_nan = false;
+    {
+        const int dq = 64 / A.W;
+        const int t0 = lane / A.W, w0 = lane - t0 * A.W;
+        const double* __restrict__ lp = A.chain + (e * A.W) * A.rs + d * A.ps + (int64_t)t0 * A.ss + (int64_t)w0 * A.rs;
+        const int64_t adv = (int64_t)dq * A.ss;
+#pragma unroll
+        for (int k = 0; k < FULL; ++k) {
+            const double x = lp[k * adv];
+            v[k] = x;
+            any_nan |= (x != x);
+            mn = fmin(mn, x);
+            mx = fmax(mx, x);
+        }
+        if (TAIL) {
+            const bool have = lane < tail;
+            const double x = have ? lp[FULL * adv] : d_inf();
+            vt = x;
+            any_nan |= (x != x);
+            mn = fmin(mn, x);
+            mx = have ? fmax(mx, x) : mx;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        mn = fmin(mn, __shfl_xor(mn, off));
+        mx = fmax(mx, __shfl_xor(mx, off));
+    }
+    const double inv = (double)QSEL_BINS / (mx - mn);
+    const bool degenerate = !(mx > mn) || !isfinite(inv) || !isfinite(mn) || __any(any_nan);
+    if (degenerate) {
+        const bool flat = !(mx > mn) && isfinite(mn) && isfinite(mx) && !__any(any_nan);      // every value equal
+        if (lane < A.nq) A.out[pair * A.nq + lane] = flat ? mn : __longlong_as_double((long long)QUANT_FLAG);
+        return;
+    }
+    auto bin_of = [&](double x) { return min(QSEL_BINS - 1, (int)((x - mn) * inv)); };
+
+    // ---- histogram in the wave's LDS, exclusive prefix (16 bins per lane) ----
+#pragma unroll
+    for (int r = 0; r < QSEL_BINS / 64; ++r) hist[r * 64 + lane] = 0;
+    if (lane < QSEL_RANKS) list_fill[lane] = 0;
+    qw_sync();
+#pragma unroll
+    for (int k = 0; k < FULL; ++k) atomicAdd(&hist[bin_of(v[k])], 1);
+    if (TAIL && lane < tail) atomicAdd(&hist[bin_of(vt)], 1);
+    qw_sync();
+    {
+        constexpr int PER = QSEL_BINS / 64;
+        int c[PER];
+        int tot = 0;
+#pragma unroll
+        for (int r = 0; r < PER; ++r) {
+            c[r] = hist[lane * PER + r];
+            tot += c[r];
+        }
+        int incl = tot;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int up = __shfl_up(incl, off);
+            if (lane >= off) incl += up;
+        }
+        int run = incl - tot;
+        qw_sync();
+#pragma unroll
+        for (int r = 0; r < PER; ++r) {
+            hist[lane * PER + r] = run;                            // exclusive prefix
+            run += c[r];
+        }
+    }
+    qw_sync();
+    if (lane < n_ranks) {
+        int i0, i1;
+        double f;
+        quantile_position(A.q[lane >> 1], m, i0, i1, f);
+        const int r = (lane & 1) ? i1 : i0;
+        int lo = 0, hi = QSEL_BINS - 1;                            // last bin whose exclusive prefix is <= r
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (hist[mid] <= r) lo = mid;
+            else hi = mid - 1;
+        }
+        rank_bin[lane] = lo;
+        rank_local[lane] = r - hist[lo];
+    }
+    qw_sync();
+    int overflow = 0, n_lists = 0;
+    if (lane == 0) {
+        int used = 0;
+        for (int k = 0; k < n_ranks; ++k) {
+            const int b = rank_bin[k];
+            int sl = -1;
+            for (int j = 0; j < k; ++j)
+                if (rank_bin[j] == b) { sl = rank_slot[j]; break; }
+            if (sl < 0) {
+                const int cnt = ((b + 1 < QSEL_BINS) ? hist[b + 1] : m) - hist[b];
+                sl = n_lists++;
+                list_off[sl] = used;
+                list_cnt[sl] = cnt;
+                used += cnt;
+            }
+            rank_slot[k] = sl;
+        }
+        overflow = used > QW_POOL;
+    }
+    overflow = __shfl(overflow, 0);
+    if (overflow) {                                                  // wave-uniform
+        if (lane < A.nq) A.out[pair * A.nq + lane] = __longlong_as_double((long long)QUANT_FLAG);
+        return;
+    }
+    qw_sync();
+#pragma unroll
+    for (int r = 0; r < QSEL_BINS / 64; ++r) hist[r * 64 + lane] = -1;       // the histogram area becomes the bin -> slot map
+    qw_sync();
+    if (lane < n_ranks) hist[rank_bin[lane]] = rank_slot[lane];      // equal bins write equal slots
+    qw_sync();
+    auto gather = [&](double x) {
+        const int sl = hist[bin_of(x)];
+        if (sl >= 0) {
+            const int pos = atomicAdd(&list_fill[sl], 1);
+            pool[list_off[sl] + pos] = x;
+        }
+    };
+#pragma unroll
+    for (int k = 0; k < FULL; ++k) gather(v[k]);
+    if (TAIL && lane < tail) gather(vt);
+    qw_sync();
+    for (int k = 0; k < n_ranks; ++k) {
+        const int sl = rank_slot[k], cnt = list_cnt[sl], want = rank_local[k];
+        const double* L = pool + list_off[sl];
+        for (int j = lane; j < cnt; j += 64) {
+            const double x = L[j];
+            int before = 0;
+            for (int i = 0; i < cnt; ++i) {
+                const double y = L[i];
+                before += (y < x || (y == x && i < j)) ? 1 : 0;
+            }
+            if (before == want) result[k] = x;
+        }
+    }
+    qw_sync();
+    if (lane < A.nq) {
+        int i0, i1;
+        double f;
+        quantile_position(A.q[lane], m, i0, i1, f);
+        A.out[pair * A.nq + lane] = quantile_lerp(result[2 * lane], result[2 * lane + 1], f);
+    }
+}

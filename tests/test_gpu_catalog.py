@@ -742,23 +742,28 @@ def test_catalog_columns_path_equals_descriptor_path():
         a.close(); b.close()
 
 
-@pytest.mark.parametrize("mode", ["wave", "workgroup", "sort"])
+@pytest.mark.parametrize("mode", ["auto", "wave", "workgroup", "sort"])
 def test_chain_quantiles_adversarial_inputs(mode, monkeypatch):
-    """iso_chain_quantiles on hand-made chains (the wave-per-pair selection kernel with its flagged hand-over, the
-    workgroup selection kernel, and the full LDS sort): smooth data, constant chains, heavy ties (overflow the
-    selection lists: handed to the workgroup kernel / its sort), tiny and odd sample counts, more values than the
-    wave kernel holds, infinities; always numpy.quantile's numbers, bit for bit."""
+    """iso_chain_quantiles on hand-made chains (auto: the wave-per-pair selection kernels - the compile-time-shaped form
+    for 12 / 25 / 50 / 100 full registers of 64 values with or without a partial one, the generic form otherwise - with
+    their flagged hand-over; wave: the generic wave kernel everywhere; the workgroup selection kernel; the full LDS
+    sort): smooth data, constant chains, heavy ties (overflow the selection lists: handed to the workgroup kernel / its
+    sort), tiny and odd sample counts, more values than the wave kernel holds, infinities, both chain layouts; always
+    numpy.quantile's numbers, bit for bit."""
     import ctypes as C
     import torch
     from isochrones_amd import _cabi, device as dev
-    if mode != "wave":
+    if mode != "auto":
         monkeypatch.setenv("ISOCHRONES_AMD_QUANTILES", mode)
     lib, ctx = _cabi.lib(), dev.context(0)
     rng = np.random.default_rng(21)
     qs = np.array([0.5, 0.16, 0.84, 0.0, 1.0, 0.999, 0.3333])
     for nsteps, S, W, D in ((100, 9, 32, 5), (37, 4, 16, 3), (1, 3, 2, 2), (255, 2, 32, 6), (3, 5, 1, 1), (104, 3, 32, 2),
                             (60, 3, 48, 2), (30, 2, 100, 3), (7, 2, 65, 2), (200, 5, 32, 3), (208, 2, 32, 2), (209, 2, 32, 2),
-                            (100, 1031, 32, 5)):
+                            (100, 1031, 32, 5),
+                            # the compile-time-shaped kernel: 12 / 25 / 50 / 100 full registers, with and without a tail, W | 64
+                            (25, 3, 32, 3), (50, 4, 32, 3), (51, 3, 32, 2), (101, 3, 32, 3), (201, 3, 32, 2), (400, 3, 8, 2),
+                            (100, 3, 64, 2), (1600, 3, 2, 2), (24, 3, 32, 2), (200, 3, 16, 3), (3201, 3, 1, 2)):
         x = rng.standard_normal((nsteps, S * W, D))
         if S > 1000:
             x[:, 5 * W:6 * W, 3] = np.exp(3 * x[:, 5 * W:6 * W, 3])      # long tail: most values share the first bins
@@ -783,6 +788,12 @@ def test_chain_quantiles_adversarial_inputs(mode, monkeypatch):
         assert np.array_equal(np.isfinite(got), fin), (nsteps, S, W, D)
         assert np.array_equal(got[fin], want[fin]), (nsteps, S, W, D, np.abs(got[fin] - want[fin]).max())      # bit for bit
         assert np.array_equal(got[~fin & ~np.isnan(want)], want[~fin & ~np.isnan(want)])
+        # the same chain stored parameter-major [step][param][row] (what the sampler writes)
+        chain_pm = torch.as_tensor(np.ascontiguousarray(x.transpose(0, 2, 1)), device="cuda")
+        out2 = torch.zeros_like(out)
+        rc = lib.iso_chain_quantiles_layout(ctx, dev.ptr(chain_pm), _cabi.CHAIN_PARAM_MAJOR, nsteps, S, W, D,
+                                            qs.ctypes.data_as(C.POINTER(C.c_double)), qs.size, dev.ptr(out2), None)
+        assert rc == 0 and np.array_equal(out2.cpu().numpy(), got, equal_nan=True), (nsteps, S, W, D, "parameter-major")
 
 
 def test_fit_multinest_binary_model_respects_ordering():
