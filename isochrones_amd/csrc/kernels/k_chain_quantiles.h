@@ -484,8 +484,11 @@ __global__ __launch_bounds__(BLOCK) void k_chain_quantiles_wave(const QuantArgs 
 // A NaN in the chain (cannot occur in an accepted chain) flags the pair for the workgroup kernel instead of being
 // replaced value by value.  Host dispatch: iso_chain_quantiles_layout, sizes 12 / 25 / 50 / 100 x 64 (+ tail).
 // -------------------------------------------------------------------------------------------
+// registers: the values themselves are 2 x FULL; everything else must fit in what is left for 4 (FULL <= 50) or 2 waves per SIMD
+constexpr int qexact_waves(int full) { return full <= 25 ? 4 : full <= 50 ? 4 : 2; }
+
 template <int FULL, bool TAIL>
-__global__ __launch_bounds__(BLOCK) void k_chain_quantiles_exact(const QuantArgs A)
+__global__ __launch_bounds__(BLOCK, qexact_waves(FULL)) void k_chain_quantiles_exact(const QuantArgs A)
 {
     extern __shared__ double lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -624,8 +627,12 @@ __global__ __launch_bounds__(BLOCK) void k_chain_quantiles_exact(const QuantArgs
     qw_sync();
     if (lane < n_ranks) hist[rank_bin[lane]] = rank_slot[lane];      // equal bins write equal slots
     qw_sync();
+    // the bins are computed again here, not carried over from the histogram pass (the compiler would keep all FULL of them
+    // alive across the phases in between: 50-100 more registers, one or two waves per SIMD fewer): hide the scale from it
+    double mn2 = mn, inv2 = inv;
+    asm volatile("" : "+v"(mn2), "+v"(inv2));
     auto gather = [&](double x) {
-        const int sl = hist[bin_of(x)];
+        const int sl = hist[min(QSEL_BINS - 1, (int)((x - mn2) * inv2))];
         if (sl >= 0) {
             const int pos = atomicAdd(&list_fill[sl], 1);
             pool[list_off[sl] + pos] = x;

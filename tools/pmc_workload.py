@@ -139,7 +139,7 @@ def main():
         for _ in range(L):
             fs.quantiles()
         torch.cuda.synchronize()
-        manifest.append(dict(label="quantiles/100000x32x100", kernel="k_chain_quantiles_wave", launches=L + 1, skip=1,
+        manifest.append(dict(label="quantiles/100000x32x100", kernel="k_chain_quantiles_exact", launches=L + 1, skip=1,
                              n=S * 5, algorithmic_bytes_per_launch=float(S) * W * T * 5 * 8))
     if "primitives" in cases:
         # the batch API primitives (rows a3-a8): interp_mag on the corner-packed tables, interp_value on the wide pack
