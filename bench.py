@@ -689,6 +689,20 @@ def main():
                                   "the oracle's lnpost, one host thread; one_walker_per_call is how emcee drives the reference")
                 c4["gpu_vs_cpu_chain"] = cmp4
                 c4["speedup_vs_cpu_fit"] = c4["cpu_wall_s"] / c4["gpu_wall_s"]
+            # the other 255 CUs: 64 independent 256-walker ensembles of the same star in the same launches
+            try:
+                E = 64
+                fe = FusedEnsembleSampler(mod, 256, seed=2, n_ensembles=E)
+                pe = np.broadcast_to(p0, (E, 256, 5)).copy()
+                fe.run_mcmc(pe, 20, store=False)
+                torch.cuda.synchronize()
+                t_s = time.perf_counter()
+                fe.run_mcmc(pe, 5000, store=False)
+                torch.cuda.synchronize()
+                c4["ensembles_64x256x5000"] = {"gpu_wall_s": time.perf_counter() - t_s, "lnpost_evals": E * 256 * 5000}
+                fe.close()
+            except Exception as e:       # noqa: BLE001
+                c4["ensembles_64x256x5000"] = {"error": "%s: %s" % (type(e).__name__, e)}
             result["cfg4_mcmc_256x5000"] = c4
             fs.close()
         except Exception as e:       # noqa: BLE001

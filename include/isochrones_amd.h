@@ -297,6 +297,12 @@ typedef struct iso_sampler iso_sampler;
                                       the nsteps*W values of an (ensemble, parameter) pair are W contiguous doubles per
                                       step - the summaries below then fetch every line of the chain once */
 int  iso_sampler_create_model(iso_model* m, int nwalkers, double a, uint64_t seed, iso_sampler** out);
+/* n_ensembles independent ensembles of ONE model advanced in lock-step by the same launches (row = ensemble * W + walker
+ * keys the random numbers, so ensemble e of such a sampler makes the moves star e of a catalog sampler would): a single
+ * star's fit occupies one workgroup of the chip, so further chains of it - for convergence diagnostics across
+ * independently started ensembles, or simply more samples - cost no extra time until the workgroups fill the chip. */
+int  iso_sampler_create_model_ensembles(iso_model* m, int64_t n_ensembles, int nwalkers, double a, uint64_t seed,
+                                        iso_sampler** out);
 int  iso_sampler_create_catalog(iso_catalog* c, int nwalkers, double a, uint64_t seed, iso_sampler** out);
 void iso_sampler_destroy(iso_sampler* s);
 /* How iso_sampler_run lays out its `chain` output from now on (chain_lnp is [nsteps][n_ens*W] either way). */

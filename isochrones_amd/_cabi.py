@@ -101,7 +101,7 @@ EXPORTED_SYMBOLS = (
     "iso_lnpost", "iso_lnpost_host", "iso_unit_cube", "iso_time_lnpost", "iso_time_lnpost_rotating",
     "iso_catalog_create", "iso_catalog_create_columns", "iso_catalog_destroy", "iso_catalog_lnpost",
     "iso_eep_table_create", "iso_eep_table_destroy", "iso_interp_eep", "iso_interp_eep_host",
-    "iso_sampler_create_model", "iso_sampler_create_catalog", "iso_sampler_destroy", "iso_sampler_run",
+    "iso_sampler_create_model", "iso_sampler_create_model_ensembles", "iso_sampler_create_catalog", "iso_sampler_destroy", "iso_sampler_run",
     "iso_sampler_set_chain_layout", "iso_chain_quantiles", "iso_chain_quantiles_layout",
     "iso_tree_model_create", "iso_tree_model_destroy", "iso_tree_lnpost", "iso_tree_lnpost_host",
 )
@@ -185,6 +185,7 @@ def lib():
     L.iso_interp_eep_host.argtypes = [vp, hdp, hdp, hdp, i64, hdp]
     L.iso_sampler_create_model.argtypes = [vp, C.c_int, dbl, C.c_uint64, C.POINTER(vp)]
     L.iso_sampler_create_catalog.argtypes = [vp, C.c_int, dbl, C.c_uint64, C.POINTER(vp)]
+    L.iso_sampler_create_model_ensembles.argtypes = [vp, i64, C.c_int, dbl, C.c_uint64, C.POINTER(vp)]
     L.iso_sampler_destroy.argtypes = [vp]
     L.iso_sampler_destroy.restype = None
     L.iso_sampler_run.argtypes = [vp, pd, pd, C.c_int, pd, pd, pd, vp]

@@ -1856,6 +1856,16 @@ int iso_sampler_create_model(iso_model* m, int nwalkers, double a, uint64_t seed
     return ISO_OK;
 }
 
+int iso_sampler_create_model_ensembles(iso_model* m, int64_t n_ensembles, int nwalkers, double a, uint64_t seed,
+                                       iso_sampler** out)
+{
+    if (n_ensembles < 1 || n_ensembles > (int64_t(1) << 24))
+        return fail(ISO_ERR_INVALID, "iso_sampler_create_model_ensembles: n_ensembles out of range");
+    const int rc = iso_sampler_create_model(m, nwalkers, a, seed, out);
+    if (rc == ISO_OK) (*out)->n_ensembles = n_ensembles;      // every row evaluates the one model (multi = 0)
+    return rc;
+}
+
 int iso_sampler_create_catalog(iso_catalog* c, int nwalkers, double a, uint64_t seed, iso_sampler** out)
 {
     if (!c || !out) return fail(ISO_ERR_INVALID, "iso_sampler_create_catalog: NULL argument");

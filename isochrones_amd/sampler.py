@@ -127,7 +127,7 @@ class FusedEnsembleSampler:
     which produces bit-identical chains and is the faster form at every catalog size but those just
     above one round (``ISOCHRONES_AMD_SAMPLER=auto|persistent|stepwise`` selects the form)."""
 
-    def __init__(self, target, nwalkers, a=2.0, seed=0, device=None):
+    def __init__(self, target, nwalkers, a=2.0, seed=0, device=None, n_ensembles=1):
         import ctypes as C
         import torch
         from . import _cabi, device as dev
@@ -136,7 +136,12 @@ class FusedEnsembleSampler:
         self.nwalkers = int(nwalkers)
         self.ndim = target.n_params
         self.is_catalog = isinstance(target, CatalogPosterior)
-        self.n_ensembles = target.n_models if self.is_catalog else 1
+        # a model with n_ensembles > 1: that many independent ensembles of the one posterior in the same launches (shapes
+        # then carry a leading ensemble axis, as a catalog's carry the star axis)
+        self.multi_ensemble = (not self.is_catalog) and int(n_ensembles) > 1
+        if self.is_catalog and int(n_ensembles) != 1:
+            raise ValueError("n_ensembles is for a single model; a catalog has one ensemble per star")
+        self.n_ensembles = target.n_models if self.is_catalog else int(n_ensembles)
         self.device_index = (target.device if self.is_catalog else
                              (dev.current_device() if device is None else device))
         self.device = torch.device("cuda", self.device_index)
@@ -144,6 +149,9 @@ class FusedEnsembleSampler:
         lib = _cabi.lib()
         if self.is_catalog:
             _cabi.check(lib.iso_sampler_create_catalog(target._h, self.nwalkers, float(a), int(seed), C.byref(h)))
+        elif self.multi_ensemble:
+            _cabi.check(lib.iso_sampler_create_model_ensembles(target.handle(self.device_index), self.n_ensembles,
+                                                               self.nwalkers, float(a), int(seed), C.byref(h)))
         else:
             _cabi.check(lib.iso_sampler_create_model(target.handle(self.device_index), self.nwalkers, float(a),
                                                      int(seed), C.byref(h)))
@@ -177,7 +185,7 @@ class FusedEnsembleSampler:
         if self.is_catalog:
             sid = torch.arange(self.n_ensembles, device=self.device, dtype=torch.int32).repeat_interleave(self.nwalkers)
             return self.target.lnpost(pos, sid)
-        return self.target.lnpost(pos)
+        return self.target.lnpost(pos)          # a model's ensembles all evaluate the one posterior
 
     def run_mcmc(self, p0, nsteps, lnprob0=None, store=True):
         """p0: [W, ndim] (model) or [S, W, ndim] (catalog).  Returns (pos, lnprob) in that shape."""
@@ -198,7 +206,7 @@ class FusedEnsembleSampler:
         if store:
             self._chain = chain if self._chain is None else torch.cat([self._chain, chain], dim=0)
             self._lnprob = clnp if self._lnprob is None else torch.cat([self._lnprob, clnp], dim=0)
-        shape = (self.n_ensembles, self.nwalkers) if self.is_catalog else (self.nwalkers,)
+        shape = (self.n_ensembles, self.nwalkers) if self._stacked else (self.nwalkers,)
         return pos.view(*shape, self.ndim), lnp.view(*shape)
 
     @property
@@ -217,7 +225,7 @@ class FusedEnsembleSampler:
         if self._chain is None:
             return torch.empty(self.nwalkers, 0, self.ndim, dtype=torch.float64, device=self.device)
         c = self._chain.view(-1, self.ndim, self.n_ensembles, self.nwalkers).permute(2, 3, 0, 1)
-        return c if self.is_catalog else c[0]
+        return c if self._stacked else c[0]
 
     @property
     def lnprobability(self):
@@ -225,16 +233,16 @@ class FusedEnsembleSampler:
         if self._lnprob is None:
             return torch.empty(self.nwalkers, 0, dtype=torch.float64, device=self.device)
         c = self._lnprob.view(-1, self.n_ensembles, self.nwalkers).permute(1, 2, 0)
-        return c if self.is_catalog else c[0]
+        return c if self._stacked else c[0]
 
     @property
     def flatchain(self):
-        return self.chain.reshape(-1, self.ndim) if not self.is_catalog else self.chain.reshape(
+        return self.chain.reshape(-1, self.ndim) if not self._stacked else self.chain.reshape(
             self.n_ensembles, -1, self.ndim)
 
     @property
     def flatlnprobability(self):
-        return self.lnprobability.reshape(-1) if not self.is_catalog else self.lnprobability.reshape(
+        return self.lnprobability.reshape(-1) if not self._stacked else self.lnprobability.reshape(
             self.n_ensembles, -1)
 
     def quantiles(self, q=(0.5, 0.16, 0.84)):
@@ -266,9 +274,28 @@ class FusedEnsembleSampler:
             i1 = torch.clamp(i0 + 1, max=m - 1)
             frac = pick - i0.to(torch.float64)
             out = srt[:, :, i0] * (1 - frac) + srt[:, :, i1] * frac
-        return out if self.is_catalog else out[0]
+        return out if self._stacked else out[0]
 
     @property
     def acceptance_fraction(self):
         acc = self.accepted.to(dtype=__import__("torch").float64) / max(self.iterations, 1)
-        return acc.view(self.n_ensembles, self.nwalkers) if self.is_catalog else acc
+        return acc.view(self.n_ensembles, self.nwalkers) if self._stacked else acc
+
+    @property
+    def _stacked(self):
+        """results carry a leading ensemble axis: catalogs (one ensemble per star) and multi-ensemble model samplers"""
+        return self.is_catalog or self.multi_ensemble
+
+    def gelman_rubin(self):
+        """Potential scale reduction factor R-hat per parameter across the independent ensembles of a multi-ensemble
+        model sampler (Gelman & Rubin 1992: between- vs within-chain variance of the ensemble means; each ensemble's
+        stored samples are one "chain").  Values near 1 mean the ensembles agree."""
+        import torch
+        if not self.multi_ensemble or self._chain is None:
+            raise ValueError("needs a stored chain of a sampler with n_ensembles > 1")
+        x = self.flatchain                                             # [E, n, D]
+        n = x.shape[1]
+        means = x.mean(dim=1)
+        Wv = x.var(dim=1, unbiased=True).mean(dim=0)
+        B = means.var(dim=0, unbiased=True) * n
+        return torch.sqrt(((n - 1) / n * Wv + B / n) / Wv)

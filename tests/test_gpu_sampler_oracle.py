@@ -246,3 +246,35 @@ def test_cfg5_catalog_sampler_moves_against_the_oracle(monkeypatch):
         assert st["near_ties"] <= 2
         fs.close()
     post.close()
+
+
+def test_independent_ensembles_of_one_model_in_one_launch():
+    """iso_sampler_create_model_ensembles: E ensembles of the cfg-2 star advanced by the same launches.  Every move of
+    every ensemble against the oracle (row = ensemble * W + walker keys the random numbers), ensemble 0 bit-identical to
+    the single-ensemble sampler, differently started ensembles agree on the posterior (R-hat)."""
+    import torch
+    import bench
+    from isochrones_amd.sampler import FusedEnsembleSampler
+    ic, mod = bench.build_model()
+    E, W, T, seed = 6, 64, 400, 5
+    p0 = np.stack([_cfg4_start(mod, W, seed=10 + e) for e in range(E)])              # [E, W, 5]
+    fn = _oracle_fn(ic, [mod.model_desc()])
+    lnp0 = fn(np.zeros(E * W, dtype=int), p0.reshape(E * W, 5)).reshape(E, W)
+    assert np.isfinite(lnp0).all()
+    fs = FusedEnsembleSampler(mod, W, seed=seed, n_ensembles=E)
+    pos, lnp = fs.run_mcmc(p0, T, lnprob0=lnp0, store=True)
+    assert tuple(pos.shape) == (E, W, 5) and tuple(fs.chain.shape) == (E, W, T, 5) and tuple(fs.acceptance_fraction.shape) == (E, W)
+    chain = fs.chain_steps.cpu().numpy()            # [T, E*W, 5]
+    clnp = fs._lnprob.cpu().numpy()
+    st = _replay.replay(p0.reshape(E * W, 5), lnp0.reshape(-1), chain, clnp, W, 2.0, seed, 0,
+                        lambda blk, pars: fn(np.zeros(len(blk), dtype=int), pars))
+    assert st["moves"] == E * W * T and st["near_ties"] <= 2 and st["max_lnp_rel"] < 1e-9
+    # ensemble 0 = the plain single-ensemble sampler with the same seed and start
+    one = FusedEnsembleSampler(mod, W, seed=seed)
+    one.run_mcmc(p0[0], T, lnprob0=lnp0[0], store=True)
+    assert torch.equal(one.chain, fs.chain[0]) and torch.equal(one.lnprobability, fs.lnprobability[0])
+    # the ensembles sample the same posterior
+    rhat = fs.gelman_rubin().cpu().numpy()
+    assert rhat.shape == (5,) and np.all(rhat < 1.2), rhat
+    q = fs.quantiles((0.5,)).cpu().numpy()           # [E, 5, 1]
+    assert q.shape == (E, 5, 1)
