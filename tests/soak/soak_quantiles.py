@@ -14,6 +14,13 @@ t0, rounds, pairs, bad = time.time(), 0, 0, 0
 while time.time() - t0 < budget:
     W = int(rng.choice([1, 2, 7, 16, 24, 32, 32, 32, 48, 64, 100]))
     T = int(rng.integers(1, max(2, min(8192 // W, 260)) + 1))
+    if rng.random() < 0.4:
+        # the compile-time-shaped wave kernel: W divides 64 and T W = 64 F (+ a tail < 64) with F in {12, 25, 50, 100}
+        W = int(rng.choice([2, 4, 8, 16, 32, 32, 64]))
+        F = int(rng.choice([12, 25, 50, 100]))
+        T = (64 * F + int(rng.integers(0, 64)) + W - 1) // W
+        if (T * W) // 64 != F:
+            T = 64 * F // W
     S, D = int(rng.integers(1, 400)), int(rng.integers(1, 9))
     kind = rng.choice(["normal", "lognormal", "ties", "few", "const", "mixed", "inf"])
     x = rng.standard_normal((T, S * W, D))
