@@ -261,8 +261,12 @@ __global__ __launch_bounds__(BLOCK, 4) void k_lnpost_wide(const FastArgs A)
     }
 }
 
+// (the asteroseismic instantiation carries two more gathered values and one more cooperative gather: at the 80
+// registers of 6 waves it spills 56-68 B per lane and every added byte of scratch shows - 117 -> 134 us when the
+// non-uniform-axis branch raised it from 56 to 68 B; at 5 waves it does not spill)
 template <int KIND, int NS, int NB, bool PACKED, bool MULTI, bool ASTERO = false>
-__global__ __launch_bounds__(BLOCK, fast_min_waves(NS, NB)) void k_lnpost_fast(const FastArgs A)
+__global__ __launch_bounds__(BLOCK, ASTERO ? (fast_min_waves(NS, NB) > 5 ? 5 : fast_min_waves(NS, NB)) : fast_min_waves(NS, NB))
+void k_lnpost_fast(const FastArgs A)
 {
     extern __shared__ double lds[];
     for (int j = threadIdx.x; j < A.axes_len; j += BLOCK) lds[j] = A.axes_blob[j];
