@@ -32,7 +32,8 @@ inline bool launch_stretch_nb(int nb, const FastArgs& A, const StretchArgs& S, h
                 return qe == hipSuccess;                                                                  \
             }                                                                                             \
             if (S.dense) hipLaunchKernelGGL((k_stretch_persist<KIND, NS, N, true, ASTERO>), gp, b, shp(N), s, A, S);   \
-            else hipLaunchKernelGGL((k_stretch_persist<KIND, NS, N, false, ASTERO>), gp, b, shp(N), s, A, S);     \
+            else if (S.multi) hipLaunchKernelGGL((k_stretch_persist<KIND, NS, N, false, ASTERO>), gp, b, shp(N), s, A, S); \
+            else hipLaunchKernelGGL((k_stretch_persist<KIND, NS, N, false, ASTERO, true>), gp, b, shp(N), s, A, S);   \
             return true;
             ISO_PERSIST_CASE(0) ISO_PERSIST_CASE(1) ISO_PERSIST_CASE(2) ISO_PERSIST_CASE(3) ISO_PERSIST_CASE(4) ISO_PERSIST_CASE(5)
             ISO_PERSIST_CASE(6) ISO_PERSIST_CASE(7) ISO_PERSIST_CASE(8) ISO_PERSIST_CASE(9) ISO_PERSIST_CASE(10)

@@ -34,7 +34,9 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 // [NP][rows]: rs = 1, ps = rows - consecutive walkers then store consecutive doubles and a (star, parameter)
 // pair of the chain is contiguous per step, which is what the summaries read).  The Philox
 // counter is (step, half, global row): both kernels draw identical numbers for a given move.
-template <int KIND, int NS, int NB, bool ASTERO>
+// UNI: every row of the launch evaluates the one model A.m[0] (a single star's fit): its constants then come through scalar
+// loads instead of one vector load per field and lane (a catalog row has to index its own star's block).
+template <int KIND, int NS, int NB, bool ASTERO, bool UNI = false>
 __device__ __forceinline__ void stretch_move(const FastArgs& A, const StretchArgs& S, double* lds, const CoopLds& L,
                                              bool active, int64_t star, int k, int half, uint32_t step,
                                              double* __restrict__ pos, double* __restrict__ lnp, int32_t* acc_cnt,
@@ -64,11 +66,14 @@ __device__ __forceinline__ void stretch_move(const FastArgs& A, const StretchArg
         y[q] = fma(z, xk[q] - xj, xj);
     }
     const double lold = lnp[lsrc];
-    const DevModel& M = A.m[S.multi ? star : 0];
+    // UNI: the block is read through the constant address space (same memory; tells the compiler that none of this
+    // kernel's stores can touch it, which is what a scalar load needs)
+    typedef const __attribute__((address_space(4))) DevModel* const_model_ptr;
+    const DevModel& M = UNI ? *(const DevModel*)((const_model_ptr)(uintptr_t)A.m) : A.m[S.multi ? star : 0];
     double lnp_unused, lnl_unused;
     const double lnew = lnpost_wave<KIND, NS, NB, true, ASTERO, true>(A, lds, L, active, M, y, false, lnp_unused, lnl_unused);
-    const double lnq = (NP - 1) * log(z) + lnew - lold;
-    const bool acc = active && isfinite(lnew) && (log(u2) < lnq);
+    const double lnq = (NP - 1) * fast_log(z) + lnew - lold;
+    const bool acc = active && isfinite(lnew) && (fast_log(u2) < lnq);
     if (acc) {
 #pragma unroll
         for (int q = 0; q < NP; ++q) pos[lr * NP + q] = y[q];
@@ -169,8 +174,8 @@ __global__ __launch_bounds__(BLOCK, stretch_half_waves(NB)) void k_stretch_half(
         yy[q] = fma(m.z, xk[q] - xj, xj);
     }
     const double lold = lnp[m.lr];
-    const double lnq = (NP - 1) * log(m.z) + lnew - lold;
-    const bool acc = isfinite(lnew) && (log(m.u2) < lnq);
+    const double lnq = (NP - 1) * fast_log(m.z) + lnew - lold;
+    const bool acc = isfinite(lnew) && (fast_log(m.u2) < lnq);
     if (acc) {
 #pragma unroll
         for (int q = 0; q < NP; ++q) pos[m.lr * NP + q] = yy[q];
@@ -201,7 +206,7 @@ __host__ __device__ constexpr int persist_extra_doubles(int W, int np)
 // DENSE: registers capped for 3 waves/SIMD, so that 3 workgroups share a CU (catalogs of 513-768 workgroups
 // stay resident in one round: 10^4 stars x 32 walkers 53 -> 42 us per iteration); the uncapped form (182 VGPR,
 // 2 workgroups per CU) is 10 % faster when latency is all that matters.
-template <int KIND, int NS, int NB, bool DENSE, bool ASTERO = false>
+template <int KIND, int NS, int NB, bool DENSE, bool ASTERO = false, bool UNI = false>
 __global__ __launch_bounds__(BLOCK, DENSE ? 3 : 1) void k_stretch_persist(const FastArgs A, const StretchArgs S)
 {
     extern __shared__ double lds[];
@@ -256,7 +261,7 @@ __global__ __launch_bounds__(BLOCK, DENSE ? 3 : 1) void k_stretch_persist(const 
                 const int k = k0 + kk;
                 const bool active = mine && k < h;
                 if (__any(active))                        // wave-uniform: idle waves go straight to the barrier
-                    stretch_move<KIND, NS, NB, ASTERO>(A, S, lds, L, active, star0 + gs, active ? k : h - 1, half,
+                    stretch_move<KIND, NS, NB, ASTERO, UNI>(A, S, lds, L, active, star0 + gs, active ? k : h - 1, half,
                                                S.step + (uint32_t)it, lpos + gs * W * NP, llnp + gs * W,
                                                lacc + gs * W, cp, cl);
             }
