@@ -3,9 +3,10 @@
 #pragma once
 
 // dynamic LDS of the persistent form; the host uses it to decide whether an ensemble fits
-inline size_t stretch_persist_lds_bytes(int axes_len, int nb, int W, int np)
+inline size_t stretch_persist_lds_bytes(int axes_len, int nb, int W, int np, bool dense = false)
 {
-    return (size_t)(((axes_len + 1) & ~1) + coop_lds_doubles(nb) + persist_extra_doubles(W, np)) * sizeof(double);
+    return (size_t)(((axes_len + 1) & ~1) + BLOCK * persist_slot_stride(dense, nb, np - 4) +
+                    persist_extra_doubles(W, np, persist_slim(dense, nb, np - 4))) * sizeof(double);
 }
 
 template <int KIND, int NS, bool ASTERO = false>
@@ -16,7 +17,7 @@ inline bool launch_stretch_nb(int nb, const FastArgs& A, const StretchArgs& S, h
         const int64_t n_ens = S.n_active / (S.W >> 1);
         const int G = persist_group(S.W);
         const dim3 gp((unsigned)((n_ens + G - 1) / G));
-        auto shp = [&](int n) { return stretch_persist_lds_bytes(A.axes_len, n, S.W, NS + 4); };
+        auto shp = [&](int n) { return stretch_persist_lds_bytes(A.axes_len, n, S.W, NS + 4, S.dense != 0); };
         switch (nb) {
         // with S.occupancy_query set: report resident workgroups per CU of this instantiation, launch nothing
 #define ISO_PERSIST_CASE(N)                                                                               \

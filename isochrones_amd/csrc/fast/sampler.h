@@ -192,26 +192,38 @@ __global__ __launch_bounds__(BLOCK, stretch_half_waves(NB)) void k_stretch_half(
 
 // persistent form: ALL S.nsteps iterations in a single launch.  A workgroup owns G = max(1, BLOCK / (W/2))
 // whole ensembles (one lane per walker of the active half, so a 32-walker catalog packs 16 stars into a
-// workgroup; a large ensemble is walked in chunks of BLOCK).  Positions, lnpost values and acceptance
-// counters live in LDS; the two half-steps of an iteration are separated by workgroup barriers instead
+// workgroup; a large ensemble is walked in chunks of BLOCK).  Positions (and, except in the slim form, lnpost values
+// and acceptance counters) live in LDS; the two half-steps of an iteration are separated by workgroup barriers instead
 // of kernel boundaries, so an iteration costs two dependent evaluation chains instead of two launches.
 // Same moves, same random numbers, bit-identical chains as the step-wise form.
-// LDS: [axes][request/response slots][pos R*NP][lnp R][acc R (int32)],  R = G * W rows
+// LDS: [axes][request/response slots][pos R*NP]( [lnp R][acc R (int32)] ),  R = G * W rows
 __host__ __device__ constexpr int persist_group(int W) { return (W >> 1) >= BLOCK ? 1 : BLOCK / (W >> 1); }
-__host__ __device__ constexpr int persist_extra_doubles(int W, int np)
+// DENSE with at most 6 bands is "slim": FOUR workgroups per CU.  That takes 128 registers (the evaluation fits once
+// MachineLICM no longer hoists its constants out of the iteration loop: build flag -disable-machine-licm, 167 -> 134
+// registers at the 3-wave cap, 126-128 with 12-28 B of scratch at the 4-wave cap) and 40 KB of LDS: the gather slots
+// shrink to 7 doubles (5 of request, <= 6 of response) and only the positions stay in LDS - a move reads its own
+// lnpost from the global array at the start of its half-step and writes it and its acceptance counter back when it
+// is accepted (16 B per move next to the 816 B its gathers move; every row has exactly one owner lane).
+// (single stars only: a binary's evaluation spills 68-156 B per lane at 128 registers, a triple's 124-208 B)
+__host__ __device__ constexpr bool persist_slim(bool dense, int nb, int ns) { return dense && nb <= 6 && ns == 1; }
+__host__ __device__ constexpr int persist_slot_stride(bool dense, int nb, int ns) { return persist_slim(dense, nb, ns) ? 7 : slot_stride(nb); }
+__host__ __device__ constexpr int persist_extra_doubles(int W, int np, bool slim = false)
 {
-    return persist_group(W) * W * (np + 1) + (persist_group(W) * W + 1) / 2;
+    return slim ? persist_group(W) * W * np : persist_group(W) * W * (np + 1) + (persist_group(W) * W + 1) / 2;
 }
 
-// DENSE: registers capped for 3 waves/SIMD, so that 3 workgroups share a CU (catalogs of 513-768 workgroups
-// stay resident in one round: 10^4 stars x 32 walkers 53 -> 42 us per iteration); the uncapped form (182 VGPR,
-// 2 workgroups per CU) is 10 % faster when latency is all that matters.
+// DENSE: registers capped so that 3 (slim: 4) workgroups share a CU; the uncapped form (2 workgroups per CU) is 10 %
+// faster when latency is all that matters (every workgroup resident at once, e.g. a single star's fit).
 template <int KIND, int NS, int NB, bool DENSE, bool ASTERO = false, bool UNI = false>
-__global__ __launch_bounds__(BLOCK, DENSE ? 3 : 1) void k_stretch_persist(const FastArgs A, const StretchArgs S)
+__global__ __launch_bounds__(BLOCK, DENSE ? (persist_slim(DENSE, NB, NS) ? 4 : 3) : 1) void k_stretch_persist(const FastArgs A, const StretchArgs S)
 {
     extern __shared__ double lds[];
     for (int j = threadIdx.x; j < A.axes_len; j += BLOCK) lds[j] = A.axes_blob[j];
-    const CoopLds L = coop_lds<NB>(lds, A.axes_len);
+    constexpr bool SLIM = persist_slim(DENSE, NB, NS);
+    constexpr int STRIDE = persist_slot_stride(DENSE, NB, NS);
+    CoopLds L = coop_lds<NB>(lds, A.axes_len);
+    L.req = L.rsp = lds + ((A.axes_len + 1) & ~1) + (threadIdx.x >> 6) * 64 * STRIDE;
+    L.stride = STRIDE;
     constexpr int NP = NS + 4;
     const int W = S.W, h = W >> 1;
     const int G = persist_group(W);
@@ -221,13 +233,15 @@ __global__ __launch_bounds__(BLOCK, DENSE ? 3 : 1) void k_stretch_persist(const 
     const int here = (int)((n_ens - star0) < G ? (n_ens - star0) : G);   // ensembles this workgroup owns
     const int R = here * W;
     const int64_t r0 = star0 * W;
-    double* lpos = lds + ((A.axes_len + 1) & ~1) + coop_lds_doubles(NB);
-    double* llnp = lpos + G * W * NP;
-    int32_t* lacc = reinterpret_cast<int32_t*>(llnp + G * W);
+    double* lpos = lds + ((A.axes_len + 1) & ~1) + BLOCK * STRIDE;
+    double* llnp = SLIM ? S.lnp + r0 : lpos + G * W * NP;                       // slim: the global arrays themselves
+    int32_t* lacc = SLIM ? (S.accepted ? S.accepted + r0 : nullptr) : reinterpret_cast<int32_t*>(llnp + G * W);
     for (int j = threadIdx.x; j < R * NP; j += BLOCK) lpos[j] = S.pos[r0 * NP + j];
-    for (int j = threadIdx.x; j < R; j += BLOCK) {
-        llnp[j] = S.lnp[r0 + j];
-        lacc[j] = 0;
+    if (!SLIM) {
+        for (int j = threadIdx.x; j < R; j += BLOCK) {
+            llnp[j] = S.lnp[r0 + j];
+            lacc[j] = 0;
+        }
     }
     __syncthreads();
     const int64_t rows_total = n_ens * W;
@@ -263,7 +277,7 @@ __global__ __launch_bounds__(BLOCK, DENSE ? 3 : 1) void k_stretch_persist(const 
                 if (__any(active))                        // wave-uniform: idle waves go straight to the barrier
                     stretch_move<KIND, NS, NB, ASTERO, UNI>(A, S, lds, L, active, star0 + gs, active ? k : h - 1, half,
                                                S.step + (uint32_t)it, lpos + gs * W * NP, llnp + gs * W,
-                                               lacc + gs * W, cp, cl);
+                                               lacc ? lacc + gs * W : nullptr, cp, cl);
             }
             if (wave_local) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -275,8 +289,10 @@ __global__ __launch_bounds__(BLOCK, DENSE ? 3 : 1) void k_stretch_persist(const 
     }
     if (wave_local) __syncthreads();                      // the write-back below reads rows of the other waves
     for (int j = threadIdx.x; j < R * NP; j += BLOCK) S.pos[r0 * NP + j] = lpos[j];
-    for (int j = threadIdx.x; j < R; j += BLOCK) {
-        S.lnp[r0 + j] = llnp[j];
-        if (S.accepted) S.accepted[r0 + j] += lacc[j];
+    if (!SLIM) {
+        for (int j = threadIdx.x; j < R; j += BLOCK) {
+            S.lnp[r0 + j] = llnp[j];
+            if (S.accepted) S.accepted[r0 + j] += lacc[j];
+        }
     }
 }
