@@ -282,8 +282,8 @@ int  iso_tree_lnpost_host(iso_tree_model* m, const double* pars, int64_t n, doub
 /* Device-resident affine-invariant ensemble sampler (stretch move, Goodman & Weare 2010) — what the
  * reference obtains from emcee.EnsembleSampler(nwalkers, npars, self.lnpost).run_mcmc(...)
  * (isochrones/starmodel.py:951-969), with the proposal, the fused lnpost and the accept step in one
- * kernel: either one launch per half-ensemble step, or — whenever an ensemble fits a workgroup's LDS, except
- * for catalogs just above one round of resident workgroups — a single persistent launch for all nsteps
+ * kernel: either one launch per half-ensemble step, or — whenever an ensemble fits a workgroup's LDS — a single
+ * persistent launch for all nsteps
  * iterations whose workgroups own their ensembles (same moves, same Philox numbers, identical
  * chains; environment ISOCHRONES_AMD_SAMPLER=auto|persistent|stepwise overrides the choice).  pos [n_ens*W, n_params] row-major and lnp [n_ens*W] are DEVICE arrays
  * updated in place (lnp must hold lnpost(pos) on entry); chain [nsteps][n_ens*W][n_params],

@@ -1913,11 +1913,11 @@ int iso_sampler_run(iso_sampler* sp, double* pos, double* lnp, int nsteps, doubl
     S.chain_ps = sp->chain_layout == ISO_CHAIN_PARAM_MAJOR ? rows : 1;
     // ISOCHRONES_AMD_SAMPLER = auto | persistent | stepwise.  Both forms produce bit-identical chains.  The persistent
     // kernel (workgroups own their ensembles for all iterations of the call, positions in LDS) is the faster one
-    // at every catalog size measured (tools/sampler_mode_sweep.py: 7-25 % over 2 x 10^3 ... 4 x 10^5 stars, 1-8 bands,
-    // 1-3 stars per system, 16-64 walkers): beyond the chip's capacity its workgroups run in rounds, and the few
+    // at every catalog size measured (tools/sampler_mode_sweep.py, profiles/r03: 25-35 % over 2 x 10^3 ... 4 x 10^5 stars,
+    // 1-6 bands, 1-2 stars per system): beyond the chip's capacity its workgroups run in rounds, and the few
     // thousand ensembles resident at a time re-read table lines that are still in L2 / Infinity Cache, where a
-    // half-step launch over the whole catalog streams everything from HBM.  The exception is a catalog just above
-    // one round (1 < rounds <= 1.4): the second, nearly empty round costs more than the step-wise form.
+    // half-step launch over the whole catalog streams everything from HBM.  `auto` therefore runs it whenever an
+    // ensemble fits a workgroup's LDS.
     const char* env = getenv("ISOCHRONES_AMD_SAMPLER");
     std::string mode = env ? env : "auto";
     const bool force_dense = mode == "persistent-dense";          // test hook: the register-capped instantiation
@@ -1933,8 +1933,8 @@ int iso_sampler_run(iso_sampler* sp, double* pos, double* lnp, int nsteps, doubl
     int cus = 0, per_cu = 0;
     HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, sp->device));
     const int64_t blocks = (sp->n_ensembles + group - 1) / group;
-    // two instantiations: uncapped registers (2 workgroups per CU, fastest per iteration) and "dense"
-    // (3 per CU); persistent is chosen while one of them keeps every workgroup resident
+    // two instantiations: uncapped registers (2 workgroups per CU, fastest per iteration) and "dense" (4 per CU for single
+    // stars with <= 6 bands, else 3): the first that keeps every workgroup resident, else the dense one in rounds
     int dense = 0;
     if (fits && mode != "stepwise") {
         S.nsteps = 1;
@@ -1949,9 +1949,9 @@ int iso_sampler_run(iso_sampler* sp, double* pos, double* lnp, int nsteps, doubl
         }
     }
     S.dense = dense;
-    const int64_t resident = (int64_t)cus * per_cu;
-    const bool rounds_ok = blocks <= resident || (resident > 0 && 5 * blocks > 7 * resident);      // not in (1, 1.4] rounds
-    const bool persistent = nsteps > 0 && fits && (mode == "persistent" || (mode == "auto" && rounds_ok));
+    // (round 2 kept the step-wise form for catalogs of 1-1.4 rounds, where a nearly empty second round cost more than it;
+    // with four workgroups per CU the persistent form is ahead there too - profiles/r03/sampler_mode_sweep.txt)
+    const bool persistent = nsteps > 0 && fits && per_cu > 0 && mode != "stepwise";
     if (persistent) {
         S.step = sp->step;
         S.nsteps = nsteps;

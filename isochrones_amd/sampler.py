@@ -124,8 +124,8 @@ class FusedEnsembleSampler:
     single ~10 us launch instead of ~25 framework launches; whenever an ensemble fits a workgroup's
     LDS the library runs ALL iterations of a ``run_mcmc`` call in one persistent launch
     (workgroup-resident ensembles, positions in LDS; catalogs larger than the chip run in rounds),
-    which produces bit-identical chains and is the faster form at every catalog size but those just
-    above one round (``ISOCHRONES_AMD_SAMPLER=auto|persistent|stepwise`` selects the form)."""
+    which produces bit-identical chains and is the faster form at every catalog size
+    (``ISOCHRONES_AMD_SAMPLER=auto|persistent|stepwise`` selects the form)."""
 
     def __init__(self, target, nwalkers, a=2.0, seed=0, device=None, n_ensembles=1):
         import ctypes as C
