@@ -80,3 +80,42 @@ def test_replay_accepts_a_faithful_chain_and_rejects_tampering():
     bad_c[t, r], bad_l[t, r] = prev_c[t, r], prev[t, r]
     with pytest.raises(AssertionError):
         _replay.replay(p0, lnp0, bad_c, bad_l, W, a, seed, step0, fn, star_of_block=stars)
+
+
+def test_cpu_sampler_makes_the_moves_the_replay_expects():
+    """oracle/cpu_sampler.stretch_fit (the host fit behind bench.py's measured cfg 4 / cfg 5 CPU baselines): its chain
+    passes the teacher-forced replay with zero near ties, one-call-per-walker and one-call-per-half-ensemble give the
+    same chain bit for bit, a second call continues the counter stream, and `row0` shifts the random numbers as the
+    device sampler's global row does."""
+    from oracle import cpu_sampler
+    rng = np.random.default_rng(3)
+    W, D, T, a, seed = 32, 5, 60, 2.0, 0xABCDEF
+    mu = np.array([1.0, 355.0, 0.0, 100.0, 0.1])
+    sig = np.array([0.05, 10.0, 0.1, 5.0, 0.05])
+
+    def lnpost_rows(rows):
+        r = (rows - mu) / sig
+        out = -0.5 * np.sum(r * r, axis=1)
+        out[rows[:, 4] < 0] = -np.inf                       # a hard bound, as the AV prior
+        return out
+
+    p0 = mu + sig * rng.standard_normal((W, D))
+    p0[:, 4] = np.abs(p0[:, 4])
+    lnp0 = lnpost_rows(p0)
+    star = 7
+    pos, lnp, chain, clnp, nacc = cpu_sampler.stretch_fit(lnpost_rows, p0, lnp0, T, a=a, seed=seed, row0=star * W, scalar_calls=True)
+    pos2, lnp2, chain2, clnp2, nacc2 = cpu_sampler.stretch_fit(lnpost_rows, p0, lnp0, T, a=a, seed=seed, row0=star * W, scalar_calls=False)
+    assert np.array_equal(chain, chain2) and np.array_equal(clnp, clnp2) and np.array_equal(nacc, nacc2)
+    assert np.array_equal(pos, chain[-1]) and np.array_equal(lnp, clnp[-1])
+    st = _replay.replay(p0, lnp0, chain, clnp, W, a, seed, 0, lambda blk, pars: lnpost_rows(pars), star_of_block=np.array([star]))
+    assert st["moves"] == W * T and st["near_ties"] == 0 and 0.2 < st["accepted"] / st["moves"] < 0.9
+    assert nacc.sum() == st["accepted"]
+    # continuing: step0 = T picks the stream up where the first call left it
+    _, _, c3, l3, _ = cpu_sampler.stretch_fit(lnpost_rows, pos, lnp, 10, a=a, seed=seed, step0=T, row0=star * W)
+    _, _, c4, l4, _ = cpu_sampler.stretch_fit(lnpost_rows, p0, lnp0, T + 10, a=a, seed=seed, row0=star * W)
+    assert np.array_equal(c3, c4[T:]) and np.array_equal(l3, l4[T:])
+    # another star's rows draw other numbers
+    _, _, c5, _, _ = cpu_sampler.stretch_fit(lnpost_rows, p0, lnp0, 5, a=a, seed=seed, row0=(star + 1) * W)
+    assert not np.array_equal(c5, chain[:5])
+    with pytest.raises(AssertionError):                      # and the replay notices the wrong star
+        _replay.replay(p0, lnp0, chain, clnp, W, a, seed, 0, lambda blk, pars: lnpost_rows(pars), star_of_block=np.array([star + 1]))
