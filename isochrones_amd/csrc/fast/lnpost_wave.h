@@ -223,7 +223,8 @@ constexpr int fast_min_waves(int ns, int nb) { return (ns == 1 && nb <= 2) ? 6 :
 // 32-band model is 4 KB: registers hold one tile of it at a time).  Batch form only.
 constexpr int WIDE_TILE = 8;
 // tile width per multiplicity: a system of 2-3 stars keeps every component's BC bracket and a flux sum per band of the
-// tile alive, which at 8 bands spills (208-320 B of scratch per lane at 128 registers)
+// tile alive, which at 8 bands spills (84 B of scratch per lane for a binary at 128 registers; with tiles of 4 none -
+// 100-118 registers - once MachineLICM no longer hoists constants out of the tile loop)
 constexpr int wide_tile(int ns) { return ns == 1 ? WIDE_TILE : 4; }
 
 template <int KIND, int NS>
