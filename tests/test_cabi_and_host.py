@@ -253,3 +253,21 @@ def test_pdf_array_is_pdf_element_by_element():
         assert np.array_equal(np.isnan(got), np.isnan(want)) and np.allclose(got, want, rtol=1e-14, atol=0, equal_nan=True), type(p).__name__
     s = priors.ChabrierPrior(bounds=(0.1, 300)).sample(5000, rng)
     assert s.min() >= 0.1 and s.max() <= 300 and 0.2 < np.median(s) < 0.7
+
+
+def test_integration_md_stub_mirrors_the_header_structs():
+    """The ctypes structures spelled out in INTEGRATION.md section 1 (what a maintainer of the reference would copy) have the
+    field names, offsets and sizes of the library's iso_prior / iso_model_desc; the GPU suite runs the stub itself."""
+    import re
+    import types
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    block = re.findall(r"```python\n(.*?)```", text[text.index("## 1."):text.index("## 2.")], flags=re.S)[0]
+    block = block.replace('_lib = C.CDLL("libiso_hip.so")', "_lib = None").replace("import ctypes as C, numpy as np, torch",
+                                                                                   "import ctypes as C, numpy as np")
+    stub = types.ModuleType("integration_stub")
+    exec(compile(block, "INTEGRATION.md#1", "exec"), stub.__dict__)
+    for mine, theirs in ((stub.Prior, _cabi.IsoPrior), (stub.ModelDesc, _cabi.IsoModelDesc)):
+        assert ctypes.sizeof(mine) == ctypes.sizeof(theirs)
+        assert [n for n, _ in mine._fields_] == [n for n, _ in theirs._fields_]
+        assert all(getattr(mine, n).offset == getattr(theirs, n).offset for n, _ in mine._fields_)

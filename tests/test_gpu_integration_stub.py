@@ -63,6 +63,18 @@ for tracks in (True, False):
     for got, want, name in ((T, oT, "Teff"), (g, og, "logg"), (f, of, "feh"), (m, om, "mags")):
         fx.assert_close(got, want, 1e-12, what="INTEGRATION stub %%s (%%s)" %% (name, "tracks" if tracks else "isochrones"))
     assert np.isfinite(om).all(axis=1).sum() > 1000 and np.isnan(om).any()
+    # the posterior route: the stub's own mirror of iso_model_desc filled with a model's descriptor, iso_model_create, iso_lnpost
+    import ctypes
+    mod = ia.SingleStarModel(ic, Teff=(5770, 100), logg=(4.4, 0.1), J=(9.5, 0.03), K=(9.1, 0.03), G=(10.6, 0.02), parallax=(10.0, 0.2))
+    src = mod.model_desc()
+    assert ctypes.sizeof(stub.ModelDesc) == ctypes.sizeof(src)          # the stub's structure is the header's
+    desc = stub.ModelDesc.from_buffer_copy(bytes(src))
+    assert desc.n_bands == 3 and desc.prior_feh.kind == src.prior_feh.kind and desc.bound_hi[3] == src.bound_hi[3]
+    mh = stub.model(handle, desc)
+    got = stub.lnpost(mh, pars.T)
+    want = fx.make_oracle_ic(ic).lnpost(src, pars, parts=False)
+    fx.assert_close(got, want, 1e-9, atol=1e-10, what="INTEGRATION stub lnpost (%%s)" %% ("tracks" if tracks else "isochrones"))
+    assert np.isfinite(want).sum() > 200
 print("STUB_OK")
 '''
 
@@ -71,7 +83,7 @@ def test_integration_md_stub_runs_verbatim_and_matches_the_oracle(tmp_path):
     text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     sec1 = text[text.index("## 1."):text.index("## 2.")]
     blocks = re.findall(r"```python\n(.*?)```", sec1, flags=re.S)
-    assert len(blocks) == 1 and "iso_ic_create" in blocks[0] and "def interp_mags" in blocks[0]
+    assert len(blocks) == 1 and "iso_ic_create" in blocks[0] and "def interp_mags" in blocks[0] and "def lnpost" in blocks[0]
     stub = tmp_path / "_hip.py"
     stub.write_text(blocks[0])
     driver = tmp_path / "driver.py"
