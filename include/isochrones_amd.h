@@ -202,6 +202,13 @@ int  iso_model_n_params(const iso_model* m);
 #define ISO_PATH_FUSED_COMPACT  1
 #define ISO_PATH_FUSED_PACKED   2
 int  iso_model_kernel_path(const iso_model* m);
+/* Host-side test helper, no device involved: the bracket index the fused kernels compute for every x[k] on axis
+ * `which` of a set of axes - bucket table (planned for all `n_axes` axes together within `budget` bytes, exactly as
+ * the library stages them in LDS) + windowed bisection.  It must equal what the reference's searchsorted /
+ * find_indices give (interp.py:10-35,116-123): #{a_j <= x} - 1, clamped to [0, n - 2], for a0 <= x <= a_last.
+ * plan_out (optional, 5 ints per axis): buckets, window, levels, shift, first bucket.  Returns 0 or an ISO_ERR code. */
+int  iso_axis_bracket_host(const double* const* axes, const int32_t* n_nodes, int n_axes, int budget, int which,
+                           const double* x, int64_t n, int32_t* index_out, int32_t* plan_out);
 
 /* lnpost = lnprior + lnlike, or -inf where lnprior is not finite (starmodel.py:538-542).
  * lnprior_out / lnlike_out are optional (NULL to skip); when requested they hold the values

@@ -98,6 +98,7 @@ EXPORTED_SYMBOLS = (
     "iso_table_create", "iso_table_destroy", "iso_interp", "iso_interp_host",
     "iso_ic_create", "iso_ic_destroy", "iso_interp_mag", "iso_interp_mag_host",
     "iso_model_create", "iso_model_destroy", "iso_model_n_params", "iso_model_kernel_path",
+    "iso_axis_bracket_host",
     "iso_lnpost", "iso_lnpost_host", "iso_unit_cube", "iso_time_lnpost", "iso_time_lnpost_rotating",
     "iso_catalog_create", "iso_catalog_create_columns", "iso_catalog_destroy", "iso_catalog_lnpost",
     "iso_eep_table_create", "iso_eep_table_destroy", "iso_interp_eep", "iso_interp_eep_host",
@@ -161,6 +162,8 @@ def lib():
     L.iso_model_destroy.restype = None
     L.iso_model_n_params.argtypes = [vp]
     L.iso_model_kernel_path.argtypes = [vp]
+    L.iso_axis_bracket_host.argtypes = [C.POINTER(pd), C.POINTER(i32), C.c_int, C.c_int, C.c_int, pd, i64,
+                                        C.POINTER(i32), C.POINTER(i32)]
     L.iso_lnpost.argtypes = [vp, pd, i64, i64, i64, pd, pd, pd, vp]
     L.iso_lnpost_host.argtypes = [vp, vp, i64, vp, vp, vp]
     L.iso_unit_cube.argtypes = [vp, pd, i64, i64, i64, vp]

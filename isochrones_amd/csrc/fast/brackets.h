@@ -8,10 +8,22 @@ __device__ __forceinline__ bool lds_oob(const double* lds, const FastAxis ax, do
     return (x < lds[ax.off]) || (x > lds[ax.off + ax.n - 1]);
 }
 
+// Where the bisection of an axis starts (fast/axis_lut.h): a byte table indexed by the exponent and leading mantissa
+// bits of x + c gives a node at or below x, and the bracket lies within the next lut_win(ax) nodes - the same integer
+// #{a_j <= x} - 1 the reference's searchsorted (interp.py:10-35) arrives at, in 1-3 levels instead of 4-8.
+__device__ __forceinline__ int lut_start(const double* lds, const FastAxis ax, double x)
+{
+    // no clamp: every caller has checked a_0 <= x <= a_last (lds_oob) and the bucket function is monotone, so the
+    // byte read is one of the table's
+    const uint8_t* tab = reinterpret_cast<const uint8_t*>(lds) + ax.lutb;
+    return (int)tab[__double2hiint(x + __hiloint2double(ax.chi, 0)) >> (ax.shw & 31)];
+}
+__device__ __forceinline__ int lut_win(const FastAxis ax) { return ax.shw >> 8; }
+
 __device__ __forceinline__ void lds_bracket(const double* lds, const FastAxis ax, double x, int& i, double& t)
 {
     const double* a = lds + ax.off;
-    int base = 0, len = ax.n;
+    int base = lut_start(lds, ax, x), len = lut_win(ax);
     while (len > 1) {
         const int half = len >> 1;
         base = (a[base + half] <= x) ? base + half : base;
@@ -22,7 +34,7 @@ __device__ __forceinline__ void lds_bracket(const double* lds, const FastAxis ax
     t = (x - a[base]) * a[ax.n + base];
 }
 
-// The same bisection for several axes in lock-step: the LDS reads of one level are issued back to back,
+// The same (windowed) bisection for several axes in lock-step: the LDS reads of one level are issued back to back,
 // so a sample pays one LDS latency per level instead of one per level per axis (an axis that has
 // converged re-reads its node, which changes nothing).
 __device__ __forceinline__ void lds_bracket2(const double* lds, const FastAxis axa, const FastAxis axb, double xa,
@@ -30,7 +42,7 @@ __device__ __forceinline__ void lds_bracket2(const double* lds, const FastAxis a
 {
     const double* a = lds + axa.off;
     const double* b = lds + axb.off;
-    int ba = 0, bb = 0, la = axa.n, lb = axb.n;
+    int ba = lut_start(lds, axa, xa), bb = lut_start(lds, axb, xb), la = lut_win(axa), lb = lut_win(axb);
     while ((la | lb) > 1) {
         const int ha = la >> 1, hb = lb >> 1;
         const double va = a[ba + ha], vb = b[bb + hb];
@@ -56,7 +68,8 @@ __device__ __forceinline__ void lds_bracket4(const double* lds, const FastAxis a
     const double* a1 = lds + ax1.off;
     const double* a2 = lds + ax2.off;
     const double* a3 = lds + ax3.off;
-    int b0 = 0, b1 = 0, b2 = 0, b3 = 0, l0 = ax0.n, l1 = ax1.n, l2 = ax2.n, l3 = ax3.n;
+    int b0 = lut_start(lds, ax0, x0), b1 = lut_start(lds, ax1, x1), b2 = lut_start(lds, ax2, x2), b3 = lut_start(lds, ax3, x3);
+    int l0 = lut_win(ax0), l1 = lut_win(ax1), l2 = lut_win(ax2), l3 = lut_win(ax3);
     while ((l0 | l1 | l2 | l3) > 1) {
         const int h0 = l0 >> 1, h1 = l1 >> 1, h2 = l2 >> 1, h3 = l3 >> 1;
         const double v0 = a0[b0 + h0], v1 = a1[b1 + h1], v2 = a2[b2 + h2], v3 = a3[b3 + h3];
@@ -97,7 +110,7 @@ __device__ __forceinline__ void eep_bracket(const FastArgs& A, const double* lds
     const int n = A.e_n;
     if (A.e_axis) {
         const double* c = lds + A.ec.off;
-        int base = 0, len = A.ec.n;
+        int base = lut_start(lds, A.ec, x), len = lut_win(A.ec);
         while (len > 1) {
             const int half = len >> 1;
             base = (c[base + half] <= x) ? base + half : base;

@@ -36,8 +36,10 @@ __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* l
         int i2 = 0;
         if (ok) eep_bracket(A, lds, eep, i2, w.t2);
         if (PACKED) {
-            const uint32_t cell = (uint32_t)((int64_t)i0 * A.s0 + (int64_t)i1 * A.s1 + i2);
+            uint32_t cell = (uint32_t)((int64_t)i0 * A.s0 + (int64_t)i1 * A.s1 + i2);
+            ISO_STAMP(2, cell);
             coop_star(A, L, ok, cell, w, star[s]);
+            ISO_STAMP(3, star[s][0]);
             // asteroseismic pair of the primary (reference starmodel.py:1603-1612); a separate instantiation,
             // because even a never-taken branch here costs the common kernel registers (measured: +29 %)
             if (ASTERO && s == 0) coop_pair(A.astq, L, ok && M.has_numax, cell, w, astero);
@@ -66,6 +68,7 @@ __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* l
     lnp += ln_pdf<true>(M.prior_distance, dist, ld);
     lnp += ln_pdf<false>(M.prior_AV, AV, 0.0);
     if (rejected) lnp = -f_inf();
+    ISO_STAMP(4, lnp);
     const bool prior_ok = active && isfinite(lnp);
     const bool go = active && (prior_ok || want_parts);     // evaluate the likelihood for this lane
     lnp_out = lnp;
@@ -148,8 +151,10 @@ __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* l
                 lds_bracket4(lds, A.b0, A.b1, A.b2, A.b3, T, g, f, AV, j0, j1, j2, j3, w4v.t0, w4v.t1, w4v.t2, w4v.t3);
             }
             if (PACKED) {
-                const uint32_t cell = (uint32_t)((int64_t)j0 * A.bs0 + (int64_t)j1 * A.bs1 + (int64_t)j2 * A.bs2 + j3);
+                uint32_t cell = (uint32_t)((int64_t)j0 * A.bs0 + (int64_t)j1 * A.bs1 + (int64_t)j2 * A.bs2 + j3);
+                ISO_STAMP(5, cell);
                 coop_bc<NB>(A, L, ok, cell, w4v, bc);
+                ISO_STAMP(6, bc[0]);
             } else if (ok) {
                 gather_bc<NB>(A, j0, j1, j2, j3, w4v, bc);
             } else {
@@ -196,6 +201,7 @@ __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* l
             lnl += M.dnu_g0 - r2 * r2 * M.dnu_hinv;
         }
     }
+    ISO_STAMP(7, lnl);
     lnl_out = go ? lnl : f_nan();
     return prior_ok ? lnp + lnl : -f_inf();
 }

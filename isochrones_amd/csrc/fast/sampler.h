@@ -44,7 +44,8 @@ __device__ __forceinline__ void stretch_move(const FastArgs& A, const StretchArg
 {
     constexpr int NP = NS + 4;
     const int h = S.W >> 1;
-    const int lr = (half ? h : 0) + k;                  // row within the star's ensemble
+    int lr = (half ? h : 0) + k;                        // row within the star's ensemble
+    ISO_STAMP(0, lr);
     const int64_t row = star * S.W + lr;
     uint32_t rnd[4];
     philox4x32_10((uint32_t)(2u * step + (uint32_t)half), (uint32_t)row, (uint32_t)((uint64_t)row >> 32), 0x51u,
@@ -65,6 +66,7 @@ __device__ __forceinline__ void stretch_move(const FastArgs& A, const StretchArg
         const double xj = pos[lp * NP + q];
         y[q] = fma(z, xk[q] - xj, xj);
     }
+    ISO_STAMP(1, y[0]);
     const double lold = lnp[lsrc];
     // UNI: the block is read through the constant address space (same memory; tells the compiler that none of this
     // kernel's stores can touch it, which is what a scalar load needs)
@@ -86,6 +88,7 @@ __device__ __forceinline__ void stretch_move(const FastArgs& A, const StretchArg
         for (int q = 0; q < NP; ++q) chain_pos[lr * S.chain_rs + q * S.chain_ps] = acc ? y[q] : xk[q];
     }
     if (active && chain_lnp) chain_lnp[lr] = acc ? lnew : lold;
+    ISO_STAMP(8, lr);
 }
 
 // step-wise form: one launch = one half-step of every ensemble (grid over stars x W/2 walkers);
@@ -285,6 +288,7 @@ __global__ __launch_bounds__(BLOCK, DENSE ? (persist_slim(DENSE, NB, NS) ? 4 : 3
             } else {
                 __syncthreads();
             }
+            ISO_STAMP_HERE(9);
         }
     }
     if (wave_local) __syncthreads();                      // the write-back below reads rows of the other waves

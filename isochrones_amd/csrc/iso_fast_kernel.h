@@ -62,6 +62,24 @@ __device__ __forceinline__ double fast_log(double x)
 
 __device__ __forceinline__ double fast_log10(double x) { return fast_log(x) * kInvLn10; }
 
+// Instrumentation builds only (tools/phase_clock.py: -DISO_PHASE_CLOCK): lane 0 of workgroup 0 stores the shader clock at
+// the phase boundaries of an evaluation; `val` is pinned so that the phase's result exists when the clock is read.
+#ifdef ISO_PHASE_CLOCK
+static __device__ unsigned long long g_phase_stamps[16];
+#define ISO_STAMP(k, val)                                                                                   \
+    do {                                                                                                    \
+        asm volatile("" : "+v"(val));                                                                       \
+        if (blockIdx.x == 0 && threadIdx.x == 0) g_phase_stamps[k] = __builtin_readcyclecounter();          \
+    } while (0)
+#define ISO_STAMP_HERE(k)                                                                                   \
+    do {                                                                                                    \
+        if (blockIdx.x == 0 && threadIdx.x == 0) g_phase_stamps[k] = __builtin_readcyclecounter();          \
+    } while (0)
+#else
+#define ISO_STAMP(k, val) do { } while (0)
+#define ISO_STAMP_HERE(k) do { } while (0)
+#endif
+
 #include "fast/brackets.h"
 #include "fast/gather_lane.h"
 #include "fast/priors_log.h"

@@ -5,3 +5,11 @@ namespace iso {
 ISO_DEFINE_FAST_LAUNCHER(launch_fast_track1, ISO_KIND_TRACK, 1)
 ISO_DEFINE_STRETCH_LAUNCHER(launch_stretch_track1, ISO_KIND_TRACK, 1)
 }  // namespace iso
+
+#ifdef ISO_PHASE_CLOCK
+// instrumentation build (tools/phase_clock.py): the shader-clock stamps of the last evaluation workgroup 0 ran
+extern "C" int iso_debug_phase_stamps(unsigned long long* out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(iso::fastk::g_phase_stamps), 16 * sizeof(unsigned long long));
+}
+#endif

@@ -42,6 +42,7 @@
 // host-side bookkeeping
 // ======================================================================================
 #include "iso_internal.h"
+#include "fast/axis_lut.h"
 
 using namespace iso;
 
@@ -742,6 +743,7 @@ hipError_t build_fast(const iso_ic* ic, int nb, const double* d_bc_hot, double**
     *ok = false;
     std::vector<double> blob;
     FastAxis fa[6];
+    std::memset(fa, 0, sizeof(fa));
     const std::vector<double>* src[6] = {&ic->h_axes_model[0], &ic->h_axes_model[1], &ic->h_axes_bc[0],
                                          &ic->h_axes_bc[1], &ic->h_axes_bc[2], &ic->h_axes_bc[3]};
     for (int a = 0; a < 6; ++a) {
@@ -753,14 +755,45 @@ hipError_t build_fast(const iso_ic* ic, int nb, const double* d_bc_hot, double**
         blob.push_back(0.0);
     }
     FastAxis coarse;
-    coarse.off = coarse.n = 0;
+    std::memset(&coarse, 0, sizeof(coarse));
     const bool e_uniform = ic->model->ax[2].uniform != 0;
     if (!e_uniform) {
         const std::vector<double>& v = ic->h_axes_model[2];
         if (v.size() < 9) return hipSuccess;
         coarse.off = (int)blob.size();
         for (size_t j = 0; j < v.size(); j += 8) blob.push_back(v[j]);
+        // the bucket table of this axis is entered with any x of the full axis: close it with the last node (a
+        // coarse bracket there is clamped to the last window anyway)
+        if ((v.size() - 1) % 8 != 0) blob.push_back(v.back());
         coarse.n = (int)blob.size() - coarse.off;
+    }
+    // bucket tables of the seven staged axes (fast/axis_lut.h), bytes behind the doubles.  Budget: what the
+    // four-workgroups-per-CU persistent sampler has left of its 40 KB (axes + 256 gather slots of 7 doubles + 512
+    // positions of 5 doubles; 736 B with the MIST axes), at most 1 KB.
+    {
+        std::vector<const std::vector<double>*> planned(src, src + 6);
+        std::vector<double> coarse_nodes;
+        if (!e_uniform) {
+            coarse_nodes.assign(blob.begin() + coarse.off, blob.begin() + coarse.off + coarse.n);
+            planned.push_back(&coarse_nodes);
+        }
+        const int spare = 6144 - (int)(blob.size() * sizeof(double));
+        const int budget = spare >= 64 ? std::min(spare & ~7, 1024) : 512;
+        const std::vector<AxisLutChoice> plan = axis_lut_plan(planned, budget);
+        std::vector<uint8_t> bytes;
+        for (size_t a = 0; a < planned.size(); ++a) {
+            FastAxis& ax = a < 6 ? fa[a] : coarse;
+            const AxisLutChoice& ch = plan[a];
+            ax.lutb = (int)(blob.size() * sizeof(double) + bytes.size()) - ch.b0;
+            ax.shw = ch.sh | (ch.win << 8);
+            ax.chi = lut_hi32(ch.c);
+            bytes.resize(bytes.size() + (size_t)ch.nbk);
+            axis_lut_fill(*planned[a], ch, bytes.data() + bytes.size() - (size_t)ch.nbk);
+        }
+        bytes.resize((bytes.size() + 7) & ~(size_t)7, 0);
+        const size_t at = blob.size();
+        blob.resize(at + bytes.size() / sizeof(double));
+        std::memcpy(blob.data() + at, bytes.data(), bytes.size());
     }
     if ((int)blob.size() > FAST_MAX_BLOB) return hipSuccess;
     hipError_t e = hipMalloc(d_axes_blob, blob.size() * sizeof(double));
@@ -969,6 +1002,45 @@ void iso_model_destroy(iso_model* m)
 }
 
 int iso_model_n_params(const iso_model* m) { return m ? m->desc.n_stars + 4 : ISO_ERR_INVALID; }
+
+int iso_axis_bracket_host(const double* const* axes, const int32_t* n_nodes, int n_axes, int budget, int which,
+                          const double* x, int64_t n, int32_t* index_out, int32_t* plan_out)
+{
+    if (!axes || !n_nodes || n_axes < 1 || which < 0 || which >= n_axes || (n > 0 && (!x || !index_out)))
+        return fail(ISO_ERR_INVALID, "iso_axis_bracket_host: bad arguments");
+    std::vector<std::vector<double>> ax(n_axes);
+    std::vector<const std::vector<double>*> ptr(n_axes);
+    for (int a = 0; a < n_axes; ++a) {
+        if (n_nodes[a] < 2) return fail(ISO_ERR_INVALID, "iso_axis_bracket_host: an axis needs two nodes");
+        ax[a].assign(axes[a], axes[a] + n_nodes[a]);
+        ptr[a] = &ax[a];
+    }
+    const std::vector<AxisLutChoice> plan = axis_lut_plan(ptr, budget);
+    for (int a = 0; plan_out && a < n_axes; ++a) {
+        plan_out[5 * a + 0] = plan[a].nbk;
+        plan_out[5 * a + 1] = plan[a].win;
+        plan_out[5 * a + 2] = plan[a].levels;
+        plan_out[5 * a + 3] = plan[a].sh;
+        plan_out[5 * a + 4] = plan[a].b0;
+    }
+    const AxisLutChoice& ch = plan[which];
+    const std::vector<double>& v = ax[which];
+    std::vector<uint8_t> tab((size_t)ch.nbk);
+    axis_lut_fill(v, ch, tab.data());
+    const int nn = (int)v.size();
+    for (int64_t k = 0; k < n; ++k) {                 // the statements of lut_start() + lds_bracket() (fast/brackets.h)
+        const int b = lut_bucket(x[k], ch.c, ch.sh, ch.b0);
+        if (b < 0 || b >= ch.nbk) return fail(ISO_ERR_INVALID, "iso_axis_bracket_host: bucket outside the table (x outside the axis?)");
+        int base = tab[(size_t)b], len = ch.win;
+        while (len > 1) {
+            const int half = len >> 1;
+            base = (v[(size_t)(base + half)] <= x[k]) ? base + half : base;
+            len -= half;
+        }
+        index_out[k] = std::min(base, nn - 2);
+    }
+    return ISO_OK;
+}
 
 int iso_model_kernel_path(const iso_model* m)
 {

@@ -76,6 +76,12 @@ struct DevModel {
 struct FastAxis {
     int off;   // LDS offset (doubles): values at [off, off+n), reciprocal spacings at [off+n, off+2n-1)
     int n;
+    // bucket table (fast/axis_lut.h): the byte at blob byte offset lutb + (hi32(x + c) >> sh) is a node at or below
+    // every x of that bucket, and the bracket lies within the `win` nodes from there (one bucket, win = n: the plain
+    // bisection).  c is a double whose low word is zero (chi = its high word); five scalar registers per axis.
+    int lutb;  // byte offset of the table inside the staged blob, minus the bucket number of the first node
+    int shw;   // sh | win << 8
+    int chi;
 };
 
 struct FastArgs {
@@ -83,7 +89,7 @@ struct FastArgs {
     double e_a0, e_step, e_inv;      // model axis 2 = EEP: exactly uniform -> O(1) index (e_axis == null)
     double e_last;                   // its last node (upper bound of the table)
     int e_n;
-    FastAxis ec;                     // ... or not uniform: every 8th node staged in LDS (off, n = ceil(e_n / 8))
+    FastAxis ec;                     // ... or not uniform: every 8th node (+ the last one) staged in LDS
     const double* e_axis;            //     and the axis itself on the device (null for a uniform axis)
     FastAxis b0, b1, b2, b3;         // BC axes
     const double* axes_blob;         // [values | 1/spacing] of the six LDS axes, concatenated
