@@ -34,6 +34,7 @@ inline bool launch_stretch_nb(int nb, const FastArgs& A, const StretchArgs& S, h
             }                                                                                             \
             if (S.dense) hipLaunchKernelGGL((k_stretch_persist<KIND, NS, N, true, ASTERO>), gp, b, shp(N), s, A, S);   \
             else if (S.multi) hipLaunchKernelGGL((k_stretch_persist<KIND, NS, N, false, ASTERO>), gp, b, shp(N), s, A, S); \
+            else if (S.std_priors) hipLaunchKernelGGL((k_stretch_persist<KIND, NS, N, false, ASTERO, true, true>), gp, b, shp(N), s, A, S); \
             else hipLaunchKernelGGL((k_stretch_persist<KIND, NS, N, false, ASTERO, true>), gp, b, shp(N), s, A, S);   \
             return true;
             ISO_PERSIST_CASE(0) ISO_PERSIST_CASE(1) ISO_PERSIST_CASE(2) ISO_PERSIST_CASE(3) ISO_PERSIST_CASE(4) ISO_PERSIST_CASE(5)

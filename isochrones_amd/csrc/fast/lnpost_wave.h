@@ -10,7 +10,9 @@
 // (starmodel.py:1427-1433).
 // TILED (batch kernels for 13-32 bands, k_lnpost_wide): NB is the width of a band tile and the photometric terms are
 // taken tile by tile over the A.nb_total bands of the corner-packed BC cell (each star's BC bracket is found once and kept).
-template <int KIND, int NS, int NB, bool PACKED, bool ASTERO = false, bool MASKED = false, bool TILED = false>
+// STDP: the model's priors are the reference's default families (Chabrier mass, flat-in-age, local-disk [Fe/H],
+// power-law distance, flat AV - the host checks the records): the families are compile-time constants here.
+template <int KIND, int NS, int NB, bool PACKED, bool ASTERO = false, bool MASKED = false, bool TILED = false, bool STDP = false>
 __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* lds, const CoopLds& L, bool active,
                                               const DevModel& M, const double* __restrict__ p, bool want_parts,
                                               double& lnp_out, double& lnl_out)
@@ -57,16 +59,19 @@ __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* l
     bool rejected = false;
     if (NS == 2) rejected = p[1] > p[0];
     if (NS == 3) rejected = !(p[0] > p[1]) && (p[1] > p[2]);
-    if (KIND == ISO_KIND_TRACK) lnp += ln_pdf<false>(M.prior_mass, p[0], 0.0);
+    constexpr int K_MASS = STDP ? ISO_PRIOR_CHABRIER : -1, K_AGE = STDP ? ISO_PRIOR_FLATLOG : -1, K_FEH = STDP ? ISO_PRIOR_FEH : -1,
+                  K_DIST = STDP ? ISO_PRIOR_POWERLAW : -1, K_AV = STDP ? ISO_PRIOR_FLAT : -1;
+    if (KIND == ISO_KIND_TRACK) lnp += ln_pdf<false, K_MASS>(M.prior_mass, p[0], 0.0);
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         const double eep = (KIND == ISO_KIND_TRACK) ? p[1] : p[s];
-        lnp += eep_term(M, (KIND == ISO_KIND_TRACK) ? M.prior_age : M.prior_mass, eep, star[s][4], star[s][5]);
+        lnp += (KIND == ISO_KIND_TRACK) ? eep_term<K_AGE>(M, M.prior_age, eep, star[s][4], star[s][5])
+                                        : eep_term<K_MASS>(M, M.prior_mass, eep, star[s][4], star[s][5]);
     }
-    if (KIND == ISO_KIND_ISO) lnp += ln_pdf<false>(M.prior_age, q1, 0.0);
-    lnp += ln_pdf<false>(M.prior_feh, feh_par, 0.0);
-    lnp += ln_pdf<true>(M.prior_distance, dist, ld);
-    lnp += ln_pdf<false>(M.prior_AV, AV, 0.0);
+    if (KIND == ISO_KIND_ISO) lnp += ln_pdf<false, K_AGE>(M.prior_age, q1, 0.0);
+    lnp += ln_pdf<false, K_FEH>(M.prior_feh, feh_par, 0.0);
+    lnp += ln_pdf<true, K_DIST>(M.prior_distance, dist, ld);
+    lnp += ln_pdf<false, K_AV>(M.prior_AV, AV, 0.0);
     if (rejected) lnp = -f_inf();
     ISO_STAMP(4, lnp);
     const bool prior_ok = active && isfinite(lnp);
@@ -79,10 +84,17 @@ __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* l
     double lnl = 0.0;
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
-        const double val = M.spec_val[q];
-        if (val == val) {
+        if constexpr (STDP) {          // a select, not a branch: the nine constants arrive in one batch of scalar loads
+            const double val = M.spec_val[q], g0 = M.spec_g0[q], hinv = M.spec_hinv[q];
             const double r = val - star[0][q];
-            lnl += M.spec_g0[q] - r * r * M.spec_hinv[q];
+            const double term = g0 - r * r * hinv;
+            lnl += (val == val) ? term : 0.0;
+        } else {                       // (the batch / catalog kernels sit at their register caps: fetched when needed)
+            const double val = M.spec_val[q];
+            if (val == val) {
+                const double r = val - star[0][q];
+                lnl += M.spec_g0[q] - r * r * M.spec_hinv[q];
+            }
         }
     }
     const double dm = fma(ld, 5.0 * kInvLn10, -5.0);   // 5*log10(d/10)
@@ -185,8 +197,15 @@ __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* l
     #pragma unroll
         for (int b = 0; b < NB; ++b) {
             const double mag = (NS == 1) ? tot[b] : fma(-2.5, fast_log10(rel[b]), tot[b]);
-            const double r = M.mag_val[b] - mag;
-            if (!MASKED || M.mag_val[b] == M.mag_val[b]) lnl += M.mag_g0[b] - r * r * M.mag_hinv[b];
+            if constexpr (STDP) {
+                const double mv = M.mag_val[b], g0 = M.mag_g0[b], hinv = M.mag_hinv[b];
+                const double r = mv - mag;
+                const double term = g0 - r * r * hinv;
+                lnl += (!MASKED || mv == mv) ? term : 0.0;
+            } else {
+                const double r = M.mag_val[b] - mag;
+                if (!MASKED || M.mag_val[b] == M.mag_val[b]) lnl += M.mag_g0[b] - r * r * M.mag_hinv[b];
+            }
         }
     }
     if (M.has_parallax) {

@@ -36,7 +36,8 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 // counter is (step, half, global row): both kernels draw identical numbers for a given move.
 // UNI: every row of the launch evaluates the one model A.m[0] (a single star's fit): its constants then come through scalar
 // loads instead of one vector load per field and lane (a catalog row has to index its own star's block).
-template <int KIND, int NS, int NB, bool ASTERO, bool UNI = false>
+// STDP (with UNI): that model's priors are the reference's defaults - their families are compile-time constants.
+template <int KIND, int NS, int NB, bool ASTERO, bool UNI = false, bool STDP = false>
 __device__ __forceinline__ void stretch_move(const FastArgs& A, const StretchArgs& S, double* lds, const CoopLds& L,
                                              bool active, int64_t star, int k, int half, uint32_t step,
                                              double* __restrict__ pos, double* __restrict__ lnp, int32_t* acc_cnt,
@@ -73,7 +74,7 @@ __device__ __forceinline__ void stretch_move(const FastArgs& A, const StretchArg
     typedef const __attribute__((address_space(4))) DevModel* const_model_ptr;
     const DevModel& M = UNI ? *(const DevModel*)((const_model_ptr)(uintptr_t)A.m) : A.m[S.multi ? star : 0];
     double lnp_unused, lnl_unused;
-    const double lnew = lnpost_wave<KIND, NS, NB, true, ASTERO, true>(A, lds, L, active, M, y, false, lnp_unused, lnl_unused);
+    const double lnew = lnpost_wave<KIND, NS, NB, true, ASTERO, true, false, STDP>(A, lds, L, active, M, y, false, lnp_unused, lnl_unused);
     const double lnq = (NP - 1) * fast_log(z) + lnew - lold;
     const bool acc = active && isfinite(lnew) && (fast_log(u2) < lnq);
     if (acc) {
@@ -217,7 +218,7 @@ __host__ __device__ constexpr int persist_extra_doubles(int W, int np, bool slim
 
 // DENSE: registers capped so that 3 (slim: 4) workgroups share a CU; the uncapped form (2 workgroups per CU) is 10 %
 // faster when latency is all that matters (every workgroup resident at once, e.g. a single star's fit).
-template <int KIND, int NS, int NB, bool DENSE, bool ASTERO = false, bool UNI = false>
+template <int KIND, int NS, int NB, bool DENSE, bool ASTERO = false, bool UNI = false, bool STDP = false>
 __global__ __launch_bounds__(BLOCK, DENSE ? (persist_slim(DENSE, NB, NS) ? 4 : 3) : 1) void k_stretch_persist(const FastArgs A, const StretchArgs S)
 {
     extern __shared__ double lds[];
@@ -278,7 +279,7 @@ __global__ __launch_bounds__(BLOCK, DENSE ? (persist_slim(DENSE, NB, NS) ? 4 : 3
                 const int k = k0 + kk;
                 const bool active = mine && k < h;
                 if (__any(active))                        // wave-uniform: idle waves go straight to the barrier
-                    stretch_move<KIND, NS, NB, ASTERO, UNI>(A, S, lds, L, active, star0 + gs, active ? k : h - 1, half,
+                    stretch_move<KIND, NS, NB, ASTERO, UNI, STDP>(A, S, lds, L, active, star0 + gs, active ? k : h - 1, half,
                                                S.step + (uint32_t)it, lpos + gs * W * NP, llnp + gs * W,
                                                lacc ? lacc + gs * W : nullptr, cp, cl);
             }

@@ -1908,6 +1908,7 @@ int sampler_common(iso_sampler* sp, int device, int kind, int n_stars, int n_ban
     sp->seed = seed;
     sp->step = 0;
     sp->multi = multi;
+    sp->std_priors = 0;
     sp->chain_layout = ISO_CHAIN_ROW_MAJOR;
     sp->fast = F;
     return ISO_OK;
@@ -1924,6 +1925,13 @@ int iso_sampler_create_model(iso_model* m, int nwalkers, double a, uint64_t seed
     iso_sampler* sp = new (std::nothrow) iso_sampler();
     if (!sp) return fail(ISO_ERR_NOMEM, "iso_sampler_create_model: out of host memory");
     sampler_common(sp, m->device, m->ic->kind, m->desc.n_stars, m->desc.n_bands, 1, m->fast, 0, nwalkers, a, seed);
+    // the reference's default prior families (starmodel.py:1459-1475, priors.py): the sampler kernel then has them as
+    // compile-time constants
+    const iso_model_desc& d = m->desc;
+    sp->std_priors = d.prior_mass.kind == ISO_PRIOR_CHABRIER && d.prior_age.kind == ISO_PRIOR_FLATLOG &&
+                     d.prior_feh.kind == ISO_PRIOR_FEH && d.prior_feh.c != 0.0 &&
+                     d.prior_distance.kind == ISO_PRIOR_POWERLAW && d.prior_AV.kind == ISO_PRIOR_FLAT;
+    if (const char* e = std::getenv("ISOCHRONES_AMD_STD_PRIORS")) sp->std_priors = sp->std_priors && std::atoi(e) != 0;   // A/B switch
     *out = sp;
     return ISO_OK;
 }
@@ -1977,6 +1985,7 @@ int iso_sampler_run(iso_sampler* sp, double* pos, double* lnp, int nsteps, doubl
     S.accepted = accepted;
     S.W = sp->W;
     S.multi = sp->multi;
+    S.std_priors = sp->std_priors;
     S.n_active = sp->n_ensembles * (sp->W / 2);
     if (S.n_active >= (int64_t(1) << 31)) return fail(ISO_ERR_INVALID, "iso_sampler_run: more than 2^31 moves per half-step");
     S.a = sp->a;

@@ -152,6 +152,7 @@ struct StretchArgs {
     double* chain_lnp;    // optional: this step's [n_rows] slab
     int* occupancy_query; // host side only, persistent form: non-null = report workgroups/CU, do not launch
     int dense;            // host side only, persistent form: 1 = the register-capped (3 waves/SIMD) instantiation
+    int std_priors;       // host side only: the single model's priors are the reference's default families
 };
 
 }  // namespace iso
@@ -255,6 +256,7 @@ struct iso_sampler {
     uint64_t seed;
     uint32_t step;           // running step counter (keeps the RNG stream moving across runs)
     int multi;
+    int std_priors;          // single model whose priors are the reference's default families (compile-time kinds)
     int chain_layout;        // ISO_CHAIN_ROW_MAJOR / ISO_CHAIN_PARAM_MAJOR
     iso::FastArgs fast;      // tables + model(s); copied at create time (owner must outlive the sampler)
 };
