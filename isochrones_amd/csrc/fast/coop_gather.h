@@ -63,6 +63,7 @@ __device__ __forceinline__ void coop_star(const FastArgs& A, const CoopLds& L, b
     __builtin_amdgcn_wave_barrier();
     const unsigned long long m = __ballot(need);
     const int j = L.lane & 3, grp = L.lane >> 2;
+    ISO_STAMP_HERE(10);
     // two batches of two iterations: the 12 loads of a batch are in flight before the first use
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
@@ -84,14 +85,15 @@ __device__ __forceinline__ void coop_star(const FastArgs& A, const CoopLds& L, b
             wlo[k] = nd ? (1 - t0) * g : 0.0;     // corners 0..3 (axis-0 offset 0)
             whi[k] = nd ? t0 * g : 0.0;           // corners 4..7
         }
+        if (half == 0) { ISO_STAMP(11, whi[1]); ISO_STAMP(12, u[0][0].x); ISO_STAMP(13, u[1][5].y); }
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int src = 16 * (2 * half + k) + grp;
             double part[6];
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
-                part[2 * q] = quad_sum(u[k][q].x * wlo[k] + u[k][3 + q].x * whi[k]);
-                part[2 * q + 1] = quad_sum(u[k][q].y * wlo[k] + u[k][3 + q].y * whi[k]);
+                part[2 * q] = quad_sum(corner_pair(u[k][q].x, wlo[k], u[k][3 + q].x, whi[k]));
+                part[2 * q + 1] = quad_sum(corner_pair(u[k][q].y, wlo[k], u[k][3 + q].y, whi[k]));
             }
             double* rs = L.rsp + src * L.stride;
             // spread the six stores over the quad: lane j writes values j and j+4
@@ -100,6 +102,7 @@ __device__ __forceinline__ void coop_star(const FastArgs& A, const CoopLds& L, b
             if (j < 2) rs[4 + j] = (j == 0) ? part[4] : part[5];
         }
     }
+    ISO_STAMP_HERE(14);
     __builtin_amdgcn_wave_barrier();
     const double* rs = L.rsp + L.lane * L.stride;
 #pragma unroll
@@ -139,8 +142,8 @@ __device__ __forceinline__ void coop_pair(const double* __restrict__ tab, const 
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         if (((m >> (16 * k)) & 0xFFFFull) == 0) continue;                      // wave-uniform
-        const double a = quad_sum(lo[k].x * wlo[k] + hi[k].x * whi[k]);
-        const double b = quad_sum(lo[k].y * wlo[k] + hi[k].y * whi[k]);
+        const double a = quad_sum(corner_pair(lo[k].x, wlo[k], hi[k].x, whi[k]));
+        const double b = quad_sum(corner_pair(lo[k].y, wlo[k], hi[k].y, whi[k]));
         double* rs = L.rsp + (16 * k + grp) * L.stride;
         if (j == 0) rs[0] = a;
         if (j == 1) rs[1] = b;
@@ -196,8 +199,7 @@ __device__ __forceinline__ void coop_bc(const FastArgs& A, const CoopLds& L, boo
             double* rs = L.rsp + src * L.stride;
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
-                const double part = quad_sum(x[k][b].x * wa[k][0] + x[k][b].y * wb[k][0] +
-                                             x[k][NB + b].x * wa[k][1] + x[k][NB + b].y * wb[k][1]);
+                const double part = quad_sum(corner_quad(x[k][b], wa[k][0], wb[k][0], x[k][NB + b], wa[k][1], wb[k][1]));
                 if (j == (b & 3)) rs[b] = part;
             }
         }
@@ -247,7 +249,7 @@ __device__ __forceinline__ void coop_bc_tile(const FastArgs& A, const CoopLds& L
         double* rs = L.rsp + src * L.stride;
 #pragma unroll
         for (int b = 0; b < TB; ++b) {
-            const double part = quad_sum(x[b].x * wa0 + x[b].y * wb0 + x[TB + b].x * wa1 + x[TB + b].y * wb1);
+            const double part = quad_sum(corner_quad(x[b], wa0, wb0, x[TB + b], wa1, wb1));
             if (j == (b & 3)) rs[b] = part;
         }
     }

@@ -12,7 +12,10 @@
 // taken tile by tile over the A.nb_total bands of the corner-packed BC cell (each star's BC bracket is found once and kept).
 // STDP: the model's priors are the reference's default families (Chabrier mass, flat-in-age, local-disk [Fe/H],
 // power-law distance, flat AV - the host checks the records): the families are compile-time constants here.
-template <int KIND, int NS, int NB, bool PACKED, bool ASTERO = false, bool MASKED = false, bool TILED = false, bool STDP = false>
+// LANE (with PACKED; bit 0: model table and asteroseismic pair, bit 1: BC table): every lane gathers its own sample
+// from the corner-packed table (gather_lane.h) - the latency form of a lone workgroup.
+template <int KIND, int NS, int NB, bool PACKED, bool ASTERO = false, bool MASKED = false, bool TILED = false, bool STDP = false,
+          int LANE = 0>
 __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* lds, const CoopLds& L, bool active,
                                               const DevModel& M, const double* __restrict__ p, bool want_parts,
                                               double& lnp_out, double& lnl_out)
@@ -40,11 +43,15 @@ __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* l
         if (PACKED) {
             uint32_t cell = (uint32_t)((int64_t)i0 * A.s0 + (int64_t)i1 * A.s1 + i2);
             ISO_STAMP(2, cell);
-            coop_star(A, L, ok, cell, w, star[s]);
+            if constexpr (LANE & 1) lane_star(A, ok, cell, w, star[s]);
+            else coop_star(A, L, ok, cell, w, star[s]);
             ISO_STAMP(3, star[s][0]);
             // asteroseismic pair of the primary (reference starmodel.py:1603-1612); a separate instantiation,
             // because even a never-taken branch here costs the common kernel registers (measured: +29 %)
-            if (ASTERO && s == 0) coop_pair(A.astq, L, ok && M.has_numax, cell, w, astero);
+            if (ASTERO && s == 0) {
+                if constexpr (LANE & 1) lane_pair(A.astq, ok && M.has_numax, cell, w, astero);
+                else coop_pair(A.astq, L, ok && M.has_numax, cell, w, astero);
+            }
         } else if (ok) {
             gather_star(A, i0, i1, i2, w, star[s]);
         } else {
@@ -165,7 +172,8 @@ __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* l
             if (PACKED) {
                 uint32_t cell = (uint32_t)((int64_t)j0 * A.bs0 + (int64_t)j1 * A.bs1 + (int64_t)j2 * A.bs2 + j3);
                 ISO_STAMP(5, cell);
-                coop_bc<NB>(A, L, ok, cell, w4v, bc);
+                if constexpr (LANE & 2) lane_bc<NB>(A, ok, cell, w4v, bc);
+                else coop_bc<NB>(A, L, ok, cell, w4v, bc);
                 ISO_STAMP(6, bc[0]);
             } else if (ok) {
                 gather_bc<NB>(A, j0, j1, j2, j3, w4v, bc);

@@ -74,7 +74,8 @@ __device__ __forceinline__ void stretch_move(const FastArgs& A, const StretchArg
     typedef const __attribute__((address_space(4))) DevModel* const_model_ptr;
     const DevModel& M = UNI ? *(const DevModel*)((const_model_ptr)(uintptr_t)A.m) : A.m[S.multi ? star : 0];
     double lnp_unused, lnl_unused;
-    const double lnew = lnpost_wave<KIND, NS, NB, true, ASTERO, true, false, STDP>(A, lds, L, active, M, y, false, lnp_unused, lnl_unused);
+    // UNI: a single star's fit (or a few ensembles of it) - one workgroup per CU at most, nothing to overlap with
+    const double lnew = lnpost_wave<KIND, NS, NB, true, ASTERO, true, false, STDP, UNI ? ISO_UNI_LANE : 0>(A, lds, L, active, M, y, false, lnp_unused, lnl_unused);
     const double lnq = (NP - 1) * fast_log(z) + lnew - lold;
     const bool acc = active && isfinite(lnew) && (fast_log(u2) < lnq);
     if (acc) {

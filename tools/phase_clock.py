@@ -39,7 +39,8 @@ def main():
         rc = lib.iso_debug_phase_stamps(st)
         assert rc == 0, rc
         t = np.array(st[:10], dtype=np.int64)
-        out.append({"steps": steps, "ticks_from_entry": (t - t[0]).tolist(), "phase_ticks": dict(zip(NAMES[1:], np.diff(t).tolist()))})
+        inner = np.array(st[10:15], dtype=np.int64)
+        out.append({"steps": steps, "coop_star_from_phase_start(request published, loads issued + weights, first piece in, last piece in, responses written)": (inner - t[2]).tolist(), "ticks_from_entry": (t - t[0]).tolist(), "phase_ticks": dict(zip(NAMES[1:], np.diff(t).tolist()))})
     print(json.dumps(out, indent=1))
 
 
