@@ -43,6 +43,18 @@ __device__ __forceinline__ double quad_sum(double x)
     return x;
 }
 
+// Cell numbers of the corner-packed tables are 32-bit (the host packs a table only if its cells fit): products of the
+// low words, the same number the 64-bit expression gave after truncation - without 64-bit multiplies and with one
+// scalar register per stride instead of two.
+__device__ __forceinline__ uint32_t cell3(const FastArgs& A, int i0, int i1, int i2)
+{
+    return (uint32_t)i0 * (uint32_t)A.s0 + (uint32_t)i1 * (uint32_t)A.s1 + (uint32_t)i2;
+}
+__device__ __forceinline__ uint32_t cell4(const FastArgs& A, int j0, int j1, int j2, int j3)
+{
+    return (uint32_t)j0 * (uint32_t)A.bs0 + (uint32_t)j1 * (uint32_t)A.bs1 + (uint32_t)j2 * (uint32_t)A.bs2 + (uint32_t)j3;
+}
+
 struct CoopLds {
     double* req;    // this wave's 64 request slots
     double* rsp;    // this wave's 64 response slots (same storage)

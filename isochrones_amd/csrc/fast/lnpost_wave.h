@@ -41,7 +41,7 @@ __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* l
         int i2 = 0;
         if (ok) eep_bracket(A, lds, eep, i2, w.t2);
         if (PACKED) {
-            uint32_t cell = (uint32_t)((int64_t)i0 * A.s0 + (int64_t)i1 * A.s1 + i2);
+            uint32_t cell = cell3(A, i0, i1, i2);
             ISO_STAMP(2, cell);
             if constexpr (LANE & 1) lane_star(A, ok, cell, w, star[s]);
             else coop_star(A, L, ok, cell, w, star[s]);
@@ -122,7 +122,7 @@ __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* l
             if (okb[s]) {
                 lds_bracket4(lds, A.b0, A.b1, A.b2, A.b3, T, g, f, AV, j0, j1, j2, j3, wb[s].t0, wb[s].t1, wb[s].t2, wb[s].t3);
             }
-            cellb[s] = (uint32_t)((int64_t)j0 * A.bs0 + (int64_t)j1 * A.bs1 + (int64_t)j2 * A.bs2 + j3);
+            cellb[s] = cell4(A, j0, j1, j2, j3);
         }
         for (int b0 = 0; b0 < nbt; b0 += NB) {                   // wave-uniform
             double tot[NB], rel[NS > 1 ? NB : 1];
@@ -170,7 +170,7 @@ __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* l
                 lds_bracket4(lds, A.b0, A.b1, A.b2, A.b3, T, g, f, AV, j0, j1, j2, j3, w4v.t0, w4v.t1, w4v.t2, w4v.t3);
             }
             if (PACKED) {
-                uint32_t cell = (uint32_t)((int64_t)j0 * A.bs0 + (int64_t)j1 * A.bs1 + (int64_t)j2 * A.bs2 + j3);
+                uint32_t cell = cell4(A, j0, j1, j2, j3);
                 ISO_STAMP(5, cell);
                 if constexpr (LANE & 2) lane_bc<NB>(A, ok, cell, w4v, bc);
                 else coop_bc<NB>(A, L, ok, cell, w4v, bc);

@@ -49,8 +49,12 @@ __device__ __forceinline__ void stretch_move(const FastArgs& A, const StretchArg
     ISO_STAMP(0, lr);
     const int64_t row = star * S.W + lr;
     uint32_t rnd[4];
-    philox4x32_10((uint32_t)(2u * step + (uint32_t)half), (uint32_t)row, (uint32_t)((uint64_t)row >> 32), 0x51u,
-                  (uint32_t)S.seed, (uint32_t)(S.seed >> 32), rnd);
+    // the key passes through an empty asm statement: otherwise the ten round keys are computed once, kept in scalar
+    // registers the kernel does not have, and come back through v_readlane in every round (20 vector-slot instructions
+    // per move instead of 20 scalar additions)
+    uint32_t key0 = (uint32_t)S.seed, key1 = (uint32_t)(S.seed >> 32);
+    asm volatile("" : "+s"(key0), "+s"(key1));
+    philox4x32_10((uint32_t)(2u * step + (uint32_t)half), (uint32_t)row, (uint32_t)((uint64_t)row >> 32), 0x51u, key0, key1, rnd);
     const int j = (int)(((uint64_t)rnd[0] * (uint64_t)h) >> 32);          // uniform in [0, h)
     const int lp = (half ? 0 : h) + j;
     const double u1 = ((double)rnd[1] + (double)(rnd[2] & 0xFFFFu) * (1.0 / 65536.0)) * (1.0 / 4294967296.0);

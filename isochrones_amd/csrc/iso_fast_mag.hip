@@ -34,7 +34,7 @@ __global__ __launch_bounds__(BLOCK) void k_interp_mag_fast(const FastArgs A, con
         eep_bracket(A, lds, eep, i2, w.t2);
     }
     double star[6];
-    coop_star(A, L, ok3, (uint32_t)((int64_t)i0 * A.s0 + (int64_t)i1 * A.s1 + i2), w, star);
+    coop_star(A, L, ok3, cell3(A, i0, i1, i2), w, star);
     const double T = star[0], g = star[1], f = star[2];
     if (active) {
         if (O.Teff) O.Teff[i] = T;
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(BLOCK) void k_interp_mag_fast(const FastArgs A, con
     w4v.t0 = w4v.t1 = w4v.t2 = w4v.t3 = 0.0;
     if (ok4) lds_bracket4(lds, A.b0, A.b1, A.b2, A.b3, T, g, f, AV, j0, j1, j2, j3, w4v.t0, w4v.t1, w4v.t2, w4v.t3);
     double bc[NB];
-    coop_bc<NB>(A, L, ok4, (uint32_t)((int64_t)j0 * A.bs0 + (int64_t)j1 * A.bs1 + (int64_t)j2 * A.bs2 + j3), w4v, bc);
+    coop_bc<NB>(A, L, ok4, cell4(A, j0, j1, j2, j3), w4v, bc);
     if (active) {
         const double dm = 5.0 * log10(dist / 10.0);
         double* __restrict__ o = O.mags + i * NB;

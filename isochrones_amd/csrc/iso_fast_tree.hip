@@ -109,7 +109,7 @@ __global__ __launch_bounds__(tree_block<NL>()) void k_lnpost_tree_fast(const Fas
             eep_bracket(A, lds, eep, i2, w.t2);
         }
         double v[6];
-        coop_star(A, L, ok3, (uint32_t)((int64_t)i0 * A.s0 + (int64_t)i1 * A.s1 + i2), w, v);
+        coop_star(A, L, ok3, cell3(A, i0, i1, i2), w, v);
 #pragma unroll
         for (int q = 0; q < 6; ++q) S.set_star(l, q, v[q]);
         const double Tf = v[0], g = v[1], f = v[2];
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(tree_block<NL>()) void k_lnpost_tree_fast(const Fas
         w4v.t0 = w4v.t1 = w4v.t2 = w4v.t3 = 0.0;
         if (ok4) lds_bracket4(lds, A.b0, A.b1, A.b2, A.b3, Tf, g, f, AV, j0, j1, j2, j3, w4v.t0, w4v.t1, w4v.t2, w4v.t3);
         double bc[NB];
-        coop_bc<NB>(A, L, ok4, (uint32_t)((int64_t)j0 * A.bs0 + (int64_t)j1 * A.bs1 + (int64_t)j2 * A.bs2 + j3), w4v, bc);
+        coop_bc<NB>(A, L, ok4, cell4(A, j0, j1, j2, j3), w4v, bc);
         const double dm = 5 * log10(dist / 10.0);
 #pragma unroll
         for (int b = 0; b < NB; ++b) S.set_flux(l, b, exp10(-0.4 * (v[3] + dm - bc[b])));

@@ -243,6 +243,7 @@ hipError_t pack_corners(const double* src, int ncol, int keep, int ndim, const i
         P.n[d] = n[d];
         P.ncells *= n[d];
     }
+    if (P.ncells >= (int64_t(1) << 32)) return hipErrorInvalidValue;     // the fused kernels number cells in 32 bits
     const size_t bytes = (size_t)P.ncells * (size_t)(1 << ndim) * keep * sizeof(double);
     hipError_t e = hipMalloc(out, bytes);
     if (e != hipSuccess) return e;
