@@ -5,7 +5,9 @@
 // ---- brackets -----------------------------------------------------------------------------
 __device__ __forceinline__ bool lds_oob(const double* lds, const FastAxis ax, double x)
 {
-    return (x < lds[ax.off]) || (x > lds[ax.off + ax.n - 1]);
+    // (| and & instead of || and && in the bounds tests of this file and of lnpost_wave.h: a short-circuit makes every
+    // operand a branch of its own, and the bound reads then go to LDS one after the other instead of together)
+    return bool((x < lds[ax.off]) | (x > lds[ax.off + ax.n - 1]));
 }
 
 // Where the bisection of an axis starts (fast/axis_lut.h): a byte table indexed by the exponent and leading mantissa
@@ -102,7 +104,7 @@ __device__ __forceinline__ void lds_bracket4(const double* lds, const FastAxis a
 // argument), so the uniform case pays one scalar compare for it.
 __device__ __forceinline__ bool eep_oob(const FastArgs& A, double x)
 {
-    return (x < A.e_a0) || (x > A.e_last);
+    return bool((x < A.e_a0) | (x > A.e_last));
 }
 
 __device__ __forceinline__ void eep_bracket(const FastArgs& A, const double* lds, double x, int& i, double& t)

@@ -25,7 +25,7 @@ __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* l
     // ---- model table: axes 0/1 are shared by all components of an isochrone system ----
     const double x0 = (KIND == ISO_KIND_TRACK) ? p[2] : q1;        // feh | age
     const double x1 = (KIND == ISO_KIND_TRACK) ? p[0] : feh_par;   // mass | feh
-    const bool ok01 = active && !(x0 != x0) && !(x1 != x1) && !lds_oob(lds, A.m0, x0) && !lds_oob(lds, A.m1, x1);
+    const bool ok01 = bool(active & !(x0 != x0) & !(x1 != x1) & !lds_oob(lds, A.m0, x0) & !lds_oob(lds, A.m1, x1));
     int i0 = 0, i1 = 0;
     W3 w;
     w.t0 = w.t1 = w.t2 = 0.0;
@@ -37,7 +37,7 @@ __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* l
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         const double eep = (KIND == ISO_KIND_TRACK) ? p[1] : p[s];
-        const bool ok = ok01 && !(eep != eep) && !eep_oob(A, eep);
+        const bool ok = bool(ok01 & !(eep != eep) & !eep_oob(A, eep));
         int i2 = 0;
         if (ok) eep_bracket(A, lds, eep, i2, w.t2);
         if (PACKED) {
@@ -108,15 +108,15 @@ __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* l
     if constexpr (TILED) {
         static_assert(PACKED && NB > 0, "band tiles run on the corner-packed tables");
         const int nbt = A.nb_total;
-        const bool okA = go && !(AV != AV) && !lds_oob(lds, A.b3, AV);
+        const bool okA = bool(go & !(AV != AV) & !lds_oob(lds, A.b3, AV));
         bool okb[NS];
         uint32_t cellb[NS];
         W4 wb[NS];
     #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const double T = star[s][0], g = star[s][1], f = star[s][2];
-            okb[s] = okA && !(T != T) && !(g != g) && !(f != f) && !lds_oob(lds, A.b0, T) && !lds_oob(lds, A.b1, g) &&
-                     !lds_oob(lds, A.b2, f);
+            okb[s] = bool(okA & !(T != T) & !(g != g) & !(f != f) & !lds_oob(lds, A.b0, T) & !lds_oob(lds, A.b1, g) &
+                          !lds_oob(lds, A.b2, f));
             int j0 = 0, j1 = 0, j2 = 0, j3 = 0;
             wb[s].t0 = wb[s].t1 = wb[s].t2 = wb[s].t3 = 0.0;
             if (okb[s]) {
@@ -156,12 +156,12 @@ __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* l
         }
     } else if constexpr (NB > 0) {   // NB = 0: spectroscopy / parallax only, the BC table is never touched
         double tot[NB], rel[NS > 1 ? NB : 1];
-        const bool okA = go && !(AV != AV) && !lds_oob(lds, A.b3, AV);
+        const bool okA = bool(go & !(AV != AV) & !lds_oob(lds, A.b3, AV));
     #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const double T = star[s][0], g = star[s][1], f = star[s][2];
-            const bool ok = okA && !(T != T) && !(g != g) && !(f != f) && !lds_oob(lds, A.b0, T) &&
-                            !lds_oob(lds, A.b1, g) && !lds_oob(lds, A.b2, f);
+            const bool ok = bool(okA & !(T != T) & !(g != g) & !(f != f) & !lds_oob(lds, A.b0, T) &
+                                 !lds_oob(lds, A.b1, g) & !lds_oob(lds, A.b2, f));
             double bc[NB];
             int j0 = 0, j1 = 0, j2 = 0, j3 = 0;
             W4 w4v;

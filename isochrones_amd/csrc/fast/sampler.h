@@ -280,6 +280,17 @@ __global__ __launch_bounds__(BLOCK, DENSE ? (persist_slim(DENSE, NB, NS) ? 4 : 3
         double* cp = S.chain_pos ? S.chain_pos + (int64_t)it * rows_total * NP + (r0 + gs * W) * S.chain_rs : nullptr;
         double* cl = S.chain_lnp ? S.chain_lnp + (int64_t)it * rows_total + r0 + gs * W : nullptr;
         for (int half = 0; half < 2; ++half) {
+#if ISO_KERNARG_REREAD
+            // both argument blocks are read again from the kernel-argument segment in every half-step (scalar loads through
+            // a pointer the optimiser cannot see through): what a move needs of them then does not have to survive the
+            // evaluation in scalar registers the kernel does not have (they were spilled to vector lanes and came back
+            // through v_readlane, a vector-slot instruction each)
+            typedef const __attribute__((address_space(4))) char* kernarg_ptr;
+            kernarg_ptr kp = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(kp));
+            const FastArgs& A = *(const FastArgs*)(const __attribute__((address_space(4))) FastArgs*)kp;
+            const StretchArgs& S = *(const StretchArgs*)(const __attribute__((address_space(4))) StretchArgs*)(kp + ((sizeof(FastArgs) + 7) & ~size_t(7)));
+#endif
             for (int k0 = 0; k0 < h; k0 += per) {
                 const int k = k0 + kk;
                 const bool active = mine && k < h;

@@ -83,6 +83,11 @@ static __device__ unsigned long long g_phase_stamps[16];
 // gathers of the single-model sampler (lnpost_wave's LANE): measured on cfg 4 (phase clocks, profiles/r03) the BC cell
 // (8 x 16 B per band) comes in sooner lane-per-sample (1 750 -> 700-1 000 cycles), the model cell (24 x 16 B, three
 // lines touched eight times each by every lane) does not (3 700 -> 5 500-6 500): cooperative model gather, lane BC gather
+// persistent sampler kernels: argument blocks re-read from the kernel-argument segment in every half-step (sampler.h);
+// -DISO_KERNARG_REREAD=0 builds the A/B counterpart
+#ifndef ISO_KERNARG_REREAD
+#define ISO_KERNARG_REREAD 1
+#endif
 #ifndef ISO_UNI_LANE
 #define ISO_UNI_LANE 2
 #endif

@@ -24,8 +24,8 @@ __global__ __launch_bounds__(BLOCK) void k_interp_mag_fast(const FastArgs A, con
     const double x0 = (KIND == ISO_KIND_TRACK) ? p2 : p1;
     const double x1 = (KIND == ISO_KIND_TRACK) ? p0 : p2;
     const double eep = (KIND == ISO_KIND_TRACK) ? p1 : p0;
-    const bool ok3 = active && !(x0 != x0) && !(x1 != x1) && !(eep != eep) && !lds_oob(lds, A.m0, x0) &&
-                     !lds_oob(lds, A.m1, x1) && !eep_oob(A, eep);
+    const bool ok3 = bool(active & !(x0 != x0) & !(x1 != x1) & !(eep != eep) & !lds_oob(lds, A.m0, x0) &
+                     !lds_oob(lds, A.m1, x1) & !eep_oob(A, eep));
     int i0 = 0, i1 = 0, i2 = 0;
     W3 w;
     w.t0 = w.t1 = w.t2 = 0.0;
@@ -42,8 +42,8 @@ __global__ __launch_bounds__(BLOCK) void k_interp_mag_fast(const FastArgs A, con
         if (O.feh) O.feh[i] = f;
     }
     if (!O.mags) return;                                    // wave-uniform
-    const bool ok4 = ok3 && !(AV != AV) && !(T != T) && !(g != g) && !(f != f) && !lds_oob(lds, A.b0, T) &&
-                     !lds_oob(lds, A.b1, g) && !lds_oob(lds, A.b2, f) && !lds_oob(lds, A.b3, AV);
+    const bool ok4 = bool(ok3 & !(AV != AV) & !(T != T) & !(g != g) & !(f != f) & !lds_oob(lds, A.b0, T) &
+                     !lds_oob(lds, A.b1, g) & !lds_oob(lds, A.b2, f) & !lds_oob(lds, A.b3, AV));
     int j0 = 0, j1 = 0, j2 = 0, j3 = 0;
     W4 w4v;
     w4v.t0 = w4v.t1 = w4v.t2 = w4v.t3 = 0.0;

@@ -99,8 +99,8 @@ __global__ __launch_bounds__(tree_block<NL>()) void k_lnpost_tree_fast(const Fas
         const int base = T.sys_base[s], N = T.n_stars[s];
         const double eep = par(base + T.leaf_slot[l]), age = par(base + N), feh = par(base + N + 1);
         const double dist = par(base + N + 2), AV = par(base + N + 3);
-        const bool ok3 = active && !(age != age) && !(feh != feh) && !(eep != eep) && !lds_oob(lds, A.m0, age) &&
-                         !lds_oob(lds, A.m1, feh) && !eep_oob(A, eep);
+        const bool ok3 = bool(active & !(age != age) & !(feh != feh) & !(eep != eep) & !lds_oob(lds, A.m0, age) &
+                         !lds_oob(lds, A.m1, feh) & !eep_oob(A, eep));
         int i0 = 0, i1 = 0, i2 = 0;
         W3 w;
         w.t0 = w.t1 = w.t2 = 0.0;
@@ -113,8 +113,8 @@ __global__ __launch_bounds__(tree_block<NL>()) void k_lnpost_tree_fast(const Fas
 #pragma unroll
         for (int q = 0; q < 6; ++q) S.set_star(l, q, v[q]);
         const double Tf = v[0], g = v[1], f = v[2];
-        const bool ok4 = ok3 && !(AV != AV) && !(Tf != Tf) && !(g != g) && !(f != f) && !lds_oob(lds, A.b0, Tf) &&
-                         !lds_oob(lds, A.b1, g) && !lds_oob(lds, A.b2, f) && !lds_oob(lds, A.b3, AV);
+        const bool ok4 = bool(ok3 & !(AV != AV) & !(Tf != Tf) & !(g != g) & !(f != f) & !lds_oob(lds, A.b0, Tf) &
+                         !lds_oob(lds, A.b1, g) & !lds_oob(lds, A.b2, f) & !lds_oob(lds, A.b3, AV));
         int j0 = 0, j1 = 0, j2 = 0, j3 = 0;
         W4 w4v;
         w4v.t0 = w4v.t1 = w4v.t2 = w4v.t3 = 0.0;
