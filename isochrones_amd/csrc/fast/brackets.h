@@ -15,12 +15,14 @@ __device__ __forceinline__ bool lds_oob(const double* lds, const FastAxis ax, do
 // #{a_j <= x} - 1 the reference's searchsorted (interp.py:10-35) arrives at, in 1-3 levels instead of 4-8.
 __device__ __forceinline__ int lut_start(const double* lds, const FastAxis ax, double x)
 {
-    // no clamp: every caller has checked a_0 <= x <= a_last (lds_oob) and the bucket function is monotone, so the
-    // byte read is one of the table's
-    const uint8_t* tab = reinterpret_cast<const uint8_t*>(lds) + ax.lutb;
-    return (int)tab[__double2hiint(x + __hiloint2double(ax.chi, 0)) >> (ax.shw & 31)];
+    // The bucket number is clamped to the table (one v_med3): the brackets are computed for every lane, in range or not
+    // (NaN, outside the axis - such a lane's result is never used), so that the table read does not wait behind the
+    // bounds test.  For a_0 <= x <= a_last the clamp changes nothing (the bucket function is monotone).
+    const uint8_t* tab = reinterpret_cast<const uint8_t*>(lds) + ax.lut;
+    const int b = (__double2hiint(x + __hiloint2double(ax.chi, 0)) >> (ax.shw & 31)) - ax.b0;
+    return (int)tab[max(0, min(b, (int)((unsigned)ax.shw >> 17)))];
 }
-__device__ __forceinline__ int lut_win(const FastAxis ax) { return ax.shw >> 8; }
+__device__ __forceinline__ int lut_win(const FastAxis ax) { return (ax.shw >> 5) & 4095; }
 
 __device__ __forceinline__ void lds_bracket(const double* lds, const FastAxis ax, double x, int& i, double& t)
 {

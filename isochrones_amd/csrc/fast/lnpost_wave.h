@@ -26,20 +26,20 @@ __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* l
     const double x0 = (KIND == ISO_KIND_TRACK) ? p[2] : q1;        // feh | age
     const double x1 = (KIND == ISO_KIND_TRACK) ? p[0] : feh_par;   // mass | feh
     const bool ok01 = bool(active & !(x0 != x0) & !(x1 != x1) & !lds_oob(lds, A.m0, x0) & !lds_oob(lds, A.m1, x1));
-    int i0 = 0, i1 = 0;
+    // brackets are computed for every lane, usable or not (lut_start clamps; an unusable lane's numbers are never used): a
+    // branch here would make the table reads wait for the bounds test
+    int i0, i1;
     W3 w;
-    w.t0 = w.t1 = w.t2 = 0.0;
-    if (ok01) {
-        lds_bracket2(lds, A.m0, A.m1, x0, x1, i0, i1, w.t0, w.t1);
-    }
+    w.t2 = 0.0;
+    lds_bracket2(lds, A.m0, A.m1, x0, x1, i0, i1, w.t0, w.t1);
     double star[NS][6];
     double astero[2] = {0.0, 0.0};
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         const double eep = (KIND == ISO_KIND_TRACK) ? p[1] : p[s];
         const bool ok = bool(ok01 & !(eep != eep) & !eep_oob(A, eep));
-        int i2 = 0;
-        if (ok) eep_bracket(A, lds, eep, i2, w.t2);
+        int i2;
+        eep_bracket(A, lds, eep, i2, w.t2);
         if (PACKED) {
             uint32_t cell = cell3(A, i0, i1, i2);
             ISO_STAMP(2, cell);
@@ -117,11 +117,8 @@ __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* l
             const double T = star[s][0], g = star[s][1], f = star[s][2];
             okb[s] = bool(okA & !(T != T) & !(g != g) & !(f != f) & !lds_oob(lds, A.b0, T) & !lds_oob(lds, A.b1, g) &
                           !lds_oob(lds, A.b2, f));
-            int j0 = 0, j1 = 0, j2 = 0, j3 = 0;
-            wb[s].t0 = wb[s].t1 = wb[s].t2 = wb[s].t3 = 0.0;
-            if (okb[s]) {
-                lds_bracket4(lds, A.b0, A.b1, A.b2, A.b3, T, g, f, AV, j0, j1, j2, j3, wb[s].t0, wb[s].t1, wb[s].t2, wb[s].t3);
-            }
+            int j0, j1, j2, j3;
+            lds_bracket4(lds, A.b0, A.b1, A.b2, A.b3, T, g, f, AV, j0, j1, j2, j3, wb[s].t0, wb[s].t1, wb[s].t2, wb[s].t3);
             cellb[s] = cell4(A, j0, j1, j2, j3);
         }
         for (int b0 = 0; b0 < nbt; b0 += NB) {                   // wave-uniform
@@ -163,12 +160,9 @@ __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* l
             const bool ok = bool(okA & !(T != T) & !(g != g) & !(f != f) & !lds_oob(lds, A.b0, T) &
                                  !lds_oob(lds, A.b1, g) & !lds_oob(lds, A.b2, f));
             double bc[NB];
-            int j0 = 0, j1 = 0, j2 = 0, j3 = 0;
+            int j0, j1, j2, j3;
             W4 w4v;
-            w4v.t0 = w4v.t1 = w4v.t2 = w4v.t3 = 0.0;
-            if (ok) {
-                lds_bracket4(lds, A.b0, A.b1, A.b2, A.b3, T, g, f, AV, j0, j1, j2, j3, w4v.t0, w4v.t1, w4v.t2, w4v.t3);
-            }
+            lds_bracket4(lds, A.b0, A.b1, A.b2, A.b3, T, g, f, AV, j0, j1, j2, j3, w4v.t0, w4v.t1, w4v.t2, w4v.t3);
             if (PACKED) {
                 uint32_t cell = cell4(A, j0, j1, j2, j3);
                 ISO_STAMP(5, cell);

@@ -785,9 +785,10 @@ hipError_t build_fast(const iso_ic* ic, int nb, const double* d_bc_hot, double**
         for (size_t a = 0; a < planned.size(); ++a) {
             FastAxis& ax = a < 6 ? fa[a] : coarse;
             const AxisLutChoice& ch = plan[a];
-            ax.lutb = (int)(blob.size() * sizeof(double) + bytes.size()) - ch.b0;
-            ax.shw = ch.sh | (ch.win << 8);
+            ax.lut = (int)(blob.size() * sizeof(double) + bytes.size());
+            ax.shw = ch.sh | (ch.win << 5) | ((ch.nbk - 1) << 17);          // sh < 32, win <= n <= 2048, nbk <= 1024
             ax.chi = lut_hi32(ch.c);
+            ax.b0 = ch.b0;
             bytes.resize(bytes.size() + (size_t)ch.nbk);
             axis_lut_fill(*planned[a], ch, bytes.data() + bytes.size() - (size_t)ch.nbk);
         }
@@ -1031,8 +1032,7 @@ int iso_axis_bracket_host(const double* const* axes, const int32_t* n_nodes, int
     const int nn = (int)v.size();
     for (int64_t k = 0; k < n; ++k) {                 // the statements of lut_start() + lds_bracket() (fast/brackets.h)
         const int b = lut_bucket(x[k], ch.c, ch.sh, ch.b0);
-        if (b < 0 || b >= ch.nbk) return fail(ISO_ERR_INVALID, "iso_axis_bracket_host: bucket outside the table (x outside the axis?)");
-        int base = tab[(size_t)b], len = ch.win;
+        int base = tab[(size_t)std::max(0, std::min(b, ch.nbk - 1))], len = ch.win;
         while (len > 1) {
             const int half = len >> 1;
             base = (v[(size_t)(base + half)] <= x[k]) ? base + half : base;

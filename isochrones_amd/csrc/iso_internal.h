@@ -76,12 +76,14 @@ struct DevModel {
 struct FastAxis {
     int off;   // LDS offset (doubles): values at [off, off+n), reciprocal spacings at [off+n, off+2n-1)
     int n;
-    // bucket table (fast/axis_lut.h): the byte at blob byte offset lutb + (hi32(x + c) >> sh) is a node at or below
-    // every x of that bucket, and the bracket lies within the `win` nodes from there (one bucket, win = n: the plain
-    // bisection).  c is a double whose low word is zero (chi = its high word); five scalar registers per axis.
-    int lutb;  // byte offset of the table inside the staged blob, minus the bucket number of the first node
-    int shw;   // sh | win << 8
+    // bucket table (fast/axis_lut.h): the byte at blob byte offset lut + clamp((hi32(x + c) >> sh) - b0, 0, nbk - 1) is a
+    // node at or below every x of that bucket, and the bracket lies within the `win` nodes from there (one bucket,
+    // win = n: the plain bisection).  c is a double whose low word is zero (chi = its high word); six scalar registers
+    // per axis.
+    int lut;   // byte offset of the table inside the staged blob
+    int shw;   // sh | win << 5 | (nbk - 1) << 17   (sh < 32, win < 4096, nbk <= 32768)
     int chi;
+    int b0;
 };
 
 struct FastArgs {
