@@ -64,8 +64,15 @@ struct CoopLds {
 
 // Model table: every lane may own one request (need, cell, w); returns the 6 interpolated columns
 // of the lane's own sample in v (NaN if !need).  Must be called by all 64 lanes of the wave.
+// `between` (optional) runs once, after the loads of the first two rounds have been issued and before their data is
+// used: work that does not depend on the gather, for a kernel that has nothing else to hide the wait with (the
+// single-model sampler; the first half is then never skipped).
+struct NoWorkBetween {
+    __device__ __forceinline__ void operator()() const {}
+};
+template <bool RUN_BETWEEN = false, class Between = NoWorkBetween>
 __device__ __forceinline__ void coop_star(const FastArgs& A, const CoopLds& L, bool need, uint32_t cell, const W3& w,
-                                          double* __restrict__ v)
+                                          double* __restrict__ v, Between&& between = Between())
 {
     double* mine = L.req + L.lane * L.stride;
     mine[0] = __hiloint2double(need ? 1 : 0, (int)cell);
@@ -79,7 +86,7 @@ __device__ __forceinline__ void coop_star(const FastArgs& A, const CoopLds& L, b
     // two batches of two iterations: the 12 loads of a batch are in flight before the first use
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
-        if (((m >> (32 * half)) & 0xFFFFFFFFull) == 0) continue;          // wave-uniform
+        if ((!RUN_BETWEEN || half != 0) && ((m >> (32 * half)) & 0xFFFFFFFFull) == 0) continue;          // wave-uniform
         double2 u[2][6];
         double wlo[2], whi[2];
 #pragma unroll
@@ -97,6 +104,7 @@ __device__ __forceinline__ void coop_star(const FastArgs& A, const CoopLds& L, b
             wlo[k] = nd ? (1 - t0) * g : 0.0;     // corners 0..3 (axis-0 offset 0)
             whi[k] = nd ? t0 * g : 0.0;           // corners 4..7
         }
+        if (RUN_BETWEEN && half == 0) between();
         if (half == 0) { ISO_STAMP(11, whi[1]); ISO_STAMP(12, u[0][0].x); ISO_STAMP(13, u[1][5].y); }
 #pragma unroll
         for (int k = 0; k < 2; ++k) {

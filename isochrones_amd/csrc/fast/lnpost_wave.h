@@ -14,6 +14,8 @@
 // power-law distance, flat AV - the host checks the records): the families are compile-time constants here.
 // LANE (with PACKED; bit 0: model table and asteroseismic pair, bit 1: BC table): every lane gathers its own sample
 // from the corner-packed table (gather_lane.h) - the latency form of a lone workgroup.
+// bit 2 of LANE: the priors that do not depend on the model table are evaluated between the issue of the primary's
+// model gather and the use of its data (coop_star's `between`).
 template <int KIND, int NS, int NB, bool PACKED, bool ASTERO = false, bool MASKED = false, bool TILED = false, bool STDP = false,
           int LANE = 0>
 __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* lds, const CoopLds& L, bool active,
@@ -32,6 +34,20 @@ __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* l
     W3 w;
     w.t2 = 0.0;
     lds_bracket2(lds, A.m0, A.m1, x0, x1, i0, i1, w.t0, w.t1);
+    // the prior terms that need nothing from the tables: evaluated either right after the gathers (as written in the
+    // reference, starmodel.py:1616-1635) or, where a lone workgroup would only wait, while the primary's cell is on its way;
+    // added up further down in the reference's order either way, so the sum is the same number
+    constexpr int K_MASS = STDP ? ISO_PRIOR_CHABRIER : -1, K_AGE = STDP ? ISO_PRIOR_FLATLOG : -1, K_FEH = STDP ? ISO_PRIOR_FEH : -1,
+                  K_DIST = STDP ? ISO_PRIOR_POWERLAW : -1, K_AV = STDP ? ISO_PRIOR_FLAT : -1;
+    constexpr bool OVERLAP = PACKED && (LANE & 4) != 0 && (LANE & 1) == 0;
+    double ld = 0.0, t_first = 0.0, t_feh = 0.0, t_dist = 0.0, t_av = 0.0;
+    auto table_free_priors = [&]() {
+        ld = fast_log(dist);
+        t_first = (KIND == ISO_KIND_TRACK) ? ln_pdf<false, K_MASS>(M.prior_mass, p[0], 0.0) : ln_pdf<false, K_AGE>(M.prior_age, q1, 0.0);
+        t_feh = ln_pdf<false, K_FEH>(M.prior_feh, feh_par, 0.0);
+        t_dist = ln_pdf<true, K_DIST>(M.prior_distance, dist, ld);
+        t_av = ln_pdf<false, K_AV>(M.prior_AV, AV, 0.0);
+    };
     double star[NS][6];
     double astero[2] = {0.0, 0.0};
 #pragma unroll
@@ -44,7 +60,10 @@ __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* l
             uint32_t cell = cell3(A, i0, i1, i2);
             ISO_STAMP(2, cell);
             if constexpr (LANE & 1) lane_star(A, ok, cell, w, star[s]);
-            else coop_star(A, L, ok, cell, w, star[s]);
+            else if constexpr (OVERLAP) {
+                if (s == 0) coop_star<true>(A, L, ok, cell, w, star[s], table_free_priors);
+                else coop_star(A, L, ok, cell, w, star[s]);
+            } else coop_star(A, L, ok, cell, w, star[s]);
             ISO_STAMP(3, star[s][0]);
             // asteroseismic pair of the primary (reference starmodel.py:1603-1612); a separate instantiation,
             // because even a never-taken branch here costs the common kernel registers (measured: +29 %)
@@ -61,24 +80,22 @@ __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* l
     }
 
     // ---- lnprior ----
-    const double ld = fast_log(dist);
+    if constexpr (!OVERLAP) table_free_priors();
     double lnp = 0.0;
     bool rejected = false;
     if (NS == 2) rejected = p[1] > p[0];
     if (NS == 3) rejected = !(p[0] > p[1]) && (p[1] > p[2]);
-    constexpr int K_MASS = STDP ? ISO_PRIOR_CHABRIER : -1, K_AGE = STDP ? ISO_PRIOR_FLATLOG : -1, K_FEH = STDP ? ISO_PRIOR_FEH : -1,
-                  K_DIST = STDP ? ISO_PRIOR_POWERLAW : -1, K_AV = STDP ? ISO_PRIOR_FLAT : -1;
-    if (KIND == ISO_KIND_TRACK) lnp += ln_pdf<false, K_MASS>(M.prior_mass, p[0], 0.0);
+    if (KIND == ISO_KIND_TRACK) lnp += t_first;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         const double eep = (KIND == ISO_KIND_TRACK) ? p[1] : p[s];
         lnp += (KIND == ISO_KIND_TRACK) ? eep_term<K_AGE>(M, M.prior_age, eep, star[s][4], star[s][5])
                                         : eep_term<K_MASS>(M, M.prior_mass, eep, star[s][4], star[s][5]);
     }
-    if (KIND == ISO_KIND_ISO) lnp += ln_pdf<false, K_AGE>(M.prior_age, q1, 0.0);
-    lnp += ln_pdf<false, K_FEH>(M.prior_feh, feh_par, 0.0);
-    lnp += ln_pdf<true, K_DIST>(M.prior_distance, dist, ld);
-    lnp += ln_pdf<false, K_AV>(M.prior_AV, AV, 0.0);
+    if (KIND == ISO_KIND_ISO) lnp += t_first;
+    lnp += t_feh;
+    lnp += t_dist;
+    lnp += t_av;
     if (rejected) lnp = -f_inf();
     ISO_STAMP(4, lnp);
     const bool prior_ok = active && isfinite(lnp);

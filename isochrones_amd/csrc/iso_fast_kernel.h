@@ -88,8 +88,9 @@ static __device__ unsigned long long g_phase_stamps[16];
 #ifndef ISO_KERNARG_REREAD
 #define ISO_KERNARG_REREAD 1
 #endif
+// (bit 2: the table-free priors are evaluated while the primary's model cell is on its way)
 #ifndef ISO_UNI_LANE
-#define ISO_UNI_LANE 2
+#define ISO_UNI_LANE 6
 #endif
 
 #include "fast/brackets.h"
