@@ -92,6 +92,12 @@ static __device__ unsigned long long g_phase_stamps[16];
 #ifndef ISO_UNI_LANE
 #define ISO_UNI_LANE 6
 #endif
+#ifndef ISO_DENSE_LANE
+#define ISO_DENSE_LANE 0
+#endif
+#ifndef ISO_MULTI_LANE
+#define ISO_MULTI_LANE 0
+#endif
 
 #include "fast/brackets.h"
 #include "fast/gather_lane.h"
