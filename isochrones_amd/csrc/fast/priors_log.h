@@ -114,28 +114,27 @@ __device__ __forceinline__ double eep_term_rt(const DevModel& M, const DevPrior&
 template <bool HAS_LX, int K>
 __device__ __forceinline__ double ln_pdf_ct(const DevPrior& P, double x, double lx)
 {
-    const bool outside = bool((x < P.lo) | (x > P.hi));
+    const bool outside = (x < P.lo) || (x > P.hi);
     switch (K) {
     case ISO_PRIOR_FLAT: return outside ? -f_inf() : P.k1;
     case ISO_PRIOR_FLATLOG: return outside ? -f_inf() : fma(x, kLn10, P.k1);
     case ISO_PRIOR_POWERLAW: {
         const double l = HAS_LX ? lx : fast_log(x);
-        return bool((P.bounded != 0) & outside) ? -f_inf() : fma(P.a, l, P.k1);
+        return (P.bounded && outside) ? -f_inf() : fma(P.a, l, P.k1);
     }
     case ISO_PRIOR_GAUSS: {
         const double z = (x - P.a) * P.r0;
-        return bool((P.bounded != 0) & outside) ? -f_inf() : (-0.5 * (z * z) + kLogInvRoot2Pi) - P.k1 - P.c;
+        return (P.bounded && outside) ? -f_inf() : (-0.5 * (z * z) + kLogInvRoot2Pi) - P.k1 - P.c;
     }
     case ISO_PRIOR_LOGNORMAL: return lognormal_ln(P, HAS_LX ? lx : fast_log(x));
     case ISO_PRIOR_CHABRIER: {
         const double l = HAS_LX ? lx : fast_log(x);
         const double below = lognormal_ln(P, l) - P.k3, above = fma(P.c, l, P.k5) - P.k4;
-        return (x < P.d) ? below : (bool((x < P.g) | (x > P.h)) ? -f_inf() : above);
+        return (x < P.d) ? below : ((x < P.g || x > P.h) ? -f_inf() : above);
     }
     case ISO_PRIOR_FEH: {
         const double pdf = feh_pdf<1>(P, x);
-        const double lp = fast_log(pdf);
-        return bool(!outside & (pdf != 0)) ? lp : -f_inf();
+        return (!outside && pdf != 0) ? fast_log(pdf) : -f_inf();
     }
     }
     return f_nan();
@@ -144,7 +143,7 @@ __device__ __forceinline__ double ln_pdf_ct(const DevPrior& P, double x, double 
 template <int K>
 __device__ __forceinline__ double ln_call_ct(const DevPrior& P, double x)
 {
-    const bool outside = bool((x < P.lo) | (x > P.hi));
+    const bool outside = (x < P.lo) || (x > P.hi);
     switch (K) {
     case ISO_PRIOR_FLAT: return outside ? -f_inf() : P.k1;
     case ISO_PRIOR_FLATLOG: return outside ? -f_inf() : fma(x, kLn10, P.k1);
@@ -157,13 +156,12 @@ __device__ __forceinline__ double ln_call_ct(const DevPrior& P, double x)
     case ISO_PRIOR_CHABRIER: {
         const double l = fast_log(x);
         const double below = lognormal_ln(P, l) - P.k3, above = fma(P.c, l, P.k5) - P.k4;
-        const double inside = (x < P.d) ? ((x < 0) ? -f_inf() : below) : (bool((x < P.g) | (x > P.h)) ? -f_inf() : above);
+        const double inside = (x < P.d) ? ((x < 0) ? -f_inf() : below) : ((x < P.g || x > P.h) ? -f_inf() : above);
         return outside ? -f_inf() : inside;
     }
     case ISO_PRIOR_FEH: {
         const double pdf = feh_pdf<1>(P, x);
-        const double lp = fast_log(pdf);
-        return bool(!outside & (pdf != 0)) ? lp : -f_inf();
+        return (!outside && pdf != 0) ? fast_log(pdf) : -f_inf();
     }
     }
     return f_nan();
@@ -174,10 +172,9 @@ __device__ __forceinline__ double eep_term_ct(const DevModel& M, const DevPrior&
                                            double deriv)
 {
     const double lc = ln_call_ct<K>(orig, value);
-    const double full = lc + fast_log(deriv);                                     // deriv == 0 -> -inf, deriv < 0 -> NaN, NaN -> NaN
     const double t = (lc == -f_inf()) ? ((deriv != deriv) ? f_nan() : -f_inf())   // 0 * deriv
-                                      : full;
-    return bool((eep < M.eep_lo) | (eep > M.eep_hi)) ? -f_inf() : t;
+                                      : lc + fast_log(deriv);                     // deriv == 0 -> -inf, deriv < 0 -> NaN, NaN -> NaN
+    return (eep < M.eep_lo || eep > M.eep_hi) ? -f_inf() : t;
 }
 
 // dispatch: K < 0 = the family the record names

@@ -83,7 +83,7 @@ __device__ __forceinline__ void stretch_move(const FastArgs& A, const StretchArg
     // UNI: a single star's fit (or a few ensembles of it) - one workgroup per CU at most, nothing to overlap with
     const double lnew = lnpost_wave<KIND, NS, NB, true, ASTERO, true, false, STDP, LANE>(A, lds, L, active, M, y, false, lnp_unused, lnl_unused);
     const double lnq = (NP - 1) * fast_log(z) + lnew - lold;
-    const bool acc = bool(active & isfinite(lnew) & (fast_log(u2) < lnq));
+    const bool acc = active && isfinite(lnew) && (fast_log(u2) < lnq);
     if (acc) {
 #pragma unroll
         for (int q = 0; q < NP; ++q) pos[lr * NP + q] = y[q];
