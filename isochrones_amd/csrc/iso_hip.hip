@@ -768,6 +768,7 @@ hipError_t build_fast(const iso_ic* ic, int nb, const double* d_bc_hot, double**
         if ((v.size() - 1) % 8 != 0) blob.push_back(v.back());
         coarse.n = (int)blob.size() - coarse.off;
     }
+    if ((int)blob.size() > FAST_MAX_BLOB) return hipSuccess;          // (the tables below add at most 1 KB to that)
     // bucket tables of the seven staged axes (fast/axis_lut.h), bytes behind the doubles.  Budget: what the
     // four-workgroups-per-CU persistent sampler has left of its 40 KB (axes + 256 gather slots of 7 doubles + 512
     // positions of 5 doubles; 736 B with the MIST axes), at most 1 KB.
@@ -797,7 +798,6 @@ hipError_t build_fast(const iso_ic* ic, int nb, const double* d_bc_hot, double**
         blob.resize(at + bytes.size() / sizeof(double));
         std::memcpy(blob.data() + at, bytes.data(), bytes.size());
     }
-    if ((int)blob.size() > FAST_MAX_BLOB) return hipSuccess;
     hipError_t e = hipMalloc(d_axes_blob, blob.size() * sizeof(double));
     if (e == hipSuccess) e = hipMemcpy(*d_axes_blob, blob.data(), blob.size() * sizeof(double), hipMemcpyHostToDevice);
     if (e != hipSuccess) return e;
