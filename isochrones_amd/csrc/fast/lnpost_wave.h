@@ -19,9 +19,12 @@
 template <int KIND, int NS, int NB, bool PACKED, bool ASTERO = false, bool MASKED = false, bool TILED = false, bool STDP = false,
           int LANE = 0>
 __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* lds, const CoopLds& L, bool active,
-                                              const DevModel& M, const double* __restrict__ p, bool want_parts,
+                                              const DevModel& M, const DevModel& MP, const double* __restrict__ p, bool want_parts,
                                               double& lnp_out, double& lnl_out)
 {
+    // MP: the block the mass / age / [Fe/H] / A_V priors and the EEP bounds are read from - the sample's own block M, or
+    // (catalogs whose stars share them: FastArgs.shared_priors) the first star's; observations and the distance prior
+    // are always M's
     const double q1 = p[NS], feh_par = p[NS + 1], dist = p[NS + 2], AV = p[NS + 3];
 
     // ---- model table: axes 0/1 are shared by all components of an isochrone system ----
@@ -43,10 +46,10 @@ __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* l
     double ld = 0.0, t_first = 0.0, t_feh = 0.0, t_dist = 0.0, t_av = 0.0;
     auto table_free_priors = [&]() {
         ld = fast_log(dist);
-        t_first = (KIND == ISO_KIND_TRACK) ? ln_pdf<false, K_MASS>(M.prior_mass, p[0], 0.0) : ln_pdf<false, K_AGE>(M.prior_age, q1, 0.0);
-        t_feh = ln_pdf<false, K_FEH>(M.prior_feh, feh_par, 0.0);
+        t_first = (KIND == ISO_KIND_TRACK) ? ln_pdf<false, K_MASS>(MP.prior_mass, p[0], 0.0) : ln_pdf<false, K_AGE>(MP.prior_age, q1, 0.0);
+        t_feh = ln_pdf<false, K_FEH>(MP.prior_feh, feh_par, 0.0);
         t_dist = ln_pdf<true, K_DIST>(M.prior_distance, dist, ld);
-        t_av = ln_pdf<false, K_AV>(M.prior_AV, AV, 0.0);
+        t_av = ln_pdf<false, K_AV>(MP.prior_AV, AV, 0.0);
     };
     double star[NS][6];
     double astero[2] = {0.0, 0.0};
@@ -89,8 +92,8 @@ __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* l
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         const double eep = (KIND == ISO_KIND_TRACK) ? p[1] : p[s];
-        lnp += (KIND == ISO_KIND_TRACK) ? eep_term<K_AGE>(M, M.prior_age, eep, star[s][4], star[s][5])
-                                        : eep_term<K_MASS>(M, M.prior_mass, eep, star[s][4], star[s][5]);
+        lnp += (KIND == ISO_KIND_TRACK) ? eep_term<K_AGE>(MP, MP.prior_age, eep, star[s][4], star[s][5])
+                                        : eep_term<K_MASS>(MP, MP.prior_mass, eep, star[s][4], star[s][5]);
     }
     if (KIND == ISO_KIND_ISO) lnp += t_first;
     lnp += t_feh;
@@ -244,6 +247,15 @@ __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* l
     return prior_ok ? lnp + lnl : -f_inf();
 }
 
+template <int KIND, int NS, int NB, bool PACKED, bool ASTERO = false, bool MASKED = false, bool TILED = false, bool STDP = false,
+          int LANE = 0>
+__device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* lds, const CoopLds& L, bool active,
+                                              const DevModel& M, const double* __restrict__ p, bool want_parts,
+                                              double& lnp_out, double& lnl_out)
+{
+    return lnpost_wave<KIND, NS, NB, PACKED, ASTERO, MASKED, TILED, STDP, LANE>(A, lds, L, active, M, M, p, want_parts, lnp_out, lnl_out);
+}
+
 // LDS layout of the fast kernels: [axes blob, rounded to an even count][request slots][response slots]
 template <int NB>
 __device__ __forceinline__ CoopLds coop_lds(double* lds, int axes_len)
@@ -329,7 +341,8 @@ void k_lnpost_fast(const FastArgs A)
         for (int j = 0; j < NP; ++j) p[j] = src[j * A.stride_p];
     }
     double lnp, lnl;
-    const double r = lnpost_wave<KIND, NS, NB, PACKED, ASTERO, MULTI>(A, lds, L, active, M, p, A.lnlike != nullptr, lnp, lnl);
+    const DevModel& MP = (MULTI && A.shared_priors) ? A.m[0] : M;
+    const double r = lnpost_wave<KIND, NS, NB, PACKED, ASTERO, MULTI>(A, lds, L, active, M, MP, p, A.lnlike != nullptr, lnp, lnl);
     if (active) {
         if (A.lnpost) A.lnpost[i] = r;
         if (A.lnprior) A.lnprior[i] = lnp;

@@ -81,7 +81,8 @@ __device__ __forceinline__ void stretch_move(const FastArgs& A, const StretchArg
     const DevModel& M = UNI ? *(const DevModel*)((const_model_ptr)(uintptr_t)A.m) : A.m[S.multi ? star : 0];
     double lnp_unused, lnl_unused;
     // UNI: a single star's fit (or a few ensembles of it) - one workgroup per CU at most, nothing to overlap with
-    const double lnew = lnpost_wave<KIND, NS, NB, true, ASTERO, true, false, STDP, LANE>(A, lds, L, active, M, y, false, lnp_unused, lnl_unused);
+    const DevModel& MP = (!UNI && S.multi && A.shared_priors) ? A.m[0] : M;      // catalogs: the priors all stars share
+    const double lnew = lnpost_wave<KIND, NS, NB, true, ASTERO, true, false, STDP, LANE>(A, lds, L, active, M, MP, y, false, lnp_unused, lnl_unused);
     const double lnq = (NP - 1) * fast_log(z) + lnew - lold;
     const bool acc = active && isfinite(lnew) && (fast_log(u2) < lnq);
     if (acc) {
@@ -169,7 +170,8 @@ __global__ __launch_bounds__(BLOCK, stretch_half_waves(NB)) void k_stretch_half(
         Mp = A.m + (S.multi ? m.star : 0);
     }
     double lnp_unused, lnl_unused;
-    const double lnew = lnpost_wave<KIND, NS, NB, true, ASTERO, true>(A, lds, L, active, *Mp, y, false, lnp_unused, lnl_unused);
+    const DevModel* MPp = (S.multi && A.shared_priors) ? A.m : Mp;
+    const double lnew = lnpost_wave<KIND, NS, NB, true, ASTERO, true>(A, lds, L, active, *Mp, *MPp, y, false, lnp_unused, lnl_unused);
     // ---- decide and store: everything about the move is rebuilt from the thread index ----
     int tid = (int)threadIdx.x;
     asm volatile("" : "+v"(tid));

@@ -1567,6 +1567,22 @@ int iso_catalog_create(iso_ic* ic, const iso_model_desc* descs, int64_t n_models
         return fail(e == hipErrorOutOfMemory ? ISO_ERR_NOMEM : ISO_ERR_HIP, msg);
     }
     c->fast.m = c->d_models;
+    // do all stars share the priors other than the distance prior (and the EEP bounds)?  Then the kernels read them from
+    // the first star's block.
+    {
+        bool shared = true;
+        const DevModel& h0 = H[0];
+        for (int64_t k = 1; k < n_models && shared; ++k) {
+            const DevModel& h = H[(size_t)k];
+            shared = std::memcmp(&h.prior_mass, &h0.prior_mass, sizeof(DevPrior)) == 0 &&
+                     std::memcmp(&h.prior_age, &h0.prior_age, sizeof(DevPrior)) == 0 &&
+                     std::memcmp(&h.prior_feh, &h0.prior_feh, sizeof(DevPrior)) == 0 &&
+                     std::memcmp(&h.prior_AV, &h0.prior_AV, sizeof(DevPrior)) == 0 &&
+                     h.eep_lo == h0.eep_lo && h.eep_hi == h0.eep_hi;
+        }
+        c->fast.shared_priors = shared ? 1 : 0;
+        if (const char* env = std::getenv("ISOCHRONES_AMD_SHARED_PRIORS")) c->fast.shared_priors = shared && std::atoi(env) != 0;
+    }
     c->packed = true;
     *out = c;
     return ISO_OK;
@@ -1658,6 +1674,8 @@ int iso_catalog_create_columns(iso_ic* ic, const iso_model_desc* tmpl, int64_t n
         return fail(e == hipErrorOutOfMemory ? ISO_ERR_NOMEM : ISO_ERR_HIP, msg);
     }
     c->fast.m = c->d_models;
+    c->fast.shared_priors = 1;          // every block is the template's but for observations and the distance prior
+    if (const char* env = std::getenv("ISOCHRONES_AMD_SHARED_PRIORS")) c->fast.shared_priors = std::atoi(env) != 0;   // A/B switch
     c->packed = true;
     *out = c;
     return ISO_OK;

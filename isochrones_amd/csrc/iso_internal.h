@@ -106,6 +106,9 @@ struct FastArgs {
     int nb_total;                    // bands in a cell of bcq (the band-tiled kernels, 13-32 bands, read it)
     int64_t bs0, bs1, bs2;
     const DevModel* m;               // one model, or an array indexed by star_id (catalog kernels)
+    int shared_priors;               // catalog kernels: every star's mass / age / [Fe/H] / A_V priors and EEP bounds equal
+                                     // those of m[0] (only the distance prior is per star) - they are then read from m[0],
+                                     // one cached block for the whole launch instead of five lines per star and half-step
     const int32_t* star_id;          // per-row model index (catalog kernels only)
     const double* pars;
     int64_t stride_n, stride_p, n;
