@@ -21,6 +21,76 @@ def _small_track(bands=("G", "BP", "RP")):
                               limits=dict(mass=(masses[0], masses[-1]), feh=(-1.0, 0.5), age=(5, 10.13)))
 
 
+def test_catalog_whose_stars_have_different_priors(monkeypatch):
+    """A catalog built from per-star descriptors may give every star its own priors (each star.ini of a batch_starfit
+    folder can set them).  The catalog kernels read the priors the stars share from the first star's block only when the
+    library has found them equal; here they are not - two stars carry their own [Fe/H], A_V and mass priors - and both
+    the batch kernel and the samplers must use each star's own.  Also: the same catalog with equal priors gives the same
+    numbers whether the shared block is used or not (ISOCHRONES_AMD_SHARED_PRIORS=0)."""
+    import torch
+    from isochrones_amd import priors as P
+    from isochrones_amd.sampler import FusedEnsembleSampler
+    from isochrones_amd.catalog import initial_positions
+    rng = np.random.default_rng(12)
+    bands = ("G", "BP", "RP")
+    ic = _small_track(bands)
+    lo = np.array([ic.model_grid.masses[0], 150, -1.0, 20.0, 0.0])
+    hi = np.array([ic.model_grid.masses[-1], 699, 0.5, 1500.0, 1.0])
+    truth = np.array([1.0, 355.0, 0.0, 300.0, 0.1])
+    mags = ic.interp_mag(list(truth), list(bands))[3]
+
+    def build(different):
+        models = []
+        for k in range(6):
+            obs = {b: (float(mags[j]) + 0.01 * k, 0.02) for j, b in enumerate(bands)}
+            obs["parallax"] = (1000.0 / 300.0, 0.05)
+            m = ia.BasicStarModel(ic, **obs)
+            if different and k == 2:
+                m.set_prior(feh=P.FlatPrior((-0.6, 0.3)), AV=P.GaussianPrior(0.2, 0.1, bounds=(0.0, 1.0)))
+            if different and k == 4:
+                m.set_prior(mass=P.PowerLawPrior(-2.35, (0.2, 3.0)))
+            models.append(m)
+        return models
+
+    models = build(True)
+    post = CatalogPosterior(ic, models)
+    n = 30_000
+    pars = rng.uniform(lo, hi, size=(n, lo.size))
+    pars[: n // 2] = truth + np.array([0.05, 10.0, 0.2, 30.0, 0.1]) * rng.standard_normal((n // 2, 5))
+    sid = rng.integers(0, len(models), n).astype(np.int32)
+    got = post.lnpost(torch.as_tensor(pars, device="cuda"), torch.as_tensor(sid, device="cuda")).cpu().numpy()
+    oic = fx.make_oracle_ic(ic)
+    want = np.empty(n)
+    for k in range(len(models)):
+        m = sid == k
+        want[m] = oic.lnpost(models[k].model_desc(), pars[m].T.copy(), parts=False, nthreads=8)
+    assert np.isfinite(want).sum() > n // 10
+    fx.assert_close(got, want, RTOL, atol=ATOL, what="catalog lnpost, per-star priors")
+    # the samplers (step-wise and persistent) on it: stored lnprob = oracle lnpost of the stored positions, star by star
+    W = 32
+    pos, lnp, failed = initial_positions(post, W, rng_seed=3)
+    assert not bool(failed.any())
+    for mode in ("stepwise", "persistent"):
+        monkeypatch.setenv("ISOCHRONES_AMD_SAMPLER", mode)
+        fs = FusedEnsembleSampler(post, W, seed=5)
+        fs.run_mcmc(pos, 12, lnprob0=lnp, store=True)
+        chain = fs.chain.cpu().numpy()                     # [S, W, steps, D]
+        lp = fs.lnprobability.cpu().numpy()                # [S, W, steps]
+        for k in range(len(models)):
+            w = oic.lnpost(models[k].model_desc(), chain[k].reshape(-1, 5).T.copy(), parts=False, nthreads=4)
+            fx.assert_close(lp[k].reshape(-1), w, RTOL, atol=ATOL, what="stored lnprob, star %d, %s" % (k, mode))
+    post.close()
+    # equal priors: with and without the shared block
+    same = build(False)
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("ISOCHRONES_AMD_SHARED_PRIORS", flag)
+        p2 = CatalogPosterior(ic, same)
+        outs.append(p2.lnpost(torch.as_tensor(pars, device="cuda"), torch.as_tensor(sid, device="cuda")).cpu().numpy())
+        p2.close()
+    assert np.array_equal(outs[0], outs[1], equal_nan=True)
+
+
 @pytest.mark.parametrize("kind,n_stars", [("track", 1), ("iso", 2)])
 def test_catalog_lnpost_vs_oracle(kind, n_stars):
     import torch
