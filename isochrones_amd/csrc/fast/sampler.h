@@ -39,7 +39,10 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 // STDP (with UNI): that model's priors are the reference's defaults - their families are compile-time constants.
 // LANE: lnpost_wave's gather / overlap form (ISO_UNI_LANE for the single-model kernel, ISO_DENSE_LANE for the register-capped
 // catalog kernel, 0 otherwise).
-template <int KIND, int NS, int NB, bool ASTERO, bool UNI = false, bool STDP = false, int LANE = 0>
+// SHAREDP: the priors the stars of the launch share are read from the first block through the constant address space
+// (scalar loads, scalar branches on their families) - the register-capped catalog kernel, which the host only picks
+// for launches whose stars do share them.
+template <int KIND, int NS, int NB, bool ASTERO, bool UNI = false, bool STDP = false, int LANE = 0, bool SHAREDP = false>
 __device__ __forceinline__ void stretch_move(const FastArgs& A, const StretchArgs& S, double* lds, const CoopLds& L,
                                              bool active, int64_t star, int k, int half, uint32_t step,
                                              double* __restrict__ pos, double* __restrict__ lnp, int32_t* acc_cnt,
@@ -81,7 +84,8 @@ __device__ __forceinline__ void stretch_move(const FastArgs& A, const StretchArg
     const DevModel& M = UNI ? *(const DevModel*)((const_model_ptr)(uintptr_t)A.m) : A.m[S.multi ? star : 0];
     double lnp_unused, lnl_unused;
     // UNI: a single star's fit (or a few ensembles of it) - one workgroup per CU at most, nothing to overlap with
-    const DevModel& MP = (!UNI && S.multi && A.shared_priors) ? A.m[0] : M;      // catalogs: the priors all stars share
+    const DevModel& MP = SHAREDP ? *(const DevModel*)((const_model_ptr)(uintptr_t)A.m)
+                                 : ((!UNI && S.multi && A.shared_priors) ? A.m[0] : M);      // catalogs: the priors all stars share
     const double lnew = lnpost_wave<KIND, NS, NB, true, ASTERO, true, false, STDP, LANE>(A, lds, L, active, M, MP, y, false, lnp_unused, lnl_unused);
     const double lnq = (NP - 1) * fast_log(z) + lnew - lold;
     const bool acc = active && isfinite(lnew) && (fast_log(u2) < lnq);
@@ -299,7 +303,7 @@ __global__ __launch_bounds__(BLOCK, DENSE ? (persist_slim(DENSE, NB, NS) ? 4 : 3
                 const int k = k0 + kk;
                 const bool active = mine && k < h;
                 if (__any(active))                        // wave-uniform: idle waves go straight to the barrier
-                    stretch_move<KIND, NS, NB, ASTERO, UNI, STDP, UNI ? ISO_UNI_LANE : (DENSE ? ISO_DENSE_LANE : ISO_MULTI_LANE)>(A, S, lds, L, active, star0 + gs, active ? k : h - 1, half,
+                    stretch_move<KIND, NS, NB, ASTERO, UNI, STDP, UNI ? ISO_UNI_LANE : (DENSE ? ISO_DENSE_LANE : ISO_MULTI_LANE), DENSE && ISO_DENSE_SHARED>(A, S, lds, L, active, star0 + gs, active ? k : h - 1, half,
                                                S.step + (uint32_t)it, lpos + gs * W * NP, llnp + gs * W,
                                                lacc ? lacc + gs * W : nullptr, cp, cl);
             }

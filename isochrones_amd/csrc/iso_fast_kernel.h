@@ -95,6 +95,11 @@ static __device__ unsigned long long g_phase_stamps[16];
 #ifndef ISO_DENSE_LANE
 #define ISO_DENSE_LANE 0
 #endif
+// the register-capped catalog kernel reads the shared priors through scalar loads (the host never picks it for a launch whose
+// stars have priors of their own); 0 builds the A/B counterpart
+#ifndef ISO_DENSE_SHARED
+#define ISO_DENSE_SHARED 1
+#endif
 #ifndef ISO_MULTI_LANE
 #define ISO_MULTI_LANE 0
 #endif

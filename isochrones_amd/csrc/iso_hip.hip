@@ -2038,7 +2038,10 @@ int iso_sampler_run(iso_sampler* sp, double* pos, double* lnp, int nsteps, doubl
     int dense = 0;
     if (fits && mode != "stepwise") {
         S.nsteps = 1;
-        for (int dn = force_dense ? 1 : 0; dn < 2; ++dn) {
+        // (the register-capped instantiation takes the stars' shared priors from the first block: not for a catalog whose
+        // stars carry priors of their own)
+        const bool dense_ok = !sp->multi || sp->fast.shared_priors;
+        for (int dn = (force_dense && dense_ok) ? 1 : 0; dn < (dense_ok ? 2 : 1); ++dn) {
             S.dense = dn;
             S.occupancy_query = &per_cu;
             per_cu = 0;
