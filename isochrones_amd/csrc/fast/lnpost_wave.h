@@ -166,9 +166,9 @@ __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* l
             for (int b = 0; b < NB; ++b) {
                 const int band = min(b0 + b, nbt - 1);
                 const double mag = (NS == 1) ? tot[b] : fma(-2.5, fast_log10(rel[b]), tot[b]);
-                const double mv = M.band[band].val;
+                const double mv = M.mag_val[band];
                 const double r = mv - mag;
-                if (b0 + b < nbt && (!MASKED || mv == mv)) lnl += M.band[band].g0 - r * r * M.band[band].hinv;
+                if (b0 + b < nbt && (!MASKED || mv == mv)) lnl += M.mag_g0[band] - r * r * M.mag_hinv[band];
             }
         }
     } else if constexpr (NB > 0) {   // NB = 0: spectroscopy / parallax only, the BC table is never touched
@@ -220,13 +220,13 @@ __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* l
         for (int b = 0; b < NB; ++b) {
             const double mag = (NS == 1) ? tot[b] : fma(-2.5, fast_log10(rel[b]), tot[b]);
             if constexpr (STDP) {
-                const double mv = M.band[b].val, g0 = M.band[b].g0, hinv = M.band[b].hinv;
+                const double mv = M.mag_val[b], g0 = M.mag_g0[b], hinv = M.mag_hinv[b];
                 const double r = mv - mag;
                 const double term = g0 - r * r * hinv;
                 lnl += (!MASKED || mv == mv) ? term : 0.0;
             } else {
-                const double r = M.band[b].val - mag;
-                if (!MASKED || M.band[b].val == M.band[b].val) lnl += M.band[b].g0 - r * r * M.band[b].hinv;
+                const double r = M.mag_val[b] - mag;
+                if (!MASKED || M.mag_val[b] == M.mag_val[b]) lnl += M.mag_g0[b] - r * r * M.mag_hinv[b];
             }
         }
     }

@@ -681,8 +681,8 @@ void fill_dev_model(const iso_model_desc* desc, int kind, DevModel& H)
     H.has_numax = desc->has_numax;
     H.has_dnu = desc->has_numax ? desc->has_dnu : 0;
     for (int b = 0; b < desc->n_bands; ++b) {
-        H.band[b].val = desc->mag_val[b];
-        gauss_consts(desc->mag_unc[b], H.band[b].g0, H.band[b].unc2, &H.band[b].hinv);
+        H.mag_val[b] = desc->mag_val[b];
+        gauss_consts(desc->mag_unc[b], H.mag_g0[b], H.mag_unc2[b], &H.mag_hinv[b]);
     }
     for (int q = 0; q < 3; ++q) {
         H.spec_val[q] = desc->spec_val[q];

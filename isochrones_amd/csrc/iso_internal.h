@@ -56,28 +56,18 @@ struct DevPrior {
     double r0, r1, r2;    // reciprocals / log-constants used by the fast kernels
 };
 
-// One observation band of a model: value and the host-precomputed constants of its Gaussian term.
-struct DevBand {
-    double val;
-    double g0;      // log(1/sqrt(2 pi)) + log(unc)
-    double unc2;    // unc*unc
-    double hinv;    // 0.5/(unc*unc)
-};
-
-// Field order: what a catalog kernel reads PER STAR comes first and is contiguous - flags, parallax, spectroscopy, the
-// distance prior (its bounds follow the star's parallax), then the bands: 312 + 32 nb bytes = four 128-B lines for three
-// bands (the priors all stars share are read from the first star's block, FastArgs.shared_priors).  Blocks start on
-// line boundaries.
-struct alignas(128) DevModel {
+struct DevModel {
     int n_stars, n_bands, kind;
     int has_parallax, has_numax, has_dnu;
-    double plx_val, plx_g0, plx_unc2, plx_hinv;
+    double mag_val[ISO_MAX_BANDS];
+    double mag_g0[ISO_MAX_BANDS];    // log(1/sqrt(2 pi)) + log(unc)
+    double mag_unc2[ISO_MAX_BANDS];  // unc*unc
+    double mag_hinv[ISO_MAX_BANDS];  // 0.5/(unc*unc)
     double spec_val[3], spec_g0[3], spec_unc2[3], spec_hinv[3];
-    DevPrior prior_distance;
-    DevBand band[ISO_MAX_BANDS];
+    double plx_val, plx_g0, plx_unc2, plx_hinv;
     double numax_val, numax_g0, numax_unc2, numax_hinv;
     double dnu_val, dnu_g0, dnu_unc2, dnu_hinv;
-    DevPrior prior_mass, prior_age, prior_feh, prior_AV;
+    DevPrior prior_mass, prior_age, prior_feh, prior_distance, prior_AV;
     double eep_lo, eep_hi;
     double bound_lo[ISO_MAX_PARAMS], bound_hi[ISO_MAX_PARAMS];
 };

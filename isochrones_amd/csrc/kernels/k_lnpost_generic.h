@@ -121,7 +121,7 @@ __global__ __launch_bounds__(BLOCK) void k_lnpost(const PostArgs A)
 #pragma unroll
                 for (int b = 0; b < NB; ++b) {
                     const double mag = (NS == 1) ? tot[b] : -2.5 * log10(tot[b]);
-                    lnl += gauss_term(M.band[b].val, M.band[b].g0, M.band[b].unc2, mag);
+                    lnl += gauss_term(M.mag_val[b], M.mag_g0[b], M.mag_unc2[b], mag);
                 }
             } else {
                 for (int b = 0; b < M.n_bands; ++b) {
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(BLOCK) void k_lnpost(const PostArgs A)
                         else tot += exp10(-0.4 * mag);
                     }
                     const double mag = (NS == 1) ? tot : -2.5 * log10(tot);
-                    lnl += gauss_term(M.band[b].val, M.band[b].g0, M.band[b].unc2, mag);
+                    lnl += gauss_term(M.mag_val[b], M.mag_g0[b], M.mag_unc2[b], mag);
                 }
             }
             if (M.has_parallax) lnl += gauss_term(M.plx_val, M.plx_g0, M.plx_unc2, 1000.0 / dist);

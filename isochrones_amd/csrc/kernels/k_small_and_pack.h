@@ -142,8 +142,8 @@ __global__ __launch_bounds__(BLOCK) void k_catalog_fill(const FillCatalogArgs A)
     for (int64_t s = (int64_t)blockIdx.x * BLOCK + threadIdx.x; s < A.n; s += (int64_t)gridDim.x * BLOCK) {
         DevModel& M = A.models[s];
         for (int b = 0; b < A.nb; ++b) {
-            M.band[b].val = A.mag_val[s * A.nb + b];
-            dev_gauss_consts(A.mag_unc[s * A.nb + b], M.band[b].g0, M.band[b].unc2, M.band[b].hinv);
+            M.mag_val[b] = A.mag_val[s * A.nb + b];
+            dev_gauss_consts(A.mag_unc[s * A.nb + b], M.mag_g0[b], M.mag_unc2[b], M.mag_hinv[b]);
         }
         for (int q = 0; q < 3; ++q) {
             M.spec_val[q] = A.spec_val[s * 3 + q];

@@ -33,6 +33,10 @@ def build(rng):
     kind = rng.choice(["track", "iso"])
     n_stars = 1 if kind == "track" else int(rng.choice([1, 1, 2, 3]))
     nb = int(rng.choice([0, 1, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11]))
+    # pin the shape from the environment (to chase a failure): SOAK_KIND, SOAK_NSTARS, SOAK_NB
+    kind = os.environ.get("SOAK_KIND", kind)
+    n_stars = 1 if kind == "track" else int(os.environ.get("SOAK_NSTARS", n_stars))
+    nb = int(os.environ.get("SOAK_NB", nb))
     bands = list(ia.grids.DEFAULT_BANDS[:max(nb, 1)])
     all_fehs = np.array([-2.0, -1.5, -1.0, -0.75, -0.5, -0.25, 0.0, 0.25, 0.5])
     # the [Fe/H] axis keeps its end points (the bounds below) and a random subset of the inner nodes

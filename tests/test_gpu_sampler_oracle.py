@@ -278,3 +278,52 @@ def test_independent_ensembles_of_one_model_in_one_launch():
     assert rhat.shape == (5,) and np.all(rhat < 1.2), rhat
     q = fs.quantiles((0.5,)).cpu().numpy()           # [E, 5, 1]
     assert q.shape == (E, 5, 1)
+
+
+@pytest.mark.parametrize("n_stars,nb", [(3, 9), (3, 12), (2, 11), (1, 12), (3, 6), (2, 9)])
+def test_single_model_sampler_on_random_models_of_the_largest_shapes(n_stars, nb, monkeypatch):
+    """Random isochrone models (the soak's generator: random observables, priors, prior keywords, table axes) of the
+    shapes whose single-model kernels carry the most state, every stored move replayed against the oracle.
+    Regression guard: a reordering of the model block's fields once made exactly the (3 stars, 9 bands) instantiation
+    disagree with the oracle on most random models while the fixed-model tests and every other shape stayed clean -
+    only the randomised soak (tests/soak/soak_sampler.py) saw it."""
+    from isochrones_amd._cabi import IsoError
+    from isochrones_amd.sampler import FusedEnsembleSampler
+    from tests.soak import soak, soak_sampler
+    monkeypatch.setenv("SOAK_KIND", "iso")
+    monkeypatch.setenv("SOAK_NSTARS", str(n_stars))
+    monkeypatch.setenv("SOAK_NB", str(nb))
+    monkeypatch.setenv("ISOCHRONES_AMD_SAMPLER", "auto")
+    rng = np.random.default_rng(1000 * n_stars + nb)
+    done = 0
+    for _ in range(60):
+        cfg, ic, mod, axes, lo, hi = soak.build(rng)
+        W = int(rng.choice([4, 30, 100, 256]))
+        a = float(rng.choice([1.3, 2.0, 3.0]))
+        sseed = int(rng.integers(0, 2 ** 40))
+        try:
+            fs = FusedEnsembleSampler(mod, W, a=a, seed=sseed)
+        except IsoError:                 # a model the fused kernels do not take
+            ic.release()
+            continue
+        p0 = soak_sampler.start_points(rng, mod, lo, hi, W, True)
+        if p0 is None:
+            ic.release()
+            continue
+        oic = fx.make_oracle_ic(ic)
+        desc = mod.model_desc()
+
+        def fn(blk, pars, oic=oic, desc=desc):
+            return oic.lnpost(desc, np.ascontiguousarray(pars.T), nthreads=8, parts=False)
+        lnp0 = fn(None, p0)
+        assert np.isfinite(lnp0).all(), cfg
+        fs.run_mcmc(p0, 12, lnprob0=lnp0, store=True)
+        st = _replay.replay(p0, lnp0, fs.chain_steps.cpu().numpy(), fs._lnprob.cpu().numpy(), W, a, sseed, 0, fn,
+                            lnp_atol=1e-7, margin=1e-8)
+        assert st["near_ties"] <= 3, (st, cfg)
+        fs.close()
+        ic.release()
+        done += 1
+        if done >= 8:
+            break
+    assert done >= 4
