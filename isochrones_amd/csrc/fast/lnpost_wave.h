@@ -16,6 +16,7 @@
 // from the corner-packed table (gather_lane.h) - the latency form of a lone workgroup.
 // bit 2 of LANE: the priors that do not depend on the model table are evaluated between the issue of the primary's
 // model gather and the use of its data (coop_star's `between`).
+constexpr int LANE_BC_MAX_BANDS = 4;
 template <int KIND, int NS, int NB, bool PACKED, bool ASTERO = false, bool MASKED = false, bool TILED = false, bool STDP = false,
           int LANE = 0>
 __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* lds, const CoopLds& L, bool active,
@@ -186,7 +187,10 @@ __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* l
             if (PACKED) {
                 uint32_t cell = cell4(A, j0, j1, j2, j3);
                 ISO_STAMP(5, cell);
-                if constexpr (LANE & 2) lane_bc<NB>(A, ok, cell, w4v, bc);
+                // (the lane form keeps 8 NB pieces of 16 B in flight per lane: up to four bands.  Beyond that it pushed the
+                // single-model kernels of the large shapes to 256 vector + 100-odd accumulation registers - the regime in which
+                // one of them went wrong under a field reordering, DESIGN section 7 - for a gather that is no faster there)
+                if constexpr ((LANE & 2) != 0 && NB <= LANE_BC_MAX_BANDS) lane_bc<NB>(A, ok, cell, w4v, bc);
                 else coop_bc<NB>(A, L, ok, cell, w4v, bc);
                 ISO_STAMP(6, bc[0]);
             } else if (ok) {
