@@ -410,6 +410,23 @@ class Rotation:
         return ms.value
 
 
+def spawn_ranks(n_ranks, argv=None):
+    """Re-run this script under torch.distributed.run with one rank per GPU (a bare `python bench.py --gpus N`).
+    Returns the launcher's exit code; the ranks inherit stdout / stderr, so rank 0's JSON line is this process's."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n_ranks) // n_ranks)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)]
+    cmd += list(sys.argv[1:] if argv is None else argv)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -450,7 +467,10 @@ def main():
     if args.gpus != world and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if args.gpus > 1 and world == 1:
-        raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, exactly as the driver's
+        # `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...`
+        # would, and hand their output (rank 0's one JSON line) through
+        raise SystemExit(spawn_ranks(args.gpus))
     # test hooks (single-GPU boxes): ISO_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and
     # ISO_BENCH_BACKEND=gloo replaces RCCL for the collectives
     backend = os.environ.get("ISO_BENCH_BACKEND", "nccl")

@@ -61,6 +61,21 @@ def test_bench_two_ranks_prints_one_valid_line():
         assert leg["rows_gathered_on_rank0"] == n
 
 
+def test_bench_gpus_2_without_a_launcher_spawns_its_own_ranks():
+    """`python bench.py --gpus 2 ...` with no WORLD_SIZE in the environment (how the driver starts the N = 1 run):
+    bench.py starts the ranks itself and still prints exactly one line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(ISO_BENCH_SHARE_GPU="1", ISO_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
+                        "--no-catalog"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-4000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 5 and r["startup"]["world"] == 2
+    assert r["startup"]["tables"] == "broadcast from rank 0"
+
+
 def test_bench_single_rank_default_line_has_roofline_and_cpu_baseline():
     env = dict(os.environ)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5"],
