@@ -197,11 +197,22 @@ int  iso_model_create(iso_ic* ic, const iso_model_desc* desc, iso_model** out);
 void iso_model_destroy(iso_model* m);
 int  iso_model_n_params(const iso_model* m);
 /* Which kernel family evaluates this model (measurement / test helper): the generic kernel (any table shape, any
- * band count), the fused kernel on the compact tables, or the fused kernel on the corner-packed tables. */
+ * band count) or the fused kernel on the corner-packed tables.  (ISO_PATH_FUSED_COMPACT, the fused kernel on the
+ * compact tables, is no longer produced: since round 4 the fused kernels read the corner-packed tables only and a
+ * model without them - ISOCHRONES_AMD_PATH=compact, a pack that did not fit - runs the generic kernel.) */
 #define ISO_PATH_GENERIC        0
 #define ISO_PATH_FUSED_COMPACT  1
 #define ISO_PATH_FUSED_PACKED   2
 int  iso_model_kernel_path(const iso_model* m);
+/* Test hooks: which kernel instantiations the library's launchers choose.  iso_debug_trace_kernels(1) clears the calling
+ * thread's list and turns recording on (0: off; returns the previous state); every launch made by a thread is then noted
+ * once per distinct instantiation, spelled as c++filt spells the kernel's symbol ("k_lnpost_fast<0, 1, 1, false, false>").
+ * iso_debug_kernels copies the calling thread's list, one name per line, into buf (NUL-terminated, truncated to `size`)
+ * and returns the number of bytes the whole list needs.  tests/test_gpu_dispatch_table.py ticks every kernel the build
+ * compiled off against the oracle with these.  Recording costs one atomic load per launch when it is off. */
+int     iso_debug_trace_kernels(int on);
+int64_t iso_debug_kernels(char* buf, int64_t size);
+
 /* Host-side test helper, no device involved: the bracket index the fused kernels compute for every x[k] on axis
  * `which` of a set of axes - bucket table (planned for all `n_axes` axes together within `budget` bytes, exactly as
  * the library stages them in LDS) + windowed bisection.  It must equal what the reference's searchsorted /

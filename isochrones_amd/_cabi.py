@@ -98,7 +98,7 @@ EXPORTED_SYMBOLS = (
     "iso_table_create", "iso_table_destroy", "iso_interp", "iso_interp_host",
     "iso_ic_create", "iso_ic_destroy", "iso_interp_mag", "iso_interp_mag_host",
     "iso_model_create", "iso_model_destroy", "iso_model_n_params", "iso_model_kernel_path",
-    "iso_axis_bracket_host",
+    "iso_axis_bracket_host", "iso_debug_trace_kernels", "iso_debug_kernels",
     "iso_lnpost", "iso_lnpost_host", "iso_unit_cube", "iso_time_lnpost", "iso_time_lnpost_rotating",
     "iso_catalog_create", "iso_catalog_create_columns", "iso_catalog_destroy", "iso_catalog_lnpost",
     "iso_eep_table_create", "iso_eep_table_destroy", "iso_interp_eep", "iso_interp_eep_host",
@@ -119,6 +119,21 @@ def library_path() -> str:
 
 class IsoError(RuntimeError):
     pass
+
+
+def trace_kernels(on=True):
+    """Test hook: start (and clear) / stop recording which kernel instantiations this thread's calls launch."""
+    return lib().iso_debug_trace_kernels(1 if on else 0)
+
+
+def traced_kernels():
+    """Names of the distinct kernel instantiations launched by this thread since trace_kernels(True), as c++filt spells
+    them (the keys of isochrones_amd.csrc.build.resource_table())."""
+    L = lib()
+    need = L.iso_debug_kernels(None, 0)
+    buf = C.create_string_buffer(int(need))
+    L.iso_debug_kernels(buf, need)
+    return [k for k in buf.value.decode().split("\n") if k]
 
 
 def lib():
@@ -144,6 +159,10 @@ def lib():
     L.iso_last_error.argtypes = []
     L.iso_version.restype = C.c_char_p
     L.iso_version.argtypes = []
+    if hasattr(L, "iso_debug_trace_kernels"):        # (absent from libraries built from older source states: tools/build_variant.py --src)
+        L.iso_debug_trace_kernels.argtypes = [C.c_int]
+        L.iso_debug_kernels.argtypes = [C.c_char_p, C.c_int64]
+        L.iso_debug_kernels.restype = C.c_int64
     L.iso_ctx_create.argtypes = [C.POINTER(vp), C.c_int]
     L.iso_ctx_destroy.argtypes = [vp]
     L.iso_ctx_destroy.restype = None
@@ -201,6 +220,8 @@ def lib():
     L.iso_tree_lnpost.argtypes = [vp, pd, i64, i64, i64, pd, pd, pd, vp]
     L.iso_tree_lnpost_host.argtypes = [vp, C.POINTER(dbl), i64, C.POINTER(dbl), C.POINTER(dbl), C.POINTER(dbl)]
     for name in EXPORTED_SYMBOLS:
+        if name.startswith("iso_debug_") and not hasattr(L, name) and os.environ.get("ISOCHRONES_AMD_LIB"):
+            continue                                   # a variant library built from an older source state
         fn = getattr(L, name)
         if fn.restype is C.c_int:
             fn.restype = C.c_int

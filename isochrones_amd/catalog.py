@@ -575,7 +575,7 @@ def fit_stars_gpu(catalog: StarCatalog, ic, indices, N=1, nwalkers=32, nburn=150
 
 
 #: bump when the stored result rows change meaning (columns, summaries, sampler defaults)
-SHARD_FORMAT = 2
+SHARD_FORMAT = 3
 
 
 def _stable_repr(key, value):
@@ -623,17 +623,36 @@ def _shard_fingerprint(catalog, mine, N, fit_kwargs, ic=None):
     return h.hexdigest()
 
 
+def _table_content_hash(interp):
+    """sha256 over a table's axes and a strided sample of its values (at most ~2^16 doubles, NaN padding included):
+    tables of the same shape - the synthetic MIST-shaped fallback and the real grid, two grid versions, two vvcrit
+    values - differ in it, and it costs a few milliseconds even on the 724-MB track table."""
+    import hashlib
+    grid = getattr(interp, "grid", None)
+    if grid is None:
+        return None
+    h = hashlib.sha256()
+    for ax in getattr(interp, "index_columns", ()) or ():
+        h.update(np.ascontiguousarray(ax, dtype=np.float64).tobytes())
+    flat = np.asarray(grid).reshape(-1)
+    step = max(1, flat.size // 65521)          # a prime number of samples: no resonance with the table's strides
+    h.update(np.ascontiguousarray(flat[::step], dtype=np.float64).tobytes())
+    h.update(repr((flat.size, step)).encode())
+    return h.hexdigest()
+
+
 def _ic_signature(ic):
-    """What identifies the interpolator a shard was fitted with: parametrisation, bands, table shapes, EEP bounds
-    (whatever of these the object has - fit_fn may be handed any stand-in)."""
+    """What identifies the interpolator a shard was fitted with: parametrisation, bands, table shapes, EEP bounds, where
+    the tables came from (``data_source``: 'synthetic', a directory of MIST caches, ...) and a content hash of both
+    tables (whatever of these the object has - fit_fn may be handed any stand-in)."""
     sig = [type(ic).__name__]
-    for name in ("eep_replaces", "bands", "eep_bounds", "param_names"):
+    for name in ("eep_replaces", "bands", "eep_bounds", "param_names", "data_source"):
         v = getattr(ic, name, None)
         sig.append((name, tuple(v) if isinstance(v, (list, tuple)) else v))
     for name in ("model_grid", "bc_grid"):
         interp = getattr(getattr(ic, name, None), "interp", None)
         grid = getattr(interp, "grid", None)
-        sig.append((name, tuple(grid.shape) if grid is not None else None))
+        sig.append((name, tuple(grid.shape) if grid is not None else None, _table_content_hash(interp)))
     return tuple(sig)
 
 

@@ -44,6 +44,12 @@ def _newer(target, deps):
 
 
 STAMP = os.path.join(HERE, "libiso_hip.stamp")
+#: registers / scratch of every kernel of the library (written by build(), read by tests/test_resource_gate.py)
+RESOURCES = os.path.join(HERE, "libiso_hip.resources.json")
+
+
+class ResourceBudgetError(RuntimeError):
+    """A kernel of the library uses accumulation registers or more scratch than its family's budget (resources.py)."""
 
 
 def source_digest() -> str:
@@ -53,7 +59,7 @@ def source_digest() -> str:
     import hashlib
     h = hashlib.sha256()
     h.update(repr(FLAGS).encode())
-    for path in sources() + HEADERS + [os.path.abspath(__file__)]:
+    for path in sources() + HEADERS + [os.path.abspath(__file__), os.path.join(HERE, "resources.py")]:
         h.update(os.path.basename(path).encode() + b"\0")
         with open(path, "rb") as f:
             h.update(f.read())
@@ -91,10 +97,27 @@ def built_library_sha256():
 
 def up_to_date() -> bool:
     src, so = read_stamp()
-    return os.path.exists(OUT) and src == source_digest() and so is not None and so == file_sha256(OUT)
+    return (os.path.exists(OUT) and os.path.exists(RESOURCES) and src == source_digest() and so is not None
+            and so == file_sha256(OUT))
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def resource_table() -> dict:
+    """{kernel: {sgpr, vgpr, agpr, scratch, waves, sgpr_spill, ...}} of the library as built (hipcc's
+    -Rpass-analysis=kernel-resource-usage remarks of every translation unit)."""
+    import json
+    with open(RESOURCES) as f:
+        return json.load(f)
+
+
+def build(force: bool = False, verbose: bool = False, gate: bool = True) -> str:
+    """Compile what is out of date, link, record every kernel's register / scratch use and enforce the budget of
+    resources.py on it (gate; ISOCHRONES_AMD_RESOURCE_GATE=0 turns a violation into a warning for experiments)."""
+    import json
+    try:
+        from . import resources as R
+    except ImportError:                  # run as a script
+        sys.path.insert(0, HERE)
+        import resources as R
     digest = source_digest()
     if not force and not verbose and up_to_date():
         return OUT                       # this very file was built from exactly these sources: nothing to do
@@ -107,16 +130,52 @@ def build(force: bool = False, verbose: bool = False) -> str:
     for src in sources():
         obj = os.path.join(OBJDIR, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
-        if force or _newer(obj, [src, me] + HEADERS):
-            cmd = [cc] + FLAGS + (["-Rpass-analysis=kernel-resource-usage"] if verbose else []) + ["-c", src, "-o", obj]
-            jobs.append(cmd)
+        if force or _newer(obj, [src, me] + HEADERS) or not os.path.exists(obj[:-2] + ".res"):
+            jobs.append((([cc] + FLAGS + ["-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", obj]), obj[:-2] + ".res"))
+
+    def compile_one(job):
+        cmd, log = job
+        p = subprocess.run(cmd, cwd=HERE, stderr=subprocess.PIPE, text=True, errors="replace")
+        with open(log, "w") as f:
+            f.write(p.stderr)
+        # the remarks go to the log; anything else the compiler said (warnings, errors) is passed on
+        rest = [ln for ln in p.stderr.splitlines() if "kernel-resource-usage" not in ln and not R.is_remark_context(ln)]
+        if verbose:
+            sys.stderr.write(p.stderr)
+        elif rest and (p.returncode != 0 or any("warning:" in ln or "error:" in ln for ln in rest)):
+            sys.stderr.write("\n".join(rest) + "\n")
+        if p.returncode != 0:
+            try:
+                os.remove(log)
+            except OSError:
+                pass
+        return p.returncode
+
     if jobs:
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 2)) as ex:
-            for rc in ex.map(lambda c: subprocess.run(c, cwd=HERE).returncode, jobs):
+            for rc in ex.map(compile_one, jobs):
                 if rc != 0:
                     raise RuntimeError("hipcc failed")
+    table = {}
+    for obj in objs:
+        with open(obj[:-2] + ".res", errors="replace") as f:
+            table.update(R.parse(f.read()))
+    bad = R.violations(table)
+    if bad:
+        msg = ("%d kernel(s) of libiso_hip.so outside the resource budget (isochrones_amd/csrc/resources.py):\n  " % len(bad)
+               + "\n  ".join(bad[:40]) + ("\n  ..." if len(bad) > 40 else ""))
+        if gate and os.environ.get("ISOCHRONES_AMD_RESOURCE_GATE", "1") != "0":
+            for stale_file in (STAMP, RESOURCES):
+                try:
+                    os.remove(stale_file)      # never leave a stamp that calls such a library up to date
+                except OSError:
+                    pass
+            raise ResourceBudgetError(msg)
+        sys.stderr.write("WARNING: " + msg + "\n")
     if force or jobs or stale or _newer(OUT, objs):
         subprocess.check_call([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs, cwd=HERE)
+    with open(RESOURCES, "w") as f:
+        json.dump(table, f, indent=0, sort_keys=True)
     with open(STAMP, "w") as f:
         f.write(digest + "\n" + file_sha256(OUT) + "\n")
     return OUT

@@ -104,6 +104,13 @@ __device__ __forceinline__ void lds_bracket4(const double* lds, const FastAxis a
 //   i = clamp(#{a_j <= x} - 1, 0, n - 2),  t = (x - a_i) / (a_{i+1} - a_i)        (a true division: no table of 1/spacing)
 // - the rule of the LDS axes, i.e. searchsorted + find_indices bit for bit.  The branch is wave-uniform (a kernel
 // argument), so the uniform case pays one scalar compare for it.
+__device__ __forceinline__ int cvt_i32_saturating(double v)
+{
+    int r;
+    asm("v_cvt_i32_f64 %0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+
 __device__ __forceinline__ bool eep_oob(const FastArgs& A, double x)
 {
     return bool((x < A.e_a0) | (x > A.e_last));
@@ -149,7 +156,10 @@ __device__ __forceinline__ void eep_bracket(const FastArgs& A, const double* lds
         t = (x - lo) / (hi - lo);
         return;
     }
-    int k = (int)((x - A.e_a0) * A.e_inv);
+    // brackets are computed for every lane, usable or not (lnpost_wave): x may be NaN or far outside the axis here.  A C++
+    // cast of such a value is undefined (fptosi poison); the hardware conversion is not - v_cvt_i32_f64 saturates and
+    // maps NaN to 0 - so the instruction is named directly: same single instruction, defined for every input
+    int k = cvt_i32_saturating((x - A.e_a0) * A.e_inv);
     k = max(0, min(k, n - 2));
     const double lo = fma((double)k, A.e_step, A.e_a0);
     if (lo > x) --k;

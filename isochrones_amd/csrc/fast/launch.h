@@ -1,5 +1,9 @@
 // kernel launch switches over the band count
 // (part of iso_fast_kernel.h: included inside namespace iso::fastk)
+//
+// Every launcher names the instantiation it chose (note_kernel: a no-op unless iso_debug_trace_kernels(1) was called) in
+// the spelling c++filt gives the kernel's symbol, so that tests/test_gpu_dispatch_table.py can tick off every kernel the
+// build compiled (libiso_hip.resources.json) against the oracle.
 #pragma once
 
 // dynamic LDS of the persistent form; the host uses it to decide whether an ensemble fits
@@ -7,6 +11,47 @@ inline size_t stretch_persist_lds_bytes(int axes_len, int nb, int W, int np, boo
 {
     return (size_t)(((axes_len + 1) & ~1) + BLOCK * persist_slot_stride(dense, nb, np - 4) +
                     persist_extra_doubles(W, np, persist_slim(dense, nb, np - 4))) * sizeof(double);
+}
+
+// The persistent instantiation a run takes - ONE place decides it, for the occupancy query and for the launch alike
+// (round 3 queried the catalog form even when the single-model forms, with other register counts, were launched):
+//   dense                     register-capped: 4 (single stars, <= 6 bands) or 3 workgroups per CU, catalogs / many ensembles in rounds
+//   multi                     catalog, every workgroup resident: uncapped registers
+//   single model, std priors  UNI + STDP: model block through scalar loads, prior families compile-time constants
+//   single model              UNI
+// Models with asteroseismic terms (ASTERO) are single models by construction (iso_catalog_create refuses them) and
+// have no register-capped form: a run of very many ensembles of such a model takes the UNI kernel in rounds.
+struct PersistKernel {
+    const void* fn;
+    bool dense;
+    char name[96];
+};
+
+template <int KIND, int NS, int N, bool ASTERO>
+inline PersistKernel persist_kernel(const StretchArgs& S)
+{
+    PersistKernel k;
+    bool dense = S.dense != 0, uni = false, stdp = false;
+    if constexpr (ASTERO) {
+        dense = false;
+        uni = true;
+        stdp = S.std_priors != 0;
+        k.fn = stdp ? (const void*)k_stretch_persist<KIND, NS, N, false, true, true, true>
+                    : (const void*)k_stretch_persist<KIND, NS, N, false, true, true, false>;
+    } else if (dense) {
+        k.fn = (const void*)k_stretch_persist<KIND, NS, N, true, false>;
+    } else if (S.multi) {
+        if constexpr (N == 0) k.fn = nullptr;          // a catalog has 1-12 bands (iso_catalog_create)
+        else k.fn = (const void*)k_stretch_persist<KIND, NS, N, false, false>;
+    } else {
+        uni = true;
+        stdp = S.std_priors != 0;
+        k.fn = stdp ? (const void*)k_stretch_persist<KIND, NS, N, false, false, true, true>
+                    : (const void*)k_stretch_persist<KIND, NS, N, false, false, true, false>;
+    }
+    k.dense = dense;
+    snprintf(k.name, sizeof k.name, "k_stretch_persist<%d, %d, %d, %s, %s, %s, %s>", KIND, NS, N, tf(dense), tf(ASTERO), tf(uni), tf(stdp));
+    return k;
 }
 
 template <int KIND, int NS, bool ASTERO = false>
@@ -17,72 +62,55 @@ inline bool launch_stretch_nb(int nb, const FastArgs& A, const StretchArgs& S, h
         const int64_t n_ens = S.n_active / (S.W >> 1);
         const int G = persist_group(S.W);
         const dim3 gp((unsigned)((n_ens + G - 1) / G));
-        auto shp = [&](int n) { return stretch_persist_lds_bytes(A.axes_len, n, S.W, NS + 4, S.dense != 0); };
+        PersistKernel k;
         switch (nb) {
-        // with S.occupancy_query set: report resident workgroups per CU of this instantiation, launch nothing
-#define ISO_PERSIST_CASE(N)                                                                               \
-        case N:                                                                                           \
-            if (S.occupancy_query) {                                                                      \
-                const hipError_t qe = S.dense                                                             \
-                    ? hipOccupancyMaxActiveBlocksPerMultiprocessor(S.occupancy_query,                     \
-                                                                   k_stretch_persist<KIND, NS, N, true, ASTERO>,  \
-                                                                   BLOCK, shp(N))                         \
-                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(S.occupancy_query,                     \
-                                                                   k_stretch_persist<KIND, NS, N, false, ASTERO>, \
-                                                                   BLOCK, shp(N));                        \
-                return qe == hipSuccess;                                                                  \
-            }                                                                                             \
-            if (S.dense) hipLaunchKernelGGL((k_stretch_persist<KIND, NS, N, true, ASTERO>), gp, b, shp(N), s, A, S);   \
-            else if (S.multi) hipLaunchKernelGGL((k_stretch_persist<KIND, NS, N, false, ASTERO>), gp, b, shp(N), s, A, S); \
-            else if (S.std_priors) hipLaunchKernelGGL((k_stretch_persist<KIND, NS, N, false, ASTERO, true, true>), gp, b, shp(N), s, A, S); \
-            else hipLaunchKernelGGL((k_stretch_persist<KIND, NS, N, false, ASTERO, true>), gp, b, shp(N), s, A, S);   \
-            return true;
+#define ISO_PERSIST_CASE(N) case N: k = persist_kernel<KIND, NS, N, ASTERO>(S); break;
             ISO_PERSIST_CASE(0) ISO_PERSIST_CASE(1) ISO_PERSIST_CASE(2) ISO_PERSIST_CASE(3) ISO_PERSIST_CASE(4) ISO_PERSIST_CASE(5)
             ISO_PERSIST_CASE(6) ISO_PERSIST_CASE(7) ISO_PERSIST_CASE(8) ISO_PERSIST_CASE(9) ISO_PERSIST_CASE(10)
             ISO_PERSIST_CASE(11) ISO_PERSIST_CASE(12)
 #undef ISO_PERSIST_CASE
         default: return false;
         }
+        if (!k.fn) return false;
+        const size_t lds_bytes = stretch_persist_lds_bytes(A.axes_len, nb, S.W, NS + 4, k.dense);
+        // with S.occupancy_query set: report resident workgroups per CU of this instantiation, launch nothing
+        if (S.occupancy_query)
+            return hipOccupancyMaxActiveBlocksPerMultiprocessor(S.occupancy_query, k.fn, BLOCK, lds_bytes) == hipSuccess;
+        note_kernel("%s", k.name);
+        void* args[] = {const_cast<FastArgs*>(&A), const_cast<StretchArgs*>(&S)};
+        return hipLaunchKernel(k.fn, gp, b, args, lds_bytes, s) == hipSuccess;
     }
     const dim3 g((unsigned)((S.n_active + BLOCK - 1) / BLOCK));
     auto sh = [&](int n) { return (size_t)(((A.axes_len + 1) & ~1) + coop_lds_doubles(n)) * sizeof(double); };
     switch (nb) {
-    case 0: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 0, ASTERO>), g, b, sh(0), s, A, S); return true;
-    case 1: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 1, ASTERO>), g, b, sh(1), s, A, S); return true;
-    case 2: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 2, ASTERO>), g, b, sh(2), s, A, S); return true;
-    case 3: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 3, ASTERO>), g, b, sh(3), s, A, S); return true;
-    case 4: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 4, ASTERO>), g, b, sh(4), s, A, S); return true;
-    case 5: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 5, ASTERO>), g, b, sh(5), s, A, S); return true;
-    case 6: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 6, ASTERO>), g, b, sh(6), s, A, S); return true;
-    case 7: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 7, ASTERO>), g, b, sh(7), s, A, S); return true;
-    case 8: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 8, ASTERO>), g, b, sh(8), s, A, S); return true;
-    case 9: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 9, ASTERO>), g, b, sh(9), s, A, S); return true;
-    case 10: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 10, ASTERO>), g, b, sh(10), s, A, S); return true;
-    case 11: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 11, ASTERO>), g, b, sh(11), s, A, S); return true;
-    case 12: hipLaunchKernelGGL((k_stretch_half<KIND, NS, 12, ASTERO>), g, b, sh(12), s, A, S); return true;
+#define ISO_HALF_CASE(N)                                                                              \
+    case N:                                                                                           \
+        note_kernel("k_stretch_half<%d, %d, %d, %s>", KIND, NS, N, tf(ASTERO));                       \
+        hipLaunchKernelGGL((k_stretch_half<KIND, NS, N, ASTERO>), g, b, sh(N), s, A, S);              \
+        return true;
+        ISO_HALF_CASE(0) ISO_HALF_CASE(1) ISO_HALF_CASE(2) ISO_HALF_CASE(3) ISO_HALF_CASE(4) ISO_HALF_CASE(5) ISO_HALF_CASE(6)
+        ISO_HALF_CASE(7) ISO_HALF_CASE(8) ISO_HALF_CASE(9) ISO_HALF_CASE(10) ISO_HALF_CASE(11) ISO_HALF_CASE(12)
+#undef ISO_HALF_CASE
     default: return false;
     }
 }
 
-template <int KIND, int NS, bool PACKED, bool MULTI, bool ASTERO = false>
+template <int KIND, int NS, bool MULTI, bool ASTERO = false>
 inline bool launch_nb(int nb, const FastArgs& A, hipStream_t s)
 {
     const dim3 g((unsigned)((A.n + BLOCK - 1) / BLOCK)), b(BLOCK);
-    auto sh = [&](int n) { return (size_t)(((A.axes_len + 1) & ~1) + (PACKED ? coop_lds_doubles(n) : 0)) * sizeof(double); };
+    auto sh = [&](int n) { return (size_t)(((A.axes_len + 1) & ~1) + coop_lds_doubles(n)) * sizeof(double); };
     switch (nb) {
-    case 0: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 0, PACKED, MULTI, ASTERO>), g, b, sh(0), s, A); return true;
-    case 1: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 1, PACKED, MULTI, ASTERO>), g, b, sh(1), s, A); return true;
-    case 2: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 2, PACKED, MULTI, ASTERO>), g, b, sh(2), s, A); return true;
-    case 3: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 3, PACKED, MULTI, ASTERO>), g, b, sh(3), s, A); return true;
-    case 4: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 4, PACKED, MULTI, ASTERO>), g, b, sh(4), s, A); return true;
-    case 5: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 5, PACKED, MULTI, ASTERO>), g, b, sh(5), s, A); return true;
-    case 6: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 6, PACKED, MULTI, ASTERO>), g, b, sh(6), s, A); return true;
-    case 7: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 7, PACKED, MULTI, ASTERO>), g, b, sh(7), s, A); return true;
-    case 8: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 8, PACKED, MULTI, ASTERO>), g, b, sh(8), s, A); return true;
-    case 9: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 9, PACKED, MULTI, ASTERO>), g, b, sh(9), s, A); return true;
-    case 10: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 10, PACKED, MULTI, ASTERO>), g, b, sh(10), s, A); return true;
-    case 11: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 11, PACKED, MULTI, ASTERO>), g, b, sh(11), s, A); return true;
-    case 12: hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, 12, PACKED, MULTI, ASTERO>), g, b, sh(12), s, A); return true;
+#define ISO_FAST_CASE(N)                                                                              \
+    case N:                                                                                           \
+        if constexpr (MULTI && N == 0) return false;      /* a catalog has 1-12 bands (iso_catalog_create) */ \
+        else {                                                                                        \
+        note_kernel("k_lnpost_fast<%d, %d, %d, %s, %s>", KIND, NS, N, tf(MULTI), tf(ASTERO));         \
+        hipLaunchKernelGGL((k_lnpost_fast<KIND, NS, N, MULTI, ASTERO>), g, b, sh(N), s, A);           \
+        return true; }
+        ISO_FAST_CASE(0) ISO_FAST_CASE(1) ISO_FAST_CASE(2) ISO_FAST_CASE(3) ISO_FAST_CASE(4) ISO_FAST_CASE(5) ISO_FAST_CASE(6)
+        ISO_FAST_CASE(7) ISO_FAST_CASE(8) ISO_FAST_CASE(9) ISO_FAST_CASE(10) ISO_FAST_CASE(11) ISO_FAST_CASE(12)
+#undef ISO_FAST_CASE
     default: return false;
     }
 }

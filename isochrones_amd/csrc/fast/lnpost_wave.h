@@ -3,7 +3,7 @@
 #pragma once
 
 // lnpost of the lane's sample (p = its NS+4 parameters).  Shared by the batch kernel and the
-// sampler kernel.  With PACKED every gather is wave-cooperative, so ALL 64 lanes of the wave must
+// sampler kernel.  The gathers are wave-cooperative (corner-packed tables), so ALL 64 lanes of the wave must
 // call this function together; `active` = the lane really has a sample (inactive lanes only help).
 // MASKED (catalog rows and the sampler kernels): a band whose observed magnitude is NaN is a band this star
 // was not observed in - its term is skipped, as the reference drops NaN measurements when it builds a model
@@ -12,12 +12,12 @@
 // taken tile by tile over the A.nb_total bands of the corner-packed BC cell (each star's BC bracket is found once and kept).
 // STDP: the model's priors are the reference's default families (Chabrier mass, flat-in-age, local-disk [Fe/H],
 // power-law distance, flat AV - the host checks the records): the families are compile-time constants here.
-// LANE (with PACKED; bit 0: model table and asteroseismic pair, bit 1: BC table): every lane gathers its own sample
+// LANE (bit 0: model table and asteroseismic pair, bit 1: BC table): every lane gathers its own sample
 // from the corner-packed table (gather_lane.h) - the latency form of a lone workgroup.
 // bit 2 of LANE: the priors that do not depend on the model table are evaluated between the issue of the primary's
 // model gather and the use of its data (coop_star's `between`).
 constexpr int LANE_BC_MAX_BANDS = 4;
-template <int KIND, int NS, int NB, bool PACKED, bool ASTERO = false, bool MASKED = false, bool TILED = false, bool STDP = false,
+template <int KIND, int NS, int NB, bool ASTERO = false, bool MASKED = false, bool TILED = false, bool STDP = false,
           int LANE = 0>
 __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* lds, const CoopLds& L, bool active,
                                               const DevModel& M, const DevModel& MP, const double* __restrict__ p, bool want_parts,
@@ -43,7 +43,7 @@ __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* l
     // added up further down in the reference's order either way, so the sum is the same number
     constexpr int K_MASS = STDP ? ISO_PRIOR_CHABRIER : -1, K_AGE = STDP ? ISO_PRIOR_FLATLOG : -1, K_FEH = STDP ? ISO_PRIOR_FEH : -1,
                   K_DIST = STDP ? ISO_PRIOR_POWERLAW : -1, K_AV = STDP ? ISO_PRIOR_FLAT : -1;
-    constexpr bool OVERLAP = PACKED && (LANE & 4) != 0 && (LANE & 1) == 0;
+    constexpr bool OVERLAP = (LANE & 4) != 0 && (LANE & 1) == 0;
     double ld = 0.0, t_first = 0.0, t_feh = 0.0, t_dist = 0.0, t_av = 0.0;
     auto table_free_priors = [&]() {
         ld = fast_log(dist);
@@ -60,7 +60,7 @@ __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* l
         const bool ok = bool(ok01 & !(eep != eep) & !eep_oob(A, eep));
         int i2;
         eep_bracket(A, lds, eep, i2, w.t2);
-        if (PACKED) {
+        {
             uint32_t cell = cell3(A, i0, i1, i2);
             ISO_STAMP(2, cell);
             if constexpr (LANE & 1) lane_star(A, ok, cell, w, star[s]);
@@ -75,11 +75,6 @@ __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* l
                 if constexpr (LANE & 1) lane_pair(A.astq, ok && M.has_numax, cell, w, astero);
                 else coop_pair(A.astq, L, ok && M.has_numax, cell, w, astero);
             }
-        } else if (ok) {
-            gather_star(A, i0, i1, i2, w, star[s]);
-        } else {
-#pragma unroll
-            for (int q = 0; q < 6; ++q) star[s][q] = f_nan();
         }
     }
 
@@ -106,7 +101,6 @@ __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* l
     const bool go = active && (prior_ok || want_parts);     // evaluate the likelihood for this lane
     lnp_out = lnp;
     lnl_out = f_nan();
-    if (!PACKED && !go) return -f_inf();            // lane-wise path: nothing cooperative follows
 
     // ---- lnlike ----
     double lnl = 0.0;
@@ -127,7 +121,7 @@ __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* l
     }
     const double dm = fma(ld, 5.0 * kInvLn10, -5.0);   // 5*log10(d/10)
     if constexpr (TILED) {
-        static_assert(PACKED && NB > 0, "band tiles run on the corner-packed tables");
+        static_assert(NB > 0, "a band tile has at least one band");
         const int nbt = A.nb_total;
         const bool okA = bool(go & !(AV != AV) & !lds_oob(lds, A.b3, AV));
         bool okb[NS];
@@ -184,20 +178,14 @@ __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* l
             int j0, j1, j2, j3;
             W4 w4v;
             lds_bracket4(lds, A.b0, A.b1, A.b2, A.b3, T, g, f, AV, j0, j1, j2, j3, w4v.t0, w4v.t1, w4v.t2, w4v.t3);
-            if (PACKED) {
+            {
                 uint32_t cell = cell4(A, j0, j1, j2, j3);
                 ISO_STAMP(5, cell);
-                // (the lane form keeps 8 NB pieces of 16 B in flight per lane: up to four bands.  Beyond that it pushed the
-                // single-model kernels of the large shapes to 256 vector + 100-odd accumulation registers - the regime in which
-                // one of them went wrong under a field reordering, DESIGN section 7 - for a gather that is no faster there)
+                // (the lane form keeps 8 NB pieces of 16 B in flight per lane: up to four bands - beyond that the cooperative
+                // gather is no slower and the kernel needs far fewer registers; DESIGN section 7 has the history)
                 if constexpr ((LANE & 2) != 0 && NB <= LANE_BC_MAX_BANDS) lane_bc<NB>(A, ok, cell, w4v, bc);
                 else coop_bc<NB>(A, L, ok, cell, w4v, bc);
                 ISO_STAMP(6, bc[0]);
-            } else if (ok) {
-                gather_bc<NB>(A, j0, j1, j2, j3, w4v, bc);
-            } else {
-    #pragma unroll
-                for (int b = 0; b < NB; ++b) bc[b] = f_nan();
             }
             // total magnitude of an unresolved system (reference utils.py:67-75: -2.5 log10 sum_c 10^(-0.4 m_c)) written
             // relative to the primary, m_0 - 2.5 log10(1 + sum_{c>0} 10^(-0.4 (m_c - m_0))): the same number to a few ulp
@@ -251,13 +239,13 @@ __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* l
     return prior_ok ? lnp + lnl : -f_inf();
 }
 
-template <int KIND, int NS, int NB, bool PACKED, bool ASTERO = false, bool MASKED = false, bool TILED = false, bool STDP = false,
+template <int KIND, int NS, int NB, bool ASTERO = false, bool MASKED = false, bool TILED = false, bool STDP = false,
           int LANE = 0>
 __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* lds, const CoopLds& L, bool active,
                                               const DevModel& M, const double* __restrict__ p, bool want_parts,
                                               double& lnp_out, double& lnl_out)
 {
-    return lnpost_wave<KIND, NS, NB, PACKED, ASTERO, MASKED, TILED, STDP, LANE>(A, lds, L, active, M, M, p, want_parts, lnp_out, lnl_out);
+    return lnpost_wave<KIND, NS, NB, ASTERO, MASKED, TILED, STDP, LANE>(A, lds, L, active, M, M, p, want_parts, lnp_out, lnl_out);
 }
 
 // LDS layout of the fast kernels: [axes blob, rounded to an even count][request slots][response slots]
@@ -306,7 +294,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_lnpost_wide(const FastArgs A)
         for (int j = 0; j < NP; ++j) p[j] = src[j * A.stride_p];
     }
     double lnp, lnl;
-    const double r = lnpost_wave<KIND, NS, wide_tile(NS), true, false, false, true>(A, lds, L, active, M, p, A.lnlike != nullptr, lnp, lnl);
+    const double r = lnpost_wave<KIND, NS, wide_tile(NS), false, false, true>(A, lds, L, active, M, p, A.lnlike != nullptr, lnp, lnl);
     if (active) {
         if (A.lnpost) A.lnpost[i] = r;
         if (A.lnprior) A.lnprior[i] = lnp;
@@ -325,7 +313,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_lnpost_wide(const FastArgs A)
 // (the asteroseismic instantiation carries two more gathered values and one more cooperative gather: at the 80
 // registers of 6 waves it spills 56-68 B per lane and every added byte of scratch shows - 117 -> 134 us when the
 // non-uniform-axis branch raised it from 56 to 68 B; at 5 waves it does not spill)
-template <int KIND, int NS, int NB, bool PACKED, bool MULTI, bool ASTERO = false>
+template <int KIND, int NS, int NB, bool MULTI, bool ASTERO = false>
 __global__ __launch_bounds__(BLOCK, ASTERO ? (fast_min_waves(NS, NB) > 5 ? 5 : fast_min_waves(NS, NB)) : fast_min_waves(NS, NB))
 void k_lnpost_fast(const FastArgs A)
 {
@@ -346,7 +334,7 @@ void k_lnpost_fast(const FastArgs A)
     }
     double lnp, lnl;
     const DevModel& MP = (MULTI && A.shared_priors) ? A.m[0] : M;
-    const double r = lnpost_wave<KIND, NS, NB, PACKED, ASTERO, MULTI>(A, lds, L, active, M, MP, p, A.lnlike != nullptr, lnp, lnl);
+    const double r = lnpost_wave<KIND, NS, NB, ASTERO, MULTI>(A, lds, L, active, M, MP, p, A.lnlike != nullptr, lnp, lnl);
     if (active) {
         if (A.lnpost) A.lnpost[i] = r;
         if (A.lnprior) A.lnprior[i] = lnp;

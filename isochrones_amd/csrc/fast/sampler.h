@@ -86,7 +86,7 @@ __device__ __forceinline__ void stretch_move(const FastArgs& A, const StretchArg
     // UNI: a single star's fit (or a few ensembles of it) - one workgroup per CU at most, nothing to overlap with
     const DevModel& MP = SHAREDP ? *(const DevModel*)((const_model_ptr)(uintptr_t)A.m)
                                  : ((!UNI && S.multi && A.shared_priors) ? A.m[0] : M);      // catalogs: the priors all stars share
-    const double lnew = lnpost_wave<KIND, NS, NB, true, ASTERO, true, false, STDP, LANE>(A, lds, L, active, M, MP, y, false, lnp_unused, lnl_unused);
+    const double lnew = lnpost_wave<KIND, NS, NB, ASTERO, true, false, STDP, LANE>(A, lds, L, active, M, MP, y, false, lnp_unused, lnl_unused);
     const double lnq = (NP - 1) * fast_log(z) + lnew - lold;
     const bool acc = active && isfinite(lnew) && (fast_log(u2) < lnq);
     if (acc) {
@@ -147,7 +147,7 @@ __device__ __forceinline__ MoveIds move_ids(const StretchArgs& S, int tid)
 
 // five waves per SIMD up to 7 bands (93-96 registers, at most 12 B of scratch); beyond that the evaluation itself
 // needs 138-168 registers and the cap would only spill
-constexpr int stretch_half_waves(int nb) { return nb <= 7 ? 5 : 1; }
+constexpr int stretch_half_waves(int nb) { return nb <= 7 ? 5 : 2; }
 
 template <int KIND, int NS, int NB, bool ASTERO = false>
 __global__ __launch_bounds__(BLOCK, stretch_half_waves(NB)) void k_stretch_half(const FastArgs A, const StretchArgs S)
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(BLOCK, stretch_half_waves(NB)) void k_stretch_half(
     }
     double lnp_unused, lnl_unused;
     const DevModel* MPp = (S.multi && A.shared_priors) ? A.m : Mp;
-    const double lnew = lnpost_wave<KIND, NS, NB, true, ASTERO, true>(A, lds, L, active, *Mp, *MPp, y, false, lnp_unused, lnl_unused);
+    const double lnew = lnpost_wave<KIND, NS, NB, ASTERO, true>(A, lds, L, active, *Mp, *MPp, y, false, lnp_unused, lnl_unused);
     // ---- decide and store: everything about the move is rebuilt from the thread index ----
     int tid = (int)threadIdx.x;
     asm volatile("" : "+v"(tid));
@@ -232,7 +232,7 @@ __host__ __device__ constexpr int persist_extra_doubles(int W, int np, bool slim
 // DENSE: registers capped so that 3 (slim: 4) workgroups share a CU; the uncapped form (2 workgroups per CU) is 10 %
 // faster when latency is all that matters (every workgroup resident at once, e.g. a single star's fit).
 template <int KIND, int NS, int NB, bool DENSE, bool ASTERO = false, bool UNI = false, bool STDP = false>
-__global__ __launch_bounds__(BLOCK, DENSE ? (persist_slim(DENSE, NB, NS) ? 4 : 3) : 1) void k_stretch_persist(const FastArgs A, const StretchArgs S)
+__global__ __launch_bounds__(BLOCK, DENSE ? (persist_slim(DENSE, NB, NS) ? 4 : 3) : 2) void k_stretch_persist(const FastArgs A, const StretchArgs S)
 {
     extern __shared__ double lds[];
     for (int j = threadIdx.x; j < A.axes_len; j += BLOCK) lds[j] = A.axes_blob[j];

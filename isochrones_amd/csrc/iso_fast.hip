@@ -3,16 +3,16 @@
 
 namespace iso {
 
-bool launch_lnpost_fast(int kind, int n_stars, int n_bands, bool packed, bool multi, const FastArgs& A,
-                        hipStream_t s)
+bool launch_lnpost_fast(int kind, int n_stars, int n_bands, bool multi, const FastArgs& A, hipStream_t s)
 {
+    if (!A.hotq || (!A.bcq && n_bands > 0)) return false;      // no corner-packed tables: the generic kernel's business
     if (n_bands > fastk::FAST_MAX_NB)        // 13-32 bands: band-tiled batch kernels (iso_fast_wide.hip)
-        return packed && !multi && !A.astq && launch_fast_wide(kind, n_stars, A, s);
-    if (kind == ISO_KIND_TRACK) return n_stars == 1 && launch_fast_track1(n_bands, packed, multi, A, s);
+        return !multi && !A.astq && launch_fast_wide(kind, n_stars, A, s);
+    if (kind == ISO_KIND_TRACK) return n_stars == 1 && launch_fast_track1(n_bands, multi, A, s);
     switch (n_stars) {
-    case 1: return launch_fast_iso1(n_bands, packed, multi, A, s);
-    case 2: return launch_fast_iso2(n_bands, packed, multi, A, s);
-    case 3: return launch_fast_iso3(n_bands, packed, multi, A, s);
+    case 1: return launch_fast_iso1(n_bands, multi, A, s);
+    case 2: return launch_fast_iso2(n_bands, multi, A, s);
+    case 3: return launch_fast_iso3(n_bands, multi, A, s);
     }
     return false;
 }

@@ -115,14 +115,12 @@ static __device__ unsigned long long g_phase_stamps[16];
 }  // namespace fastk
 
 // one definition per translation unit iso_fast_<tag>.hip
-// (the catalog form is only built on the corner-packed layout)
+// (the fused kernels read the corner-packed tables only; a model whose interpolator has none runs the generic kernel)
 #define ISO_DEFINE_FAST_LAUNCHER(NAME, KIND, NS)                                              \
-    bool NAME(int nb, bool packed, bool multi, const FastArgs& A, hipStream_t s)              \
+    bool NAME(int nb, bool multi, const FastArgs& A, hipStream_t s)                           \
     {                                                                                         \
-        if (A.astq) return packed && !multi && fastk::launch_nb<KIND, NS, true, false, true>(nb, A, s); \
-        if (multi) return packed && fastk::launch_nb<KIND, NS, true, true>(nb, A, s);         \
-        return packed ? fastk::launch_nb<KIND, NS, true, false>(nb, A, s)                     \
-                      : fastk::launch_nb<KIND, NS, false, false>(nb, A, s);                   \
+        if (A.astq) return !multi && fastk::launch_nb<KIND, NS, false, true>(nb, A, s);       \
+        return multi ? fastk::launch_nb<KIND, NS, true>(nb, A, s) : fastk::launch_nb<KIND, NS, false>(nb, A, s); \
     }
 
 #define ISO_DEFINE_STRETCH_LAUNCHER(NAME, KIND, NS)                                           \
@@ -148,9 +146,9 @@ bool launch_stretch_iso1(int nb, const FastArgs& A, const StretchArgs& S, hipStr
 bool launch_stretch_iso2(int nb, const FastArgs& A, const StretchArgs& S, hipStream_t s);
 bool launch_stretch_iso3(int nb, const FastArgs& A, const StretchArgs& S, hipStream_t s);
 bool launch_fast_wide(int kind, int n_stars, const FastArgs& A, hipStream_t s);
-bool launch_fast_track1(int nb, bool packed, bool multi, const FastArgs& A, hipStream_t s);
-bool launch_fast_iso1(int nb, bool packed, bool multi, const FastArgs& A, hipStream_t s);
-bool launch_fast_iso2(int nb, bool packed, bool multi, const FastArgs& A, hipStream_t s);
-bool launch_fast_iso3(int nb, bool packed, bool multi, const FastArgs& A, hipStream_t s);
+bool launch_fast_track1(int nb, bool multi, const FastArgs& A, hipStream_t s);
+bool launch_fast_iso1(int nb, bool multi, const FastArgs& A, hipStream_t s);
+bool launch_fast_iso2(int nb, bool multi, const FastArgs& A, hipStream_t s);
+bool launch_fast_iso3(int nb, bool multi, const FastArgs& A, hipStream_t s);
 
 }  // namespace iso

@@ -8,7 +8,7 @@ namespace iso {
 namespace fastk {
 
 template <int KIND, int NB>
-__global__ __launch_bounds__(BLOCK) void k_interp_mag_fast(const FastArgs A, const MagOut O)
+__global__ __launch_bounds__(BLOCK, 2) void k_interp_mag_fast(const FastArgs A, const MagOut O)
 {
     extern __shared__ double lds[];
     for (int j = threadIdx.x; j < A.axes_len; j += BLOCK) lds[j] = A.axes_blob[j];
@@ -65,7 +65,7 @@ static bool launch_mag_nb(int nb, const FastArgs& A, const MagOut& O, hipStream_
     auto sh = [&](int n) { return (size_t)(((A.axes_len + 1) & ~1) + coop_lds_doubles(n)) * sizeof(double); };
     switch (nb) {
 #define ISO_MAG_CASE(N) \
-    case N: hipLaunchKernelGGL((k_interp_mag_fast<KIND, N>), g, b, sh(N), s, A, O); return true;
+    case N: note_kernel("k_interp_mag_fast<%d, %d>", KIND, N); hipLaunchKernelGGL((k_interp_mag_fast<KIND, N>), g, b, sh(N), s, A, O); return true;
         ISO_MAG_CASE(1) ISO_MAG_CASE(2) ISO_MAG_CASE(3) ISO_MAG_CASE(4) ISO_MAG_CASE(5) ISO_MAG_CASE(6)
         ISO_MAG_CASE(7) ISO_MAG_CASE(8) ISO_MAG_CASE(9) ISO_MAG_CASE(10) ISO_MAG_CASE(11) ISO_MAG_CASE(12)
 #undef ISO_MAG_CASE

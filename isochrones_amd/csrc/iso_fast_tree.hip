@@ -76,7 +76,7 @@ template <int NL>
 constexpr int tree_block() { return NL > 0 ? BLOCK : 64; }
 
 template <int NB, int NL>
-__global__ __launch_bounds__(tree_block<NL>()) void k_lnpost_tree_fast(const FastArgs A, const DevTree* __restrict__ Tp)
+__global__ __launch_bounds__(tree_block<NL>(), 2) void k_lnpost_tree_fast(const FastArgs A, const DevTree* __restrict__ Tp)
 {
     constexpr int TB = tree_block<NL>();
     extern __shared__ double lds[];
@@ -231,17 +231,20 @@ static bool launch_tree_nl(int nb, int n_leaves, const FastArgs& A, const DevTre
     if (sh(nb) > 64 * 1024) return false;      // (7-8 stars x 10-12 bands: the generic tree kernel takes those)
     switch (nb) {
 #define ISO_TREE_CASE(N) \
-    case N: hipLaunchKernelGGL((k_lnpost_tree_fast<N, NL>), g, b, sh(N), s, A, T); return true;
+    case N: note_kernel("k_lnpost_tree_fast<%d, %d>", N, NL); hipLaunchKernelGGL((k_lnpost_tree_fast<N, NL>), g, b, sh(N), s, A, T); return true;
         ISO_TREE_CASE(1) ISO_TREE_CASE(2) ISO_TREE_CASE(3) ISO_TREE_CASE(4) ISO_TREE_CASE(5) ISO_TREE_CASE(6)
         ISO_TREE_CASE(7) ISO_TREE_CASE(8)
     default: break;
     }
-    if (NL != 0) return false;
-    switch (nb) {
-        ISO_TREE_CASE(9) ISO_TREE_CASE(10) ISO_TREE_CASE(11) ISO_TREE_CASE(12)
-#undef ISO_TREE_CASE
-    default: return false;
+    if constexpr (NL != 0) {
+        return false;                          // 9-12 bands exist in the runtime-leaf form only
+    } else {
+        switch (nb) {
+            ISO_TREE_CASE(9) ISO_TREE_CASE(10) ISO_TREE_CASE(11) ISO_TREE_CASE(12)
+        default: return false;
+        }
     }
+#undef ISO_TREE_CASE
 }
 
 // n_leaves 1..4 with up to 8 bands run the register-resident instantiation, everything else the runtime one

@@ -9,13 +9,14 @@ bool launch_fast_wide(int kind, int n_stars, const FastArgs& A, hipStream_t s)
     const size_t sh = (size_t)(((A.axes_len + 1) & ~1) + fastk::coop_lds_doubles(fastk::WIDE_TILE)) * sizeof(double);
     if (kind == ISO_KIND_TRACK) {
         if (n_stars != 1) return false;
+        note_kernel("k_lnpost_wide<%d, 1>", ISO_KIND_TRACK);
         hipLaunchKernelGGL((fastk::k_lnpost_wide<ISO_KIND_TRACK, 1>), g, b, sh, s, A);
         return true;
     }
     switch (n_stars) {
-    case 1: hipLaunchKernelGGL((fastk::k_lnpost_wide<ISO_KIND_ISO, 1>), g, b, sh, s, A); return true;
-    case 2: hipLaunchKernelGGL((fastk::k_lnpost_wide<ISO_KIND_ISO, 2>), g, b, sh, s, A); return true;
-    case 3: hipLaunchKernelGGL((fastk::k_lnpost_wide<ISO_KIND_ISO, 3>), g, b, sh, s, A); return true;
+    case 1: note_kernel("k_lnpost_wide<%d, 1>", ISO_KIND_ISO); hipLaunchKernelGGL((fastk::k_lnpost_wide<ISO_KIND_ISO, 1>), g, b, sh, s, A); return true;
+    case 2: note_kernel("k_lnpost_wide<%d, 2>", ISO_KIND_ISO); hipLaunchKernelGGL((fastk::k_lnpost_wide<ISO_KIND_ISO, 2>), g, b, sh, s, A); return true;
+    case 3: note_kernel("k_lnpost_wide<%d, 3>", ISO_KIND_ISO); hipLaunchKernelGGL((fastk::k_lnpost_wide<ISO_KIND_ISO, 3>), g, b, sh, s, A); return true;
     }
     return false;
 }

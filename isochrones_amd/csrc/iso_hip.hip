@@ -41,6 +41,8 @@
 // ======================================================================================
 // host-side bookkeeping
 // ======================================================================================
+#include <cstdarg>
+#include <cstdio>
 #include "iso_internal.h"
 #include "fast/axis_lut.h"
 
@@ -248,6 +250,7 @@ hipError_t pack_corners(const double* src, int ncol, int keep, int ndim, const i
     hipError_t e = hipMalloc(out, bytes);
     if (e != hipSuccess) return e;
     P.out = *out;
+    note_kernel("k_pack_corners");
     hipLaunchKernelGGL(k_pack_corners, dim3(grid_blocks(P.ncells * (1 << ndim) * keep)), dim3(BLOCK), 0, 0, P);
     e = hipGetLastError();
     if (e == hipSuccess) e = hipDeviceSynchronize();
@@ -315,6 +318,7 @@ int ensure_wide_pack(iso_table* t, int64_t n)
     P.out = w;
     P.n0 = t->shape[0]; P.n1 = t->shape[1]; P.n2 = t->shape[2];
     P.ncol = (int)t->shape[3];
+    note_kernel("k_pack_wide");
     hipLaunchKernelGGL(k_pack_wide, dim3(grid_blocks((int64_t)(bytes / sizeof(double)))), dim3(BLOCK), 0, 0, P);
     e = hipGetLastError();
     if (e == hipSuccess) e = hipDeviceSynchronize();
@@ -332,6 +336,48 @@ namespace {
 void free_mag_pack(MagPack& mp);
 int acquire_mag_pack(iso_ic* ic, const int32_t* bc_cols, int nb, int64_t n, iso::FastArgs& F);
 }  // namespace
+
+// ---- test hook: which kernel instantiations the launchers chose (iso_debug_trace_kernels / iso_debug_kernels) ----------
+namespace iso {
+namespace {
+std::atomic<int> g_trace_kernels{0};
+thread_local std::vector<std::string> t_kernels;
+}  // namespace
+
+void note_kernel(const char* fmt, ...)
+{
+    if (!g_trace_kernels.load(std::memory_order_relaxed)) return;
+    char buf[160];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    for (const std::string& k : t_kernels)
+        if (k == buf) return;
+    if (t_kernels.size() < 4096) t_kernels.emplace_back(buf);
+}
+}  // namespace iso
+
+extern "C" int iso_debug_trace_kernels(int on)
+{
+    iso::t_kernels.clear();
+    return iso::g_trace_kernels.exchange(on ? 1 : 0);
+}
+
+extern "C" int64_t iso_debug_kernels(char* buf, int64_t size)
+{
+    std::string all;
+    for (const std::string& k : iso::t_kernels) {
+        all += k;
+        all += '\n';
+    }
+    if (buf && size > 0) {
+        const size_t n = std::min<size_t>((size_t)size - 1, all.size());
+        std::memcpy(buf, all.data(), n);
+        buf[n] = 0;
+    }
+    return (int64_t)all.size() + 1;
+}
 
 extern "C" {
 
@@ -476,6 +522,7 @@ int iso_interp(iso_table* t, const double* const* x, int64_t n, const int32_t* i
             for (int c = 0; c < k; ++c) W.icols[c] = A.icols[c];
             W.out = out;
             const size_t sh = (size_t)(lds + ISO_MAX_COLS / 2 + BLOCK * WIDE_SLOT) * sizeof(double);
+            note_kernel("k_interp3_wide");
             hipLaunchKernelGGL(k_interp3_wide, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), sh, as_stream(stream), W);
             HIP_TRY(hipGetLastError());
             return ISO_OK;
@@ -486,9 +533,9 @@ int iso_interp(iso_table* t, const double* const* x, int64_t n, const int32_t* i
     const dim3 g(grid_blocks(waves * 64)), b(BLOCK);
     const size_t shmem = (size_t)lds * sizeof(double);
     switch (t->ndim) {
-    case 2: hipLaunchKernelGGL(k_interp<2>, g, b, shmem, as_stream(stream), A); break;
-    case 3: hipLaunchKernelGGL(k_interp<3>, g, b, shmem, as_stream(stream), A); break;
-    default: hipLaunchKernelGGL(k_interp<4>, g, b, shmem, as_stream(stream), A); break;
+    case 2: note_kernel("k_interp<2>"); hipLaunchKernelGGL(k_interp<2>, g, b, shmem, as_stream(stream), A); break;
+    case 3: note_kernel("k_interp<3>"); hipLaunchKernelGGL(k_interp<3>, g, b, shmem, as_stream(stream), A); break;
+    default: note_kernel("k_interp<4>"); hipLaunchKernelGGL(k_interp<4>, g, b, shmem, as_stream(stream), A); break;
     }
     HIP_TRY(hipGetLastError());
     return ISO_OK;
@@ -538,6 +585,7 @@ int iso_ic_create(iso_ctx* ctx, iso_table* model_grid, iso_table* bc_grid, int k
                                    astero_cols[0], astero_cols[1]};
     std::memcpy(P.src, src, sizeof(src));
     P.hot = ic->d_hot;
+    note_kernel("k_pack_hot");
     hipLaunchKernelGGL(k_pack_hot, dim3(grid_blocks(P.ncells * HOT_COLS)), dim3(BLOCK), 0, 0, P);
     e = hipGetLastError();
     if (e == hipSuccess) e = hipDeviceSynchronize();
@@ -639,6 +687,7 @@ int iso_interp_mag(iso_ic* ic, const double* pars, int64_t stride_n, int64_t str
     const int64_t waves = (n + samples_per_wave - 1) / samples_per_wave;
     const dim3 g(grid_blocks(waves * 64)), b(BLOCK);
     const size_t shmem = (size_t)ic->lds_doubles * sizeof(double);
+    note_kernel("k_interp_mag<%d>", ic->kind == ISO_KIND_TRACK ? ISO_KIND_TRACK : ISO_KIND_ISO);
     if (ic->kind == ISO_KIND_TRACK) hipLaunchKernelGGL(k_interp_mag<ISO_KIND_TRACK>, g, b, shmem, as_stream(stream), A);
     else hipLaunchKernelGGL(k_interp_mag<ISO_KIND_ISO>, g, b, shmem, as_stream(stream), A);
     HIP_TRY(hipGetLastError());
@@ -720,6 +769,7 @@ hipError_t pack_bands(const iso_ic* ic, const int32_t* bc_cols, int nb, double**
     P.ncells = ncells;
     for (int b = 0; b < nb; ++b) P.src[b] = bc_cols[b];
     P.out = *out;
+    note_kernel("k_pack_bc");
     hipLaunchKernelGGL(k_pack_bc, dim3(grid_blocks(ncells * nb)), dim3(BLOCK), 0, 0, P);
     e = hipGetLastError();
     if (e == hipSuccess) e = hipDeviceSynchronize();
@@ -955,6 +1005,9 @@ int iso_model_create(iso_ic* ic, const iso_model_desc* desc, iso_model** out)
             if (!m->fast.astq || (!m->d_bcq && desc->n_bands > 0)) m->fast_ok = false;     // generic kernel
         }
     }
+    // the fused kernels exist on the corner-packed tables only (round 4: the compact-table instantiations, 52 kernels that
+    // nothing but ISOCHRONES_AMD_PATH=compact selected, are gone): without the packs the generic kernel evaluates the model
+    if (m->fast_ok && (!m->fast.hotq || (!m->fast.bcq && desc->n_bands > 0))) m->fast_ok = false;
     if (e == hipSuccess && !m->fast_ok && ic->d_hotq) {
         // generic kernel: give its lane-per-sample gathers the corner-packed forms too (whole-line reads), whatever
         // made the model miss the fast path (> 12 bands, ISOCHRONES_AMD_PATH=generic)
@@ -1047,8 +1100,7 @@ int iso_model_kernel_path(const iso_model* m)
 {
     if (!m) return ISO_ERR_INVALID;
     if (!m->fast_ok) return ISO_PATH_GENERIC;
-    const bool packed = m->fast.hotq != nullptr && (m->fast.bcq != nullptr || m->desc.n_bands == 0);
-    return packed ? ISO_PATH_FUSED_PACKED : ISO_PATH_FUSED_COMPACT;
+    return ISO_PATH_FUSED_PACKED;       // (ISO_PATH_FUSED_COMPACT: rounds 1-3; the fused kernels read the corner-packed tables only now)
 }
 
 }  // extern "C"
@@ -1059,15 +1111,15 @@ template <int KIND, int NS, bool PARTS>
 void launch_lnpost_nb(int nb, dim3 g, dim3 b, size_t shmem, hipStream_t s, const PostArgs& A)
 {
     switch (nb) {
-    case 1: hipLaunchKernelGGL((k_lnpost<KIND, NS, 1, PARTS>), g, b, shmem, s, A); break;
-    case 2: hipLaunchKernelGGL((k_lnpost<KIND, NS, 2, PARTS>), g, b, shmem, s, A); break;
-    case 3: hipLaunchKernelGGL((k_lnpost<KIND, NS, 3, PARTS>), g, b, shmem, s, A); break;
-    case 4: hipLaunchKernelGGL((k_lnpost<KIND, NS, 4, PARTS>), g, b, shmem, s, A); break;
-    case 5: hipLaunchKernelGGL((k_lnpost<KIND, NS, 5, PARTS>), g, b, shmem, s, A); break;
-    case 6: hipLaunchKernelGGL((k_lnpost<KIND, NS, 6, PARTS>), g, b, shmem, s, A); break;
-    case 7: hipLaunchKernelGGL((k_lnpost<KIND, NS, 7, PARTS>), g, b, shmem, s, A); break;
-    case 8: hipLaunchKernelGGL((k_lnpost<KIND, NS, 8, PARTS>), g, b, shmem, s, A); break;
-    default: hipLaunchKernelGGL((k_lnpost<KIND, NS, 0, PARTS>), g, b, shmem, s, A); break;
+    case 1: note_kernel("k_lnpost<%d, %d, 1, %s>", KIND, NS, tf(PARTS)); hipLaunchKernelGGL((k_lnpost<KIND, NS, 1, PARTS>), g, b, shmem, s, A); break;
+    case 2: note_kernel("k_lnpost<%d, %d, 2, %s>", KIND, NS, tf(PARTS)); hipLaunchKernelGGL((k_lnpost<KIND, NS, 2, PARTS>), g, b, shmem, s, A); break;
+    case 3: note_kernel("k_lnpost<%d, %d, 3, %s>", KIND, NS, tf(PARTS)); hipLaunchKernelGGL((k_lnpost<KIND, NS, 3, PARTS>), g, b, shmem, s, A); break;
+    case 4: note_kernel("k_lnpost<%d, %d, 4, %s>", KIND, NS, tf(PARTS)); hipLaunchKernelGGL((k_lnpost<KIND, NS, 4, PARTS>), g, b, shmem, s, A); break;
+    case 5: note_kernel("k_lnpost<%d, %d, 5, %s>", KIND, NS, tf(PARTS)); hipLaunchKernelGGL((k_lnpost<KIND, NS, 5, PARTS>), g, b, shmem, s, A); break;
+    case 6: note_kernel("k_lnpost<%d, %d, 6, %s>", KIND, NS, tf(PARTS)); hipLaunchKernelGGL((k_lnpost<KIND, NS, 6, PARTS>), g, b, shmem, s, A); break;
+    case 7: note_kernel("k_lnpost<%d, %d, 7, %s>", KIND, NS, tf(PARTS)); hipLaunchKernelGGL((k_lnpost<KIND, NS, 7, PARTS>), g, b, shmem, s, A); break;
+    case 8: note_kernel("k_lnpost<%d, %d, 8, %s>", KIND, NS, tf(PARTS)); hipLaunchKernelGGL((k_lnpost<KIND, NS, 8, PARTS>), g, b, shmem, s, A); break;
+    default: note_kernel("k_lnpost<%d, %d, 0, %s>", KIND, NS, tf(PARTS)); hipLaunchKernelGGL((k_lnpost<KIND, NS, 0, PARTS>), g, b, shmem, s, A); break;
     }
 }
 
@@ -1102,8 +1154,7 @@ int enqueue_lnpost(iso_model* m, const double* pars, int64_t stride_n, int64_t s
         F.lnprior = lnprior_out;
         // lnprior alone still needs the likelihood flag off; lnlike requested -> evaluate everywhere
         F.lnlike = lnlike_out;
-        const bool packed = F.hotq != nullptr && (F.bcq != nullptr || m->desc.n_bands == 0);
-        if (launch_lnpost_fast(m->ic->kind, m->desc.n_stars, m->desc.n_bands, packed, false, F, s)) {
+        if (launch_lnpost_fast(m->ic->kind, m->desc.n_stars, m->desc.n_bands, false, F, s)) {
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) return fail(ISO_ERR_HIP, std::string("iso_lnpost (fast) launch: ") + hipGetErrorString(e));
             return ISO_OK;
@@ -1312,6 +1363,7 @@ int iso_unit_cube(iso_model* m, double* cube, int64_t stride_n, int64_t stride_p
     if (n < 0) return fail(ISO_ERR_INVALID, "iso_unit_cube: n < 0");
     if (n == 0) return ISO_OK;
     DeviceGuard guard(m->ic->ctx->device);
+    note_kernel("k_unit_cube");
     hipLaunchKernelGGL(k_unit_cube, dim3(grid_blocks(n * (m->desc.n_stars + 4))), dim3(BLOCK), 0, as_stream(stream),
                        m->d_model, cube, stride_n, stride_p, n);
     HIP_TRY(hipGetLastError());
@@ -1390,6 +1442,7 @@ int iso_interp_eep(iso_eep_table* t, const double* x, const double* x0, const do
     for (int d = 0; d < 2; ++d)
         if (A.ax[d].lds_off >= 0) lds += A.ax[d].n;
     DeviceGuard guard(t->device);
+    note_kernel("k_interp_eep");
     hipLaunchKernelGGL(k_interp_eep, dim3(grid_blocks(n)), dim3(BLOCK), (size_t)lds * sizeof(double), as_stream(stream), A);
     HIP_TRY(hipGetLastError());
     return ISO_OK;
@@ -1429,6 +1482,7 @@ int ctx_wait(iso_ctx* ctx, double* h, double* d)
     }
     const unsigned long long seq = ++ctx->stage_seq;
     volatile unsigned long long* h_flag = reinterpret_cast<volatile unsigned long long*>(h + ISO_CTX_STAGE_DOUBLES);
+    note_kernel("k_signal_done");
     hipLaunchKernelGGL(k_signal_done, dim3(1), dim3(1), 0, nullptr,
                        reinterpret_cast<volatile unsigned long long*>(d + ISO_CTX_STAGE_DOUBLES), seq);
     HIP_TRY(hipGetLastError());
@@ -1652,8 +1706,10 @@ int iso_catalog_create_columns(iso_ic* ic, const iso_model_desc* tmpl, int64_t n
         F.nb = nb;
         F.i_dist = tmpl->n_stars + 2;
         F.has_plx = d_has;
+        note_kernel("k_catalog_copy_template");
         hipLaunchKernelGGL(k_catalog_copy_template, dim3(grid_blocks(n_models * (int64_t)(sizeof(DevModel) / 8))), dim3(BLOCK),
                            0, 0, F);
+        note_kernel("k_catalog_fill");
         hipLaunchKernelGGL(k_catalog_fill, dim3(grid_blocks(n_models)), dim3(BLOCK), 0, 0, F);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipDeviceSynchronize();
@@ -1706,7 +1762,7 @@ int iso_catalog_lnpost(iso_catalog* c, const int32_t* star_id, const double* par
     F.stride_p = stride_p;
     F.n = n;
     F.lnpost = lnpost_out;
-    if (!launch_lnpost_fast(c->ic->kind, c->n_stars, c->n_bands, true, true, F, as_stream(stream)))
+    if (!launch_lnpost_fast(c->ic->kind, c->n_stars, c->n_bands, true, F, as_stream(stream)))
         return fail(ISO_ERR_INVALID, "iso_catalog_lnpost: no kernel specialisation");
     HIP_TRY(hipGetLastError());
     return ISO_OK;
@@ -1874,6 +1930,7 @@ int iso_tree_lnpost(iso_tree_model* m, const double* pars, int64_t stride_n, int
     A.lnprior = lnprior_out;
     A.lnlike = lnlike_out;
     DeviceGuard guard(m->device);
+    note_kernel("k_lnpost_tree");
     hipLaunchKernelGGL(k_lnpost_tree, dim3(grid_blocks(n)), dim3(BLOCK), (size_t)m->ic->lds_doubles * sizeof(double),
                        as_stream(stream), A);
     HIP_TRY(hipGetLastError());
@@ -2127,6 +2184,7 @@ int iso_chain_quantiles_layout(iso_ctx* ctx, const double* chain, int layout, in
     const dim3 g((unsigned)(n_ens * n_params)), b(BLOCK);
     A.only_flagged = 0;
     if (qm && !std::strcmp(qm, "sort")) {
+        note_kernel("k_chain_quantiles");
         hipLaunchKernelGGL(k_chain_quantiles, g, b, sort_bytes, as_stream(stream), A);
     } else if (m <= 64 * QW_IPL_BIG && !(qm && !std::strcmp(qm, "workgroup"))) {
         // one wave per pair, values in registers; the few pairs it flags (heavy ties, non-finite values) go to the
@@ -2143,6 +2201,7 @@ int iso_chain_quantiles_layout(iso_ctx* ctx, const double* chain, int layout, in
             hipStream_t st = as_stream(stream);
 #define ISO_QEXACT(F)                                                                                      \
             case F:                                                                                        \
+                note_kernel("k_chain_quantiles_exact<%d, %s>", F, tf(tail));                               \
                 if (tail) hipLaunchKernelGGL((k_chain_quantiles_exact<F, true>), gw, b, qsh, st, A);       \
                 else hipLaunchKernelGGL((k_chain_quantiles_exact<F, false>), gw, b, qsh, st, A);           \
                 break;
@@ -2153,14 +2212,19 @@ int iso_chain_quantiles_layout(iso_ctx* ctx, const double* chain, int layout, in
 #undef ISO_QEXACT
         }
         if (exact) {
-        } else if (m <= 64 * QW_IPL)
+        } else if (m <= 64 * QW_IPL) {
+            note_kernel("k_chain_quantiles_wave<%d>", QW_IPL);
             hipLaunchKernelGGL(k_chain_quantiles_wave<QW_IPL>, gw, b, (size_t)QW_WAVES * QW_LDS_PER_WAVE, as_stream(stream), A);
-        else
+        } else {
+            note_kernel("k_chain_quantiles_wave<%d>", QW_IPL_BIG);
             hipLaunchKernelGGL(k_chain_quantiles_wave<QW_IPL_BIG>, gw, b, (size_t)QW_WAVES * QW_LDS_PER_WAVE, as_stream(stream), A);
+        }
         HIP_TRY(hipGetLastError());
         A.only_flagged = 1;
+        note_kernel("k_chain_quantiles_select");
         hipLaunchKernelGGL(k_chain_quantiles_select, g, b, std::max(sel_bytes, sort_bytes), as_stream(stream), A);
     } else {
+        note_kernel("k_chain_quantiles_select");
         hipLaunchKernelGGL(k_chain_quantiles_select, g, b, std::max(sel_bytes, sort_bytes), as_stream(stream), A);
     }
     HIP_TRY(hipGetLastError());

@@ -280,6 +280,9 @@ bool launch_stretch(int kind, int n_stars, int n_bands, const FastArgs& A, const
 size_t stretch_persist_lds(int n_bands, int axes_len, int W, int n_params, int* ensembles_per_workgroup);
 // defined in iso_fast_*.hip: launch the specialised fused kernel; returns false if no
 // specialisation exists for (kind, n_stars, n_bands)
-bool launch_lnpost_fast(int kind, int n_stars, int n_bands, bool packed, bool multi, const FastArgs& A,
-                        hipStream_t s);
+bool launch_lnpost_fast(int kind, int n_stars, int n_bands, bool multi, const FastArgs& A, hipStream_t s);
+// test hook (iso_debug_trace_kernels / iso_debug_kernels): launchers name the instantiation they chose, spelled as c++filt
+// spells the kernel's symbol; a no-op unless tracing is on
+void note_kernel(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
+inline const char* tf(bool b) { return b ? "true" : "false"; }
 }  // namespace iso

@@ -74,7 +74,7 @@ __device__ __forceinline__ void bitonic_sort_chain(const QuantArgs& A, int64_t e
     }
 }
 
-__global__ __launch_bounds__(BLOCK) void k_chain_quantiles(const QuantArgs A)
+__global__ __launch_bounds__(BLOCK, 2) void k_chain_quantiles(const QuantArgs A)
 {
     extern __shared__ double lds[];
     if (A.only_flagged && !quant_flagged(A, blockIdx.x)) return;      // workgroup-uniform
@@ -106,7 +106,7 @@ constexpr int QSEL_BINS = 1024;
 constexpr int QSEL_CAP = 128;      // elements per gathered list
 constexpr int QSEL_RANKS = 16;     // 2 x nq, nq <= 8
 
-__global__ __launch_bounds__(BLOCK) void k_chain_quantiles_select(const QuantArgs A)
+__global__ __launch_bounds__(BLOCK, 2) void k_chain_quantiles_select(const QuantArgs A)
 {
     extern __shared__ double lds[];
     // LDS map (the bitonic fallback reuses the whole area from offset 0):
@@ -296,7 +296,7 @@ __device__ __forceinline__ void qw_sync()
 
 // (capping the registers at 128 for a fourth wave per SIMD spills 106 of them: measured 22 instead of 16.5 ns per pair)
 template <int IPL>
-__global__ __launch_bounds__(BLOCK) void k_chain_quantiles_wave(const QuantArgs A)
+__global__ __launch_bounds__(BLOCK, 2) void k_chain_quantiles_wave(const QuantArgs A)
 {
     extern __shared__ double lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

@@ -24,7 +24,7 @@ struct InterpArgs {
 // (cheap: ~150 VALU against >= 1 KB of gathered table per sample).  k = 1, 2 degenerate to one lane
 // per sample.
 template <int ND>
-__global__ __launch_bounds__(BLOCK) void k_interp(const InterpArgs A)
+__global__ __launch_bounds__(BLOCK, 2) void k_interp(const InterpArgs A)
 {
     extern __shared__ double lds[];
     stage_axes<ND>(A.ax, lds);
@@ -118,7 +118,7 @@ struct PackWideArgs {
     int ncol;
 };
 
-__global__ __launch_bounds__(BLOCK) void k_pack_wide(const PackWideArgs P)
+__global__ __launch_bounds__(BLOCK, 2) void k_pack_wide(const PackWideArgs P)
 {
     const int64_t total = P.n0 * P.n1 * P.n2 * P.ncol * 8;
     for (int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x; e < total; e += (int64_t)gridDim.x * BLOCK) {
@@ -150,7 +150,7 @@ __device__ __forceinline__ double wide_dpp(double x, int which)
 constexpr int WIDE_SLOT = 5;      // doubles per request slot (4 used; odd stride: conflict-free)
 constexpr int WIDE_UNROLL = 8;    // passes whose loads are in flight together
 
-__global__ __launch_bounds__(BLOCK) void k_interp3_wide(const WideArgs A)
+__global__ __launch_bounds__(BLOCK, 2) void k_interp3_wide(const WideArgs A)
 {
     extern __shared__ double lds[];
     stage_axes<3>(A.ax, lds);

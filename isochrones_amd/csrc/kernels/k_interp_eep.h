@@ -35,7 +35,7 @@ __device__ __forceinline__ int64_t ref_searchsorted(const double* __restrict__ a
     return L;
 }
 
-__global__ __launch_bounds__(BLOCK) void k_interp_eep(const EepArgs A)
+__global__ __launch_bounds__(BLOCK, 2) void k_interp_eep(const EepArgs A)
 {
     extern __shared__ double lds[];
     stage_axes<2>(A.ax, lds);

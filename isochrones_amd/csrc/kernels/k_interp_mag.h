@@ -22,7 +22,7 @@ struct MagArgs {
 // per corner the G lanes read neighbouring columns of one BC row and finally write nb contiguous
 // magnitudes.
 template <int KIND>
-__global__ __launch_bounds__(BLOCK) void k_interp_mag(const MagArgs A)
+__global__ __launch_bounds__(BLOCK, 2) void k_interp_mag(const MagArgs A)
 {
     extern __shared__ double lds[];
     stage_axes<3>(A.g3.ax, lds);

@@ -18,7 +18,7 @@ struct PostArgs {
 
 // NB > 0: compile-time band count (register-resident accumulators); NB == 0: runtime loop.
 template <int KIND, int NS, int NB, bool PARTS>
-__global__ __launch_bounds__(BLOCK) void k_lnpost(const PostArgs A)
+__global__ __launch_bounds__(BLOCK, 2) void k_lnpost(const PostArgs A)
 {
     extern __shared__ double lds[];
     stage_axes<3>(A.g3.ax, lds);

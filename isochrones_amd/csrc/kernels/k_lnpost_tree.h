@@ -24,7 +24,7 @@ __device__ __forceinline__ double tree_addmags(const double (*flux)[ISO_TREE_MAX
     return -2.5 * log10(tot);
 }
 
-__global__ __launch_bounds__(BLOCK) void k_lnpost_tree(const TreeArgs A)
+__global__ __launch_bounds__(BLOCK, 2) void k_lnpost_tree(const TreeArgs A)
 {
     extern __shared__ double lds[];
     stage_axes<3>(A.g3.ax, lds);

@@ -5,7 +5,7 @@
 // -------------------------------------------------------------------------------------------
 // small kernels
 // -------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k_unit_cube(const DevModel* m, double* cube, int64_t stride_n,
+__global__ __launch_bounds__(BLOCK, 2) void k_unit_cube(const DevModel* m, double* cube, int64_t stride_n,
                                                     int64_t stride_p, int64_t n)
 {
     const int np = m->n_stars + 4;
@@ -31,7 +31,7 @@ struct PackHotArgs {
     double* hot;
 };
 
-__global__ __launch_bounds__(BLOCK) void k_pack_hot(const PackHotArgs A)
+__global__ __launch_bounds__(BLOCK, 2) void k_pack_hot(const PackHotArgs A)
 {
     const int64_t total = A.ncells * HOT_COLS;
     for (int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x; e < total; e += (int64_t)gridDim.x * BLOCK) {
@@ -50,7 +50,7 @@ struct PackBcArgs {
     double* out;
 };
 
-__global__ __launch_bounds__(BLOCK) void k_pack_bc(const PackBcArgs A)
+__global__ __launch_bounds__(BLOCK, 2) void k_pack_bc(const PackBcArgs A)
 {
     const int64_t total = A.ncells * A.nb;
     for (int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x; e < total; e += (int64_t)gridDim.x * BLOCK) {
@@ -75,7 +75,7 @@ struct PackCornersArgs {
 //           P = keep/2 column pairs (3 for the model table, 1 for the asteroseismic pair)
 //   ndim 4: double index e = 2*((k*NB + band)*4 + j) + comp  ->  axis-0 offset k, (axis-1, axis-2)
 //           offsets = bits of j, axis-3 offset comp
-__global__ __launch_bounds__(BLOCK) void k_pack_corners(const PackCornersArgs A)
+__global__ __launch_bounds__(BLOCK, 2) void k_pack_corners(const PackCornersArgs A)
 {
     const int per = (1 << A.ndim) * A.keep;
     const int64_t total = A.ncells * per;
@@ -119,7 +119,7 @@ struct FillCatalogArgs {
     const double* dist_hi;                // [n] or null
 };
 
-__global__ __launch_bounds__(BLOCK) void k_catalog_copy_template(const FillCatalogArgs A)
+__global__ __launch_bounds__(BLOCK, 2) void k_catalog_copy_template(const FillCatalogArgs A)
 {
     constexpr int64_t WORDS = sizeof(DevModel) / sizeof(double);
     static_assert(sizeof(DevModel) % sizeof(double) == 0, "DevModel must be a whole number of doubles");
@@ -137,7 +137,7 @@ __device__ __forceinline__ void dev_gauss_consts(double unc, double& g0, double&
     hinv = 0.5 / unc2;
 }
 
-__global__ __launch_bounds__(BLOCK) void k_catalog_fill(const FillCatalogArgs A)
+__global__ __launch_bounds__(BLOCK, 2) void k_catalog_fill(const FillCatalogArgs A)
 {
     for (int64_t s = (int64_t)blockIdx.x * BLOCK + threadIdx.x; s < A.n; s += (int64_t)gridDim.x * BLOCK) {
         DevModel& M = A.models[s];

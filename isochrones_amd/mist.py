@@ -41,6 +41,20 @@ class MistDataNotFound(FileNotFoundError):
     """The data directory has no MIST cache this build can read (the message says which file is missing)."""
 
 
+def nothing_there(root=None, tracks=False, **kw):
+    """True when the data directory holds neither the model cache of this grid nor any bolometric-correction frame:
+    the only situation in which ``get_ichrone('mist')`` may hand out the synthetic tables instead.  A cache that exists
+    but cannot be used (an HDF5 frame without pytables, axes that cannot be recovered, another number of
+    metallicities) is an error the user has to see - a fit on invented physics that "worked" is worse."""
+    p = mist_paths(root, tracks, **kw)
+    if os.path.exists(p["full_grid"]):
+        return False
+    try:
+        return not any(f.endswith((".h5", ".npz")) for f in os.listdir(p["bc_dir"]))
+    except OSError:
+        return True
+
+
 def data_root(root=None):
     """``$ISOCHRONES`` or ``~/.isochrones`` (isochrones/config.py:5)."""
     return os.path.expanduser(root or os.getenv("ISOCHRONES") or os.path.join("~", ".isochrones"))
@@ -88,11 +102,28 @@ def _axis_from_column(values, along, what):
         raise MistDataNotFound("the %s axis cannot be read off the table (a node without any populated cell); "
                                "export the axes with isochrones_amd.mist.export_axes" % what)
     if not np.array_equal(lo, hi):
-        raise MistDataNotFound("the table's %s column is not constant across a node of its axis; export the axes with "
-                               "isochrones_amd.mist.export_axes" % what)
+        # the reference's interpolated tracks carry lo (1 - d) + hi d in this column, which can differ from the node by
+        # an ulp or two from cell to cell: a spread of a few ulp is still the node (the caller snaps it to the
+        # reference's list where it knows one); anything wider is not an axis column
+        if not np.all(hi - lo <= 8 * np.spacing(np.maximum(np.abs(lo), np.abs(hi)))):
+            raise MistDataNotFound("the table's %s column is not constant across a node of its axis; export the axes with "
+                                   "isochrones_amd.mist.export_axes" % what)
+        with np.errstate(invalid="ignore"):
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore", RuntimeWarning)
+                lo = np.nanmedian(v, axis=1)
     if not np.all(np.diff(lo) > 0):
         raise MistDataNotFound("recovered %s axis is not increasing" % what)
     return lo
+
+
+def _snap(axis, nominal):
+    """The nominal list (the reference's index level) when the recovered nodes are that list to rounding."""
+    nominal = np.asarray(nominal, dtype=float)
+    if axis.size == nominal.size and np.allclose(axis, nominal, rtol=1e-9, atol=0.0):
+        return nominal.copy()
+    return axis
 
 
 def model_axes(grid, columns, tracks, axes_file=None):
@@ -113,7 +144,8 @@ def model_axes(grid, columns, tracks, axes_file=None):
     fehs = np.array(grids.MIST_FEHS, dtype=float)
     eeps = _axis_from_column(grid[..., col["eep"]], 2, "EEP")
     if tracks:
-        return [fehs, _axis_from_column(grid[..., col["initial_mass"]], 1, "initial mass"), eeps], names
+        # (the reference's mass axis is the list of nominal track masses - the frame's index level, mist/models.py)
+        return [fehs, _snap(_axis_from_column(grid[..., col["initial_mass"]], 1, "initial mass"), grids.mist_masses()), eeps], names
     return [_axis_from_column(grid[..., col["age"]], 0, "age"), fehs, eeps], names
 
 

@@ -566,6 +566,7 @@ def synthetic_track(bands=grids.DEFAULT_BANDS, fehs=None, masses=None, eeps=None
     mg = EvolutionTrackGrid(DFInterpolator.from_arrays(g, ax, cols, ["initial_feh", "initial_mass", "EEP"]),
                             limits=limits)
     ic = EvolutionTrackInterpolator(mg, _bc(bands, bc_axes), bands=bands, eep_bounds=eep_bounds)
+    ic.data_source = "synthetic"
     if fehs is None and masses is None and eeps is None:          # full-size tables: the companion is well defined
         ic._companion_factory = lambda: synthetic_isochrone(bands, bc_axes=bc_axes)
     return ic
@@ -578,6 +579,7 @@ def synthetic_isochrone(bands=grids.DEFAULT_BANDS, ages=None, fehs=None, eeps=No
     mg = IsochroneGrid(DFInterpolator.from_arrays(g, ax, cols, ["log10_isochrone_age_yr", "feh", "EEP"]),
                        limits=limits)
     ic = IsochroneInterpolator(mg, _bc(bands, bc_axes), bands=bands, eep_bounds=eep_bounds)
+    ic.data_source = "synthetic"
     if ages is None and fehs is None and eeps is None:
         ic._companion_factory = lambda: synthetic_track(bands, bc_axes=bc_axes)
     return ic
@@ -605,8 +607,12 @@ def get_ichrone(models="mist", bands=None, default=False, tracks=False, basic=Fa
             return mist.load_mist(bands, tracks=tracks, **grid_kw)
         except mist.MistDataNotFound as e:
             import warnings
+            # synthetic tables only when NOTHING is there; a cache that exists but cannot be used is the user's to fix
+            if not mist.nothing_there(tracks=tracks, **grid_kw):
+                raise
             warnings.warn("get_ichrone('mist'): no MIST tables under %s (%s) - using synthetic MIST-shaped tables "
                           "(isochrones_amd.grids: same axes and columns, invented physics)" % (mist.data_root(), e),
                           UserWarning, stacklevel=2)
         kwargs = {k: v for k, v in kwargs.items() if k not in grid_kw}
-    return synthetic_track(bands, **kwargs) if tracks else synthetic_isochrone(bands, **kwargs)
+    ic = synthetic_track(bands, **kwargs) if tracks else synthetic_isochrone(bands, **kwargs)
+    return ic

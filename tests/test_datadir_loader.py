@@ -116,7 +116,7 @@ def test_no_data_directory_means_a_warning_not_silence(monkeypatch, tmp_path):
     monkeypatch.setenv("ISOCHRONES", str(tmp_path))
     with pytest.warns(UserWarning, match="synthetic MIST-shaped tables"):
         ic = ia.get_ichrone("mist", bands=["G"], tracks=True)
-    assert ic.model_grid.interp.grid.shape[:3] == (15, 196, 1710) and not hasattr(ic, "data_source")
+    assert ic.model_grid.interp.grid.shape[:3] == (15, 196, 1710) and ic.data_source == "synthetic"
     with warnings.catch_warnings():
         warnings.simplefilter("error")
         ia.get_ichrone("synthetic", bands=["G"], tracks=True)            # asked for by name: nothing to warn about
@@ -139,10 +139,52 @@ def test_missing_bc_frames_are_an_error_that_says_what_to_do(monkeypatch, tmp_pa
         pass
     with pytest.raises(mist.MistDataNotFound, match="export_frame_npz"):
         mist.load_mist(["J"], tracks=True, root=str(root))
-    # get_ichrone turns the same condition into the loud fallback
+    # get_ichrone does NOT fall back to the synthetic tables here: the caches exist, this build just cannot read one of
+    # them - a fit on invented physics that "succeeded" would be worse than the error
     monkeypatch.setenv("ISOCHRONES", str(root))
-    with pytest.warns(UserWarning, match="export_frame_npz"):
-        ia.get_ichrone("mist", bands=["J"], tracks=True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        with pytest.raises(mist.MistDataNotFound, match="export_frame_npz"):
+            ia.get_ichrone("mist", bands=["J"], tracks=True)
+
+
+def test_a_cache_that_cannot_be_used_is_an_error_not_a_synthetic_fit(monkeypatch, tmp_path):
+    """A model cache whose [Fe/H] axis is not MIST's (no axes file), or whose axis column is not an axis: the loader's
+    error reaches the caller of get_ichrone; only an EMPTY data directory gives the synthetic tables."""
+    import shutil
+    root = tmp_path / "iso"
+    shutil.copytree(TREE, root)
+    d = dict(np.load(root / "mist" / "tracks" / "full_grid_v1.2_vvcrit0.4.npz", allow_pickle=False))
+    os.remove(root / "mist" / "tracks" / "full_grid_v1.2_vvcrit0.4_axes.npz") if os.path.exists(
+        root / "mist" / "tracks" / "full_grid_v1.2_vvcrit0.4_axes.npz") else None
+    cols = [str(c) for c in d["columns"]]
+    g = d["grid"].copy()
+    g[..., cols.index("eep")] += np.linspace(0.0, 0.5, g.shape[1])[None, :, None]      # no longer constant across a node
+    np.savez(root / "mist" / "tracks" / "full_grid_v1.2_vvcrit0.4.npz", grid=g, columns=d["columns"])
+    monkeypatch.setenv("ISOCHRONES", str(root))
+    assert not mist.nothing_there(tracks=True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        with pytest.raises(mist.MistDataNotFound):
+            ia.get_ichrone("mist", bands=["G"], tracks=True)
+    empty = tmp_path / "empty"
+    empty.mkdir()
+    monkeypatch.setenv("ISOCHRONES", str(empty))
+    assert mist.nothing_there(tracks=True)
+
+
+def test_mass_axis_recovered_to_an_ulp_is_snapped_to_the_nominal_list():
+    """The reference's interpolated tracks carry lo (1 - d) + hi d in `initial_mass`: a node whose cells differ by an
+    ulp is still that node, and nodes that are MIST's mass list to rounding are that list."""
+    masses = ia.grids.mist_masses()
+    vals = np.repeat(masses[None, :, None], 3, axis=0).repeat(5, axis=2).astype(float)
+    vals[1, 7, 2] = np.nextafter(vals[1, 7, 2], np.inf)
+    vals[2, 100, 0] = np.nextafter(vals[2, 100, 0], -np.inf)
+    got = mist._snap(mist._axis_from_column(vals, 1, "initial mass"), masses)
+    assert np.array_equal(got, masses)
+    vals[0, 3, 1] *= 1.0 + 1e-9                       # not rounding any more
+    with pytest.raises(mist.MistDataNotFound, match="not constant"):
+        mist._axis_from_column(vals, 1, "initial mass")
 
 
 def test_companion_grid_comes_from_the_same_directory(tree_env):
