@@ -179,6 +179,19 @@ def cpu_baseline(ic, mod, pars_host, wall_budget_s=4.0, full_passes=3, scalar_ca
             time.sleep(0.2)                                            # let the quota period roll over
     dt = time.perf_counter() - t0
     passes = len(times)
+    # the same passes with as many threads as the quota grants (threads = min(cores, quota)): no throttling, so the passes
+    # agree with each other - `value_quota` is their median, the stable figure beside the best-of `value`
+    quota_threads = max(1, min(cores, int(quota))) if quota else cores
+    times_q = []
+    if quota_threads != cores:
+        oic.lnpost(desc, soa, nthreads=quota_threads, parts=False)
+        tq = time.perf_counter()
+        while time.perf_counter() - tq < min(wall_budget_s, 3.0) or len(times_q) < 3:
+            t = time.perf_counter()
+            oic.lnpost(desc, soa, nthreads=quota_threads, parts=False)
+            times_q.append(time.perf_counter() - t)
+    else:
+        times_q = list(times)
     # B2: one thread, the reference's serial interp_mags-style loop without Python overhead, at 10^4
     # samples (BASELINE configs[0]'s size) and over the whole batch; median of 5 / 3 passes
     def one_thread(m, reps):
@@ -211,11 +224,15 @@ def cpu_baseline(ic, mod, pars_host, wall_budget_s=4.0, full_passes=3, scalar_ca
                        "figure: %d passes over the first %d samples (%.1f s)"
                        % (passes, n, dt, cores, ("%.1f CPUs" % quota) if quota else "none", p1, n1, dt1),
                 value_median_pass=n / float(np.median(times)), cpu_quota_cores=quota,
+                value_quota=n / float(np.median(times_q)), quota_threads=quota_threads, quota_passes=len(times_q),
+                quota_pass_spread=float((max(times_q) - min(times_q)) / np.median(times_q)),
                 value_1thread=b2_full,
                 modes={"B1_scalar_call": {"us_per_call": scalar_us, "calls": len(one), "evals_per_s": 1e6 / scalar_us},
                        "B2_one_thread_1e4": {"evals_per_s": b2_small}, "B2_one_thread_full_batch": {"evals_per_s": b2_full},
                        "B3_all_cores_full_batch": {"evals_per_s": n / min(times), "median_pass": n / float(np.median(times)),
-                                                   "threads": cores}}), out
+                                                   "threads": cores},
+                       "B3_quota_threads_full_batch": {"evals_per_s": n / float(np.median(times_q)), "threads": quota_threads,
+                                                       "passes": len(times_q)}}), out
 
 
 def cpu_mcmc_baseline(ic, mod, p0, nsteps, seed, gpu_chain=None, gpu_lnp=None):

@@ -285,6 +285,19 @@ void iso_catalog_destroy(iso_catalog* c);
 int  iso_catalog_lnpost(iso_catalog* c, const int32_t* star_id, const double* pars, int64_t stride_n,
                         int64_t stride_p, int64_t n, double* lnpost_out, void* stream);
 
+/* Start points of a catalog fit, found on the device (one workgroup per star; fast/start_points.h): every star draws
+ * oversample x nwalkers candidates inside its parameter bounds - log-uniform in mass, distance within 4 sigma of the
+ * parallax distance where the star has a positive parallax, the EEPs of a multiple system in descending order -
+ * evaluates them with the catalog kernels' lnpost and keeps its best nwalkers; while fewer than nwalkers are finite it
+ * draws again, up to max_tries times as many.  Replaces the reference's per-star `sample_from_prior` loop
+ * (starmodel.py:903-949: one Python lnpost call per draw until nwalkers rows are valid) for S stars at once.
+ * best [S][nwalkers][n_params], best_lnp [S][nwalkers] (descending per star), failed [S] (1 = fewer than nwalkers finite
+ * candidates: that star's rows are NaN) are DEVICE arrays.  Random numbers: Philox4x32-10, counter
+ * (4 chunk + call, star, lane, 0x57), key = seed - a given (seed, catalog) gives the same start points on every run.
+ * nwalkers <= 256. */
+int  iso_catalog_start_points(iso_catalog* c, int nwalkers, int oversample, int max_tries, uint64_t seed, double* best,
+                              double* best_lnp, int32_t* failed, void* stream);
+
 /* Generic (observation-tree) StarModel: lnpost / lnprior / lnlike of starmodel.py:538-613 +
  * observation.py:1181-1234.  Outputs as iso_lnpost; lnlike is -inf (never NaN) when not finite,
  * as the reference. */

@@ -19,6 +19,8 @@ from __future__ import annotations
 import ctypes as C
 import re
 
+import os
+
 import numpy as np
 
 from . import _cabi, device as dev
@@ -387,17 +389,34 @@ class BatchedEnsembleSampler:
         return chain, lnps
 
 
-def initial_positions(post: CatalogPosterior, nwalkers, rng_seed=0, oversample=8, max_tries=6):
+def initial_positions(post: CatalogPosterior, nwalkers, rng_seed=0, oversample=8, max_tries=6, method=None):
     """[S, W, D] start points with finite lnpost: draw ``oversample * W`` candidates per star inside
-    the parameter bounds (distance centred on the parallax when there is one), evaluate them in
-    one launch, keep each star's best W.  Stars that never reach W finite candidates are returned
+    the parameter bounds (distance centred on the parallax when there is one), evaluate them,
+    keep each star's best W.  Stars that never reach W finite candidates are returned
     in ``failed`` (their rows hold NaN) — per-star failure isolation, as the reference's
     try/except around each star (isochrones/starfit.py:155-159).
 
-    The candidates are held parameter-major ([D, S, K]: one contiguous plane per parameter, drawn and transformed
-    in place; the catalog kernel reads them through its stride arguments), so a pass costs a few sweeps over
-    S x K doubles per parameter instead of a dozen over the interleaved [S, K, D] block."""
+    ``method`` (default: ``$ISOCHRONES_AMD_START`` or "kernel"): "kernel" = one launch of the start-point kernel
+    (``iso_catalog_start_points``: one workgroup per star draws with Philox, evaluates with the catalog kernels' lnpost and
+    selects in LDS; no candidate leaves the chip, no host synchronisation); "torch" = the framework version of rounds 1-3
+    (candidates [D, S, K] in memory, one catalog-kernel launch and a dozen sort / topk / gather passes per attempt), kept
+    as the A/B counterpart and for ensembles of more than 256 walkers.  Both draw from the same candidate distribution;
+    the random numbers differ."""
     import torch
+    method = method or os.environ.get("ISOCHRONES_AMD_START", "kernel")
+    if method not in ("kernel", "torch"):
+        raise ValueError("initial_positions: method must be 'kernel' or 'torch'")
+    if method == "kernel" and nwalkers <= 256 and hasattr(_cabi.lib(), "iso_catalog_start_points"):
+        S, D, W = post.n_models, post.n_params, int(nwalkers)
+        device = torch.device("cuda", post.device)
+        best = torch.empty(S, W, D, dtype=torch.float64, device=device)
+        best_lnp = torch.empty(S, W, dtype=torch.float64, device=device)
+        failed = torch.empty(S, dtype=torch.int32, device=device)
+        rc = _cabi.lib().iso_catalog_start_points(post._h, W, int(oversample), int(max_tries), int(rng_seed) & 0xFFFFFFFFFFFFFFFF,
+                                                  dev.ptr(best), dev.ptr(best_lnp), dev.ptr(failed), dev.stream_ptr(post.device))
+        if rc == 0:
+            return best, best_lnp, failed.to(torch.bool)
+        _cabi.lib().iso_last_error()             # no instantiation for this shape (LDS): the framework version below
     S, D, W = post.n_models, post.n_params, nwalkers
     device = torch.device("cuda", post.device)
     gen = torch.Generator(device=device)

@@ -127,17 +127,40 @@ def build(force: bool = False, verbose: bool = False, gate: bool = True) -> str:
     stale = not up_to_date()             # objects of another source state are only reused when their times say so
     jobs = []
     objs = []
+    # an object is reused when the digest of what it was compiled from - its source, every header, the flags, taken BEFORE
+    # the compiler started - is the digest of those files now (file times are not trusted: an edit made while a build was
+    # running left objects that were newer than the header they had not seen)
+    import hashlib
+    hh = hashlib.sha256(repr(FLAGS).encode())
+    for path in HEADERS + [me]:
+        with open(path, "rb") as f:
+            hh.update(os.path.basename(path).encode() + b"\0" + f.read())
     for src in sources():
         obj = os.path.join(OBJDIR, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
-        if force or _newer(obj, [src, me] + HEADERS) or not os.path.exists(obj[:-2] + ".res"):
-            jobs.append((([cc] + FLAGS + ["-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", obj]), obj[:-2] + ".res"))
+        h1 = hh.copy()
+        with open(src, "rb") as f:
+            h1.update(f.read())
+        dig = h1.hexdigest()
+        try:
+            have = open(obj[:-2] + ".dig").read().strip()
+        except OSError:
+            have = None
+        if force or have != dig or not os.path.exists(obj) or not os.path.exists(obj[:-2] + ".res"):
+            jobs.append((([cc] + FLAGS + ["-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", obj]), obj[:-2] + ".res", dig))
 
     def compile_one(job):
-        cmd, log = job
+        cmd, log, dig = job
+        try:
+            os.remove(log[:-4] + ".dig")
+        except OSError:
+            pass
         p = subprocess.run(cmd, cwd=HERE, stderr=subprocess.PIPE, text=True, errors="replace")
         with open(log, "w") as f:
             f.write(p.stderr)
+        if p.returncode == 0:
+            with open(log[:-4] + ".dig", "w") as f:
+                f.write(dig + "\n")
         # the remarks go to the log; anything else the compiler said (warnings, errors) is passed on
         rest = [ln for ln in p.stderr.splitlines() if "kernel-resource-usage" not in ln and not R.is_remark_context(ln)]
         if verbose:

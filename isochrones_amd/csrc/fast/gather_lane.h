@@ -92,9 +92,12 @@ __device__ __forceinline__ void lane_pair(const double* __restrict__ tab, bool n
 template <int NB>
 __device__ __forceinline__ void lane_bc(const FastArgs& A, bool need, uint32_t cell, const W4& w, double* __restrict__ v)
 {
-#pragma unroll
-    for (int b = 0; b < NB; ++b) v[b] = f_nan();
-    if (!need) return;
+    // Every lane gathers, needed or not (a lane without a usable bracket reads cell 0, which always exists, and gets NaN at
+    // the end): no divergent region around the 8 NB loads.  Round 3's wrong sampler instantiation - (isochrone, 3 stars,
+    // 9 bands) under a reordered model block - had `if (!need) return;` here, 72 loads in flight inside the branch; every
+    // build of that source state that made wrong moves had it, and the same source without it made none (round 4's hunt:
+    // profiles/r04/miscompile_hunt.md).  The cause inside the compiler's output was not found; the shape is avoided.
+    cell = need ? cell : 0u;
     const double2* __restrict__ pc = reinterpret_cast<const double2*>(A.bcq + (size_t)cell * (16 * NB));
     double part[NB][4];
     const double t0 = rounded(w.t0), t1 = rounded(w.t1), t2 = rounded(w.t2), t3 = rounded(w.t3);
@@ -107,5 +110,5 @@ __device__ __forceinline__ void lane_bc(const FastArgs& A, bool need, uint32_t c
         for (int b = 0; b < NB; ++b) part[b][j] = corner_quad(pc[4 * b + j], wa0, wb0, pc[4 * (NB + b) + j], wa1, wb1);
     }
 #pragma unroll
-    for (int b = 0; b < NB; ++b) v[b] = lane_quad_total(part[b]);
+    for (int b = 0; b < NB; ++b) v[b] = need ? lane_quad_total(part[b]) : f_nan();
 }

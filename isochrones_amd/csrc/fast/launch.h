@@ -16,7 +16,9 @@ inline size_t stretch_persist_lds_bytes(int axes_len, int nb, int W, int np, boo
 // The persistent instantiation a run takes - ONE place decides it, for the occupancy query and for the launch alike
 // (round 3 queried the catalog form even when the single-model forms, with other register counts, were launched):
 //   dense                     register-capped: 4 (single stars, <= 6 bands) or 3 workgroups per CU, catalogs / many ensembles in rounds
-//   multi                     catalog, every workgroup resident: uncapped registers
+//   multi                     catalog, every workgroup resident: uncapped registers; + STDP when the stars share the
+//                             reference's default priors: shared block through scalar loads, compile-time families,
+//                             lane BC gather (<= 4 bands), table-free priors during the model gather
 //   single model, std priors  UNI + STDP: model block through scalar loads, prior families compile-time constants
 //   single model              UNI
 // Models with asteroseismic terms (ASTERO) are single models by construction (iso_catalog_create refuses them) and
@@ -41,8 +43,12 @@ inline PersistKernel persist_kernel(const StretchArgs& S)
     } else if (dense) {
         k.fn = (const void*)k_stretch_persist<KIND, NS, N, true, false>;
     } else if (S.multi) {
+        // resident catalog: when its stars share their priors and those are the reference's defaults, the form that reads
+        // them through scalar loads with the families as compile-time constants (STDP without UNI)
+        stdp = S.std_priors != 0;
         if constexpr (N == 0) k.fn = nullptr;          // a catalog has 1-12 bands (iso_catalog_create)
-        else k.fn = (const void*)k_stretch_persist<KIND, NS, N, false, false>;
+        else k.fn = stdp ? (const void*)k_stretch_persist<KIND, NS, N, false, false, false, true>
+                         : (const void*)k_stretch_persist<KIND, NS, N, false, false, false, false>;
     } else {
         uni = true;
         stdp = S.std_priors != 0;
@@ -60,7 +66,8 @@ inline bool launch_stretch_nb(int nb, const FastArgs& A, const StretchArgs& S, h
     const dim3 b(BLOCK);
     if (S.nsteps > 0) {                                       // persistent: workgroups own whole ensembles
         const int64_t n_ens = S.n_active / (S.W >> 1);
-        const int G = persist_group(S.W);
+        const int GL = persist_group(S.W);
+        const int G = (S.group > 0 && S.group < GL) ? S.group : GL;
         const dim3 gp((unsigned)((n_ens + G - 1) / G));
         PersistKernel k;
         switch (nb) {

@@ -265,7 +265,13 @@ __device__ __forceinline__ CoopLds coop_lds(double* lds, int axes_len)
 
 // waves per SIMD the register allocator must leave room for: 6 for the small single-star kernels
 // (88 -> 80 VGPR, a few dwords of scratch; measured +2 %), otherwise whatever the kernel needs
+// (tools/sweep_fast_waves.py builds the multiple-star kernels with -DISO_FAST_WAVES_MULTI=2|3|4 and times every shape:
+// the per-shape table below is what that sweep measured)
+#ifdef ISO_FAST_WAVES_MULTI
+constexpr int fast_min_waves(int ns, int nb) { return (ns == 1 && nb <= 2) ? 6 : (ns == 1 ? 4 : ISO_FAST_WAVES_MULTI); }
+#else
 constexpr int fast_min_waves(int ns, int nb) { return (ns == 1 && nb <= 2) ? 6 : 4; }
+#endif
 
 // 13-32 bands: the same evaluation with the photometric terms taken in tiles of WIDE_TILE bands (the BC cell of a
 // 32-band model is 4 KB: registers hold one tile of it at a time).  Batch form only.

@@ -243,7 +243,11 @@ __global__ __launch_bounds__(BLOCK, DENSE ? (persist_slim(DENSE, NB, NS) ? 4 : 3
     L.stride = STRIDE;
     constexpr int NP = NS + 4;
     const int W = S.W, h = W >> 1;
-    const int G = persist_group(W);
+    const int GL = persist_group(W);                     // ensembles the LDS arrays are laid out for
+    // ensembles this launch gives a workgroup: all GL, or fewer when the host spreads a small catalog over more CUs (a wave
+    // that runs alone on its SIMD and its CU's L1 finishes a half-step sooner; the moves are keyed by (step, half, row),
+    // so the chain does not depend on the split)
+    const int G = (S.group > 0 && S.group < GL) ? S.group : GL;
     const int per = h < BLOCK ? h : BLOCK;               // lanes one ensemble occupies per chunk
     const int64_t n_ens = S.n_active / h;
     const int64_t star0 = (int64_t)blockIdx.x * G;
@@ -251,8 +255,8 @@ __global__ __launch_bounds__(BLOCK, DENSE ? (persist_slim(DENSE, NB, NS) ? 4 : 3
     const int R = here * W;
     const int64_t r0 = star0 * W;
     double* lpos = lds + ((A.axes_len + 1) & ~1) + BLOCK * STRIDE;
-    double* llnp = SLIM ? S.lnp + r0 : lpos + G * W * NP;                       // slim: the global arrays themselves
-    int32_t* lacc = SLIM ? (S.accepted ? S.accepted + r0 : nullptr) : reinterpret_cast<int32_t*>(llnp + G * W);
+    double* llnp = SLIM ? S.lnp + r0 : lpos + GL * W * NP;                      // slim: the global arrays themselves
+    int32_t* lacc = SLIM ? (S.accepted ? S.accepted + r0 : nullptr) : reinterpret_cast<int32_t*>(llnp + GL * W);
     for (int j = threadIdx.x; j < R * NP; j += BLOCK) lpos[j] = S.pos[r0 * NP + j];
     if (!SLIM) {
         for (int j = threadIdx.x; j < R; j += BLOCK) {
@@ -303,7 +307,9 @@ __global__ __launch_bounds__(BLOCK, DENSE ? (persist_slim(DENSE, NB, NS) ? 4 : 3
                 const int k = k0 + kk;
                 const bool active = mine && k < h;
                 if (__any(active))                        // wave-uniform: idle waves go straight to the barrier
-                    stretch_move<KIND, NS, NB, ASTERO, UNI, STDP, UNI ? ISO_UNI_LANE : (DENSE ? ISO_DENSE_LANE : ISO_MULTI_LANE), DENSE && ISO_DENSE_SHARED>(A, S, lds, L, active, star0 + gs, active ? k : h - 1, half,
+                    stretch_move<KIND, NS, NB, ASTERO, UNI, STDP,
+                                 UNI ? ISO_UNI_LANE : (DENSE ? ISO_DENSE_LANE : (STDP ? ISO_MULTI_STD_LANE : ISO_MULTI_LANE)),
+                                 (DENSE && ISO_DENSE_SHARED) || (!UNI && !DENSE && STDP)>(A, S, lds, L, active, star0 + gs, active ? k : h - 1, half,
                                                S.step + (uint32_t)it, lpos + gs * W * NP, llnp + gs * W,
                                                lacc ? lacc + gs * W : nullptr, cp, cl);
             }

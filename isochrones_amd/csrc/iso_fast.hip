@@ -37,6 +37,28 @@ bool launch_stretch(int kind, int n_stars, int n_bands, const FastArgs& A, const
     return false;
 }
 
+// start points of a catalog (fast/start_points.h); W walkers per star, oversample * W candidates at least
+int launch_catalog_start(int kind, int n_stars, int n_bands, const FastArgs& A, double* best, double* best_lnp, int32_t* failed,
+                         int64_t n_models, int W, int oversample, int max_tries, uint64_t seed, hipStream_t s)
+{
+    fastk::StartArgs T;
+    T.best = best;
+    T.best_lnp = best_lnp;
+    T.failed = failed;
+    T.n_stars = n_models;
+    T.W = W;
+    T.chunks_min = std::max(1, (oversample * W + BLOCK - 1) / BLOCK);
+    T.chunks_max = std::max(T.chunks_min, T.chunks_min * std::max(1, max_tries));
+    T.seed = seed;
+    if (W < 1 || W > fastk::START_MAX_W) return 0;
+    bool ok = false;
+    if (kind == ISO_KIND_TRACK) ok = n_stars == 1 && launch_start_track1(n_bands, A, T, s);
+    else if (n_stars == 1) ok = launch_start_iso1(n_bands, A, T, s);
+    else if (n_stars == 2) ok = launch_start_iso2(n_bands, A, T, s);
+    else if (n_stars == 3) ok = launch_start_iso3(n_bands, A, T, s);
+    return ok ? 1 : 0;
+}
+
 size_t stretch_persist_lds(int n_bands, int axes_len, int W, int n_params, int* ensembles_per_workgroup)
 {
     if (ensembles_per_workgroup) *ensembles_per_workgroup = fastk::persist_group(W);

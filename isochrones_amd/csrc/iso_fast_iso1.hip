@@ -4,4 +4,5 @@
 namespace iso {
 ISO_DEFINE_FAST_LAUNCHER(launch_fast_iso1, ISO_KIND_ISO, 1)
 ISO_DEFINE_STRETCH_LAUNCHER(launch_stretch_iso1, ISO_KIND_ISO, 1)
+ISO_DEFINE_START_LAUNCHER(launch_start_iso1, ISO_KIND_ISO, 1)
 }  // namespace iso

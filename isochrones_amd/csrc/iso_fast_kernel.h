@@ -62,6 +62,42 @@ __device__ __forceinline__ double fast_log(double x)
 
 __device__ __forceinline__ double fast_log10(double x) { return fast_log(x) * kInvLn10; }
 
+// exp(x) for x <= 0 (the Gaussian exponents of the [Fe/H] prior: -u^2 / 2 sigma^2).  The device library's exp() spends
+// ~45 vector instructions on the full domain (overflow, the subnormal tail, +-inf); an argument that is never positive
+// needs none of that: k = round(x log2 e), r = x - k ln 2 in two pieces (|r| <= 0.3466), a degree-13 Taylor polynomial
+// (truncation 2.5e-18 relative), one v_ldexp_f64: ~20 instructions, < 1 ulp over 10^7 arguments in [-745, 0]
+// (tools/fast_log_check.c runs the same arithmetic on the host).  x < -745.2 and -inf give 0 (the library flushes
+// there too), NaN stays NaN.  ISO_FAST_EXP=0 builds the A/B counterpart on the library's exp().
+#ifndef ISO_FAST_EXP
+#define ISO_FAST_EXP 1
+#endif
+__device__ __forceinline__ double exp_nonpos(double x)
+{
+#if ISO_FAST_EXP
+    const double k = rint(x * 1.4426950408889634074);
+    double r = fma(-k, 6.93147180369123816490e-01, x);
+    r = fma(-k, 1.90821492927058770002e-10, r);
+    double p = 1.6059043836821613e-10;                       // 1/13!
+    p = fma(p, r, 2.08767569878681e-09);                     // 1/12!
+    p = fma(p, r, 2.505210838544172e-08);                    // 1/11!
+    p = fma(p, r, 2.755731922398589e-07);                    // 1/10!
+    p = fma(p, r, 2.7557319223985893e-06);                   // 1/9!
+    p = fma(p, r, 2.48015873015873e-05);                     // 1/8!
+    p = fma(p, r, 1.984126984126984e-04);                    // 1/7!
+    p = fma(p, r, 1.388888888888889e-03);                    // 1/6!
+    p = fma(p, r, 8.333333333333333e-03);                    // 1/5!
+    p = fma(p, r, 4.1666666666666664e-02);                   // 1/4!
+    p = fma(p, r, 1.6666666666666666e-01);                   // 1/3!
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    const double v = __builtin_amdgcn_ldexp(p, (int)k);      // (k >= -1075 wherever v is used)
+    return (x >= -745.2) ? v : ((x != x) ? x : 0.0);
+#else
+    return exp(x);
+#endif
+}
+
 // Instrumentation builds only (tools/phase_clock.py: -DISO_PHASE_CLOCK): lane 0 of workgroup 0 stores the shader clock at
 // the phase boundaries of an evaluation; `val` is pinned so that the phase's result exists when the clock is read.
 #ifdef ISO_PHASE_CLOCK
@@ -103,6 +139,11 @@ static __device__ unsigned long long g_phase_stamps[16];
 #ifndef ISO_MULTI_LANE
 #define ISO_MULTI_LANE 0
 #endif
+// the resident catalog kernel of stars that share the reference's default priors (STDP without UNI): a small catalog is
+// latency-bound like a single star's fit - lane BC gather (<= 4 bands) and the table-free priors during the model gather
+#ifndef ISO_MULTI_STD_LANE
+#define ISO_MULTI_STD_LANE 6
+#endif
 
 #include "fast/brackets.h"
 #include "fast/gather_lane.h"
@@ -110,6 +151,7 @@ static __device__ unsigned long long g_phase_stamps[16];
 #include "fast/coop_gather.h"
 #include "fast/lnpost_wave.h"
 #include "fast/sampler.h"
+#include "fast/start_points.h"
 #include "fast/launch.h"
 
 }  // namespace fastk
@@ -121,6 +163,12 @@ static __device__ unsigned long long g_phase_stamps[16];
     {                                                                                         \
         if (A.astq) return !multi && fastk::launch_nb<KIND, NS, false, true>(nb, A, s);       \
         return multi ? fastk::launch_nb<KIND, NS, true>(nb, A, s) : fastk::launch_nb<KIND, NS, false>(nb, A, s); \
+    }
+
+#define ISO_DEFINE_START_LAUNCHER(NAME, KIND, NS)                                             \
+    bool NAME(int nb, const FastArgs& A, const fastk::StartArgs& T, hipStream_t s)            \
+    {                                                                                         \
+        return fastk::launch_start_nb<KIND, NS>(nb, A, T, s);                                 \
     }
 
 #define ISO_DEFINE_STRETCH_LAUNCHER(NAME, KIND, NS)                                           \
@@ -146,6 +194,10 @@ bool launch_stretch_iso1(int nb, const FastArgs& A, const StretchArgs& S, hipStr
 bool launch_stretch_iso2(int nb, const FastArgs& A, const StretchArgs& S, hipStream_t s);
 bool launch_stretch_iso3(int nb, const FastArgs& A, const StretchArgs& S, hipStream_t s);
 bool launch_fast_wide(int kind, int n_stars, const FastArgs& A, hipStream_t s);
+bool launch_start_track1(int nb, const FastArgs& A, const fastk::StartArgs& T, hipStream_t s);
+bool launch_start_iso1(int nb, const FastArgs& A, const fastk::StartArgs& T, hipStream_t s);
+bool launch_start_iso2(int nb, const FastArgs& A, const fastk::StartArgs& T, hipStream_t s);
+bool launch_start_iso3(int nb, const FastArgs& A, const fastk::StartArgs& T, hipStream_t s);
 bool launch_fast_track1(int nb, bool multi, const FastArgs& A, hipStream_t s);
 bool launch_fast_iso1(int nb, bool multi, const FastArgs& A, hipStream_t s);
 bool launch_fast_iso2(int nb, bool multi, const FastArgs& A, hipStream_t s);

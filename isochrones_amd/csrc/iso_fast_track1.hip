@@ -4,6 +4,7 @@
 namespace iso {
 ISO_DEFINE_FAST_LAUNCHER(launch_fast_track1, ISO_KIND_TRACK, 1)
 ISO_DEFINE_STRETCH_LAUNCHER(launch_stretch_track1, ISO_KIND_TRACK, 1)
+ISO_DEFINE_START_LAUNCHER(launch_start_track1, ISO_KIND_TRACK, 1)
 }  // namespace iso
 
 #ifdef ISO_PHASE_CLOCK

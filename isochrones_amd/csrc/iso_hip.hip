@@ -60,6 +60,26 @@ int fail(int code, const std::string& msg)
 }
 }  // namespace iso
 
+BandPack::~BandPack()
+{
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    (void)hipSetDevice(device);
+    if (d_bcq) (void)hipFree(d_bcq);
+    if (d_axes_blob) (void)hipFree(d_axes_blob);
+    if (prev >= 0) (void)hipSetDevice(prev);
+}
+
+namespace {
+// the reference's default prior families (starmodel.py:1459-1475, priors.py): the sampler kernels then have them as
+// compile-time constants
+bool default_prior_families(const iso_model_desc& d)
+{
+    return d.prior_mass.kind == ISO_PRIOR_CHABRIER && d.prior_age.kind == ISO_PRIOR_FLATLOG && d.prior_feh.kind == ISO_PRIOR_FEH &&
+           d.prior_feh.c != 0.0 && d.prior_distance.kind == ISO_PRIOR_POWERLAW && d.prior_AV.kind == ISO_PRIOR_FLAT;
+}
+}  // namespace
+
 #define HIP_TRY(expr)                                                                         \
     do {                                                                                      \
         hipError_t e_ = (expr);                                                               \
@@ -335,6 +355,7 @@ int ensure_wide_pack(iso_table* t, int64_t n)
 namespace {
 void free_mag_pack(MagPack& mp);
 int acquire_mag_pack(iso_ic* ic, const int32_t* bc_cols, int nb, int64_t n, iso::FastArgs& F);
+hipError_t acquire_band_pack(iso_ic* ic, const int32_t* bc_cols, int nb, std::shared_ptr<BandPack>* out, bool* ok);
 }  // namespace
 
 // ---- test hook: which kernel instantiations the launchers chose (iso_debug_trace_kernels / iso_debug_kernels) ----------
@@ -893,6 +914,40 @@ hipError_t build_fast(const iso_ic* ic, int nb, const double* d_bc_hot, double**
 }
 
 
+// the shared pack of a band list (BandPack, iso_internal.h): found in the interpolator's cache or built and cached
+hipError_t acquire_band_pack(iso_ic* ic, const int32_t* bc_cols, int nb, std::shared_ptr<BandPack>* out, bool* ok)
+{
+    *ok = false;
+    std::lock_guard<std::mutex> lock(ic->mag_mu);
+    for (size_t k = 0; k < ic->band_packs.size(); ++k) {
+        std::shared_ptr<BandPack> bp = ic->band_packs[k];
+        if ((int)bp->cols.size() == nb && std::equal(bp->cols.begin(), bp->cols.end(), bc_cols)) {
+            ic->band_packs.erase(ic->band_packs.begin() + (long)k);
+            ic->band_packs.push_back(bp);
+            *out = bp;
+            *ok = true;
+            return hipSuccess;
+        }
+    }
+    std::shared_ptr<BandPack> bp(new BandPack());
+    bp->device = ic->device;
+    bp->cols.assign(bc_cols, bc_cols + nb);
+    bp->d_bcq = bp->d_axes_blob = nullptr;
+    double* d_bc_hot = nullptr;
+    hipError_t e = pack_bands(ic, bc_cols, nb, &d_bc_hot);
+    if (e == hipSuccess) e = build_fast(ic, nb, d_bc_hot, &bp->d_axes_blob, &bp->d_bcq, bp->fast, ok);
+    if (d_bc_hot) (void)hipFree(d_bc_hot);               // the fused kernels read the corner-packed copy only
+    bp->fast.bc = nullptr;
+    if (e != hipSuccess || !*ok || !bp->d_bcq) {
+        *ok = false;
+        return e;
+    }
+    if (ic->band_packs.size() >= 6) ic->band_packs.erase(ic->band_packs.begin());     // the cache lets go; holders keep theirs
+    ic->band_packs.push_back(bp);
+    *out = bp;
+    return hipSuccess;
+}
+
 void free_mag_pack(MagPack& mp)
 {
     if (mp.d_bc_hot) (void)hipFree(mp.d_bc_hot);
@@ -1173,7 +1228,7 @@ int enqueue_lnpost(iso_model* m, const double* pars, int64_t stride_n, int64_t s
     A.lnpost = lnpost_out;
     A.lnprior = lnprior_out;
     A.lnlike = lnlike_out;
-    const dim3 g(grid_blocks(n)), b(BLOCK);
+    const dim3 g((unsigned)((n + BLOCK - 1) / BLOCK)), b(BLOCK);        // one sample per lane (k_lnpost has no grid-stride loop)
     const size_t shmem = (size_t)m->ic->lds_doubles * sizeof(double);
     if (lnprior_out || lnlike_out) launch_lnpost<true>(m, g, b, shmem, s, A);
     else launch_lnpost<false>(m, g, b, shmem, s, A);
@@ -1608,13 +1663,13 @@ int iso_catalog_create(iso_ic* ic, const iso_model_desc* descs, int64_t n_models
     for (int64_t k = 0; k < n_models; ++k) fill_dev_model(&descs[k], ic->kind, H[(size_t)k]);
     hipError_t e = hipMalloc(&c->d_models, sizeof(DevModel) * (size_t)n_models);
     if (e == hipSuccess) e = hipMemcpy(c->d_models, H.data(), sizeof(DevModel) * (size_t)n_models, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = pack_bands(ic, d0.bc_cols, d0.n_bands, &c->d_bc_hot);
     bool ok = false;
-    if (e == hipSuccess) e = build_fast(ic, d0.n_bands, c->d_bc_hot, &c->d_axes_blob, &c->d_bcq, c->fast, &ok);
-    if (e == hipSuccess && (!ok || !c->d_bcq)) {
+    if (e == hipSuccess) e = acquire_band_pack(ic, d0.bc_cols, d0.n_bands, &c->pack, &ok);
+    if (e == hipSuccess && !ok) {
         iso_catalog_destroy(c);
         return fail(ISO_ERR_INVALID, "iso_catalog_create: tables not representable on the fast path");
     }
+    if (e == hipSuccess) c->fast = c->pack->fast;
     if (e != hipSuccess) {
         std::string msg = std::string("iso_catalog_create: ") + hipGetErrorString(e);
         iso_catalog_destroy(c);
@@ -1636,6 +1691,9 @@ int iso_catalog_create(iso_ic* ic, const iso_model_desc* descs, int64_t n_models
         }
         c->fast.shared_priors = shared ? 1 : 0;
         if (const char* env = std::getenv("ISOCHRONES_AMD_SHARED_PRIORS")) c->fast.shared_priors = shared && std::atoi(env) != 0;
+        bool all_default = true;                       // (the distance prior is per star: every star's family counts)
+        for (int64_t k = 0; k < n_models && all_default; ++k) all_default = default_prior_families(descs[k]);
+        c->std_priors = all_default ? 1 : 0;
     }
     c->packed = true;
     *out = c;
@@ -1669,58 +1727,54 @@ int iso_catalog_create_columns(iso_ic* ic, const iso_model_desc* tmpl, int64_t n
     const int nb = tmpl->n_bands;
     DevModel H;
     fill_dev_model(tmpl, ic->kind, H);
-    // one staging allocation: template block | columns
+    // one device block, one copy: [template block | columns | parallax flags]; the per-star blocks are filled from it by
+    // two kernels on the null stream (the callers' work on any blocking stream is ordered behind them)
     const size_t n = (size_t)n_models;
     const size_t col_doubles = n * (2 * (size_t)nb + 6 + 2 + (dist_hi ? 1 : 0));
-    DevModel* d_tmpl = nullptr;
-    double* d_cols = nullptr;
-    int32_t* d_has = nullptr;
+    const size_t tmpl_doubles = sizeof(DevModel) / sizeof(double);
+    const size_t stage_bytes = (tmpl_doubles + col_doubles) * sizeof(double) + n * sizeof(int32_t);
+    std::vector<double> stage((stage_bytes + 7) / 8);
+    std::memcpy(stage.data(), &H, sizeof(DevModel));
+    double* d_stage = nullptr;
     hipError_t e = hipMalloc(&c->d_models, sizeof(DevModel) * n);
-    if (e == hipSuccess) e = hipMalloc(&d_tmpl, sizeof(DevModel));
-    if (e == hipSuccess) e = hipMalloc(&d_cols, col_doubles * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc(&d_has, n * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc(&d_stage, stage.size() * sizeof(double));
     FillCatalogArgs F;
     std::memset(&F, 0, sizeof(F));
     if (e == hipSuccess) {
-        double* p = d_cols;
-        auto up = [&](const double* src, size_t count, const double** slot) {
-            *slot = p;
-            hipError_t r = hipMemcpy(p, src, count * sizeof(double), hipMemcpyHostToDevice);
-            p += count;
-            return r;
+        size_t off = tmpl_doubles;
+        auto put = [&](const double* src, size_t count, const double** slot) {
+            std::memcpy(stage.data() + off, src, count * sizeof(double));
+            *slot = d_stage + off;
+            off += count;
         };
-        e = hipMemcpy(d_tmpl, &H, sizeof(DevModel), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = up(mag_val, n * nb, &F.mag_val);
-        if (e == hipSuccess) e = up(mag_unc, n * nb, &F.mag_unc);
-        if (e == hipSuccess) e = up(spec_val, n * 3, &F.spec_val);
-        if (e == hipSuccess) e = up(spec_unc, n * 3, &F.spec_unc);
-        if (e == hipSuccess) e = up(plx_val, n, &F.plx_val);
-        if (e == hipSuccess) e = up(plx_unc, n, &F.plx_unc);
-        if (e == hipSuccess && dist_hi) e = up(dist_hi, n, &F.dist_hi);
-        if (e == hipSuccess) e = hipMemcpy(d_has, has_plx, n * sizeof(int32_t), hipMemcpyHostToDevice);
+        put(mag_val, n * nb, &F.mag_val);
+        put(mag_unc, n * nb, &F.mag_unc);
+        put(spec_val, n * 3, &F.spec_val);
+        put(spec_unc, n * 3, &F.spec_unc);
+        put(plx_val, n, &F.plx_val);
+        put(plx_unc, n, &F.plx_unc);
+        if (dist_hi) put(dist_hi, n, &F.dist_hi);
+        std::memcpy(stage.data() + off, has_plx, n * sizeof(int32_t));
+        F.has_plx = reinterpret_cast<const int32_t*>(d_stage + off);
+        e = hipMemcpy(d_stage, stage.data(), stage.size() * sizeof(double), hipMemcpyHostToDevice);
     }
     if (e == hipSuccess) {
         F.models = c->d_models;
-        F.tmpl = d_tmpl;
+        F.tmpl = reinterpret_cast<const DevModel*>(d_stage);
         F.n = n_models;
         F.nb = nb;
         F.i_dist = tmpl->n_stars + 2;
-        F.has_plx = d_has;
         note_kernel("k_catalog_copy_template");
         hipLaunchKernelGGL(k_catalog_copy_template, dim3(grid_blocks(n_models * (int64_t)(sizeof(DevModel) / 8))), dim3(BLOCK),
                            0, 0, F);
         note_kernel("k_catalog_fill");
         hipLaunchKernelGGL(k_catalog_fill, dim3(grid_blocks(n_models)), dim3(BLOCK), 0, 0, F);
         e = hipGetLastError();
-        if (e == hipSuccess) e = hipDeviceSynchronize();
     }
-    if (d_tmpl) (void)hipFree(d_tmpl);
-    if (d_cols) (void)hipFree(d_cols);
-    if (d_has) (void)hipFree(d_has);
-    if (e == hipSuccess) e = pack_bands(ic, tmpl->bc_cols, nb, &c->d_bc_hot);
+    if (d_stage) (void)hipFree(d_stage);                 // (hipFree waits for the kernels that read it)
     bool ok = false;
-    if (e == hipSuccess) e = build_fast(ic, nb, c->d_bc_hot, &c->d_axes_blob, &c->d_bcq, c->fast, &ok);
-    if (e == hipSuccess && (!ok || !c->d_bcq)) {
+    if (e == hipSuccess) e = acquire_band_pack(ic, tmpl->bc_cols, nb, &c->pack, &ok);
+    if (e == hipSuccess && !ok) {
         iso_catalog_destroy(c);
         return fail(ISO_ERR_INVALID, "iso_catalog_create_columns: tables not representable on the fast path");
     }
@@ -1729,9 +1783,11 @@ int iso_catalog_create_columns(iso_ic* ic, const iso_model_desc* tmpl, int64_t n
         iso_catalog_destroy(c);
         return fail(e == hipErrorOutOfMemory ? ISO_ERR_NOMEM : ISO_ERR_HIP, msg);
     }
+    c->fast = c->pack->fast;
     c->fast.m = c->d_models;
     c->fast.shared_priors = 1;          // every block is the template's but for observations and the distance prior
     if (const char* env = std::getenv("ISOCHRONES_AMD_SHARED_PRIORS")) c->fast.shared_priors = std::atoi(env) != 0;   // A/B switch
+    c->std_priors = default_prior_families(*tmpl) ? 1 : 0;
     c->packed = true;
     *out = c;
     return ISO_OK;
@@ -1764,6 +1820,23 @@ int iso_catalog_lnpost(iso_catalog* c, const int32_t* star_id, const double* par
     F.lnpost = lnpost_out;
     if (!launch_lnpost_fast(c->ic->kind, c->n_stars, c->n_bands, true, F, as_stream(stream)))
         return fail(ISO_ERR_INVALID, "iso_catalog_lnpost: no kernel specialisation");
+    HIP_TRY(hipGetLastError());
+    return ISO_OK;
+}
+
+int iso_catalog_start_points(iso_catalog* c, int nwalkers, int oversample, int max_tries, uint64_t seed, double* best,
+                             double* best_lnp, int32_t* failed, void* stream)
+{
+    if (!c || !best || !best_lnp || !failed) return fail(ISO_ERR_INVALID, "iso_catalog_start_points: NULL argument");
+    if (nwalkers < 1 || oversample < 1 || max_tries < 1)
+        return fail(ISO_ERR_INVALID, "iso_catalog_start_points: nwalkers, oversample and max_tries must be positive");
+    if ((int64_t)oversample * nwalkers * max_tries > (int64_t(1) << 24))
+        return fail(ISO_ERR_INVALID, "iso_catalog_start_points: more than 2^24 candidates per star");
+    DeviceGuard guard(c->device);
+    if (!launch_catalog_start(c->ic->kind, c->n_stars, c->n_bands, c->fast, best, best_lnp, failed, c->n_models, nwalkers,
+                              oversample, max_tries, seed, as_stream(stream)))
+        return fail(ISO_ERR_INVALID, "iso_catalog_start_points: no kernel for this shape (more than 256 walkers, or an "
+                                         "ensemble whose records do not fit the workgroup's LDS)");
     HIP_TRY(hipGetLastError());
     return ISO_OK;
 }
@@ -1931,8 +2004,8 @@ int iso_tree_lnpost(iso_tree_model* m, const double* pars, int64_t stride_n, int
     A.lnlike = lnlike_out;
     DeviceGuard guard(m->device);
     note_kernel("k_lnpost_tree");
-    hipLaunchKernelGGL(k_lnpost_tree, dim3(grid_blocks(n)), dim3(BLOCK), (size_t)m->ic->lds_doubles * sizeof(double),
-                       as_stream(stream), A);
+    hipLaunchKernelGGL(k_lnpost_tree, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK),      // one sample per lane
+                       (size_t)m->ic->lds_doubles * sizeof(double), as_stream(stream), A);
     HIP_TRY(hipGetLastError());
     return ISO_OK;
 }
@@ -2001,12 +2074,7 @@ int iso_sampler_create_model(iso_model* m, int nwalkers, double a, uint64_t seed
     iso_sampler* sp = new (std::nothrow) iso_sampler();
     if (!sp) return fail(ISO_ERR_NOMEM, "iso_sampler_create_model: out of host memory");
     sampler_common(sp, m->device, m->ic->kind, m->desc.n_stars, m->desc.n_bands, 1, m->fast, 0, nwalkers, a, seed);
-    // the reference's default prior families (starmodel.py:1459-1475, priors.py): the sampler kernel then has them as
-    // compile-time constants
-    const iso_model_desc& d = m->desc;
-    sp->std_priors = d.prior_mass.kind == ISO_PRIOR_CHABRIER && d.prior_age.kind == ISO_PRIOR_FLATLOG &&
-                     d.prior_feh.kind == ISO_PRIOR_FEH && d.prior_feh.c != 0.0 &&
-                     d.prior_distance.kind == ISO_PRIOR_POWERLAW && d.prior_AV.kind == ISO_PRIOR_FLAT;
+    sp->std_priors = default_prior_families(m->desc);
     if (const char* e = std::getenv("ISOCHRONES_AMD_STD_PRIORS")) sp->std_priors = sp->std_priors && std::atoi(e) != 0;   // A/B switch
     *out = sp;
     return ISO_OK;
@@ -2029,6 +2097,10 @@ int iso_sampler_create_catalog(iso_catalog* c, int nwalkers, double a, uint64_t 
     iso_sampler* sp = new (std::nothrow) iso_sampler();
     if (!sp) return fail(ISO_ERR_NOMEM, "iso_sampler_create_catalog: out of host memory");
     sampler_common(sp, c->device, c->ic->kind, c->n_stars, c->n_bands, c->n_models, c->fast, 1, nwalkers, a, seed);
+    // stars that share their priors, and those the reference's defaults: the resident catalog kernel reads them from the
+    // first block through scalar loads with the families as compile-time constants (fast/launch.h)
+    sp->std_priors = c->std_priors && c->fast.shared_priors;
+    if (const char* e = std::getenv("ISOCHRONES_AMD_STD_PRIORS")) sp->std_priors = sp->std_priors && std::atoi(e) != 0;   // A/B switch
     *out = sp;
     return ISO_OK;
 }
@@ -2056,6 +2128,7 @@ int iso_sampler_run(iso_sampler* sp, double* pos, double* lnp, int nsteps, doubl
     StretchArgs S;
     S.occupancy_query = nullptr;
     S.dense = 0;
+    S.group = 0;
     S.pos = pos;
     S.lnp = lnp;
     S.accepted = accepted;
@@ -2109,6 +2182,27 @@ int iso_sampler_run(iso_sampler* sp, double* pos, double* lnp, int nsteps, doubl
         }
     }
     S.dense = dense;
+    // A catalog that leaves CUs idle at `group` ensembles per workgroup is spread over more of them: fewer ensembles per
+    // workgroup (a power of two, at least 64 moves per half-step so that every wave keeps a full gather round), as many
+    // workgroups as there are CUs at most.  ISOCHRONES_AMD_PERSIST_GROUP=n pins the number (sweeps, A/B).
+    if (fits && per_cu > 0 && mode != "stepwise" && sp->n_ensembles > 1) {
+        const int h = sp->W / 2;
+        int gmin = 1;
+        while (gmin * h < 64 && gmin < group) gmin <<= 1;
+        int g = group;
+        while (g > gmin && (sp->n_ensembles + (g >> 1) - 1) / (g >> 1) <= (int64_t)cus) g >>= 1;
+        if (const char* e = std::getenv("ISOCHRONES_AMD_PERSIST_GROUP")) {
+            const int want = std::atoi(e);
+            if (want >= 1) g = std::min(want, group);
+        }
+        if (g < group) {
+            S.group = g;
+            // fewer ensembles per workgroup = more workgroups: does the launch still fit the chip in one round with the form
+            // chosen above?  If not, the register-capped form takes it (when the catalog allows it).
+            const int64_t blocks_g = (sp->n_ensembles + g - 1) / g;
+            if (blocks_g > (int64_t)cus * per_cu) S.group = 0;
+        }
+    }
     // (round 2 kept the step-wise form for catalogs of 1-1.4 rounds, where a nearly empty second round cost more than it;
     // with four workgroups per CU the persistent form is ahead there too - profiles/r03/sampler_mode_sweep.txt)
     const bool persistent = nsteps > 0 && fits && per_cu > 0 && mode != "stepwise";

@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <cstring>
 #include <string>
+#include <memory>
 #include <mutex>
 #include <vector>
 #include <atomic>
@@ -158,6 +159,8 @@ struct StretchArgs {
     int* occupancy_query; // host side only, persistent form: non-null = report workgroups/CU, do not launch
     int dense;            // host side only, persistent form: 1 = the register-capped (3 waves/SIMD) instantiation
     int std_priors;       // host side only: the single model's priors are the reference's default families
+    int group;            // persistent form: ensembles per workgroup (0 or >= the most a workgroup holds: that many);
+                          // fewer spread a small catalog over more CUs - LDS is laid out for the maximum either way
 };
 
 }  // namespace iso
@@ -197,6 +200,19 @@ struct MagPack {
     uint64_t last_use;
 };
 
+// Corner-packed BC + staged axes of one band list, shared by the catalogs an interpolator's fits build (a fit in slices /
+// shards creates one catalog per slice; packing 54 MB per band and planning the bucket tables again for each cost 1.5 ms
+// of a 10^4-star fit).  Reference-counted: the interpolator's cache and every catalog hold a reference, the device
+// buffers go with the last one - a catalog never reaches back into its interpolator to release anything.
+struct BandPack {
+    int device;
+    std::vector<int32_t> cols;
+    double* d_bcq;
+    double* d_axes_blob;
+    iso::FastArgs fast;
+    ~BandPack();
+};
+
 struct iso_ic {
     int device;
     iso_ctx* ctx;
@@ -214,6 +230,7 @@ struct iso_ic {
     std::vector<double> h_axes_model[3], h_axes_bc[4];
     std::mutex mag_mu;       // guards mag_packs
     std::vector<MagPack> mag_packs;
+    std::vector<std::shared_ptr<BandPack>> band_packs;   // catalogs' packs, most recently used last (guarded by mag_mu)
     uint64_t mag_clock;
 };
 
@@ -228,6 +245,8 @@ struct iso_catalog {
     double* d_axes_blob;
     bool packed;
     iso::FastArgs fast;
+    std::shared_ptr<BandPack> pack;   // the band list's shared pack (d_bcq / d_axes_blob above are then null)
+    int std_priors;                   // the priors the stars share are the reference's default families (and they do share them)
 };
 
 struct iso_model {
@@ -281,6 +300,9 @@ size_t stretch_persist_lds(int n_bands, int axes_len, int W, int n_params, int* 
 // defined in iso_fast_*.hip: launch the specialised fused kernel; returns false if no
 // specialisation exists for (kind, n_stars, n_bands)
 bool launch_lnpost_fast(int kind, int n_stars, int n_bands, bool multi, const FastArgs& A, hipStream_t s);
+// defined in iso_fast.hip: the start-point kernel of a catalog fit (fast/start_points.h); 0 = no instantiation for this shape
+int launch_catalog_start(int kind, int n_stars, int n_bands, const FastArgs& A, double* best, double* best_lnp, int32_t* failed,
+                         int64_t n_models, int W, int oversample, int max_tries, uint64_t seed, hipStream_t s);
 // test hook (iso_debug_trace_kernels / iso_debug_kernels): launchers name the instantiation they chose, spelled as c++filt
 // spells the kernel's symbol; a no-op unless tracing is on
 void note_kernel(const char* fmt, ...) __attribute__((format(printf, 1, 2)));

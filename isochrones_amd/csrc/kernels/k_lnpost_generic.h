@@ -26,8 +26,12 @@ __global__ __launch_bounds__(BLOCK, 2) void k_lnpost(const PostArgs A)
     __syncthreads();
     const DevModel& M = *A.m;
     constexpr int NP = NS + 4;
-    const int64_t stride_grid = (int64_t)gridDim.x * BLOCK;
-    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < A.n; i += stride_grid) {
+    // one sample per lane, no grid-stride loop: a loop keeps all ~110 dwords of the two grid descriptors alive around its
+    // body - more scalar registers than the machine has, 167-208 of them spilled to vector lanes and fetched back with
+    // v_readlane (3 801 vector instructions per wave against 1 273 in the fused kernel); straight-line code loads a
+    // descriptor field where it is used
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i < A.n) {
         double p[NP];
         {
             const double* __restrict__ src = A.pars + i * A.stride_n;

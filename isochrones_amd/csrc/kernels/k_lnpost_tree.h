@@ -31,8 +31,9 @@ __global__ __launch_bounds__(BLOCK, 2) void k_lnpost_tree(const TreeArgs A)
     stage_axes<4>(A.g4.ax, lds);
     __syncthreads();
     const DevTree& T = *A.T;
-    const int64_t stride_grid = (int64_t)gridDim.x * BLOCK;
-    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < A.n; i += stride_grid) {
+    // one sample per lane (no grid-stride loop: see k_lnpost)
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i < A.n) {
         double p[ISO_TREE_MAX_PARAMS];
         {
             const double* __restrict__ src = A.pars + i * A.stride_n;

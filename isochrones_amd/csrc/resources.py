@@ -65,12 +65,13 @@ def family(name: str) -> str:
 SCRATCH_BUDGET = {
     # family: bytes per lane.  A ratchet: set to what the family's worst instantiation needs today, lowered when a kernel
     # is reworked, never raised without a measurement that says the scratch is cheaper than the alternative.
-    "k_lnpost_fast": 364,            # triples with 9-12 bands at the 4-wave cap
+    "k_lnpost_fast": 380,            # triples with 9-12 bands at the 4-wave cap (per-shape caps: tools/sweep_fast_waves.py)
     "k_lnpost_wide": 20,
+    "k_catalog_start": 64,
     "k_stretch_half": 248,
     "k_stretch_persist": 388,        # register-capped catalog form, triples with many bands
-    "k_lnpost": 384,                 # generic fallback kernel
-    "k_lnpost_tree": 1648,           # generic tree kernel: per-leaf arrays
+    "k_lnpost": 96,                  # generic fallback kernel (one sample per lane since round 4: 384 -> 96)
+    "k_lnpost_tree": 1664,           # generic tree kernel (last-resort fallback): per-leaf arrays per lane
     "k_chain_quantiles_exact": 40,
 }
 DEFAULT_SCRATCH = 0

@@ -271,6 +271,71 @@ def test_persistent_sampler_kernel_bit_identical_to_stepwise(W, monkeypatch):
         assert torch.equal(x, y)
 
 
+@pytest.mark.parametrize("group", ["1", "2", "4", "8"])
+def test_persistent_chain_does_not_depend_on_the_ensembles_per_workgroup(group, monkeypatch):
+    """A small catalog is spread over more CUs by giving a workgroup fewer ensembles (iso_sampler_run picks the number;
+    ISOCHRONES_AMD_PERSIST_GROUP pins it).  The moves are keyed by (step, half, row), not by the lane that makes them:
+    chains, lnprob, final state and acceptance counters are bit for bit those of the step-wise kernel."""
+    import torch
+    from isochrones_amd.catalog import initial_positions
+    ic = _small_track(("G", "BP", "RP"))
+    cat, truth = synthetic_catalog(ic, 70, bands=["G", "BP", "RP"], seed=14, mag_unc=0.01)
+    post = CatalogPosterior.from_catalog(cat, ic)
+    W = 32
+    pos, lnp, failed = initial_positions(post, W, rng_seed=3)
+    assert not bool(failed.any())
+    a = _run_fused(post, pos, lnp, W, 30, "stepwise", monkeypatch)
+    monkeypatch.setenv("ISOCHRONES_AMD_PERSIST_GROUP", group)
+    for mode in ("persistent", "persistent-dense"):
+        b = _run_fused(post, pos, lnp, W, 30, mode, monkeypatch)
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+    monkeypatch.delenv("ISOCHRONES_AMD_PERSIST_GROUP")
+    b = _run_fused(post, pos, lnp, W, 30, "auto", monkeypatch)          # the library's own choice for 70 stars
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    post.close()
+
+
+def test_catalogs_of_one_interpolator_share_a_band_pack_and_outlive_each_other():
+    """The corner-packed BC + staged axes of a band list are built once per interpolator and shared by its catalogs
+    (reference-counted: closing one catalog must not pull the pack from under another; another band list gets its own)."""
+    import torch
+    ic = _small_track(("G", "BP", "RP", "J"))
+    cat1, _ = synthetic_catalog(ic, 40, bands=["G", "BP", "RP"], seed=1, mag_unc=0.01)
+    cat2, _ = synthetic_catalog(ic, 50, bands=["G", "BP", "RP"], seed=2, mag_unc=0.01)
+    cat3, _ = synthetic_catalog(ic, 30, bands=["J", "G"], seed=3, mag_unc=0.01)
+    p1 = CatalogPosterior.from_catalog(cat1, ic)
+    p2 = CatalogPosterior.from_catalog(cat2, ic)
+    p3 = CatalogPosterior.from_catalog(cat3, ic)
+    rng = np.random.default_rng(0)
+
+    def rows(post, n):
+        x = np.array([1.0, 355.0, 0.0, 300.0, 0.1]) + np.array([0.05, 10.0, 0.1, 50.0, 0.05]) * rng.standard_normal((n, 5))
+        x[:, 4] = np.abs(x[:, 4])
+        sid = rng.integers(0, post.n_models, n).astype(np.int32)
+        return torch.as_tensor(x, device="cuda"), torch.as_tensor(sid, device="cuda")
+    x2, s2 = rows(p2, 3000)
+    x3, s3 = rows(p3, 3000)
+    before2, before3 = p2.lnpost(x2, s2).clone(), p3.lnpost(x3, s3).clone()
+    p1.close()                                       # the first holder of the (G, BP, RP) pack goes
+    torch.cuda.synchronize()
+    junk = torch.full((64 << 20,), float("nan"), dtype=torch.float64, device="cuda")      # reuse freed memory if any was freed
+    after2, after3 = p2.lnpost(x2, s2), p3.lnpost(x3, s3)
+    assert torch.equal(torch.nan_to_num(before2, nan=1.5), torch.nan_to_num(after2, nan=1.5))
+    assert torch.equal(torch.nan_to_num(before3, nan=1.5), torch.nan_to_num(after3, nan=1.5))
+    del junk
+    # and the values are right: star by star against the oracle
+    oic = fx.make_oracle_ic(ic)
+    got = after2.cpu().numpy()
+    xs, ss = x2.cpu().numpy(), s2.cpu().numpy()
+    for k in np.unique(ss)[:10]:
+        sel = np.flatnonzero(ss == k)
+        want = oic.lnpost(cat2.model(int(k), ic).model_desc(), np.ascontiguousarray(xs[sel].T), nthreads=4, parts=False)
+        fx.assert_close(got[sel], want, 1e-9, atol=1e-10, what="catalog sharing a band pack")
+    p2.close(); p3.close()
+
+
 def test_persistent_sampler_binary_model_and_bad_mode(monkeypatch):
     import torch
     from isochrones_amd.sampler import FusedEnsembleSampler

@@ -309,8 +309,13 @@ def test_fused_families(kind, ns, nb):
             with traced(tid) as t:
                 pos, lnp, good = check_catalog_batch(cat, post, ic, oic, ns, rng, tid + " catalog batch")
             expect(t.names, "k_lnpost_fast<%d, %d, %d, true, false>" % (K, ns, nb), tid)
-            with env(ISOCHRONES_AMD_SAMPLER="persistent"), traced(tid) as t:
-                check_catalog_sampler(cat, post, ic, oic, ns, pos, lnp, good, 8, 90 + nb, tid + " catalog persistent")
+            expect(t.names, "k_catalog_start<%d, %d, %d>" % (K, ns, nb), tid)
+            # resident catalog kernel: shared default priors as compile-time families / every prior read at run time
+            with env(ISOCHRONES_AMD_SAMPLER="persistent", ISOCHRONES_AMD_STD_PRIORS=None), traced(tid) as t:
+                check_catalog_sampler(cat, post, ic, oic, ns, pos, lnp, good, 8, 90 + nb, tid + " catalog persistent, default priors")
+            expect(t.names, "k_stretch_persist<%d, %d, %d, false, false, false, true>" % (K, ns, nb), tid)
+            with env(ISOCHRONES_AMD_SAMPLER="persistent", ISOCHRONES_AMD_STD_PRIORS="0"), traced(tid) as t:
+                check_catalog_sampler(cat, post, ic, oic, ns, pos, lnp, good, 8, 93 + nb, tid + " catalog persistent, run-time priors")
             expect(t.names, "k_stretch_persist<%d, %d, %d, false, false, false, false>" % (K, ns, nb), tid)
             with env(ISOCHRONES_AMD_SAMPLER="persistent-dense"), traced(tid) as t:
                 check_catalog_sampler(cat, post, ic, oic, ns, pos, lnp, good, 8, 91 + nb, tid + " catalog dense")
@@ -489,10 +494,11 @@ def test_eep_unit_cube_and_summary_families():
     with traced(tid) as t:
         e = ic.get_eep(m, a, f)
     expect(t.names, "k_interp_eep", tid)
-    ok = np.isfinite(e)
-    assert ok.sum() > 500
-    back = ic.interp_value([m[ok], e[ok], f[ok]], ["age"])[:, 0]
-    assert np.allclose(back, a[ok], rtol=0, atol=2e-3)          # the EEP found reproduces the age (piecewise-linear inverse)
+    from oracle import oracle as orc
+    # the reference's interp_eeps returns 1 + the fractional row index (its EEP axis starts at 1): this table's does too
+    want = orc.interp_eep(a, f, m, np.asarray(ic.model_grid.fehs, float), np.asarray(ic.model_grid.masses, float), ic._age_grid, ic._array_lengths)
+    assert np.isfinite(want).sum() > 500
+    fx.assert_close(e, want + (float(ic.model_grid.interp.index_columns[2][0]) - 1.0), 1e-12, what="get_eep vs oracle")
     # k_unit_cube
     mod = ia.SingleStarModel(ic, Teff=(5770, 100), G=(10.0, 0.02))
     cube = rng.uniform(size=(1000, 5))

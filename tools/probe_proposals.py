@@ -22,6 +22,7 @@ def main():
     t0 = time.time()
     runs = bad_runs = 0
     shown = 0
+    codes = {}
     while time.time() - t0 < budget:
         cfg, ic, mod, axes, lo, hi = soak.build(rng)
         W = int(os.environ.get("SOAK_W", rng.choice([4, 8, 16, 30, 64, 100, 256])))
@@ -51,6 +52,9 @@ def main():
         bad[fin] = ~np.isclose(got[fin], want[fin], rtol=1e-9, atol=1e-8)
         bad[~fin] = np.isfinite(got[~fin])
         runs += 1
+        if os.environ.get("PROBE_KERNARG"):        # -DISO_DEBUG_KERNARG builds: accepted[1] carries a comparison of the re-read argument blocks
+            code = int(fs.accepted[1].item())
+            codes[(bool(bad.any()), code // 1000000, (code // 1000) % 1000, code % 1000)] = codes.get((bool(bad.any()), code // 1000000, (code // 1000) % 1000, code % 1000), 0) + 1
         if bad.any():
             bad_runs += 1
             if shown < int(os.environ.get("PROBE_SHOW", 12)):
@@ -72,6 +76,10 @@ def main():
         del fs
         ic.release()
     print("probe: %d runs, %d with wrong proposal values, %.0f s" % (runs, bad_runs, time.time() - t0))
+    if codes:
+        print("(bad run, FastArgs dwords that differ, StretchArgs dwords that differ, first differing dword or 999): runs")
+        for k in sorted(codes):
+            print("  ", k, codes[k])
 
 
 if __name__ == "__main__":
