@@ -380,6 +380,8 @@ def catalog_leg(ic, rank, world, barrier, dist, reduce_device, sizes=(10_000, 40
             out["%d_stars" % n_stars] = {"error": err or "a rank other than 0 failed"}
         else:
             out["%d_stars" % n_stars] = {"wall_s": wall, "stars_per_s": n_stars / wall, "fit_s": fit_s, "gather_s": gather_s,
+                                         # rank 0's shard by phase (seconds): per-star blocks, start points (one kernel), sampler, summaries
+                                         **{k: float(v) for k, v in (tm.get("phases") or {}).items()},
                                          "first_call_wall_s": first,
                                          "stars_per_rank_all": [int(x) for x in share.tolist()],
                                          "rows_gathered_on_rank0": int(np.isfinite(res.iloc[:, -1].values).sum()),

@@ -693,7 +693,9 @@ def fit_catalog(catalog: StarCatalog, ic, N=1, fit_fn=None, checkpoint_dir=None,
     (isochrones/starfit.py:66-77).  A stored shard is reused only if the stars, their measurements, the interpolator
     and the fit settings are the ones it was made with (a digest of all of them is stored next to the rows).
 
-    ``result.attrs["timings"]``: this rank's seconds in the fit (``fit_s``) and in the result exchange (``gather_s``)."""
+    ``result.attrs["timings"]``: this rank's seconds in the fit (``fit_s``) and in the result exchange (``gather_s``), and
+    ``phases``: the fit by phase (``build_s`` per-star blocks, ``start_s`` start points, ``sample_s`` burn-in + sampling,
+    ``summary_s`` quantile summaries and the copy of the rows to the host)."""
     import time as _time
     import warnings
     import pandas as pd
@@ -709,6 +711,7 @@ def fit_catalog(catalog: StarCatalog, ic, N=1, fit_fn=None, checkpoint_dir=None,
     fit_fn = fit_fn or fit_stars_gpu
     width = 3 * (N + 4) + 3
     rows, ckpt, error = None, None, None
+    phases = {}
     t_fit = _time.perf_counter()
 
     def fit_shard():
@@ -726,7 +729,10 @@ def fit_catalog(catalog: StarCatalog, ic, N=1, fit_fn=None, checkpoint_dir=None,
                 except Exception:        # noqa: BLE001 - an unreadable shard file is refitted
                     rows = None
         if rows is None:
-            rows = np.asarray(fit_fn(catalog, ic, mine, N=N, **fit_kwargs), dtype=np.float64)
+            kw = dict(fit_kwargs)
+            if fit_fn is fit_stars_gpu and "timings" not in kw:
+                kw["timings"] = phases           # where this rank's fit spends its time (attrs["timings"]["phases"])
+            rows = np.asarray(fit_fn(catalog, ic, mine, N=N, **kw), dtype=np.float64)
             if rows.shape != (len(mine), width):
                 raise ValueError("fit_fn returned rows of shape %s, expected %s" % (rows.shape, (len(mine), width)))
             if ckpt is not None:
@@ -787,7 +793,11 @@ def fit_catalog(catalog: StarCatalog, ic, N=1, fit_fn=None, checkpoint_dir=None,
     out = pd.DataFrame(full, index=catalog.df.index, columns=result_columns(names))
     out.attrs["shard_errors"] = errors
     out.attrs["timings"] = {"fit_s": t_gather - t_fit, "gather_s": t_end - t_gather, "world": world, "rank": rank,
-                            "backend": dist.get_backend() if distributed else None, "stars_of_this_rank": int(len(mine))}
+                            "backend": dist.get_backend() if distributed else None, "stars_of_this_rank": int(len(mine)),
+                            # this rank's shard by phase: per-star blocks, start points, burn-in + sampling, summaries (+ D2H)
+                            "phases": {"build_s": phases.get("build_posteriors", 0.0), "start_s": phases.get("initial_positions", 0.0),
+                                       "sample_s": phases.get("burn_in", 0.0) + phases.get("sampling", 0.0),
+                                       "summary_s": phases.get("summaries", 0.0)}}
     return out
 
 

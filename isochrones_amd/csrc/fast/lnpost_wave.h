@@ -265,12 +265,20 @@ __device__ __forceinline__ CoopLds coop_lds(double* lds, int axes_len)
 
 // waves per SIMD the register allocator must leave room for: 6 for the small single-star kernels
 // (88 -> 80 VGPR, a few dwords of scratch; measured +2 %), otherwise whatever the kernel needs
-// (tools/sweep_fast_waves.py builds the multiple-star kernels with -DISO_FAST_WAVES_MULTI=2|3|4 and times every shape:
-// the per-shape table below is what that sweep measured)
+// Multiple systems with many bands: the blanket 4-wave cap of rounds 1-3 held them to 128 registers and 288-364 B of
+// scratch per lane.  tools/sweep_fast_waves.py built the two- and three-star kernels for 2, 3 and 4 waves and timed every
+// (stars, bands) shape on 10^6-row batches, memory-bound and posterior-like (profiles/r04/fast_waves_*.jsonl): no
+// difference up to 8 (binaries) / 7 (triples) bands; beyond, 3 waves win by 9-20 % on both workloads (binary, 12 bands:
+// 414 -> 336 us; triple, 11 bands: 543 -> 447 us), and the triple with 12 bands takes 2 (622 -> 482 us).
 #ifdef ISO_FAST_WAVES_MULTI
 constexpr int fast_min_waves(int ns, int nb) { return (ns == 1 && nb <= 2) ? 6 : (ns == 1 ? 4 : ISO_FAST_WAVES_MULTI); }
 #else
-constexpr int fast_min_waves(int ns, int nb) { return (ns == 1 && nb <= 2) ? 6 : 4; }
+constexpr int fast_min_waves(int ns, int nb)
+{
+    if (ns == 1) return nb <= 2 ? 6 : 4;
+    if (ns == 2) return nb >= 9 ? 3 : 4;
+    return nb >= 12 ? 2 : (nb >= 8 ? 3 : 4);
+}
 #endif
 
 // 13-32 bands: the same evaluation with the photometric terms taken in tiles of WIDE_TILE bands (the BC cell of a

@@ -20,15 +20,15 @@ __device__ __forceinline__ double feh_pdf(const DevPrior& P, double x)
         constexpr double c1 = 0.8 / 0.15 / 2.5066282746310007, c2 = 0.2 / 0.22 / 2.5066282746310007;
         constexpr double e1 = -0.5 / (0.15 * 0.15), e2 = -0.5 / (0.22 * 0.22);
         const double u = x - 0.016, v = x + 0.15;
-        disk = c1 * exp_nonpos(e1 * (u * u)) + c2 * exp_nonpos(e2 * (v * v));
+        disk = c1 * exp(e1 * (u * u)) + c2 * exp(e2 * (v * v));
     } else {
         constexpr double c0 = kInvRoot2Pi / 0.3, e0 = -0.5 / (0.3 * 0.3);
         const double u = x + 0.3;
-        disk = c0 * exp_nonpos(e0 * (u * u));
+        disk = c0 * exp(e0 * (u * u));
     }
     constexpr double eh = -0.5 / (0.4 * 0.4);
     const double h = x + 1.5;
-    const double halo = P.k0 * exp_nonpos(eh * (h * h));
+    const double halo = P.k0 * exp(eh * (h * h));
     return (P.a * halo + (1 - P.a) * disk) * P.r0;   // r0 = 1/norm
 }
 

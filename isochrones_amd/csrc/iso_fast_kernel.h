@@ -62,42 +62,6 @@ __device__ __forceinline__ double fast_log(double x)
 
 __device__ __forceinline__ double fast_log10(double x) { return fast_log(x) * kInvLn10; }
 
-// exp(x) for x <= 0 (the Gaussian exponents of the [Fe/H] prior: -u^2 / 2 sigma^2).  The device library's exp() spends
-// ~45 vector instructions on the full domain (overflow, the subnormal tail, +-inf); an argument that is never positive
-// needs none of that: k = round(x log2 e), r = x - k ln 2 in two pieces (|r| <= 0.3466), a degree-13 Taylor polynomial
-// (truncation 2.5e-18 relative), one v_ldexp_f64: ~20 instructions, < 1 ulp over 10^7 arguments in [-745, 0]
-// (tools/fast_log_check.c runs the same arithmetic on the host).  x < -745.2 and -inf give 0 (the library flushes
-// there too), NaN stays NaN.  ISO_FAST_EXP=0 builds the A/B counterpart on the library's exp().
-#ifndef ISO_FAST_EXP
-#define ISO_FAST_EXP 1
-#endif
-__device__ __forceinline__ double exp_nonpos(double x)
-{
-#if ISO_FAST_EXP
-    const double k = rint(x * 1.4426950408889634074);
-    double r = fma(-k, 6.93147180369123816490e-01, x);
-    r = fma(-k, 1.90821492927058770002e-10, r);
-    double p = 1.6059043836821613e-10;                       // 1/13!
-    p = fma(p, r, 2.08767569878681e-09);                     // 1/12!
-    p = fma(p, r, 2.505210838544172e-08);                    // 1/11!
-    p = fma(p, r, 2.755731922398589e-07);                    // 1/10!
-    p = fma(p, r, 2.7557319223985893e-06);                   // 1/9!
-    p = fma(p, r, 2.48015873015873e-05);                     // 1/8!
-    p = fma(p, r, 1.984126984126984e-04);                    // 1/7!
-    p = fma(p, r, 1.388888888888889e-03);                    // 1/6!
-    p = fma(p, r, 8.333333333333333e-03);                    // 1/5!
-    p = fma(p, r, 4.1666666666666664e-02);                   // 1/4!
-    p = fma(p, r, 1.6666666666666666e-01);                   // 1/3!
-    p = fma(p, r, 0.5);
-    p = fma(p, r, 1.0);
-    p = fma(p, r, 1.0);
-    const double v = __builtin_amdgcn_ldexp(p, (int)k);      // (k >= -1075 wherever v is used)
-    return (x >= -745.2) ? v : ((x != x) ? x : 0.0);
-#else
-    return exp(x);
-#endif
-}
-
 // Instrumentation builds only (tools/phase_clock.py: -DISO_PHASE_CLOCK): lane 0 of workgroup 0 stores the shader clock at
 // the phase boundaries of an evaluation; `val` is pinned so that the phase's result exists when the clock is read.
 #ifdef ISO_PHASE_CLOCK

@@ -91,7 +91,10 @@ __global__ __launch_bounds__(tree_block<NL>(), 2) void k_lnpost_tree_fast(const 
     auto par = [&](int j) { return src[j * A.stride_p]; };        // parameters stay in memory (L1/L2 hits)
     const int n_leaves = (NL > 0) ? NL : T.n_leaves;
     TreeLeaves<NB, NL> S;
-    S.lds_ = lds + ((A.axes_len + 1) & ~1) + coop_lds_doubles(NB) + threadIdx.x;     // (unused by the register form)
+    // (unused by the register form.)  The gather slots in front of it are one per lane of THIS workgroup: TB, not BLOCK - the
+    // one-wave runtime form had been given the 256 slots of a four-wave workgroup, 14 of its 33 KB, which halved the
+    // workgroups a CU holds
+    S.lds_ = lds + ((A.axes_len + 1) & ~1) + TB * slot_stride(NB) + threadIdx.x;
     S.stride_ = TB;
     // ---- every model star: model-table gather, then magnitudes as fluxes ----
     auto leaf = [&](int l) {
@@ -226,7 +229,7 @@ static bool launch_tree_nl(int nb, int n_leaves, const FastArgs& A, const DevTre
     const dim3 g((unsigned)((A.n + TB - 1) / TB)), b(TB);
     // the runtime-leaf form keeps n_leaves * (6 + bands) values per lane in LDS behind the staged axes and gather slots
     auto sh = [&](int n) {
-        return (size_t)(((A.axes_len + 1) & ~1) + coop_lds_doubles(n) + (NL > 0 ? 0 : n_leaves * (6 + n) * TB)) * sizeof(double);
+        return (size_t)(((A.axes_len + 1) & ~1) + TB * slot_stride(n) + (NL > 0 ? 0 : n_leaves * (6 + n) * TB)) * sizeof(double);
     };
     if (sh(nb) > 64 * 1024) return false;      // (7-8 stars x 10-12 bands: the generic tree kernel takes those)
     switch (nb) {

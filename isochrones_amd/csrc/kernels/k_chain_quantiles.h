@@ -485,7 +485,10 @@ __global__ __launch_bounds__(BLOCK, 2) void k_chain_quantiles_wave(const QuantAr
 // replaced value by value.  Host dispatch: iso_chain_quantiles_layout, sizes 12 / 25 / 50 / 100 x 64 (+ tail).
 // -------------------------------------------------------------------------------------------
 // registers: the values themselves are 2 x FULL; everything else must fit in what is left for 4 (FULL <= 50) or 2 waves per SIMD
-constexpr int qexact_waves(int full) { return full <= 25 ? 4 : full <= 50 ? 4 : 2; }
+#ifndef ISO_QEXACT_WAVES_50
+#define ISO_QEXACT_WAVES_50 4
+#endif
+constexpr int qexact_waves(int full) { return full <= 25 ? 4 : full <= 50 ? ISO_QEXACT_WAVES_50 : 2; }
 
 template <int FULL, bool TAIL>
 __global__ __launch_bounds__(BLOCK, qexact_waves(FULL)) void k_chain_quantiles_exact(const QuantArgs A)

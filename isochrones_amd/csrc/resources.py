@@ -65,7 +65,7 @@ def family(name: str) -> str:
 SCRATCH_BUDGET = {
     # family: bytes per lane.  A ratchet: set to what the family's worst instantiation needs today, lowered when a kernel
     # is reworked, never raised without a measurement that says the scratch is cheaper than the alternative.
-    "k_lnpost_fast": 380,            # triples with 9-12 bands at the 4-wave cap (per-shape caps: tools/sweep_fast_waves.py)
+    "k_lnpost_fast": 108,            # per-shape wave caps since round 4 (was 364 at the blanket 4-wave cap)
     "k_lnpost_wide": 20,
     "k_catalog_start": 64,
     "k_stretch_half": 248,

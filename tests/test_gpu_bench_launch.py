@@ -56,6 +56,9 @@ def test_bench_two_ranks_prints_one_valid_line():
         assert "error" not in leg, leg
         assert leg["stars_per_s"] > 0 and leg["ok_fraction"] > 0.99
         assert leg["fit_s"] > 0 and leg["gather_s"] > 0 and leg["wall_s"] >= leg["fit_s"]
+        # the fit by phase (rank 0's shard): blocks, start points, sampler, summaries - the sampler is the bulk of it
+        assert leg["build_s"] > 0 and leg["start_s"] > 0 and leg["sample_s"] > 0 and leg["summary_s"] > 0
+        assert leg["sample_s"] > leg["start_s"] and leg["build_s"] + leg["start_s"] + leg["sample_s"] + leg["summary_s"] <= leg["fit_s"] * 1.05
         # star i -> rank (i + 1) % 2: each rank owns n // 2 stars, and after the all-gather rank 0 holds every row
         assert leg["stars_per_rank_all"] == [n // 2, n // 2]
         assert leg["rows_gathered_on_rank0"] == n
@@ -94,7 +97,10 @@ def test_bench_single_rank_default_line_has_roofline_and_cpu_baseline():
     cb = r["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["parity_pattern_ok"]
     assert cb["parity_max_rel_err"] < 1e-9
-    assert set(cb["modes"]) == {"B1_scalar_call", "B2_one_thread_1e4", "B2_one_thread_full_batch", "B3_all_cores_full_batch"}
+    assert set(cb["modes"]) == {"B1_scalar_call", "B2_one_thread_1e4", "B2_one_thread_full_batch", "B3_all_cores_full_batch",
+                                "B3_quota_threads_full_batch"}
+    # the all-cores figure is the best pass; beside it the stable one: threads = min(cores, cgroup quota), median pass
+    assert cb["value_quota"] > 0 and cb["quota_threads"] >= 1 and cb["value_quota"] <= cb["value"] * 1.5
     # every secondary line carries what bounds it (memory side or VALU issue), as a fraction that cannot exceed 1
     c3 = r["cfg3_binary_6_bands"]
     assert "error" not in c3

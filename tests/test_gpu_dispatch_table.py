@@ -305,8 +305,8 @@ def test_fused_families(kind, ns, nb):
             del mod
     if nb >= 1:      # catalog (MULTI) forms: per-row star index
         with env(ISOCHRONES_AMD_PATH="auto"):
-            cat, post = make_catalog(ic, kind, ns, bands, 24, 5 + nb)
-            with traced(tid) as t:
+            with traced(tid) as t:          # (the per-star blocks are built on the device: k_catalog_copy_template, k_catalog_fill)
+                cat, post = make_catalog(ic, kind, ns, bands, 24, 5 + nb)
                 pos, lnp, good = check_catalog_batch(cat, post, ic, oic, ns, rng, tid + " catalog batch")
             expect(t.names, "k_lnpost_fast<%d, %d, %d, true, false>" % (K, ns, nb), tid)
             expect(t.names, "k_catalog_start<%d, %d, %d>" % (K, ns, nb), tid)

@@ -65,9 +65,9 @@ def main():
         if "cfg2" in cases:
             mod.lnpost(samples["prior"][0][:4096])                      # builds the packs outside the counted launches
             for wl, batches in samples.items():
-                lnpost_launches("cfg2/" + wl, "k_lnpost_fast<0, 1, 1, true, false, false>", mod, batches, 560)
+                lnpost_launches("cfg2/" + wl, "k_lnpost_fast<0, 1, 1, false, false>", mod, batches, 560)
             # the one-batch-repeated form of rounds 1-2 next to it (what the Infinity Cache hides)
-            lnpost_launches("cfg2/prior_valid_single_batch", "k_lnpost_fast<0, 1, 1, true, false, false>", mod,
+            lnpost_launches("cfg2/prior_valid_single_batch", "k_lnpost_fast<0, 1, 1, false, false>", mod,
                             samples["prior_valid"][:1], 560)
         if "generic" in cases:
             os.environ["ISOCHRONES_AMD_PATH"] = "generic"
@@ -86,7 +86,7 @@ def main():
             if first:
                 mod3.lnpost(batches[0][:4096])
                 first = False
-            lnpost_launches("cfg3/" + wl, "k_lnpost_fast<1, 2, 6, true, false, false>", mod3, batches, 2360)
+            lnpost_launches("cfg3/" + wl, "k_lnpost_fast<1, 2, 6, false, false>", mod3, batches, 2360)
             del batches
         del mod3, ic3
     if "astero" in cases:
@@ -95,7 +95,7 @@ def main():
                                  nu_max=(3000.0, 100.0), delta_nu=(135.0, 3.0))
         batches = [bench.make_samples(np.random.default_rng(12345 + b), n, "prior_valid") for b in range(NB)]
         mod.lnpost(batches[0][:4096])
-        lnpost_launches("astero/prior_valid", "k_lnpost_fast<0, 1, 1, true, false, true>", mod, batches, 688)
+        lnpost_launches("astero/prior_valid", "k_lnpost_fast<0, 1, 1, false, true>", mod, batches, 688)
         del batches
         del mod, ic
     if "tree" in cases:
