@@ -1165,6 +1165,9 @@ namespace {
 template <int KIND, int NS, bool PARTS>
 void launch_lnpost_nb(int nb, dim3 g, dim3 b, size_t shmem, hipStream_t s, const PostArgs& A)
 {
+    // ISOCHRONES_AMD_GENERIC_RUNTIME_NB=1: the run-time band loop for every band count (A/B of the compile-time band counts)
+    static const bool runtime_nb = [] { const char* e = std::getenv("ISOCHRONES_AMD_GENERIC_RUNTIME_NB"); return e && e[0] == '1'; }();
+    if (runtime_nb) nb = 0;
     switch (nb) {
     case 1: note_kernel("k_lnpost<%d, %d, 1, %s>", KIND, NS, tf(PARTS)); hipLaunchKernelGGL((k_lnpost<KIND, NS, 1, PARTS>), g, b, shmem, s, A); break;
     case 2: note_kernel("k_lnpost<%d, %d, 2, %s>", KIND, NS, tf(PARTS)); hipLaunchKernelGGL((k_lnpost<KIND, NS, 2, PARTS>), g, b, shmem, s, A); break;
