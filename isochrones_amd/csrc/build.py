@@ -111,13 +111,16 @@ def resource_table() -> dict:
 
 def build(force: bool = False, verbose: bool = False, gate: bool = True) -> str:
     """Compile what is out of date, link, record every kernel's register / scratch use and enforce the budget of
-    resources.py on it (gate; ISOCHRONES_AMD_RESOURCE_GATE=0 turns a violation into a warning for experiments)."""
+    resources.py on it (gate; ISOCHRONES_AMD_RESOURCE_GATE=0 turns a violation into a warning for experiments); scan every
+    translation unit's generated code with isa_check.py (ISOCHRONES_AMD_ISA_GATE=0: warning only)."""
     import json
     try:
         from . import resources as R
+        from . import isa_check as I
     except ImportError:                  # run as a script
         sys.path.insert(0, HERE)
         import resources as R
+        import isa_check as I
     digest = source_digest()
     if not force and not verbose and up_to_date():
         return OUT                       # this very file was built from exactly these sources: nothing to do
@@ -194,6 +197,37 @@ def build(force: bool = False, verbose: bool = False, gate: bool = True) -> str:
                 except OSError:
                     pass
             raise ResourceBudgetError(msg)
+        sys.stderr.write("WARNING: " + msg + "\n")
+    # the generated code of every translation unit, checked for vector instructions ahead of an exec restore (isa_check.py:
+    # the one code-generation fault this project has met); a result is kept with the digests of the object and the checker
+    with open(I.__file__, "rb") as f:
+        checker = hashlib.sha256(f.read()).hexdigest()
+
+    def isa_of(obj):
+        want = {"checker": checker, "object": open(obj[:-2] + ".dig").read().strip()}
+        try:
+            with open(obj[:-2] + ".isa") as f:
+                have = json.load(f)
+            if all(have.get(k) == v for k, v in want.items()):
+                return have["found"]
+        except (OSError, ValueError):
+            pass
+        want["found"] = I.scan_library(obj, jobs=1)
+        with open(obj[:-2] + ".isa", "w") as f:
+            json.dump(want, f)
+        return want["found"]
+
+    with ThreadPoolExecutor(max_workers=os.cpu_count() or 2) as ex:
+        faults = [tuple(r) for found in ex.map(isa_of, objs) for r in found]
+    if faults:
+        msg = I.render(faults)
+        if gate and os.environ.get("ISOCHRONES_AMD_ISA_GATE", "1") != "0":
+            for stale_file in (STAMP, RESOURCES):
+                try:
+                    os.remove(stale_file)
+                except OSError:
+                    pass
+            raise I.IsaFault(msg)
         sys.stderr.write("WARNING: " + msg + "\n")
     if force or jobs or stale or _newer(OUT, objs):
         subprocess.check_call([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs, cwd=HERE)
