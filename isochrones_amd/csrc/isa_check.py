@@ -21,6 +21,10 @@ The check: for every `s_cbranch_execz` that directly follows an instruction narr
 exec at the target being an `s_or_b64 exec, exec, sN`, no vector instruction may stand between the target and that
 restore.  Scalar instructions (s_mov, s_load, s_waitcnt, s_nop, ...) are exec-independent and allowed.
 
+Out of reach of a listing: an `if` whose `then` side is so short that the compiler emits no skip branch has no branch target
+to anchor on, and a copy in front of its `s_or_b64 exec` cannot be told from the `then` side's own last instruction.  For
+that form the net is tests/test_gpu_dispatch_table.py (every instantiation against the oracle, default priors).
+
     python -m isochrones_amd.csrc.isa_check libiso_hip.so          # exit 1 and a listing when anything is found
 Used by build.py on every translation unit's object (ISOCHRONES_AMD_ISA_GATE=0 turns a finding into a warning) and by
 tests/test_resource_gate.py.
