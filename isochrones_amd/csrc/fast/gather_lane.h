@@ -93,10 +93,10 @@ template <int NB>
 __device__ __forceinline__ void lane_bc(const FastArgs& A, bool need, uint32_t cell, const W4& w, double* __restrict__ v)
 {
     // Every lane gathers, needed or not (a lane without a usable bracket reads cell 0, which always exists, and gets NaN at
-    // the end): no divergent region around the 8 NB loads.  Round 3's wrong sampler instantiation - (isochrone, 3 stars,
-    // 9 bands) under a reordered model block - had `if (!need) return;` here, 72 loads in flight inside the branch; every
-    // build of that source state that made wrong moves had it, and the same source without it made none (round 4's hunt:
-    // profiles/r04/miscompile_hunt.md).  The cause inside the compiler's output was not found; the shape is avoided.
+    // the end): no divergent region around the 8 NB loads, i.e. one `if` less whose join block the register allocator can
+    // fill with copies.  (Round 3's wrong (isochrone, 3 stars, 9 bands) sampler kernel was such a copy placed ahead of a join
+    // block's exec restore - in the flux sum's |m| > 700 region, not here: profiles/r04/miscompile_hunt.md; csrc/isa_check.py
+    // refuses a build that has the shape anywhere.)
     cell = need ? cell : 0u;
     const double2* __restrict__ pc = reinterpret_cast<const double2*>(A.bcq + (size_t)cell * (16 * NB));
     double part[NB][4];

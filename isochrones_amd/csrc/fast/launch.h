@@ -18,7 +18,7 @@ inline size_t stretch_persist_lds_bytes(int axes_len, int nb, int W, int np, boo
 //   dense                     register-capped: 4 (single stars, <= 6 bands) or 3 workgroups per CU, catalogs / many ensembles in rounds
 //   multi                     catalog, every workgroup resident: uncapped registers; + STDP when the stars share the
 //                             reference's default priors: shared block through scalar loads, compile-time families,
-//                             lane BC gather (<= 4 bands), table-free priors during the model gather
+//                             lane BC gather (one band), table-free priors during the model gather
 //   single model, std priors  UNI + STDP: model block through scalar loads, prior families compile-time constants
 //   single model              UNI
 // Models with asteroseismic terms (ASTERO) are single models by construction (iso_catalog_create refuses them) and

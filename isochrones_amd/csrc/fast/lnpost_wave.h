@@ -16,7 +16,15 @@
 // from the corner-packed table (gather_lane.h) - the latency form of a lone workgroup.
 // bit 2 of LANE: the priors that do not depend on the model table are evaluated between the issue of the primary's
 // model gather and the use of its data (coop_star's `between`).
-constexpr int LANE_BC_MAX_BANDS = 4;
+// Bands up to which the BC gather is taken lane-per-sample where LANE asks for it.  Measured per step of one star's fit
+// (tools/single_fit_shapes.py, profiles/r04/lane_bc_cap_ab.jsonl; 256 walkers): 1 band 8.97 us against 9.67 cooperative;
+// 2 / 3 / 4 bands 10.08 / 10.58 / 11.63 against 9.35 / 9.67 / 9.93; lifted to 8 bands: 5 / 6 / 8 bands 12.6 / 13.8 / 22.6
+// against 10.3 / 10.7 / 11.9 (16 loads of 16 B per band and lane).  The resident catalog kernel at 3 bands: 10^4 stars
+// 9.49 -> 8.20 ms cooperative.  Only 32-walker single fits liked 2-3 bands lane-wise (3-6 %).  So: one band.
+#ifndef ISO_LANE_BC_MAX_BANDS
+#define ISO_LANE_BC_MAX_BANDS 1
+#endif
+constexpr int LANE_BC_MAX_BANDS = ISO_LANE_BC_MAX_BANDS;
 template <int KIND, int NS, int NB, bool ASTERO = false, bool MASKED = false, bool TILED = false, bool STDP = false,
           int LANE = 0>
 __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* lds, const CoopLds& L, bool active,
@@ -181,8 +189,7 @@ __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* l
             {
                 uint32_t cell = cell4(A, j0, j1, j2, j3);
                 ISO_STAMP(5, cell);
-                // (the lane form keeps 8 NB pieces of 16 B in flight per lane: up to four bands - beyond that the cooperative
-                // gather is no slower and the kernel needs far fewer registers; DESIGN section 7 has the history)
+                // (the lane form keeps 16 NB pieces of 16 B in flight per lane: it pays for one band only - LANE_BC_MAX_BANDS)
                 if constexpr ((LANE & 2) != 0 && NB <= LANE_BC_MAX_BANDS) lane_bc<NB>(A, ok, cell, w4v, bc);
                 else coop_bc<NB>(A, L, ok, cell, w4v, bc);
                 ISO_STAMP(6, bc[0]);

@@ -104,7 +104,7 @@ static __device__ unsigned long long g_phase_stamps[16];
 #define ISO_MULTI_LANE 0
 #endif
 // the resident catalog kernel of stars that share the reference's default priors (STDP without UNI): a small catalog is
-// latency-bound like a single star's fit - lane BC gather (<= 4 bands) and the table-free priors during the model gather
+// latency-bound like a single star's fit - lane BC gather (one band: lnpost_wave.h) and the table-free priors during the model gather
 #ifndef ISO_MULTI_STD_LANE
 #define ISO_MULTI_STD_LANE 6
 #endif
