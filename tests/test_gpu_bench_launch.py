@@ -62,6 +62,9 @@ def test_bench_two_ranks_prints_one_valid_line():
         # star i -> rank (i + 1) % 2: each rank owns n // 2 stars, and after the all-gather rank 0 holds every row
         assert leg["stars_per_rank_all"] == [n // 2, n // 2]
         assert leg["rows_gathered_on_rank0"] == n
+        # small catalogs are timed five times and the median pass is the one reported
+        assert leg["timed_passes"] == (5 if n <= 20_000 else 1) and len(leg["wall_s_all_passes"]) == leg["timed_passes"]
+        assert leg["wall_s_all_passes"] == sorted(leg["wall_s_all_passes"])
 
 
 def test_bench_gpus_2_without_a_launcher_spawns_its_own_ranks():
