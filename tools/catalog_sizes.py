@@ -18,8 +18,9 @@ def main():
     ap.add_argument("--groups", default="0")
     ap.add_argument("--start", default="kernel")
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--bands", default="G,BP,RP")
     args = ap.parse_args()
-    bands = ["G", "BP", "RP"]
+    bands = args.bands.split(",")
     ic = ia.synthetic_track(bands=bands)
     warm, _ = ia.synthetic_catalog(ic, 64, bands=bands, seed=1, mag_unc=0.01)
     fit_stars_gpu(warm, ic, np.arange(64), nwalkers=32, nburn=5, niter=5)
