@@ -70,7 +70,11 @@ struct CoopLds {
 struct NoWorkBetween {
     __device__ __forceinline__ void operator()() const {}
 };
-template <bool RUN_BETWEEN = false, class Between = NoWorkBetween>
+// DEEP: the loads of all four rounds (24 x 16 B per lane) are in flight before the first use.  Slower than two batches of two
+// wherever the rounds of a wave serve one star (profiles/r04/coop_deep_batches_ab.jsonl) - the short batches overlap already -
+// but in the one-star-per-lane form the lower rounds are the primaries' and the upper ones the companions': two batches would
+// put the two stars' latencies one behind the other again.
+template <bool RUN_BETWEEN = false, class Between = NoWorkBetween, bool DEEP = false>
 __device__ __forceinline__ void coop_star(const FastArgs& A, const CoopLds& L, bool need, uint32_t cell, const W3& w,
                                           double* __restrict__ v, Between&& between = Between())
 {
@@ -83,15 +87,17 @@ __device__ __forceinline__ void coop_star(const FastArgs& A, const CoopLds& L, b
     const unsigned long long m = __ballot(need);
     const int j = L.lane & 3, grp = L.lane >> 2;
     ISO_STAMP_HERE(10);
-    // two batches of two iterations: the 12 loads of a batch are in flight before the first use
+    // two batches of two iterations: the 12 loads of a batch are in flight before the first use (DEEP: one batch of four)
+    constexpr int PER = DEEP ? 4 : 2;
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        if ((!RUN_BETWEEN || half != 0) && ((m >> (32 * half)) & 0xFFFFFFFFull) == 0) continue;          // wave-uniform
-        double2 u[2][6];
-        double wlo[2], whi[2];
+    for (int half = 0; half < 4 / PER; ++half) {
+        if (!DEEP && (!RUN_BETWEEN || half != 0) && ((m >> (32 * half)) & 0xFFFFFFFFull) == 0) continue;          // wave-uniform
+        double2 u[PER][6];
+        double wlo[PER], whi[PER];
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int src = 16 * (2 * half + k) + grp;
+        for (int k = 0; k < PER; ++k) {
+            if (DEEP && k > 0 && ((m >> (16 * k)) & 0xFFFFull) == 0) continue;      // wave-uniform: nobody owns these 16 slots
+            const int src = 16 * (PER * half + k) + grp;
             const double* rq = L.req + src * L.stride;
             const double hdr = rq[0];
             const double t0 = rq[1], t1 = rq[2], t2 = rq[3];
@@ -107,8 +113,9 @@ __device__ __forceinline__ void coop_star(const FastArgs& A, const CoopLds& L, b
         if (RUN_BETWEEN && half == 0) between();
         if (half == 0) { ISO_STAMP(11, whi[1]); ISO_STAMP(12, u[0][0].x); ISO_STAMP(13, u[1][5].y); }
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int src = 16 * (2 * half + k) + grp;
+        for (int k = 0; k < PER; ++k) {
+            if (DEEP && k > 0 && ((m >> (16 * k)) & 0xFFFFull) == 0) continue;
+            const int src = 16 * (PER * half + k) + grp;
             double part[6];
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
@@ -176,7 +183,7 @@ __device__ __forceinline__ void coop_pair(const double* __restrict__ tab, const 
 }
 
 // BC table: lane j of a quad handles the corners whose (axis-1, axis-2) offsets are the bits of j
-template <int NB>
+template <int NB, bool DEEP = false>
 __device__ __forceinline__ void coop_bc(const FastArgs& A, const CoopLds& L, bool need, uint32_t cell, const W4& w,
                                         double* __restrict__ v)
 {
@@ -189,16 +196,21 @@ __device__ __forceinline__ void coop_bc(const FastArgs& A, const CoopLds& L, boo
     __builtin_amdgcn_wave_barrier();
     const unsigned long long m = __ballot(need);
     const int j = L.lane & 3, grp = L.lane >> 2;
-    // batches sized so that <= 12 x 16-B loads per lane are in flight before the first use
-    constexpr int BATCH = (NB <= 1) ? 4 : (NB <= 3) ? 2 : 1;
+    // batches sized so that <= 12 x 16-B loads per lane are in flight before the first use (DEEP, see coop_star: <= 32, and
+    // never fewer than two rounds - a primary's and a companion's)
+    // a batch of two is then rounds {r, r + 2} - one of the primaries', one of the companions')
+    constexpr int BATCH = DEEP ? ((NB <= 4) ? 4 : (NB <= 8) ? 2 : 1) : ((NB <= 1) ? 4 : (NB <= 3) ? 2 : 1);
+    constexpr bool PAIRED = DEEP && BATCH == 2;
 #pragma unroll
     for (int r0 = 0; r0 < 4; r0 += BATCH) {
-        if (((m >> (16 * r0)) & ((BATCH == 4) ? ~0ull : ((1ull << (16 * BATCH)) - 1ull))) == 0) continue;   // wave-uniform
+        if (PAIRED) {
+            if ((((m >> (8 * r0)) | (m >> (32 + 8 * r0))) & 0xFFFFull) == 0) continue;                      // rounds r0/2 and 2 + r0/2
+        } else if (((m >> (16 * r0)) & ((BATCH == 4) ? ~0ull : ((1ull << (16 * BATCH)) - 1ull))) == 0) continue;   // wave-uniform
         double2 x[BATCH][2 * NB];
         double wa[BATCH][2], wb[BATCH][2];
 #pragma unroll
         for (int k = 0; k < BATCH; ++k) {
-            const int src = 16 * (r0 + k) + grp;
+            const int src = 16 * (PAIRED ? (2 * k + (r0 >> 1)) : (r0 + k)) + grp;
             const double* rq = L.req + src * L.stride;
             const double hdr = rq[0];
             const double t0 = rq[1], t1 = rq[2], t2 = rq[3], t3 = rq[4];
@@ -215,7 +227,7 @@ __device__ __forceinline__ void coop_bc(const FastArgs& A, const CoopLds& L, boo
         }
 #pragma unroll
         for (int k = 0; k < BATCH; ++k) {
-            const int src = 16 * (r0 + k) + grp;
+            const int src = 16 * (PAIRED ? (2 * k + (r0 >> 1)) : (r0 + k)) + grp;
             double* rs = L.rsp + src * L.stride;
 #pragma unroll
             for (int b = 0; b < NB; ++b) {

@@ -21,6 +21,7 @@ inline size_t stretch_persist_lds_bytes(int axes_len, int nb, int W, int np, boo
 //                             lane BC gather (one band), table-free priors during the model gather
 //   single model, std priors  UNI + STDP: model block through scalar loads, prior families compile-time constants
 //   single model              UNI
+//   single binary             k_stretch_pair (+ STDP): one star per lane, when a half-step's moves fit half a workgroup
 // Models with asteroseismic terms (ASTERO) are single models by construction (iso_catalog_create refuses them) and
 // have no register-capped form: a run of very many ensembles of such a model takes the UNI kernel in rounds.
 struct PersistKernel {
@@ -52,6 +53,22 @@ inline PersistKernel persist_kernel(const StretchArgs& S)
     } else {
         uni = true;
         stdp = S.std_priors != 0;
+        if constexpr (KIND == ISO_KIND_ISO && NS == 2) {
+            // a single binary whose half-step fits half a workgroup: one star per lane (k_stretch_pair, sampler.h)
+            const int h = S.W >> 1;
+            const int64_t n_ens = S.n_active / h;
+            const int GL = persist_group(S.W);
+            const int G = (S.group > 0 && S.group < GL) ? S.group : GL;
+            // measured (profiles/r04/pair_kernel_ab.jsonl, us per step): up to 16 moves per wave 13.2 -> 10.0 (1 band), 21.7 ->
+            // 19.4 (12 bands); 17-32 moves per wave 14.4 -> 13.4 (1 band), nothing beyond 4 bands
+            const int64_t moves = (n_ens < G ? n_ens : G) * h;
+            if (S.pair && moves <= BLOCK / 2 && (moves <= BLOCK / 4 || N <= 4)) {
+                k.fn = stdp ? (const void*)k_stretch_pair<N, true> : (const void*)k_stretch_pair<N, false>;
+                k.dense = false;
+                snprintf(k.name, sizeof k.name, "k_stretch_pair<%d, %s>", N, tf(stdp));
+                return k;
+            }
+        }
         k.fn = stdp ? (const void*)k_stretch_persist<KIND, NS, N, false, false, true, true>
                     : (const void*)k_stretch_persist<KIND, NS, N, false, false, true, false>;
     }

@@ -16,6 +16,11 @@
 // from the corner-packed table (gather_lane.h) - the latency form of a lone workgroup.
 // bit 2 of LANE: the priors that do not depend on the model table are evaluated between the issue of the primary's
 // model gather and the use of its data (coop_star's `between`).
+// bit 4 of LANE (binaries, NS = 2): ONE STAR PER LANE.  The caller has given lanes l and l + 32 of a wave the same sample;
+// lane l walks the primary's chain (EEP bracket, model gather, BC brackets, BC gather), lane l + 32 the companion's, side
+// by side instead of one after the other - a lone wave has nothing else to overlap them with, and a second star then costs
+// one exchange across the wave's halves (6 + NB values) instead of most of an evaluation.  After the exchanges both lanes
+// hold both stars' numbers and do the same arithmetic in the same order: the result is the one of the plain form, bit for bit.
 // Bands up to which the BC gather is taken lane-per-sample where LANE asks for it.  Measured per step of one star's fit
 // (tools/single_fit_shapes.py, profiles/r04/lane_bc_cap_ab.jsonl; 256 walkers): 1 band 8.97 us against 9.67 cooperative;
 // 2 / 3 / 4 bands 10.08 / 10.58 / 11.63 against 9.35 / 9.67 / 9.93; lifted to 8 bands: 5 / 6 / 8 bands 12.6 / 13.8 / 22.6
@@ -62,8 +67,29 @@ __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* l
     };
     double star[NS][6];
     double astero[2] = {0.0, 0.0};
+    constexpr bool SPREAD = (LANE & 16) != 0;
+    static_assert(!SPREAD || (NS == 2 && KIND == ISO_KIND_ISO && !TILED && !ASTERO && (LANE & 1) == 0),
+                  "one star per lane: binaries on the isochrone grid, cooperative model gather");
+    const bool companion = SPREAD && (L.lane & 32) != 0;
+    if constexpr (SPREAD) {
+        const double eep = companion ? p[1] : p[0];
+        const bool ok = bool(ok01 & !(eep != eep) & !eep_oob(A, eep));
+        int i2;
+        eep_bracket(A, lds, eep, i2, w.t2);
+        const uint32_t cell = cell3(A, i0, i1, i2);
+        double mine[6];
+        // (DEEP: the primaries' rounds and the companions' in one flight)
+        if constexpr (OVERLAP) coop_star<true, decltype(table_free_priors)&, true>(A, L, ok, cell, w, mine, table_free_priors);
+        else coop_star<false, NoWorkBetween, true>(A, L, ok, cell, w, mine);
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
+        for (int q = 0; q < 6; ++q) {
+            const double other = __shfl_xor(mine[q], 32);
+            star[0][q] = companion ? other : mine[q];
+            star[1][q] = companion ? mine[q] : other;
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < (SPREAD ? 0 : NS); ++s) {
         const double eep = (KIND == ISO_KIND_TRACK) ? p[1] : p[s];
         const bool ok = bool(ok01 & !(eep != eep) & !eep_oob(A, eep));
         int i2;
@@ -172,6 +198,52 @@ __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* l
                 const double mv = M.mag_val[band];
                 const double r = mv - mag;
                 if (b0 + b < nbt && (!MASKED || mv == mv)) lnl += M.mag_g0[band] - r * r * M.mag_hinv[band];
+            }
+        }
+    } else if constexpr (SPREAD && NB > 0) {
+        // each lane gathers the BC of its own star; the halves of the wave swap them; the flux sum then runs as below
+        double tot[NB], rel[NB];
+        const bool okA = bool(go & !(AV != AV) & !lds_oob(lds, A.b3, AV));
+        double bcm[NB];
+        {
+            const double T = companion ? star[1][0] : star[0][0], g = companion ? star[1][1] : star[0][1],
+                         f = companion ? star[1][2] : star[0][2];
+            const bool ok = bool(okA & !(T != T) & !(g != g) & !(f != f) & !lds_oob(lds, A.b0, T) &
+                                 !lds_oob(lds, A.b1, g) & !lds_oob(lds, A.b2, f));
+            int j0, j1, j2, j3;
+            W4 w4v;
+            lds_bracket4(lds, A.b0, A.b1, A.b2, A.b3, T, g, f, AV, j0, j1, j2, j3, w4v.t0, w4v.t1, w4v.t2, w4v.t3);
+            const uint32_t cell = cell4(A, j0, j1, j2, j3);
+            if constexpr ((LANE & 2) != 0 && NB <= LANE_BC_MAX_BANDS) lane_bc<NB>(A, ok, cell, w4v, bcm);
+            else coop_bc<NB, true>(A, L, ok, cell, w4v, bcm);
+        }
+    #pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const double other = __shfl_xor(bcm[b], 32);
+            const double bc0 = companion ? other : bcm[b], bc1 = companion ? bcm[b] : other;
+            {   // primary (the s == 0 step of the loop below)
+                const double mag = star[0][3] + dm - bc0;
+                const bool far = fabs(mag) > 700.0;
+                tot[b] = far ? 0.0 : mag;
+                rel[b] = 1.0;
+                if (__ballot(far)) rel[b] = far ? exp10(-0.4 * mag) : 1.0;
+            }
+            {   // companion (s == 1)
+                const double mag = star[1][3] + dm - bc1;
+                rel[b] += exp10(-0.4 * (mag - tot[b]));
+            }
+        }
+    #pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const double mag = fma(-2.5, fast_log10(rel[b]), tot[b]);
+            if constexpr (STDP) {
+                const double mv = M.mag_val[b], g0 = M.mag_g0[b], hinv = M.mag_hinv[b];
+                const double r = mv - mag;
+                const double term = g0 - r * r * hinv;
+                lnl += (!MASKED || mv == mv) ? term : 0.0;
+            } else {
+                const double r = M.mag_val[b] - mag;
+                if (!MASKED || M.mag_val[b] == M.mag_val[b]) lnl += M.mag_g0[b] - r * r * M.mag_hinv[b];
             }
         }
     } else if constexpr (NB > 0) {   // NB = 0: spectroscopy / parallax only, the BC table is never touched

@@ -44,7 +44,7 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 // for launches whose stars do share them.
 template <int KIND, int NS, int NB, bool ASTERO, bool UNI = false, bool STDP = false, int LANE = 0, bool SHAREDP = false>
 __device__ __forceinline__ void stretch_move(const FastArgs& A, const StretchArgs& S, double* lds, const CoopLds& L,
-                                             bool active, int64_t star, int k, int half, uint32_t step,
+                                             bool active, bool owner, int64_t star, int k, int half, uint32_t step,
                                              double* __restrict__ pos, double* __restrict__ lnp, int32_t* acc_cnt,
                                              double* __restrict__ chain_pos, double* __restrict__ chain_lnp)
 {
@@ -88,7 +88,9 @@ __device__ __forceinline__ void stretch_move(const FastArgs& A, const StretchArg
                                  : ((!UNI && S.multi && A.shared_priors) ? A.m[0] : M);      // catalogs: the priors all stars share
     const double lnew = lnpost_wave<KIND, NS, NB, ASTERO, true, false, STDP, LANE>(A, lds, L, active, M, MP, y, false, lnp_unused, lnl_unused);
     const double lnq = (NP - 1) * fast_log(z) + lnew - lold;
-    const bool acc = active && isfinite(lnew) && (fast_log(u2) < lnq);
+    // owner: the lane that decides and stores the move (= active, except in the one-star-per-lane form, where the companion's
+    // lane evaluates the same proposal alongside and leaves the rest to the primary's)
+    const bool acc = owner && isfinite(lnew) && (fast_log(u2) < lnq);
     if (acc) {
 #pragma unroll
         for (int q = 0; q < NP; ++q) pos[lr * NP + q] = y[q];
@@ -96,11 +98,11 @@ __device__ __forceinline__ void stretch_move(const FastArgs& A, const StretchArg
         if (acc_cnt) acc_cnt[lr] += 1;
     }
     // chain recording: every move stores the row it owns (its value for this step)
-    if (active && chain_pos) {
+    if (owner && chain_pos) {
 #pragma unroll
         for (int q = 0; q < NP; ++q) chain_pos[lr * S.chain_rs + q * S.chain_ps] = acc ? y[q] : xk[q];
     }
-    if (active && chain_lnp) chain_lnp[lr] = acc ? lnew : lold;
+    if (owner && chain_lnp) chain_lnp[lr] = acc ? lnew : lold;
     ISO_STAMP(8, lr);
 }
 
@@ -231,8 +233,10 @@ __host__ __device__ constexpr int persist_extra_doubles(int W, int np, bool slim
 
 // DENSE: registers capped so that 3 (slim: 4) workgroups share a CU; the uncapped form (2 workgroups per CU) is 10 %
 // faster when latency is all that matters (every workgroup resident at once, e.g. a single star's fit).
-template <int KIND, int NS, int NB, bool DENSE, bool ASTERO = false, bool UNI = false, bool STDP = false>
-__global__ __launch_bounds__(BLOCK, DENSE ? (persist_slim(DENSE, NB, NS) ? 4 : 3) : 2) void k_stretch_persist(const FastArgs A, const StretchArgs S)
+// PAIR (single binaries, at most BLOCK / 2 moves per half-step): one star per lane - lanes l and l + 32 of a wave share a
+// move, the primary's lane owns it (lnpost_wave's LANE bit 4).
+template <int KIND, int NS, int NB, bool DENSE, bool ASTERO, bool UNI, bool STDP, bool PAIR>
+__device__ __forceinline__ void persist_body(const FastArgs& A, const StretchArgs& S)
 {
     extern __shared__ double lds[];
     for (int j = threadIdx.x; j < A.axes_len; j += BLOCK) lds[j] = A.axes_blob[j];
@@ -273,7 +277,20 @@ __global__ __launch_bounds__(BLOCK, DENSE ? (persist_slim(DENSE, NB, NS) ? 4 : 3
     // (step, half, row), not by the lane, so the chain does not depend on this mapping.
     int g = (int)threadIdx.x / per, kk = (int)threadIdx.x - g * per;
     bool mine = g < here;
-    if (h < BLOCK && here * h < BLOCK) {
+    bool owns = true;
+    if constexpr (PAIR) {
+        // here * h <= BLOCK / 2 moves (the host's condition for this form): at most 32 per wave, in multiples of 16, in the
+        // lower half of the wave; the upper half mirrors them for the companions
+        const int total = here * h;
+        int pw = (((total + 3) >> 2) + 15) & ~15;
+        pw = pw < 16 ? 16 : pw;
+        const int l5 = (int)threadIdx.x & 31;
+        const int a = ((int)threadIdx.x >> 6) * pw + l5;
+        mine = l5 < pw && a < total;
+        g = mine ? a / h : 0;
+        kk = mine ? a - g * h : 0;
+        owns = ((int)threadIdx.x & 32) == 0;
+    } else if (h < BLOCK && here * h < BLOCK) {
         const int total = here * h;
         int pw = (((total + 3) >> 2) + 15) & ~15;
         pw = pw < 16 ? 16 : pw;
@@ -287,7 +304,7 @@ __global__ __launch_bounds__(BLOCK, DENSE ? (persist_slim(DENSE, NB, NS) ? 4 : 3
     // use), a half-step only depends on LDS rows its own wave wrote: the waves then need no workgroup barrier between
     // half-steps and run through the iterations independently - a wave that waits for memory no longer holds up the
     // other three.  (LDS operations of one wave complete in order; the fence keeps the compiler from moving them.)
-    const bool wave_local = h <= 64 && (64 % h) == 0 && !(h < BLOCK && here * h < BLOCK);
+    const bool wave_local = !PAIR && h <= 64 && (64 % h) == 0 && !(h < BLOCK && here * h < BLOCK);
     for (int it = 0; it < S.nsteps; ++it) {
         double* cp = S.chain_pos ? S.chain_pos + (int64_t)it * rows_total * NP + (r0 + gs * W) * S.chain_rs : nullptr;
         double* cl = S.chain_lnp ? S.chain_lnp + (int64_t)it * rows_total + r0 + gs * W : nullptr;
@@ -308,8 +325,8 @@ __global__ __launch_bounds__(BLOCK, DENSE ? (persist_slim(DENSE, NB, NS) ? 4 : 3
                 const bool active = mine && k < h;
                 if (__any(active))                        // wave-uniform: idle waves go straight to the barrier
                     stretch_move<KIND, NS, NB, ASTERO, UNI, STDP,
-                                 UNI ? ISO_UNI_LANE : (DENSE ? ISO_DENSE_LANE : (STDP ? ISO_MULTI_STD_LANE : ISO_MULTI_LANE)),
-                                 (DENSE && ISO_DENSE_SHARED) || (!UNI && !DENSE && STDP)>(A, S, lds, L, active, star0 + gs, active ? k : h - 1, half,
+                                 (UNI ? ISO_UNI_LANE : (DENSE ? ISO_DENSE_LANE : (STDP ? ISO_MULTI_STD_LANE : ISO_MULTI_LANE))) | (PAIR ? 16 : 0),
+                                 (DENSE && ISO_DENSE_SHARED) || (!UNI && !DENSE && STDP)>(A, S, lds, L, active, active && owns, star0 + gs, active ? k : h - 1, half,
                                                S.step + (uint32_t)it, lpos + gs * W * NP, llnp + gs * W,
                                                lacc ? lacc + gs * W : nullptr, cp, cl);
             }
@@ -330,4 +347,17 @@ __global__ __launch_bounds__(BLOCK, DENSE ? (persist_slim(DENSE, NB, NS) ? 4 : 3
             if (S.accepted) S.accepted[r0 + j] += lacc[j];
         }
     }
+}
+
+template <int KIND, int NS, int NB, bool DENSE, bool ASTERO = false, bool UNI = false, bool STDP = false>
+__global__ __launch_bounds__(BLOCK, DENSE ? (persist_slim(DENSE, NB, NS) ? 4 : 3) : 2) void k_stretch_persist(const FastArgs A, const StretchArgs S)
+{
+    persist_body<KIND, NS, NB, DENSE, ASTERO, UNI, STDP, false>(A, S);
+}
+
+// a single binary's fit (isochrone grid, no asteroseismic terms, at most BLOCK / 2 moves per half-step): one star per lane
+template <int NB, bool STDP>
+__global__ __launch_bounds__(BLOCK, 2) void k_stretch_pair(const FastArgs A, const StretchArgs S)
+{
+    persist_body<ISO_KIND_ISO, 2, NB, false, false, true, STDP, true>(A, S);
 }

@@ -2132,6 +2132,8 @@ int iso_sampler_run(iso_sampler* sp, double* pos, double* lnp, int nsteps, doubl
     S.occupancy_query = nullptr;
     S.dense = 0;
     S.group = 0;
+    S.pair = 1;           // ISOCHRONES_AMD_STAR_LANES=0: a single binary's fit through the one-lane-walks-both-stars kernel (A/B, tests)
+    if (const char* e = std::getenv("ISOCHRONES_AMD_STAR_LANES")) S.pair = std::atoi(e) != 0;
     S.pos = pos;
     S.lnp = lnp;
     S.accepted = accepted;

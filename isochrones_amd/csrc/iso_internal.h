@@ -161,6 +161,7 @@ struct StretchArgs {
     int std_priors;       // host side only: the single model's priors are the reference's default families
     int group;            // persistent form: ensembles per workgroup (0 or >= the most a workgroup holds: that many);
                           // fewer spread a small catalog over more CUs - LDS is laid out for the maximum either way
+    int pair;             // host side only: a single binary may take the one-star-per-lane kernel (k_stretch_pair)
 };
 
 }  // namespace iso

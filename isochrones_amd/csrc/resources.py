@@ -70,6 +70,7 @@ SCRATCH_BUDGET = {
     "k_catalog_start": 64,
     "k_stretch_half": 248,
     "k_stretch_persist": 388,        # register-capped catalog form, triples with many bands
+    "k_stretch_pair": 200,           # a single binary, one star per lane (uncapped registers)
     "k_lnpost": 96,                  # generic fallback kernel (one sample per lane since round 4: 384 -> 96)
     "k_lnpost_tree": 1664,           # generic tree kernel (last-resort fallback): per-leaf arrays per lane
     "k_chain_quantiles_exact": 40,

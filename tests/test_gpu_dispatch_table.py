@@ -291,12 +291,23 @@ def test_fused_families(kind, ns, nb):
                 check_sampler(mod, oic, p0, 16, 10, 77 + nb, tid + " stepwise")
             expect(t.names, "k_stretch_half<%d, %d, %d, %s>" % (K, ns, nb, a), tid)
             # persistent, single model: default priors as compile-time constants / read at run time
-            with env(ISOCHRONES_AMD_SAMPLER="persistent"), traced(tid) as t:
+            # (a single binary without asteroseismic terms takes the one-star-per-lane kernel unless told otherwise)
+            pair = kind == "iso" and ns == 2 and not astero
+            with env(ISOCHRONES_AMD_SAMPLER="persistent", ISOCHRONES_AMD_STAR_LANES="0"), traced(tid) as t:
                 check_sampler(mod, oic, p0, 16, 10, 78 + nb, tid + " persistent std priors")
             expect(t.names, "k_stretch_persist<%d, %d, %d, false, %s, true, true>" % (K, ns, nb, a), tid)
-            with env(ISOCHRONES_AMD_SAMPLER="persistent", ISOCHRONES_AMD_STD_PRIORS="0"), traced(tid) as t:
+            with env(ISOCHRONES_AMD_SAMPLER="persistent", ISOCHRONES_AMD_STD_PRIORS="0", ISOCHRONES_AMD_STAR_LANES="0"), traced(tid) as t:
                 check_sampler(mod, oic, p0, 16, 10, 79 + nb, tid + " persistent run-time priors")
             expect(t.names, "k_stretch_persist<%d, %d, %d, false, %s, true, false>" % (K, ns, nb, a), tid)
+            if pair:
+                for W in ((16, 160) if nb <= 4 else (16, 48)):     # 8 / 24 / 80 moves per half-step: up to 16 per wave, or 32 (<= 4 bands)
+                    pw = start_ball(rng, mod, kind, ns, W)
+                    with env(ISOCHRONES_AMD_SAMPLER="persistent", ISOCHRONES_AMD_STAR_LANES=None), traced(tid) as t:
+                        check_sampler(mod, oic, pw, W, 10, 178 + nb + W, tid + " one star per lane, std priors, W=%d" % W)
+                    expect(t.names, "k_stretch_pair<%d, true>" % nb, tid)
+                with env(ISOCHRONES_AMD_SAMPLER="persistent", ISOCHRONES_AMD_STD_PRIORS="0", ISOCHRONES_AMD_STAR_LANES=None), traced(tid) as t:
+                    check_sampler(mod, oic, p0, 16, 10, 179 + nb, tid + " one star per lane, run-time priors")
+                expect(t.names, "k_stretch_pair<%d, false>" % nb, tid)
             if not astero:
                 # register-capped form with a single model (many ensembles of one star run it in rounds)
                 with env(ISOCHRONES_AMD_SAMPLER="persistent-dense"), traced(tid) as t:
