@@ -66,6 +66,35 @@ def source_digest() -> str:
     return h.hexdigest()
 
 
+_INCLUDE = None
+
+
+def include_closure(src):
+    """The source and the project headers it reaches through #include "..." lines (searched next to the including file,
+    then under csrc/ and include/), in a fixed order.  System headers (<...>) belong to the toolchain, not to the digest."""
+    global _INCLUDE
+    import re
+    if _INCLUDE is None:
+        _INCLUDE = re.compile(r'^[ \t]*#[ \t]*include[ \t]*"([^"]+)"', re.M)
+    roots = [HERE, os.path.join(HERE, "..", "..", "include")]
+    seen, order, todo = set(), [], [os.path.abspath(src)]
+    while todo:
+        path = todo.pop()
+        if path in seen:
+            continue
+        seen.add(path)
+        order.append(path)
+        with open(path, errors="replace") as f:
+            text = f.read()
+        for name in _INCLUDE.findall(text):
+            for base in [os.path.dirname(path)] + roots:
+                cand = os.path.abspath(os.path.join(base, name))
+                if os.path.exists(cand):
+                    todo.append(cand)
+                    break
+    return [order[0]] + sorted(order[1:])
+
+
 def file_sha256(path) -> str:
     import hashlib
     h = hashlib.sha256()
@@ -130,20 +159,18 @@ def build(force: bool = False, verbose: bool = False, gate: bool = True) -> str:
     stale = not up_to_date()             # objects of another source state are only reused when their times say so
     jobs = []
     objs = []
-    # an object is reused when the digest of what it was compiled from - its source, every header, the flags, taken BEFORE
-    # the compiler started - is the digest of those files now (file times are not trusted: an edit made while a build was
-    # running left objects that were newer than the header they had not seen)
+    # an object is reused when the digest of what it was compiled from - its source, every header it includes (directly or
+    # through another header), the flags, taken BEFORE the compiler started - is the digest of those files now (file times are
+    # not trusted: an edit made while a build was running left objects that were newer than the header they had not seen).
+    # Headers are followed per translation unit: an edit under kernels/ recompiles iso_hip.hip alone, not the fused families.
     import hashlib
-    hh = hashlib.sha256(repr(FLAGS).encode())
-    for path in HEADERS + [me]:
-        with open(path, "rb") as f:
-            hh.update(os.path.basename(path).encode() + b"\0" + f.read())
     for src in sources():
         obj = os.path.join(OBJDIR, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
-        h1 = hh.copy()
-        with open(src, "rb") as f:
-            h1.update(f.read())
+        h1 = hashlib.sha256(repr(FLAGS).encode())
+        for path in include_closure(src):
+            with open(path, "rb") as f:
+                h1.update(os.path.relpath(path, HERE).encode() + b"\0" + f.read())
         dig = h1.hexdigest()
         try:
             have = open(obj[:-2] + ".dig").read().strip()

@@ -543,8 +543,19 @@ int iso_interp(iso_table* t, const double* const* x, int64_t n, const int32_t* i
             for (int c = 0; c < k; ++c) W.icols[c] = A.icols[c];
             W.out = out;
             const size_t sh = (size_t)(lds + ISO_MAX_COLS / 2 + BLOCK * WIDE_SLOT) * sizeof(double);
-            note_kernel("k_interp3_wide");
-            hipLaunchKernelGGL(k_interp3_wide, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), sh, as_stream(stream), W);
+            // groups of 64 samples per wave: as many as leave every CU ~8 workgroups of work (a workgroup's fixed part -
+            // staging the axes, one barrier - is then paid once per 256 x groups samples); A/B switches for both choices
+            const int64_t wgs1 = (n + BLOCK - 1) / BLOCK;
+            int groups = (int)std::min<int64_t>(4, std::max<int64_t>(1, wgs1 / (8 * 256)));
+            if (const char* e = std::getenv("ISOCHRONES_AMD_WIDE_GROUPS")) groups = std::max(1, std::atoi(e));
+            bool narrow = k == 1;
+            if (const char* e = std::getenv("ISOCHRONES_AMD_WIDE_NARROW")) narrow = narrow && std::atoi(e) != 0;
+            W.groups = groups;
+            const int64_t per_wg = (int64_t)BLOCK * groups;
+            const dim3 grid((unsigned)((n + per_wg - 1) / per_wg));
+            note_kernel("k_interp3_wide<%d>", narrow ? 4 : WIDE_UNROLL);
+            if (narrow) hipLaunchKernelGGL(k_interp3_wide<4>, grid, dim3(BLOCK), sh, as_stream(stream), W);
+            else hipLaunchKernelGGL(k_interp3_wide<WIDE_UNROLL>, grid, dim3(BLOCK), sh, as_stream(stream), W);
             HIP_TRY(hipGetLastError());
             return ISO_OK;
         }

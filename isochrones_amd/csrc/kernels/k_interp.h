@@ -107,6 +107,7 @@ struct WideArgs {
     int k;
     uint64_t kinv;           // floor(2^32 / k) + 1: u / k == (u * kinv) >> 32 for u < 2^16 (k = 1: 2^32 + 1)
     int lds_axes;            // doubles of staged axes
+    int groups;              // groups of 64 samples per wave
     int32_t icols[ISO_MAX_COLS];
     double* out;
 };
@@ -148,9 +149,18 @@ __device__ __forceinline__ double wide_dpp(double x, int which)
 }
 
 constexpr int WIDE_SLOT = 5;      // doubles per request slot (4 used; odd stride: conflict-free)
-constexpr int WIDE_UNROLL = 8;    // passes whose loads are in flight together
+constexpr int WIDE_UNROLL = 8;    // passes whose loads are in flight together (U of the kernel below)
 
-__global__ __launch_bounds__(BLOCK, 2) void k_interp3_wide(const WideArgs A)
+// U = passes of 16 (sample, column) units whose loads are in flight together.  8 for k >= 2 columns.  U = 4 is the
+// one-column form: a wave's 64 samples are 64 units = 4 passes, the other four of the 8-pass form only repeated the last
+// unit's load (and held 126 registers = 4 waves per SIMD; this form fits 6).
+// A.groups = groups of 64 samples one wave serves one after the other.  With one group per wave a workgroup lives for
+// 256 samples and pays for them the staging of the three axes (15 KB from L2 for the MIST track table) and a barrier:
+// on a one-column call (96 algorithmic bytes per sample) that fixed part is what kept the kernel at 4.8 of the 6.3 TB/s
+// the fabric delivers to a gather (profiles/r03: 34.8 us for 10^6 samples).  The coordinates of the next group are
+// fetched before the current group's gathers are waited for.
+template <int U>
+__global__ __launch_bounds__(BLOCK, U == 4 ? 6 : 4) void k_interp3_wide(const WideArgs A)
 {
     extern __shared__ double lds[];
     stage_axes<3>(A.ax, lds);
@@ -159,71 +169,85 @@ __global__ __launch_bounds__(BLOCK, 2) void k_interp3_wide(const WideArgs A)
     __syncthreads();
     double* slots = lds + A.lds_axes + (ISO_MAX_COLS / 2) + (threadIdx.x >> 6) * 64 * WIDE_SLOT;
     const int lane = threadIdx.x & 63;
-    const int64_t first = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) & ~(int64_t)63;   // the wave's first sample
-    const int64_t i = first + lane;
-    {
-        bool bad = i >= A.n;
-        double x[3] = {0.0, 0.0, 0.0};
-        if (!bad) {
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                x[d] = A.x[d][i];
-                bad |= (x[d] != x[d]);
-            }
-        }
-        if (!bad) {
-#pragma unroll
-            for (int d = 0; d < 3; ++d) bad |= out_of_axis(A.ax[d], lds, x[d]);
-        }
-        double t[3] = {0.0, 0.0, 0.0};
-        int64_t cell = -1;
-        if (!bad) {
-            cell = 0;
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                int idx;
-                bracket(A.ax[d], lds, x[d], idx, t[d]);
-                cell += (int64_t)idx * A.stride[d];
-            }
-        }
-        double* mine = slots + lane * WIDE_SLOT;
-        mine[0] = __longlong_as_double(cell);
-        mine[1] = t[0];
-        mine[2] = t[1];
-        mine[3] = t[2];
-    }
-    __builtin_amdgcn_wave_barrier();
+    const int groups = A.groups;
+    const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
+    const int64_t first0 = wave * groups * 64;                  // the wave's first sample
     const int j = lane & 3, grp = lane >> 2;
     const int k = A.k;
-    const int here = (int)min((int64_t)64, A.n - first);       // samples of this wave
-    const int units = here * k;
-    double* __restrict__ out = A.out + first * k;
-    for (int u0 = 0; u0 < units; u0 += 16 * WIDE_UNROLL) {
-        double2 v[WIDE_UNROLL];
-        double wx[WIDE_UNROLL], wy[WIDE_UNROLL];
-        bool bad[WIDE_UNROLL];
+    double xn[3] = {0.0, 0.0, 0.0};
+    if (first0 + lane < A.n) {
 #pragma unroll
-        for (int r = 0; r < WIDE_UNROLL; ++r) {
-            const int u = min(u0 + 16 * r + grp, units - 1);
-            const int s = (int)(((uint64_t)(uint32_t)u * A.kinv) >> 32);      // u / k
-            const int c = u - s * k;
-            const double* rq = slots + s * WIDE_SLOT;
-            const long long cell = __double_as_longlong(rq[0]);
-            const double t0 = rq[1], t1 = rq[2], t2 = rq[3];
-            bad[r] = cell < 0;
-            const int64_t cc = bad[r] ? 0 : cell;
-            v[r] = *reinterpret_cast<const double2*>(A.wide + ((cc * A.ncol + lcols[c]) << 3) + 2 * j);
-            const double g = ((j & 2) ? t0 : (1 - t0)) * ((j & 1) ? t1 : (1 - t1));
-            wx[r] = g * (1 - t2);
-            wy[r] = g * t2;
-        }
+        for (int d = 0; d < 3; ++d) xn[d] = A.x[d][first0 + lane];
+    }
+    for (int g = 0; g < groups; ++g) {
+        const int64_t first = first0 + (int64_t)g * 64;
+        if (first >= A.n) break;                                // wave-uniform
+        const int64_t i = first + lane;
+        {
+            bool bad = i >= A.n;
+            double x[3];
 #pragma unroll
-        for (int r = 0; r < WIDE_UNROLL; ++r) {
-            double part = v[r].x * wx[r] + v[r].y * wy[r];
-            part += wide_dpp(part, 0);
-            part += wide_dpp(part, 1);
-            const int u = u0 + 16 * r + grp;
-            if (j == 0 && u < units) out[u] = bad[r] ? d_nan() : part;
+            for (int d = 0; d < 3; ++d) {
+                x[d] = xn[d];
+                bad |= (x[d] != x[d]);
+            }
+            if (g + 1 < groups && i + 64 < A.n) {               // the next group's coordinates are on their way meanwhile
+#pragma unroll
+                for (int d = 0; d < 3; ++d) xn[d] = A.x[d][i + 64];
+            }
+            if (!bad) {
+#pragma unroll
+                for (int d = 0; d < 3; ++d) bad |= out_of_axis(A.ax[d], lds, x[d]);
+            }
+            double t[3] = {0.0, 0.0, 0.0};
+            int64_t cell = -1;
+            if (!bad) {
+                cell = 0;
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    int idx;
+                    bracket(A.ax[d], lds, x[d], idx, t[d]);
+                    cell += (int64_t)idx * A.stride[d];
+                }
+            }
+            double* mine = slots + lane * WIDE_SLOT;
+            mine[0] = __longlong_as_double(cell);
+            mine[1] = t[0];
+            mine[2] = t[1];
+            mine[3] = t[2];
         }
+        __builtin_amdgcn_wave_barrier();
+        const int here = (int)min((int64_t)64, A.n - first);       // samples of this group
+        const int units = here * k;
+        double* __restrict__ out = A.out + first * k;
+        for (int u0 = 0; u0 < units; u0 += 16 * U) {
+            double2 v[U];
+            double wx[U], wy[U];
+            bool bad[U];
+#pragma unroll
+            for (int r = 0; r < U; ++r) {
+                const int u = min(u0 + 16 * r + grp, units - 1);
+                const int s = (int)(((uint64_t)(uint32_t)u * A.kinv) >> 32);      // u / k
+                const int c = u - s * k;
+                const double* rq = slots + s * WIDE_SLOT;
+                const long long cell = __double_as_longlong(rq[0]);
+                const double t0 = rq[1], t1 = rq[2], t2 = rq[3];
+                bad[r] = cell < 0;
+                const int64_t cc = bad[r] ? 0 : cell;
+                v[r] = *reinterpret_cast<const double2*>(A.wide + ((cc * A.ncol + lcols[c]) << 3) + 2 * j);
+                const double gw = ((j & 2) ? t0 : (1 - t0)) * ((j & 1) ? t1 : (1 - t1));
+                wx[r] = gw * (1 - t2);
+                wy[r] = gw * t2;
+            }
+#pragma unroll
+            for (int r = 0; r < U; ++r) {
+                double part = v[r].x * wx[r] + v[r].y * wy[r];
+                part += wide_dpp(part, 0);
+                part += wide_dpp(part, 1);
+                const int u = u0 + 16 * r + grp;
+                if (j == 0 && u < units) out[u] = bad[r] ? d_nan() : part;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();                        // the slots are rewritten by the next group
     }
 }

@@ -490,7 +490,12 @@ def test_interpolation_families():
                 want = orc.OracleTable(mi.grid, mi.index_columns).interp([x[:, order[0]], x[:, order[1]], x[:, order[2]]],
                                                                           [mi.column_index[c] for c in cols], nthreads=8)
                 fx.assert_close(v, want, RTOL, atol=ATOL, what="interp_value wide")
-                expect(t.names, "k_interp3_wide", tid)
+                expect(t.names, "k_interp3_wide<8>", tid)
+                # one column: the four-pass form
+                with traced(tid) as t:
+                    v1 = ic.interp_value([x[:, 0], x[:, 1], x[:, 2]], cols[1:2])
+                fx.assert_close(np.asarray(v1).reshape(-1), want[:, 1], RTOL, atol=ATOL, what="interp_value wide, one column")
+                expect(t.names, "k_interp3_wide<4>", tid)
             ic.release()
     RAN.add(tid)
 
