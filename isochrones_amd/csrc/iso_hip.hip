@@ -546,7 +546,10 @@ int iso_interp(iso_table* t, const double* const* x, int64_t n, const int32_t* i
             // groups of 64 samples per wave: as many as leave every CU ~8 workgroups of work (a workgroup's fixed part -
             // staging the axes, one barrier - is then paid once per 256 x groups samples); A/B switches for both choices
             const int64_t wgs1 = (n + BLOCK - 1) / BLOCK;
-            int groups = (int)std::min<int64_t>(4, std::max<int64_t>(1, wgs1 / (8 * 256)));
+            // measured (tools/wide_form_ab.py, profiles/r04/wide_form_ab.jsonl; 10^6 samples): 1 column 31.8 -> 29.0 us with
+            // the four-pass form, 28.2 with four groups; 2 columns 49.8 -> 45.1; 3 columns 69.1 -> 67.1; 18 columns 206 -> 208
+            // (a wave already has 72 passes of work there); eight groups, or any grouping at 10^5 samples, leave CUs idle
+            int groups = k <= 3 ? (int)std::min<int64_t>(4, std::max<int64_t>(1, wgs1 / 900)) : 1;
             if (const char* e = std::getenv("ISOCHRONES_AMD_WIDE_GROUPS")) groups = std::max(1, std::atoi(e));
             bool narrow = k == 1;
             if (const char* e = std::getenv("ISOCHRONES_AMD_WIDE_NARROW")) narrow = narrow && std::atoi(e) != 0;
@@ -2307,6 +2310,9 @@ int iso_chain_quantiles_layout(iso_ctx* ctx, const double* chain, int layout, in
         const bool tail = (m % 64) != 0;
         const size_t qsh = (size_t)QW_WAVES * QW_LDS_PER_WAVE;
         bool exact = W <= 64 && (64 % W) == 0 && !(qm && !std::strcmp(qm, "wave"));
+        // (its loads address the chain as scalar base + 32-bit lane offset: steps 0 .. 64 / W - 1, walkers 0 .. W - 1)
+        if (exact && ((64 / W) * std::llabs((long long)A.ss) + W * std::llabs((long long)A.rs)) * 8 >= ((int64_t)1 << 32)) exact = false;
+        if (exact && (A.ss < 0 || A.rs < 0)) exact = false;
         if (exact) {
             hipStream_t st = as_stream(stream);
 #define ISO_QEXACT(F)                                                                                      \

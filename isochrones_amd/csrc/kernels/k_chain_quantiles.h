@@ -489,12 +489,47 @@ __global__ __launch_bounds__(BLOCK, 2) void k_chain_quantiles_wave(const QuantAr
 #define ISO_QEXACT_WAVES_50 4
 #endif
 constexpr int qexact_waves(int full) { return full <= 25 ? 4 : full <= 50 ? ISO_QEXACT_WAVES_50 : 2; }
+// LEAN (default): fewer fp64 instructions per value - the kernel is bound by vector instruction issue (4 waves per SIMD x
+// ~2 100 instructions per pair against 25.6 KB of chain).  Any monotone binning selects the same order statistics, so
+//   * the bin of x is (int) fma(x, inv, -mn * inv) clamped to [0, BINS - 1] by one v_med3_i32: two fp64 instructions instead
+//     of three (subtract, multiply, convert), in the histogram pass and again in the gather pass;
+//   * the range [mn, mx] the bins divide comes from every fourth register (a quarter of the values): what lies outside it
+//     falls into the two edge bins (a handful of values), and two of the three fp64 instructions of the load pass go for
+//     three registers out of four.  A pair whose sampled range is empty is flagged for the workgroup kernel (it may still
+//     hold different values elsewhere); the wave-uniform "every value equal" answer needs the full range and stays with
+//     the ISO_QEXACT_LEAN=0 form and the generic wave kernel.
+// Measured (tools/quantile_timing.py, this form against the previous library, interleaved; profiles/r04/quantile_lean_ab.txt,
+// quantile_order_ab.txt): 10^5 stars x 3 200 values 3.27-3.31 -> 3.21-3.25 ms, 6 400 values 3.89 -> 3.79, 3 232 values (tail)
+// 3.50 -> 3.35 - 1-4 %, together with the scalar-base loads below.  ISO_QEXACT_SUBRANGE=1 (range from a quarter of the values)
+// is not the default: the compiler then fetches the other three quarters in a second round trip behind the test of the
+// range, and holding the loads in place costs 228-384 B of scratch per lane.  Also measured: consecutive waves on
+// consecutive ensembles of one parameter (contiguous 1-KB runs per workgroup and step instead of four runs 25 MB apart):
+// 3.22-3.25 against 3.21-3.24 ms - no difference, not kept.  The kernel is bound by neither address arithmetic nor DRAM
+// locality; what is left is the length of a pair's dependent phases at four waves per SIMD.
+#ifndef ISO_QEXACT_LEAN
+#define ISO_QEXACT_LEAN 1
+#endif
+#ifndef ISO_QEXACT_SUBRANGE
+#define ISO_QEXACT_SUBRANGE 0
+#endif
+// the hardware's double -> int conversion, named directly: it saturates and gives 0 for NaN, where a C++ cast is undefined
+__device__ __forceinline__ int qcvt_i32(double v)
+{
+#ifdef ISO_QCVT_CAST
+    return (int)v;
+#else
+    int r;
+    asm("v_cvt_i32_f64 %0, %1" : "=v"(r) : "v"(v));
+    return r;
+#endif
+}
 
 template <int FULL, bool TAIL>
 __global__ __launch_bounds__(BLOCK, qexact_waves(FULL)) void k_chain_quantiles_exact(const QuantArgs A)
 {
     extern __shared__ double lds[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // (the wave index through readfirstlane: everything derived from the pair - its chain base above all - is then scalar)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t pair = (int64_t)blockIdx.x * QW_WAVES + wave;
     if (pair >= A.n_ens * A.D) return;                              // wave-uniform; no workgroup barrier below
     char* base = reinterpret_cast<char*>(lds) + (size_t)wave * QW_LDS_PER_WAVE;
@@ -521,23 +556,51 @@ __global__ __launch_bounds__(BLOCK, qexact_waves(FULL)) void k_chain_quantiles_e
     {
         const int dq = 64 / A.W;
         const int t0 = lane / A.W, w0 = lane - t0 * A.W;
-        const double* __restrict__ lp = A.chain + (e * A.W) * A.rs + d * A.ps + (int64_t)t0 * A.ss + (int64_t)w0 * A.rs;
-        const int64_t adv = (int64_t)dq * A.ss;
+        // address = scalar base of the pair's register k + the lane's own 32-bit byte offset (the host sends a chain whose
+        // lane offsets do not fit 32 bits to the generic wave kernel): the load takes its base from a scalar register pair
+        // and no vector instruction computes an address - 50 64-bit vector additions, and as many register pairs, less
+        const char* __restrict__ sbase = reinterpret_cast<const char*>(A.chain + (e * A.W) * A.rs + d * A.ps);
+        const uint32_t loff = (uint32_t)(((int64_t)t0 * A.ss + (int64_t)w0 * A.rs) * 8);
+        const int64_t adv = (int64_t)dq * A.ss * 8;
+        // (the scalar base of register k is made opaque: otherwise the lane offset is folded into one 64-bit vector base and
+        // every load gets a vector address again)
+        auto at = [&](int k) {
+            typedef const char __attribute__((address_space(1))) gchar;         // (global: an opaque generic pointer would
+            typedef const double __attribute__((address_space(1))) gdouble;     //  make these flat loads)
+            gchar* b = (gchar*)(sbase + k * adv);
+            asm volatile("" : "+s"(b));
+            return *(gdouble*)(b + loff);
+        };
 #pragma unroll
         for (int k = 0; k < FULL; ++k) {
-            const double x = lp[k * adv];
+            const double x = at(k);
             v[k] = x;
             any_nan |= (x != x);
-            mn = fmin(mn, x);
-            mx = fmax(mx, x);
+            if (!ISO_QEXACT_SUBRANGE) {
+                mn = fmin(mn, x);
+                mx = fmax(mx, x);
+            }
+        }
+        if (ISO_QEXACT_SUBRANGE) {
+            // every load is issued before the range is reduced: the values the range does not need must not be fetched in a
+            // second round trip behind the test of the range (which is where the compiler puts them when left alone)
+#pragma unroll
+            for (int k = 0; k < FULL; ++k) asm volatile("" : "+v"(v[k]));
+#pragma unroll
+            for (int k = 0; k < FULL; k += 4) {
+                mn = fmin(mn, v[k]);
+                mx = fmax(mx, v[k]);
+            }
         }
         if (TAIL) {
             const bool have = lane < tail;
-            const double x = have ? lp[FULL * adv] : d_inf();
+            const double x = have ? at(FULL) : d_inf();
             vt = x;
             any_nan |= (x != x);
-            mn = fmin(mn, x);
-            mx = have ? fmax(mx, x) : mx;
+            if (!ISO_QEXACT_SUBRANGE) {
+                mn = fmin(mn, x);
+                mx = have ? fmax(mx, x) : mx;
+            }
         }
     }
     for (int off = 32; off > 0; off >>= 1) {
@@ -547,11 +610,16 @@ __global__ __launch_bounds__(BLOCK, qexact_waves(FULL)) void k_chain_quantiles_e
     const double inv = (double)QSEL_BINS / (mx - mn);
     const bool degenerate = !(mx > mn) || !isfinite(inv) || !isfinite(mn) || __any(any_nan);
     if (degenerate) {
-        const bool flat = !(mx > mn) && isfinite(mn) && isfinite(mx) && !__any(any_nan);      // every value equal
+        const bool flat = !ISO_QEXACT_SUBRANGE && !(mx > mn) && isfinite(mn) && isfinite(mx) && !__any(any_nan);      // every value equal
         if (lane < A.nq) A.out[pair * A.nq + lane] = flat ? mn : __longlong_as_double((long long)QUANT_FLAG);
         return;
     }
+#if ISO_QEXACT_LEAN
+    const double off = -mn * inv;
+    auto bin_of = [&](double x) { return min(max(qcvt_i32(fma(x, inv, off)), 0), QSEL_BINS - 1); };
+#else
     auto bin_of = [&](double x) { return min(QSEL_BINS - 1, (int)((x - mn) * inv)); };
+#endif
 
     // ---- histogram in the wave's LDS, exclusive prefix (16 bins per lane) ----
 #pragma unroll
@@ -632,10 +700,17 @@ __global__ __launch_bounds__(BLOCK, qexact_waves(FULL)) void k_chain_quantiles_e
     qw_sync();
     // the bins are computed again here, not carried over from the histogram pass (the compiler would keep all FULL of them
     // alive across the phases in between: 50-100 more registers, one or two waves per SIMD fewer): hide the scale from it
+#if ISO_QEXACT_LEAN
+    double mn2 = off, inv2 = inv;
+    asm volatile("" : "+v"(mn2), "+v"(inv2));
+    auto bin2 = [&](double x) { return min(max(qcvt_i32(fma(x, inv2, mn2)), 0), QSEL_BINS - 1); };
+#else
     double mn2 = mn, inv2 = inv;
     asm volatile("" : "+v"(mn2), "+v"(inv2));
+    auto bin2 = [&](double x) { return min(QSEL_BINS - 1, (int)((x - mn2) * inv2)); };
+#endif
     auto gather = [&](double x) {
-        const int sl = hist[min(QSEL_BINS - 1, (int)((x - mn2) * inv2))];
+        const int sl = hist[bin2(x)];
         if (sl >= 0) {
             const int pos = atomicAdd(&list_fill[sl], 1);
             pool[list_off[sl] + pos] = x;
