@@ -512,6 +512,22 @@ constexpr int qexact_waves(int full) { return full <= 25 ? 4 : full <= 50 ? ISO_
 #ifndef ISO_QEXACT_SUBRANGE
 #define ISO_QEXACT_SUBRANGE 0
 #endif
+// v_min_f64 / v_max_f64 as they are: fmin() / fmax() first canonicalise every operand that comes from memory (one more
+// v_max_f64 x, x per value: 74 of the kernel's ~1 370 vector instructions) so that a signalling NaN is quieted.  Here a NaN of
+// either kind only has to reach the "not finite" exit: a quiet one is skipped by the instruction and caught by the x != x test
+// next to it, a signalling one makes the range NaN.
+__device__ __forceinline__ double qmin_raw(double a, double b)
+{
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double qmax_raw(double a, double b)
+{
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 // the hardware's double -> int conversion, named directly: it saturates and gives 0 for NaN, where a C++ cast is undefined
 __device__ __forceinline__ int qcvt_i32(double v)
 {
@@ -577,8 +593,8 @@ __global__ __launch_bounds__(BLOCK, qexact_waves(FULL)) void k_chain_quantiles_e
             v[k] = x;
             any_nan |= (x != x);
             if (!ISO_QEXACT_SUBRANGE) {
-                mn = fmin(mn, x);
-                mx = fmax(mx, x);
+                mn = qmin_raw(mn, x);
+                mx = qmax_raw(mx, x);
             }
         }
         if (ISO_QEXACT_SUBRANGE) {
@@ -588,8 +604,8 @@ __global__ __launch_bounds__(BLOCK, qexact_waves(FULL)) void k_chain_quantiles_e
             for (int k = 0; k < FULL; ++k) asm volatile("" : "+v"(v[k]));
 #pragma unroll
             for (int k = 0; k < FULL; k += 4) {
-                mn = fmin(mn, v[k]);
-                mx = fmax(mx, v[k]);
+                mn = qmin_raw(mn, v[k]);
+                mx = qmax_raw(mx, v[k]);
             }
         }
         if (TAIL) {
@@ -598,8 +614,8 @@ __global__ __launch_bounds__(BLOCK, qexact_waves(FULL)) void k_chain_quantiles_e
             vt = x;
             any_nan |= (x != x);
             if (!ISO_QEXACT_SUBRANGE) {
-                mn = fmin(mn, x);
-                mx = have ? fmax(mx, x) : mx;
+                mn = qmin_raw(mn, x);
+                mx = have ? qmax_raw(mx, x) : mx;
             }
         }
     }

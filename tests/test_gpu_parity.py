@@ -210,6 +210,40 @@ def test_interp_wide_pack_matches_column_parallel_kernel(k, monkeypatch):
     assert np.array_equal(np.nan_to_num(small, nan=7.0), np.nan_to_num(got[:1500], nan=7.0))
 
 
+@pytest.mark.parametrize("k", [1, 2, 3, 5])
+@pytest.mark.parametrize("groups", [2, 3, 4, 7])
+def test_interp_wide_pack_groups_per_wave(k, groups, monkeypatch):
+    """Large 1-3 column batches let one wave serve several groups of 64 samples (next group's coordinates prefetched; one column
+    through the four-pass instantiation).  Forced here on a batch whose size leaves the last wave with fewer groups than the others
+    and its last group partially filled: bit for bit the one-group form, which the test above pins; bad samples at group borders."""
+    import torch
+    rng = np.random.default_rng(300 + 10 * k + groups)
+    ax = [np.sort(rng.uniform(-2, 2, 9)), np.array([0.1, 0.2, 0.5, 0.9, 1.0, 1.5, 4.0]), np.arange(1.0, 151.0)]
+    ncol = 12
+    grid = rng.standard_normal((9, 7, 150, ncol))
+    grid[2:4, 2:4, 100:, :] = np.nan
+    t = DFInterpolator.from_arrays(grid, ax, ["c%d" % j for j in range(ncol)])
+    n = 64 * groups * 4 * 37 + 64 * (groups - 1) + 17
+    n = max(n, 40_000 + 17)
+    x = [rng.uniform(a[0] - 0.02 * (a[-1] - a[0]), a[-1] + 0.02 * (a[-1] - a[0]), n) for a in ax]
+    for i in (63, 64, 65, 64 * groups - 1, 64 * groups, n - 18, n - 1):
+        x[i % 3][i] = np.nan
+    cols = np.array(list(rng.choice(ncol, size=k, replace=False)))
+    xt = [torch.as_tensor(v, device="cuda") for v in x]
+    monkeypatch.setenv("ISOCHRONES_AMD_WIDE_GROUPS", "1")
+    monkeypatch.setenv("ISOCHRONES_AMD_WIDE_NARROW", "0")
+    want = t.interp_device(xt, cols).cpu().numpy()
+    assert np.isfinite(want).mean() > 0.5
+    for narrow in ("0", "1"):
+        monkeypatch.setenv("ISOCHRONES_AMD_WIDE_GROUPS", str(groups))
+        monkeypatch.setenv("ISOCHRONES_AMD_WIDE_NARROW", narrow)
+        got = t.interp_device(xt, cols).cpu().numpy()
+        assert np.array_equal(np.nan_to_num(got, nan=7.0), np.nan_to_num(want, nan=7.0)), (k, groups, narrow)
+    monkeypatch.setenv("ISOCHRONES_AMD_PATH", "generic")
+    ref = t.interp_device(xt, cols).cpu().numpy()
+    fx.assert_close(want, ref, 1e-12, atol=1e-12, what="wide pack, one group, k=%d" % k)
+
+
 def test_interp_mag_packed_path_matches_generic_kernel(monkeypatch):
     """iso_interp_mag switches to the corner-packed tables for large batches (a pack per band list, built on
     first use, at most 6 kept): both kernels against each other on the same samples incl. NaN / out-of-range
