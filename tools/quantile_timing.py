@@ -23,6 +23,10 @@ def main():
         chain = torch.empty(T, D, rows, dtype=torch.float64, device="cuda")
         chain.normal_()
         chain += torch.arange(D, device="cuda", dtype=torch.float64)[None, :, None]
+        if "--correlated" in sys.argv:          # a real chain: a walker's value repeats whenever its move was rejected (~70 %)
+            for t in range(1, T):
+                keep = torch.rand(D, rows, device="cuda") < 0.7
+                chain[t] = torch.where(keep, chain[t - 1], chain[t])
         res = torch.empty(S, D, 3, dtype=torch.float64, device="cuda")
         rec = {}
         for mode in ("auto", "wave"):
