@@ -335,6 +335,22 @@ int  iso_sampler_create_model(iso_model* m, int nwalkers, double a, uint64_t see
 int  iso_sampler_create_model_ensembles(iso_model* m, int64_t n_ensembles, int nwalkers, double a, uint64_t seed,
                                         iso_sampler** out);
 int  iso_sampler_create_catalog(iso_catalog* c, int nwalkers, double a, uint64_t seed, iso_sampler** out);
+/* The same sampler for the model classes that are not a BasicStarModel with at most 12 bands - the reference fits every
+ * StarModel through the one fit_mcmc (isochrones/starmodel.py:886-972):
+ *   iso_sampler_create_model     also takes models with 13-32 bands (band-tiled evaluation);
+ *   iso_sampler_create_tree      an observation tree (likelihood of observation.py:1181-1234; n_params = sum over systems
+ *                                of (stars + 4), rows [n_ens*W][n_params]);
+ *   iso_sampler_create_isotrack  the reference's IsoTrackModel (starmodel.py:2010-2104): parameters (eep, mass, age, feh,
+ *                                distance, AV); iso_m / track_m are single-star models with the same bands on the
+ *                                isochrone / evolution-track grid (track_m owns the priors and the parallax term), the age
+ *                                prior is ln p(age) = age_lnorm + age ln 10 inside [age_lo, age_hi], -inf outside.
+ * All three run every iteration of iso_sampler_run in ONE persistent launch, one workgroup per ensemble, positions in LDS
+ * (a 300-walker ensemble of a 10-parameter tree takes 77 KB of the CU's 160 KB); same Philox stream and move arithmetic as
+ * the kernels above.  n_ensembles independent ensembles as iso_sampler_create_model_ensembles.  ISO_ERR_INVALID when the
+ * shape has no kernel (a tree off the corner-packed path or with more than 12 bands) or an ensemble does not fit a CU's LDS. */
+int  iso_sampler_create_tree(iso_tree_model* m, int64_t n_ensembles, int nwalkers, double a, uint64_t seed, iso_sampler** out);
+int  iso_sampler_create_isotrack(iso_model* iso_m, iso_model* track_m, double age_lo, double age_hi, double age_lnorm,
+                                 int64_t n_ensembles, int nwalkers, double a, uint64_t seed, iso_sampler** out);
 void iso_sampler_destroy(iso_sampler* s);
 /* How iso_sampler_run lays out its `chain` output from now on (chain_lnp is [nsteps][n_ens*W] either way). */
 int  iso_sampler_set_chain_layout(iso_sampler* s, int layout);
@@ -347,7 +363,9 @@ int  iso_sampler_run(iso_sampler* s, double* pos, double* lnp, int nsteps, doubl
  * parameter d the order statistics of the nsteps*W values are selected (one wavefront per pair with the values
  * in registers; a workgroup selection / LDS sort for more than 6656 values or heavy ties) and
  * out[(e*n_params + d)*nq + k] receives the q[k] quantile with linear interpolation between order statistics
- * (numpy.percentile's default, bit for bit).  q is a HOST array of nq <= 8 levels in [0, 1]; nsteps*W <= 8192.
+ * (numpy.percentile's default, bit for bit).  q is a HOST array of nq <= 8 levels in [0, 1].  More than 8192 values per
+ * pair (the reference's default fit keeps 300 walkers x 100 iterations) are selected by refinement passes streamed from
+ * the chain - any length below 2^31.
  * ISOCHRONES_AMD_QUANTILES=workgroup|sort forces the older forms (tests, A/B runs). */
 int  iso_chain_quantiles(iso_ctx* ctx, const double* chain, int64_t nsteps, int64_t n_ens, int W, int n_params,
                          const double* q, int nq, double* out, void* stream);

@@ -15,6 +15,7 @@ ISO_MAX_COLS = 64
 
 KIND_TRACK = 0
 KIND_ISO = 1
+ERR_INVALID, ERR_HIP, ERR_NOMEM = -1, -2, -3      # include/isochrones_amd.h
 CHAIN_ROW_MAJOR = 0
 CHAIN_PARAM_MAJOR = 1
 
@@ -103,6 +104,7 @@ EXPORTED_SYMBOLS = (
     "iso_catalog_create", "iso_catalog_create_columns", "iso_catalog_destroy", "iso_catalog_lnpost", "iso_catalog_start_points",
     "iso_eep_table_create", "iso_eep_table_destroy", "iso_interp_eep", "iso_interp_eep_host",
     "iso_sampler_create_model", "iso_sampler_create_model_ensembles", "iso_sampler_create_catalog", "iso_sampler_destroy", "iso_sampler_run",
+    "iso_sampler_create_tree", "iso_sampler_create_isotrack",
     "iso_sampler_set_chain_layout", "iso_chain_quantiles", "iso_chain_quantiles_layout",
     "iso_tree_model_create", "iso_tree_model_destroy", "iso_tree_lnpost", "iso_tree_lnpost_host",
 )
@@ -210,6 +212,8 @@ def lib():
     L.iso_sampler_create_model.argtypes = [vp, C.c_int, dbl, C.c_uint64, C.POINTER(vp)]
     L.iso_sampler_create_catalog.argtypes = [vp, C.c_int, dbl, C.c_uint64, C.POINTER(vp)]
     L.iso_sampler_create_model_ensembles.argtypes = [vp, i64, C.c_int, dbl, C.c_uint64, C.POINTER(vp)]
+    L.iso_sampler_create_tree.argtypes = [vp, i64, C.c_int, dbl, C.c_uint64, C.POINTER(vp)]
+    L.iso_sampler_create_isotrack.argtypes = [vp, vp, dbl, dbl, dbl, i64, C.c_int, dbl, C.c_uint64, C.POINTER(vp)]
     L.iso_sampler_destroy.argtypes = [vp]
     L.iso_sampler_destroy.restype = None
     L.iso_sampler_run.argtypes = [vp, pd, pd, C.c_int, pd, pd, pd, vp]

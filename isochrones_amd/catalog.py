@@ -400,13 +400,13 @@ def initial_positions(post: CatalogPosterior, nwalkers, rng_seed=0, oversample=8
     (``iso_catalog_start_points``: one workgroup per star draws with Philox, evaluates with the catalog kernels' lnpost and
     selects in LDS; no candidate leaves the chip, no host synchronisation); "torch" = the framework version of rounds 1-3
     (candidates [D, S, K] in memory, one catalog-kernel launch and a dozen sort / topk / gather passes per attempt), kept
-    as the A/B counterpart and for ensembles of more than 256 walkers.  Both draw from the same candidate distribution;
-    the random numbers differ."""
+    as the A/B counterpart and for ensembles the kernel has no LDS for (more than 1024 walkers).  Both draw from the same
+    candidate distribution; the random numbers differ - so the method is part of a stored shard's digest."""
     import torch
     method = method or os.environ.get("ISOCHRONES_AMD_START", "kernel")
     if method not in ("kernel", "torch"):
         raise ValueError("initial_positions: method must be 'kernel' or 'torch'")
-    if method == "kernel" and nwalkers <= 256 and hasattr(_cabi.lib(), "iso_catalog_start_points"):
+    if method == "kernel" and hasattr(_cabi.lib(), "iso_catalog_start_points"):
         S, D, W = post.n_models, post.n_params, int(nwalkers)
         device = torch.device("cuda", post.device)
         best = torch.empty(S, W, D, dtype=torch.float64, device=device)
@@ -416,7 +416,11 @@ def initial_positions(post: CatalogPosterior, nwalkers, rng_seed=0, oversample=8
                                                   dev.ptr(best), dev.ptr(best_lnp), dev.ptr(failed), dev.stream_ptr(post.device))
         if rc == 0:
             return best, best_lnp, failed.to(torch.bool)
-        _cabi.lib().iso_last_error()             # no instantiation for this shape (LDS): the framework version below
+        if rc != _cabi.ERR_INVALID:              # a HIP failure is an error, not a reason to change the random numbers
+            _cabi.check(rc)
+        import warnings
+        warnings.warn("initial_positions: no start-point kernel for this shape (%s); using the framework version, whose "
+                      "random numbers differ" % (_cabi.lib().iso_last_error() or b"").decode(), RuntimeWarning, stacklevel=2)
     S, D, W = post.n_models, post.n_params, nwalkers
     device = torch.device("cuda", post.device)
     gen = torch.Generator(device=device)
@@ -594,7 +598,7 @@ def fit_stars_gpu(catalog: StarCatalog, ic, indices, N=1, nwalkers=32, nburn=150
 
 
 #: bump when the stored result rows change meaning (columns, summaries, sampler defaults)
-SHARD_FORMAT = 3
+SHARD_FORMAT = 4
 
 
 def _stable_repr(key, value):
@@ -639,6 +643,7 @@ def _shard_fingerprint(catalog, mine, N, fit_kwargs, ic=None):
     h.update(repr(sorted((k, _stable_repr(k, v)) for k, v in fit_kwargs.items() if k != "timings")).encode())
     h.update(repr(sorted((k, _stable_repr(k, v)) for k, v in catalog._prior_settings.items())).encode())
     h.update(repr(_ic_signature(ic)).encode())
+    h.update(repr(("start", os.environ.get("ISOCHRONES_AMD_START", "kernel"))).encode())     # the two methods draw different numbers
     return h.hexdigest()
 
 
@@ -661,13 +666,16 @@ def _table_content_hash(interp):
 
 
 def _ic_signature(ic):
-    """What identifies the interpolator a shard was fitted with: parametrisation, bands, table shapes, EEP bounds, where
-    the tables came from (``data_source``: 'synthetic', a directory of MIST caches, ...) and a content hash of both
-    tables (whatever of these the object has - fit_fn may be handed any stand-in)."""
+    """What identifies the interpolator a shard was fitted with: parametrisation, bands, table shapes, EEP bounds, the
+    kind of source the tables came from ('synthetic' or 'mist' - not the path: a shard stays valid when $ISOCHRONES moves
+    or another host mounts it elsewhere) and a content hash of both tables (whatever of these the object has - fit_fn may
+    be handed any stand-in)."""
     sig = [type(ic).__name__]
-    for name in ("eep_replaces", "bands", "eep_bounds", "param_names", "data_source"):
+    for name in ("eep_replaces", "bands", "eep_bounds", "param_names"):
         v = getattr(ic, name, None)
         sig.append((name, tuple(v) if isinstance(v, (list, tuple)) else v))
+    src = getattr(ic, "data_source", None)
+    sig.append(("data_source", src if src in (None, "synthetic") else "mist"))
     for name in ("model_grid", "bc_grid"):
         interp = getattr(getattr(ic, name, None), "interp", None)
         grid = getattr(interp, "grid", None)

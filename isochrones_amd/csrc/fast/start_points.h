@@ -23,7 +23,9 @@
 //     isolation of the reference's try / except around each star (isochrones/starfit.py:155-159).
 // No candidate ever leaves the chip: the framework version moved 4 GB of them at 4 x 10^5 stars.
 // -------------------------------------------------------------------------------------------
-constexpr int START_MAX_W = BLOCK;
+// (a workgroup merges a chunk of BLOCK candidates into the W records kept so far; ensembles of more than BLOCK walkers - the
+// reference's default is 300, starmodel.py:889 - walk their kept records in strides of BLOCK)
+constexpr int START_MAX_W = 1024;
 
 struct StartArgs {
     double* best;         // [n_stars][W][NP]
@@ -118,22 +120,20 @@ __global__ __launch_bounds__(BLOCK, start_min_waves(NS, NB)) void k_catalog_star
             rank += (int)((v > key) | ((v == key) & (f < tid)));
         }
         for (int f = 0; f < nkept; ++f) rank += (int)(kc[f * REC + NP] >= key);
-        int krank = W;
-        double kv = 0.0;
-        if (tid < nkept) {
-            kv = kc[tid * REC + NP];
-            krank = tid;                                   // the kept list is sorted: tid records of it are ahead already
-            for (int f = 0; f < BLOCK; ++f) krank += (int)(new_lnp[f] > kv);
-        }
         if (rank < W) {
 #pragma unroll
             for (int q = 0; q < NP; ++q) kn[rank * REC + q] = p[q];
             kn[rank * REC + NP] = key;
         }
-        if (krank < W) {
+        for (int t = tid; t < nkept; t += BLOCK) {         // (one pass unless the ensemble has more than BLOCK walkers)
+            const double kv = kc[t * REC + NP];
+            int krank = t;                                 // the kept list is sorted: t records of it are ahead already
+            for (int f = 0; f < BLOCK; ++f) krank += (int)(new_lnp[f] > kv);
+            if (krank < W) {
 #pragma unroll
-            for (int q = 0; q < NP; ++q) kn[krank * REC + q] = kc[tid * REC + q];
-            kn[krank * REC + NP] = kv;
+                for (int q = 0; q < NP; ++q) kn[krank * REC + q] = kc[t * REC + q];
+                kn[krank * REC + NP] = kv;
+            }
         }
         __syncthreads();
         nkept = min(W, nkept + BLOCK);
@@ -162,7 +162,10 @@ inline bool launch_start_nb(int nb, const FastArgs& A, const StartArgs& T, hipSt
     switch (nb) {
 #define ISO_START_CASE(N)                                                                             \
     case N:                                                                                           \
-        if (sh(N) > 64 * 1024) return false;                                                          \
+        if (sh(N) > 160 * 1024) return false;                                                         \
+        if (sh(N) > 64 * 1024 &&                     /* beyond what a launch gets without asking */   \
+            hipFuncSetAttribute((const void*)k_catalog_start<KIND, NS, N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh(N)) != hipSuccess) \
+            return false;                                                                             \
         note_kernel("k_catalog_start<%d, %d, %d>", KIND, NS, N);                                      \
         hipLaunchKernelGGL((k_catalog_start<KIND, NS, N>), g, b, sh(N), s, A, T);                     \
         return true;

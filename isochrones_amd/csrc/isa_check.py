@@ -37,7 +37,28 @@ import sys
 import tempfile
 from concurrent.futures import ThreadPoolExecutor
 
-LLVM = "/opt/rocm/lib/llvm/bin/"
+
+
+def llvm_tool(name="llvm-objdump"):
+    """The LLVM binary that belongs to the compiler the library is built with: $ISOCHRONES_AMD_LLVM_BIN, else next to the
+    resolved hipcc (<rocm>/bin/hipcc -> <rocm>/lib/llvm/bin), else $ROCM_PATH, /opt/rocm, PATH."""
+    cands = []
+    if os.environ.get("ISOCHRONES_AMD_LLVM_BIN"):
+        cands.append(os.path.join(os.environ["ISOCHRONES_AMD_LLVM_BIN"], name))
+    cc = os.environ.get("HIPCC") or shutil.which("hipcc")
+    if cc:
+        root = os.path.dirname(os.path.dirname(os.path.realpath(cc)))
+        cands += [os.path.join(root, "lib", "llvm", "bin", name), os.path.join(root, "llvm", "bin", name)]
+    for root in (os.environ.get("ROCM_PATH"), "/opt/rocm"):
+        if root:
+            cands.append(os.path.join(root, "lib", "llvm", "bin", name))
+    cands.append(shutil.which(name))
+    for c in cands:
+        if c and os.path.exists(c):
+            return c
+    raise FileNotFoundError("%s not found (set ISOCHRONES_AMD_LLVM_BIN to the directory that holds it)" % name)
+
+
 LANE_OPS = ("v_writelane_b32", "v_readlane_b32", "v_readfirstlane_b32")     # SGPR <-> one VGPR lane: not exec-masked
 WINDOW = 64            # instructions looked at after a branch target before giving up (a restore is normally the first)
 
@@ -121,12 +142,12 @@ def code_objects(lib, workdir):
     """The gfx950 code objects bundled in a host object / shared library, extracted into `workdir`."""
     local = os.path.join(workdir, os.path.basename(lib))
     shutil.copy(lib, local)
-    subprocess.run([LLVM + "llvm-objdump", "--offloading", local], check=True, stdout=subprocess.DEVNULL, cwd=workdir)
+    subprocess.run([llvm_tool(), "--offloading", local], check=True, stdout=subprocess.DEVNULL, cwd=workdir)
     return sorted(os.path.join(workdir, f) for f in os.listdir(workdir) if "amdgcn" in f and os.path.getsize(os.path.join(workdir, f)) > 0)
 
 
 def scan_code_object(path):
-    p = subprocess.Popen([LLVM + "llvm-objdump", "-d", path], stdout=subprocess.PIPE, text=True, errors="replace")
+    p = subprocess.Popen([llvm_tool(), "-d", path], stdout=subprocess.PIPE, text=True, errors="replace")
     out = scan_listing(p.stdout)
     p.wait()
     return out

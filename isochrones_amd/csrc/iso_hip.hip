@@ -928,25 +928,51 @@ hipError_t build_fast(const iso_ic* ic, int nb, const double* d_bc_hot, double**
 }
 
 
-// the shared pack of a band list (BandPack, iso_internal.h): found in the interpolator's cache or built and cached
+// the shared pack of a band list (BandPack, iso_internal.h): found in the interpolator's cache or built and cached.
+// The cache holds references to the most recently used packs up to a byte bound (ISOCHRONES_AMD_PACK_CACHE_MB, default 2048:
+// a 12-band pack of the MIST BC grid is 654 MB) and at most 6 of them; a pack the cache lets go lives on with the catalogs
+// that hold it and is freed with the last one.  The pack is built OUTSIDE the lock (a pass over the BC table and a device
+// synchronise): concurrent catalog creation on other band lists does not queue behind it; two callers that build the same
+// list at once both succeed and the second one's copy is dropped in favour of the cached one.
+size_t band_pack_cache_bytes()
+{
+    if (const char* e = std::getenv("ISOCHRONES_AMD_PACK_CACHE_MB")) {
+        const long mb = std::atol(e);
+        if (mb >= 0) return (size_t)mb << 20;
+    }
+    return (size_t)2048 << 20;
+}
+
+static bool same_bands(const BandPack& bp, const int32_t* bc_cols, int nb)
+{
+    return (int)bp.cols.size() == nb && std::equal(bp.cols.begin(), bp.cols.end(), bc_cols);
+}
+
 hipError_t acquire_band_pack(iso_ic* ic, const int32_t* bc_cols, int nb, std::shared_ptr<BandPack>* out, bool* ok)
 {
     *ok = false;
-    std::lock_guard<std::mutex> lock(ic->mag_mu);
-    for (size_t k = 0; k < ic->band_packs.size(); ++k) {
-        std::shared_ptr<BandPack> bp = ic->band_packs[k];
-        if ((int)bp->cols.size() == nb && std::equal(bp->cols.begin(), bp->cols.end(), bc_cols)) {
-            ic->band_packs.erase(ic->band_packs.begin() + (long)k);
-            ic->band_packs.push_back(bp);
-            *out = bp;
-            *ok = true;
-            return hipSuccess;
+    auto lookup = [&]() -> bool {              // (with mag_mu held) most recently used last
+        for (size_t k = 0; k < ic->band_packs.size(); ++k) {
+            std::shared_ptr<BandPack> bp = ic->band_packs[k];
+            if (same_bands(*bp, bc_cols, nb)) {
+                ic->band_packs.erase(ic->band_packs.begin() + (long)k);
+                ic->band_packs.push_back(bp);
+                *out = bp;
+                *ok = true;
+                return true;
+            }
         }
+        return false;
+    };
+    {
+        std::lock_guard<std::mutex> lock(ic->mag_mu);
+        if (lookup()) return hipSuccess;
     }
     std::shared_ptr<BandPack> bp(new BandPack());
     bp->device = ic->device;
     bp->cols.assign(bc_cols, bc_cols + nb);
     bp->d_bcq = bp->d_axes_blob = nullptr;
+    bp->bytes = (size_t)ic->bc->ncells * 16 * (size_t)nb * sizeof(double);
     double* d_bc_hot = nullptr;
     hipError_t e = pack_bands(ic, bc_cols, nb, &d_bc_hot);
     if (e == hipSuccess) e = build_fast(ic, nb, d_bc_hot, &bp->d_axes_blob, &bp->d_bcq, bp->fast, ok);
@@ -956,8 +982,17 @@ hipError_t acquire_band_pack(iso_ic* ic, const int32_t* bc_cols, int nb, std::sh
         *ok = false;
         return e;
     }
-    if (ic->band_packs.size() >= 6) ic->band_packs.erase(ic->band_packs.begin());     // the cache lets go; holders keep theirs
+    std::lock_guard<std::mutex> lock(ic->mag_mu);
+    if (lookup()) return hipSuccess;                     // somebody else cached the same list meanwhile: theirs is used, ours goes
+    const size_t bound = band_pack_cache_bytes();
     ic->band_packs.push_back(bp);
+    size_t total = 0;
+    for (const auto& q : ic->band_packs) total += q->bytes;
+    while (ic->band_packs.size() > 1 && (ic->band_packs.size() > 6 || total > bound)) {       // the cache lets go; holders keep theirs
+        total -= ic->band_packs.front()->bytes;
+        ic->band_packs.erase(ic->band_packs.begin());
+    }
+    if (bp->bytes > bound) ic->band_packs.clear();       // a pack beyond the bound is not cached at all
     *out = bp;
     return hipSuccess;
 }
@@ -1852,8 +1887,8 @@ int iso_catalog_start_points(iso_catalog* c, int nwalkers, int oversample, int m
     DeviceGuard guard(c->device);
     if (!launch_catalog_start(c->ic->kind, c->n_stars, c->n_bands, c->fast, best, best_lnp, failed, c->n_models, nwalkers,
                               oversample, max_tries, seed, as_stream(stream)))
-        return fail(ISO_ERR_INVALID, "iso_catalog_start_points: no kernel for this shape (more than 256 walkers, or an "
-                                         "ensemble whose records do not fit the workgroup's LDS)");
+        return fail(ISO_ERR_INVALID, "iso_catalog_start_points: no kernel for this shape (more than 1024 walkers, or an "
+                                         "ensemble whose records do not fit a CU's LDS)");
     HIP_TRY(hipGetLastError());
     return ISO_OK;
 }
@@ -2077,7 +2112,61 @@ int sampler_common(iso_sampler* sp, int device, int kind, int n_stars, int n_ban
     sp->std_priors = 0;
     sp->chain_layout = ISO_CHAIN_ROW_MAJOR;
     sp->fast = F;
+    sp->form = 0;
+    sp->d_tree = nullptr;
+    sp->n_leaves = 0;
+    sp->fast2 = F;
+    sp->age = IsoTrackAge{0.0, 0.0, 0.0};
     return ISO_OK;
+}
+
+bool walkers_ok(int nwalkers, double a) { return nwalkers >= 2 && !(nwalkers & 1) && a > 1.0; }
+
+// the moves' side of a run of the any-model persistent sampler
+AnyStretchArgs any_args(const iso_sampler* sp, double* pos, double* lnp, int32_t* accepted, int nsteps, double* chain,
+                        double* chain_lnp)
+{
+    const int64_t rows = sp->n_ensembles * sp->W;
+    AnyStretchArgs S;
+    S.pos = pos;
+    S.lnp = lnp;
+    S.accepted = accepted;
+    S.W = sp->W;
+    S.NP = sp->n_params;
+    S.lanes = BLOCK;
+    S.own_off = 0;
+    S.n_ens = sp->n_ensembles;
+    S.a = sp->a;
+    S.seed = sp->seed;
+    S.step = sp->step;
+    S.nsteps = nsteps;
+    S.chain_rs = sp->chain_layout == ISO_CHAIN_PARAM_MAJOR ? 1 : sp->n_params;
+    S.chain_ps = sp->chain_layout == ISO_CHAIN_PARAM_MAJOR ? rows : 1;
+    S.chain_pos = chain;
+    S.chain_lnp = chain_lnp;
+    return S;
+}
+
+// launch (query == null) or ask whether a kernel exists whose LDS fits (query != null)
+bool launch_any_form(const iso_sampler* sp, const AnyStretchArgs& S, int* query, hipStream_t s)
+{
+    switch (sp->form) {
+    case ISO_SAMPLER_TREE: return launch_stretch_tree(sp->n_bands, sp->n_leaves, sp->fast, sp->d_tree, S, query, s);
+    case ISO_SAMPLER_ISOTRACK: return launch_stretch_isotrack(sp->n_bands, sp->fast, sp->fast2, sp->age, S, query, s);
+    case ISO_SAMPLER_WIDE: return launch_stretch_wide(sp->kind, sp->n_stars, sp->fast, S, query, s);
+    }
+    return false;
+}
+
+// a sampler of one of the any-model forms is only handed out when a kernel for its shape exists and an ensemble fits a CU's LDS
+int any_form_ready(iso_sampler* sp, const char* who)
+{
+    int lanes = 0;
+    const AnyStretchArgs S = any_args(sp, nullptr, nullptr, nullptr, 0, nullptr, nullptr);
+    if (launch_any_form(sp, S, &lanes, nullptr)) return ISO_OK;
+    delete sp;
+    return fail(ISO_ERR_INVALID, std::string(who) + ": no device-resident sampler for this shape (band count without a kernel, or "
+                                                    "an ensemble whose positions do not fit a CU's 160 KB of LDS)");
 }
 }  // namespace
 
@@ -2085,12 +2174,24 @@ int iso_sampler_create_model(iso_model* m, int nwalkers, double a, uint64_t seed
 {
     if (!m || !out) return fail(ISO_ERR_INVALID, "iso_sampler_create_model: NULL argument");
     if (nwalkers < 2 || (nwalkers & 1) || !(a > 1.0)) return fail(ISO_ERR_INVALID, "iso_sampler_create_model: need an even walker count and a > 1");
-    if (!m->fast_ok || !m->fast.hotq || (!m->fast.bcq && m->desc.n_bands > 0) || m->desc.n_bands > FAST_NB_MAX)
+    if (!m->fast_ok || !m->fast.hotq || (!m->fast.bcq && m->desc.n_bands > 0))
         return fail(ISO_ERR_INVALID, "iso_sampler_create_model: the model is not on the corner-packed fast path "
-                                     "(needs <= 12 bands, ISOCHRONES_AMD_PATH=auto)");
+                                     "(ISOCHRONES_AMD_PATH=auto, tables that could be packed)");
     iso_sampler* sp = new (std::nothrow) iso_sampler();
     if (!sp) return fail(ISO_ERR_NOMEM, "iso_sampler_create_model: out of host memory");
     sampler_common(sp, m->device, m->ic->kind, m->desc.n_stars, m->desc.n_bands, 1, m->fast, 0, nwalkers, a, seed);
+    if (m->desc.n_bands > FAST_NB_MAX) {
+        // 13-32 bands: the band-tiled evaluation inside the any-model persistent sampler (k_stretch_wide)
+        if (m->fast.astq) {
+            delete sp;
+            return fail(ISO_ERR_INVALID, "iso_sampler_create_model: no device-resident sampler for asteroseismic terms with more than 12 bands");
+        }
+        sp->form = ISO_SAMPLER_WIDE;
+        const int rc = any_form_ready(sp, "iso_sampler_create_model");
+        if (rc != ISO_OK) return rc;
+        *out = sp;
+        return ISO_OK;
+    }
     sp->std_priors = default_prior_families(m->desc);
     if (const char* e = std::getenv("ISOCHRONES_AMD_STD_PRIORS")) sp->std_priors = sp->std_priors && std::atoi(e) != 0;   // A/B switch
     *out = sp;
@@ -2122,6 +2223,57 @@ int iso_sampler_create_catalog(iso_catalog* c, int nwalkers, double a, uint64_t 
     return ISO_OK;
 }
 
+int iso_sampler_create_tree(iso_tree_model* m, int64_t n_ensembles, int nwalkers, double a, uint64_t seed, iso_sampler** out)
+{
+    if (!m || !out) return fail(ISO_ERR_INVALID, "iso_sampler_create_tree: NULL argument");
+    if (!walkers_ok(nwalkers, a)) return fail(ISO_ERR_INVALID, "iso_sampler_create_tree: need an even walker count and a > 1");
+    if (n_ensembles < 1 || n_ensembles > (int64_t(1) << 24))
+        return fail(ISO_ERR_INVALID, "iso_sampler_create_tree: n_ensembles out of range");
+    if (!m->fast_ok)
+        return fail(ISO_ERR_INVALID, "iso_sampler_create_tree: the tree model is not on the corner-packed fast path (1-12 bands, "
+                                     "ISOCHRONES_AMD_PATH=auto)");
+    iso_sampler* sp = new (std::nothrow) iso_sampler();
+    if (!sp) return fail(ISO_ERR_NOMEM, "iso_sampler_create_tree: out of host memory");
+    sampler_common(sp, m->device, ISO_KIND_ISO, 0, m->n_bands, n_ensembles, m->fast, 0, nwalkers, a, seed);
+    sp->n_params = m->n_params;
+    sp->form = ISO_SAMPLER_TREE;
+    sp->d_tree = m->d_tree;
+    sp->n_leaves = m->n_leaves;
+    const int rc = any_form_ready(sp, "iso_sampler_create_tree");
+    if (rc != ISO_OK) return rc;
+    *out = sp;
+    return ISO_OK;
+}
+
+int iso_sampler_create_isotrack(iso_model* iso_m, iso_model* track_m, double age_lo, double age_hi, double age_lnorm,
+                                int64_t n_ensembles, int nwalkers, double a, uint64_t seed, iso_sampler** out)
+{
+    if (!iso_m || !track_m || !out) return fail(ISO_ERR_INVALID, "iso_sampler_create_isotrack: NULL argument");
+    if (!walkers_ok(nwalkers, a)) return fail(ISO_ERR_INVALID, "iso_sampler_create_isotrack: need an even walker count and a > 1");
+    if (n_ensembles < 1 || n_ensembles > (int64_t(1) << 24))
+        return fail(ISO_ERR_INVALID, "iso_sampler_create_isotrack: n_ensembles out of range");
+    if (iso_m->ic->kind != ISO_KIND_ISO || track_m->ic->kind != ISO_KIND_TRACK || iso_m->desc.n_stars != 1 || track_m->desc.n_stars != 1)
+        return fail(ISO_ERR_INVALID, "iso_sampler_create_isotrack: need a single-star model on the isochrone grid and one on the track grid");
+    if (iso_m->device != track_m->device) return fail(ISO_ERR_INVALID, "iso_sampler_create_isotrack: the two models live on different devices");
+    if (iso_m->desc.n_bands != track_m->desc.n_bands || iso_m->desc.n_bands > FAST_NB_MAX)
+        return fail(ISO_ERR_INVALID, "iso_sampler_create_isotrack: both models must carry the same (at most 12) bands");
+    for (iso_model* m : {iso_m, track_m})
+        if (!m->fast_ok || !m->fast.hotq || (!m->fast.bcq && m->desc.n_bands > 0) || m->fast.astq)
+            return fail(ISO_ERR_INVALID, "iso_sampler_create_isotrack: both models must be on the corner-packed fast path, without "
+                                         "asteroseismic terms");
+    iso_sampler* sp = new (std::nothrow) iso_sampler();
+    if (!sp) return fail(ISO_ERR_NOMEM, "iso_sampler_create_isotrack: out of host memory");
+    sampler_common(sp, iso_m->device, ISO_KIND_ISO, 1, iso_m->desc.n_bands, n_ensembles, iso_m->fast, 0, nwalkers, a, seed);
+    sp->n_params = 6;
+    sp->form = ISO_SAMPLER_ISOTRACK;
+    sp->fast2 = track_m->fast;
+    sp->age = IsoTrackAge{age_lo, age_hi, age_lnorm};
+    const int rc = any_form_ready(sp, "iso_sampler_create_isotrack");
+    if (rc != ISO_OK) return rc;
+    *out = sp;
+    return ISO_OK;
+}
+
 void iso_sampler_destroy(iso_sampler* s) { delete s; }
 
 int iso_sampler_set_chain_layout(iso_sampler* s, int layout)
@@ -2142,6 +2294,19 @@ int iso_sampler_run(iso_sampler* sp, double* pos, double* lnp, int nsteps, doubl
     DeviceGuard guard(sp->device);
     hipStream_t s = as_stream(stream);
     const int64_t rows = sp->n_ensembles * sp->W;
+    if (sp->form != 0) {
+        // trees, IsoTrackModel, 13-32 bands: one persistent launch, one workgroup per ensemble (fast/sampler_any.h)
+        if (nsteps == 0) return ISO_OK;
+        const AnyStretchArgs S = any_args(sp, pos, lnp, accepted, nsteps, chain, chain_lnp);
+        sp->step += (uint32_t)nsteps;
+        if (!launch_any_form(sp, S, nullptr, s)) {
+            const hipError_t e = hipGetLastError();
+            return fail(e == hipSuccess ? ISO_ERR_INVALID : ISO_ERR_HIP,
+                        std::string("iso_sampler_run: any-model sampler launch failed") + (e == hipSuccess ? "" : std::string(": ") + hipGetErrorString(e)));
+        }
+        HIP_TRY(hipGetLastError());
+        return ISO_OK;
+    }
     StretchArgs S;
     S.occupancy_query = nullptr;
     S.dense = 0;
@@ -2209,17 +2374,23 @@ int iso_sampler_run(iso_sampler* sp, double* pos, double* lnp, int nsteps, doubl
         int gmin = 1;
         while (gmin * h < 64 && gmin < group) gmin <<= 1;
         int g = group;
-        while (g > gmin && (sp->n_ensembles + (g >> 1) - 1) / (g >> 1) <= (int64_t)cus) g >>= 1;
+        while ((g >> 1) >= gmin && (sp->n_ensembles + (g >> 1) - 1) / (g >> 1) <= (int64_t)cus) g >>= 1;     // (never below gmin: a
+                                                                                         // group size need not be a power of two)
         if (const char* e = std::getenv("ISOCHRONES_AMD_PERSIST_GROUP")) {
             const int want = std::atoi(e);
             if (want >= 1) g = std::min(want, group);
         }
         if (g < group) {
             S.group = g;
-            // fewer ensembles per workgroup = more workgroups: does the launch still fit the chip in one round with the form
-            // chosen above?  If not, the register-capped form takes it (when the catalog allows it).
+            // fewer ensembles per workgroup = more workgroups, and possibly ANOTHER instantiation (a single binary's
+            // one-star-per-lane form is chosen by the moves a workgroup holds): ask again with the group in place, so that the
+            // occupancy is the launched kernel's.  If the launch no longer fits the chip in one round, keep the full groups.
+            int per_cu_g = 0;
+            S.occupancy_query = &per_cu_g;
+            if (!launch_stretch(sp->kind, sp->n_stars, sp->n_bands, sp->fast, S, s)) per_cu_g = 0;
+            S.occupancy_query = nullptr;
             const int64_t blocks_g = (sp->n_ensembles + g - 1) / g;
-            if (blocks_g > (int64_t)cus * per_cu) S.group = 0;
+            if (per_cu_g <= 0 || blocks_g > (int64_t)cus * per_cu_g) S.group = 0;
         }
     }
     // (round 2 kept the step-wise form for catalogs of 1-1.4 rounds, where a nearly empty second round cost more than it;
@@ -2267,7 +2438,7 @@ int iso_chain_quantiles_layout(iso_ctx* ctx, const double* chain, int layout, in
     if (nsteps < 1 || n_ens < 1 || W < 1 || n_params < 1 || nq < 1 || nq > 8)
         return fail(ISO_ERR_INVALID, "iso_chain_quantiles: counts out of range");
     const int64_t m = nsteps * W;
-    if (m > 8192) return fail(ISO_ERR_INVALID, "iso_chain_quantiles: more than 8192 samples per ensemble");
+    if (m >= ((int64_t)1 << 31)) return fail(ISO_ERR_INVALID, "iso_chain_quantiles: 2^31 or more samples per ensemble");
     if (n_ens * n_params > 0x7fffffff) return fail(ISO_ERR_INVALID, "iso_chain_quantiles: too many ensembles");
     QuantArgs A;
     A.chain = chain;
@@ -2280,7 +2451,7 @@ int iso_chain_quantiles_layout(iso_ctx* ctx, const double* chain, int layout, in
     A.D = n_params;
     A.nq = nq;
     A.P = 2;
-    while (A.P < m) A.P <<= 1;
+    while (A.P < m && A.P < 8192) A.P <<= 1;
     for (int k = 0; k < 8; ++k) A.q[k] = 0.0;
     for (int k = 0; k < nq; ++k) {
         if (!(q[k] >= 0.0 && q[k] <= 1.0)) return fail(ISO_ERR_INVALID, "iso_chain_quantiles: quantile level outside [0, 1]");
@@ -2296,7 +2467,12 @@ int iso_chain_quantiles_layout(iso_ctx* ctx, const double* chain, int layout, in
     const size_t sort_bytes = (size_t)A.P * sizeof(double);
     const dim3 g((unsigned)(n_ens * n_params)), b(BLOCK);
     A.only_flagged = 0;
-    if (qm && !std::strcmp(qm, "sort")) {
+    if (m > 8192) {
+        // longer than the LDS forms hold (the reference's default fit: 300 walkers x 100 iterations per parameter):
+        // selection by refinement, every pass streamed from the chain
+        note_kernel("k_chain_quantiles_big");
+        hipLaunchKernelGGL(k_chain_quantiles_big, g, b, QBIG_LDS, as_stream(stream), A);
+    } else if (qm && !std::strcmp(qm, "sort")) {
         note_kernel("k_chain_quantiles");
         hipLaunchKernelGGL(k_chain_quantiles, g, b, sort_bytes, as_stream(stream), A);
     } else if (m <= 64 * QW_IPL_BIG && !(qm && !std::strcmp(qm, "workgroup"))) {

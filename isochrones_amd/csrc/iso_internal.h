@@ -164,6 +164,29 @@ struct StretchArgs {
     int pair;             // host side only: a single binary may take the one-star-per-lane kernel (k_stretch_pair)
 };
 
+// the moves' side of a run of the any-model persistent sampler (fast/sampler_any.h)
+struct AnyStretchArgs {
+    double* pos;          // [n_ens * W][NP] row-major
+    double* lnp;          // [n_ens * W]
+    int32_t* accepted;    // [n_ens * W] acceptance counters, may be null
+    int W, NP;
+    int lanes;            // lanes of a workgroup that take moves (64, 128, 192 or 256)
+    int own_off;          // doubles of LDS in front of the sampler's own arrays (the evaluator's: axes, gather slots, leaf values)
+    int64_t n_ens;
+    double a;
+    uint64_t seed;
+    uint32_t step;
+    int nsteps;
+    int64_t chain_rs, chain_ps;   // as StretchArgs: element strides of a stored step between rows / between parameters
+    double* chain_pos;    // optional [nsteps] slabs of n_ens * W * NP
+    double* chain_lnp;    // optional [nsteps][n_ens * W]
+};
+
+// closed-form age prior of an IsoTrackModel (the reference's AgePrior, flat in linear age): lnorm + age ln 10 inside [lo, hi]
+struct IsoTrackAge {
+    double lo, hi, lnorm;
+};
+
 }  // namespace iso
 
 struct iso_ctx {
@@ -211,6 +234,7 @@ struct BandPack {
     double* d_bcq;
     double* d_axes_blob;
     iso::FastArgs fast;
+    size_t bytes;            // of the corner-packed copy (what the interpolator's cache is bounded by)
     ~BandPack();
 };
 
@@ -284,7 +308,15 @@ struct iso_sampler {
     int std_priors;          // single model whose priors are the reference's default families (compile-time kinds)
     int chain_layout;        // ISO_CHAIN_ROW_MAJOR / ISO_CHAIN_PARAM_MAJOR
     iso::FastArgs fast;      // tables + model(s); copied at create time (owner must outlive the sampler)
+    // the any-model persistent sampler (fast/sampler_any.h): 0 = the fused BasicStarModel kernels above,
+    // ISO_SAMPLER_TREE / _ISOTRACK / _WIDE otherwise
+    int form;
+    const iso::DevTree* d_tree;   // tree: the model's device record (the tree model must outlive the sampler)
+    int n_leaves;
+    iso::FastArgs fast2;     // isotrack: the track-grid model's tables (fast = the isochrone-grid model's)
+    iso::IsoTrackAge age;
 };
+constexpr int ISO_SAMPLER_TREE = 1, ISO_SAMPLER_ISOTRACK = 2, ISO_SAMPLER_WIDE = 3;
 
 namespace iso {
 struct MagOut {
@@ -295,6 +327,12 @@ bool launch_interp_mag_fast(int kind, int nb, const FastArgs& A, const MagOut& O
 // defined in iso_fast_tree.hip: observation-tree lnpost on the corner-packed tables (1..12 bands)
 bool launch_tree_fast(int nb, int n_leaves, const FastArgs& A, const DevTree* T, hipStream_t s);
 bool launch_stretch(int kind, int n_stars, int n_bands, const FastArgs& A, const StretchArgs& S, hipStream_t s);
+// defined in iso_fast_stretch_tree.hip / iso_fast_stretch_more.hip: the any-model persistent sampler (one workgroup per
+// ensemble).  `query` non-null: report whether a kernel exists for the shape and its LDS fits a CU, launch nothing.
+bool launch_stretch_tree(int nb, int n_leaves, const FastArgs& A, const DevTree* T, const AnyStretchArgs& S, int* query, hipStream_t s);
+bool launch_stretch_isotrack(int nb, const FastArgs& Ai, const FastArgs& At, const IsoTrackAge& P, AnyStretchArgs S, int* query,
+                             hipStream_t s);
+bool launch_stretch_wide(int kind, int n_stars, const FastArgs& A, AnyStretchArgs S, int* query, hipStream_t s);
 // dynamic LDS bytes one workgroup of the persistent sampler kernel needs for W-walker ensembles, and how
 // many ensembles such a workgroup owns
 size_t stretch_persist_lds(int n_bands, int axes_len, int W, int n_params, int* ensembles_per_workgroup);

@@ -273,6 +273,272 @@ __global__ __launch_bounds__(BLOCK, 2) void k_chain_quantiles_select(const Quant
 
 
 // -------------------------------------------------------------------------------------------
+// Chains of ANY length (more than 8 192 values per pair: the reference's default fit keeps 300 walkers x 100 iterations =
+// 30 000 per parameter, starmodel.py:889-893): selection by REFINEMENT, nothing proportional to the chain in LDS.
+//   pass 1   min / max of the finite values; counts of -inf and of +inf / NaN (they sort first / last)
+//   pass 2   QBIG_BINS-bin histogram over [min, max], prefix, the bin and the rank inside it of each of the 2 nq targets
+//   pass 3   the target bins that hold at most QBIG_CAP values are gathered into LDS lists; rank by counting
+//   refine   a target whose bin holds more (a chain with many repeats of one value, a narrow posterior): the bin's values
+//            are exactly those in [lo, hi] = their own min / max (the binning is monotone), so the same three steps run on
+//            that interval with the whole list area (4 096 values) as capacity - until it fits, or lo == hi (all equal).
+// Every pass streams the pair's values from memory (the W values of a step are contiguous in the parameter-major chain);
+// a 30 000-value pair is 240 KB - L2 / Infinity Cache hits after the first pass.  Bit for bit numpy.percentile.
+// -------------------------------------------------------------------------------------------
+constexpr int QBIG_BINS = 4096;
+constexpr int QBIG_CAP = 256;                              // values per gathered list in the common pass
+constexpr int QBIG_POOL = QSEL_RANKS * QBIG_CAP;           // = the single list of a refinement pass (4 096 values)
+constexpr size_t QBIG_LDS = (size_t)QBIG_POOL * 8 + QBIG_BINS * 4 + QBIG_BINS + 6 * QSEL_RANKS * 4 + 16 * 8 + 8 * 4 + QSEL_RANKS * 8;
+
+__global__ __launch_bounds__(BLOCK, 2) void k_chain_quantiles_big(const QuantArgs A)
+{
+    extern __shared__ double lds[];
+    double* lists = lds;
+    int* hist = reinterpret_cast<int*>(lds + QBIG_POOL);
+    unsigned char* slot_of_bin = reinterpret_cast<unsigned char*>(hist + QBIG_BINS);
+    int* rank_bin = reinterpret_cast<int*>(slot_of_bin + QBIG_BINS);       // [QSEL_RANKS]
+    int* rank_local = rank_bin + QSEL_RANKS;
+    int* rank_slot = rank_local + QSEL_RANKS;                               // list slot, -1 = resolved, -2 = needs refinement
+    int* list_count = rank_slot + QSEL_RANKS;
+    int* rank_cnt = list_count + QSEL_RANKS;                                // values in the target's bin
+    int* spare = rank_cnt + QSEL_RANKS;
+    double* red = reinterpret_cast<double*>(spare + QSEL_RANKS);            // [16] reduction partials
+    int* ired = reinterpret_cast<int*>(red + 16);                           // [8]
+    double* result = reinterpret_cast<double*>(ired + 8);                   // [QSEL_RANKS]
+
+    const int64_t e = blockIdx.x / A.D;
+    const int d = (int)(blockIdx.x - e * A.D);
+    const int m = (int)(A.nsteps * A.W);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_ranks = 2 * A.nq;
+    const double* __restrict__ base = A.chain + e * A.W * A.rs + d * A.ps;
+    // value i of the pair (step i / W, walker i % W); NaN sorts last, as +inf
+    auto value = [&](int t, int w) {
+        const double v = base[(int64_t)t * A.ss + (int64_t)w * A.rs];
+        return (v != v) ? d_inf() : v;
+    };
+    // a pass over the pair's values: thread tid starts at (t, w) = (tid / W, tid % W) and advances by BLOCK values
+    const int dt = BLOCK / A.W, dw = BLOCK - dt * A.W;
+#define QBIG_FOR_VALUES(v)                                                                     \
+    for (int i_ = tid, t_ = tid / A.W, w_ = tid - (tid / A.W) * A.W; i_ < m;                  \
+         i_ += BLOCK, t_ += dt, w_ += dw, t_ += (w_ >= A.W) ? 1 : 0, w_ -= (w_ >= A.W) ? A.W : 0) \
+        if (const double v = value(t_, w_); true)
+
+    auto block_minmax = [&](double& mn, double& mx) {        // workgroup reduction; every thread gets the result
+        for (int off = 32; off > 0; off >>= 1) {
+            mn = fmin(mn, __shfl_xor(mn, off));
+            mx = fmax(mx, __shfl_xor(mx, off));
+        }
+        __syncthreads();
+        if (lane == 0) {
+            red[wave] = mn;
+            red[4 + wave] = mx;
+        }
+        __syncthreads();
+        mn = fmin(fmin(red[0], red[1]), fmin(red[2], red[3]));
+        mx = fmax(fmax(red[4], red[5]), fmax(red[6], red[7]));
+    };
+    auto prefix_hist = [&]() {                               // hist -> exclusive prefix (all threads)
+        constexpr int PER = QBIG_BINS / BLOCK;
+        int c[PER];
+        int tot = 0;
+#pragma unroll
+        for (int r = 0; r < PER; ++r) {
+            c[r] = hist[tid * PER + r];
+            tot += c[r];
+        }
+        int incl = tot;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int up = __shfl_up(incl, off);
+            if (lane >= off) incl += up;
+        }
+        __syncthreads();
+        if (lane == 63) ired[wave] = incl;
+        __syncthreads();
+        int b0 = incl - tot;
+        for (int w = 0; w < wave; ++w) b0 += ired[w];
+#pragma unroll
+        for (int r = 0; r < PER; ++r) {
+            hist[tid * PER + r] = b0;
+            b0 += c[r];
+        }
+        __syncthreads();
+    };
+    auto find_bin = [&](int r) {                             // last bin whose exclusive prefix is <= r
+        int lo = 0, hi = QBIG_BINS - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (hist[mid] <= r) lo = mid;
+            else hi = mid - 1;
+        }
+        return lo;
+    };
+    // rank `want` of the `cnt` values of a list, by counting: an element's rank = elements before it in (value, position) order
+    auto select_in_list = [&](const double* Lp, int cnt, int want, int k, int first, int stride) {
+        for (int j = first; j < cnt; j += stride) {
+            const double x = Lp[j];
+            int before = 0;
+            for (int i = 0; i < cnt; ++i) {
+                const double y = Lp[i];
+                before += (y < x || (y == x && i < j)) ? 1 : 0;
+            }
+            if (before == want) result[k] = x;
+        }
+    };
+
+    // ---- pass 1: finite min / max, counts of the infinities ----
+    double mn = d_inf(), mx = -d_inf();
+    int n_neg = 0, n_pos = 0;
+    QBIG_FOR_VALUES(v) {
+        const bool neg = v == -d_inf(), pos = v == d_inf();
+        n_neg += neg;
+        n_pos += pos;
+        mn = (neg | pos) ? mn : fmin(mn, v);
+        mx = (neg | pos) ? mx : fmax(mx, v);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        n_neg += __shfl_xor(n_neg, off);
+        n_pos += __shfl_xor(n_pos, off);
+    }
+    if (lane == 0) {
+        ired[wave] = n_neg;
+        ired[4 + wave] = n_pos;
+    }
+    block_minmax(mn, mx);
+    n_neg = ired[0] + ired[1] + ired[2] + ired[3];
+    n_pos = ired[4] + ired[5] + ired[6] + ired[7];
+    const int mfin = m - n_neg - n_pos;
+    __syncthreads();
+    // ---- the targets: order statistics i0, i1 of each level ----
+    if (tid < n_ranks) {
+        int i0, i1;
+        double f;
+        quantile_position(A.q[tid >> 1], m, i0, i1, f);
+        const int r = (tid & 1) ? i1 : i0;
+        rank_slot[tid] = -2;
+        rank_local[tid] = r - n_neg;                         // rank among the finite values
+        if (r < n_neg) { result[tid] = -d_inf(); rank_slot[tid] = -1; }
+        else if (r >= n_neg + mfin) { result[tid] = d_inf(); rank_slot[tid] = -1; }
+        else if (!(mx > mn)) { result[tid] = mn; rank_slot[tid] = -1; }      // every finite value equal
+    }
+    for (int i = tid; i < QBIG_BINS; i += BLOCK) {
+        hist[i] = 0;
+        slot_of_bin[i] = 0xFF;
+    }
+    __syncthreads();
+    if (mfin > 0 && mx > mn) {                               // workgroup-uniform
+        // ---- pass 2: histogram over [mn, mx] ----
+        const double inv = (double)QBIG_BINS / (mx - mn);
+        auto bin_of = [&](double v) { return min(QBIG_BINS - 1, (int)((v - mn) * inv)); };
+        QBIG_FOR_VALUES(v) {
+            if (v > -d_inf() && v < d_inf()) atomicAdd(&hist[bin_of(v)], 1);
+        }
+        __syncthreads();
+        prefix_hist();
+        if (tid < n_ranks && rank_slot[tid] == -2) {
+            const int b = find_bin(rank_local[tid]);
+            rank_bin[tid] = b;
+            rank_cnt[tid] = ((b + 1 < QBIG_BINS) ? hist[b + 1] : mfin) - hist[b];
+            rank_local[tid] -= hist[b];
+        }
+        __syncthreads();
+        if (tid == 0) {                                      // distinct target bins that fit a list -> list slots
+            int n_lists = 0;
+            for (int k = 0; k < n_ranks; ++k) {
+                if (rank_slot[k] != -2 || rank_cnt[k] > QBIG_CAP) continue;
+                const int b = rank_bin[k];
+                if (slot_of_bin[b] == 0xFF) {
+                    slot_of_bin[b] = (unsigned char)n_lists;
+                    list_count[n_lists] = 0;
+                    ++n_lists;
+                }
+                rank_slot[k] = slot_of_bin[b];
+            }
+        }
+        __syncthreads();
+        // ---- pass 3: gather, select ----
+        QBIG_FOR_VALUES(v) {
+            if (v > -d_inf() && v < d_inf()) {
+                const int sl = slot_of_bin[bin_of(v)];
+                if (sl != 0xFF) lists[sl * QBIG_CAP + atomicAdd(&list_count[sl], 1)] = v;
+            }
+        }
+        __syncthreads();
+        for (int k = wave; k < n_ranks; k += BLOCK / 64) {
+            const int sl = rank_slot[k];
+            if (sl >= 0) select_in_list(lists + sl * QBIG_CAP, list_count[sl], rank_local[k], k, lane, 64);
+        }
+        __syncthreads();
+        // ---- refinement of the targets whose bin did not fit ----
+        for (int k = 0; k < n_ranks; ++k) {
+            if (rank_slot[k] != -2) continue;                // workgroup-uniform (LDS word)
+            // the bin's values: the finite v with bin_of(v) == rank_bin[k]; from the second round on: lo <= v <= hi
+            int want = rank_local[k];
+            const int b0 = rank_bin[k];
+            double lo = d_inf(), hi = -d_inf();
+            QBIG_FOR_VALUES(v) {
+                if (v > -d_inf() && v < d_inf() && bin_of(v) == b0) {
+                    lo = fmin(lo, v);
+                    hi = fmax(hi, v);
+                }
+            }
+            block_minmax(lo, hi);
+            for (int round = 0; round < 64; ++round) {       // (each round splits the interval 4 096 ways: a few at most)
+                if (!(hi > lo)) {
+                    if (tid == 0) result[k] = lo;
+                    break;
+                }
+                for (int i = tid; i < QBIG_BINS; i += BLOCK) hist[i] = 0;
+                __syncthreads();
+                const double inv2 = (double)QBIG_BINS / (hi - lo);
+                auto bin2 = [&](double v) { return min(QBIG_BINS - 1, (int)((v - lo) * inv2)); };
+                QBIG_FOR_VALUES(v) {
+                    if (v >= lo && v <= hi) atomicAdd(&hist[bin2(v)], 1);
+                }
+                __syncthreads();
+                const int total = hist[QBIG_BINS - 1];       // (read before the prefix overwrites it)
+                __syncthreads();
+                prefix_hist();
+                const int b2 = find_bin(want);
+                const int cnt2 = ((b2 + 1 < QBIG_BINS) ? hist[b2 + 1] : hist[QBIG_BINS - 1] + total) - hist[b2];
+                const int want2 = want - hist[b2];
+                __syncthreads();
+                if (cnt2 <= QBIG_POOL) {
+                    if (tid == 0) list_count[0] = 0;
+                    __syncthreads();
+                    QBIG_FOR_VALUES(v) {
+                        if (v >= lo && v <= hi && bin2(v) == b2) lists[atomicAdd(&list_count[0], 1)] = v;
+                    }
+                    __syncthreads();
+                    select_in_list(lists, list_count[0], want2, k, tid, BLOCK);
+                    break;
+                }
+                double lo2 = d_inf(), hi2 = -d_inf();
+                QBIG_FOR_VALUES(v) {
+                    if (v >= lo && v <= hi && bin2(v) == b2) {
+                        lo2 = fmin(lo2, v);
+                        hi2 = fmax(hi2, v);
+                    }
+                }
+                block_minmax(lo2, hi2);
+                lo = lo2;
+                hi = hi2;
+                want = want2;
+            }
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    if (tid < A.nq) {
+        int i0, i1;
+        double f;
+        quantile_position(A.q[tid], m, i0, i1, f);
+        A.out[(e * A.D + d) * A.nq + tid] = quantile_lerp(result[2 * tid], result[2 * tid + 1], f);
+    }
+#undef QBIG_FOR_VALUES
+}
+
+
+// -------------------------------------------------------------------------------------------
 // Selection with ONE WAVEFRONT per (ensemble, parameter) pair, the values held in registers.
 // The workgroup kernel above spends its time in barriers between short phases (~60 us per pair for 3 200
 // values, 1 280 pairs in flight): a wave needs no barrier at all, keeps its <= 64 x IPL values in VGPRs after a

@@ -74,6 +74,8 @@ SCRATCH_BUDGET = {
     "k_lnpost": 96,                  # generic fallback kernel (one sample per lane since round 4: 384 -> 96)
     "k_lnpost_tree": 1664,           # generic tree kernel (last-resort fallback): per-leaf arrays per lane
     "k_chain_quantiles_exact": 40,
+    "k_stretch_isotrack": 24,        # 10-12 bands
+    "k_stretch_tree": 24,            # register-leaf forms: 20 B (five dwords of the evaluator's record, written once)
 }
 DEFAULT_SCRATCH = 0
 MAX_AGPR = 0

@@ -119,8 +119,10 @@ def summarize_chain(flatchain, flatlnprob):
 class FusedEnsembleSampler:
     """The same stretch-move ensemble, but with proposal + fused lnpost + accept in ONE HIP kernel
     per half-ensemble (``iso_sampler_*``; Philox counter RNG in-kernel).  ``target`` is a
-    :class:`BasicStarModel` (one ensemble) or a :class:`CatalogPosterior` (one ensemble per star,
-    all advanced in lock-step; row = star * nwalkers + walker).  A 256-walker half-step is a
+    :class:`BasicStarModel` (one ensemble; 13-32 bands run the band-tiled persistent kernel), a
+    :class:`TreeStarModel` or :class:`IsoTrackModel` (one persistent launch per ``run_mcmc``, one workgroup per
+    ensemble: ``iso_sampler_create_tree`` / ``iso_sampler_create_isotrack``) or a :class:`CatalogPosterior` (one
+    ensemble per star, all advanced in lock-step; row = star * nwalkers + walker).  A 256-walker half-step is a
     single ~10 us launch instead of ~25 framework launches; whenever an ensemble fits a workgroup's
     LDS the library runs ALL iterations of a ``run_mcmc`` call in one persistent launch
     (workgroup-resident ensembles, positions in LDS; catalogs larger than the chip run in rounds),
@@ -147,8 +149,17 @@ class FusedEnsembleSampler:
         self.device = torch.device("cuda", self.device_index)
         h = C.c_void_p()
         lib = _cabi.lib()
+        from .starmodel import IsoTrackModel, TreeStarModel
         if self.is_catalog:
             _cabi.check(lib.iso_sampler_create_catalog(target._h, self.nwalkers, float(a), int(seed), C.byref(h)))
+        elif isinstance(target, TreeStarModel):
+            _cabi.check(lib.iso_sampler_create_tree(target.handle(self.device_index), self.n_ensembles, self.nwalkers,
+                                                    float(a), int(seed), C.byref(h)))
+        elif isinstance(target, IsoTrackModel):
+            lo, hi, lnorm = target.age_prior_constants()
+            _cabi.check(lib.iso_sampler_create_isotrack(target._iso_model.handle(self.device_index),
+                                                        target._track_model.handle(self.device_index), lo, hi, lnorm,
+                                                        self.n_ensembles, self.nwalkers, float(a), int(seed), C.byref(h)))
         elif self.multi_ensemble:
             _cabi.check(lib.iso_sampler_create_model_ensembles(target.handle(self.device_index), self.n_ensembles,
                                                                self.nwalkers, float(a), int(seed), C.byref(h)))
@@ -247,9 +258,10 @@ class FusedEnsembleSampler:
 
     def quantiles(self, q=(0.5, 0.16, 0.84)):
         """Per-ensemble quantiles of the stored chain, [S, ndim, len(q)] (model: [ndim, len(q)]) CUDA tensor,
-        linear interpolation between order statistics as ``numpy.percentile``.  One LDS sort per
-        (ensemble, parameter) on the device (``iso_chain_quantiles``); chains longer than 8 192 samples
-        per ensemble fall back to a framework sort."""
+        linear interpolation between order statistics as ``numpy.percentile``, bit for bit.  Selection on the device
+        (``iso_chain_quantiles``: one wavefront per (ensemble, parameter) pair up to 6 656 values, a workgroup up to
+        8 192, refinement passes streamed from the chain beyond - the reference's default 300 walkers x 100
+        iterations); only more than 8 quantile levels at once fall back to a framework sort."""
         import ctypes as C
         import torch
         from . import _cabi, device as dev
@@ -257,7 +269,7 @@ class FusedEnsembleSampler:
             raise ValueError("no stored chain")
         nsteps = self._chain.shape[0]
         q = np.ascontiguousarray(q, dtype=np.float64)
-        if nsteps * self.nwalkers <= 8192 and q.size <= 8:
+        if q.size <= 8:
             out = torch.empty(self.n_ensembles, self.ndim, q.size, dtype=torch.float64, device=self.device)
             chain = self._chain.contiguous()
             _cabi.check(_cabi.lib().iso_chain_quantiles_layout(dev.context(self.device_index), dev.ptr(chain),

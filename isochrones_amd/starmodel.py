@@ -129,6 +129,42 @@ class _ConvenienceMixin:
         return persist.load_model(cls, filename, ic=ic, name=name)
 
 
+def _run_mcmc_fit(model, nwalkers, nburn, niter, p0, seed, fused, n_ensembles=1):
+    """Burn in, reset, sample with the device-resident sampler (``fused`` None: whenever the library has a kernel for the
+    model's shape; False: the framework-op :class:`EnsembleSampler`, a debugging aid that evaluates lnpost through the
+    batch kernels; True: raise if there is no device-resident form).  Reference: fit_mcmc_old, starmodel.py:889-972."""
+    import torch
+    from .sampler import EnsembleSampler, FusedEnsembleSampler
+    rng = np.random.default_rng(seed)
+    npars = model.n_params
+    if p0 is None:
+        p0 = model.sample_from_prior(nwalkers * n_ensembles, rng=rng)
+    else:
+        centre = np.asarray(p0, dtype=float)
+        p0 = rng.normal(size=(nwalkers * n_ensembles, npars)) * 0.01 + centre[None, :]
+        bad = ~np.isfinite(model.lnpost(p0))
+        p0[bad] = centre                       # a perturbed walker that left the support starts on the point itself
+    p0 = np.asarray(p0, dtype=float)
+    sampler = None
+    if fused is None or fused:
+        try:
+            sampler = FusedEnsembleSampler(model, nwalkers, seed=int(rng.integers(2 ** 62)), n_ensembles=n_ensembles)
+        except _cabi.IsoError:
+            if fused:
+                raise
+    if sampler is None:
+        if n_ensembles != 1:
+            raise ValueError("n_ensembles > 1 needs the device-resident sampler")
+        sampler = EnsembleSampler(nwalkers, npars, model.lnpost, seed=int(rng.integers(2 ** 62)),
+                                  device=torch.device("cuda", dev.current_device()))
+    if n_ensembles > 1:
+        p0 = p0.reshape(n_ensembles, nwalkers, npars)
+    pos, prob = sampler.run_mcmc(p0, nburn, store=False)
+    sampler.reset()
+    sampler.run_mcmc(pos, niter, lnprob0=prob)
+    return sampler
+
+
 class _NestedFitMixin:
     """``fit_multinest`` / ``evidence`` for any model with ``param_names``, ``bounds(par)`` and a
     batched ``lnpost``: the reference hands ``mnest_loglike`` (= lnpost) and the flat-box ``mnest_prior``
@@ -1173,24 +1209,15 @@ class TreeStarModel(_NestedFitMixin, _ConvenienceMixin):
 
     emcee_p0 = sample_from_prior
 
-    def fit_mcmc(self, nwalkers=300, nburn=200, niter=100, p0=None, seed=None, **kwargs):
-        """Stretch-move ensemble on the device; every half-step evaluates the tree kernel once."""
-        import torch
-        from .sampler import EnsembleSampler
-        rng = np.random.default_rng(seed)
-        if p0 is None:
-            p0 = self.sample_from_prior(nwalkers, rng=rng)
-        else:
-            p0 = rng.normal(size=(nwalkers, self.n_params)) * 0.01 + np.asarray(p0, dtype=float)[None, :]
-        sampler = EnsembleSampler(nwalkers, self.n_params, self.lnpost, seed=int(rng.integers(2 ** 62)),
-                                  device=torch.device("cuda", dev.current_device()))
-        pos, prob = sampler.run_mcmc(p0, nburn, store=False)
-        sampler.reset()
-        sampler.run_mcmc(pos, niter, lnprob0=prob)
-        self._sampler = sampler
+    def fit_mcmc(self, nwalkers=300, nburn=200, niter=100, p0=None, seed=None, fused=None, n_ensembles=1, **kwargs):
+        """Stretch-move ensemble resident on the device: burn-in and sampling are one persistent launch each
+        (``k_stretch_tree``: proposal, tree lnpost and accept step of every iteration inside the kernel, positions in
+        LDS).  ``fused=False`` selects the framework-op sampler around the batch kernel (debugging aid; also what runs
+        when the tree has no device-resident form - more than 12 bands or tables off the corner-packed path)."""
+        self._sampler = _run_mcmc_fit(self, nwalkers, nburn, niter, p0, seed, fused, n_ensembles)
         self._samples = None
         self._fit_kind = "mcmc"
-        return sampler
+        return self._sampler
 
     fit_mcmc_old = fit_mcmc
 
@@ -1289,6 +1316,11 @@ class IsoTrackModel(_NestedFitMixin):
     def prior(self, prop, val, **kwargs):
         return self._priors[prop](val, **kwargs)
 
+    def age_prior_constants(self):
+        """(lo, hi, lnorm) of the closed-form age prior: ln p(age) = lnorm + age ln 10 inside [lo, hi]."""
+        lo, hi = self._priors["age"].bounds
+        return float(lo), float(hi), math.log(math.log(10.0) / (10.0 ** hi - 10.0 ** lo))
+
     def _split(self, p):
         import torch
         iso_p = torch.stack([p[:, 0], p[:, 2], p[:, 3], p[:, 4], p[:, 5]], dim=1).contiguous()
@@ -1302,9 +1334,8 @@ class IsoTrackModel(_NestedFitMixin):
         _, t_prior, t_like = self._track_model.evaluate_device(trk_p, parts=True)
         _, _, i_like = self._iso_model.evaluate_device(iso_p, parts=True)
         age = p[:, 2]
-        ap = self._priors["age"]
-        lo, hi = ap.bounds
-        ln_age = math.log(math.log(10.0) / (10.0 ** hi - 10.0 ** lo)) + age * math.log(10.0)
+        lo, hi, lnorm = self.age_prior_constants()
+        ln_age = lnorm + age * math.log(10.0)
         ln_age = torch.where((age < lo) | (age > hi), torch.full_like(age, -float("inf")), ln_age)
         lnprior = t_prior + ln_age
         lnlike = i_like + t_like
@@ -1347,21 +1378,12 @@ class IsoTrackModel(_NestedFitMixin):
 
     emcee_p0 = sample_from_prior
 
-    def fit_mcmc(self, nwalkers=300, nburn=200, niter=100, p0=None, seed=None, **kwargs):
-        import torch
-        from .sampler import EnsembleSampler
-        rng = np.random.default_rng(seed)
-        if p0 is None:
-            p0 = self.sample_from_prior(nwalkers, rng=rng)
-        else:
-            p0 = rng.normal(size=(nwalkers, 6)) * 0.01 + np.asarray(p0, dtype=float)[None, :]
-        sampler = EnsembleSampler(nwalkers, 6, self.lnpost, seed=int(rng.integers(2 ** 62)),
-                                  device=torch.device("cuda", dev.current_device()))
-        pos, prob = sampler.run_mcmc(p0, nburn, store=False)
-        sampler.reset()
-        sampler.run_mcmc(pos, niter, lnprob0=prob)
-        self._sampler, self._samples, self._fit_kind = sampler, None, "mcmc"
-        return sampler
+    def fit_mcmc(self, nwalkers=300, nburn=200, niter=100, p0=None, seed=None, fused=None, n_ensembles=1, **kwargs):
+        """Device-resident stretch-move ensemble (``k_stretch_isotrack``: both grids' evaluations inside one
+        persistent kernel); ``fused=False``: the framework-op sampler around :meth:`evaluate_device`."""
+        self._sampler = _run_mcmc_fit(self, nwalkers, nburn, niter, p0, seed, fused, n_ensembles)
+        self._samples, self._fit_kind = None, "mcmc"
+        return self._sampler
 
     fit_mcmc_old = fit_mcmc
 

@@ -714,13 +714,14 @@ def test_tree_model_fits_and_quantile_errors():
     assert np.isfinite(res.logz) and res.niter < 400 + 6          # a macro-step retires n_live // 10 points at a time
     lz, err = mod.evidence
     assert lz == res.logz and err > 0 and len(mod.samples) >= 1
-    # iso_chain_quantiles refuses what it cannot sort in LDS / bad levels
+    # iso_chain_quantiles refuses bad levels / NULL; any chain length is served
     lib, ctx = _cabi.lib(), dev.context(0)
     x = torch.zeros(4, 8, 3, dtype=torch.float64, device="cuda")
     out = torch.zeros(1, 3, 1, dtype=torch.float64, device="cuda")
     q = (C.c_double * 1)(0.5)
     assert lib.iso_chain_quantiles(ctx, dev.ptr(x), 4, 1, 8, 3, q, 1, dev.ptr(out), None) == 0
-    assert lib.iso_chain_quantiles(ctx, dev.ptr(x), 2000, 1, 8, 3, q, 1, dev.ptr(out), None) != 0      # 16000 samples
+    x2 = torch.zeros(2000, 8, 3, dtype=torch.float64, device="cuda")
+    assert lib.iso_chain_quantiles(ctx, dev.ptr(x2), 2000, 1, 8, 3, q, 1, dev.ptr(out), None) == 0     # 16000 samples: streamed
     assert lib.iso_chain_quantiles(ctx, dev.ptr(x), 4, 1, 8, 3, (C.c_double * 1)(1.5), 1, dev.ptr(out), None) != 0
     assert lib.iso_chain_quantiles(ctx, None, 4, 1, 8, 3, q, 1, dev.ptr(out), None) != 0
 
@@ -947,7 +948,10 @@ def test_chain_quantiles_adversarial_inputs(mode, monkeypatch):
                             (100, 1031, 32, 5),
                             # the compile-time-shaped kernel: 12 / 25 / 50 / 100 full registers, with and without a tail, W | 64
                             (25, 3, 32, 3), (50, 4, 32, 3), (51, 3, 32, 2), (101, 3, 32, 3), (201, 3, 32, 2), (400, 3, 8, 2),
-                            (100, 3, 64, 2), (1600, 3, 2, 2), (24, 3, 32, 2), (200, 3, 16, 3), (3201, 3, 1, 2)):
+                            (100, 3, 64, 2), (1600, 3, 2, 2), (24, 3, 32, 2), (200, 3, 16, 3), (3201, 3, 1, 2),
+                            # more than 8 192 values per pair: selection by refinement, streamed from the chain
+                            # (k_chain_quantiles_big; 300 walkers x 100 iterations is the reference's default fit)
+                            (100, 4, 300, 3), (129, 3, 64, 2), (300, 3, 100, 3), (1000, 3, 300, 2), (8193, 3, 1, 2)):
         x = rng.standard_normal((nsteps, S * W, D))
         if S > 1000:
             x[:, 5 * W:6 * W, 3] = np.exp(3 * x[:, 5 * W:6 * W, 3])      # long tail: most values share the first bins

@@ -9,8 +9,9 @@ iso_debug_kernels) and checks the result against the CPU oracle:
 
   * batch kernels (k_lnpost_fast, k_lnpost_wide, k_lnpost, tree kernels): 4 096 seeded rows - wide over the bounds, a
     cluster near a solution, special values - lnpost / lnprior / lnlike vs the oracle, exact NaN / -inf pattern, 1e-9;
-  * sampler kernels (k_stretch_half, k_stretch_persist): a short run whose every move is replayed on the host with the
-    kernel's Philox stream and the oracle's lnpost (tests/_replay.py);
+  * sampler kernels (k_stretch_half, k_stretch_persist, k_stretch_pair, and the any-model family k_stretch_tree /
+    k_stretch_isotrack / k_stretch_wide): a short run whose every move is replayed on the host with the kernel's Philox
+    stream and the oracle's lnpost (tests/_replay.py);
   * the interpolation / summary / set-up kernels: their own oracle or numpy equivalents.
 
 The last test requires that the kernels seen by the tracer are exactly the kernels the build compiled: an entry nobody
@@ -175,12 +176,13 @@ def start_ball(rng, mod, kind, ns, W):
     raise AssertionError("no start points")
 
 
-def check_sampler(mod, oic, p0, W, steps, seed, what, n_ensembles=1):
+def check_sampler(mod, oic, p0, W, steps, seed, what, n_ensembles=1, fn=None):
     from isochrones_amd.sampler import FusedEnsembleSampler
-    desc = mod.model_desc()
+    if fn is None:
+        desc = mod.model_desc()
 
-    def fn(blk, pars):
-        return oic.lnpost(desc, np.ascontiguousarray(pars.T), nthreads=8, parts=False)
+        def fn(blk, pars):
+            return oic.lnpost(desc, np.ascontiguousarray(pars.T), nthreads=8, parts=False)
     kw = dict(n_ensembles=n_ensembles) if n_ensembles > 1 else {}
     fs = FusedEnsembleSampler(mod, W, a=2.0, seed=seed, **kw)
     start = np.broadcast_to(p0, (n_ensembles,) + p0.shape).reshape(-1, p0.shape[1]).copy() if n_ensembles > 1 else p0
@@ -350,7 +352,11 @@ def test_band_tiled_family(kind, ns):
         mod = make_model(ic, kind, ns, bands)
         with traced(tid) as t:
             check_batch(mod, oic, batch_rows(rng, kind, ns, lo, hi), tid)
-    expect(t.names, "k_lnpost_wide<%d, %d>" % (KIND_ID[kind], ns), tid)
+        expect(t.names, "k_lnpost_wide<%d, %d>" % (KIND_ID[kind], ns), tid)
+        # the any-model persistent sampler with the band-tiled evaluation
+        with traced(tid) as t:
+            check_sampler(mod, oic, start_ball(rng, mod, kind, ns, 16), 16, 10, 7100 + ns, tid + " sampler")
+        expect(t.names, "k_stretch_wide<%d, %d>" % (KIND_ID[kind], ns), tid)
     ic.release()
     RAN.add(tid)
 
@@ -421,6 +427,31 @@ def check_tree(mod, oic, rng, what):
     fx.assert_close(mod.lnlike(x), w_like, RTOL, atol=ATOL, what=what + " lnlike")
 
 
+def check_tree_sampler(mod, oic, rng, what, W=16, steps=10, seed=5):
+    from oracle import oracle as orc
+    names = list(mod.param_names)
+    c = np.array([340.0 if nm.startswith("eep") else {"age": 9.6, "feh": 0.0, "distance": 330.0, "AV": 0.1}[nm.split("_")[0]] for nm in names])
+    w = np.array([3.0 if nm.startswith("eep") else {"age": 0.02, "feh": 0.02, "distance": 3.0, "AV": 0.01}[nm.split("_")[0]] for nm in names])
+    desc = mod.tree_desc()
+
+    def fn(blk, pars):
+        return orc.tree_lnpost(oic, desc, np.ascontiguousarray(pars.T), nthreads=8)[0]
+    p0 = None
+    for _ in range(20):
+        x = c + w * rng.standard_normal((8 * W, c.size))
+        i = 0
+        for s in mod.obs.systems:
+            k = mod.obs.Nstars[s]
+            x[:, i:i + k] = -np.sort(-x[:, i:i + k], axis=1)
+            i += 4 + k
+        good = np.flatnonzero(np.isfinite(fn(None, x)))
+        if good.size >= W:
+            p0 = x[good[:W]]
+            break
+    assert p0 is not None, what + ": no start points"
+    check_sampler(mod, oic, p0, W, steps, seed, what, fn=fn)
+
+
 @pytest.mark.parametrize("nb", list(range(1, 13)))
 def test_tree_families(nb):
     tid = "tree-%d" % nb
@@ -434,6 +465,9 @@ def test_tree_families(nb):
                 check_tree(mod, oic, rng, "%s leaves=%d" % (tid, leaves))
             nl = leaves if (leaves <= 4 and nb <= 8) else 0
             expect(t.names, "k_lnpost_tree_fast<%d, %d>" % (nb, nl), tid)
+            with traced(tid) as t:
+                check_tree_sampler(mod, oic, rng, "%s leaves=%d sampler" % (tid, leaves), seed=300 + 10 * nb + leaves)
+            expect(t.names, "k_stretch_tree<%d, %d>" % (nb, nl), tid)
     if nb == 3:       # the generic tree kernel (any shape; here by request)
         with env(ISOCHRONES_AMD_PATH="generic"):
             ic2, _, _ = make_ic("iso", ia.grids.KNOWN_BANDS[:nb])
@@ -443,6 +477,58 @@ def test_tree_families(nb):
             expect(t.names, "k_lnpost_tree", tid)
             ic2.release()
     ic.release()
+    RAN.add(tid)
+
+
+# ---- IsoTrackModel: both grids inside one persistent sampler kernel -------------------------------------------------------
+@pytest.mark.parametrize("nb", list(range(13)))
+def test_isotrack_family(nb):
+    """k_stretch_isotrack<NB>: reference starmodel.py:2010-2104 composed from the oracle's two evaluations."""
+    import math
+    tid = "isotrack-%d" % nb
+    rng = np.random.default_rng(15000 + nb)
+    bands = ia.grids.KNOWN_BANDS[:nb]
+    with env(ISOCHRONES_AMD_PATH="auto"):
+        iso, _, _ = make_ic("iso", bands)
+        track, _, _ = make_ic("track", bands)
+        truth = np.array([355.0, 1.0, 9.6, 0.0, 300.0, 0.1])           # (eep, mass, age, feh, distance, AV)
+        obs = dict(Teff=(5700.0, 150.0), feh=(0.0, 0.15), parallax=(1000.0 / truth[4], 0.05))
+        if nb:
+            mags = track.interp_mag([truth[1], truth[0], truth[3], truth[4], truth[5]], list(bands))[3]
+            for j, b in enumerate(bands):
+                obs[b] = (float(mags[j]), 0.05)
+        mod = ia.IsoTrackModel(iso, track, **obs)
+        oi, ot = fx.make_oracle_ic(iso), fx.make_oracle_ic(track)
+        di, dt = mod._iso_model.model_desc(), mod._track_model.model_desc()
+        lo, hi, lnorm = mod.age_prior_constants()
+
+        def fn(blk, p):
+            iso_p = np.column_stack([p[:, 0], p[:, 2], p[:, 3], p[:, 4], p[:, 5]])
+            trk_p = np.column_stack([p[:, 1], p[:, 0], p[:, 3], p[:, 4], p[:, 5]])
+            t = ot.lnpost(dt, trk_p.T.copy(), nthreads=8)
+            i = oi.lnpost(di, iso_p.T.copy(), nthreads=8)
+            age = p[:, 2]
+            with np.errstate(all="ignore"):
+                ln_age = np.where((age < lo) | (age > hi), -np.inf, lnorm + age * math.log(10))
+                prior = t[1] + ln_age
+                return np.where(np.isfinite(prior), prior + (i[2] + t[2]), -np.inf)
+        W, p0 = 16, None
+        for _ in range(20):
+            x = truth + np.array([2.0, 0.01, 0.02, 0.01, 2.0, 0.01]) * rng.standard_normal((8 * W, 6))
+            x[:, 5] = np.abs(x[:, 5])
+            good = np.flatnonzero(np.isfinite(fn(None, x)))
+            if good.size >= W:
+                p0 = x[good[:W]]
+                break
+        assert p0 is not None, tid + ": no start points"
+        # the batch composition (two fused launches + framework ops) agrees with the oracle's ...
+        fx.assert_close(mod.lnpost(p0), fn(None, p0), RTOL, atol=1e-8, what=tid + " batch")
+        # ... and so does every move of the resident sampler
+        with traced(tid) as t:
+            check_sampler(mod, None, p0, W, 10, 15100 + nb, tid + " sampler", fn=fn)
+        expect(t.names, "k_stretch_isotrack<%d>" % nb, tid)
+    iso.release()
+    track.release()
     RAN.add(tid)
 
 
@@ -563,7 +649,7 @@ def test_every_compiled_kernel_was_launched_and_checked():
     and catalog set-up kernels have no check of their own: every result above was computed from tables they laid out.)"""
     expected_tests = ({"fused-%s%d-%d" % (k, n, b) for k, n in SHAPES for b in range(13)} | {"wide-%s%d" % s for s in SHAPES}
                       | {"generic-%s%d-%d" % (k, n, b) for k, n in SHAPES for b in range(10)} | {"tree-%d" % b for b in range(1, 13)}
-                      | {"interp", "misc"})
+                      | {"isotrack-%d" % b for b in range(13)} | {"interp", "misc"})
     if RAN != expected_tests:
         pytest.skip("only part of this file ran (%d of %d enumeration tests): the closure check needs all of them"
                     % (len(RAN), len(expected_tests)))

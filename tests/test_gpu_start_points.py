@@ -63,7 +63,10 @@ def host_candidates(desc, kind, ns, star, chunk, seed):
     return p
 
 
-@pytest.mark.parametrize("kind,ns,nb,W", [("track", 1, 3, 32), ("iso", 1, 1, 16), ("iso", 2, 6, 32), ("iso", 3, 9, 64), ("track", 1, 12, 8)])
+@pytest.mark.parametrize("kind,ns,nb,W", [("track", 1, 3, 32), ("iso", 1, 1, 16), ("iso", 2, 6, 32), ("iso", 3, 9, 64), ("track", 1, 12, 8),
+                                          # more walkers than a workgroup has lanes (the reference's default is 300, starmodel.py:889);
+                                          # 600 x 7 parameters: records beyond the 64 KB of LDS a launch gets without asking
+                                          ("iso", 1, 3, 300), ("track", 1, 3, 300), ("iso", 3, 2, 600)])
 def test_start_points_are_the_best_of_the_kernels_candidate_stream(kind, ns, nb, W):
     bands = list(ia.grids.KNOWN_BANDS[:nb])
     ic = small_ic(kind, bands)

@@ -380,3 +380,25 @@ def test_checkpoint_digest_covers_the_interpolator_and_flags_unstable_settings(t
     assert _shard_fingerprint(cat, mine, 1, k, TrackIC()) == _shard_fingerprint(cat, mine, 1, dict(model_kwargs=dict(w=np.arange(3.0))), TrackIC())
     with pytest.warns(RuntimeWarning, match="no stable representation"):
         _shard_fingerprint(cat, mine, 1, dict(callback=object()), TrackIC())
+    # where the MIST caches are mounted is not part of the digest (the tables' content hash is), real-vs-synthetic is
+    TrackIC.data_source = "/data/one/mist/tracks/full_grid_v1.2_vvcrit0.4.npz"
+    b = _shard_fingerprint(cat, mine, 1, dict(nwalkers=32), TrackIC())
+    TrackIC.data_source = "/mnt/elsewhere/full_grid_v1.2_vvcrit0.4.npz"
+    assert b == _shard_fingerprint(cat, mine, 1, dict(nwalkers=32), TrackIC())
+    TrackIC.data_source = "synthetic"
+    assert b != _shard_fingerprint(cat, mine, 1, dict(nwalkers=32), TrackIC())
+
+
+def test_checkpoint_digest_follows_the_start_point_method(monkeypatch):
+    """the start-point kernel and the framework version draw different random numbers: a shard fitted with one is not the
+    shard of the other"""
+    import pandas as pd
+    from isochrones_amd.catalog import _shard_fingerprint
+    df = pd.DataFrame({"V_mag": np.linspace(8, 12, 5), "V_mag_unc": 0.02}, index=["s%d" % i for i in range(5)])
+    cat = ia.StarCatalog(df, bands=["V"])
+    monkeypatch.delenv("ISOCHRONES_AMD_START", raising=False)
+    a = _shard_fingerprint(cat, np.arange(5), 1, dict(nwalkers=32), None_IC())
+    monkeypatch.setenv("ISOCHRONES_AMD_START", "kernel")
+    assert a == _shard_fingerprint(cat, np.arange(5), 1, dict(nwalkers=32), None_IC())
+    monkeypatch.setenv("ISOCHRONES_AMD_START", "torch")
+    assert a != _shard_fingerprint(cat, np.arange(5), 1, dict(nwalkers=32), None_IC())
