@@ -297,7 +297,8 @@ def cpu_catalog_baseline(ic, cat, stars, nwalkers, nburn, niter, seed=5):
         hi = np.array([desc.bound_hi[j] for j in range(D)])
         K = 8 * nwalkers
         cand = lo + (hi - lo) * rng.uniform(size=(K, D))
-        cand[:, 0] = np.exp(rng.uniform(np.log(lo[0]), np.log(hi[0]), K))                   # mass: log-uniform
+        if ic.eep_replaces == "age":              # evolution-track parametrisation (mass, eep, feh, distance, AV)
+            cand[:, 0] = np.exp(rng.uniform(np.log(lo[0]), np.log(hi[0]), K))               # mass: log-uniform
         if desc.has_parallax and desc.plx_val > 0:
             d0, rel = 1000.0 / desc.plx_val, min(max(desc.plx_unc / desc.plx_val, 1e-3), 0.3)
             cand[:, 3] = d0 * (1.0 + 4.0 * rel * (2.0 * rng.uniform(size=K) - 1.0))
@@ -322,7 +323,7 @@ def cpu_catalog_baseline(ic, cat, stars, nwalkers, nburn, niter, seed=5):
 
 
 def catalog_leg(ic, rank, world, barrier, dist, reduce_device, sizes=(10_000, 400_000), nwalkers=32, nburn=150, niter=100,
-                cpu_subsample=0):
+                cpu_subsample=0, timed_passes=None):
     """The catalog path (BASELINE configs[4]) as `fit_catalog` runs it: the whole catalog has a fixed size (strong
     scaling), rank r fits the stars scripts/batch_starfit would give task r (NR % P) with the device-resident sampler,
     and ONE all-gather (RCCL on GPUs) hands every rank all result rows.  Wall-clock of the slowest rank, bracketed by
@@ -339,7 +340,8 @@ def catalog_leg(ic, rank, world, barrier, dist, reduce_device, sizes=(10_000, 40
     except Exception as e:           # noqa: BLE001
         err = "%s: %s" % (type(e).__name__, e)
     out = {"rule": "fit_catalog: star i -> rank (i + 1) % P, no collective in the fit, one all-gather of the result rows",
-           "walkers": nwalkers, "steps": nburn + niter, "bands": bands, "world": world,
+           "parametrisation": list(ic.param_names), "walkers": nwalkers, "steps": nburn + niter, "nburn": nburn, "niter": niter,
+           "bands": bands, "world": world,
            "backend": (dist.get_backend() if dist is not None else None)}
     for n_stars in sizes:
         cat, res, tm = None, None, {}
@@ -354,7 +356,7 @@ def catalog_leg(ic, rank, world, barrier, dist, reduce_device, sizes=(10_000, 40
         # around the kernels), so sizes up to 20 000 stars take five timed passes and report the median one (all walls listed)
         first = None
         passes = []
-        n_timed = 5 if n_stars <= 20000 else 1
+        n_timed = timed_passes or (5 if n_stars <= 20000 else 1)
         for timed in (False,) + (True,) * n_timed:
             barrier()
             t0 = time.perf_counter()
@@ -660,6 +662,33 @@ def main():
                                             cpu_subsample=(64 if (world == 1 and not args.no_cpu_baseline) else 0))
         except Exception as e:       # noqa: BLE001 - the extra leg must not take the benchmark line down
             result["catalog"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        # The same catalog path ON THE REFERENCE'S OWN WORKLOAD: `starfit` builds get_ichrone(models, bands) = MIST_Isochrone,
+        # parameters (eep, age, feh, distance, AV) (isochrones/starfit.py:86, isochrone.py:62-75), and fits with fit_mcmc's
+        # defaults nwalkers=300, nburn=200, niter=100 (starmodel.py:889-893): 9 x 10^4 lnpost evaluations per star, 11 x the
+        # leg above; 30 000 stored samples per parameter (summaries: k_chain_quantiles_big).  Rank 0 builds the isochrone-grid
+        # tables, one broadcast ships them.
+        try:
+            t0 = time.perf_counter()
+            ic_iso = ia.synthetic_isochrone(bands=("G", "BP", "RP")) if rank == 0 else None
+            build_s = time.perf_counter() - t0
+            tb = {}
+            if distributed:
+                ic_iso = ia.broadcast_interpolator(ic_iso, src=0, timings=tb)
+            ref = catalog_leg(ic_iso, rank, world, barrier, dist if distributed else None, reduce_device, sizes=(10_000,),
+                              nwalkers=300, nburn=200, niter=100, timed_passes=3,
+                              cpu_subsample=(12 if (world == 1 and not args.no_cpu_baseline) else 0))
+            ref["table_build_rank0_s"] = build_s
+            ref.update({"broadcast_" + k: v for k, v in tb.items()})
+            ref["workload"] = ("the reference's batch_starfit workload: MIST_Isochrone parametrisation, fit_mcmc defaults "
+                               "300 walkers x (200 burn-in + 100 kept) iterations, 10^4 stars")
+            if isinstance(result.get("catalog"), dict):
+                result["catalog"]["reference_shape"] = ref
+            else:
+                result["catalog_reference_shape"] = ref
+            ic_iso.release()
+            del ic_iso
+        except Exception as e:       # noqa: BLE001
+            (result["catalog"] if isinstance(result.get("catalog"), dict) else result)["reference_shape_error"] = "%s: %s" % (type(e).__name__, e)
     if world == 1 and not args.no_extras:
         ms = C.c_double()
         # secondary sample distributions, same kernel, rotating in the same way (reported, never `value`)

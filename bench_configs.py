@@ -379,6 +379,84 @@ def tree(n=1_000_000, reps=20):
             "parity_max_rel_err": rel, "reference_published_us_per_call": 1230.0}
 
 
+def fits(nwalkers=256, nsteps=5000, ops_steps=100):
+    """cfg 4's fit shape (256 walkers x 5000 iterations) for the model classes that are not a BasicStarModel with at most
+    12 bands: the resolved binary of docs/multiple.ipynb (an observation tree; reference: 1.23 ms per lnpost call, so
+    1 570 s for this fit on its emcee path), IsoTrackModel, a 24-band single star.  Device-resident sampler (one persistent
+    launch: k_stretch_tree / k_stretch_isotrack / k_stretch_wide) against the framework-op sampler (~25 launches per
+    half-step around the batch kernel; timed on `ops_steps` iterations and scaled) and the reference's default fit shape
+    (300 walkers, 200 + 100 iterations)."""
+    import torch
+    import isochrones_amd as ia
+    from isochrones_amd.sampler import EnsembleSampler, FusedEnsembleSampler
+    out = {"config": "fits", "metric": "wall-clock of a %d-walker x %d-step ensemble fit, device-resident sampler" % (nwalkers, nsteps),
+           "walkers": nwalkers, "steps": nsteps}
+
+    def start(mod, centre, width, W, order=None):
+        rng = np.random.default_rng(3)
+        got = []
+        for _ in range(50):
+            x = centre + width * rng.standard_normal((4 * W, len(centre)))
+            x[:, -1] = np.abs(x[:, -1])
+            if order:
+                x[:, :order] = -np.sort(-x[:, :order], axis=1)
+            ok = np.isfinite(mod.lnpost(x))
+            got.extend(x[ok])
+            if len(got) >= W:
+                return np.array(got[:W])
+        raise RuntimeError("no start points")
+
+    def run(name, mod, centre, width, order=None):
+        leg = {"n_params": int(mod.n_params)}
+        p0 = start(mod, centre, width, nwalkers, order)
+        fs = FusedEnsembleSampler(mod, nwalkers, seed=2)
+        fs.run_mcmc(p0, 20, store=False)
+        fs.reset()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        fs.run_mcmc(p0, nsteps, store=True)
+        torch.cuda.synchronize()
+        leg["gpu_wall_s"] = time.perf_counter() - t
+        leg["us_per_step"] = leg["gpu_wall_s"] / nsteps * 1e6
+        leg["acceptance"] = float(fs.acceptance_fraction.mean())
+        leg["finite_chain"] = bool(torch.isfinite(fs._lnprob).all())
+        fs.close()
+        es = EnsembleSampler(nwalkers, mod.n_params, mod.lnpost, seed=2, device=torch.device("cuda"))
+        es.run_mcmc(p0, 5, store=False)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        es.run_mcmc(p0, ops_steps, store=True)
+        torch.cuda.synchronize()
+        leg["framework_op_sampler_wall_s_scaled"] = (time.perf_counter() - t) * nsteps / ops_steps
+        leg["resident_over_framework_ops"] = leg["framework_op_sampler_wall_s_scaled"] / leg["gpu_wall_s"]
+        # the reference's default fit shape through the model's own fit_mcmc (start points included)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        mod.fit_mcmc(nwalkers=300, nburn=200, niter=100, p0=p0[0], seed=4)
+        torch.cuda.synchronize()
+        leg["fit_mcmc_300x300_wall_s"] = time.perf_counter() - t
+        out[name] = leg
+
+    mod, _ = tree_model_and_samples(16)
+    run("tree_resolved_binary", mod, np.array([300.0, 280.0, 9.6, 0.0, 400.0, 0.1]), np.array([3.0, 3.0, 0.02, 0.02, 5.0, 0.01]), order=2)
+    out["tree_resolved_binary"]["reference_published_us_per_call"] = 1230.0
+    out["tree_resolved_binary"]["reference_fit_estimate_s"] = 1230e-6 * nwalkers * nsteps
+    iso = ia.synthetic_isochrone(bands=("G", "BP", "RP"))
+    track = ia.synthetic_track(bands=("G", "BP", "RP"))
+    truth = np.array([355.0, 1.0, 9.6, 0.0, 300.0, 0.1])
+    mags = track.interp_mag([truth[1], truth[0], truth[3], truth[4], truth[5]], ["G", "BP", "RP"])[3]
+    it = ia.IsoTrackModel(iso, track, Teff=(5700.0, 150.0), feh=(0.0, 0.15), parallax=(1000.0 / 300.0, 0.05),
+                          **{b: (float(m), 0.05) for b, m in zip(("G", "BP", "RP"), mags)})
+    run("isotrack", it, truth, np.array([1.0, 0.005, 0.01, 0.01, 2.0, 0.01]))
+    bands24 = tuple(list(ia.grids.KNOWN_BANDS) + ["X%02d" % j for j in range(16)])[:24]
+    ic24 = ia.synthetic_track(bands=bands24)
+    t24 = np.array([1.0, 355.0, 0.0, 300.0, 0.1])
+    m24 = ic24.interp_mag(list(t24), list(bands24))[3]
+    mod24 = ia.SingleStarModel(ic24, Teff=(5700.0, 120.0), parallax=(1000.0 / 300.0, 0.05), **{b: (float(m), 0.03) for b, m in zip(bands24, m24)})
+    run("single_star_24_bands", mod24, t24, np.array([0.01, 1.0, 0.01, 1.0, 0.01]))
+    return out
+
+
 def cfg5(n_stars=10_000, nwalkers=32, nburn=150, niter=100):
     import torch
     import torch.distributed as dist
@@ -435,7 +513,7 @@ def main():
     args = ap.parse_args()
     for name in args.configs.split(","):
         fn = {"cfg1": cfg1, "cfg3": cfg3, "cfg4": cfg4, "cfg5": lambda: cfg5(args.stars),
-              "primitives": primitives, "tree": tree, "nested": nested, "astero": astero, "published": published}[name.strip()]
+              "primitives": primitives, "tree": tree, "fits": fits, "nested": nested, "astero": astero, "published": published}[name.strip()]
         r = fn()
         if r is not None:
             print(json.dumps(r), flush=True)

@@ -433,6 +433,20 @@ def initial_positions(post: CatalogPosterior, nwalkers, rng_seed=0, oversample=8
     plx = torch.as_tensor(post.parallax, **f64)
     plx_e = torch.as_tensor(post.parallax_unc, **f64)
     n_eep = sum(1 for n in names if n.startswith("eep"))
+    # the ranges candidates are drawn from: the stars' bounds cut to the tables (as the kernel does, fast/start_points.h: a
+    # prior without finite bounds would give log(0) / inf maps, and nothing outside the table has a posterior)
+    ic = post.ic
+    max_, may = ic.model_grid.interp.index_columns, ic.bc_grid.interp.index_columns
+    cuts = {"eep": (float(max_[2][0]), float(max_[2][-1])), "distance": (0.0, 1.0e5),
+            "AV": (float(may[3][0]), float(may[3][-1])) if len(post.template.bands) else (0.0, 10.0)}
+    if "mass" in names:          # evolution tracks: table axes (feh, mass, eep)
+        cuts.update(feh=(float(max_[0][0]), float(max_[0][-1])), mass=(float(max_[1][0]), float(max_[1][-1])))
+    else:                        # isochrones: table axes (age, feh, eep)
+        cuts.update(age=(float(max_[0][0]), float(max_[0][-1])), feh=(float(max_[1][0]), float(max_[1][-1])))
+    for j, nm in enumerate(names):
+        c_lo, c_hi = cuts["eep" if nm.startswith("eep") else nm]
+        lo[:, j].clamp_(min=c_lo)
+        hi[:, j].clamp_(max=c_hi)
     K = oversample * W
     # per-star affine maps u -> a + b u of every parameter; mass and a prior-drawn distance are then exponentiated
     a, b = lo.clone(), hi - lo

@@ -36,11 +36,12 @@ inline PersistKernel persist_kernel(const StretchArgs& S)
     PersistKernel k;
     bool dense = S.dense != 0, uni = false, stdp = false;
     if constexpr (ASTERO) {
+        // one form: single model, priors read at run time (the compile-time-prior twin bought 13 % of a half-step and doubled
+        // the asteroseismic instantiations: pruned in round 5, with the step-wise asteroseismic kernels)
         dense = false;
         uni = true;
-        stdp = S.std_priors != 0;
-        k.fn = stdp ? (const void*)k_stretch_persist<KIND, NS, N, false, true, true, true>
-                    : (const void*)k_stretch_persist<KIND, NS, N, false, true, true, false>;
+        stdp = false;
+        k.fn = (const void*)k_stretch_persist<KIND, NS, N, false, true, true, false>;
     } else if (dense) {
         k.fn = (const void*)k_stretch_persist<KIND, NS, N, true, false>;
     } else if (S.multi) {
@@ -104,18 +105,23 @@ inline bool launch_stretch_nb(int nb, const FastArgs& A, const StretchArgs& S, h
         void* args[] = {const_cast<FastArgs*>(&A), const_cast<StretchArgs*>(&S)};
         return hipLaunchKernel(k.fn, gp, b, args, lds_bytes, s) == hipSuccess;
     }
+    // asteroseismic models: persistent form only (iso_sampler_create_model checks that the ensemble fits)
+    if constexpr (ASTERO) {
+        return false;
+    } else {
     const dim3 g((unsigned)((S.n_active + BLOCK - 1) / BLOCK));
     auto sh = [&](int n) { return (size_t)(((A.axes_len + 1) & ~1) + coop_lds_doubles(n)) * sizeof(double); };
     switch (nb) {
 #define ISO_HALF_CASE(N)                                                                              \
     case N:                                                                                           \
-        note_kernel("k_stretch_half<%d, %d, %d, %s>", KIND, NS, N, tf(ASTERO));                       \
-        hipLaunchKernelGGL((k_stretch_half<KIND, NS, N, ASTERO>), g, b, sh(N), s, A, S);              \
+        note_kernel("k_stretch_half<%d, %d, %d, false>", KIND, NS, N);                                \
+        hipLaunchKernelGGL((k_stretch_half<KIND, NS, N, false>), g, b, sh(N), s, A, S);               \
         return true;
         ISO_HALF_CASE(0) ISO_HALF_CASE(1) ISO_HALF_CASE(2) ISO_HALF_CASE(3) ISO_HALF_CASE(4) ISO_HALF_CASE(5) ISO_HALF_CASE(6)
         ISO_HALF_CASE(7) ISO_HALF_CASE(8) ISO_HALF_CASE(9) ISO_HALF_CASE(10) ISO_HALF_CASE(11) ISO_HALF_CASE(12)
 #undef ISO_HALF_CASE
     default: return false;
+    }
     }
 }
 

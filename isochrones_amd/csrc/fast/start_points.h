@@ -26,6 +26,7 @@
 // (a workgroup merges a chunk of BLOCK candidates into the W records kept so far; ensembles of more than BLOCK walkers - the
 // reference's default is 300, starmodel.py:889 - walk their kept records in strides of BLOCK)
 constexpr int START_MAX_W = 1024;
+constexpr double START_MAX_DISTANCE = 1.0e5;     // pc: candidates of a star without a usable parallax are drawn log-uniform below this
 
 struct StartArgs {
     double* best;         // [n_stars][W][NP]
@@ -64,26 +65,56 @@ __global__ __launch_bounds__(BLOCK, start_min_waves(NS, NB)) void k_catalog_star
     const DevModel& M = A.m[star];
     const DevModel& MP = A.shared_priors ? A.m[0] : M;
     __syncthreads();
-    // per-parameter maps u -> a + b u (mass and a prior-drawn distance are exponentiated)
+    // per-parameter maps u -> a + b u (mass and a prior-drawn distance are exponentiated).  The ranges are the star's bounds
+    // CUT TO THE TABLES: a prior without finite bounds (a log-normal mass prior lives on (0, inf)) would otherwise give
+    // log(0) / inf - inf maps, and a candidate outside the table has no posterior anyway.  Distances are drawn below
+    // START_MAX_DISTANCE, extinctions inside the BC table's A_V axis (below 10 mag for a model without bands).
     double a[NP], b[NP];
+    {
+        double lo[NP], hi[NP];
 #pragma unroll
-    for (int q = 0; q < NP; ++q) {
-        a[q] = M.bound_lo[q];
-        b[q] = M.bound_hi[q] - M.bound_lo[q];
+        for (int q = 0; q < NP; ++q) {
+            lo[q] = M.bound_lo[q];
+            hi[q] = M.bound_hi[q];
+        }
+        auto cut = [&](int q, double t_lo, double t_hi) {
+            lo[q] = fmax(lo[q], t_lo);
+            hi[q] = fmin(hi[q], t_hi);
+        };
+        const double ax0_lo = lds[A.m0.off], ax0_hi = lds[A.m0.off + A.m0.n - 1], ax1_lo = lds[A.m1.off], ax1_hi = lds[A.m1.off + A.m1.n - 1];
+        if (KIND == ISO_KIND_TRACK) {            // (mass, eep, feh, ...): table axes (feh, mass, eep)
+            cut(0, ax1_lo, ax1_hi);
+            cut(1, A.e_a0, A.e_last);
+            cut(2, ax0_lo, ax0_hi);
+        } else {                                 // (eep[, eep_1[, eep_2]], age, feh, ...): table axes (age, feh, eep)
+#pragma unroll
+            for (int s = 0; s < NS; ++s) cut(s, A.e_a0, A.e_last);
+            cut(NS, ax0_lo, ax0_hi);
+            cut(NS + 1, ax1_lo, ax1_hi);
+        }
+        cut(NS + 2, 0.0, START_MAX_DISTANCE);
+        if (NB > 0) cut(NS + 3, lds[A.b3.off], lds[A.b3.off + A.b3.n - 1]);
+        else cut(NS + 3, 0.0, 10.0);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            a[q] = lo[q];
+            b[q] = hi[q] - lo[q];
+        }
+        constexpr int QD0 = NS + 2;
+        if (KIND == ISO_KIND_TRACK) {
+            b[0] = log(hi[0] / lo[0]);
+            a[0] = log(lo[0]);
+        }
+        const double plx0 = M.plx_val, d00 = 1000.0 / plx0;
+        const bool use_plx0 = M.has_parallax && plx0 > 0.0 && isfinite(d00);
+        const double dlo = fmax(lo[QD0], 1.0);
+        const double rel = fmin(fmax(sqrt(M.plx_unc2) / plx0, 1e-3), 0.3);
+        a[QD0] = use_plx0 ? d00 * (1.0 - 4.0 * rel) : log(dlo);
+        b[QD0] = use_plx0 ? 8.0 * rel * d00 : log(hi[QD0] / dlo);
     }
     constexpr int QD = NS + 2;
-    if (KIND == ISO_KIND_TRACK) {
-        b[0] = log(M.bound_hi[0] / M.bound_lo[0]);
-        a[0] = log(M.bound_lo[0]);
-    }
     const double plx = M.plx_val, d0 = 1000.0 / plx;
     const bool use_plx = M.has_parallax && plx > 0.0 && isfinite(d0);
-    {
-        const double dlo = fmax(M.bound_lo[QD], 1.0);
-        const double rel = fmin(fmax(sqrt(M.plx_unc2) / plx, 1e-3), 0.3);
-        a[QD] = use_plx ? d0 * (1.0 - 4.0 * rel) : log(dlo);
-        b[QD] = use_plx ? 8.0 * rel * d0 : log(M.bound_hi[QD] / dlo);
-    }
     int nkept = 0, cur = 0;
     for (int chunk = 0; chunk < T.chunks_max; ++chunk) {
         double p[NP];

@@ -1074,6 +1074,10 @@ int iso_model_create(iso_ic* ic, const iso_model_desc* desc, iso_model** out)
     m->d_axes_blob = nullptr;
     m->fast_ok = false;
     m->h_stage = nullptr;
+    m->mbox = m->d_mbox = nullptr;
+    m->mbox_stream = nullptr;
+    m->mbox_count = 0;
+    m->mbox_state = 0;
     m->stage_rows = 0;
     m->stage_seq = 0;
     m->d_pipe = nullptr;
@@ -1144,10 +1148,13 @@ int iso_model_create(iso_ic* ic, const iso_model_desc* desc, iso_model** out)
     return ISO_OK;
 }
 
+void mailbox_stop(iso_model* m, bool release);
+
 void iso_model_destroy(iso_model* m)
 {
     if (!m) return;
     DeviceGuard guard(m->device);
+    mailbox_stop(m, true);            // the resident wave reads the tables below (and hipFree would wait for it anyway)
     if (m->d_model) (void)hipFree(m->d_model);
     if (m->d_bc_hot) (void)hipFree(m->d_bc_hot);
     if (m->d_bcq) (void)hipFree(m->d_bcq);
@@ -1211,36 +1218,35 @@ int iso_model_kernel_path(const iso_model* m)
 
 namespace {
 
-template <int KIND, int NS, bool PARTS>
+template <int KIND, int NS>
 void launch_lnpost_nb(int nb, dim3 g, dim3 b, size_t shmem, hipStream_t s, const PostArgs& A)
 {
     // ISOCHRONES_AMD_GENERIC_RUNTIME_NB=1: the run-time band loop for every band count (A/B of the compile-time band counts)
     static const bool runtime_nb = [] { const char* e = std::getenv("ISOCHRONES_AMD_GENERIC_RUNTIME_NB"); return e && e[0] == '1'; }();
     if (runtime_nb) nb = 0;
     switch (nb) {
-    case 1: note_kernel("k_lnpost<%d, %d, 1, %s>", KIND, NS, tf(PARTS)); hipLaunchKernelGGL((k_lnpost<KIND, NS, 1, PARTS>), g, b, shmem, s, A); break;
-    case 2: note_kernel("k_lnpost<%d, %d, 2, %s>", KIND, NS, tf(PARTS)); hipLaunchKernelGGL((k_lnpost<KIND, NS, 2, PARTS>), g, b, shmem, s, A); break;
-    case 3: note_kernel("k_lnpost<%d, %d, 3, %s>", KIND, NS, tf(PARTS)); hipLaunchKernelGGL((k_lnpost<KIND, NS, 3, PARTS>), g, b, shmem, s, A); break;
-    case 4: note_kernel("k_lnpost<%d, %d, 4, %s>", KIND, NS, tf(PARTS)); hipLaunchKernelGGL((k_lnpost<KIND, NS, 4, PARTS>), g, b, shmem, s, A); break;
-    case 5: note_kernel("k_lnpost<%d, %d, 5, %s>", KIND, NS, tf(PARTS)); hipLaunchKernelGGL((k_lnpost<KIND, NS, 5, PARTS>), g, b, shmem, s, A); break;
-    case 6: note_kernel("k_lnpost<%d, %d, 6, %s>", KIND, NS, tf(PARTS)); hipLaunchKernelGGL((k_lnpost<KIND, NS, 6, PARTS>), g, b, shmem, s, A); break;
-    case 7: note_kernel("k_lnpost<%d, %d, 7, %s>", KIND, NS, tf(PARTS)); hipLaunchKernelGGL((k_lnpost<KIND, NS, 7, PARTS>), g, b, shmem, s, A); break;
-    case 8: note_kernel("k_lnpost<%d, %d, 8, %s>", KIND, NS, tf(PARTS)); hipLaunchKernelGGL((k_lnpost<KIND, NS, 8, PARTS>), g, b, shmem, s, A); break;
-    default: note_kernel("k_lnpost<%d, %d, 0, %s>", KIND, NS, tf(PARTS)); hipLaunchKernelGGL((k_lnpost<KIND, NS, 0, PARTS>), g, b, shmem, s, A); break;
+    case 1: note_kernel("k_lnpost<%d, %d, 1>", KIND, NS); hipLaunchKernelGGL((k_lnpost<KIND, NS, 1>), g, b, shmem, s, A); break;
+    case 2: note_kernel("k_lnpost<%d, %d, 2>", KIND, NS); hipLaunchKernelGGL((k_lnpost<KIND, NS, 2>), g, b, shmem, s, A); break;
+    case 3: note_kernel("k_lnpost<%d, %d, 3>", KIND, NS); hipLaunchKernelGGL((k_lnpost<KIND, NS, 3>), g, b, shmem, s, A); break;
+    case 4: note_kernel("k_lnpost<%d, %d, 4>", KIND, NS); hipLaunchKernelGGL((k_lnpost<KIND, NS, 4>), g, b, shmem, s, A); break;
+    case 5: note_kernel("k_lnpost<%d, %d, 5>", KIND, NS); hipLaunchKernelGGL((k_lnpost<KIND, NS, 5>), g, b, shmem, s, A); break;
+    case 6: note_kernel("k_lnpost<%d, %d, 6>", KIND, NS); hipLaunchKernelGGL((k_lnpost<KIND, NS, 6>), g, b, shmem, s, A); break;
+    case 7: note_kernel("k_lnpost<%d, %d, 7>", KIND, NS); hipLaunchKernelGGL((k_lnpost<KIND, NS, 7>), g, b, shmem, s, A); break;
+    case 8: note_kernel("k_lnpost<%d, %d, 8>", KIND, NS); hipLaunchKernelGGL((k_lnpost<KIND, NS, 8>), g, b, shmem, s, A); break;
+    default: note_kernel("k_lnpost<%d, %d, 0>", KIND, NS); hipLaunchKernelGGL((k_lnpost<KIND, NS, 0>), g, b, shmem, s, A); break;
     }
 }
 
-template <bool PARTS>
 void launch_lnpost(const iso_model* m, dim3 g, dim3 b, size_t shmem, hipStream_t s, const PostArgs& A)
 {
     const int nb = m->desc.n_bands;
     if (m->ic->kind == ISO_KIND_TRACK) {
-        launch_lnpost_nb<ISO_KIND_TRACK, 1, PARTS>(nb, g, b, shmem, s, A);
+        launch_lnpost_nb<ISO_KIND_TRACK, 1>(nb, g, b, shmem, s, A);
     } else {
         switch (m->desc.n_stars) {
-        case 1: launch_lnpost_nb<ISO_KIND_ISO, 1, PARTS>(nb, g, b, shmem, s, A); break;
-        case 2: launch_lnpost_nb<ISO_KIND_ISO, 2, PARTS>(nb, g, b, shmem, s, A); break;
-        default: launch_lnpost_nb<ISO_KIND_ISO, 3, PARTS>(nb, g, b, shmem, s, A); break;
+        case 1: launch_lnpost_nb<ISO_KIND_ISO, 1>(nb, g, b, shmem, s, A); break;
+        case 2: launch_lnpost_nb<ISO_KIND_ISO, 2>(nb, g, b, shmem, s, A); break;
+        default: launch_lnpost_nb<ISO_KIND_ISO, 3>(nb, g, b, shmem, s, A); break;
         }
     }
 }
@@ -1282,8 +1288,7 @@ int enqueue_lnpost(iso_model* m, const double* pars, int64_t stride_n, int64_t s
     A.lnlike = lnlike_out;
     const dim3 g((unsigned)((n + BLOCK - 1) / BLOCK)), b(BLOCK);        // one sample per lane (k_lnpost has no grid-stride loop)
     const size_t shmem = (size_t)m->ic->lds_doubles * sizeof(double);
-    if (lnprior_out || lnlike_out) launch_lnpost<true>(m, g, b, shmem, s, A);
-    else launch_lnpost<false>(m, g, b, shmem, s, A);
+    launch_lnpost(m, g, b, shmem, s, A);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(ISO_ERR_HIP, std::string("iso_lnpost launch: ") + hipGetErrorString(e));
     return ISO_OK;
@@ -1402,6 +1407,134 @@ static int lnpost_host_pipelined(iso_model* m, const double* pars, int64_t n, do
     return ISO_OK;
 }
 
+// ---- the per-point callback through the model's resident mailbox wave (iso_fast_mailbox.hip) --------------------------------
+// ISOCHRONES_AMD_MAILBOX=0 keeps every call on the launch path; ISOCHRONES_AMD_MAILBOX_IDLE_US (default 1000) is how long the
+// wave stays without a request - the longest a device-wide synchronise elsewhere in the process can be held up by it.
+namespace {
+constexpr double WALL_CLOCK_HZ = 1.0e8;          // wall_clock64(): the constant 100 MHz counter
+
+inline unsigned long long mb_load(const volatile unsigned long long* p)
+{
+    return __atomic_load_n(p, __ATOMIC_ACQUIRE);
+}
+
+bool mailbox_enabled()
+{
+    const char* e = std::getenv("ISOCHRONES_AMD_MAILBOX");
+    return !(e && e[0] == '0');
+}
+
+bool mailbox_launch(iso_model* m)
+{
+    double idle_us = 1000.0;
+    if (const char* e = std::getenv("ISOCHRONES_AMD_MAILBOX_IDLE_US")) idle_us = std::max(10.0, std::atof(e));
+    const unsigned long long idle = (unsigned long long)(idle_us * 1e-6 * WALL_CLOCK_HZ);
+    const unsigned long long life = (unsigned long long)(30.0 * WALL_CLOCK_HZ);       // 30 s whatever happens
+    __atomic_store_n(&m->mbox->ctl[1], 0ull, __ATOMIC_RELAXED);
+    __atomic_store_n(&m->mbox->ctl[0], 1ull, __ATOMIC_RELEASE);                    // running (the wave writes 2 when it leaves)
+    if (!launch_mailbox(m->ic->kind, m->desc.n_stars, m->desc.n_bands, m->fast, m->d_mbox, idle, life, m->mbox_stream) ||
+        hipGetLastError() != hipSuccess) {
+        __atomic_store_n(&m->mbox->ctl[0], 2ull, __ATOMIC_RELEASE);
+        return false;
+    }
+    return true;
+}
+
+// lazily: the pinned mailbox, its stream; false = this model has no mailbox (the caller takes the launch path)
+bool mailbox_ready(iso_model* m)
+{
+    if (m->mbox_state < 0) return false;
+    if (m->mbox_state > 0) return true;
+    m->mbox_state = -1;
+    if (!m->fast_ok || !m->fast.hotq || (!m->fast.bcq && m->desc.n_bands > 0) || m->fast.astq || m->desc.n_bands > FAST_NB_MAX) return false;
+    if (hipHostMalloc(reinterpret_cast<void**>(&m->mbox), sizeof(IsoMailbox), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+        (void)hipGetLastError();
+        m->mbox = nullptr;
+        return false;
+    }
+    std::memset(m->mbox, 0, sizeof(IsoMailbox));
+    m->mbox->ctl[0] = 2;                             // no wave yet
+    if (hipHostGetDevicePointer(reinterpret_cast<void**>(&m->d_mbox), m->mbox, 0) != hipSuccess ||
+        hipStreamCreateWithFlags(&m->mbox_stream, hipStreamNonBlocking) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipHostFree(m->mbox);
+        m->mbox = nullptr;
+        return false;
+    }
+    m->mbox_state = 1;
+    return true;
+}
+
+// n <= ISO_MAILBOX_ROWS rows through the resident wave; ISO_OK, or 1 = not served (the caller launches instead)
+int mailbox_call(iso_model* m, const double* pars, int n, double* lnpost_out, double* lnprior_out, double* lnlike_out)
+{
+    IsoMailbox* mb = m->mbox;
+    const int np_ = m->desc.n_stars + 4;
+    const bool parts = lnprior_out || lnlike_out;
+    const unsigned long long seq = (++m->mbox_count << 16) | ((unsigned long long)parts << 8) | (unsigned long long)(n - 1);
+    if (n == 1) {
+        for (int q = 0; q < np_; ++q) {
+            unsigned long long w;
+            std::memcpy(&w, pars + q, 8);
+            __atomic_store_n(&mb->req[1 + q], w, __ATOMIC_RELAXED);
+        }
+    } else {
+        std::memcpy(mb->rows, pars, sizeof(double) * (size_t)n * np_);
+    }
+    __atomic_store_n(&mb->req[0], seq, __ATOMIC_RELEASE);        // the sequence word last
+    if (mb_load(&mb->ctl[0]) != 1 && !mailbox_launch(m)) return 1;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint64_t spins = 1; mb_load(&mb->done[0]) != seq; ++spins) {
+        if ((spins & 255) == 0) {
+            // the wave may have left (idle / lifetime) between our look at the state and its last poll: start another one,
+            // which finds the request waiting.  A wave that neither answers nor leaves within 2 s is a fault.
+            if (mb_load(&mb->ctl[0]) == 2 && mb_load(&mb->done[0]) != seq) {
+                if (!mailbox_launch(m)) return 1;
+            } else if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
+                __atomic_store_n(&mb->ctl[1], 1ull, __ATOMIC_RELEASE);
+                (void)hipStreamSynchronize(m->mbox_stream);
+                m->mbox_state = -1;
+                return 1;
+            }
+        }
+    }
+    if (n == 1) {
+        double r[3];
+        for (int k = 0; k < 3; ++k) {
+            const unsigned long long w = __atomic_load_n(&mb->done[1 + k], __ATOMIC_RELAXED);
+            std::memcpy(&r[k], &w, 8);
+        }
+        if (lnpost_out) *lnpost_out = r[0];
+        if (lnprior_out) *lnprior_out = r[1];
+        if (lnlike_out) *lnlike_out = r[2];
+    } else {
+        if (lnpost_out) std::memcpy(lnpost_out, mb->out, sizeof(double) * n);
+        if (lnprior_out) std::memcpy(lnprior_out, mb->out + ISO_MAILBOX_ROWS, sizeof(double) * n);
+        if (lnlike_out) std::memcpy(lnlike_out, mb->out + 2 * ISO_MAILBOX_ROWS, sizeof(double) * n);
+    }
+    return ISO_OK;
+}
+}  // namespace
+
+// ask the model's resident wave to leave and wait until it has (before its tables go, or before a device-wide synchronise
+// that should not wait for the idle timeout); frees the mailbox when `release`
+void mailbox_stop(iso_model* m, bool release)
+{
+    if (!m->mbox) return;
+    if (mb_load(&m->mbox->ctl[0]) == 1) {
+        __atomic_store_n(&m->mbox->ctl[1], 1ull, __ATOMIC_RELEASE);
+        (void)hipStreamSynchronize(m->mbox_stream);
+    }
+    if (release) {
+        (void)hipStreamSynchronize(m->mbox_stream);
+        (void)hipStreamDestroy(m->mbox_stream);
+        (void)hipHostFree(m->mbox);
+        m->mbox = m->d_mbox = nullptr;
+        m->mbox_stream = nullptr;
+        m->mbox_state = 0;
+    }
+}
+
 int iso_lnpost_host(iso_model* m, const double* pars, int64_t n, double* lnpost_out, double* lnprior_out,
                     double* lnlike_out)
 {
@@ -1412,6 +1545,11 @@ int iso_lnpost_host(iso_model* m, const double* pars, int64_t n, double* lnpost_
     DeviceGuard guard(m->device);
     std::lock_guard<std::mutex> lock(m->host_mu);       // ctypes drops the GIL: two Python threads may call one model
     const int np_ = m->desc.n_stars + 4;
+    // a sampler's per-point callback (one row, or a few): the model's resident mailbox wave - no launch
+    if (n <= ISO_MAILBOX_ROWS && mailbox_enabled() && mailbox_ready(m)) {
+        const int rc = mailbox_call(m, pars, (int)n, lnpost_out, lnprior_out, lnlike_out);
+        if (rc <= 0) return rc;
+    }
     constexpr int64_t CAP = 8192;
     if (n > 4 * CAP) return lnpost_host_pipelined(m, pars, n, lnpost_out, lnprior_out, lnlike_out);
     if (!m->h_stage) {
@@ -2194,6 +2332,16 @@ int iso_sampler_create_model(iso_model* m, int nwalkers, double a, uint64_t seed
     }
     sp->std_priors = default_prior_families(m->desc);
     if (const char* e = std::getenv("ISOCHRONES_AMD_STD_PRIORS")) sp->std_priors = sp->std_priors && std::atoi(e) != 0;   // A/B switch
+    if (m->fast.astq) {
+        // asteroseismic terms: the persistent kernel only (its step-wise twin was pruned - a single model's ensemble fits a
+        // workgroup's LDS up to ~1 000 walkers), priors read at run time
+        sp->std_priors = 0;
+        if (stretch_persist_lds(sp->n_bands, sp->fast.axes_len, sp->W, sp->n_params, nullptr) > 64 * 1024) {
+            delete sp;
+            return fail(ISO_ERR_INVALID, "iso_sampler_create_model: an ensemble of this size does not fit the persistent kernel's LDS, and "
+                                         "models with asteroseismic terms have no step-wise sampler kernel");
+        }
+    }
     *out = sp;
     return ISO_OK;
 }
@@ -2338,6 +2486,7 @@ int iso_sampler_run(iso_sampler* sp, double* pos, double* lnp, int nsteps, doubl
     if (force_dense) mode = "persistent";
     if (mode != "auto" && mode != "persistent" && mode != "stepwise")
         return fail(ISO_ERR_INVALID, "ISOCHRONES_AMD_SAMPLER must be auto, persistent or stepwise");
+    if (sp->fast.astq && mode == "stepwise") mode = "persistent";      // asteroseismic models have the persistent form only
     int group = 1;
     const size_t lds_bytes = stretch_persist_lds(sp->n_bands, sp->fast.axes_len, sp->W, sp->n_params, &group);
     const bool fits = lds_bytes <= 64 * 1024;

@@ -182,6 +182,19 @@ struct AnyStretchArgs {
     double* chain_lnp;    // optional [nsteps][n_ens * W]
 };
 
+// the per-point callback's mailbox (iso_fast_mailbox.hip): pinned host memory, device-mapped, 64-byte lines
+constexpr int ISO_MAILBOX_ROWS = 128;
+struct IsoMailbox {
+    unsigned long long req[8];        // line 0, host -> device: req[0] = sequence word (counter << 16 | parts << 8 | rows - 1),
+                                      //         req[1..7] = the parameters of a one-row request
+    unsigned long long done[8];       // line 1, device -> host: done[0] = sequence word of the last finished request,
+                                      //         done[1..3] = lnpost, lnprior, lnlike of a one-row request
+    unsigned long long ctl[8];        // line 2: ctl[0] = state (0 none, 1 running, 2 exited; the device writes 2),
+                                      //         ctl[1] = quit (host -> device)
+    double rows[ISO_MAILBOX_ROWS * ISO_MAX_PARAMS];     // requests of 2..128 rows, [row][parameter]
+    double out[3 * ISO_MAILBOX_ROWS];                   // their results: lnpost | lnprior | lnlike
+};
+
 // closed-form age prior of an IsoTrackModel (the reference's AgePrior, flat in linear age): lnorm + age ln 10 inside [lo, hi]
 struct IsoTrackAge {
     double lo, hi, lnorm;
@@ -294,6 +307,12 @@ struct iso_model {
     int64_t pipe_rows;
     hipStream_t pipe_stream[2];
     std::mutex host_mu;      // iso_lnpost_host: one caller at a time per model (the staging areas are the model's)
+    // resident mailbox wave of the per-point callback (lazy; guarded by host_mu)
+    iso::IsoMailbox* mbox;   // pinned, device-mapped
+    iso::IsoMailbox* d_mbox; // its device address
+    hipStream_t mbox_stream; // non-blocking: the resident wave must not order itself against the null stream
+    unsigned long long mbox_count;   // requests posted
+    int mbox_state;          // 0 untried, 1 usable, -1 not available for this model (no instantiation / allocation failed)
 };
 
 struct iso_sampler {
@@ -327,6 +346,9 @@ bool launch_interp_mag_fast(int kind, int nb, const FastArgs& A, const MagOut& O
 // defined in iso_fast_tree.hip: observation-tree lnpost on the corner-packed tables (1..12 bands)
 bool launch_tree_fast(int nb, int n_leaves, const FastArgs& A, const DevTree* T, hipStream_t s);
 bool launch_stretch(int kind, int n_stars, int n_bands, const FastArgs& A, const StretchArgs& S, hipStream_t s);
+// defined in iso_fast_mailbox.hip: start a model's resident mailbox wave (false: no instantiation for the shape)
+bool launch_mailbox(int kind, int n_stars, int n_bands, const FastArgs& A, IsoMailbox* d_mb, unsigned long long idle_ticks,
+                    unsigned long long life_ticks, hipStream_t s);
 // defined in iso_fast_stretch_tree.hip / iso_fast_stretch_more.hip: the any-model persistent sampler (one workgroup per
 // ensemble).  `query` non-null: report whether a kernel exists for the shape and its LDS fits a CU, launch nothing.
 bool launch_stretch_tree(int nb, int n_leaves, const FastArgs& A, const DevTree* T, const AnyStretchArgs& S, int* query, hipStream_t s);

@@ -17,9 +17,12 @@ struct PostArgs {
 };
 
 // NB > 0: compile-time band count (register-resident accumulators); NB == 0: runtime loop.
-template <int KIND, int NS, int NB, bool PARTS>
+// (Whether lnprior / lnlike are wanted as well is a run-time flag: as a template axis it doubled the family - 72 kernels -
+// for a fallback kernel whose time goes into its lane-per-sample gathers.)
+template <int KIND, int NS, int NB>
 __global__ __launch_bounds__(BLOCK, 2) void k_lnpost(const PostArgs A)
 {
+    const bool PARTS = A.lnprior != nullptr || A.lnlike != nullptr;
     extern __shared__ double lds[];
     stage_axes<3>(A.g3.ax, lds);
     stage_axes<4>(A.g4.ax, lds);

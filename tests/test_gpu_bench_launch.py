@@ -67,6 +67,39 @@ def test_bench_two_ranks_prints_one_valid_line():
         assert leg["wall_s_all_passes"] == sorted(leg["wall_s_all_passes"])
 
 
+def _check_reference_shape(cat, world):
+    """the catalog leg on the reference's own workload (MIST_Isochrone parametrisation, fit_mcmc's defaults)"""
+    ref = cat["reference_shape"]
+    assert "error" not in ref and ref["parametrisation"] == ["eep", "age", "feh", "distance", "AV"]
+    assert ref["walkers"] == 300 and ref["nburn"] == 200 and ref["niter"] == 100 and ref["world"] == world
+    leg = ref["10000_stars"]
+    assert "error" not in leg, leg
+    assert leg["stars_per_s"] > 0 and leg["ok_fraction"] > 0.99 and leg["rows_gathered_on_rank0"] == 10_000
+    assert leg["lnpost_evals"] == 10_000 * 300 * 300
+    assert leg["build_s"] > 0 and leg["start_s"] > 0 and leg["sample_s"] > leg["start_s"] and leg["summary_s"] > 0
+    assert sum(leg["stars_per_rank_all"]) == 10_000 and max(leg["stars_per_rank_all"]) - min(leg["stars_per_rank_all"]) <= 1
+    return leg
+
+
+def test_bench_eight_ranks_rehearsal_on_one_gpu():
+    """The shape of the driver's scaling run at N = 8, rehearsed on the one GPU of this box (eight contexts on cuda:0,
+    gloo for the collectives): rendezvous, one broadcast of each table set to seven receivers, 1 250 stars per rank in both
+    catalog legs, one JSON line, exit code 0.  (batch_starfit's rule: scripts/batch_starfit:60-62.)"""
+    r = _launch(8, ["--steps", "5", "--warmup", "2", "--n", "200000"])
+    assert r["n_gpus"] == 8 and r["steps"] == 5 and r["scaling"] == "weak" and r["value"] > 0
+    assert abs(r["value"] - 8 * r["config"]["batch"] / (r["ms_per_step"] * 1e-3)) < 1e-6 * r["value"]
+    st = r["startup"]
+    assert st["world"] == 8 and st["tables"] == "broadcast from rank 0"
+    cat = r["catalog"]
+    assert "error" not in cat and cat["world"] == 8
+    for key, n in (("10000_stars", 10_000), ("400000_stars", 400_000)):
+        leg = cat[key]
+        assert "error" not in leg, leg
+        assert leg["stars_per_rank_all"] == [n // 8] * 8 and leg["rows_gathered_on_rank0"] == n and leg["ok_fraction"] > 0.99
+    leg = _check_reference_shape(cat, 8)
+    assert leg["stars_per_rank_all"] == [1250] * 8
+
+
 def test_bench_gpus_2_without_a_launcher_spawns_its_own_ranks():
     """`python bench.py --gpus 2 ...` with no WORLD_SIZE in the environment (how the driver starts the N = 1 run):
     bench.py starts the ranks itself and still prints exactly one line."""
@@ -129,3 +162,6 @@ def test_bench_single_rank_default_line_has_roofline_and_cpu_baseline():
     assert leg["ok_fraction"] > 0.99 and leg["rows_gathered_on_rank0"] == 10_000
     assert leg["cpu_baseline"]["fitted"] >= 60 and leg["cpu_baseline"]["stars_per_s"] > 0
     assert leg["gpu_over_cpu_one_thread"] if "gpu_over_cpu_one_thread" in leg else leg["cpu_baseline"]["gpu_over_cpu_one_thread"] > 10
+    # ... and on the reference's own workload (isochrone parametrisation, 300 walkers x (200 + 100) iterations)
+    ref = _check_reference_shape(r["catalog"], 1)
+    assert ref["cpu_baseline"]["fitted"] >= 10 and ref["cpu_baseline"]["gpu_over_cpu_one_thread"] > 10

@@ -115,7 +115,24 @@ def bounds_of(kind, ns, lo, hi):
     return np.concatenate([[lo[0]] * ns, lo[1:]]), np.concatenate([[hi[0]] * ns, hi[1:]])
 
 
-def make_model(ic, kind, ns, bands, astero=False, custom_prior=False, spec=True):
+def prior_set(which, kind):
+    """Two sets of NON-DEFAULT prior families, between them every family of ln_pdf's run-time switch in every slot
+    (reference priors.py:235-381): the families the fused kernels read at run time when a model does not carry the
+    reference's defaults.  Bounds wide enough for the test's samples."""
+    P = ia.priors
+    if which == "A":
+        d = dict(mass=P.LogNormalPrior(0.0, 0.4), age=P.GaussianPrior(9.6, 0.3, bounds=(8.0, 10.13)), feh=P.FlatPrior((-1.5, 0.4)),
+                 distance=P.GaussianPrior(300.0, 60.0, bounds=(1.0, 2000.0)), AV=P.PowerLawPrior(0.5, (0.0, 1.0)))
+        orig = P.GaussianPrior(7.7, 0.8, bounds=(5.0, 10.13)) if kind == "track" else P.LogNormalPrior(-0.1, 0.5)      # (the synthetic tracks are young)
+    else:
+        d = dict(mass=P.PowerLawPrior(-2.35, (0.1, 10.0)), age=P.FlatLogPrior((8.0, 10.13)), feh=P.GaussianPrior(-0.2, 0.3, bounds=(-1.9, 0.5)),
+                 distance=P.LogNormalPrior(5.7, 0.5), AV=P.GaussianPrior(0.2, 0.1, bounds=(0.0, 1.0)))
+        orig = P.FlatLogPrior((5.0, 10.13)) if kind == "track" else P.PowerLawPrior(-2.35, (0.1, 10.0))
+    direct = {k: v for k, v in d.items() if k != ("age" if kind == "track" else "mass")}      # the other one enters through the EEP term
+    return direct, orig
+
+
+def make_model(ic, kind, ns, bands, astero=False, custom_prior=False, spec=True, priors=None):
     truth = truth_of(kind, ns)
     prim = [truth[0]] + list(truth[ns:]) if kind == "iso" else list(truth)
     obs = {}
@@ -133,6 +150,10 @@ def make_model(ic, kind, ns, bands, astero=False, custom_prior=False, spec=True)
     mod = ia.BasicStarModel(ic, N=ns, **obs)
     if custom_prior:
         mod.set_prior(AV=ia.priors.FlatPrior((0.0, 0.8)))
+    if priors:
+        direct, orig = prior_set(priors, kind)
+        mod.set_prior(**direct)
+        mod._priors["eep"].orig_prior = orig
     return mod
 
 
@@ -288,16 +309,31 @@ def test_fused_families(kind, ns, nb):
                 check_batch(mod, oic, x, "%s astero=%s" % (tid, a))
             expect(t.names, "k_lnpost_fast<%d, %d, %d, false, %s>" % (K, ns, nb, a), tid)
             p0 = start_ball(rng, mod, kind, ns, 16)
-            # step-wise sampler kernel
+            if not astero:
+                # the per-point callback: host rows in, host values out through the model's resident mailbox wave (one row in
+                # the request line, several rows behind it) - the launch path's numbers bit for bit, and the oracle's
+                with env(ISOCHRONES_AMD_MAILBOX=None), traced(tid) as t:
+                    one = mod.lnpost(p0[0])
+                    few = mod.lnpost(x[:100])
+                    pri = mod.lnprior(x[:100])
+                expect(t.names, "k_mailbox_lnpost<%d, %d, %d>" % (K, ns, nb), tid)
+                with env(ISOCHRONES_AMD_MAILBOX="0"):
+                    assert one == mod.lnpost(p0[0])
+                    assert np.array_equal(few, mod.lnpost(x[:100]), equal_nan=True) and np.array_equal(pri, mod.lnprior(x[:100]), equal_nan=True)
+                w3 = oic.lnpost(mod.model_desc(), np.ascontiguousarray(x[:100].T), nthreads=4)
+                fx.assert_close(few, w3[0], RTOL, atol=ATOL, what=tid + " mailbox lnpost")
+                fx.assert_close(pri, w3[1], RTOL, atol=ATOL, what=tid + " mailbox lnprior")
+            # step-wise sampler kernel (asteroseismic models have the persistent form only: asked for step-wise they take it)
             with env(ISOCHRONES_AMD_SAMPLER="stepwise"), traced(tid) as t:
                 check_sampler(mod, oic, p0, 16, 10, 77 + nb, tid + " stepwise")
-            expect(t.names, "k_stretch_half<%d, %d, %d, %s>" % (K, ns, nb, a), tid)
+            expect(t.names, ("k_stretch_persist<%d, %d, %d, false, true, true, false>" if astero else "k_stretch_half<%d, %d, %d, false>") % (K, ns, nb), tid)
             # persistent, single model: default priors as compile-time constants / read at run time
             # (a single binary without asteroseismic terms takes the one-star-per-lane kernel unless told otherwise)
             pair = kind == "iso" and ns == 2 and not astero
             with env(ISOCHRONES_AMD_SAMPLER="persistent", ISOCHRONES_AMD_STAR_LANES="0"), traced(tid) as t:
                 check_sampler(mod, oic, p0, 16, 10, 78 + nb, tid + " persistent std priors")
-            expect(t.names, "k_stretch_persist<%d, %d, %d, false, %s, true, true>" % (K, ns, nb, a), tid)
+            # (asteroseismic models: one persistent form, priors read at run time)
+            expect(t.names, "k_stretch_persist<%d, %d, %d, false, %s, true, %s>" % (K, ns, nb, a, "false" if astero else "true"), tid)
             with env(ISOCHRONES_AMD_SAMPLER="persistent", ISOCHRONES_AMD_STD_PRIORS="0", ISOCHRONES_AMD_STAR_LANES="0"), traced(tid) as t:
                 check_sampler(mod, oic, p0, 16, 10, 79 + nb, tid + " persistent run-time priors")
             expect(t.names, "k_stretch_persist<%d, %d, %d, false, %s, true, false>" % (K, ns, nb, a), tid)
@@ -314,6 +350,36 @@ def test_fused_families(kind, ns, nb):
                 # register-capped form with a single model (many ensembles of one star run it in rounds)
                 with env(ISOCHRONES_AMD_SAMPLER="persistent-dense"), traced(tid) as t:
                     check_sampler(mod, oic, p0, 16, 8, 80 + nb, tid + " persistent dense, one model", n_ensembles=3)
+                expect(t.names, "k_stretch_persist<%d, %d, %d, true, false, false, false>" % (K, ns, nb), tid)
+            del mod
+    # ---- the same table entries with NON-DEFAULT prior families in every slot: the arms of ln_pdf's run-time switch inside
+    # the batch, step-wise, persistent (run-time priors), one-star-per-lane and register-capped kernels (the default-prior
+    # passes above only ever execute the arms of the reference's defaults)
+    which = "A" if nb % 2 == 0 else "B"
+    for astero in (False, True):
+        a = "true" if astero else "false"
+        with env(ISOCHRONES_AMD_PATH="auto", ISOCHRONES_AMD_STD_PRIORS=None):
+            mod = make_model(ic, kind, ns, bands, astero=astero, priors=which)
+            w = "%s astero=%s priors %s" % (tid, a, which)
+            with traced(tid) as t:
+                check_batch(mod, oic, x, w)
+            expect(t.names, "k_lnpost_fast<%d, %d, %d, false, %s>" % (K, ns, nb, a), tid)
+            p0 = start_ball(rng, mod, kind, ns, 16)
+            if not astero:
+                with env(ISOCHRONES_AMD_SAMPLER="stepwise"), traced(tid) as t:
+                    check_sampler(mod, oic, p0, 16, 10, 277 + nb, w + " stepwise")
+                expect(t.names, "k_stretch_half<%d, %d, %d, false>" % (K, ns, nb), tid)
+            # (the library sees that these are not the default families: the run-time form without being asked)
+            with env(ISOCHRONES_AMD_SAMPLER="persistent", ISOCHRONES_AMD_STAR_LANES="0"), traced(tid) as t:
+                check_sampler(mod, oic, p0, 16, 10, 278 + nb, w + " persistent")
+            expect(t.names, "k_stretch_persist<%d, %d, %d, false, %s, true, false>" % (K, ns, nb, a), tid)
+            if kind == "iso" and ns == 2 and not astero:
+                with env(ISOCHRONES_AMD_SAMPLER="persistent", ISOCHRONES_AMD_STAR_LANES=None), traced(tid) as t:
+                    check_sampler(mod, oic, p0, 16, 10, 279 + nb, w + " one star per lane")
+                expect(t.names, "k_stretch_pair<%d, false>" % nb, tid)
+            if not astero:
+                with env(ISOCHRONES_AMD_SAMPLER="persistent-dense"), traced(tid) as t:
+                    check_sampler(mod, oic, p0, 16, 8, 280 + nb, w + " persistent dense", n_ensembles=3)
                 expect(t.names, "k_stretch_persist<%d, %d, %d, true, false, false, false>" % (K, ns, nb), tid)
             del mod
     if nb >= 1:      # catalog (MULTI) forms: per-row star index
@@ -336,6 +402,21 @@ def test_fused_families(kind, ns, nb):
             with env(ISOCHRONES_AMD_SAMPLER="stepwise"), traced(tid) as t:
                 check_catalog_sampler(cat, post, ic, oic, ns, pos, lnp, good, 6, 92 + nb, tid + " catalog stepwise")
             expect(t.names, "k_stretch_half<%d, %d, %d, false>" % (K, ns, nb), tid)
+            post.close()
+            # catalog-wide NON-DEFAULT priors (reference catalog.py:117-124): shared by the stars, read at run time
+            direct, _ = prior_set(which, kind)
+            cat.set_prior(**{k: v for k, v in direct.items() if k != "distance"})       # (the distance prior stays per star)
+            post = __import__("isochrones_amd.catalog", fromlist=["CatalogPosterior"]).CatalogPosterior.from_catalog(cat, ic, N=ns)
+            with traced(tid) as t:
+                pos, lnp, good = check_catalog_batch(cat, post, ic, oic, ns, rng, tid + " catalog batch, priors " + which)
+            expect(t.names, "k_lnpost_fast<%d, %d, %d, true, false>" % (K, ns, nb), tid)
+            expect(t.names, "k_catalog_start<%d, %d, %d>" % (K, ns, nb), tid)
+            with env(ISOCHRONES_AMD_SAMPLER="persistent"), traced(tid) as t:
+                check_catalog_sampler(cat, post, ic, oic, ns, pos, lnp, good, 8, 290 + nb, tid + " catalog persistent, priors " + which)
+            expect(t.names, "k_stretch_persist<%d, %d, %d, false, false, false, false>" % (K, ns, nb), tid)
+            with env(ISOCHRONES_AMD_SAMPLER="persistent-dense"), traced(tid) as t:
+                check_catalog_sampler(cat, post, ic, oic, ns, pos, lnp, good, 8, 291 + nb, tid + " catalog dense, priors " + which)
+            expect(t.names, "k_stretch_persist<%d, %d, %d, true, false, false, false>" % (K, ns, nb), tid)
             post.close()
     ic.release()
     RAN.add(tid)
@@ -364,7 +445,7 @@ def test_band_tiled_family(kind, ns):
 @pytest.mark.parametrize("nb", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
 @pytest.mark.parametrize("kind,ns", SHAPES)
 def test_generic_family(kind, ns, nb):
-    """k_lnpost<KIND, NS, NB, PARTS>: NB 1-8 compile-time, 0 = run-time loop (no band or more than 8)."""
+    """k_lnpost<KIND, NS, NB>: NB 1-8 compile-time, 0 = run-time loop (no band or more than 8)."""
     tid = "generic-%s%d-%d" % (kind, ns, nb)
     rng = np.random.default_rng(9000 + 100 * KIND_ID[kind] + 10 * ns + nb)
     bands = ia.grids.KNOWN_BANDS[:nb]
@@ -378,8 +459,7 @@ def test_generic_family(kind, ns, nb):
         with traced(tid) as t:
             check_batch(mod, oic, x, tid)
     code = nb if 1 <= nb <= 8 else 0
-    expect(t.names, "k_lnpost<%d, %d, %d, false>" % (K, ns, code), tid)
-    expect(t.names, "k_lnpost<%d, %d, %d, true>" % (K, ns, code), tid)
+    expect(t.names, "k_lnpost<%d, %d, %d>" % (K, ns, code), tid)
     ic.release()
     RAN.add(tid)
 
@@ -625,6 +705,7 @@ def test_eep_unit_cube_and_summary_families():
     shapes["k_chain_quantiles_wave<104>"] = (170, 30, None)         # 5 100 values
     shapes["k_chain_quantiles_select"] = (250, 30, "workgroup")
     shapes["k_chain_quantiles"] = (100, 30, "sort")
+    shapes["k_chain_quantiles_big"] = (100, 300, None)              # 30 000 values per pair: the reference's default fit
     for kernel, (steps, Wk, mode) in shapes.items():
         S, D = 40, 5
         host = rng.standard_normal((steps, D, S * Wk)).round(2)                                       # rounded: ties

@@ -28,10 +28,22 @@ def small_ic(kind, bands):
                                   limits=dict(age=(ages[0], ages[-1]), feh=(-2.0, 0.5)))
 
 
-def host_candidates(desc, kind, ns, star, chunk, seed):
+def table_cuts(ic, kind, ns, nb):
+    """[lo, hi] per parameter the kernel cuts a star's bounds to: the tables' axes, 10^5 pc, the BC table's A_V axis."""
+    mx, bx = ic.model_grid.interp.index_columns, ic.bc_grid.interp.index_columns
+    r = lambda ax: (float(ax[0]), float(ax[-1]))
+    av = r(bx[3]) if nb else (0.0, 10.0)
+    if kind == "track":
+        return [r(mx[1]), r(mx[2]), r(mx[0]), (0.0, 1.0e5), av]
+    return [r(mx[2])] * ns + [r(mx[0]), r(mx[1]), (0.0, 1.0e5), av]
+
+
+def host_candidates(desc, kind, ns, star, chunk, seed, cuts=None):
     """The BLOCK candidates lane 0..255 of the workgroup of `star` draw in `chunk` (start_points.h, same arithmetic)."""
     D = ns + 4
     lo = np.array([desc.bound_lo[j] for j in range(D)]); hi = np.array([desc.bound_hi[j] for j in range(D)])
+    if cuts is not None:
+        lo = np.maximum(lo, [c[0] for c in cuts]); hi = np.minimum(hi, [c[1] for c in cuts])
     a, b = lo.copy(), hi - lo
     if kind == "track":
         a[0], b[0] = np.log(lo[0]), np.log(hi[0] / lo[0])
@@ -87,7 +99,7 @@ def test_start_points_are_the_best_of_the_kernels_candidate_stream(kind, ns, nb,
     n_ok = 0
     for k in range(0, S, 3):
         desc = cat.model(k, ic, N=ns).model_desc()
-        cand = np.concatenate([host_candidates(desc, kind, ns, k, c, seed) for c in range(chunks)], axis=0)
+        cand = np.concatenate([host_candidates(desc, kind, ns, k, c, seed, table_cuts(ic, kind, ns, nb)) for c in range(chunks)], axis=0)
         want = oic.lnpost(desc, np.ascontiguousarray(cand.T), nthreads=8, parts=False)
         want = np.where(np.isfinite(want), want, -np.inf)
         order = np.argsort(-want, kind="stable")[:W]

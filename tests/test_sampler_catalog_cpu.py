@@ -402,3 +402,72 @@ def test_checkpoint_digest_follows_the_start_point_method(monkeypatch):
     assert a == _shard_fingerprint(cat, np.arange(5), 1, dict(nwalkers=32), None_IC())
     monkeypatch.setenv("ISOCHRONES_AMD_START", "torch")
     assert a != _shard_fingerprint(cat, np.arange(5), 1, dict(nwalkers=32), None_IC())
+
+
+# ---- eight ranks: the shape of the driver's scaling run (scripts/batch_starfit:60-62) -----------------------------
+def _world8_worker(rank, world, port, n_stars, out_dir):
+    """What one rank of `bench.py --gpus 8` does around its kernels: receive the tables from rank 0, fit its share of a
+    10^4-star catalog (star i -> rank (i + 1) % 8), meet the others in ONE all-gather.  Rank 5's fit fails."""
+    sys.path.insert(0, ROOT)
+    import warnings
+    import pandas as pd
+    import torch.distributed as dist
+    import isochrones_amd as ia_
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ic = None
+    if rank == 0:
+        ic = ia_.synthetic_isochrone(bands=("G", "BP", "RP"), ages=[9.0, 9.5, 10.0], fehs=[-0.5, 0.0, 0.5],
+                                     eeps=np.arange(300., 340.), eep_bounds=(300, 339), limits=dict(age=(9.0, 10.0), feh=(-0.5, 0.5)))
+    ic = ia_.broadcast_interpolator(ic, src=0)
+    df = pd.DataFrame({"G_mag": np.linspace(8, 12, n_stars), "G_mag_unc": 0.02}, index=["s%05d" % i for i in range(n_stars)])
+    cat = ia_.StarCatalog(df, bands=["G"])
+    mine = ia_.shard_indices(n_stars, rank, world)
+    seen = []
+
+    def fit(catalog, ic_, indices, N=1, **kw):
+        seen.extend(int(i) for i in indices)
+        if rank == 5:
+            raise RuntimeError("HIP error on this rank")
+        rows = np.zeros((len(indices), 3 * (N + 4) + 3))
+        rows[:, 0] = np.asarray(indices) * 2.0 + 1.0
+        rows[:, -3] = rank
+        rows[:, -1] = 1.0
+        return rows
+
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        res = ia_.fit_catalog(cat, ic, N=1, fit_fn=fit)
+    assert seen == [int(i) for i in mine]
+    assert any("rank 5" in str(x.message) for x in w)
+    assert res.attrs["timings"]["world"] == world and res.attrs["timings"]["stars_of_this_rank"] == len(mine)
+    if rank in (0, 5, 7):
+        res.to_pickle(os.path.join(out_dir, "res%d.pkl" % rank))
+        np.save(os.path.join(out_dir, "grid%d.npy" % rank), ic.model_grid.interp.grid)
+        with open(os.path.join(out_dir, "err%d.txt" % rank), "w") as f:
+            f.write(repr(sorted(res.attrs["shard_errors"])))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_ranks_broadcast_fit_and_gather_with_uneven_shards_and_one_failing_rank(tmp_path):
+    """World size 8 on gloo: the rank count of the driver's scaling run, a catalog whose size 8 does not divide (10 003
+    stars: five ranks get 1 250, three get 1 251), one rank whose fit raises.  Every rank ends with the same table; the
+    failing rank's stars are NaN / ok = 0, everyone else's arrive; nobody hangs."""
+    import pandas as pd
+    import torch.multiprocessing as mp
+    n = 10_003
+    mp.spawn(_world8_worker, args=(8, _free_port(), n, str(tmp_path)), nprocs=8, join=True)
+    r0, r5, r7 = (pd.read_pickle(tmp_path / ("res%d.pkl" % r)) for r in (0, 5, 7))
+    assert r0.equals(r5) and r0.equals(r7) and len(r0) == n
+    owner = (np.arange(n) + 1) % 8                              # batch_starfit's rule: awk 'NR % NPROCS == TASK', NR = i + 1
+    assert sorted(np.bincount(owner)) == [1250] * 5 + [1251] * 3
+    ok = owner != 5
+    assert np.array_equal(r0["ok"].values, ok.astype(float))
+    assert np.array_equal(r0.iloc[ok, 0].values, np.flatnonzero(ok) * 2.0 + 1.0)
+    assert np.array_equal(r0["lnpost_max"].values[ok], owner[ok].astype(float))
+    assert np.isnan(r0.iloc[~ok, :-1].values).all()
+    for r in (0, 5, 7):
+        assert open(tmp_path / ("err%d.txt" % r)).read() == "[5]"
+        assert np.array_equal(np.load(tmp_path / ("grid%d.npy" % r)), np.load(tmp_path / "grid0.npy"), equal_nan=True)
