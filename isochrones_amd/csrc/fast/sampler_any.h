@@ -80,6 +80,7 @@ __device__ __forceinline__ void persist_any(EV& ev, const AnyStretchArgs& S0, do
                 const bool active = mine && k < h;
                 if (!__any(active)) continue;                 // wave-uniform: idle waves go straight to the barrier
                 const int lr = (half ? h : 0) + (active ? k : h - 1);
+                ISO_STAMP_HERE(0);
                 const int64_t row = r0 + lr;
                 uint32_t rnd[4];
                 asm volatile("" : "+s"(key0), "+s"(key1));    // (sampler.h: round keys as scalar additions)
@@ -98,6 +99,7 @@ __device__ __forceinline__ void persist_any(EV& ev, const AnyStretchArgs& S0, do
                     const double b = xj[q];
                     return fma(z, xk[q] - b, b);
                 };
+                ISO_STAMP_HERE(1);
                 const double lnew = ev(kp, active, par);
                 const double lold = llnp[lr];
                 const double lnq = (NP - 1) * fast_log(z) + lnew - lold;
@@ -114,8 +116,10 @@ __device__ __forceinline__ void persist_any(EV& ev, const AnyStretchArgs& S0, do
                     for (int q = 0; q < NP; ++q) cp[q * S.chain_ps] = mine_row[q];
                 }
                 if (active && S.chain_lnp) S.chain_lnp[(int64_t)it * rows_total + row] = acc ? lnew : lold;
+                ISO_STAMP_HERE(9);
             }
             __syncthreads();
+            ISO_STAMP_HERE(10);
         }
     }
     for (int j = threadIdx.x; j < W * NP; j += BLOCK) S.pos[r0 * NP + j] = lpos[j];

@@ -92,7 +92,9 @@ __device__ __forceinline__ double tree_lnpost(const FastArgs& A, const DevTree& 
             eep_bracket(A, lds, eep, i2, w.t2);
         }
         double v[6];
+        if (l == 0) { ISO_STAMP(2, w.t2); }
         coop_star(A, L, ok3, cell3(A, i0, i1, i2), w, v);
+        if (l == 0) { ISO_STAMP(3, v[0]); }
 #pragma unroll
         for (int q = 0; q < 6; ++q) S.set_star(l, q, v[q]);
         const double Tf = v[0], g = v[1], f = v[2];
@@ -103,8 +105,10 @@ __device__ __forceinline__ double tree_lnpost(const FastArgs& A, const DevTree& 
         w4v.t0 = w4v.t1 = w4v.t2 = w4v.t3 = 0.0;
         if (ok4) lds_bracket4(lds, A.b0, A.b1, A.b2, A.b3, Tf, g, f, AV, j0, j1, j2, j3, w4v.t0, w4v.t1, w4v.t2, w4v.t3);
         double bc[NB];
+        if (l == 0) { ISO_STAMP(4, w4v.t3); }
         coop_bc<NB>(A, L, ok4, cell4(A, j0, j1, j2, j3), w4v, bc);
-        const double dm = 5 * log10(dist / 10.0);
+        if (l == 0) { ISO_STAMP(5, bc[0]); }
+        const double dm = fma(fast_log(dist), 5.0 * kInvLn10, -5.0);      // 5 log10(d / 10), as lnpost_wave takes it
 #pragma unroll
         for (int b = 0; b < NB; ++b) S.set_flux(l, b, exp10(-0.4 * (v[3] + dm - bc[b])));
     };
@@ -114,6 +118,7 @@ __device__ __forceinline__ double tree_lnpost(const FastArgs& A, const DevTree& 
     } else {
         for (int l = 0; l < n_leaves; ++l) leaf(l);
     }
+    ISO_STAMP_HERE(6);                        // every leaf gathered, fluxes formed
     lnp_out = lnl_out = f_nan();
     if (!active) return f_nan();              // no cooperative work below
     // ---- lnprior (starmodel.py:557-613) ----
@@ -151,6 +156,7 @@ __device__ __forceinline__ double tree_lnpost(const FastArgs& A, const DevTree& 
         }
     }
     if (dead) lnp = -f_inf();
+    ISO_STAMP(7, lnp);
     const bool prior_ok = isfinite(lnp);
     // ---- lnlike (observation.py:1181-1234): -inf as soon as the running sum is not finite ----
     double lnl = f_nan();
@@ -166,13 +172,13 @@ __device__ __forceinline__ double tree_lnpost(const FastArgs& A, const DevTree& 
                 mag -= tt.ref_mag;
             }
             const double r = mag - mod;
-            lnl += -0.5 * (r * r) / (tt.unc * tt.unc) + T.term_g0[t];
+            lnl += T.term_g0[t] - (r * r) * T.term_hinv[t];
             if (!isfinite(lnl)) bad = true;
         }
         for (int k = 0; k < T.n_spec && !bad; ++k) {
             const iso_tree_prop& sp = T.spec[k];
             const double r = sp.a - S.prop(sp.leaf, sp.prop);
-            lnl += -0.5 * (r * r) / (sp.b * sp.b) + T.spec_g0[k];
+            lnl += T.spec_g0[k] - (r * r) * T.spec_hinv[k];
             if (!isfinite(lnl)) bad = true;
         }
         for (int k = 0; k < T.n_limits && !bad; ++k) {
@@ -184,17 +190,18 @@ __device__ __forceinline__ double tree_lnpost(const FastArgs& A, const DevTree& 
             for (int s = 0; s < T.n_systems; ++s)
                 if (T.has_plx[s]) {
                     const double r = T.plx_val[s] - 1.0 / par(T.sys_base[s] + T.n_stars[s] + 2) * 1000.0;
-                    lnl += -0.5 * (r * r) / (T.plx_unc[s] * T.plx_unc[s]) + T.plx_g0[s];
+                    lnl += T.plx_g0[s] - (r * r) * T.plx_hinv[s];
                 }
             for (int s = 0; s < T.n_systems; ++s)
                 if (T.has_av[s]) {
                     const double r = T.av_val[s] - par(T.sys_base[s] + T.n_stars[s] + 3);
-                    lnl += -0.5 * (r * r) / (T.av_unc[s] * T.av_unc[s]) + T.av_g0[s];
+                    lnl += T.av_g0[s] - (r * r) * T.av_hinv[s];
                 }
             if (!isfinite(lnl)) bad = true;
         }
         if (bad) lnl = -f_inf();
     }
+    ISO_STAMP(8, lnl);
     lnp_out = lnp;
     lnl_out = lnl;
     return prior_ok ? lnp + lnl : -f_inf();

@@ -115,3 +115,11 @@ bool launch_stretch_tree(int nb, int n_leaves, const FastArgs& A, const DevTree*
 }
 
 }  // namespace iso
+
+#ifdef ISO_PHASE_CLOCK
+// instrumentation build (tools/phase_clock_any.py): the shader-clock stamps of the last half-step workgroup 0 ran
+extern "C" int iso_debug_phase_stamps_tree(unsigned long long* out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(iso::fastk::g_phase_stamps), 16 * sizeof(unsigned long long));
+}
+#endif

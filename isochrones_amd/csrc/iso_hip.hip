@@ -2094,8 +2094,8 @@ int iso_tree_model_create(iso_ic* ic, const iso_tree_desc* d, iso_tree_model** o
         H->plx_val[s] = d->plx_val[s]; H->plx_unc[s] = d->plx_unc[s];
         H->av_val[s] = d->av_val[s]; H->av_unc[s] = d->av_unc[s];
         double u2;
-        gauss_consts(d->plx_unc[s], H->plx_g0[s], u2);
-        gauss_consts(d->av_unc[s], H->av_g0[s], u2);
+        gauss_consts(d->plx_unc[s], H->plx_g0[s], u2, &H->plx_hinv[s]);
+        gauss_consts(d->av_unc[s], H->av_g0[s], u2, &H->av_hinv[s]);
     }
     H->n_params = base;
     m->n_params = base;
@@ -2106,12 +2106,12 @@ int iso_tree_model_create(iso_ic* ic, const iso_tree_desc* d, iso_tree_model** o
     for (int t = 0; t < d->n_terms; ++t) {
         H->terms[t] = d->terms[t];
         double u2;
-        gauss_consts(d->terms[t].unc, H->term_g0[t], u2);
+        gauss_consts(d->terms[t].unc, H->term_g0[t], u2, &H->term_hinv[t]);
     }
     for (int k = 0; k < d->n_spec; ++k) {
         H->spec[k] = d->spec[k];
         double u2;
-        gauss_consts(d->spec[k].b, H->spec_g0[k], u2);
+        gauss_consts(d->spec[k].b, H->spec_g0[k], u2, &H->spec_hinv[k]);
     }
     for (int k = 0; k < d->n_limits; ++k) H->limits[k] = d->limits[k];
     H->prior_mass = make_dev_prior(d->prior_mass);
@@ -2193,9 +2193,16 @@ int iso_tree_lnpost(iso_tree_model* m, const double* pars, int64_t stride_n, int
     A.lnprior = lnprior_out;
     A.lnlike = lnlike_out;
     DeviceGuard guard(m->device);
+    // per-leaf values in LDS behind the staged axes, [slot][lane]: as many lanes per workgroup as fit the CU's 160 KB
+    const size_t axes = (size_t)m->ic->lds_doubles, per_lane = (size_t)m->n_leaves * (6 + (size_t)m->n_bands);
+    int lanes = BLOCK;
+    while (lanes > 64 && (axes + per_lane * lanes) * sizeof(double) > 160 * 1024) lanes >>= 1;
+    const size_t bytes = (axes + per_lane * lanes) * sizeof(double);
+    if (bytes > 160 * 1024) return fail(ISO_ERR_INVALID, "iso_tree_lnpost: the tree's per-star values do not fit a CU's LDS");
+    if (bytes > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_lnpost_tree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     note_kernel("k_lnpost_tree");
-    hipLaunchKernelGGL(k_lnpost_tree, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK),      // one sample per lane
-                       (size_t)m->ic->lds_doubles * sizeof(double), as_stream(stream), A);
+    hipLaunchKernelGGL(k_lnpost_tree, dim3((unsigned)((n + lanes - 1) / lanes)), dim3(lanes),      // one sample per lane
+                       bytes, as_stream(stream), A, (int)axes);
     HIP_TRY(hipGetLastError());
     return ISO_OK;
 }

@@ -130,11 +130,12 @@ struct DevTree {
     int leaf_system[ISO_TREE_MAX_LEAVES], leaf_slot[ISO_TREE_MAX_LEAVES];
     iso_tree_term terms[ISO_TREE_MAX_TERMS];
     double term_g0[ISO_TREE_MAX_TERMS];          // log(1/sqrt(2 pi)) + log(unc)
+    double term_hinv[ISO_TREE_MAX_TERMS];        // 0.5 / unc^2 (the fused tree evaluation multiplies; the generic kernel divides)
     iso_tree_prop spec[ISO_TREE_MAX_SPEC], limits[ISO_TREE_MAX_SPEC];
-    double spec_g0[ISO_TREE_MAX_SPEC];
+    double spec_g0[ISO_TREE_MAX_SPEC], spec_hinv[ISO_TREE_MAX_SPEC];
     int has_plx[ISO_TREE_MAX_SYSTEMS], has_av[ISO_TREE_MAX_SYSTEMS];
-    double plx_val[ISO_TREE_MAX_SYSTEMS], plx_unc[ISO_TREE_MAX_SYSTEMS], plx_g0[ISO_TREE_MAX_SYSTEMS];
-    double av_val[ISO_TREE_MAX_SYSTEMS], av_unc[ISO_TREE_MAX_SYSTEMS], av_g0[ISO_TREE_MAX_SYSTEMS];
+    double plx_val[ISO_TREE_MAX_SYSTEMS], plx_unc[ISO_TREE_MAX_SYSTEMS], plx_g0[ISO_TREE_MAX_SYSTEMS], plx_hinv[ISO_TREE_MAX_SYSTEMS];
+    double av_val[ISO_TREE_MAX_SYSTEMS], av_unc[ISO_TREE_MAX_SYSTEMS], av_g0[ISO_TREE_MAX_SYSTEMS], av_hinv[ISO_TREE_MAX_SYSTEMS];
     DevPrior prior_mass, prior_age, prior_feh, prior_distance, prior_AV;
     double eep_lo, eep_hi;
     double bound_lo[4], bound_hi[4];

@@ -72,7 +72,7 @@ SCRATCH_BUDGET = {
     "k_stretch_persist": 388,        # register-capped catalog form, triples with many bands
     "k_stretch_pair": 200,           # a single binary, one star per lane (uncapped registers)
     "k_lnpost": 96,                  # generic fallback kernel (one sample per lane since round 4: 384 -> 96)
-    "k_lnpost_tree": 1664,           # generic tree kernel (last-resort fallback): per-leaf arrays per lane
+    "k_lnpost_tree": 16,             # generic tree kernel: per-leaf values in LDS since round 5 (1 664 B of per-lane arrays before)
     "k_chain_quantiles_exact": 40,
     "k_stretch_isotrack": 24,        # 10-12 bands
     "k_stretch_tree": 24,            # register-leaf forms: 20 B (five dwords of the evaluator's record, written once)

@@ -33,6 +33,11 @@ def _ncdf(z):
     return 0.5 * math.erfc(-z / math.sqrt(2.0))
 
 
+#: bumped whenever ANY prior object (or a model's EEP prior) is mutated: a model's cached scalar-call state
+#: (starmodel.BasicStarModel._scalar_call) is valid as long as this number has not moved
+EPOCH = [0]
+
+
 class Prior:
     """Common surface: ``bounds``, ``pdf(x)``, ``lnpdf(x)``, ``__call__`` (= pdf), ``desc()``."""
 
@@ -49,6 +54,7 @@ class Prior:
     def bounds(self, new):
         self._bounds = (float(new[0]), float(new[1]))
         self._version += 1
+        EPOCH[0] += 1
         self._rebuild()
 
     def _rebuild(self):

@@ -51,6 +51,16 @@ class EEPPrior:
         self.bounds = tuple(bounds) if bounds is not None else tuple(ic.eep_bounds)
         self.orig_par = ic.eep_replaces
 
+    @property
+    def bounds(self):
+        return self._bounds
+
+    @bounds.setter
+    def bounds(self, new):
+        from . import priors as _p
+        self._bounds = tuple(new)
+        _p.EPOCH[0] += 1
+
     # As in the reference, the EEP term keeps the prior object it was built with: set_prior() on the
     # parameter EEP replaces does not reach it (starmodel.py:1447 + :629-632); assigning this attribute does.
     @property
@@ -62,6 +72,8 @@ class EEPPrior:
         if not isinstance(prior, DEVICE_PRIOR_TYPES):
             raise NotImplementedError("prior %r is not evaluable on the device" % (prior,))
         self._orig_prior = prior
+        from . import priors as _p
+        _p.EPOCH[0] += 1
         for owner in list(self._owners):
             owner._dirty()
 
@@ -490,6 +502,28 @@ class BasicStarModel(_NestedFitMixin, _ConvenienceMixin):
         self._handles = {}
         self._handle_ic = {}
         self._handle_state = {}
+        self._scalar_cache = None
+
+    def _scalar_call(self, p, which):
+        """lnpost / lnprior / lnlike of ONE host row as a float: the per-point callback of emcee / MultiNest
+        (reference starmodel.py:797,952,966).  Everything a call needs besides the numbers - the model handle, a
+        parameter buffer, an output buffer, their addresses, the C entry point - is kept between calls and revalidated
+        by two integer comparisons (no prior object anywhere was mutated since; the interpolator was not rebound), so the
+        wrapper adds about a microsecond to the C call (whose resident mailbox wave answers without a launch)."""
+        from . import priors as _p
+        c = getattr(self, "_scalar_cache", None)
+        if c is None or c[0] != _p.EPOCH[0] or c[1] != self.ic._generation:
+            device = dev.current_device()
+            h = self.handle(device)                      # the full check (prior objects' versions, interpolator)
+            buf, out = np.empty(self.n_params), np.empty(3)
+            c = self._scalar_cache = (_p.EPOCH[0], self.ic._generation, h, buf, out, buf.ctypes.data,
+                                      tuple(out.ctypes.data + 8 * k for k in range(3)), _cabi.lib().iso_lnpost_host)
+        c[3][:] = p                                      # (a row of the wrong length raises here)
+        a = c[6]
+        rc = c[7](c[2], c[5], 1, a[0] if which == 0 else None, a[1] if which == 1 else None, a[2] if which == 2 else None)
+        if rc:
+            _cabi.check(rc)
+        return float(c[4][which])
 
     def handle(self, device=None):
         if device is None:
@@ -500,6 +534,7 @@ class BasicStarModel(_NestedFitMixin, _ConvenienceMixin):
         if h is not None and (self._handle_ic.get(device) != self.ic._generation or self._handle_state.get(device) != state):
             _cabi.lib().iso_model_destroy(h)   # the interpolator was rebound / a shared prior object changed: rebuild
             self._handles.pop(device, None)
+            self._scalar_cache = None
             h = None
         if h is None:
             if -1 in self.ic._prior_cols:
@@ -549,6 +584,9 @@ class BasicStarModel(_NestedFitMixin, _ConvenienceMixin):
         return (post, prior, like) if parts else post
 
     def _evaluate(self, p, which, soa=False):
+        tp = type(p)
+        if (tp is list or tp is tuple or (tp is np.ndarray and p.ndim == 1)) and len(p) == self.n_params:
+            return self._scalar_call(p, which)
         if dev.is_tensor(p) and p.is_cuda:
             import torch
             single = p.dim() == 1

@@ -312,7 +312,8 @@ def test_fused_families(kind, ns, nb):
             if not astero:
                 # the per-point callback: host rows in, host values out through the model's resident mailbox wave (one row in
                 # the request line, several rows behind it) - the launch path's numbers bit for bit, and the oracle's
-                with env(ISOCHRONES_AMD_MAILBOX=None), traced(tid) as t:
+                __import__("time").sleep(0.005)          # a wave started by an earlier small call has left by now (idle 1 ms):
+                with env(ISOCHRONES_AMD_MAILBOX=None), traced(tid) as t:      # this call starts - and names - a new one
                     one = mod.lnpost(p0[0])
                     few = mod.lnpost(x[:100])
                     pri = mod.lnprior(x[:100])
