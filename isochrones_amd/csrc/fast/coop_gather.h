@@ -89,6 +89,66 @@ __device__ __forceinline__ void coop_star(const FastArgs& A, const CoopLds& L, b
     ISO_STAMP_HERE(10);
     // two batches of two iterations: the 12 loads of a batch are in flight before the first use (DEEP: one batch of four)
     constexpr int PER = DEEP ? 4 : 2;
+#if ISO_COOP_STAR3
+    // THREE LANES PER SAMPLE, NO CROSS-LANE SUMS.  Lane q = 0..2 of a quad takes column pair q of all eight corners (the
+    // pieces 12 (c / 4) + 4 q + c % 4 of the same corner-packed cell; lane 3 shadows lane 2 - same addresses, merged by the
+    // texture unit) and forms, per column, exactly what the four lanes of a quad formed between them: the shares
+    // fma(hi_j, whi_j, lo_j * wlo_j), j = 0..3, then (p0 + p1) + (p2 + p3) - the same bits, without the 24 DPP moves and
+    // 12 additions per round of the quad form (95 -> 55 vector instructions per round; 8 loads of 16 B per lane instead
+    // of 6, three quarters of the lanes active).  The weights of an unneeded slot are not zeroed: nobody reads its response.
+    // Rounds per batch (8 loads of 16 B per lane and round in flight before the first use): ISO_COOP_STAR3_PER, or all four (DEEP).
+    const int qcol = j < 2 ? j : 2;
+    // (a kernel that runs work `between` is a lone workgroup's latency form with registers to spare: both rounds of its first
+    // half in flight at once)
+    constexpr int PER3 = DEEP ? 4 : (RUN_BETWEEN ? 2 : ISO_COOP_STAR3_PER);
+    constexpr unsigned long long BATCH_MASK = PER3 == 4 ? ~0ull : ((1ull << (16 * PER3)) - 1ull);
+#pragma unroll
+    for (int half = 0; half < 4 / PER3; ++half) {
+        if (!DEEP && (!RUN_BETWEEN || half != 0) && ((m >> (16 * PER3 * half)) & BATCH_MASK) == 0) continue;          // wave-uniform
+        constexpr int PER = PER3;
+        double2 u[PER][8];
+        double tt[PER][3];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            if ((DEEP || PER > 1) && k > 0 && ((m >> (16 * (PER * half + k))) & 0xFFFFull) == 0) continue;      // wave-uniform: nobody owns these 16 slots
+            const int src = 16 * (PER * half + k) + grp;
+            const double* rq = L.req + src * L.stride;
+            const double hdr = rq[0];
+            const double t0 = rq[1], t1 = rq[2], t2 = rq[3];
+            const bool nd = __double2hiint(hdr) != 0;
+            const uint32_t c = nd ? (uint32_t)__double2loint(hdr) : 0u;      // cell 0 is always readable
+            const double2* __restrict__ pc = reinterpret_cast<const double2*>(A.hotq + (size_t)c * PACK_ENTRY) + 4 * qcol;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) u[k][e] = pc[12 * (e >> 2) + (e & 3)];
+            tt[k][0] = t0;
+            tt[k][1] = t1;
+            tt[k][2] = t2;
+        }
+        if (RUN_BETWEEN && half == 0) between();
+        if (half == 0) { ISO_STAMP(11, tt[PER - 1][0]); ISO_STAMP(12, u[0][0].x); ISO_STAMP(13, u[PER - 1][7].y); }
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            if ((DEEP || PER > 1) && k > 0 && ((m >> (16 * (PER * half + k))) & 0xFFFFull) == 0) continue;
+            const int src = 16 * (PER * half + k) + grp;
+            // (the eight weights are formed here, not next to the loads: 3 instead of 8 values per round kept across the wait)
+            const double t0 = tt[k][0], t1 = tt[k][1], t2 = tt[k][2];
+            const double a0 = 1 - t0, a1 = 1 - t1, a2 = 1 - t2;
+            double px[4], py[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const double g = ((jj & 2) ? t1 : a1) * ((jj & 1) ? t2 : a2);
+                const double wl = a0 * g, wh = t0 * g;
+                px[jj] = corner_pair(u[k][jj].x, wl, u[k][4 + jj].x, wh);
+                py[jj] = corner_pair(u[k][jj].y, wl, u[k][4 + jj].y, wh);
+            }
+            double* rs = L.rsp + src * L.stride + 2 * qcol;
+            if (j < 3) {
+                rs[0] = lane_quad_total(px);
+                rs[1] = lane_quad_total(py);
+            }
+        }
+    }
+#else
 #pragma unroll
     for (int half = 0; half < 4 / PER; ++half) {
         if (!DEEP && (!RUN_BETWEEN || half != 0) && ((m >> (32 * half)) & 0xFFFFFFFFull) == 0) continue;          // wave-uniform
@@ -129,6 +189,7 @@ __device__ __forceinline__ void coop_star(const FastArgs& A, const CoopLds& L, b
             if (j < 2) rs[4 + j] = (j == 0) ? part[4] : part[5];
         }
     }
+#endif
     ISO_STAMP_HERE(14);
     __builtin_amdgcn_wave_barrier();
     const double* rs = L.rsp + L.lane * L.stride;

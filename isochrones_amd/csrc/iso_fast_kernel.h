@@ -103,6 +103,14 @@ static __device__ unsigned long long g_phase_stamps[16];
 #ifndef ISO_MULTI_LANE
 #define ISO_MULTI_LANE 0
 #endif
+// model-table gather of the cooperative form: 1 = three lanes per sample, each summing all eight corners of one column pair
+// (no cross-lane sums); 0 = four lanes per sample with DPP quad sums (coop_gather.h).  Same bits either way.
+#ifndef ISO_COOP_STAR3
+#define ISO_COOP_STAR3 0
+#endif
+#ifndef ISO_COOP_STAR3_PER
+#define ISO_COOP_STAR3_PER 2
+#endif
 // the resident catalog kernel of stars that share the reference's default priors (STDP without UNI): a small catalog is
 // latency-bound like a single star's fit - lane BC gather (one band: lnpost_wave.h) and the table-free priors during the model gather
 #ifndef ISO_MULTI_STD_LANE
