@@ -74,7 +74,8 @@ struct NoWorkBetween {
 // wherever the rounds of a wave serve one star (profiles/r04/coop_deep_batches_ab.jsonl) - the short batches overlap already -
 // but in the one-star-per-lane form the lower rounds are the primaries' and the upper ones the companions': two batches would
 // put the two stars' latencies one behind the other again.
-template <bool RUN_BETWEEN = false, class Between = NoWorkBetween, bool DEEP = false>
+// THREE: three lanes per sample, no cross-lane sums (below) - the form of a lone workgroup (lnpost_wave's LANE bit 3).
+template <bool RUN_BETWEEN = false, class Between = NoWorkBetween, bool DEEP = false, bool THREE = (ISO_COOP_STAR3 != 0)>
 __device__ __forceinline__ void coop_star(const FastArgs& A, const CoopLds& L, bool need, uint32_t cell, const W3& w,
                                           double* __restrict__ v, Between&& between = Between())
 {
@@ -89,13 +90,16 @@ __device__ __forceinline__ void coop_star(const FastArgs& A, const CoopLds& L, b
     ISO_STAMP_HERE(10);
     // two batches of two iterations: the 12 loads of a batch are in flight before the first use (DEEP: one batch of four)
     constexpr int PER = DEEP ? 4 : 2;
-#if ISO_COOP_STAR3
+    if constexpr (THREE) {
     // THREE LANES PER SAMPLE, NO CROSS-LANE SUMS.  Lane q = 0..2 of a quad takes column pair q of all eight corners (the
     // pieces 12 (c / 4) + 4 q + c % 4 of the same corner-packed cell; lane 3 shadows lane 2 - same addresses, merged by the
     // texture unit) and forms, per column, exactly what the four lanes of a quad formed between them: the shares
     // fma(hi_j, whi_j, lo_j * wlo_j), j = 0..3, then (p0 + p1) + (p2 + p3) - the same bits, without the 24 DPP moves and
     // 12 additions per round of the quad form (95 -> 55 vector instructions per round; 8 loads of 16 B per lane instead
     // of 6, three quarters of the lanes active).  The weights of an unneeded slot are not zeroed: nobody reads its response.
+    // Measured (profiles/r05/ab_star3_qbig.jsonl, same bits everywhere): a single star's fit 9.11 -> 8.73 us per step; 10^6-row
+    // batches LOSE (cache-resident 45.8 -> 52 us, binary 106 -> 118 us: a third more load instructions through the texture
+    // unit and four short batches instead of two), catalogs +2-3 %: so this is the lone workgroup's form only.
     // Rounds per batch (8 loads of 16 B per lane and round in flight before the first use): ISO_COOP_STAR3_PER, or all four (DEEP).
     const int qcol = j < 2 ? j : 2;
     // (a kernel that runs work `between` is a lone workgroup's latency form with registers to spare: both rounds of its first
@@ -148,7 +152,7 @@ __device__ __forceinline__ void coop_star(const FastArgs& A, const CoopLds& L, b
             }
         }
     }
-#else
+    } else {
 #pragma unroll
     for (int half = 0; half < 4 / PER; ++half) {
         if (!DEEP && (!RUN_BETWEEN || half != 0) && ((m >> (32 * half)) & 0xFFFFFFFFull) == 0) continue;          // wave-uniform
@@ -189,7 +193,7 @@ __device__ __forceinline__ void coop_star(const FastArgs& A, const CoopLds& L, b
             if (j < 2) rs[4 + j] = (j == 0) ? part[4] : part[5];
         }
     }
-#endif
+    }
     ISO_STAMP_HERE(14);
     __builtin_amdgcn_wave_barrier();
     const double* rs = L.rsp + L.lane * L.stride;

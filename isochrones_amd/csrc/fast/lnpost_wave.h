@@ -16,6 +16,8 @@
 // from the corner-packed table (gather_lane.h) - the latency form of a lone workgroup.
 // bit 2 of LANE: the priors that do not depend on the model table are evaluated between the issue of the primary's
 // model gather and the use of its data (coop_star's `between`).
+// bit 3 of LANE: the cooperative model gather takes three lanes per sample and no cross-lane sums (coop_star's THREE): fewer
+// instructions, more loads - a lone workgroup's trade.
 // bit 4 of LANE (binaries, NS = 2): ONE STAR PER LANE.  The caller has given lanes l and l + 32 of a wave the same sample;
 // lane l walks the primary's chain (EEP bracket, model gather, BC brackets, BC gather), lane l + 32 the companion's, side
 // by side instead of one after the other - a lone wave has nothing else to overlap them with, and a second star then costs
@@ -57,6 +59,7 @@ __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* l
     constexpr int K_MASS = STDP ? ISO_PRIOR_CHABRIER : -1, K_AGE = STDP ? ISO_PRIOR_FLATLOG : -1, K_FEH = STDP ? ISO_PRIOR_FEH : -1,
                   K_DIST = STDP ? ISO_PRIOR_POWERLAW : -1, K_AV = STDP ? ISO_PRIOR_FLAT : -1;
     constexpr bool OVERLAP = (LANE & 4) != 0 && (LANE & 1) == 0;
+    constexpr bool THREE = (LANE & 8) != 0 || ISO_COOP_STAR3 != 0;       // model gather by three lanes per sample (coop_gather.h)
     double ld = 0.0, t_first = 0.0, t_feh = 0.0, t_dist = 0.0, t_av = 0.0;
     auto table_free_priors = [&]() {
         ld = fast_log(dist);
@@ -79,13 +82,11 @@ __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* l
         const uint32_t cell = cell3(A, i0, i1, i2);
         double mine[6];
         // (DEEP: the primaries' rounds and the companions' in one flight)
-        if constexpr (OVERLAP) coop_star<true, decltype(table_free_priors)&, true>(A, L, ok, cell, w, mine, table_free_priors);
-        else coop_star<false, NoWorkBetween, true>(A, L, ok, cell, w, mine);
+        if constexpr (OVERLAP) coop_star<true, decltype(table_free_priors)&, true, THREE>(A, L, ok, cell, w, mine, table_free_priors);
+        else coop_star<false, NoWorkBetween, true, THREE>(A, L, ok, cell, w, mine);
 #pragma unroll
         for (int q = 0; q < 6; ++q) {
-            const double other = __shfl_xor(mine[q], 32);
-            star[0][q] = companion ? other : mine[q];
-            star[1][q] = companion ? mine[q] : other;
+            halves_f64(mine[q], star[0][q], star[1][q]);       // (primary's lane = lower half, companion's = upper)
         }
     }
 #pragma unroll
@@ -99,9 +100,9 @@ __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* l
             ISO_STAMP(2, cell);
             if constexpr (LANE & 1) lane_star(A, ok, cell, w, star[s]);
             else if constexpr (OVERLAP) {
-                if (s == 0) coop_star<true>(A, L, ok, cell, w, star[s], table_free_priors);
-                else coop_star(A, L, ok, cell, w, star[s]);
-            } else coop_star(A, L, ok, cell, w, star[s]);
+                if (s == 0) coop_star<true, decltype(table_free_priors)&, false, THREE>(A, L, ok, cell, w, star[s], table_free_priors);
+                else coop_star<false, NoWorkBetween, false, THREE>(A, L, ok, cell, w, star[s]);
+            } else coop_star<false, NoWorkBetween, false, THREE>(A, L, ok, cell, w, star[s]);
             ISO_STAMP(3, star[s][0]);
             // asteroseismic pair of the primary (reference starmodel.py:1603-1612); a separate instantiation,
             // because even a never-taken branch here costs the common kernel registers (measured: +29 %)
@@ -219,8 +220,8 @@ __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* l
         }
     #pragma unroll
         for (int b = 0; b < NB; ++b) {
-            const double other = __shfl_xor(bcm[b], 32);
-            const double bc0 = companion ? other : bcm[b], bc1 = companion ? bcm[b] : other;
+            double bc0, bc1;
+            halves_f64(bcm[b], bc0, bc1);
             {   // primary (the s == 0 step of the loop below)
                 const double mag = star[0][3] + dm - bc0;
                 const bool far = fabs(mag) > 700.0;

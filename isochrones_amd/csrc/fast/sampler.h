@@ -294,7 +294,18 @@ __device__ __forceinline__ void persist_body(const FastArgs& A, const StretchArg
         const int total = here * h;
         int pw = (((total + 3) >> 2) + 15) & ~15;
         pw = pw < 16 ? 16 : pw;
-        const int a = ((int)threadIdx.x >> 6) * pw + ((int)threadIdx.x & 63);
+        int wv = (int)threadIdx.x >> 6;
+#if ISO_DENSE_PACKED
+        // DENSE is the throughput form (more workgroups than the chip holds at once): there a wave costs its SIMD the same
+        // time whatever its lanes do, so the moves are PACKED into as few waves as they fill (150 moves of a 300-walker
+        // ensemble: 64 + 64 + 22 instead of 48 + 48 + 48 + 6), and which waves those are rotates with the workgroup number,
+        // so that the SIMDs of a CU share the full and the idle waves of the workgroups resident on it.
+        if constexpr (DENSE) {
+            pw = 64;
+            wv = (wv + (int)blockIdx.x) & (BLOCK / 64 - 1);
+        }
+#endif
+        const int a = wv * pw + ((int)threadIdx.x & 63);
         mine = ((int)threadIdx.x & 63) < pw && a < total;
         g = mine ? a / h : 0;
         kk = mine ? a - g * h : 0;

@@ -70,7 +70,8 @@ struct TreeLeaves {
 // `active` = the lane really has a sample.  par(j) = parameter j of the lane's sample: global memory in the batch kernel
 // (L1 / L2 hits), the proposal rebuilt from two LDS rows in the sampler.  `want_like`: evaluate the likelihood even
 // where the prior is not finite (the batch entry point's lnlike output).  An inactive lane's results mean nothing.
-template <int NB, int NL, class Par>
+// LONE: the caller is a lone workgroup (the sampler): model gather by three lanes per sample (coop_star's THREE).
+template <int NB, int NL, bool LONE = false, class Par>
 __device__ __forceinline__ double tree_lnpost(const FastArgs& A, const DevTree& T, const double* lds, const CoopLds& L,
                                               bool active, Par par, TreeLeaves<NB, NL>& S, bool want_like,
                                               double& lnp_out, double& lnl_out)
@@ -93,7 +94,7 @@ __device__ __forceinline__ double tree_lnpost(const FastArgs& A, const DevTree& 
         }
         double v[6];
         if (l == 0) { ISO_STAMP(2, w.t2); }
-        coop_star(A, L, ok3, cell3(A, i0, i1, i2), w, v);
+        coop_star<false, NoWorkBetween, false, LONE || ISO_COOP_STAR3 != 0>(A, L, ok3, cell3(A, i0, i1, i2), w, v);
         if (l == 0) { ISO_STAMP(3, v[0]); }
 #pragma unroll
         for (int q = 0; q < 6; ++q) S.set_star(l, q, v[q]);

@@ -62,6 +62,23 @@ __device__ __forceinline__ double fast_log(double x)
 
 __device__ __forceinline__ double fast_log10(double x) { return fast_log(x) * kInvLn10; }
 
+// ---- the two halves of a wavefront (gfx950: v_permlane32_swap_b32 swaps lanes 32..63 of one register with lanes 0..31
+// of another - one vector instruction per dword where __shfl_xor(x, 32) is two ds_bpermute through the LDS pipeline plus
+// the selects around it) ----
+// lower / upper = the value lane (l & 31) / lane (l & 31) + 32 holds, in every lane
+__device__ __forceinline__ void halves_f64(double x, double& lower, double& upper)
+{
+    const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+    const auto r0 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto r1 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    lower = __hiloint2double((int)r1[0], (int)r0[0]);
+    upper = __hiloint2double((int)r1[1], (int)r0[1]);
+}
+// (Tried on top of it, round 5: logarithms / exponentials of a single star's fit two at a time, the second argument in the idle
+// upper half of the wave.  121 vector instructions fewer per move and 0.4 % - a lone wave is bound by the latency of its
+// dependent instructions, and two independent logarithms already overlap in the pipeline - and the restructured code was no
+// longer bit-identical to the step-wise kernel's under -ffp-contract=fast: taken back.)
+
 // Instrumentation builds only (tools/phase_clock.py: -DISO_PHASE_CLOCK): lane 0 of workgroup 0 stores the shader clock at
 // the phase boundaries of an evaluation; `val` is pinned so that the phase's result exists when the clock is read.
 #ifdef ISO_PHASE_CLOCK
@@ -89,8 +106,9 @@ static __device__ unsigned long long g_phase_stamps[16];
 #define ISO_KERNARG_REREAD 1
 #endif
 // (bit 2: the table-free priors are evaluated while the primary's model cell is on its way)
+// (bit 3: the model gather by three lanes per sample without cross-lane sums - 9.11 -> 8.73 us per step on cfg 4)
 #ifndef ISO_UNI_LANE
-#define ISO_UNI_LANE 6
+#define ISO_UNI_LANE 14
 #endif
 #ifndef ISO_DENSE_LANE
 #define ISO_DENSE_LANE 0
@@ -103,8 +121,14 @@ static __device__ unsigned long long g_phase_stamps[16];
 #ifndef ISO_MULTI_LANE
 #define ISO_MULTI_LANE 0
 #endif
-// model-table gather of the cooperative form: 1 = three lanes per sample, each summing all eight corners of one column pair
-// (no cross-lane sums); 0 = four lanes per sample with DPP quad sums (coop_gather.h).  Same bits either way.
+// register-capped catalog kernel, workgroups that their ensembles do not fill: moves packed into full waves, rotated over the
+// SIMDs (sampler.h); 0 = spread evenly as in the latency forms (A/B switch)
+#ifndef ISO_DENSE_PACKED
+#define ISO_DENSE_PACKED 1
+#endif
+// model-table gather of the cooperative form: 1 = three lanes per sample EVERYWHERE, each summing all eight corners of one
+// column pair (no cross-lane sums); 0 = only where lnpost_wave's LANE bit 3 asks for it, four lanes per sample with DPP quad
+// sums otherwise (coop_gather.h).  Same bits either way.  (A/B switch.)
 #ifndef ISO_COOP_STAR3
 #define ISO_COOP_STAR3 0
 #endif

@@ -40,8 +40,8 @@ struct IsoTrackEval {
         const DevModel& Mt = *(const DevModel*)((const_model_ptr)(uintptr_t)At.m);
         const DevModel& Mi = *(const DevModel*)((const_model_ptr)(uintptr_t)Ai.m);
         double t_prior, t_like, i_prior, i_like;
-        lnpost_wave<ISO_KIND_TRACK, 1, NB>(At, lds_t, L, active, Mt, pt, true, t_prior, t_like);
-        lnpost_wave<ISO_KIND_ISO, 1, NB>(Ai, lds, L, active, Mi, pi, true, i_prior, i_like);
+        lnpost_wave<ISO_KIND_TRACK, 1, NB, false, false, false, false, 8>(At, lds_t, L, active, Mt, pt, true, t_prior, t_like);     // (LANE 8: a lone workgroup's model gather)
+        lnpost_wave<ISO_KIND_ISO, 1, NB, false, false, false, false, 8>(Ai, lds, L, active, Mi, pi, true, i_prior, i_like);
         // the age prior of the reference's AgePrior (flat in linear age): lnorm + age ln 10 inside its bounds; two
         // roundings, as the host-side composition of the batch path takes them (no contraction into an FMA)
         double ln_age = __dadd_rn(P.lnorm, __dmul_rn(age, kLn10));
@@ -78,7 +78,7 @@ struct WideEval {
 #pragma unroll
         for (int q = 0; q < NP; ++q) p[q] = par(q);
         double lnp, lnl;
-        return lnpost_wave<KIND, NS, wide_tile(NS), false, false, true>(A, lds, L, active, M, p, false, lnp, lnl);
+        return lnpost_wave<KIND, NS, wide_tile(NS), false, false, true, false, 8>(A, lds, L, active, M, p, false, lnp, lnl);
     }
 };
 

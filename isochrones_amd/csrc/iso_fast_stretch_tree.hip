@@ -27,7 +27,7 @@ struct TreeEval {
         const DevTree* Tp = kernarg_at<const DevTree*>(kp, ANY_EVAL_ARGS + kernarg_align8(sizeof(FastArgs)));
         const DevTree& T = *(const DevTree*)((const_tree_ptr)(uintptr_t)Tp);
         double lnp, lnl;
-        return tree_lnpost<NB, NL>(A, T, lds, L, active, par, S, false, lnp, lnl);
+        return tree_lnpost<NB, NL, true>(A, T, lds, L, active, par, S, false, lnp, lnl);
     }
 };
 

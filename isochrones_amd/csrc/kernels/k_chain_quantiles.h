@@ -280,16 +280,16 @@ __global__ __launch_bounds__(BLOCK, 2) void k_chain_quantiles_select(const Quant
 //   pass 3   the target bins that hold at most QBIG_CAP values are gathered into LDS lists; rank by counting
 //   refine   a target whose bin holds more (a chain with many repeats of one value, a narrow posterior): the bin's values
 //            are exactly those in [lo, hi] = their own min / max (the binning is monotone), so the same three steps run on
-//            that interval with the whole list area (4 096 values) as capacity - until it fits, or lo == hi (all equal).
+//            that interval with the whole list area (2 048 values) as capacity - until it fits, or lo == hi (all equal).
 // Every pass streams the pair's values from memory (the W values of a step are contiguous in the parameter-major chain);
 // a 30 000-value pair is 240 KB - L2 / Infinity Cache hits after the first pass.  Bit for bit numpy.percentile.
 // -------------------------------------------------------------------------------------------
 constexpr int QBIG_BINS = 4096;
-constexpr int QBIG_CAP = 256;                              // values per gathered list in the common pass
-constexpr int QBIG_POOL = QSEL_RANKS * QBIG_CAP;           // = the single list of a refinement pass (4 096 values)
+constexpr int QBIG_CAP = 128;                              // values per gathered list in the common pass (36 KB of LDS: four workgroups per CU)
+constexpr int QBIG_POOL = QSEL_RANKS * QBIG_CAP;           // = the single list of a refinement pass (2 048 values)
 constexpr size_t QBIG_LDS = (size_t)QBIG_POOL * 8 + QBIG_BINS * 4 + QBIG_BINS + 6 * QSEL_RANKS * 4 + 16 * 8 + 8 * 4 + QSEL_RANKS * 8;
 
-__global__ __launch_bounds__(BLOCK, 2) void k_chain_quantiles_big(const QuantArgs A)
+__global__ __launch_bounds__(BLOCK, 4) void k_chain_quantiles_big(const QuantArgs A)
 {
     extern __shared__ double lds[];
     double* lists = lds;
@@ -316,12 +316,27 @@ __global__ __launch_bounds__(BLOCK, 2) void k_chain_quantiles_big(const QuantArg
         const double v = base[(int64_t)t * A.ss + (int64_t)w * A.rs];
         return (v != v) ? d_inf() : v;
     };
-    // a pass over the pair's values: thread tid starts at (t, w) = (tid / W, tid % W) and advances by BLOCK values
-    const int dt = BLOCK / A.W, dw = BLOCK - dt * A.W;
-#define QBIG_FOR_VALUES(v)                                                                     \
-    for (int i_ = tid, t_ = tid / A.W, w_ = tid - (tid / A.W) * A.W; i_ < m;                  \
-         i_ += BLOCK, t_ += dt, w_ += dw, t_ += (w_ >= A.W) ? 1 : 0, w_ -= (w_ >= A.W) ? A.W : 0) \
-        if (const double v = value(t_, w_); true)
+    // a pass over the pair's values: thread tid takes values tid, tid + BLOCK, ... FOUR AT A TIME - four independent loads in
+    // flight per lane before the first is used (one at a time, a pass was bound by the latency of its single load: 8 waves x
+    // 512 B in flight per CU, 1.9 TB/s over the three passes of a 10^4-star x 300 x 100 catalog).  (step, walker) of value
+    // i: t = i / W by a multiply-high with floor(2^32 / W) and one correction (exact for i < 2^32).
+    const uint32_t w_magic = A.W == 1 ? 0xFFFFFFFFu : (uint32_t)((1ull << 32) / (uint32_t)A.W);     // (2^32 itself does not fit: one short, corrected like any other)
+    auto value_at = [&](int i) {
+        uint32_t t = __umulhi((uint32_t)i, w_magic);
+        uint32_t w = (uint32_t)i - t * (uint32_t)A.W;
+        const bool up = w >= (uint32_t)A.W;
+        t += up ? 1u : 0u;
+        w -= up ? (uint32_t)A.W : 0u;
+        return value((int)t, (int)w);
+    };
+    constexpr int QBIG_UN = 4;
+#define QBIG_FOR_VALUES(v)                                                                                       \
+    for (int i_ = tid; i_ < m; i_ += QBIG_UN * BLOCK)                                                             \
+        if (const double v0_ = value_at(i_), v1_ = value_at(min(i_ + BLOCK, m - 1)),                              \
+            v2_ = value_at(min(i_ + 2 * BLOCK, m - 1)), v3_ = value_at(min(i_ + 3 * BLOCK, m - 1)); true)         \
+            _Pragma("unroll") for (int u_ = 0; u_ < QBIG_UN; ++u_)                                                \
+                if (i_ + u_ * BLOCK < m)                                                                          \
+                if (const double v = (u_ == 0) ? v0_ : (u_ == 1) ? v1_ : (u_ == 2) ? v2_ : v3_; true)
 
     auto block_minmax = [&](double& mn, double& mx) {        // workgroup reduction; every thread gets the result
         for (int off = 32; off > 0; off >>= 1) {

@@ -2,7 +2,7 @@
 """A/B timing of the library's main kernels in one process (pick the library with ISOCHRONES_AMD_LIB):
 cfg 2 / cfg 3 batches (rotating over 8 distinct batches), the cfg 4 sampler, a catalog fit.  One JSON line.
 
-    python tools/ab_kernels.py [--cases cfg2,cfg3,cfg4,cfg5,generic] [--reps 100] [--stars 400000]
+    python tools/ab_kernels.py [--cases cfg2,cfg3,cfg4,cfg5,cfg5ref,generic] [--reps 100] [--stars 400000]
 """
 import argparse
 import json
@@ -88,6 +88,25 @@ def main():
                 walls.append(time.perf_counter() - t)
             out["cfg5/%d" % n_stars] = {"wall_s_min": min(walls), "walls": walls, "breakdown_last": {k: round(v, 4) for k, v in tm.items()},
                                         "rows_digest": float(np.nansum(rows[:, :15]))}
+    if "cfg5ref" in cases:
+        # the reference's batch_starfit workload (bench.py catalog.reference_shape): isochrone parametrisation, 300 x (200 + 100)
+        from isochrones_amd.catalog import fit_stars_gpu
+        bands = ["G", "BP", "RP"]
+        ic = ia.synthetic_isochrone(bands=bands)
+        warm, _ = ia.synthetic_catalog(ic, 64, bands=bands, seed=1, mag_unc=0.01)
+        fit_stars_gpu(warm, ic, np.arange(64), nwalkers=300, nburn=5, niter=5)
+        for n_stars in (1_250, 10_000):
+            cat, _ = ia.synthetic_catalog(ic, n_stars, bands=bands, seed=7, mag_unc=0.01)
+            walls, tm = [], {}
+            for k in range(3):
+                tm = {}
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                rows = fit_stars_gpu(cat, ic, np.arange(n_stars), nwalkers=300, nburn=200, niter=100, seed=11, timings=tm)
+                torch.cuda.synchronize()
+                walls.append(time.perf_counter() - t)
+            out["cfg5ref/%d" % n_stars] = {"wall_s_min": min(walls), "walls": walls, "breakdown_last": {k: round(v, 4) for k, v in tm.items()},
+                                           "rows_digest": float(np.nansum(rows[:, :15]))}
     print(json.dumps(out))
 
 
