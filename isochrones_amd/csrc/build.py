@@ -21,8 +21,13 @@ HEADERS = [os.path.join(HERE, "..", "..", "include", "isochrones_amd.h"),
 # session: cfg 2 / cfg 3 batches, cfg 4 within 0.5 %).
 # -Wno-bitwise-instead-of-logical: the bounds tests of the fused kernels use & and | on purpose (fast/brackets.h: a
 # short-circuit turns every operand into a branch and the LDS reads behind them into a chain).
+# -amdgpu-sched-strategy=max-ilp: the machine scheduler orders for instruction-level parallelism first instead of register
+# pressure first.  The fused evaluation is a handful of independent dependent chains (logarithms, exponentials, brackets of
+# several axes); a lone wave - a single star's fit - is bound by the latency of exactly those chains.  Measured (round 5,
+# profiles/r05/ab_maxilp.jsonl): cfg 4 8.77 -> 8.51 us per step, cfg 2 73.7 -> 73.2 us, bit-identical chains.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math", "-Wall",
-         "-Wno-unused-function", "-Wno-bitwise-instead-of-logical", "-mllvm", "-disable-machine-licm"]
+         "-Wno-unused-function", "-Wno-bitwise-instead-of-logical", "-mllvm", "-disable-machine-licm",
+         "-mllvm", "-amdgpu-sched-strategy=max-ilp"]
 
 
 def sources():

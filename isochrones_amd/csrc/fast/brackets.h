@@ -38,35 +38,10 @@ __device__ __forceinline__ void lds_bracket(const double* lds, const FastAxis ax
     t = (x - a[base]) * a[ax.n + base];
 }
 
-// ISO_BRACKET_SPEC: the last level of the bisection and the reads of the bracket's node and reciprocal spacing in ONE LDS round
-// trip - both candidates' (a, 1 / spacing) pairs are read together with the deciding node and selected afterwards.  The same
-// integer and the same t (index arithmetic: i = min(base or base + 1, n - 2) exactly as the plain form clamps it); four reads
-// per axis instead of three, one dependent LDS latency fewer per bracket set.
-#ifndef ISO_BRACKET_SPEC
-#define ISO_BRACKET_SPEC 0
-#endif
-struct SpecAxis {
-    int lo_i, c_i;
-    double a_lo, a_c, r_lo, r_c;
-};
-__device__ __forceinline__ SpecAxis spec_read(const double* a, int n, int base, int len)
-{
-    SpecAxis s;
-    s.lo_i = min(base, n - 2);
-    s.c_i = min(base + (len >> 1), n - 2);
-    s.a_lo = a[s.lo_i];
-    s.a_c = a[s.c_i];
-    s.r_lo = a[n + s.lo_i];
-    s.r_c = a[n + s.c_i];
-    return s;
-}
-__device__ __forceinline__ void spec_pick(const SpecAxis& s, double x, int& i, double& t)
-{
-    const bool take = s.a_c <= x;
-    i = take ? s.c_i : s.lo_i;
-    t = (x - (take ? s.a_c : s.a_lo)) * (take ? s.r_c : s.r_lo);
-}
-
+// (Round 5, measured and not kept: the last level of the bisection and the reads of the bracket's node and reciprocal spacing
+// in one LDS round trip, both candidates read and selected afterwards - 60 cycles off each bracket phase of a lone
+// workgroup's half-step by the phase stamps, nothing on the clock: cfg 4 8.75 vs 8.78 us per step,
+// profiles/r05/ab_spec_brackets.jsonl.)
 // The same (windowed) bisection for several axes in lock-step: the LDS reads of one level are issued back to back,
 // so a sample pays one LDS latency per level instead of one per level per axis (an axis that has
 // converged re-reads its node, which changes nothing).
@@ -76,22 +51,6 @@ __device__ __forceinline__ void lds_bracket2(const double* lds, const FastAxis a
     const double* a = lds + axa.off;
     const double* b = lds + axb.off;
     int ba = lut_start(lds, axa, xa), bb = lut_start(lds, axb, xb), la = lut_win(axa), lb = lut_win(axb);
-#if ISO_BRACKET_SPEC
-    while ((la > 2) | (lb > 2)) {
-        const int ha = la >> 1, hb = lb >> 1;
-        const double va = a[ba + ha], vb = b[bb + hb];
-        ba = (va <= xa) ? ba + ha : ba;
-        bb = (vb <= xb) ? bb + hb : bb;
-        la -= ha;
-        lb -= hb;
-    }
-    {
-        const SpecAxis sa = spec_read(a, axa.n, ba, la), sb = spec_read(b, axb.n, bb, lb);
-        spec_pick(sa, xa, ia, ta);
-        spec_pick(sb, xb, ib, tb);
-        return;
-    }
-#endif
     while ((la | lb) > 1) {
         const int ha = la >> 1, hb = lb >> 1;
         const double va = a[ba + ha], vb = b[bb + hb];
@@ -119,29 +78,6 @@ __device__ __forceinline__ void lds_bracket4(const double* lds, const FastAxis a
     const double* a3 = lds + ax3.off;
     int b0 = lut_start(lds, ax0, x0), b1 = lut_start(lds, ax1, x1), b2 = lut_start(lds, ax2, x2), b3 = lut_start(lds, ax3, x3);
     int l0 = lut_win(ax0), l1 = lut_win(ax1), l2 = lut_win(ax2), l3 = lut_win(ax3);
-#if ISO_BRACKET_SPEC
-    while ((l0 > 2) | (l1 > 2) | (l2 > 2) | (l3 > 2)) {
-        const int h0 = l0 >> 1, h1 = l1 >> 1, h2 = l2 >> 1, h3 = l3 >> 1;
-        const double v0 = a0[b0 + h0], v1 = a1[b1 + h1], v2 = a2[b2 + h2], v3 = a3[b3 + h3];
-        b0 = (v0 <= x0) ? b0 + h0 : b0;
-        b1 = (v1 <= x1) ? b1 + h1 : b1;
-        b2 = (v2 <= x2) ? b2 + h2 : b2;
-        b3 = (v3 <= x3) ? b3 + h3 : b3;
-        l0 -= h0;
-        l1 -= h1;
-        l2 -= h2;
-        l3 -= h3;
-    }
-    {
-        const SpecAxis s0 = spec_read(a0, ax0.n, b0, l0), s1 = spec_read(a1, ax1.n, b1, l1), s2 = spec_read(a2, ax2.n, b2, l2),
-                       s3 = spec_read(a3, ax3.n, b3, l3);
-        spec_pick(s0, x0, i0, t0);
-        spec_pick(s1, x1, i1, t1);
-        spec_pick(s2, x2, i2, t2);
-        spec_pick(s3, x3, i3, t3);
-        return;
-    }
-#endif
     while ((l0 | l1 | l2 | l3) > 1) {
         const int h0 = l0 >> 1, h1 = l1 >> 1, h2 = l2 >> 1, h3 = l3 >> 1;
         const double v0 = a0[b0 + h0], v1 = a1[b1 + h1], v2 = a2[b2 + h2], v3 = a3[b3 + h3];

@@ -68,7 +68,7 @@ SCRATCH_BUDGET = {
     "k_lnpost_fast": 108,            # per-shape wave caps since round 4 (was 364 at the blanket 4-wave cap)
     "k_lnpost_wide": 20,
     "k_catalog_start": 64,
-    "k_stretch_half": 248,
+    "k_stretch_half": 252,           # (248 before the max-ilp scheduler of round 5: one instantiation, <1, 3, 7>, +4 B; the family is the fall-back of ensembles too large for the persistent kernels)
     "k_stretch_persist": 388,        # register-capped catalog form, triples with many bands
     "k_stretch_pair": 200,           # a single binary, one star per lane (uncapped registers)
     "k_lnpost": 96,                  # generic fallback kernel (one sample per lane since round 4: 384 -> 96)
