@@ -26,8 +26,20 @@ HEADERS = [os.path.join(HERE, "..", "..", "include", "isochrones_amd.h"),
 # several axes); a lone wave - a single star's fit - is bound by the latency of exactly those chains.  Measured (round 5,
 # profiles/r05/ab_maxilp.jsonl): cfg 4 8.77 -> 8.51 us per step, cfg 2 73.7 -> 73.2 us, bit-identical chains.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math", "-Wall",
-         "-Wno-unused-function", "-Wno-bitwise-instead-of-logical", "-mllvm", "-disable-machine-licm",
-         "-mllvm", "-amdgpu-sched-strategy=max-ilp"]
+         "-Wno-unused-function", "-Wno-bitwise-instead-of-logical", "-mllvm", "-disable-machine-licm"]
+# ... for the translation units of the samplers and of the batch kernels whose registers are capped by __launch_bounds__.  A
+# kernel WITHOUT a cap pays for the parallelism in registers: the batch kernels of observation trees went from 87 to 113
+# registers (5 -> 4 waves per SIMD) and 134 -> 149 us per 10^6 rows, so their unit - and the generic / interpolation /
+# summary kernels of iso_hip.hip, which were not measured - keep the default scheduler.
+MAX_ILP_UNITS = {"iso_fast_track1", "iso_fast_iso1", "iso_fast_iso2", "iso_fast_iso3", "iso_fast_ast_track1", "iso_fast_ast_iso1",
+                 "iso_fast_ast_iso2", "iso_fast_ast_iso3", "iso_fast_stretch_more", "iso_fast_stretch_tree", "iso_fast_mailbox"}
+
+
+def unit_flags(src) -> list:
+    """hipcc flags of one translation unit."""
+    tu = os.path.basename(src)
+    tu = tu[:-4] if tu.endswith(".hip") else tu
+    return FLAGS + (["-mllvm", "-amdgpu-sched-strategy=max-ilp"] if tu in MAX_ILP_UNITS else [])
 
 
 def sources():
@@ -77,7 +89,7 @@ def source_digest() -> str:
     the library is."""
     import hashlib
     h = hashlib.sha256()
-    h.update(repr(FLAGS).encode())
+    h.update(repr(FLAGS).encode() + repr(sorted(MAX_ILP_UNITS)).encode())
     for path in sources() + HEADERS + [os.path.abspath(__file__), os.path.join(HERE, "resources.py")]:
         h.update(os.path.basename(path).encode() + b"\0")
         with open(path, "rb") as f:
@@ -187,7 +199,7 @@ def build(force: bool = False, verbose: bool = False, gate: bool = True) -> str:
     for src in sources():
         obj = os.path.join(OBJDIR, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
-        h1 = hashlib.sha256((repr(FLAGS) + compiler_version()).encode())
+        h1 = hashlib.sha256((repr(unit_flags(src)) + compiler_version()).encode())
         for path in include_closure(src):
             with open(path, "rb") as f:
                 h1.update(os.path.relpath(path, HERE).encode() + b"\0" + f.read())
@@ -197,7 +209,7 @@ def build(force: bool = False, verbose: bool = False, gate: bool = True) -> str:
         except OSError:
             have = None
         if force or have != dig or not os.path.exists(obj) or not os.path.exists(obj[:-2] + ".res"):
-            jobs.append((([cc] + FLAGS + ["-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", obj]), obj[:-2] + ".res", dig))
+            jobs.append((([cc] + unit_flags(src) + ["-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", obj]), obj[:-2] + ".res", dig))
 
     def compile_one(job):
         cmd, log, dig = job

@@ -155,6 +155,16 @@ __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* l
         }
     }
     const double dm = fma(ld, 5.0 * kInvLn10, -5.0);   // 5*log10(d/10)
+    // the parallax term needs nothing from the BC table: a lone workgroup's form (LANE bit 2) takes its division before the BC
+    // gather instead of behind it (added to the sum in the same place either way; cfg 4: 8.50 -> 8.44 us per step)
+    constexpr bool PLX_EARLY = (LANE & 4) != 0;
+    double plx_term = 0.0;
+    if constexpr (PLX_EARLY) {
+        if (M.has_parallax) {
+            const double r = M.plx_val - 1000.0 / dist;
+            plx_term = M.plx_g0 - r * r * M.plx_hinv;
+        }
+    }
     if constexpr (TILED) {
         static_assert(NB > 0, "a band tile has at least one band");
         const int nbt = A.nb_total;
@@ -303,8 +313,12 @@ __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* l
         }
     }
     if (M.has_parallax) {
-        const double r = M.plx_val - 1000.0 / dist;
-        lnl += M.plx_g0 - r * r * M.plx_hinv;
+        if constexpr (PLX_EARLY) {
+            lnl += plx_term;
+        } else {
+            const double r = M.plx_val - 1000.0 / dist;
+            lnl += M.plx_g0 - r * r * M.plx_hinv;
+        }
     }
     if (ASTERO && M.has_numax) {
         const double r = M.numax_val - astero[0];

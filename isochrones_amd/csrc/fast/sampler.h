@@ -42,6 +42,11 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 // SHAREDP: the priors the stars of the launch share are read from the first block through the constant address space
 // (scalar loads, scalar branches on their families) - the register-capped catalog kernel, which the host only picks
 // for launches whose stars do share them.
+// (Round 5, measured and taken back: the random numbers of the wave's NEXT move - and the logarithms of z and u2 - drawn
+// while the current move's BC gather is in flight, carried in registers to the next half-step.  Bit-identical chains, and
+// 2.7 % SLOWER on cfg 4 (8.44 -> 8.67 us per step, profiles/r05/ab_rng_ahead.jsonl): the wait it was meant to fill is
+// shorter than ten rounds of Philox, and nine more live registers across the evaluation cost more than the start of a
+// half-step gains.)
 template <int KIND, int NS, int NB, bool ASTERO, bool UNI = false, bool STDP = false, int LANE = 0, bool SHAREDP = false>
 __device__ __forceinline__ void stretch_move(const FastArgs& A, const StretchArgs& S, double* lds, const CoopLds& L,
                                              bool active, bool owner, int64_t star, int k, int half, uint32_t step,

@@ -47,7 +47,7 @@ def main():
             continue
         obj = os.path.join(objdir, tu + ".o")
         objs.append(obj)
-        jobs.append(([cc] + B.FLAGS + ["-Rpass-analysis=kernel-resource-usage"] + extra + ["-c", src, "-o", obj], obj[:-2] + ".res"))
+        jobs.append(([cc] + B.unit_flags(src) + ["-Rpass-analysis=kernel-resource-usage"] + extra + ["-c", src, "-o", obj], obj[:-2] + ".res"))
 
     def run(job):
         cmd, log = job
