@@ -17,6 +17,7 @@ struct TreeLeaves {
     static constexpr int PER = 6 + NB;
     double star_[ML][6];
     double flux_[ML][NB];
+    double mag_[ML][NB];   // register form only: the magnitude each flux was formed from (single-leaf nodes, addmags)
     double* lds_;          // NL = 0: this lane's column of the [slot][lane] block
     int stride_;           // lanes per workgroup
 
@@ -25,10 +26,16 @@ struct TreeLeaves {
         if constexpr (STATIC) star_[l][q] = v;
         else lds_[(l * PER + q) * stride_] = v;
     }
-    __device__ __forceinline__ void set_flux(int l, int b, double v)
+    // flux of leaf l in band b = 10^(-0.4 mag)
+    __device__ __forceinline__ void set_flux(int l, int b, double mag)
     {
-        if constexpr (STATIC) flux_[l][b] = v;
-        else lds_[(l * PER + 6 + b) * stride_] = v;
+        const double v = exp10(-0.4 * mag);
+        if constexpr (STATIC) {
+            flux_[l][b] = v;
+            mag_[l][b] = mag;
+        } else {
+            lds_[(l * PER + 6 + b) * stride_] = v;
+        }
     }
     __device__ __forceinline__ double star(int l, int q) const
     {
@@ -40,6 +47,17 @@ struct TreeLeaves {
     {
         double tot = 0.0;
         if constexpr (STATIC) {
+            // A node above ONE model star (the resolved components of docs/multiple.ipynb; mask is wave-uniform): the reference
+            // still goes through addmags, -2.5 log10(10^(-0.4 m)) = m to an ulp while 10^(-0.4 m) stays inside the doubles
+            // (|m| < 700, as in lnpost_wave's flux sum) - the logarithm is left out there and only there.
+            if ((mask & (mask - 1u)) == 0u && mask != 0u) {
+                double m = 0.0;
+#pragma unroll
+                for (int l = 0; l < NL; ++l)
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) m = (((mask >> l) & 1u) && b == band) ? mag_[l][b] : m;
+                if (!__ballot(fabs(m) > 700.0)) return m;
+            }
 #pragma unroll
             for (int l = 0; l < NL; ++l)
 #pragma unroll
@@ -111,7 +129,7 @@ __device__ __forceinline__ double tree_lnpost(const FastArgs& A, const DevTree& 
         if (l == 0) { ISO_STAMP(5, bc[0]); }
         const double dm = fma(fast_log(dist), 5.0 * kInvLn10, -5.0);      // 5 log10(d / 10), as lnpost_wave takes it
 #pragma unroll
-        for (int b = 0; b < NB; ++b) S.set_flux(l, b, exp10(-0.4 * (v[3] + dm - bc[b])));
+        for (int b = 0; b < NB; ++b) S.set_flux(l, b, v[3] + dm - bc[b]);
     };
     if constexpr (NL > 0) {
 #pragma unroll
@@ -125,6 +143,46 @@ __device__ __forceinline__ double tree_lnpost(const FastArgs& A, const DevTree& 
     // ---- lnprior (starmodel.py:557-613) ----
     double lnp = 0.0;
     bool dead = false;
+    if (T.std_priors) {
+        // The reference's default families (the host checks the records: DevTree.std_priors) as compile-time constants and
+        // WITHOUT the reference's early exits.  A sum that has left the finite numbers never comes back (adding anything to
+        // +-inf or NaN gives +-inf or NaN), so "dead at some point" = "a bound or order test failed, or the sum is not finite
+        // at one of the reference's check points": the same -inf for the same samples, the same additions in the same order
+        // for the others.  Straight-line selects instead of a switch per prior on a family that first has to arrive from
+        // memory: resolved-binary fit 31.0 -> 25.9 us per step (profiles/r05/tree_tail_ab.txt).
+        for (int s = 0; s < T.n_systems; ++s) {
+            const int base = T.sys_base[s], N = T.n_stars[s];
+            const double v_age = par(base + N), v_feh = par(base + N + 1), v_dist = par(base + N + 2), v_av = par(base + N + 3);
+            dead |= bool((v_age < T.bound_lo[0]) | (v_age > T.bound_hi[0]) | (v_feh < T.bound_lo[1]) | (v_feh > T.bound_hi[1]) |
+                         (v_dist < T.bound_lo[2]) | (v_dist > T.bound_hi[2]) | (v_av < T.bound_lo[3]) | (v_av > T.bound_hi[3]));
+            const double t_age = ln_pdf<false, ISO_PRIOR_FLATLOG>(T.prior_age, v_age, 0.0);
+            const double t_feh = ln_pdf<false, ISO_PRIOR_FEH>(T.prior_feh, v_feh, 0.0);
+            const double t_dist = ln_pdf<false, ISO_PRIOR_POWERLAW>(T.prior_distance, v_dist, 0.0);
+            const double t_av = ln_pdf<false, ISO_PRIOR_FLAT>(T.prior_AV, v_av, 0.0);
+            lnp += t_age;
+            dead |= !isfinite(lnp);
+            lnp += t_feh;
+            dead |= !isfinite(lnp);
+            lnp += t_dist;
+            dead |= !isfinite(lnp);
+            lnp += t_av;
+            dead |= !isfinite(lnp);
+            for (int j = 1; j < N; ++j) dead |= !(par(base + j) <= par(base + j - 1));
+            auto eep_prior_std = [&](int l) {
+                if (T.leaf_system[l] != s) return;              // (wave-uniform)
+                const double eep = par(base + T.leaf_slot[l]);
+                const double lc = ln_call<ISO_PRIOR_CHABRIER>(T.prior_mass, S.star(l, 4)), deriv = S.star(l, 5);
+                const double inside = (lc == -f_inf()) ? ((deriv != deriv) ? f_nan() : -f_inf()) : lc + fast_log(deriv);
+                lnp += (eep < T.eep_lo || eep > T.eep_hi) ? -f_inf() : inside;
+            };
+            if constexpr (NL > 0) {
+#pragma unroll
+                for (int l = 0; l < NL; ++l) eep_prior_std(l);
+            } else {
+                for (int l = 0; l < n_leaves; ++l) eep_prior_std(l);
+            }
+        }
+    } else
     for (int s = 0; s < T.n_systems && !dead; ++s) {
         const int base = T.sys_base[s], N = T.n_stars[s];
         const DevPrior* pri[4] = {&T.prior_age, &T.prior_feh, &T.prior_distance, &T.prior_AV};

@@ -2119,6 +2119,9 @@ int iso_tree_model_create(iso_ic* ic, const iso_tree_desc* d, iso_tree_model** o
     H->prior_feh = make_dev_prior(d->prior_feh);
     H->prior_distance = make_dev_prior(d->prior_distance);
     H->prior_AV = make_dev_prior(d->prior_AV);
+    H->std_priors = (d->prior_mass.kind == ISO_PRIOR_CHABRIER && d->prior_age.kind == ISO_PRIOR_FLATLOG && d->prior_feh.kind == ISO_PRIOR_FEH &&
+                     d->prior_feh.c != 0.0 && d->prior_distance.kind == ISO_PRIOR_POWERLAW && d->prior_AV.kind == ISO_PRIOR_FLAT) ? 1 : 0;
+    if (const char* e = std::getenv("ISOCHRONES_AMD_STD_PRIORS")) H->std_priors = H->std_priors && std::atoi(e) != 0;   // A/B switch
     H->eep_lo = d->eep_lo; H->eep_hi = d->eep_hi;
     for (int j = 0; j < 4; ++j) {
         H->bound_lo[j] = d->bound_lo[j];

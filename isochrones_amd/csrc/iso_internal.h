@@ -139,6 +139,7 @@ struct DevTree {
     DevPrior prior_mass, prior_age, prior_feh, prior_distance, prior_AV;
     double eep_lo, eep_hi;
     double bound_lo[4], bound_hi[4];
+    int std_priors;      // the five prior records are the reference's default families (fast/tree_eval.h takes them as constants)
 };
 
 struct StretchArgs {
