@@ -2,6 +2,7 @@
 #   tests      the dispatch-table closure + new sampler tests
 #   fits       bench_configs fits,cfg4,tree (any-model sampler wall-clocks), mailbox latency
 #   bench      bench.py default line + the driver's arguments
+#   shapes     one star's fit by model shape, catalog fit by size, ns per move by walkers
 #   prof       rocprofv3 --kernel-trace --stats of bench.py and of the fits
 # Results under gpurun_out/r05/ (copy what should be judged into profiles/r05/).
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -20,6 +21,10 @@ fits)
 bench)
   python bench.py > $OUT/bench_cfg2_1gpu.json 2> $OUT/bench.err; tail -c 600 $OUT/bench_cfg2_1gpu.json
   python bench.py --steps 20 --warmup 5 > $OUT/bench_cfg2_1gpu_driver_args.json 2>> $OUT/bench.err ;;
+shapes)
+  python tools/single_fit_shapes.py 2>/dev/null | grep "^{" > $OUT/single_fit_shapes.jsonl; tail -3 $OUT/single_fit_shapes.jsonl | cut -c1-300
+  python tools/catalog_sizes.py --sizes 313,625,1250,2500,5000,10000 2>/dev/null | grep "^{" > $OUT/catalog_sizes.jsonl; tail -2 $OUT/catalog_sizes.jsonl | cut -c1-300
+  python tools/walker_packing_probe.py 2>/dev/null | grep "^{" > $OUT/walker_packing.jsonl; cat $OUT/walker_packing.jsonl | cut -c1-200 ;;
 prof)
   cd /tmp && export TMPDIR=/tmp
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python $ROOT/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-extras > $OUT/bench_profiled_run.json 2> $OUT/prof.err
