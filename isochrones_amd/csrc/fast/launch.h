@@ -99,11 +99,13 @@ inline bool launch_stretch_nb(int nb, const FastArgs& A, const StretchArgs& S, h
         if (!k.fn) return false;
         const size_t lds_bytes = stretch_persist_lds_bytes(A.axes_len, nb, S.W, NS + 4, k.dense);
         // with S.occupancy_query set: report resident workgroups per CU of this instantiation, launch nothing
+        // (three-wave workgroups: only the register-capped form reads its thread count from the launch, sampler.h)
+        const int threads = (k.dense && S.threads > 0) ? S.threads : BLOCK;
         if (S.occupancy_query)
-            return hipOccupancyMaxActiveBlocksPerMultiprocessor(S.occupancy_query, k.fn, BLOCK, lds_bytes) == hipSuccess;
+            return hipOccupancyMaxActiveBlocksPerMultiprocessor(S.occupancy_query, k.fn, threads, lds_bytes) == hipSuccess;
         note_kernel("%s", k.name);
         void* args[] = {const_cast<FastArgs*>(&A), const_cast<StretchArgs*>(&S)};
-        return hipLaunchKernel(k.fn, gp, b, args, lds_bytes, s) == hipSuccess;
+        return hipLaunchKernel(k.fn, gp, dim3(threads), args, lds_bytes, s) == hipSuccess;
     }
     // asteroseismic models: persistent form only (iso_sampler_create_model checks that the ensemble fits)
     if constexpr (ASTERO) {

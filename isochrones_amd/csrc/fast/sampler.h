@@ -244,7 +244,12 @@ template <int KIND, int NS, int NB, bool DENSE, bool ASTERO, bool UNI, bool STDP
 __device__ __forceinline__ void persist_body(const FastArgs& A, const StretchArgs& S)
 {
     extern __shared__ double lds[];
-    for (int j = threadIdx.x; j < A.axes_len; j += BLOCK) lds[j] = A.axes_blob[j];
+    // NT: threads of the workgroup.  BLOCK, except that the register-capped form is launched with THREE waves for ensembles
+    // of 129 ... 192 moves per half-step (the reference's default 300 walkers: 64 + 64 + 22 lanes): the fourth wave of such a
+    // workgroup has nothing to do but holds a quarter of its register file, and three-wave workgroups fit five to a CU instead
+    // of four (launch.h).  The LDS layout stays the one of BLOCK threads.
+    const int NT = DENSE ? (int)blockDim.x : BLOCK;
+    for (int j = threadIdx.x; j < A.axes_len; j += NT) lds[j] = A.axes_blob[j];
     constexpr bool SLIM = persist_slim(DENSE, NB, NS);
     constexpr int STRIDE = persist_slot_stride(DENSE, NB, NS);
     CoopLds L = coop_lds<NB>(lds, A.axes_len);
@@ -257,7 +262,7 @@ __device__ __forceinline__ void persist_body(const FastArgs& A, const StretchArg
     // that runs alone on its SIMD and its CU's L1 finishes a half-step sooner; the moves are keyed by (step, half, row),
     // so the chain does not depend on the split)
     const int G = (S.group > 0 && S.group < GL) ? S.group : GL;
-    const int per = h < BLOCK ? h : BLOCK;               // lanes one ensemble occupies per chunk
+    const int per = h < NT ? h : NT;                     // lanes one ensemble occupies per chunk
     const int64_t n_ens = S.n_active / h;
     const int64_t star0 = (int64_t)blockIdx.x * G;
     const int here = (int)((n_ens - star0) < G ? (n_ens - star0) : G);   // ensembles this workgroup owns
@@ -266,9 +271,9 @@ __device__ __forceinline__ void persist_body(const FastArgs& A, const StretchArg
     double* lpos = lds + ((A.axes_len + 1) & ~1) + BLOCK * STRIDE;
     double* llnp = SLIM ? S.lnp + r0 : lpos + GL * W * NP;                      // slim: the global arrays themselves
     int32_t* lacc = SLIM ? (S.accepted ? S.accepted + r0 : nullptr) : reinterpret_cast<int32_t*>(llnp + GL * W);
-    for (int j = threadIdx.x; j < R * NP; j += BLOCK) lpos[j] = S.pos[r0 * NP + j];
+    for (int j = threadIdx.x; j < R * NP; j += NT) lpos[j] = S.pos[r0 * NP + j];
     if (!SLIM) {
-        for (int j = threadIdx.x; j < R; j += BLOCK) {
+        for (int j = threadIdx.x; j < R; j += NT) {
             llnp[j] = S.lnp[r0 + j];
             lacc[j] = 0;
         }
@@ -295,9 +300,10 @@ __device__ __forceinline__ void persist_body(const FastArgs& A, const StretchArg
         g = mine ? a / h : 0;
         kk = mine ? a - g * h : 0;
         owns = ((int)threadIdx.x & 32) == 0;
-    } else if (h < BLOCK && here * h < BLOCK) {
+    } else if (h < NT && here * h < NT) {
         const int total = here * h;
-        int pw = (((total + 3) >> 2) + 15) & ~15;
+        const int nw = NT / 64;                               // (4; 3 in a three-wave launch of the register-capped form)
+        int pw = (((total + nw - 1) / nw) + 15) & ~15;
         pw = pw < 16 ? 16 : pw;
         int wv = (int)threadIdx.x >> 6;
 #if ISO_DENSE_PACKED
@@ -307,7 +313,7 @@ __device__ __forceinline__ void persist_body(const FastArgs& A, const StretchArg
         // so that the SIMDs of a CU share the full and the idle waves of the workgroups resident on it.
         if constexpr (DENSE) {
             pw = 64;
-            wv = (wv + (int)blockIdx.x) & (BLOCK / 64 - 1);
+            wv = (wv + (int)blockIdx.x) % (NT / 64);
         }
 #endif
         const int a = wv * pw + ((int)threadIdx.x & 63);
@@ -320,7 +326,7 @@ __device__ __forceinline__ void persist_body(const FastArgs& A, const StretchArg
     // use), a half-step only depends on LDS rows its own wave wrote: the waves then need no workgroup barrier between
     // half-steps and run through the iterations independently - a wave that waits for memory no longer holds up the
     // other three.  (LDS operations of one wave complete in order; the fence keeps the compiler from moving them.)
-    const bool wave_local = !PAIR && h <= 64 && (64 % h) == 0 && !(h < BLOCK && here * h < BLOCK);
+    const bool wave_local = !PAIR && h <= 64 && (64 % h) == 0 && !(h < NT && here * h < NT);
     for (int it = 0; it < S.nsteps; ++it) {
         double* cp = S.chain_pos ? S.chain_pos + (int64_t)it * rows_total * NP + (r0 + gs * W) * S.chain_rs : nullptr;
         double* cl = S.chain_lnp ? S.chain_lnp + (int64_t)it * rows_total + r0 + gs * W : nullptr;
@@ -356,9 +362,9 @@ __device__ __forceinline__ void persist_body(const FastArgs& A, const StretchArg
         }
     }
     if (wave_local) __syncthreads();                      // the write-back below reads rows of the other waves
-    for (int j = threadIdx.x; j < R * NP; j += BLOCK) S.pos[r0 * NP + j] = lpos[j];
+    for (int j = threadIdx.x; j < R * NP; j += NT) S.pos[r0 * NP + j] = lpos[j];
     if (!SLIM) {
-        for (int j = threadIdx.x; j < R; j += BLOCK) {
+        for (int j = threadIdx.x; j < R; j += NT) {
             S.lnp[r0 + j] = llnp[j];
             if (S.accepted) S.accepted[r0 + j] += lacc[j];
         }

@@ -2469,6 +2469,7 @@ int iso_sampler_run(iso_sampler* sp, double* pos, double* lnp, int nsteps, doubl
     S.occupancy_query = nullptr;
     S.dense = 0;
     S.group = 0;
+    S.threads = 0;
     S.pair = 1;           // ISOCHRONES_AMD_STAR_LANES=0: a single binary's fit through the one-lane-walks-both-stars kernel (A/B, tests)
     if (const char* e = std::getenv("ISOCHRONES_AMD_STAR_LANES")) S.pair = std::atoi(e) != 0;
     S.pos = pos;
@@ -2525,6 +2526,23 @@ int iso_sampler_run(iso_sampler* sp, double* pos, double* lnp, int nsteps, doubl
         }
     }
     S.dense = dense;
+    // The register-capped form with ensembles of 129 ... 192 moves per half-step (258 ... 384 walkers; the reference's default is
+    // 300): workgroups of THREE waves - the moves are packed into full waves, a fourth would only sit at the barrier - so
+    // that five workgroups share a CU instead of four.  ISOCHRONES_AMD_DENSE_THREADS=256 keeps four waves (A/B, tests).
+    S.threads = 0;
+    if (dense && sp->W / 2 > 128 && sp->W / 2 <= 192) {
+        int want = 192;
+        if (const char* e = std::getenv("ISOCHRONES_AMD_DENSE_THREADS")) want = std::atoi(e);
+        if (want == 192) {
+            S.threads = 192;
+            int per_cu_t = 0;
+            S.occupancy_query = &per_cu_t;
+            if (!launch_stretch(sp->kind, sp->n_stars, sp->n_bands, sp->fast, S, s)) per_cu_t = 0;
+            S.occupancy_query = nullptr;
+            if (per_cu_t > 0) per_cu = per_cu_t;
+            else S.threads = 0;
+        }
+    }
     // A catalog that leaves CUs idle at `group` ensembles per workgroup is spread over more of them: fewer ensembles per
     // workgroup (a power of two, at least 64 moves per half-step so that every wave keeps a full gather round), as many
     // workgroups as there are CUs at most.  ISOCHRONES_AMD_PERSIST_GROUP=n pins the number (sweeps, A/B).

@@ -164,6 +164,8 @@ struct StretchArgs {
     int group;            // persistent form: ensembles per workgroup (0 or >= the most a workgroup holds: that many);
                           // fewer spread a small catalog over more CUs - LDS is laid out for the maximum either way
     int pair;             // host side only: a single binary may take the one-star-per-lane kernel (k_stretch_pair)
+    int threads;          // host side only, persistent register-capped form: threads per workgroup (0 = BLOCK; 192 for ensembles of
+                          // 129 ... 192 moves per half-step, fast/sampler.h)
 };
 
 // the moves' side of a run of the any-model persistent sampler (fast/sampler_any.h)

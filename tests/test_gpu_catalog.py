@@ -244,12 +244,13 @@ def _run_fused(target, p0, lnp0, W, nsteps, mode, monkeypatch, seed=9):
     return pos2.clone(), lnp2.clone(), fs.chain.clone(), fs.lnprobability.clone(), fs.accepted.clone()
 
 
-@pytest.mark.parametrize("W", [16, 100, 128, 600])
+@pytest.mark.parametrize("W", [16, 100, 128, 258, 300, 384, 600])
 def test_persistent_sampler_kernel_bit_identical_to_stepwise(W, monkeypatch):
     """The one-launch persistent kernel (workgroup per ensemble, positions in LDS) and the
     launch-per-half-step kernel make the same moves with the same Philox numbers: chains,
     lnprob, final state and acceptance counters must agree bit for bit (W=600 exercises the
-    multi-chunk half, W=16 the mostly idle workgroup)."""
+    multi-chunk half, W=16 the mostly idle workgroup; 258 / 300 / 384 the three-wave workgroups the
+    register-capped form is launched with for 129 ... 192 moves per half-step)."""
     import torch
     from isochrones_amd.catalog import initial_positions
     ic = _small_track(("G", "BP", "RP"))
