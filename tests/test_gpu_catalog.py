@@ -272,6 +272,31 @@ def test_persistent_sampler_kernel_bit_identical_to_stepwise(W, monkeypatch):
         assert torch.equal(x, y)
 
 
+@pytest.mark.parametrize("N,nb,W", [(2, 3, 300), (1, 8, 300), (3, 2, 260), (1, 3, 384)])
+def test_three_wave_workgroups_of_the_register_capped_form(N, nb, W, monkeypatch):
+    """The register-capped catalog kernel is launched with THREE waves for ensembles of 129 ... 192 moves per half-step (the
+    reference's default 300 walkers), five workgroups per CU instead of four (iso_sampler_run, fast/sampler.h NT): binaries
+    and triples, more than six bands (the forms that keep lnpost and the counters in LDS), and a full 192 moves - chains,
+    lnprob, final state and acceptance counters bit for bit those of the step-wise kernel and of the four-wave launch
+    (ISOCHRONES_AMD_DENSE_THREADS=256)."""
+    import torch
+    from isochrones_amd.catalog import initial_positions
+    bands = list(ia.grids.KNOWN_BANDS[:nb])
+    ic = ia.synthetic_isochrone(bands=bands)
+    cat, truth = synthetic_catalog(ic, 3, bands=bands, seed=6, mag_unc=0.02, with_parallax=True)
+    post = CatalogPosterior.from_catalog(cat, ic, N=N)
+    pos, lnp, failed = initial_positions(post, W, rng_seed=4, oversample=8, max_tries=4)
+    assert not bool(failed.any())
+    a = _run_fused(post, pos, lnp, W, 10, "stepwise", monkeypatch)
+    b = _run_fused(post, pos, lnp, W, 10, "persistent-dense", monkeypatch)
+    monkeypatch.setenv("ISOCHRONES_AMD_DENSE_THREADS", "256")
+    c = _run_fused(post, pos, lnp, W, 10, "persistent-dense", monkeypatch)
+    for x, y, z in zip(a, b, c):
+        assert torch.equal(x, y) and torch.equal(x, z)
+    assert int(a[4].sum()) > 0
+    post.close()
+
+
 @pytest.mark.parametrize("W,nb,n_ens", [(16, 1, 1), (32, 3, 1), (100, 6, 1), (128, 11, 1), (200, 2, 1), (256, 4, 1), (32, 3, 4), (300, 3, 1)])
 def test_single_binary_with_one_star_per_lane_makes_the_plain_kernels_chain(W, nb, n_ens, monkeypatch):
     """k_stretch_pair (a single binary, lanes l and l + 32 of a wave share a move, one star each) against the plain
