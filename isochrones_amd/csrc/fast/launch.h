@@ -15,7 +15,8 @@ inline size_t stretch_persist_lds_bytes(int axes_len, int nb, int W, int np, boo
 
 // The persistent instantiation a run takes - ONE place decides it, for the occupancy query and for the launch alike
 // (round 3 queried the catalog form even when the single-model forms, with other register counts, were launched):
-//   dense                     register-capped: 4 (single stars, <= 6 bands) or 3 workgroups per CU, catalogs / many ensembles in rounds
+//   dense                     register-capped: 4 (single stars, <= 6 bands) or 3 waves per SIMD, catalogs / many ensembles in rounds;
+//                             + STDP (3 waves per SIMD) when the stars share the default priors and the launch runs in rounds anyway
 //   multi                     catalog, every workgroup resident: uncapped registers; + STDP when the stars share the
 //                             reference's default priors: shared block through scalar loads, compile-time families,
 //                             lane BC gather (one band), table-free priors during the model gather
@@ -43,7 +44,18 @@ inline PersistKernel persist_kernel(const StretchArgs& S)
         stdp = false;
         k.fn = (const void*)k_stretch_persist<KIND, NS, N, false, true, true, false>;
     } else if (dense) {
-        k.fn = (const void*)k_stretch_persist<KIND, NS, N, true, false>;
+        // two register-capped forms: prior families read at run time (four waves per SIMD for single stars up to six bands),
+        // or - the stars share the reference's default priors and the host asks for it (StretchArgs.dense_stdp) - compiled in,
+        // at the registers of three waves per SIMD (the straight-line priors need them: 136 B of scratch at the cap of four)
+        // (single stars with up to six bands only: the other shapes sit at three waves per SIMD either way, and there the
+        // compiled-in form only adds scratch - 400-480 B per lane for systems with 11-12 bands)
+        if constexpr (persist_slim(true, N, NS)) {
+            stdp = S.std_priors != 0 && S.dense_stdp != 0;
+            k.fn = stdp ? (const void*)k_stretch_persist<KIND, NS, N, true, false, false, true>
+                        : (const void*)k_stretch_persist<KIND, NS, N, true, false>;
+        } else {
+            k.fn = (const void*)k_stretch_persist<KIND, NS, N, true, false>;
+        }
     } else if (S.multi) {
         // resident catalog: when its stars share their priors and those are the reference's defaults, the form that reads
         // them through scalar loads with the families as compile-time constants (STDP without UNI)

@@ -309,8 +309,8 @@ __device__ __forceinline__ void persist_body(const FastArgs& A, const StretchArg
 #if ISO_DENSE_PACKED
         // DENSE is the throughput form (more workgroups than the chip holds at once): there a wave costs its SIMD the same
         // time whatever its lanes do, so the moves are PACKED into as few waves as they fill (150 moves of a 300-walker
-        // ensemble: 64 + 64 + 22 instead of 48 + 48 + 48 + 6), and which waves those are rotates with the workgroup number,
-        // so that the SIMDs of a CU share the full and the idle waves of the workgroups resident on it.
+        // ensemble: 64 + 64 + 22 instead of 48 + 48 + 48 + 6); which waves those are rotates with the workgroup number (the
+        // hardware already varies the SIMD a wave index lands on - tools/simd_probe.hip -, so this is belt and braces).
         if constexpr (DENSE) {
             pw = 64;
             wv = (wv + (int)blockIdx.x) % (NT / 64);
@@ -372,7 +372,7 @@ __device__ __forceinline__ void persist_body(const FastArgs& A, const StretchArg
 }
 
 template <int KIND, int NS, int NB, bool DENSE, bool ASTERO = false, bool UNI = false, bool STDP = false>
-__global__ __launch_bounds__(BLOCK, DENSE ? (persist_slim(DENSE, NB, NS) ? 4 : 3) : 2) void k_stretch_persist(const FastArgs A, const StretchArgs S)
+__global__ __launch_bounds__(BLOCK, DENSE ? ((persist_slim(DENSE, NB, NS) && !STDP) ? 4 : 3) : 2) void k_stretch_persist(const FastArgs A, const StretchArgs S)
 {
     persist_body<KIND, NS, NB, DENSE, ASTERO, UNI, STDP, false>(A, S);
 }

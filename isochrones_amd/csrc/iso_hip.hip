@@ -2470,6 +2470,7 @@ int iso_sampler_run(iso_sampler* sp, double* pos, double* lnp, int nsteps, doubl
     S.dense = 0;
     S.group = 0;
     S.threads = 0;
+    S.dense_stdp = 0;
     S.pair = 1;           // ISOCHRONES_AMD_STAR_LANES=0: a single binary's fit through the one-lane-walks-both-stars kernel (A/B, tests)
     if (const char* e = std::getenv("ISOCHRONES_AMD_STAR_LANES")) S.pair = std::atoi(e) != 0;
     S.pos = pos;
@@ -2542,6 +2543,25 @@ int iso_sampler_run(iso_sampler* sp, double* pos, double* lnp, int nsteps, doubl
             if (per_cu_t > 0) per_cu = per_cu_t;
             else S.threads = 0;
         }
+    }
+    // The register-capped form exists twice: prior families read at run time (four waves per SIMD for single stars with up to six
+    // bands: more workgroups per CU), or - the launch's stars share the reference's default priors - compiled in, at the registers
+    // of three waves per SIMD (6-9 % fewer cycles per move, a fifth fewer workgroups per CU).  The second one unless it would
+    // split into rounds a launch that the first keeps on the chip in ONE (1 250 stars of the reference shape: 12.8 against
+    // 14 ms; 10^4 stars: 82 -> 77 ms the other way; profiles/r05/ab_dense_stdp3.jsonl).  ISOCHRONES_AMD_DENSE_STDP=0 / 1 pins it.
+    S.dense_stdp = 0;
+    if (dense && sp->std_priors) {
+        int per_cu_std = 0;
+        S.dense_stdp = 1;
+        S.occupancy_query = &per_cu_std;
+        if (!launch_stretch(sp->kind, sp->n_stars, sp->n_bands, sp->fast, S, s)) per_cu_std = 0;
+        S.occupancy_query = nullptr;
+        const bool std_one_round = per_cu_std > 0 && blocks <= (int64_t)cus * per_cu_std;
+        const bool rt_one_round = per_cu > 0 && blocks <= (int64_t)cus * per_cu;
+        bool take = per_cu_std > 0 && (std_one_round || !rt_one_round);
+        if (const char* e = std::getenv("ISOCHRONES_AMD_DENSE_STDP")) take = per_cu_std > 0 && std::atoi(e) != 0;
+        if (take) per_cu = per_cu_std;
+        else S.dense_stdp = 0;
     }
     // A catalog that leaves CUs idle at `group` ensembles per workgroup is spread over more of them: fewer ensembles per
     // workgroup (a power of two, at least 64 moves per half-step so that every wave keeps a full gather round), as many

@@ -166,6 +166,7 @@ struct StretchArgs {
     int pair;             // host side only: a single binary may take the one-star-per-lane kernel (k_stretch_pair)
     int threads;          // host side only, persistent register-capped form: threads per workgroup (0 = BLOCK; 192 for ensembles of
                           // 129 ... 192 moves per half-step, fast/sampler.h)
+    int dense_stdp;       // host side only, persistent register-capped form: 1 = the instantiation with the default prior families compiled in
 };
 
 // the moves' side of a run of the any-model persistent sampler (fast/sampler_any.h)

@@ -30,7 +30,7 @@ def pytest_collection_modifyitems(config, items):
 
 
 _SWITCHES = ("ISOCHRONES_AMD_PATH", "ISOCHRONES_AMD_SAMPLER", "ISOCHRONES_AMD_QUANTILES", "ISOCHRONES_AMD_HOST_SYNC",
-             "ISOCHRONES_AMD_TREE_RUNTIME_LEAVES", "ISOCHRONES_AMD_DENSE_THREADS", "ISOCHRONES_AMD_STD_PRIORS", "ISOCHRONES_AMD_STAR_LANES")
+             "ISOCHRONES_AMD_TREE_RUNTIME_LEAVES", "ISOCHRONES_AMD_DENSE_THREADS", "ISOCHRONES_AMD_DENSE_STDP", "ISOCHRONES_AMD_STD_PRIORS", "ISOCHRONES_AMD_STAR_LANES")
 
 
 @pytest.fixture(autouse=True)

@@ -349,8 +349,13 @@ def test_fused_families(kind, ns, nb):
                 expect(t.names, "k_stretch_pair<%d, false>" % nb, tid)
             if not astero:
                 # register-capped form with a single model (many ensembles of one star run it in rounds)
+                # (default priors: the register-capped form with the families compiled in; read at run time when told so)
                 with env(ISOCHRONES_AMD_SAMPLER="persistent-dense"), traced(tid) as t:
                     check_sampler(mod, oic, p0, 16, 8, 80 + nb, tid + " persistent dense, one model", n_ensembles=3)
+                # (single stars with up to six bands; the other shapes have the run-time form only)
+                expect(t.names, "k_stretch_persist<%d, %d, %d, true, false, false, %s>" % (K, ns, nb, "true" if (ns == 1 and nb <= 6) else "false"), tid)
+                with env(ISOCHRONES_AMD_SAMPLER="persistent-dense", ISOCHRONES_AMD_DENSE_STDP="0"), traced(tid) as t:
+                    check_sampler(mod, oic, p0, 16, 8, 81 + nb, tid + " persistent dense, one model, run-time priors", n_ensembles=3)
                 expect(t.names, "k_stretch_persist<%d, %d, %d, true, false, false, false>" % (K, ns, nb), tid)
             del mod
     # ---- the same table entries with NON-DEFAULT prior families in every slot: the arms of ln_pdf's run-time switch inside
@@ -399,6 +404,9 @@ def test_fused_families(kind, ns, nb):
             expect(t.names, "k_stretch_persist<%d, %d, %d, false, false, false, false>" % (K, ns, nb), tid)
             with env(ISOCHRONES_AMD_SAMPLER="persistent-dense"), traced(tid) as t:
                 check_catalog_sampler(cat, post, ic, oic, ns, pos, lnp, good, 8, 91 + nb, tid + " catalog dense")
+            expect(t.names, "k_stretch_persist<%d, %d, %d, true, false, false, %s>" % (K, ns, nb, "true" if (ns == 1 and nb <= 6) else "false"), tid)
+            with env(ISOCHRONES_AMD_SAMPLER="persistent-dense", ISOCHRONES_AMD_DENSE_STDP="0"), traced(tid) as t:
+                check_catalog_sampler(cat, post, ic, oic, ns, pos, lnp, good, 8, 94 + nb, tid + " catalog dense, run-time priors")
             expect(t.names, "k_stretch_persist<%d, %d, %d, true, false, false, false>" % (K, ns, nb), tid)
             with env(ISOCHRONES_AMD_SAMPLER="stepwise"), traced(tid) as t:
                 check_catalog_sampler(cat, post, ic, oic, ns, pos, lnp, good, 6, 92 + nb, tid + " catalog stepwise")
