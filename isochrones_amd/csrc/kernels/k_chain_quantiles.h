@@ -400,25 +400,63 @@ __global__ __launch_bounds__(BLOCK, 4) void k_chain_quantiles_big(const QuantArg
         }
     };
 
-    // ---- pass 1: finite min / max, counts of the infinities ----
+    // ---- pass 1: the range of the histogram - from a SAMPLE.  Any monotone binning gives the same selection (the target bins
+    // are gathered and ranked exactly; a crowded bin is refined on its own min / max), so the range need not be the exact one:
+    // the finite min / max of every 8th chunk of BLOCK values (an eighth of the traffic of a pass) spans the histogram, values
+    // outside fall into its end bins, and the counts of the infinities come out of the histogram pass.  A sample without two
+    // distinct finite values (a constant chain, a chain of infinities) takes the exact pass instead. ----
     double mn = d_inf(), mx = -d_inf();
     int n_neg = 0, n_pos = 0;
-    QBIG_FOR_VALUES(v) {
-        const bool neg = v == -d_inf(), pos = v == d_inf();
-        n_neg += neg;
-        n_pos += pos;
-        mn = (neg | pos) ? mn : fmin(mn, v);
-        mx = (neg | pos) ? mx : fmax(mx, v);
+    for (int i_ = tid; i_ < m; i_ += 8 * BLOCK) {
+        const double v = value_at(i_);
+        const bool inf = (v == -d_inf()) | (v == d_inf());
+        mn = inf ? mn : fmin(mn, v);
+        mx = inf ? mx : fmax(mx, v);
+    }
+    block_minmax(mn, mx);
+    const bool exact_range = !(mx > mn);                     // workgroup-uniform (block_minmax gives every thread the same numbers)
+    if (exact_range) {
+        mn = d_inf();
+        mx = -d_inf();
+        QBIG_FOR_VALUES(v) {
+            const bool neg = v == -d_inf(), pos = v == d_inf();
+            n_neg += neg;
+            n_pos += pos;
+            mn = (neg | pos) ? mn : fmin(mn, v);
+            mx = (neg | pos) ? mx : fmax(mx, v);
+        }
+        block_minmax(mn, mx);
+    }
+    for (int i = tid; i < QBIG_BINS; i += BLOCK) {
+        hist[i] = 0;
+        slot_of_bin[i] = 0xFF;
+    }
+    __syncthreads();
+    const bool binned = mx > mn;                             // (exact range: false = every finite value equal, or none)
+    const double inv = binned ? (double)QBIG_BINS / (mx - mn) : 0.0;
+    // (clamped: values outside a sampled range belong to the end bins; the comparison form also keeps the conversion in range)
+    auto bin_of = [&](double v) { return (int)fmin(fmax((v - mn) * inv, 0.0), (double)(QBIG_BINS - 1)); };
+    if (binned) {
+        // ---- pass 2: histogram over [mn, mx]; with a sampled range also the counts of the infinities ----
+        QBIG_FOR_VALUES(v) {
+            const bool neg = v == -d_inf(), pos = v == d_inf();
+            if (!exact_range) {
+                n_neg += neg;
+                n_pos += pos;
+            }
+            if (!(neg | pos)) atomicAdd(&hist[bin_of(v)], 1);
+        }
     }
     for (int off = 32; off > 0; off >>= 1) {
         n_neg += __shfl_xor(n_neg, off);
         n_pos += __shfl_xor(n_pos, off);
     }
+    __syncthreads();
     if (lane == 0) {
         ired[wave] = n_neg;
         ired[4 + wave] = n_pos;
     }
-    block_minmax(mn, mx);
+    __syncthreads();
     n_neg = ired[0] + ired[1] + ired[2] + ired[3];
     n_pos = ired[4] + ired[5] + ired[6] + ired[7];
     const int mfin = m - n_neg - n_pos;
@@ -433,21 +471,10 @@ __global__ __launch_bounds__(BLOCK, 4) void k_chain_quantiles_big(const QuantArg
         rank_local[tid] = r - n_neg;                         // rank among the finite values
         if (r < n_neg) { result[tid] = -d_inf(); rank_slot[tid] = -1; }
         else if (r >= n_neg + mfin) { result[tid] = d_inf(); rank_slot[tid] = -1; }
-        else if (!(mx > mn)) { result[tid] = mn; rank_slot[tid] = -1; }      // every finite value equal
-    }
-    for (int i = tid; i < QBIG_BINS; i += BLOCK) {
-        hist[i] = 0;
-        slot_of_bin[i] = 0xFF;
+        else if (!binned) { result[tid] = mn; rank_slot[tid] = -1; }      // every finite value equal (exact range)
     }
     __syncthreads();
-    if (mfin > 0 && mx > mn) {                               // workgroup-uniform
-        // ---- pass 2: histogram over [mn, mx] ----
-        const double inv = (double)QBIG_BINS / (mx - mn);
-        auto bin_of = [&](double v) { return min(QBIG_BINS - 1, (int)((v - mn) * inv)); };
-        QBIG_FOR_VALUES(v) {
-            if (v > -d_inf() && v < d_inf()) atomicAdd(&hist[bin_of(v)], 1);
-        }
-        __syncthreads();
+    if (mfin > 0 && binned) {                                // workgroup-uniform
         prefix_hist();
         if (tid < n_ranks && rank_slot[tid] == -2) {
             const int b = find_bin(rank_local[tid]);
