@@ -218,11 +218,16 @@ def cpu_baseline(ic, mod, pars_host, wall_budget_s=4.0, full_passes=3, scalar_ca
         oic.lnpost(desc, col, nthreads=1, parts=False)
     scalar_us = (time.perf_counter() - tc) / len(one) * 1e6
     p1, n1 = full_passes, n
-    return dict(value=n / min(times), unit="evals/s", cores=cores, kind="port", scalar_call_us=scalar_us,
-                sample="best of %d passes over the same %d-sample batch (%.1f s wall), C restatement of the reference "
-                       "(oracle/iso_oracle.c), OpenMP static over %d threads; container CPU quota: %s; 1-thread "
-                       "figure: %d passes over the first %d samples (%.1f s)"
-                       % (passes, n, dt, cores, ("%.1f CPUs" % quota) if quota else "none", p1, n1, dt1),
+    # `value` is the REPRODUCIBLE figure: the median pass with as many threads as the container's CPU quota grants (passes
+    # agree to ~10 %); the best pass with every hardware thread - a pass that happened to start in a fresh quota period, 5-6 x
+    # the median one on this pool - is kept beside it as `value_best_pass` (the conservative figure for a GPU / CPU ratio)
+    return dict(value=n / float(np.median(times_q)), unit="evals/s", cores=quota_threads, kind="port", scalar_call_us=scalar_us,
+                value_best_pass=n / min(times), best_pass_threads=cores,
+                sample="median of %d passes over the same %d-sample batch with %d threads (= the container's CPU quota: %s), "
+                       "C restatement of the reference (oracle/iso_oracle.c), OpenMP static; value_best_pass: best of %d "
+                       "passes with all %d hardware threads (%.1f s wall); 1-thread figure: %d passes over the first %d "
+                       "samples (%.1f s)"
+                       % (len(times_q), n, quota_threads, ("%.1f CPUs" % quota) if quota else "none", passes, cores, dt, p1, n1, dt1),
                 value_median_pass=n / float(np.median(times)), cpu_quota_cores=quota,
                 value_quota=n / float(np.median(times_q)), quota_threads=quota_threads, quota_passes=len(times_q),
                 quota_pass_spread=float((max(times_q) - min(times_q)) / np.median(times_q)),
@@ -622,8 +627,13 @@ def main():
                      "launches_rotate_over_batches": nb,
                      "distinct_table_bytes_touched_per_rotation": (rec.get("fabric_read_bytes") * nb if rec and rec.get("fabric_read_bytes") else None),
                      "bounds": bounds(label, args.n, kernel_ms, bytes_per_launch)},
+        # filled in below, placed here so that they sit in the head of the line (the driver's record keeps a bounded prefix):
+        # `summary` = the one number of every secondary leg (cfg 3 / cfg 4 / the two catalog legs / the per-point callback)
+        "cpu_baseline": None,
+        "summary": {},
         "startup": startup,
     }
+    summary = result["summary"]
     # the figure of rounds 1-2 beside it: the same batch evaluated again and again (its ~0.48 GB of lines are partly
     # still in the 256 MiB Infinity Cache when the next launch asks for them)
     try:
@@ -660,6 +670,9 @@ def main():
         try:
             result["catalog"] = catalog_leg(ic, rank, world, barrier, dist if distributed else None, reduce_device,
                                             cpu_subsample=(64 if (world == 1 and not args.no_cpu_baseline) else 0))
+            for key, leg in result["catalog"].items():
+                if key.endswith("_stars") and isinstance(leg, dict) and "stars_per_s" in leg:
+                    summary["catalog_32x250_track_%s_per_s" % key] = leg["stars_per_s"]
         except Exception as e:       # noqa: BLE001 - the extra leg must not take the benchmark line down
             result["catalog"] = {"error": "%s: %s" % (type(e).__name__, e)}
         # The same catalog path ON THE REFERENCE'S OWN WORKLOAD: `starfit` builds get_ichrone(models, bands) = MIST_Isochrone,
@@ -681,6 +694,13 @@ def main():
             ref.update({"broadcast_" + k: v for k, v in tb.items()})
             ref["workload"] = ("the reference's batch_starfit workload: MIST_Isochrone parametrisation, fit_mcmc defaults "
                                "300 walkers x (200 burn-in + 100 kept) iterations, 10^4 stars")
+            leg = ref.get("10000_stars") or {}
+            if "stars_per_s" in leg:
+                summary["catalog_reference_shape_stars_per_s"] = leg["stars_per_s"]        # 300 x (200 + 100), isochrones, 10^4 stars
+                summary["catalog_reference_shape_wall_s"] = leg["wall_s"]
+                base_c = (leg.get("cpu_baseline") or {}).get("stars_per_s")
+                if base_c:
+                    summary["catalog_reference_shape_cpu_one_thread_stars_per_s"] = base_c
             if isinstance(result.get("catalog"), dict):
                 result["catalog"]["reference_shape"] = ref
             else:
@@ -737,9 +757,12 @@ def main():
                                                   np.array_equal(np.isneginf(got3), np.isneginf(ref3)))
                 base3["reference_published_us_per_call"] = 719.0
                 cfg3["cpu_baseline"] = base3
-                cfg3["speedup_vs_cpu_all_cores"] = cfg3["prior_valid"]["evals_per_s"] / base3["value"]
+                cfg3["speedup_vs_cpu"] = cfg3["prior_valid"]["evals_per_s"] / base3["value"]
+                cfg3["speedup_vs_cpu_all_cores"] = cfg3["prior_valid"]["evals_per_s"] / base3["value_best_pass"]
                 cfg3["speedup_vs_cpu_scalar_calls"] = cfg3["prior_valid"]["evals_per_s"] / base3["modes"]["B1_scalar_call"]["evals_per_s"]
             result["cfg3_binary_6_bands"] = cfg3
+            summary["cfg3_binary_6_bands_prior_valid_evals_per_s"] = cfg3["prior_valid"]["evals_per_s"]
+            summary["cfg3_kernel_ms"] = cfg3["prior_valid"]["kernel_ms"]
             del mod3, ic3
         except Exception as e:       # noqa: BLE001 - a secondary leg must not take the benchmark line down
             result["cfg3_binary_6_bands"] = {"error": "%s: %s" % (type(e).__name__, e)}
@@ -792,6 +815,10 @@ def main():
             except Exception as e:       # noqa: BLE001
                 c4["ensembles_64x256x5000"] = {"error": "%s: %s" % (type(e).__name__, e)}
             result["cfg4_mcmc_256x5000"] = c4
+            summary["cfg4_us_per_step"] = c4["us_per_step"]
+            summary["cfg4_gpu_wall_s"] = c4["gpu_wall_s"]
+            if "cpu_wall_s" in c4:
+                summary["cfg4_cpu_wall_s_one_walker_per_call"] = c4["cpu_wall_s"]
             fs.close()
         except Exception as e:       # noqa: BLE001
             result["cfg4_mcmc_256x5000"] = {"error": "%s: %s" % (type(e).__name__, e)}
@@ -820,7 +847,10 @@ def main():
                 base["parity_pattern_ok"] = bool(ok)
                 base["finite_fraction"] = float(fin.mean())
                 result["cpu_baseline"] = base
-                result["speedup_vs_cpu_all_cores"] = value / base["value"]
+                result["speedup_vs_cpu"] = value / base["value"]
+                result["speedup_vs_cpu_all_cores"] = value / base["value_best_pass"]
+                summary["speedup_vs_cpu_quota_threads"] = value / base["value"]
+                summary["speedup_vs_cpu_best_pass_all_threads"] = value / base["value_best_pass"]
             except Exception as e:   # noqa: BLE001
                 result["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
         else:

@@ -212,6 +212,11 @@ int  iso_model_kernel_path(const iso_model* m);
  * compiled off against the oracle with these.  Recording costs one atomic load per launch when it is off. */
 int     iso_debug_trace_kernels(int on);
 int64_t iso_debug_kernels(char* buf, int64_t size);
+/* What the calling thread's last iso_sampler_run decided for the BasicStarModel / catalog kernels: out8 = {persistent form
+ * (1) or one launch per half-step (0), register-capped instantiation, threads per workgroup (256, or 192 for ensembles of 129-192
+ * moves per half-step), default prior families compiled in, ensembles per workgroup, workgroups per CU by the occupancy
+ * query, workgroups of the launch, 0}.  tests assert the launch shape of the reference-shape catalog with it. */
+int     iso_debug_sampler_plan(int32_t* out8);
 
 /* Host-side test helper, no device involved: the bracket index the fused kernels compute for every x[k] on axis
  * `which` of a set of axes - bucket table (planned for all `n_axes` axes together within `budget` bytes, exactly as

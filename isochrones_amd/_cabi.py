@@ -99,7 +99,7 @@ EXPORTED_SYMBOLS = (
     "iso_table_create", "iso_table_destroy", "iso_interp", "iso_interp_host",
     "iso_ic_create", "iso_ic_destroy", "iso_interp_mag", "iso_interp_mag_host",
     "iso_model_create", "iso_model_destroy", "iso_model_n_params", "iso_model_kernel_path",
-    "iso_axis_bracket_host", "iso_debug_trace_kernels", "iso_debug_kernels",
+    "iso_axis_bracket_host", "iso_debug_trace_kernels", "iso_debug_kernels", "iso_debug_sampler_plan",
     "iso_lnpost", "iso_lnpost_host", "iso_unit_cube", "iso_time_lnpost", "iso_time_lnpost_rotating",
     "iso_catalog_create", "iso_catalog_create_columns", "iso_catalog_destroy", "iso_catalog_lnpost", "iso_catalog_start_points",
     "iso_eep_table_create", "iso_eep_table_destroy", "iso_interp_eep", "iso_interp_eep_host",
@@ -120,7 +120,8 @@ def library_path() -> str:
 
 
 class IsoError(RuntimeError):
-    pass
+    """``rc`` is the C ABI's return code (ERR_INVALID: no kernel / bad argument; ERR_HIP, ERR_NOMEM: real failures)."""
+    rc = None
 
 
 def trace_kernels(on=True):
@@ -136,6 +137,14 @@ def traced_kernels():
     buf = C.create_string_buffer(int(need))
     L.iso_debug_kernels(buf, need)
     return [k for k in buf.value.decode().split("\n") if k]
+
+
+def last_sampler_plan():
+    """What this thread's last ``iso_sampler_run`` decided (BasicStarModel / catalog kernels): a dict with the keys
+    persistent, dense, threads, dense_stdp, group, per_cu, workgroups."""
+    out = (C.c_int32 * 8)()
+    check(lib().iso_debug_sampler_plan(out))
+    return dict(zip(("persistent", "dense", "threads", "dense_stdp", "group", "per_cu", "workgroups"), list(out)[:7]))
 
 
 def lib():
@@ -165,6 +174,8 @@ def lib():
         L.iso_debug_trace_kernels.argtypes = [C.c_int]
         L.iso_debug_kernels.argtypes = [C.c_char_p, C.c_int64]
         L.iso_debug_kernels.restype = C.c_int64
+    if hasattr(L, "iso_debug_sampler_plan"):
+        L.iso_debug_sampler_plan.argtypes = [C.POINTER(C.c_int32)]
     L.iso_ctx_create.argtypes = [C.POINTER(vp), C.c_int]
     L.iso_ctx_destroy.argtypes = [vp]
     L.iso_ctx_destroy.restype = None
@@ -238,4 +249,6 @@ def lib():
 def check(rc: int):
     if rc != 0:
         msg = lib().iso_last_error()
-        raise IsoError("isochrones_amd C-ABI error %d: %s" % (rc, (msg or b"").decode()))
+        e = IsoError("isochrones_amd C-ABI error %d: %s" % (rc, (msg or b"").decode()))
+        e.rc = rc
+        raise e

@@ -509,10 +509,13 @@ def result_columns(param_names):
 
 
 def fit_stars_gpu(catalog: StarCatalog, ic, indices, N=1, nwalkers=32, nburn=150, niter=100, seed=0,
-                  model_kwargs=None, fused=True, timings=None, max_stars_per_batch=200_000, return_chains=False):
+                  model_kwargs=None, fused=True, timings=None, max_stars_per_batch=200_000, return_chains=False,
+                  replay_record=None):
     """Fit the stars ``indices`` of the catalog on the current GPU; returns [len(indices), 3*D+3]
     float64 numpy rows (result_columns order).  ``return_chains=True`` (fused sampler, one batch): also the
-    stored chain [S, W, niter, D] and its lnpost values [S, W, niter] as CUDA tensors."""
+    stored chain [S, W, niter, D] and its lnpost values [S, W, niter] as CUDA tensors.  ``replay_record`` (a dict, tests):
+    filled with what a move-by-move replay of the SAMPLING run needs - the ensembles as burn-in left them (``pos`` [S, W, D],
+    ``lnp`` [S, W]), the sampler's ``seed``, the step counter the run starts at (``step0`` = nburn), the start points."""
     import torch
     import time as _time
 
@@ -559,8 +562,12 @@ def fit_stars_gpu(catalog: StarCatalog, ic, indices, N=1, nwalkers=32, nburn=150
             # a failed star keeps its own (hopeless) posterior: its borrowed walkers simply never move
             lnp = torch.where(failed[:, None], torch.zeros_like(lnp), lnp)
         sampler = FusedEnsembleSampler(post, nwalkers, seed=seed + 1)
+        if replay_record is not None:
+            replay_record.update(start_pos=pos.clone(), start_lnp=lnp.clone(), failed=failed.clone())
         pos, lnp = sampler.run_mcmc(pos, nburn, lnprob0=lnp, store=False)
         _mark("burn_in")
+        if replay_record is not None:
+            replay_record.update(pos=pos.clone(), lnp=lnp.clone(), seed=seed + 1, step0=int(nburn))
         sampler.reset()
         sampler.run_mcmc(pos, niter, lnprob0=lnp, store=True)
         _mark("sampling")

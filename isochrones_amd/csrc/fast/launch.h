@@ -23,6 +23,7 @@ inline size_t stretch_persist_lds_bytes(int axes_len, int nb, int W, int np, boo
 //   single model, std priors  UNI + STDP: model block through scalar loads, prior families compile-time constants
 //   single model              UNI
 //   single binary             k_stretch_pair (+ STDP): one star per lane, when a half-step's moves fit half a workgroup
+//   single triple             k_stretch_triple (+ STDP): one star per row of a wave, chunks of 64 moves
 // Models with asteroseismic terms (ASTERO) are single models by construction (iso_catalog_create refuses them) and
 // have no register-capped form: a run of very many ensembles of such a model takes the UNI kernel in rounds.
 struct PersistKernel {
@@ -79,6 +80,20 @@ inline PersistKernel persist_kernel(const StretchArgs& S)
                 k.fn = stdp ? (const void*)k_stretch_pair<N, true> : (const void*)k_stretch_pair<N, false>;
                 k.dense = false;
                 snprintf(k.name, sizeof k.name, "k_stretch_pair<%d, %s>", N, tf(stdp));
+                return k;
+            }
+        }
+        if constexpr (KIND == ISO_KIND_ISO && NS == 3) {
+            // a single triple (or a few ensembles of it - every workgroup resident at once): one star per row of a wave
+            // (k_stretch_triple, sampler.h); a run of more workgroups than the chip holds is throughput-bound and keeps the
+            // form in which a lane walks its three stars
+            const int64_t n_ens = S.n_active / (S.W >> 1);
+            const int GL = persist_group(S.W);
+            const int G = (S.group > 0 && S.group < GL) ? S.group : GL;
+            if (S.pair && (n_ens + G - 1) / G <= 512) {
+                k.fn = stdp ? (const void*)k_stretch_triple<N, true> : (const void*)k_stretch_triple<N, false>;
+                k.dense = false;
+                snprintf(k.name, sizeof k.name, "k_stretch_triple<%d, %s>", N, tf(stdp));
                 return k;
             }
         }

@@ -23,6 +23,10 @@
 // by side instead of one after the other - a lone wave has nothing else to overlap them with, and a second star then costs
 // one exchange across the wave's halves (6 + NB values) instead of most of an evaluation.  After the exchanges both lanes
 // hold both stars' numbers and do the same arithmetic in the same order: the result is the one of the plain form, bit for bit.
+// bit 5 of LANE (triples, NS = 3): the same with one star per ROW of the wave - lanes l, l + 16, l + 32 (l < 16) hold the same
+// sample and walk star 0 / 1 / 2; row 3 only helps with the gathers.  The three stars' chains were the whole of a triple's
+// half-step (round 5: 55 us per step of a 9-band triple against 20 for the binary); side by side they cost one chain and
+// two exchanges across the rows (v_permlane16_swap + v_permlane32_swap, three vector instructions per dword).
 // Bands up to which the BC gather is taken lane-per-sample where LANE asks for it.  Measured per step of one star's fit
 // (tools/single_fit_shapes.py, profiles/r04/lane_bc_cap_ab.jsonl; 256 walkers): 1 band 8.97 us against 9.67 cooperative;
 // 2 / 3 / 4 bands 10.08 / 10.58 / 11.63 against 9.35 / 9.67 / 9.93; lifted to 8 bands: 5 / 6 / 8 bands 12.6 / 13.8 / 22.6
@@ -70,13 +74,17 @@ __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* l
     };
     double star[NS][6];
     double astero[2] = {0.0, 0.0};
-    constexpr bool SPREAD = (LANE & 16) != 0;
-    static_assert(!SPREAD || (NS == 2 && KIND == ISO_KIND_ISO && !TILED && !ASTERO && (LANE & 1) == 0),
-                  "one star per lane: binaries on the isochrone grid, cooperative model gather");
-    const bool companion = SPREAD && (L.lane & 32) != 0;
+    constexpr bool SPREAD = (LANE & (16 | 32)) != 0;
+    static_assert(!SPREAD || (((LANE & 16) ? NS == 2 : NS == 3) && (LANE & 48) != 48 && KIND == ISO_KIND_ISO && !TILED && !ASTERO && (LANE & 1) == 0),
+                  "one star per lane: binaries (bit 4) / triples (bit 5) on the isochrone grid, cooperative model gather");
+    // the star this lane walks in the one-star-per-lane forms (a triple's idle fourth row shadows star 2 and asks for nothing)
+    const int my_star = !SPREAD ? 0 : (NS == 2 ? (L.lane >> 5) : ((L.lane >> 4) < 2 ? (L.lane >> 4) : 2));
+    const bool my_row = !SPREAD || NS == 2 || (L.lane >> 4) < 3;
     if constexpr (SPREAD) {
-        const double eep = companion ? p[1] : p[0];
-        const bool ok = bool(ok01 & !(eep != eep) & !eep_oob(A, eep));
+        double eep = p[0];
+#pragma unroll
+        for (int s = 1; s < NS; ++s) eep = my_star == s ? p[s] : eep;
+        const bool ok = bool(ok01 & my_row & !(eep != eep) & !eep_oob(A, eep));
         int i2;
         eep_bracket(A, lds, eep, i2, w.t2);
         const uint32_t cell = cell3(A, i0, i1, i2);
@@ -86,7 +94,10 @@ __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* l
         else coop_star<false, NoWorkBetween, true, THREE>(A, L, ok, cell, w, mine);
 #pragma unroll
         for (int q = 0; q < 6; ++q) {
-            halves_f64(mine[q], star[0][q], star[1][q]);       // (primary's lane = lower half, companion's = upper)
+            double each[NS];
+            stars_f64<NS>(mine[q], each);       // (binary: primary's lane = lower half, companion's = upper; triple: rows 0 / 1 / 2)
+#pragma unroll
+            for (int s = 0; s < NS; ++s) star[s][q] = each[s];
         }
     }
 #pragma unroll
@@ -217,9 +228,14 @@ __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* l
         const bool okA = bool(go & !(AV != AV) & !lds_oob(lds, A.b3, AV));
         double bcm[NB];
         {
-            const double T = companion ? star[1][0] : star[0][0], g = companion ? star[1][1] : star[0][1],
-                         f = companion ? star[1][2] : star[0][2];
-            const bool ok = bool(okA & !(T != T) & !(g != g) & !(f != f) & !lds_oob(lds, A.b0, T) &
+            double T = star[0][0], g = star[0][1], f = star[0][2];
+#pragma unroll
+            for (int s = 1; s < NS; ++s) {
+                T = my_star == s ? star[s][0] : T;
+                g = my_star == s ? star[s][1] : g;
+                f = my_star == s ? star[s][2] : f;
+            }
+            const bool ok = bool(okA & my_row & !(T != T) & !(g != g) & !(f != f) & !lds_oob(lds, A.b0, T) &
                                  !lds_oob(lds, A.b1, g) & !lds_oob(lds, A.b2, f));
             int j0, j1, j2, j3;
             W4 w4v;
@@ -230,17 +246,18 @@ __device__ __forceinline__ double lnpost_wave(const FastArgs& A, const double* l
         }
     #pragma unroll
         for (int b = 0; b < NB; ++b) {
-            double bc0, bc1;
-            halves_f64(bcm[b], bc0, bc1);
+            double bcs[NS];
+            stars_f64<NS>(bcm[b], bcs);
             {   // primary (the s == 0 step of the loop below)
-                const double mag = star[0][3] + dm - bc0;
+                const double mag = star[0][3] + dm - bcs[0];
                 const bool far = fabs(mag) > 700.0;
                 tot[b] = far ? 0.0 : mag;
                 rel[b] = 1.0;
                 if (__ballot(far)) rel[b] = far ? exp10(-0.4 * mag) : 1.0;
             }
-            {   // companion (s == 1)
-                const double mag = star[1][3] + dm - bc1;
+    #pragma unroll
+            for (int s = 1; s < NS; ++s) {   // companions
+                const double mag = star[s][3] + dm - bcs[s];
                 rel[b] += exp10(-0.4 * (mag - tot[b]));
             }
         }

@@ -240,9 +240,12 @@ __host__ __device__ constexpr int persist_extra_doubles(int W, int np, bool slim
 // faster when latency is all that matters (every workgroup resident at once, e.g. a single star's fit).
 // PAIR (single binaries, at most BLOCK / 2 moves per half-step): one star per lane - lanes l and l + 32 of a wave share a
 // move, the primary's lane owns it (lnpost_wave's LANE bit 4).
-template <int KIND, int NS, int NB, bool DENSE, bool ASTERO, bool UNI, bool STDP, bool PAIR>
+// TRIPLE (single triples, any number of moves): one star per ROW of a wave - lanes l, l + 16, l + 32 share a move, row 0 owns
+// it, row 3 idles (lnpost_wave's LANE bit 5); a half-step is walked in chunks of 64 moves (16 per wave).
+template <int KIND, int NS, int NB, bool DENSE, bool ASTERO, bool UNI, bool STDP, bool PAIR, bool TRIPLE = false>
 __device__ __forceinline__ void persist_body(const FastArgs& A, const StretchArgs& S)
 {
+    static_assert(!(PAIR && TRIPLE), "one form of one star per lane at a time");
     extern __shared__ double lds[];
     // NT: threads of the workgroup.  BLOCK, except that the register-capped form is launched with THREE waves for ensembles
     // of 129 ... 192 moves per half-step (the reference's default 300 walkers: 64 + 64 + 22 lanes): the fourth wave of such a
@@ -300,6 +303,12 @@ __device__ __forceinline__ void persist_body(const FastArgs& A, const StretchArg
         g = mine ? a / h : 0;
         kk = mine ? a - g * h : 0;
         owns = ((int)threadIdx.x & 32) == 0;
+    } else if constexpr (TRIPLE) {
+        // move a of a chunk = 16 * wave + (lane & 15), in the three lower rows of the wave; g / kk are set per chunk below
+        mine = ((int)threadIdx.x & 48) != 48;
+        owns = ((int)threadIdx.x & 48) == 0;
+        g = 0;
+        kk = ((int)threadIdx.x >> 6) * 16 + ((int)threadIdx.x & 15);
     } else if (h < NT && here * h < NT) {
         const int total = here * h;
         const int nw = NT / 64;                               // (4; 3 in a three-wave launch of the register-capped form)
@@ -326,7 +335,7 @@ __device__ __forceinline__ void persist_body(const FastArgs& A, const StretchArg
     // use), a half-step only depends on LDS rows its own wave wrote: the waves then need no workgroup barrier between
     // half-steps and run through the iterations independently - a wave that waits for memory no longer holds up the
     // other three.  (LDS operations of one wave complete in order; the fence keeps the compiler from moving them.)
-    const bool wave_local = !PAIR && h <= 64 && (64 % h) == 0 && !(h < NT && here * h < NT);
+    const bool wave_local = !PAIR && !TRIPLE && h <= 64 && (64 % h) == 0 && !(h < NT && here * h < NT);
     for (int it = 0; it < S.nsteps; ++it) {
         double* cp = S.chain_pos ? S.chain_pos + (int64_t)it * rows_total * NP + (r0 + gs * W) * S.chain_rs : nullptr;
         double* cl = S.chain_lnp ? S.chain_lnp + (int64_t)it * rows_total + r0 + gs * W : nullptr;
@@ -342,6 +351,21 @@ __device__ __forceinline__ void persist_body(const FastArgs& A, const StretchArg
             const FastArgs& A = *(const FastArgs*)(const __attribute__((address_space(4))) FastArgs*)kp;
             const StretchArgs& S = *(const StretchArgs*)(const __attribute__((address_space(4))) StretchArgs*)(kp + ((sizeof(FastArgs) + 7) & ~size_t(7)));
 #endif
+            if constexpr (TRIPLE) {
+                const int total = here * h;
+                for (int c0 = 0; c0 < total; c0 += 64) {
+                    const int a = c0 + kk;
+                    const bool active = mine && a < total;
+                    const int ge = active ? a / h : 0;
+                    const int k = active ? a - ge * h : h - 1;
+                    double* cpe = S.chain_pos ? S.chain_pos + (int64_t)it * rows_total * NP + (r0 + ge * W) * S.chain_rs : nullptr;
+                    double* cle = S.chain_lnp ? S.chain_lnp + (int64_t)it * rows_total + r0 + ge * W : nullptr;
+                    if (__any(active))                    // wave-uniform
+                        stretch_move<KIND, NS, NB, ASTERO, UNI, STDP, ISO_UNI_LANE | 32, false>(
+                            A, S, lds, L, active, active && owns, star0 + ge, k, half, S.step + (uint32_t)it, lpos + ge * W * NP,
+                            llnp + ge * W, lacc ? lacc + ge * W : nullptr, cpe, cle);
+                }
+            } else
             for (int k0 = 0; k0 < h; k0 += per) {
                 const int k = k0 + kk;
                 const bool active = mine && k < h;
@@ -382,4 +406,11 @@ template <int NB, bool STDP>
 __global__ __launch_bounds__(BLOCK, 2) void k_stretch_pair(const FastArgs A, const StretchArgs S)
 {
     persist_body<ISO_KIND_ISO, 2, NB, false, false, true, STDP, true>(A, S);
+}
+
+// a single triple's fit (isochrone grid, no asteroseismic terms): one star per row of a wave, 64 moves per chunk
+template <int NB, bool STDP>
+__global__ __launch_bounds__(BLOCK, 2) void k_stretch_triple(const FastArgs A, const StretchArgs S)
+{
+    persist_body<ISO_KIND_ISO, 3, NB, false, false, true, STDP, false, true>(A, S);
 }

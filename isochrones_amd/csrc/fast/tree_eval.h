@@ -69,6 +69,23 @@ struct TreeLeaves {
         return -2.5 * fast_log10(tot);
     }
 
+    // the same with the band a compile-time constant (the band-major likelihood of the register form): selects over leaves only
+    template <int B>
+    __device__ __forceinline__ double addmags_band(uint32_t mask) const
+    {
+        static_assert(STATIC, "register form");
+        if ((mask & (mask - 1u)) == 0u && mask != 0u) {          // (wave-uniform) a node above one model star: see addmags
+            double m = 0.0;
+#pragma unroll
+            for (int l = 0; l < NL; ++l) m = ((mask >> l) & 1u) ? mag_[l][B] : m;
+            if (!__ballot(fabs(m) > 700.0)) return m;
+        }
+        double tot = 0.0;
+#pragma unroll
+        for (int l = 0; l < NL; ++l) tot += ((mask >> l) & 1u) ? flux_[l][B] : 0.0;
+        return -2.5 * fast_log10(tot);
+    }
+
     __device__ __forceinline__ double prop(int leaf, int q) const
     {
         if constexpr (STATIC) {
@@ -83,6 +100,41 @@ struct TreeLeaves {
         }
     }
 };
+
+#ifndef ISO_TREE_BANDMAJOR
+#define ISO_TREE_BANDMAJOR 1
+#endif
+// terms evaluated side by side in the band-major likelihood (independent logarithms for the scheduler to interleave; a slot
+// beyond a band's last term repeats that term and adds nothing)
+#ifndef ISO_TREE_TERM_UNROLL
+#define ISO_TREE_TERM_UNROLL 2
+#endif
+
+// sum of the photometric terms of bands B .. NB - 1 (compile-time recursion over the band)
+template <int NB, int NL, int B>
+__device__ __forceinline__ void bterm_sum(const DevTree& T, const TreeLeaves<NB, NL>& S, double& lnl)
+{
+    if constexpr (B < NB) {
+        const int t0 = T.bterm_first[B], t1 = T.bterm_first[B + 1];
+        for (int t = t0; t < t1; t += ISO_TREE_TERM_UNROLL) {
+            double term[ISO_TREE_TERM_UNROLL];
+#pragma unroll
+            for (int u = 0; u < ISO_TREE_TERM_UNROLL; ++u) {
+                const bool have = t + u < t1;                  // (wave-uniform)
+                const DevTreeTerm& tt = T.bterms[have ? t + u : t];
+                double mod = S.template addmags_band<B>(tt.mask);
+                // (a node that is not relative has an empty reference mask: the select keeps the loads and the logarithm of
+                // the two sums independent of the flag)
+                const double ref = tt.relative ? S.template addmags_band<B>(tt.ref_mask) : 0.0;
+                const double r = tt.dmag - (mod - ref);
+                term[u] = have ? tt.g0 - (r * r) * tt.hinv : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < ISO_TREE_TERM_UNROLL; ++u) lnl += term[u];
+        }
+        bterm_sum<NB, NL, B + 1>(T, S, lnl);
+    }
+}
 
 // lnpost of the lane's sample.  ALL 64 lanes of a wave must call this together (the gathers are wave-cooperative);
 // `active` = the lane really has a sample.  par(j) = parameter j of the lane's sample: global memory in the batch kernel
@@ -222,6 +274,19 @@ __device__ __forceinline__ double tree_lnpost(const FastArgs& A, const DevTree& 
     if (want_like || prior_ok) {
         lnl = 0.0;
         bool bad = false;
+#if ISO_TREE_BANDMAJOR
+        if constexpr (NL > 0) {
+            // REGISTER FORM: the terms band by band (DevTree.bterms, sorted on the host), the band a compile-time index, so that
+            // a node's flux sum selects over its leaves only (the term-major loop resolved (leaf, band) through NL x NB selects,
+            // twice for one-leaf nodes), and WITHOUT the reference's exit after a non-finite partial sum: a sum that has left
+            // the finite numbers never comes back, so "-inf as soon as the running sum is not finite" (observation.py:1209-
+            // 1230) is "-inf if the sum of the photometric terms is not finite" - one test behind the loop instead of a
+            // loop-carried exit that put every term's logarithm behind the previous one's.  The additions run band-major
+            // instead of in tree order: the same terms, rounding apart.
+            bterm_sum<NB, NL, 0>(T, S, lnl);
+            bad = !isfinite(lnl);
+        } else
+#endif
         for (int t = 0; t < T.n_terms && !bad; ++t) {
             const iso_tree_term& tt = T.terms[t];
             double mag = tt.mag;
@@ -234,18 +299,21 @@ __device__ __forceinline__ double tree_lnpost(const FastArgs& A, const DevTree& 
             lnl += T.term_g0[t] - (r * r) * T.term_hinv[t];
             if (!isfinite(lnl)) bad = true;
         }
-        for (int k = 0; k < T.n_spec && !bad; ++k) {
+        // (register form: no exits - a partial sum that is not finite stays so, one test at the end says the same as the
+        // reference's test after every addition; the exits only put each term behind the one before)
+        constexpr bool EXITS = !(ISO_TREE_BANDMAJOR && NL > 0);
+        for (int k = 0; k < T.n_spec && !(EXITS && bad); ++k) {
             const iso_tree_prop& sp = T.spec[k];
             const double r = sp.a - S.prop(sp.leaf, sp.prop);
             lnl += T.spec_g0[k] - (r * r) * T.spec_hinv[k];
-            if (!isfinite(lnl)) bad = true;
+            if (EXITS && !isfinite(lnl)) bad = true;
         }
-        for (int k = 0; k < T.n_limits && !bad; ++k) {
+        for (int k = 0; k < T.n_limits && !(EXITS && bad); ++k) {
             const iso_tree_prop& lm = T.limits[k];
             const double mod = S.prop(lm.leaf, lm.prop);
             if (mod < lm.a || mod > lm.b || !isfinite(mod)) bad = true;
         }
-        if (!bad) {
+        if (!EXITS || !bad) {
             for (int s = 0; s < T.n_systems; ++s)
                 if (T.has_plx[s]) {
                     const double r = T.plx_val[s] - 1.0 / par(T.sys_base[s] + T.n_stars[s] + 2) * 1000.0;

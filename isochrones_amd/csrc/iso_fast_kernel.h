@@ -74,6 +74,35 @@ __device__ __forceinline__ void halves_f64(double x, double& lower, double& uppe
     lower = __hiloint2double((int)r1[0], (int)r0[0]);
     upper = __hiloint2double((int)r1[1], (int)r0[1]);
 }
+// ---- the four rows of a wavefront (gfx950: v_permlane16_swap_b32 swaps rows 1 / 3 - lanes 16..31 / 48..63 - of one register
+// with rows 0 / 2 of another) ----
+// r0 / r1 / r2 = the value lane (l & 15) / (l & 15) + 16 / (l & 15) + 32 holds, in every lane: three swaps per dword
+__device__ __forceinline__ void rows3_u32(unsigned x, unsigned& r0, unsigned& r1, unsigned& r2)
+{
+    const auto a = __builtin_amdgcn_permlane16_swap(x, x, false, false);       // a[0] = rows {0, 0, 2, 2}, a[1] = rows {1, 1, 3, 3}
+    const auto e = __builtin_amdgcn_permlane32_swap(a[0], a[0], false, false); // e[0] = row 0 everywhere, e[1] = row 2 everywhere
+    const auto o = __builtin_amdgcn_permlane32_swap(a[1], a[1], false, false); // o[0] = row 1 everywhere
+    r0 = e[0];
+    r1 = o[0];
+    r2 = e[1];
+}
+__device__ __forceinline__ void rows3_f64(double x, double& r0, double& r1, double& r2)
+{
+    unsigned l0, l1, l2, h0, h1, h2;
+    rows3_u32((unsigned)__double2loint(x), l0, l1, l2);
+    rows3_u32((unsigned)__double2hiint(x), h0, h1, h2);
+    r0 = __hiloint2double((int)h0, (int)l0);
+    r1 = __hiloint2double((int)h1, (int)l1);
+    r2 = __hiloint2double((int)h2, (int)l2);
+}
+// the value every star's lane of a one-star-per-lane move holds (lnpost_wave's LANE bits 4 / 5): out[s] = star s's
+template <int NS>
+__device__ __forceinline__ void stars_f64(double x, double* out)
+{
+    static_assert(NS == 2 || NS == 3, "one star per lane: binaries (halves of the wave) and triples (rows)");
+    if constexpr (NS == 2) halves_f64(x, out[0], out[1]);
+    else rows3_f64(x, out[0], out[1], out[2]);
+}
 // (Tried on top of it, round 5: logarithms / exponentials of a single star's fit two at a time, the second argument in the idle
 // upper half of the wave.  121 vector instructions fewer per move and 0.4 % - a lone wave is bound by the latency of its
 // dependent instructions, and two independent logarithms already overlap in the pipeline - and the restructured code was no

@@ -4,9 +4,12 @@
 //
 //   host                                            device (k_mailbox_lnpost, one wave)
 //   req[1..NP] = parameters; req[0] = seq  ------>  one 64-B read over PCIe per poll: lanes 0-7 take the eight words of the
-//                                                   line; a new sequence word = a request, whose parameters arrived with it
-//                                                   (the host writes the sequence word LAST; x86 keeps the store order and
-//                                                   a line is read from the host's cache in one piece)
+//                                                   line; a new sequence word = a request, whose parameters normally arrived
+//                                                   with it (the host writes the sequence word LAST; x86 keeps the store
+//                                                   order and a line is read from the host's cache in one piece).  Nothing
+//                                                   in the memory model PROMISES the one piece: the sequence word carries a
+//                                                   32-bit checksum of the parameter words, and a line that does not match
+//                                                   it (new sequence word, stale parameters) is polled again
 //                                                   evaluation: lnpost_wave, the batch kernel's device function (single-model
 //                                                   form: model block through scalar loads, lane BC gather for one band)
 //   spins on done[0] (its own cache)       <------  done[1..3] = lnpost, lnprior, lnlike; fence; done[0] = seq
@@ -64,6 +67,14 @@ __global__ __launch_bounds__(64, 2) void k_mailbox_lnpost(const FastArgs A0, Iso
         const DevModel& M = *(const DevModel*)((const_model_ptr)(uintptr_t)A.m);
         const int n = (int)(seq & 0xFF) + 1;                   // rows of the request (1..128)
         const bool parts = ((seq >> 8) & 1) != 0;              // lnprior / lnlike wanted as well
+        if (n == 1) {
+            unsigned long long words[NP];
+#pragma unroll
+            for (int q = 0; q < NP; ++q) words[q] = __shfl(w, 1 + q);
+            if (mailbox_checksum(words, NP) != (uint32_t)(seq >> 32)) continue;      // torn line (wave-uniform): poll again
+        } else {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");      // the rows behind the line are read after the sequence word
+        }
         for (int r0 = 0; r0 < n; r0 += 64) {
             const int r = r0 + lane;
             const bool active = r < n;

@@ -379,6 +379,21 @@ void note_kernel(const char* fmt, ...)
 }
 }  // namespace iso
 
+// what the calling thread's last iso_sampler_run decided: {persistent, dense, threads, dense_stdp, group, workgroups per CU,
+// workgroups, form} (tests assert the launch shape of the catalog routes with it; the kernel's NAME is in the trace above)
+namespace iso {
+namespace {
+thread_local int32_t t_sampler_plan[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+}
+}  // namespace iso
+
+extern "C" int iso_debug_sampler_plan(int32_t* out8)
+{
+    if (!out8) return ISO_ERR_INVALID;
+    std::memcpy(out8, iso::t_sampler_plan, sizeof iso::t_sampler_plan);
+    return ISO_OK;
+}
+
 extern "C" int iso_debug_trace_kernels(int on)
 {
     iso::t_kernels.clear();
@@ -1471,13 +1486,16 @@ int mailbox_call(iso_model* m, const double* pars, int n, double* lnpost_out, do
     IsoMailbox* mb = m->mbox;
     const int np_ = m->desc.n_stars + 4;
     const bool parts = lnprior_out || lnlike_out;
-    const unsigned long long seq = (++m->mbox_count << 16) | ((unsigned long long)parts << 8) | (unsigned long long)(n - 1);
+    unsigned long long seq = ((++m->mbox_count & 0xFFFFull) << 16) | ((unsigned long long)parts << 8) | (unsigned long long)(n - 1);
     if (n == 1) {
+        unsigned long long words[ISO_MAX_PARAMS];
         for (int q = 0; q < np_; ++q) {
-            unsigned long long w;
-            std::memcpy(&w, pars + q, 8);
-            __atomic_store_n(&mb->req[1 + q], w, __ATOMIC_RELAXED);
+            std::memcpy(&words[q], pars + q, 8);
+            __atomic_store_n(&mb->req[1 + q], words[q], __ATOMIC_RELAXED);
         }
+        // the wave accepts the request only with parameter words that give this number: a line read in pieces (new sequence
+        // word, old parameters) is polled again instead of evaluated
+        seq |= (unsigned long long)mailbox_checksum(words, np_) << 32;
     } else {
         std::memcpy(mb->rows, pars, sizeof(double) * (size_t)n * np_);
     }
@@ -2108,6 +2126,24 @@ int iso_tree_model_create(iso_ic* ic, const iso_tree_desc* d, iso_tree_model** o
         double u2;
         gauss_consts(d->terms[t].unc, H->term_g0[t], u2, &H->term_hinv[t]);
     }
+    {   // band-major copy of the terms (stable inside a band), constants folded
+        int n = 0;
+        for (int b = 0; b <= ISO_TREE_MAX_BANDS; ++b) {
+            H->bterm_first[b] = n;
+            if (b == ISO_TREE_MAX_BANDS) break;
+            for (int t = 0; t < d->n_terms; ++t) {
+                if (d->terms[t].band != b) continue;
+                DevTreeTerm& bt = H->bterms[n++];
+                bt.mask = d->terms[t].mask;
+                bt.ref_mask = d->terms[t].ref_mask;
+                bt.relative = d->terms[t].relative;
+                bt.pad_ = 0;
+                bt.dmag = d->terms[t].relative ? d->terms[t].mag - d->terms[t].ref_mag : d->terms[t].mag;
+                bt.g0 = H->term_g0[t];
+                bt.hinv = H->term_hinv[t];
+            }
+        }
+    }
     for (int k = 0; k < d->n_spec; ++k) {
         H->spec[k] = d->spec[k];
         double u2;
@@ -2593,6 +2629,17 @@ int iso_sampler_run(iso_sampler* sp, double* pos, double* lnp, int nsteps, doubl
     // (round 2 kept the step-wise form for catalogs of 1-1.4 rounds, where a nearly empty second round cost more than it;
     // with four workgroups per CU the persistent form is ahead there too - profiles/r03/sampler_mode_sweep.txt)
     const bool persistent = nsteps > 0 && fits && per_cu > 0 && mode != "stepwise";
+    {
+        int32_t* pl = iso::t_sampler_plan;
+        pl[0] = persistent ? 1 : 0;
+        pl[1] = S.dense;
+        pl[2] = S.threads > 0 ? S.threads : BLOCK;
+        pl[3] = S.dense_stdp;
+        pl[4] = S.group > 0 ? S.group : group;
+        pl[5] = per_cu;
+        pl[6] = (int32_t)std::min<int64_t>((sp->n_ensembles + pl[4] - 1) / pl[4], 0x7fffffff);
+        pl[7] = 0;
+    }
     if (persistent) {
         S.step = sp->step;
         S.nsteps = nsteps;

@@ -124,6 +124,14 @@ struct FastArgs {
 };
 
 // flattened observation tree of a generic StarModel (constants pre-evaluated on the host)
+// one photometric term of an observation tree as the fused evaluation reads it (constants folded on the host)
+struct DevTreeTerm {
+    uint32_t mask, ref_mask;   // leaves below the node / below its reference node
+    int32_t relative, pad_;
+    double dmag;               // observed magnitude (relative: minus the reference's)
+    double g0, hinv;           // log(1/sqrt(2 pi)) + log(unc), 0.5 / unc^2
+};
+
 struct DevTree {
     int n_systems, n_leaves, n_bands, n_terms, n_spec, n_limits, n_params;
     int n_stars[ISO_TREE_MAX_SYSTEMS], sys_base[ISO_TREE_MAX_SYSTEMS];
@@ -140,6 +148,11 @@ struct DevTree {
     double eep_lo, eep_hi;
     double bound_lo[4], bound_hi[4];
     int std_priors;      // the five prior records are the reference's default families (fast/tree_eval.h takes them as constants)
+    // the photometric terms once more, BAND-MAJOR (stable: the reference's order inside a band), for the register form of the
+    // fused evaluation (fast/tree_eval.h): the band is then a compile-time loop index there and a node's flux sum selects
+    // over leaves only; bterm_first[b] .. bterm_first[b + 1] - 1 are band b's terms
+    int bterm_first[ISO_TREE_MAX_BANDS + 1];
+    DevTreeTerm bterms[ISO_TREE_MAX_TERMS];
 };
 
 struct StretchArgs {
@@ -190,7 +203,9 @@ struct AnyStretchArgs {
 // the per-point callback's mailbox (iso_fast_mailbox.hip): pinned host memory, device-mapped, 64-byte lines
 constexpr int ISO_MAILBOX_ROWS = 128;
 struct IsoMailbox {
-    unsigned long long req[8];        // line 0, host -> device: req[0] = sequence word (counter << 16 | parts << 8 | rows - 1),
+    unsigned long long req[8];        // line 0, host -> device: req[0] = sequence word (checksum << 32 | counter << 16 | parts << 8 | rows - 1;
+                                      //         checksum = mailbox_checksum of the words of a one-row request, so that a line
+                                      //         whose eight words did not arrive together is seen as such and polled again),
                                       //         req[1..7] = the parameters of a one-row request
     unsigned long long done[8];       // line 1, device -> host: done[0] = sequence word of the last finished request,
                                       //         done[1..3] = lnpost, lnprior, lnlike of a one-row request
@@ -199,6 +214,17 @@ struct IsoMailbox {
     double rows[ISO_MAILBOX_ROWS * ISO_MAX_PARAMS];     // requests of 2..128 rows, [row][parameter]
     double out[3 * ISO_MAILBOX_ROWS];                   // their results: lnpost | lnprior | lnlike
 };
+
+// 32-bit checksum of the parameter words of a one-row mailbox request (host and device compute the same number)
+__host__ __device__ inline uint32_t mailbox_checksum(const unsigned long long* w, int n)
+{
+    uint32_t c = 0x9E3779B9u;
+    for (int q = 0; q < n; ++q) {
+        c = (c ^ (uint32_t)w[q]) * 0x85EBCA6Bu;
+        c = (c ^ (uint32_t)(w[q] >> 32)) * 0xC2B2AE35u + (uint32_t)q;
+    }
+    return c;
+}
 
 // closed-form age prior of an IsoTrackModel (the reference's AgePrior, flat in linear age): lnorm + age ln 10 inside [lo, hi]
 struct IsoTrackAge {

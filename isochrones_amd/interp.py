@@ -18,6 +18,8 @@ from . import _cabi, device as dev
 
 
 HOST_CALL_ROWS = 4096     # host inputs up to this many rows use the *_host entry points (one launch + one sync)
+TABLE_EPOCH = [0]         # bumped whenever ANY interpolator frees its device tables (release / add_column): per-call caches
+                          # that skip ic.handle() (StarModel._scalar_call, the mailbox accessors) compare this integer
 
 
 def _is_scalar(v):
@@ -112,6 +114,7 @@ class DFInterpolator:
             _cabi.lib().iso_table_destroy(h)
         self._handles = {}
         self._generation += 1
+        TABLE_EPOCH[0] += 1
 
     def __del__(self):
         try:

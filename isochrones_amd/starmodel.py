@@ -17,6 +17,7 @@ from __future__ import annotations
 import ctypes as C
 import logging
 import math
+import threading
 
 import numpy as np
 
@@ -161,9 +162,14 @@ def _run_mcmc_fit(model, nwalkers, nburn, niter, p0, seed, fused, n_ensembles=1)
     if fused is None or fused:
         try:
             sampler = FusedEnsembleSampler(model, nwalkers, seed=int(rng.integers(2 ** 62)), n_ensembles=n_ensembles)
-        except _cabi.IsoError:
-            if fused:
+        except _cabi.IsoError as e:
+            # only "the library has no resident kernel for this shape" is a reason to change samplers (the framework-op
+            # one draws different random numbers and is an order of magnitude slower); a HIP / memory failure is an error
+            if fused or e.rc not in (None, _cabi.ERR_INVALID):
                 raise
+            import warnings
+            warnings.warn("fit_mcmc: no device-resident sampler for this model shape (%s); using the framework-op "
+                          "EnsembleSampler, whose random numbers differ" % e, RuntimeWarning, stacklevel=3)
     if sampler is None:
         if n_ensembles != 1:
             raise ValueError("n_ensembles > 1 needs the device-resident sampler")
@@ -511,13 +517,24 @@ class BasicStarModel(_NestedFitMixin, _ConvenienceMixin):
         by two integer comparisons (no prior object anywhere was mutated since; the interpolator was not rebound), so the
         wrapper adds about a microsecond to the C call (whose resident mailbox wave answers without a launch)."""
         from . import priors as _p
-        c = getattr(self, "_scalar_cache", None)
-        if c is None or c[0] != _p.EPOCH[0] or c[1] != self.ic._generation:
+        from .interp import TABLE_EPOCH
+        # the cache (and with it the parameter / output buffers) is per THREAD: ctypes drops the GIL inside the C call, so
+        # two threads sharing one pair of buffers would overwrite each other's rows (threaded emcee, a pool around
+        # mnest_loglike); the C side serialises callers of one model on its own mutex
+        tls = self.__dict__.get("_scalar_tls")
+        if tls is None:
+            tls = self.__dict__.setdefault("_scalar_tls", threading.local())
+        c = getattr(tls, "c", None)
+        if (c is None or c[0] != _p.EPOCH[0] or c[1] != self.ic._generation or c[8] != TABLE_EPOCH[0]
+                or c[9] is not self._scalar_cache):
             device = dev.current_device()
-            h = self.handle(device)                      # the full check (prior objects' versions, interpolator)
+            h = self.handle(device)                      # the full check (prior objects' versions, interpolator, tables)
+            if self._scalar_cache is None:
+                self._scalar_cache = object()            # token: _dirty() / a rebuilt handle drops every thread's cache
             buf, out = np.empty(self.n_params), np.empty(3)
-            c = self._scalar_cache = (_p.EPOCH[0], self.ic._generation, h, buf, out, buf.ctypes.data,
-                                      tuple(out.ctypes.data + 8 * k for k in range(3)), _cabi.lib().iso_lnpost_host)
+            c = tls.c = (_p.EPOCH[0], self.ic._generation, h, buf, out, buf.ctypes.data,
+                         tuple(out.ctypes.data + 8 * k for k in range(3)), _cabi.lib().iso_lnpost_host,
+                         TABLE_EPOCH[0], self._scalar_cache)
         c[3][:] = p                                      # (a row of the wrong length raises here)
         a = c[6]
         rc = c[7](c[2], c[5], 1, a[0] if which == 0 else None, a[1] if which == 1 else None, a[2] if which == 2 else None)
@@ -585,7 +602,8 @@ class BasicStarModel(_NestedFitMixin, _ConvenienceMixin):
 
     def _evaluate(self, p, which, soa=False):
         tp = type(p)
-        if (tp is list or tp is tuple or (tp is np.ndarray and p.ndim == 1)) and len(p) == self.n_params:
+        if ((tp is list or tp is tuple or (tp is np.ndarray and p.ndim == 1)) and len(p) == self.n_params
+                and not isinstance(p[0], (list, tuple, np.ndarray))):     # (a list of n_params ROWS is a batch)
             return self._scalar_call(p, which)
         if dev.is_tensor(p) and p.is_cuda:
             import torch

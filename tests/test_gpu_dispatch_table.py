@@ -331,6 +331,7 @@ def test_fused_families(kind, ns, nb):
             # persistent, single model: default priors as compile-time constants / read at run time
             # (a single binary without asteroseismic terms takes the one-star-per-lane kernel unless told otherwise)
             pair = kind == "iso" and ns == 2 and not astero
+            triple = kind == "iso" and ns == 3 and not astero
             with env(ISOCHRONES_AMD_SAMPLER="persistent", ISOCHRONES_AMD_STAR_LANES="0"), traced(tid) as t:
                 check_sampler(mod, oic, p0, 16, 10, 78 + nb, tid + " persistent std priors")
             # (asteroseismic models: one persistent form, priors read at run time)
@@ -347,6 +348,18 @@ def test_fused_families(kind, ns, nb):
                 with env(ISOCHRONES_AMD_SAMPLER="persistent", ISOCHRONES_AMD_STD_PRIORS="0", ISOCHRONES_AMD_STAR_LANES=None), traced(tid) as t:
                     check_sampler(mod, oic, p0, 16, 10, 179 + nb, tid + " one star per lane, run-time priors")
                 expect(t.names, "k_stretch_pair<%d, false>" % nb, tid)
+            if triple:
+                # one star per ROW of a wave (k_stretch_triple): 8 moves per half-step (half a row), 75 (two chunks of 64, the
+                # second one partly filled), 150 (the reference's default 300 walkers: three chunks)
+                for W in ((16, 150) if nb % 3 else (16, 300)):
+                    pw = start_ball(rng, mod, kind, ns, W)
+                    with env(ISOCHRONES_AMD_SAMPLER="persistent", ISOCHRONES_AMD_STAR_LANES=None), traced(tid) as t:
+                        check_sampler(mod, oic, pw, W, 6, 378 + nb + W, tid + " one star per row, std priors, W=%d" % W)
+                    expect(t.names, "k_stretch_triple<%d, true>" % nb, tid)
+                with env(ISOCHRONES_AMD_SAMPLER="persistent", ISOCHRONES_AMD_STD_PRIORS="0", ISOCHRONES_AMD_STAR_LANES=None), traced(tid) as t:
+                    check_sampler(mod, oic, p0, 16, 10, 379 + nb, tid + " one star per row, run-time priors")
+                    check_sampler(mod, oic, p0, 16, 6, 380 + nb, tid + " one star per row, three ensembles", n_ensembles=3)
+                expect(t.names, "k_stretch_triple<%d, false>" % nb, tid)
             if not astero:
                 # register-capped form with a single model (many ensembles of one star run it in rounds)
                 # (default priors: the register-capped form with the families compiled in; read at run time when told so)
@@ -383,6 +396,10 @@ def test_fused_families(kind, ns, nb):
                 with env(ISOCHRONES_AMD_SAMPLER="persistent", ISOCHRONES_AMD_STAR_LANES=None), traced(tid) as t:
                     check_sampler(mod, oic, p0, 16, 10, 279 + nb, w + " one star per lane")
                 expect(t.names, "k_stretch_pair<%d, false>" % nb, tid)
+            if kind == "iso" and ns == 3 and not astero:
+                with env(ISOCHRONES_AMD_SAMPLER="persistent", ISOCHRONES_AMD_STAR_LANES=None), traced(tid) as t:
+                    check_sampler(mod, oic, p0, 16, 10, 289 + nb, w + " one star per row")
+                expect(t.names, "k_stretch_triple<%d, false>" % nb, tid)
             if not astero:
                 with env(ISOCHRONES_AMD_SAMPLER="persistent-dense"), traced(tid) as t:
                     check_sampler(mod, oic, p0, 16, 8, 280 + nb, w + " persistent dense", n_ensembles=3)

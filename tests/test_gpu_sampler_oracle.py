@@ -327,3 +327,56 @@ def test_single_model_sampler_on_random_models_of_the_largest_shapes(n_stars, nb
         if done >= 8:
             break
     assert done >= 4
+
+
+@pytest.mark.parametrize("n_sys", [1, 2])
+def test_reference_shape_catalog_replayed_against_the_oracle(n_sys):
+    """The catalog the reference's `starfit` runs (starfit.py:86: MIST_Isochrone parametrisation; fit_mcmc's defaults
+    nwalkers=300, starmodel.py:889-893) through `fit_stars_gpu`'s OWN route: 200 stars x 300 walkers, so that
+    iso_sampler_run takes what it takes for the benchmark's reference-shape leg - the register-capped persistent kernel,
+    for single stars with the default prior families compiled in, workgroups of three waves (150 moves per half-step packed
+    64 + 64 + 22).  Every move of 20 of the stars over the sampling run is rebuilt on the host and evaluated by the oracle
+    with that star's own model (tests/_replay.py) - HIP against the oracle, not HIP against HIP; the same for a catalog
+    of binaries (N = 2)."""
+    import torch
+    from isochrones_amd import _cabi
+    from isochrones_amd.catalog import fit_stars_gpu
+    n_stars, W, nburn, niter = 200, 300, 20, 30
+    bands = ["G", "BP", "RP"]
+    ic = ia.synthetic_isochrone(bands=bands)
+    cat, _ = ia.synthetic_catalog(ic, n_stars, bands=bands, seed=17 + n_sys, mag_unc=0.01)
+    rec = {}
+    _cabi.trace_kernels(True)
+    try:
+        rows, chain, lnps = fit_stars_gpu(cat, ic, np.arange(n_stars), N=n_sys, nwalkers=W, nburn=nburn, niter=niter, seed=5,
+                                          return_chains=True, replay_record=rec)
+        names = _cabi.traced_kernels()
+        plan = _cabi.last_sampler_plan()
+    finally:
+        _cabi.trace_kernels(False)
+    D = n_sys + 4
+    assert chain.shape == (n_stars, W, niter, D)
+    # the launch the reference-shape leg of bench.py measures: register-capped persistent form, three-wave workgroups
+    stretch = [k for k in names if k.startswith("k_stretch")]
+    want = ("k_stretch_persist<1, %d, 3, true, false, false, %s>" % (n_sys, "true" if n_sys == 1 else "false"))
+    assert stretch == [want], stretch
+    assert plan["persistent"] == 1 and plan["dense"] == 1 and plan["threads"] == 192, plan
+    assert plan["dense_stdp"] == (1 if n_sys == 1 else 0), plan
+    good = np.flatnonzero(~rec["failed"].cpu().numpy())
+    assert good.size >= 0.9 * n_stars
+    pick = np.sort(np.random.default_rng(3).choice(good, 20, replace=False))
+    descs = [cat.model(int(s), ic, N=n_sys).model_desc() for s in pick]
+    fn = _oracle_fn(ic, descs)
+    sel = torch.as_tensor(pick, device=chain.device)
+    # start points (k_catalog_start at 300 walkers) and the ensembles burn-in left: the oracle's lnpost
+    p_start = rec["start_pos"][sel].reshape(-1, D).cpu().numpy()
+    fx.assert_close(rec["start_lnp"][sel].reshape(-1).cpu().numpy(), fn(np.repeat(np.arange(20), W), p_start), 1e-9, atol=1e-10,
+                    what="start points")
+    p0 = rec["pos"][sel].reshape(-1, D).cpu().numpy()
+    l0 = rec["lnp"][sel].reshape(-1).cpu().numpy()
+    fx.assert_close(l0, fn(np.repeat(np.arange(20), W), p0), 1e-9, atol=1e-10, what="state after burn-in")
+    ch = chain[sel].permute(2, 0, 1, 3).reshape(niter, 20 * W, D).cpu().numpy()         # [T, B * W, D]
+    cl = lnps[sel].permute(2, 0, 1).reshape(niter, 20 * W).cpu().numpy()
+    st = _replay.replay(p0, l0, ch, cl, W, 2.0, rec["seed"], rec["step0"], fn, star_of_block=pick, lnp_atol=1e-9)
+    assert st["moves"] == 20 * W * niter and st["accepted"] > 0.05 * st["moves"] and st["near_ties"] <= 2, st
+    ic.release()

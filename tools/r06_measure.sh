@@ -1,0 +1,55 @@
+# Round-6 measurements on the GPU box (one script, parametrised by stage): bash tools/r06_measure.sh <stage> [...]
+#   triple     the one-star-per-row sampler of triples: dispatch-table tests of the iso3 family + time per step by shape
+#   replay     the reference-shape catalog (300 walkers, isochrones; singles and binaries) replayed against the oracle
+#   tree       tree evaluator: tests of the tree kernels + fits (resolved binary 256 x 5 000) + batch kernel timing
+#   tests      dispatch-table closure + sampler tests
+#   suite      the whole GPU suite
+#   fits       bench_configs fits,cfg4,tree; mailbox / scalar latency
+#   bench      bench.py default line + the driver's arguments
+#   shapes     one star's fit by model shape, catalog fit by size
+#   prof       rocprofv3 --kernel-trace --stats of bench.py and of the fits
+# Results under gpurun_out/r06/ (copy what should be judged into profiles/r06/).
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/r06
+mkdir -p $OUT
+for stage in "$@"; do
+case $stage in
+triple)
+  timeout 1500 python -m pytest tests/test_gpu_dispatch_table.py -q -x -k "iso-3 or iso3" 2>&1 | tail -15 | tee $OUT/pytest_triple.txt
+  SHAPES=iso:2:6,iso:3:3,iso:3:6,iso:3:9,iso:3:12 python tools/single_fit_shapes.py 2>/dev/null | grep "^{" > $OUT/single_fit_shapes_triple.jsonl; cut -c1-200 $OUT/single_fit_shapes_triple.jsonl
+  SHAPES=iso:3:9 ISOCHRONES_AMD_STAR_LANES=0 python tools/single_fit_shapes.py 2>/dev/null | grep "^{" > $OUT/single_fit_shapes_triple_off.jsonl; cut -c1-200 $OUT/single_fit_shapes_triple_off.jsonl
+  SHAPES=iso:3:9 python tools/single_fit_shapes.py 300 2000 2>/dev/null | grep "^{" >> $OUT/single_fit_shapes_triple.jsonl; tail -1 $OUT/single_fit_shapes_triple.jsonl | cut -c1-200
+  SHAPES=iso:3:9 ISOCHRONES_AMD_STAR_LANES=0 python tools/single_fit_shapes.py 300 2000 2>/dev/null | grep "^{" >> $OUT/single_fit_shapes_triple_off.jsonl; tail -1 $OUT/single_fit_shapes_triple_off.jsonl | cut -c1-200 ;;
+replay)
+  timeout 1500 python -m pytest tests/test_gpu_sampler_oracle.py -q -x -k "reference_shape" 2>&1 | tail -15 | tee $OUT/pytest_replay.txt ;;
+tree)
+  timeout 1500 python -m pytest tests/test_gpu_sampler_any.py tests/test_gpu_dispatch_table.py -q -x -k "tree or Tree" 2>&1 | tail -15 | tee $OUT/pytest_tree.txt
+  python bench_configs.py --configs fits,tree > $OUT/bench_configs_fits.jsonl 2> $OUT/bench_configs_fits.err; tail -c 2500 $OUT/bench_configs_fits.jsonl ;;
+tests)
+  timeout 2400 python -m pytest tests/test_gpu_dispatch_table.py tests/test_gpu_sampler_any.py -q 2>&1 | tail -15 | tee $OUT/pytest_dispatch_and_any.txt ;;
+suite)
+  timeout 3000 python -m pytest tests -m gpu -q 2>&1 | tail -8 | tee $OUT/pytest_gpu_suite.txt ;;
+fits)
+  python bench_configs.py --configs fits,cfg4,tree > $OUT/bench_configs_fits.jsonl 2> $OUT/bench_configs_fits.err; tail -c 2500 $OUT/bench_configs_fits.jsonl
+  python tools/mailbox_latency.py 2>&1 | grep -v amdgpu.ids | tee $OUT/mailbox_latency.txt
+  python tools/scalar_latency.py 2>&1 | grep -v amdgpu.ids | head -9 | tee $OUT/scalar_latency.txt ;;
+bench)
+  python bench.py > $OUT/bench_cfg2_1gpu.json 2> $OUT/bench.err; head -c 1500 $OUT/bench_cfg2_1gpu.json
+  python bench.py --steps 20 --warmup 5 > $OUT/bench_cfg2_1gpu_driver_args.json 2>> $OUT/bench.err ;;
+shapes)
+  python tools/single_fit_shapes.py 2>/dev/null | grep "^{" > $OUT/single_fit_shapes.jsonl; tail -3 $OUT/single_fit_shapes.jsonl | cut -c1-300
+  python tools/catalog_sizes.py --sizes 313,625,1250,2500,5000,10000 2>/dev/null | grep "^{" > $OUT/catalog_sizes.jsonl; tail -2 $OUT/catalog_sizes.jsonl | cut -c1-300 ;;
+prof)
+  cd /tmp && export TMPDIR=/tmp
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python $ROOT/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-extras > $OUT/bench_profiled_run.json 2> $OUT/prof.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_fits -- python $ROOT/bench_configs.py --configs fits,cfg4 > $OUT/prof_fits.jsonl 2> $OUT/prof_fits.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_catalog -- python $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/prof_catalog.json 2> $OUT/prof_catalog.err
+  cd $ROOT
+  for d in prof prof_fits prof_catalog; do
+    f=$(find $OUT/$d -name "*kernel_stats.csv" | head -1)
+    [ -n "$f" ] && cp "$f" $OUT/kernel_stats_$d.csv
+    find $OUT/$d -name "*.csv" -size +1M -delete
+  done
+  head -5 $OUT/kernel_stats_prof.csv; head -12 $OUT/kernel_stats_prof_fits.csv; head -16 $OUT/kernel_stats_prof_catalog.csv ;;
+esac
+done
