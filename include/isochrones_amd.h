@@ -303,6 +303,13 @@ int  iso_catalog_lnpost(iso_catalog* c, const int32_t* star_id, const double* pa
 int  iso_catalog_start_points(iso_catalog* c, int nwalkers, int oversample, int max_tries, uint64_t seed, double* best,
                               double* best_lnp, int32_t* failed, void* stream);
 
+/* A catalog fit keeps its batch rectangular without a host round trip: every star with failed[s] != 0 (its start-point search
+ * found fewer than nwalkers finite candidates) gets the walkers of the batch's first good star and lnpost 0 - on its own
+ * posterior those walkers never move, and the caller blanks its result row (the reference isolates a failing star with
+ * try / except around its fit, isochrones/starfit.py:155-159).  pos [S][nwalkers][n_params], lnp [S][nwalkers], failed [S]: DEVICE
+ * arrays as iso_catalog_start_points wrote them.  With no good star at all the positions stay NaN. */
+int  iso_catalog_patch_failed(iso_catalog* c, int nwalkers, double* pos, double* lnp, const int32_t* failed, void* stream);
+
 /* Generic (observation-tree) StarModel: lnpost / lnprior / lnlike of starmodel.py:538-613 +
  * observation.py:1181-1234.  Outputs as iso_lnpost; lnlike is -inf (never NaN) when not finite,
  * as the reference. */

@@ -101,7 +101,7 @@ EXPORTED_SYMBOLS = (
     "iso_model_create", "iso_model_destroy", "iso_model_n_params", "iso_model_kernel_path",
     "iso_axis_bracket_host", "iso_debug_trace_kernels", "iso_debug_kernels", "iso_debug_sampler_plan",
     "iso_lnpost", "iso_lnpost_host", "iso_unit_cube", "iso_time_lnpost", "iso_time_lnpost_rotating",
-    "iso_catalog_create", "iso_catalog_create_columns", "iso_catalog_destroy", "iso_catalog_lnpost", "iso_catalog_start_points",
+    "iso_catalog_create", "iso_catalog_create_columns", "iso_catalog_destroy", "iso_catalog_lnpost", "iso_catalog_start_points", "iso_catalog_patch_failed",
     "iso_eep_table_create", "iso_eep_table_destroy", "iso_interp_eep", "iso_interp_eep_host",
     "iso_sampler_create_model", "iso_sampler_create_model_ensembles", "iso_sampler_create_catalog", "iso_sampler_destroy", "iso_sampler_run",
     "iso_sampler_create_tree", "iso_sampler_create_isotrack",
@@ -211,6 +211,8 @@ def lib():
     L.iso_catalog_lnpost.argtypes = [vp, pd, pd, i64, i64, i64, pd, vp]
     if hasattr(L, "iso_catalog_start_points"):
         L.iso_catalog_start_points.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_uint64, pd, pd, pd, vp]
+    if hasattr(L, "iso_catalog_patch_failed"):
+        L.iso_catalog_patch_failed.argtypes = [vp, C.c_int, pd, pd, pd, vp]
     L.iso_eep_table_create.argtypes = [vp, C.POINTER(dbl), C.POINTER(i64), C.POINTER(dbl), i64, C.POINTER(dbl), i64,
                                        i64, dbl, C.POINTER(vp)]
     L.iso_eep_table_destroy.argtypes = [vp]
@@ -237,7 +239,7 @@ def lib():
     L.iso_tree_lnpost.argtypes = [vp, pd, i64, i64, i64, pd, pd, pd, vp]
     L.iso_tree_lnpost_host.argtypes = [vp, C.POINTER(dbl), i64, C.POINTER(dbl), C.POINTER(dbl), C.POINTER(dbl)]
     for name in EXPORTED_SYMBOLS:
-        if (name.startswith("iso_debug_") or name == "iso_catalog_start_points") and not hasattr(L, name) and os.environ.get("ISOCHRONES_AMD_LIB"):
+        if (name.startswith("iso_debug_") or name in ("iso_catalog_start_points", "iso_catalog_patch_failed")) and not hasattr(L, name) and os.environ.get("ISOCHRONES_AMD_LIB"):
             continue                                   # a variant library built from an older source state
         fn = getattr(L, name)
         if fn.restype is C.c_int:

@@ -543,33 +543,42 @@ def fit_stars_gpu(catalog: StarCatalog, ic, indices, N=1, nwalkers=32, nburn=150
     pos, lnp, failed = initial_positions(post, nwalkers, rng_seed=seed)
     _mark("initial_positions")
     good = ~failed
-    if not bool(good.any()):
-        # no star of the batch found a start point: nothing to sample, every row reports ok = 0
-        post.close()
-        out = np.full((post.n_models, 3 * D + 3), np.nan)
-        out[:, 3 * D + 2] = 0.0
-        if return_chains:
-            raise ValueError("no star of the batch has a start point with a finite lnpost")
-        return out
-    # failed stars get a copy of a good star's walkers so the batch stays rectangular
-    if bool(failed.any()) and bool(good.any()):
-        src = int(torch.nonzero(good)[0])
-        pos[failed] = pos[src]
-        lnp[failed] = lnp[src]
+    lean = fused and hasattr(_cabi.lib(), "iso_catalog_patch_failed")
+    if lean:
+        # the whole fit stays on the stream: failed stars borrow the first good star's walkers with lnpost 0 (one small
+        # launch instead of three device-to-host round trips and a dozen indexing launches), no start point is tested on the
+        # host, and a batch without any good star shows up as rows that all say ok = 0
+        fi = failed.to(torch.int32)
+        _cabi.check(_cabi.lib().iso_catalog_patch_failed(post._h, int(nwalkers), dev.ptr(pos), dev.ptr(lnp), dev.ptr(fi),
+                                                         dev.stream_ptr(post.device)))
+    else:
+        if not bool(good.any()):
+            # no star of the batch found a start point: nothing to sample, every row reports ok = 0
+            post.close()
+            out = np.full((post.n_models, 3 * D + 3), np.nan)
+            out[:, 3 * D + 2] = 0.0
+            if return_chains:
+                raise ValueError("no star of the batch has a start point with a finite lnpost")
+            return out
+        # failed stars get a copy of a good star's walkers so the batch stays rectangular
+        if bool(failed.any()) and bool(good.any()):
+            src = int(torch.nonzero(good)[0])
+            pos[failed] = pos[src]
+            lnp[failed] = lnp[src]
     if fused:
         from .sampler import FusedEnsembleSampler
-        if bool(failed.any()) and bool(good.any()):
+        if not lean and bool(failed.any()) and bool(good.any()):
             # a failed star keeps its own (hopeless) posterior: its borrowed walkers simply never move
             lnp = torch.where(failed[:, None], torch.zeros_like(lnp), lnp)
         sampler = FusedEnsembleSampler(post, nwalkers, seed=seed + 1)
         if replay_record is not None:
             replay_record.update(start_pos=pos.clone(), start_lnp=lnp.clone(), failed=failed.clone())
-        pos, lnp = sampler.run_mcmc(pos, nburn, lnprob0=lnp, store=False)
+        pos, lnp = sampler.run_mcmc(pos, nburn, lnprob0=lnp, store=False, check=not lean, inplace=lean)
         _mark("burn_in")
         if replay_record is not None:
             replay_record.update(pos=pos.clone(), lnp=lnp.clone(), seed=seed + 1, step0=int(nburn))
         sampler.reset()
-        sampler.run_mcmc(pos, niter, lnprob0=lnp, store=True)
+        sampler.run_mcmc(pos, niter, lnprob0=lnp, store=True, check=not lean, inplace=lean)
         _mark("sampling")
         chain, lnps = sampler.chain, sampler.lnprobability        # [S, W, niter, D], [S, W, niter]
         acc_frac = sampler.acceptance_fraction.mean(dim=1)
@@ -611,6 +620,9 @@ def fit_stars_gpu(catalog: StarCatalog, ic, indices, N=1, nwalkers=32, nburn=150
     out = rows.cpu().numpy()
     _mark("summaries")
     if return_chains:
+        if not out[:, 3 * D + 2].any():
+            post.close()
+            raise ValueError("no star of the batch has a start point with a finite lnpost")
         kept = (chain.clone(), lnps.clone())
         post.close()
         return out, kept[0], kept[1]

@@ -90,7 +90,8 @@ inline PersistKernel persist_kernel(const StretchArgs& S)
             const int64_t n_ens = S.n_active / (S.W >> 1);
             const int GL = persist_group(S.W);
             const int G = (S.group > 0 && S.group < GL) ? S.group : GL;
-            if (S.pair && (n_ens + G - 1) / G <= 512) {
+            const int64_t moves = (n_ens < G ? n_ens : G) * (S.W >> 1);
+            if (S.pair && moves <= S.triple_moves && (n_ens + G - 1) / G <= 512) {
                 k.fn = stdp ? (const void*)k_stretch_triple<N, true> : (const void*)k_stretch_triple<N, false>;
                 k.dense = false;
                 snprintf(k.name, sizeof k.name, "k_stretch_triple<%d, %s>", N, tf(stdp));
@@ -128,6 +129,10 @@ inline bool launch_stretch_nb(int nb, const FastArgs& A, const StretchArgs& S, h
         // with S.occupancy_query set: report resident workgroups per CU of this instantiation, launch nothing
         // (three-wave workgroups: only the register-capped form reads its thread count from the launch, sampler.h)
         const int threads = (k.dense && S.threads > 0) ? S.threads : BLOCK;
+        // beyond the 64 KB a launch gets without asking (a 256-walker triple with nine bands: 67 KB; the CU has 160)
+        if (lds_bytes > 64 * 1024 &&
+            (lds_bytes > 160 * 1024 || hipFuncSetAttribute(k.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess))
+            return false;
         if (S.occupancy_query)
             return hipOccupancyMaxActiveBlocksPerMultiprocessor(S.occupancy_query, k.fn, threads, lds_bytes) == hipSuccess;
         note_kernel("%s", k.name);

@@ -291,6 +291,7 @@ __device__ __forceinline__ void persist_body(const FastArgs& A, const StretchArg
     int g = (int)threadIdx.x / per, kk = (int)threadIdx.x - g * per;
     bool mine = g < here;
     bool owns = true;
+    int pw_spread = 0;                                    // moves per wave when the moves are spread over the waves (below)
     if constexpr (PAIR) {
         // here * h <= BLOCK / 2 moves (the host's condition for this form): at most 32 per wave, in multiples of 16, in the
         // lower half of the wave; the upper half mirrors them for the companions
@@ -329,13 +330,16 @@ __device__ __forceinline__ void persist_body(const FastArgs& A, const StretchArg
         mine = ((int)threadIdx.x & 63) < pw && a < total;
         g = mine ? a / h : 0;
         kk = mine ? a - g * h : 0;
+        pw_spread = pw;
     }
     const int gs = mine ? g : 0;                          // idle lanes shadow a move of the first ensemble
     // When every ensemble of this workgroup lies inside one wavefront (W/2 divides 64 and the plain lane mapping is in
     // use), a half-step only depends on LDS rows its own wave wrote: the waves then need no workgroup barrier between
     // half-steps and run through the iterations independently - a wave that waits for memory no longer holds up the
     // other three.  (LDS operations of one wave complete in order; the fence keeps the compiler from moving them.)
-    const bool wave_local = !PAIR && !TRIPLE && h <= 64 && (64 % h) == 0 && !(h < NT && here * h < NT);
+    // (Round 6: the same holds when the moves of a partly filled workgroup are spread over its waves in runs that are whole
+    // ensembles - a small catalog at 32 walkers, four stars per workgroup: one star per wave.)
+    const bool wave_local = !PAIR && !TRIPLE && h <= 64 && (pw_spread > 0 ? (pw_spread % h) == 0 : ((64 % h) == 0 && !(h < NT && here * h < NT)));
     for (int it = 0; it < S.nsteps; ++it) {
         double* cp = S.chain_pos ? S.chain_pos + (int64_t)it * rows_total * NP + (r0 + gs * W) * S.chain_rs : nullptr;
         double* cl = S.chain_lnp ? S.chain_lnp + (int64_t)it * rows_total + r0 + gs * W : nullptr;

@@ -104,10 +104,12 @@ struct TreeLeaves {
 #ifndef ISO_TREE_BANDMAJOR
 #define ISO_TREE_BANDMAJOR 1
 #endif
-// terms evaluated side by side in the band-major likelihood (independent logarithms for the scheduler to interleave; a slot
-// beyond a band's last term repeats that term and adds nothing)
+// terms evaluated side by side in the band-major likelihood (a slot beyond a band's last term repeats that term and adds
+// nothing).  Measured (profiles/r06/tree_ab.txt; resolved binary, 256 walkers x 5 000 / 10^6-row batch): term-major with
+// exits 26.0-26.3 us per step / 112.6-114.8 us, band-major one term at a time 25.2-25.3 / 111.1-112.9, two at a time
+// 26.6 / 113.7-116.5 (87 -> 122 registers in the batch kernel): one.
 #ifndef ISO_TREE_TERM_UNROLL
-#define ISO_TREE_TERM_UNROLL 2
+#define ISO_TREE_TERM_UNROLL 1
 #endif
 
 // sum of the photometric terms of bands B .. NB - 1 (compile-time recursion over the band)

@@ -36,6 +36,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 // ======================================================================================
@@ -102,6 +103,7 @@ namespace {
 #include "kernels/k_lnpost_tree.h"
 #include "kernels/k_chain_quantiles.h"
 #include "kernels/k_small_and_pack.h"
+#include "kernels/k_service.h"
 
 // ======================================================================================
 // host helpers
@@ -353,10 +355,16 @@ int ensure_wide_pack(iso_table* t, int64_t n)
 }  // namespace
 
 namespace {
+// the resident service wave of the scalar accessors (defined with the *_host entry points below)
+void service_stop(iso_ctx* ctx, bool release);
+void service_forget(const void* key);
 void free_mag_pack(MagPack& mp);
 int acquire_mag_pack(iso_ic* ic, const int32_t* bc_cols, int nb, int64_t n, iso::FastArgs& F);
 hipError_t acquire_band_pack(iso_ic* ic, const int32_t* bc_cols, int nb, std::shared_ptr<BandPack>* out, bool* ok);
 }  // namespace
+
+// dynamic LDS a persistent sampler workgroup may ask for (a CU's whole LDS)
+static constexpr size_t PERSIST_LDS_MAX = 160 * 1024;
 
 // ---- test hook: which kernel instantiations the launchers chose (iso_debug_trace_kernels / iso_debug_kernels) ----------
 namespace iso {
@@ -438,6 +446,10 @@ int iso_ctx_create(iso_ctx** out, int device)
 void iso_ctx_destroy(iso_ctx* ctx)
 {
     if (!ctx) return;
+    {
+        DeviceGuard guard(ctx->device);
+        service_stop(ctx, true);
+    }
     if (ctx->h_stage) {
         DeviceGuard guard(ctx->device);
         (void)hipHostFree(ctx->h_stage);
@@ -501,6 +513,8 @@ void iso_table_destroy(iso_table* t)
 {
     if (!t) return;
     DeviceGuard guard(t->device);
+    service_stop(t->ctx, false);     // a resident service wave may have this table's axes staged / be reading it
+    service_forget(t);
     if (t->d_grid) (void)hipFree(t->d_grid);
     if (t->d_wide) (void)hipFree(t->d_wide);
     for (int d = 0; d < ISO_MAX_DIM; ++d)
@@ -681,6 +695,8 @@ void iso_ic_destroy(iso_ic* ic)
 {
     if (!ic) return;
     DeviceGuard guard(ic->device);
+    service_stop(ic->ctx, false);
+    service_forget(ic);
     if (ic->d_hot) (void)hipFree(ic->d_hot);
     if (ic->d_hotq) (void)hipFree(ic->d_hotq);
     if (ic->d_astq) (void)hipFree(ic->d_astq);
@@ -1677,6 +1693,8 @@ void iso_eep_table_destroy(iso_eep_table* t)
 {
     if (!t) return;
     DeviceGuard guard(t->device);
+    service_stop(t->ctx, false);
+    service_forget(t);
     if (t->d_ages) (void)hipFree(t->d_ages);
     if (t->d_lengths) (void)hipFree(t->d_lengths);
     if (t->d_ax0) (void)hipFree(t->d_ax0);
@@ -1710,6 +1728,177 @@ int iso_interp_eep(iso_eep_table* t, const double* x, const double* x0, const do
     HIP_TRY(hipGetLastError());
     return ISO_OK;
 }
+
+
+// ---- the scalar accessors through the context's resident service wave (kernels/k_service.h) ------------------------------------
+// ISOCHRONES_AMD_MAILBOX=0 keeps every call on the launch path (as for the per-point lnpost callback).
+namespace {
+struct SvcTargetRec {
+    SvcTarget* d_target;
+    unsigned long long uid;
+};
+struct iso_service {
+    IsoSvcBox* box = nullptr;      // pinned, device-mapped
+    IsoSvcBox* d_box = nullptr;
+    hipStream_t stream = nullptr;
+    unsigned long long count = 0;
+    int state = 0;                 // 0 untried, 1 usable, -1 not available
+};
+std::mutex g_svc_mu;                                             // guards the two maps below (calls are serialised per context
+std::unordered_map<iso_ctx*, iso_service*> g_services;           // by ctx->stage_mu, which every *_host entry point holds)
+std::unordered_map<const void*, SvcTargetRec> g_svc_targets;     // iso_table* / iso_ic* / iso_eep_table* -> its device record
+std::atomic<unsigned long long> g_svc_uid{1};
+
+inline unsigned long long svc_host_load(const volatile unsigned long long* p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
+
+bool service_enabled()
+{
+    const char* e = std::getenv("ISOCHRONES_AMD_MAILBOX");
+    return !(e && e[0] == '0');
+}
+
+iso_service* service_of(iso_ctx* ctx)
+{
+    std::lock_guard<std::mutex> lock(g_svc_mu);
+    iso_service*& sv = g_services[ctx];
+    if (!sv) sv = new iso_service();
+    if (sv->state != 0) return sv->state > 0 ? sv : nullptr;
+    sv->state = -1;
+    if (hipHostMalloc(reinterpret_cast<void**>(&sv->box), sizeof(IsoSvcBox), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+        (void)hipGetLastError();
+        sv->box = nullptr;
+        return nullptr;
+    }
+    std::memset(sv->box, 0, sizeof(IsoSvcBox));
+    sv->box->ctl[0] = 2;                                         // no wave yet
+    if (hipHostGetDevicePointer(reinterpret_cast<void**>(&sv->d_box), sv->box, 0) != hipSuccess ||
+        hipStreamCreateWithFlags(&sv->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipFuncSetAttribute((const void*)k_service, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(ISO_SVC_LDS_DOUBLES * sizeof(double))) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipHostFree(sv->box);
+        sv->box = nullptr;
+        return nullptr;
+    }
+    sv->state = 1;
+    return sv;
+}
+
+bool service_launch(iso_service* sv)
+{
+    double idle_us = 1000.0;
+    if (const char* e = std::getenv("ISOCHRONES_AMD_MAILBOX_IDLE_US")) idle_us = std::max(10.0, std::atof(e));
+    const unsigned long long idle = (unsigned long long)(idle_us * 1e-6 * 1.0e8);       // wall_clock64(): 100 MHz
+    const unsigned long long life = (unsigned long long)(30.0 * 1.0e8);
+    __atomic_store_n(&sv->box->ctl[1], 0ull, __ATOMIC_RELAXED);
+    __atomic_store_n(&sv->box->ctl[0], 1ull, __ATOMIC_RELEASE);
+    note_kernel("k_service");
+    hipLaunchKernelGGL(k_service, dim3(1), dim3(64), (size_t)ISO_SVC_LDS_DOUBLES * sizeof(double), sv->stream, sv->d_box, idle, life);
+    if (hipGetLastError() != hipSuccess) {
+        __atomic_store_n(&sv->box->ctl[0], 2ull, __ATOMIC_RELEASE);
+        return false;
+    }
+    return true;
+}
+
+// ask the context's wave to leave and wait until it has; `release` frees the mailbox
+void service_stop(iso_ctx* ctx, bool release)
+{
+    iso_service* sv = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_svc_mu);
+        auto it = g_services.find(ctx);
+        if (it == g_services.end()) return;
+        sv = it->second;
+        if (release) g_services.erase(it);
+    }
+    if (sv->box) {
+        if (svc_host_load(&sv->box->ctl[0]) == 1) __atomic_store_n(&sv->box->ctl[1], 1ull, __ATOMIC_RELEASE);
+        (void)hipStreamSynchronize(sv->stream);
+    }
+    if (release) {
+        if (sv->box) {
+            (void)hipStreamDestroy(sv->stream);
+            (void)hipHostFree(sv->box);
+        }
+        delete sv;
+    }
+}
+
+// the device record of a target (created on first use); 0 = could not be created
+bool service_target(const void* key, const SvcTarget& host, SvcTargetRec* out)
+{
+    std::lock_guard<std::mutex> lock(g_svc_mu);
+    auto it = g_svc_targets.find(key);
+    if (it != g_svc_targets.end()) {
+        *out = it->second;
+        return true;
+    }
+    SvcTargetRec rec;
+    rec.uid = g_svc_uid.fetch_add(1);
+    SvcTarget h = host;
+    h.uid = rec.uid;
+    if (hipMalloc(reinterpret_cast<void**>(&rec.d_target), sizeof(SvcTarget)) != hipSuccess ||
+        hipMemcpy(rec.d_target, &h, sizeof(SvcTarget), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    g_svc_targets[key] = rec;
+    *out = rec;
+    return true;
+}
+
+// (before the object's tables are freed)
+void service_forget(const void* key)
+{
+    SvcTargetRec rec{nullptr, 0};
+    {
+        std::lock_guard<std::mutex> lock(g_svc_mu);
+        auto it = g_svc_targets.find(key);
+        if (it == g_svc_targets.end()) return;
+        rec = it->second;
+        g_svc_targets.erase(it);
+    }
+    (void)hipFree(rec.d_target);      // (a device-wide wait: a resident wave has left by its idle time-out)
+}
+
+// one request; ISO_OK, or 1 = not served (the caller launches instead).  Caller holds ctx->stage_mu.
+int service_call(iso_ctx* ctx, int op, const SvcTargetRec& tgt, const double* x, int nx, const int32_t* cols, int k, double* out,
+                 int nout)
+{
+    iso_service* sv = service_of(ctx);
+    if (!sv) return 1;
+    IsoSvcBox* mb = sv->box;
+    unsigned long long words[15];
+    std::memset(words, 0, sizeof words);
+    words[0] = (unsigned long long)(uintptr_t)tgt.d_target;
+    words[1] = tgt.uid;
+    for (int q = 0; q < nx; ++q) std::memcpy(&words[2 + q], x + q, 8);
+    for (int c = 0; c < k; ++c) words[7 + (c >> 3)] |= (unsigned long long)(cols[c] & 0xFF) << (8 * (c & 7));
+    const unsigned long long seq = ((unsigned long long)mailbox_checksum(words, 15) << 32) | ((++sv->count & 0xFFFFull) << 16) |
+                                   ((unsigned long long)k << 8) | (unsigned long long)op;
+    for (int q = 0; q < 15; ++q) __atomic_store_n(&mb->req[1 + q], words[q], __ATOMIC_RELAXED);
+    __atomic_store_n(&mb->req[0], seq, __ATOMIC_RELEASE);        // the sequence word last
+    if (svc_host_load(&mb->ctl[0]) != 1 && !service_launch(sv)) return 1;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint64_t spins = 1; svc_host_load(&mb->done[0]) != seq; ++spins) {
+        if ((spins & 255) == 0) {
+            if (svc_host_load(&mb->ctl[0]) == 2 && svc_host_load(&mb->done[0]) != seq) {
+                if (!service_launch(sv)) return 1;               // the wave left between our look at its state and its last poll
+            } else if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
+                __atomic_store_n(&mb->ctl[1], 1ull, __ATOMIC_RELEASE);
+                (void)hipStreamSynchronize(sv->stream);
+                sv->state = -1;
+                return 1;
+            }
+        }
+    }
+    for (int q = 0; q < nout; ++q) {
+        const unsigned long long w = __atomic_load_n(reinterpret_cast<unsigned long long*>(&mb->out[q]), __ATOMIC_RELAXED);
+        std::memcpy(out + q, &w, 8);
+    }
+    return ISO_OK;
+}
+}  // namespace
 
 namespace {
 // the context's pinned, device-mapped staging area (host view + device view); caller holds ctx->stage_mu
@@ -1767,6 +1956,31 @@ int iso_interp_host(iso_table* t, const double* x, int64_t n, const int32_t* ico
     if (n == 0) return ISO_OK;
     DeviceGuard guard(t->device);
     std::lock_guard<std::mutex> lock(t->ctx->stage_mu);
+    if (n == 1 && k <= ISO_SVC_MAX_COLS && t->shape[t->ndim] <= 256 && service_enabled()) {
+        // one point: the context's resident service wave - no launch (kernels/k_service.h)
+        bool cols_ok = true;
+        for (int c = 0; c < k; ++c) cols_ok = cols_ok && icols[c] >= 0 && icols[c] < t->shape[t->ndim];
+        if (!cols_ok) return fail(ISO_ERR_INVALID, "iso_interp: column index out of range");
+        SvcTarget T;
+        std::memset(&T, 0, sizeof T);
+        T.op = ISO_SVC_INTERP;
+        T.ndim = t->ndim;
+        for (int dd = 0; dd < ISO_MAX_DIM; ++dd) {
+            if (dd < t->ndim) T.I.ax[dd] = t->ax[dd];
+            T.I.ax[dd].lds_off = -1;
+        }
+        (void)assign_lds(T.I.ax, t->ndim, nullptr, 0);            // exactly as iso_interp stages them
+        int64_t st = 1;
+        for (int dd = t->ndim - 1; dd >= 0; --dd) {
+            T.I.stride[dd] = st;
+            st *= t->shape[dd];
+        }
+        T.I.grid = t->d_grid;
+        T.I.ncol = (int)t->shape[t->ndim];
+        SvcTargetRec rec;
+        if (service_target(t, T, &rec) && service_call(t->ctx, ISO_SVC_INTERP, rec, x, t->ndim, icols, k, out, k) == ISO_OK)
+            return ISO_OK;
+    }
     double *h = nullptr, *d = nullptr;
     int rc = ctx_stage(t->ctx, &h, &d);
     if (rc != ISO_OK) return rc;
@@ -1797,6 +2011,30 @@ int iso_interp_mag_host(iso_ic* ic, const double* pars, int64_t n, const int32_t
     if (n == 0) return ISO_OK;
     DeviceGuard guard(ic->device);
     std::lock_guard<std::mutex> lock(ic->ctx->stage_mu);
+    if (n == 1 && ic->g4.ncol <= 256 && service_enabled()) {
+        // one point: the context's resident service wave (the generic column-parallel evaluation, which is also what a
+        // one-point launch runs: no band pack is built for a small call)
+        if (nb > 0 && !bc_cols) return fail(ISO_ERR_INVALID, "iso_interp_mag: bc_cols is NULL");
+        for (int b = 0; b < nb; ++b)
+            if (bc_cols[b] < 0 || bc_cols[b] >= ic->g4.ncol) return fail(ISO_ERR_INVALID, "iso_interp_mag: band column out of range");
+        SvcTarget T;
+        std::memset(&T, 0, sizeof T);
+        T.op = ISO_SVC_MAG;
+        T.kind = ic->kind;
+        T.M.g3 = ic->g3;
+        T.M.g4 = ic->g4;
+        T.M.kind = ic->kind;
+        SvcTargetRec rec;
+        double o[3 + ISO_MAX_BANDS];
+        const int want = (mags && nb > 0) ? nb : 0;
+        if (service_target(ic, T, &rec) && service_call(ic->ctx, ISO_SVC_MAG, rec, pars, 5, bc_cols, want, o, 3 + want) == ISO_OK) {
+            if (Teff) Teff[0] = o[0];
+            if (logg) logg[0] = o[1];
+            if (feh) feh[0] = o[2];
+            for (int b = 0; b < want; ++b) mags[b] = o[3 + b];
+            return ISO_OK;
+        }
+    }
     double *h = nullptr, *d = nullptr;
     int rc = ctx_stage(ic->ctx, &h, &d);
     if (rc != ISO_OK) return rc;
@@ -1824,6 +2062,21 @@ int iso_interp_eep_host(iso_eep_table* t, const double* age, const double* feh, 
     if (n == 0) return ISO_OK;
     DeviceGuard guard(t->device);
     std::lock_guard<std::mutex> lock(t->ctx->stage_mu);
+    if (n == 1 && service_enabled()) {
+        SvcTarget T;
+        std::memset(&T, 0, sizeof T);
+        T.op = ISO_SVC_EEP;
+        T.E.ax[0] = t->ax[0];
+        T.E.ax[1] = t->ax[1];
+        T.E.ages = t->d_ages;
+        T.E.lengths = t->d_lengths;
+        T.E.n1 = (int)t->n1;
+        T.E.n_eep = t->n_eep;
+        T.E.eep0 = t->eep0;
+        SvcTargetRec rec;
+        const double xin[3] = {age[0], feh[0], mass[0]};
+        if (service_target(t, T, &rec) && service_call(t->ctx, ISO_SVC_EEP, rec, xin, 3, nullptr, 0, out, 1) == ISO_OK) return ISO_OK;
+    }
     double *h = nullptr, *d = nullptr;
     int rc = ctx_stage(t->ctx, &h, &d);
     if (rc != ISO_OK) return rc;
@@ -2045,6 +2298,18 @@ int iso_catalog_start_points(iso_catalog* c, int nwalkers, int oversample, int m
                               oversample, max_tries, seed, as_stream(stream)))
         return fail(ISO_ERR_INVALID, "iso_catalog_start_points: no kernel for this shape (more than 1024 walkers, or an "
                                          "ensemble whose records do not fit a CU's LDS)");
+    HIP_TRY(hipGetLastError());
+    return ISO_OK;
+}
+
+int iso_catalog_patch_failed(iso_catalog* c, int nwalkers, double* pos, double* lnp, const int32_t* failed, void* stream)
+{
+    if (!c || !pos || !lnp || !failed) return fail(ISO_ERR_INVALID, "iso_catalog_patch_failed: NULL argument");
+    if (nwalkers < 1) return fail(ISO_ERR_INVALID, "iso_catalog_patch_failed: nwalkers must be positive");
+    DeviceGuard guard(c->device);
+    note_kernel("k_catalog_patch_failed");
+    hipLaunchKernelGGL(k_catalog_patch_failed, dim3((unsigned)c->n_models), dim3(BLOCK), 0, as_stream(stream), pos, lnp, failed,
+                       c->n_models, nwalkers, c->n_stars + 4);
     HIP_TRY(hipGetLastError());
     return ISO_OK;
 }
@@ -2382,7 +2647,7 @@ int iso_sampler_create_model(iso_model* m, int nwalkers, double a, uint64_t seed
         // asteroseismic terms: the persistent kernel only (its step-wise twin was pruned - a single model's ensemble fits a
         // workgroup's LDS up to ~1 000 walkers), priors read at run time
         sp->std_priors = 0;
-        if (stretch_persist_lds(sp->n_bands, sp->fast.axes_len, sp->W, sp->n_params, nullptr) > 64 * 1024) {
+        if (stretch_persist_lds(sp->n_bands, sp->fast.axes_len, sp->W, sp->n_params, nullptr) > PERSIST_LDS_MAX) {
             delete sp;
             return fail(ISO_ERR_INVALID, "iso_sampler_create_model: an ensemble of this size does not fit the persistent kernel's LDS, and "
                                          "models with asteroseismic terms have no step-wise sampler kernel");
@@ -2507,6 +2772,8 @@ int iso_sampler_run(iso_sampler* sp, double* pos, double* lnp, int nsteps, doubl
     S.group = 0;
     S.threads = 0;
     S.dense_stdp = 0;
+    S.triple_moves = 64;  // ISOCHRONES_AMD_TRIPLE_MOVES: up to how many moves per half-step a single triple runs one star per row
+    if (const char* e = std::getenv("ISOCHRONES_AMD_TRIPLE_MOVES")) S.triple_moves = std::atoi(e);
     S.pair = 1;           // ISOCHRONES_AMD_STAR_LANES=0: a single binary's fit through the one-lane-walks-both-stars kernel (A/B, tests)
     if (const char* e = std::getenv("ISOCHRONES_AMD_STAR_LANES")) S.pair = std::atoi(e) != 0;
     S.pos = pos;
@@ -2537,7 +2804,10 @@ int iso_sampler_run(iso_sampler* sp, double* pos, double* lnp, int nsteps, doubl
     if (sp->fast.astq && mode == "stepwise") mode = "persistent";      // asteroseismic models have the persistent form only
     int group = 1;
     const size_t lds_bytes = stretch_persist_lds(sp->n_bands, sp->fast.axes_len, sp->W, sp->n_params, &group);
-    const bool fits = lds_bytes <= 64 * 1024;
+    // (up to the CU's 160 KB, asked for explicitly beyond 64 - fast/launch.h.  Until round 6 the limit here was 64 KB, and a
+    // 256-walker triple with nine bands - 67 KB with the LDS laid out for the two ensembles a workgroup of 128-move half-steps
+    // could hold - ran one launch per half-step: 55 us per step, the "triple latency" of round 5's review)
+    const bool fits = lds_bytes <= PERSIST_LDS_MAX;
     if (mode == "persistent" && !fits)
         return fail(ISO_ERR_INVALID, "iso_sampler_run: ensemble too large for the persistent kernel's LDS");
     // resident = workgroups the chip holds at once (occupancy of this kernel instantiation as the runtime reports it)

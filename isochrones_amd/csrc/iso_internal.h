@@ -180,6 +180,8 @@ struct StretchArgs {
     int threads;          // host side only, persistent register-capped form: threads per workgroup (0 = BLOCK; 192 for ensembles of
                           // 129 ... 192 moves per half-step, fast/sampler.h)
     int dense_stdp;       // host side only, persistent register-capped form: 1 = the instantiation with the default prior families compiled in
+    int triple_moves;     // host side only: a single triple takes the one-star-per-row kernel (k_stretch_triple) while a workgroup's
+                          // half-step has at most this many moves (0: never)
 };
 
 // the moves' side of a run of the any-model persistent sampler (fast/sampler_any.h)

@@ -23,6 +23,49 @@ struct InterpArgs {
 // loads and stores with no cross-lane reduction; the bracket search is repeated by the G lanes
 // (cheap: ~150 VALU against >= 1 KB of gathered table per sample).  k = 1, 2 degenerate to one lane
 // per sample.
+// One sample's share of one lane: columns c0 and c1 of the table at x (the 2^ND corners in the reference's order, bit
+// (ND-1-d) of j offsets axis d; interp.py:264-291, 309-336).  false = a NaN coordinate or a coordinate outside its axis
+// (the caller writes NaN).  Shared by the batch kernel below and the resident service wave (k_service.h): the same
+// instructions on the same inputs either way.
+template <int ND>
+__device__ __forceinline__ bool interp_point(const InterpArgs& A, const double* lds, const double* x, int c0, int c1, double& v0,
+                                             double& v1)
+{
+    bool bad = false;
+#pragma unroll
+    for (int d = 0; d < ND; ++d) bad |= (x[d] != x[d]);
+    if (!bad) {
+#pragma unroll
+        for (int d = 0; d < ND; ++d) bad |= out_of_axis(A.ax[d], lds, x[d]);
+    }
+    if (bad) return false;
+    double t[ND];
+    int64_t base = 0;
+#pragma unroll
+    for (int d = 0; d < ND; ++d) {
+        int idx;
+        bracket(A.ax[d], lds, x[d], idx, t[d]);
+        base += (int64_t)idx * A.stride[d];
+    }
+    v0 = 0.0;
+    v1 = 0.0;
+#pragma unroll
+    for (int j = 0; j < (1 << ND); ++j) {
+        double ww = 1.0;
+        int64_t oo = base;
+#pragma unroll
+        for (int d = 0; d < ND; ++d) {
+            const int bit = (j >> (ND - 1 - d)) & 1;
+            ww *= bit ? t[d] : (1 - t[d]);
+            oo += bit ? A.stride[d] : 0;
+        }
+        const double* __restrict__ cell = A.grid + oo * A.ncol;
+        v0 += cell[c0] * ww;
+        v1 += cell[c1] * ww;
+    }
+    return true;
+}
+
 template <int ND>
 __global__ __launch_bounds__(BLOCK, 2) void k_interp(const InterpArgs A)
 {
@@ -41,47 +84,13 @@ __global__ __launch_bounds__(BLOCK, 2) void k_interp(const InterpArgs A)
     const int64_t nwaves = ((int64_t)gridDim.x * BLOCK) >> 6;
     for (int64_t i = wave0 * S + slot; i < A.n; i += nwaves * S) {
         double x[ND];
-        bool bad = false;
 #pragma unroll
-        for (int d = 0; d < ND; ++d) {
-            x[d] = A.x[d][i];
-            bad |= (x[d] != x[d]);
-        }
-        if (!bad) {
-#pragma unroll
-            for (int d = 0; d < ND; ++d) bad |= out_of_axis(A.ax[d], lds, x[d]);
-        }
+        for (int d = 0; d < ND; ++d) x[d] = A.x[d][i];
+        double v0, v1;
+        const bool ok = interp_point<ND>(A, lds, x, c0, c1, v0, v1);
         double* o = A.out + i * A.k + 2 * sub;
-        if (bad) {
-            o[0] = d_nan();
-            if (two) o[1] = d_nan();
-            continue;
-        }
-        double t[ND];
-        int64_t base = 0;
-#pragma unroll
-        for (int d = 0; d < ND; ++d) {
-            int idx;
-            bracket(A.ax[d], lds, x[d], idx, t[d]);
-            base += (int64_t)idx * A.stride[d];
-        }
-        double v0 = 0.0, v1 = 0.0;
-#pragma unroll
-        for (int j = 0; j < (1 << ND); ++j) {
-            double ww = 1.0;
-            int64_t oo = base;
-#pragma unroll
-            for (int d = 0; d < ND; ++d) {
-                const int bit = (j >> (ND - 1 - d)) & 1;
-                ww *= bit ? t[d] : (1 - t[d]);
-                oo += bit ? A.stride[d] : 0;
-            }
-            const double* __restrict__ cell = A.grid + oo * A.ncol;
-            v0 += cell[c0] * ww;
-            v1 += cell[c1] * ww;
-        }
-        o[0] = v0;
-        if (two) o[1] = v1;
+        o[0] = ok ? v0 : d_nan();
+        if (two) o[1] = ok ? v1 : d_nan();
     }
 }
 

@@ -35,43 +35,47 @@ __device__ __forceinline__ int64_t ref_searchsorted(const double* __restrict__ a
     return L;
 }
 
+// EEP of one star (interp.py:488-558).  Shared by the batch kernel below and the resident service wave (k_service.h).
+__device__ __forceinline__ double interp_eep_point(const EepArgs& A, const double* lds, double x, double x0, double x1)
+{
+    double r = d_nan();
+    if (!(x != x || x0 != x0 || x1 != x1) && !out_of_axis(A.ax[0], lds, x0) && !out_of_axis(A.ax[1], lds, x1)) {
+        int i0, i1;
+        double d0, d1;
+        bracket(A.ax[0], lds, x0, i0, d0);
+        bracket(A.ax[1], lds, x1, i1, d1);
+        const int64_t ind[4] = {(int64_t)i0 * A.n1 + i1, (int64_t)i0 * A.n1 + i1 + 1,
+                                (int64_t)(i0 + 1) * A.n1 + i1, (int64_t)(i0 + 1) * A.n1 + i1 + 1};
+        int64_t ie[4], len[4];
+        bool bad = false;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            len[k] = A.lengths[ind[k]];
+            ie[k] = ref_searchsorted(A.ages + ind[k] * A.n_eep, x, len[k]);
+            bad |= ie[k] > A.n_eep - 1;
+        }
+        if (!bad) {
+            double e[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) e[k] = A.eep0 + (double)ie[k];
+            if (ie[0] >= len[0]) e[0] = e[1];      // sequential substitution, as the reference
+            if (ie[1] >= len[1]) e[1] = e[0];
+            if (ie[2] >= len[2]) e[2] = e[3];
+            if (ie[3] >= len[3]) e[3] = e[2];
+            const double e_0 = (1 - d1) * e[0] + d1 * e[1];
+            const double e_1 = (1 - d1) * e[2] + d1 * e[3];
+            r = (1 - d0) * e_0 + d0 * e_1;
+        }
+    }
+    return r;
+}
+
 __global__ __launch_bounds__(BLOCK, 2) void k_interp_eep(const EepArgs A)
 {
     extern __shared__ double lds[];
     stage_axes<2>(A.ax, lds);
     __syncthreads();
     const int64_t stride_grid = (int64_t)gridDim.x * BLOCK;
-    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < A.n; i += stride_grid) {
-        const double x = A.x[i], x0 = A.x0[i], x1 = A.x1[i];
-        double r = d_nan();
-        if (!(x != x || x0 != x0 || x1 != x1) && !out_of_axis(A.ax[0], lds, x0) && !out_of_axis(A.ax[1], lds, x1)) {
-            int i0, i1;
-            double d0, d1;
-            bracket(A.ax[0], lds, x0, i0, d0);
-            bracket(A.ax[1], lds, x1, i1, d1);
-            const int64_t ind[4] = {(int64_t)i0 * A.n1 + i1, (int64_t)i0 * A.n1 + i1 + 1,
-                                    (int64_t)(i0 + 1) * A.n1 + i1, (int64_t)(i0 + 1) * A.n1 + i1 + 1};
-            int64_t ie[4], len[4];
-            bool bad = false;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                len[k] = A.lengths[ind[k]];
-                ie[k] = ref_searchsorted(A.ages + ind[k] * A.n_eep, x, len[k]);
-                bad |= ie[k] > A.n_eep - 1;
-            }
-            if (!bad) {
-                double e[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) e[k] = A.eep0 + (double)ie[k];
-                if (ie[0] >= len[0]) e[0] = e[1];      // sequential substitution, as the reference
-                if (ie[1] >= len[1]) e[1] = e[0];
-                if (ie[2] >= len[2]) e[2] = e[3];
-                if (ie[3] >= len[3]) e[3] = e[2];
-                const double e_0 = (1 - d1) * e[0] + d1 * e[1];
-                const double e_1 = (1 - d1) * e[2] + d1 * e[3];
-                r = (1 - d0) * e_0 + d0 * e_1;
-            }
-        }
-        A.out[i] = r;
-    }
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < A.n; i += stride_grid)
+        A.out[i] = interp_eep_point(A, lds, A.x[i], A.x0[i], A.x1[i]);
 }

@@ -170,3 +170,28 @@ __global__ __launch_bounds__(BLOCK, 2) void k_catalog_fill(const FillCatalogArgs
         }
     }
 }
+
+// A catalog fit keeps its batch rectangular: a star whose start-point search failed (fewer than W finite candidates: its
+// rows are NaN) borrows the walkers of the batch's first good star with lnpost 0 - its own (hopeless) posterior then never
+// accepts a move, and its result row is blanked at the end (catalog.py: fit_stars_gpu; the reference isolates a failing
+// star with try / except, isochrones/starfit.py:155-159).  One workgroup per star; on the stream, no host round trip.
+__global__ __launch_bounds__(BLOCK, 2) void k_catalog_patch_failed(double* __restrict__ pos, double* __restrict__ lnp,
+                                                                  const int32_t* __restrict__ failed, int64_t n_stars, int W, int D)
+{
+    const int64_t s = blockIdx.x;
+    if (!failed[s]) return;
+    __shared__ int64_t src;
+    if (threadIdx.x == 0) {
+        int64_t k = 0;
+        while (k < n_stars && failed[k]) ++k;
+        src = k;
+    }
+    __syncthreads();
+    const int64_t from = src;
+    if (from >= n_stars) {                       // no star of the batch has start points: the rows stay NaN
+        for (int j = threadIdx.x; j < W; j += BLOCK) lnp[s * W + j] = 0.0;
+        return;
+    }
+    for (int j = threadIdx.x; j < W * D; j += BLOCK) pos[s * W * D + j] = pos[from * W * D + j];
+    for (int j = threadIdx.x; j < W; j += BLOCK) lnp[s * W + j] = 0.0;
+}

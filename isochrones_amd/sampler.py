@@ -198,15 +198,19 @@ class FusedEnsembleSampler:
             return self.target.lnpost(pos, sid)
         return self.target.lnpost(pos)          # a model's ensembles all evaluate the one posterior
 
-    def run_mcmc(self, p0, nsteps, lnprob0=None, store=True):
-        """p0: [W, ndim] (model) or [S, W, ndim] (catalog).  Returns (pos, lnprob) in that shape."""
+    def run_mcmc(self, p0, nsteps, lnprob0=None, store=True, check=True, inplace=False):
+        """p0: [W, ndim] (model) or [S, W, ndim] (catalog).  Returns (pos, lnprob) in that shape.
+        ``check=False`` skips the test that every start point has a finite lnpost (a device-to-host round trip; a
+        catalog fit has made sure on the device), ``inplace=True`` advances the caller's CUDA tensors themselves."""
         import torch
         from . import _cabi, device as dev
         rows = self.n_ensembles * self.nwalkers
-        pos = torch.as_tensor(p0, dtype=torch.float64, device=self.device).reshape(rows, self.ndim).contiguous().clone()
+        pos = torch.as_tensor(p0, dtype=torch.float64, device=self.device).reshape(rows, self.ndim).contiguous()
         lnp = (self.lnpost_rows(pos) if lnprob0 is None else
-               torch.as_tensor(lnprob0, dtype=torch.float64, device=self.device).reshape(rows)).contiguous().clone()
-        if not bool(torch.isfinite(lnp).all()):
+               torch.as_tensor(lnprob0, dtype=torch.float64, device=self.device).reshape(rows)).contiguous()
+        if not inplace:
+            pos, lnp = pos.clone(), (lnp.clone() if lnprob0 is not None else lnp)
+        if check and not bool(torch.isfinite(lnp).all()):
             raise ValueError("initial positions must have finite lnpost")
         chain = torch.empty(nsteps, self.ndim, rows, dtype=torch.float64, device=self.device) if store else None
         clnp = torch.empty(nsteps, rows, dtype=torch.float64, device=self.device) if store else None

@@ -20,6 +20,40 @@ triple)
   SHAPES=iso:3:9 ISOCHRONES_AMD_STAR_LANES=0 python tools/single_fit_shapes.py 2>/dev/null | grep "^{" > $OUT/single_fit_shapes_triple_off.jsonl; cut -c1-200 $OUT/single_fit_shapes_triple_off.jsonl
   SHAPES=iso:3:9 python tools/single_fit_shapes.py 300 2000 2>/dev/null | grep "^{" >> $OUT/single_fit_shapes_triple.jsonl; tail -1 $OUT/single_fit_shapes_triple.jsonl | cut -c1-200
   SHAPES=iso:3:9 ISOCHRONES_AMD_STAR_LANES=0 python tools/single_fit_shapes.py 300 2000 2>/dev/null | grep "^{" >> $OUT/single_fit_shapes_triple_off.jsonl; tail -1 $OUT/single_fit_shapes_triple_off.jsonl | cut -c1-200 ;;
+triple_sweep)
+  # one star per row against one lane per triple, by walkers (moves per half-step = walkers / 2) and bands
+  for W in 32 64 128 256 300; do
+    for TM in 0 1000; do
+      SHAPES=iso:3:3,iso:3:9 ISOCHRONES_AMD_TRIPLE_MOVES=$TM python tools/single_fit_shapes.py $W 2000 3 2>/dev/null | grep "^{" | sed "s/\"lib\": \"default\"/\"triple_moves\": $TM/" >> $OUT/triple_sweep.jsonl
+    done
+  done
+  python - <<PY
+import json
+for l in open("$OUT/triple_sweep.jsonl"):
+    d = json.loads(l)
+    print(d["n_bands"], d["walkers"], d["triple_moves"], round(d["us_per_step"], 2), d["lnprob_crc"])
+PY
+  ;;
+tree_ab)
+  # variant libraries of the tree units (tools/build_variant.py --only iso_fast_tree,iso_fast_stretch_tree): batch kernel + fit
+  for rep in 1 2; do
+  for name in ${TREE_LIBS:-default bm0 bm1}; do
+    if [ "$name" = default ]; then unset ISOCHRONES_AMD_LIB; else export ISOCHRONES_AMD_LIB=$ROOT/variants/libs/libiso_hip_$name.so; fi
+    python bench_configs.py --configs fits,tree 2>/dev/null | grep '^{' | python -c "
+import sys, json
+for l in sys.stdin:
+    d = json.loads(l)
+    if d['config'] == 'fits': print('$name', 'fit us/step', round(d['tree_resolved_binary']['us_per_step'], 2), 'acc', d['tree_resolved_binary']['acceptance'], '300x300 ms', round(1e3 * d['tree_resolved_binary']['fit_mcmc_300x300_wall_s'], 2))
+    else: print('$name', 'batch us', round(1e3 * d['kernel_ms'], 1), 'rel', d['parity_max_rel_err'])
+" | tee -a $OUT/tree_ab.txt
+  done
+  done
+  unset ISOCHRONES_AMD_LIB ;;
+catalog)
+  python tools/catalog_sizes.py --sizes 313,1250,10000 2>/dev/null | grep "^{" | tee -a $OUT/catalog_sizes.jsonl | cut -c1-400
+  python tools/ab_kernels.py --cases cfg4,cfg5,cfg5ref --label default 2>/dev/null | grep '^{' | tee -a $OUT/ab_default.jsonl | cut -c1-1500 ;;
+catalog_tests)
+  timeout 2400 python -m pytest tests/test_gpu_catalog.py tests/test_gpu_sampler_oracle.py tests/test_gpu_start_points.py -q -x 2>&1 | tail -8 | tee $OUT/pytest_catalog.txt ;;
 replay)
   timeout 1500 python -m pytest tests/test_gpu_sampler_oracle.py -q -x -k "reference_shape" 2>&1 | tail -15 | tee $OUT/pytest_replay.txt ;;
 tree)
