@@ -403,6 +403,27 @@ def catalog_leg(ic, rank, world, barrier, dist, reduce_device, sizes=(10_000, 40
                                          "stars_per_rank_all": [int(x) for x in share.tolist()],
                                          "rows_gathered_on_rank0": int(np.isfinite(res.iloc[:, -1].values).sum()),
                                          "lnpost_evals": int(n_stars) * nwalkers * (nburn + niter), "ok_fraction": ok}
+            if world == 1 and n_stars == sizes[0] and n_stars >= 8:
+                # what eight GPUs could show on this catalog: the share one of them gets - star i -> rank (i + 1) % 8, n / 8 stars -
+                # fitted here on one GPU (median of five passes), against the whole catalog's fit above.  A projection from two
+                # measurements, not a scaling curve: tables broadcast, rendezvous and the gather of the rows are not in it.
+                try:
+                    share = np.array([i for i in range(n_stars) if (i + 1) % 8 == 0])
+                    walls8 = []
+                    for _ in range(6):
+                        torch.cuda.synchronize()
+                        t8 = time.perf_counter()
+                        fit_stars_gpu(cat, ic, share, nwalkers=nwalkers, nburn=nburn, niter=niter, seed=11)
+                        torch.cuda.synchronize()
+                        walls8.append(time.perf_counter() - t8)
+                    w8 = float(np.median(walls8[1:]))
+                    out["%d_stars" % n_stars]["projection_8gpu"] = {
+                        "stars_of_one_rank": int(share.size), "fit_s_of_one_rank": w8, "fit_s_whole_catalog_one_gpu": fit_s,
+                        "speedup_upper_bound": fit_s / w8,
+                        "note": "fit of the n / 8 stars one GPU of eight gets, measured on this GPU, against the fit of the whole "
+                                "catalog; no broadcast / gather / rendezvous in either number"}
+                except Exception as e:       # noqa: BLE001
+                    out["%d_stars" % n_stars]["projection_8gpu"] = {"error": "%s: %s" % (type(e).__name__, e)}
             if cpu_subsample and rank == 0 and n_stars == sizes[0]:
                 try:
                     stars = np.linspace(0, n_stars - 1, cpu_subsample).astype(int)
@@ -673,6 +694,8 @@ def main():
             for key, leg in result["catalog"].items():
                 if key.endswith("_stars") and isinstance(leg, dict) and "stars_per_s" in leg:
                     summary["catalog_32x250_track_%s_per_s" % key] = leg["stars_per_s"]
+                    if "speedup_upper_bound" in (leg.get("projection_8gpu") or {}):
+                        summary["catalog_32x250_track_projection_8gpu_speedup"] = leg["projection_8gpu"]["speedup_upper_bound"]
         except Exception as e:       # noqa: BLE001 - the extra leg must not take the benchmark line down
             result["catalog"] = {"error": "%s: %s" % (type(e).__name__, e)}
         # The same catalog path ON THE REFERENCE'S OWN WORKLOAD: `starfit` builds get_ichrone(models, bands) = MIST_Isochrone,
@@ -698,6 +721,9 @@ def main():
             if "stars_per_s" in leg:
                 summary["catalog_reference_shape_stars_per_s"] = leg["stars_per_s"]        # 300 x (200 + 100), isochrones, 10^4 stars
                 summary["catalog_reference_shape_wall_s"] = leg["wall_s"]
+                if "speedup_upper_bound" in (leg.get("projection_8gpu") or {}):
+                    summary["catalog_reference_shape_projection_8gpu_speedup"] = leg["projection_8gpu"]["speedup_upper_bound"]
+                    summary["catalog_reference_shape_1250_stars_fit_s"] = leg["projection_8gpu"]["fit_s_of_one_rank"]
                 base_c = (leg.get("cpu_baseline") or {}).get("stars_per_s")
                 if base_c:
                     summary["catalog_reference_shape_cpu_one_thread_stars_per_s"] = base_c

@@ -166,6 +166,12 @@ void iso_ctx_destroy(iso_ctx* ctx);
  * strictly increasing values.  ndim in {2,3,4}. */
 int  iso_table_create(iso_ctx* ctx, int ndim, const int64_t* shape, const double* grid,
                       const double* const* axes, iso_table** out);
+/* The same for a table whose VALUES are already in this device's memory (d_grid: [n0]..[n_columns] float64, device
+ * pointer; axes on the host): one device-to-device copy.  What a rank that received the tables through an RCCL broadcast
+ * calls (isochrones_amd.catalog.broadcast_interpolator) instead of downloading them to a host array and uploading them
+ * again.  The caller keeps ownership of d_grid. */
+int  iso_table_create_from_device(iso_ctx* ctx, int ndim, const int64_t* shape, const double* d_grid, const double* const* axes,
+                                  iso_table** out);
 void iso_table_destroy(iso_table* t);
 
 /* out[i*k + c] = multilinear interpolation of column icols[c] at (x[0][i],..,x[ndim-1][i]).

@@ -96,7 +96,7 @@ class IsoTreeDesc(C.Structure):
 #: every symbol include/isochrones_amd.h declares (tests check the .so exports all of them)
 EXPORTED_SYMBOLS = (
     "iso_last_error", "iso_version", "iso_ctx_create", "iso_ctx_destroy",
-    "iso_table_create", "iso_table_destroy", "iso_interp", "iso_interp_host",
+    "iso_table_create", "iso_table_create_from_device", "iso_table_destroy", "iso_interp", "iso_interp_host",
     "iso_ic_create", "iso_ic_destroy", "iso_interp_mag", "iso_interp_mag_host",
     "iso_model_create", "iso_model_destroy", "iso_model_n_params", "iso_model_kernel_path",
     "iso_axis_bracket_host", "iso_debug_trace_kernels", "iso_debug_kernels", "iso_debug_sampler_plan",
@@ -181,6 +181,8 @@ def lib():
     L.iso_ctx_destroy.restype = None
     L.iso_table_create.argtypes = [vp, C.c_int, C.POINTER(i64), C.POINTER(dbl),
                                    C.POINTER(C.POINTER(dbl)), C.POINTER(vp)]
+    if hasattr(L, "iso_table_create_from_device"):
+        L.iso_table_create_from_device.argtypes = [vp, C.c_int, C.POINTER(i64), pd, C.POINTER(C.POINTER(dbl)), C.POINTER(vp)]
     L.iso_table_destroy.argtypes = [vp]
     L.iso_table_destroy.restype = None
     L.iso_interp.argtypes = [vp, C.POINTER(pd), i64, C.POINTER(i32), C.c_int, pd, vp]
@@ -219,9 +221,9 @@ def lib():
     L.iso_eep_table_destroy.restype = None
     L.iso_interp_eep.argtypes = [vp, pd, pd, pd, i64, pd, vp]
     hdp = C.POINTER(dbl)
-    L.iso_interp_host.argtypes = [vp, vp, i64, C.POINTER(C.c_int32), C.c_int, vp]           # host double* as void*: plain ints pass
+    L.iso_interp_host.argtypes = [vp, vp, i64, vp, C.c_int, vp]           # host double* as void*: plain ints pass
     L.iso_interp_mag_host.argtypes = [vp, vp, i64, C.POINTER(C.c_int32), C.c_int, vp, vp, vp, vp]
-    L.iso_interp_eep_host.argtypes = [vp, hdp, hdp, hdp, i64, hdp]
+    L.iso_interp_eep_host.argtypes = [vp, vp, vp, vp, i64, vp]
     L.iso_sampler_create_model.argtypes = [vp, C.c_int, dbl, C.c_uint64, C.POINTER(vp)]
     L.iso_sampler_create_catalog.argtypes = [vp, C.c_int, dbl, C.c_uint64, C.POINTER(vp)]
     L.iso_sampler_create_model_ensembles.argtypes = [vp, i64, C.c_int, dbl, C.c_uint64, C.POINTER(vp)]
@@ -237,9 +239,9 @@ def lib():
     L.iso_tree_model_destroy.argtypes = [vp]
     L.iso_tree_model_destroy.restype = None
     L.iso_tree_lnpost.argtypes = [vp, pd, i64, i64, i64, pd, pd, pd, vp]
-    L.iso_tree_lnpost_host.argtypes = [vp, C.POINTER(dbl), i64, C.POINTER(dbl), C.POINTER(dbl), C.POINTER(dbl)]
+    L.iso_tree_lnpost_host.argtypes = [vp, vp, i64, vp, vp, vp]
     for name in EXPORTED_SYMBOLS:
-        if (name.startswith("iso_debug_") or name in ("iso_catalog_start_points", "iso_catalog_patch_failed")) and not hasattr(L, name) and os.environ.get("ISOCHRONES_AMD_LIB"):
+        if (name.startswith("iso_debug_") or name in ("iso_catalog_start_points", "iso_catalog_patch_failed", "iso_table_create_from_device")) and not hasattr(L, name) and os.environ.get("ISOCHRONES_AMD_LIB"):
             continue                                   # a variant library built from an older source state
         fn = getattr(L, name)
         if fn.restype is C.c_int:

@@ -543,7 +543,8 @@ def fit_stars_gpu(catalog: StarCatalog, ic, indices, N=1, nwalkers=32, nburn=150
     pos, lnp, failed = initial_positions(post, nwalkers, rng_seed=seed)
     _mark("initial_positions")
     good = ~failed
-    lean = fused and hasattr(_cabi.lib(), "iso_catalog_patch_failed")
+    lean = (fused and hasattr(_cabi.lib(), "iso_catalog_patch_failed")
+            and os.environ.get("ISOCHRONES_AMD_CATALOG_LEAN", "1") != "0")       # (0: the host-checked path of rounds 1-5, A/B and tests)
     if lean:
         # the whole fit stays on the stream: failed stars borrow the first good star's walkers with lnpost 0 (one small
         # launch instead of three device-to-host round trips and a dozen indexing launches), no start point is tested on the
@@ -563,8 +564,8 @@ def fit_stars_gpu(catalog: StarCatalog, ic, indices, N=1, nwalkers=32, nburn=150
         # failed stars get a copy of a good star's walkers so the batch stays rectangular
         if bool(failed.any()) and bool(good.any()):
             src = int(torch.nonzero(good)[0])
-            pos[failed] = pos[src]
-            lnp[failed] = lnp[src]
+            pos[failed] = pos[src].clone()      # (a view of the tensor written to: torch refuses the aliasing)
+            lnp[failed] = lnp[src].clone()
     if fused:
         from .sampler import FusedEnsembleSampler
         if not lean and bool(failed.any()) and bool(good.any()):
@@ -919,17 +920,26 @@ def broadcast_interpolator(ic=None, src=0, rebuild_on_src=False, timings=None):
     meta = meta[0]
     keep = rank != src or rebuild_on_src
 
-    def bcast(arr, shape):
+    # Over RCCL the tables travel device to device and STAY there: a receiving rank hands the tensor that arrived to the
+    # library as it is (DFInterpolator.from_device -> iso_table_create_from_device, one device-to-device copy) instead of
+    # downloading 0.7 GB to a numpy array and uploading it again when the interpolator is first used; the host copy
+    # behind `.grid` is made only if somebody asks for it (checkpoint digests, table ingest).  gloo: host arrays, as before.
+    # ISOCHRONES_AMD_BROADCAST=host keeps the round trip on RCCL as well (A/B, tests).
+    on_device = use_gpu and os.environ.get("ISOCHRONES_AMD_BROADCAST", "device") != "host"
+
+    def bcast(arr, shape, table=False):
         t = (torch.as_tensor(np.ascontiguousarray(arr, dtype=np.float64), device=devt) if rank == src
              else torch.empty(shape, dtype=torch.float64, device=devt))
         dist.broadcast(t, src=src)
-        return t.cpu().numpy() if keep else None
+        if not keep:
+            return None
+        return t if (table and on_device) else t.cpu().numpy()
 
     tables = {}
     for key in ("model", "bc"):
         shape = tuple(meta[key]["shape"])
         srcobj = (ic.model_grid.interp if key == "model" else ic.bc_grid.interp) if rank == src else None
-        grid = bcast(srcobj.grid if srcobj is not None else None, shape)
+        grid = bcast(srcobj.grid if srcobj is not None else None, shape, table=True)
         axes = [bcast(srcobj.index_columns[d] if srcobj is not None else None, (shape[d],)) for d in range(len(shape) - 1)]
         tables[key] = (grid, axes)
     if use_gpu:
@@ -938,14 +948,17 @@ def broadcast_interpolator(ic=None, src=0, rebuild_on_src=False, timings=None):
     if timings is not None:
         timings["broadcast_s"] = t1 - t0
         timings["broadcast_bytes"] = int(sum(8 * int(np.prod(meta[k]["shape"])) for k in ("model", "bc")))
+        timings["tables_stay_on_device"] = bool(on_device)
     if not keep:
         return ic
     mg_cls, ic_cls = ((EvolutionTrackGrid, EvolutionTrackInterpolator) if meta["kind"] == _cabi.KIND_TRACK
                       else (IsochroneGrid, IsochroneInterpolator))
-    mg = mg_cls(DFInterpolator.from_arrays(tables["model"][0], tables["model"][1], meta["model"]["columns"],
-                                           meta["model"]["names"]), limits=meta["model"]["limits"])
-    bcg = BolometricCorrectionGrid(DFInterpolator.from_arrays(tables["bc"][0], tables["bc"][1], meta["bc"]["columns"],
-                                                              meta["bc"]["names"]), bands=meta["bc"]["bands"])
+    def table_of(key):
+        grid, axes = tables[key]
+        make = DFInterpolator.from_device if dev.is_tensor(grid) else DFInterpolator.from_arrays
+        return make(grid, axes, meta[key]["columns"], meta[key]["names"])
+    mg = mg_cls(table_of("model"), limits=meta["model"]["limits"])
+    bcg = BolometricCorrectionGrid(table_of("bc"), bands=meta["bc"]["bands"])
     out = ic_cls(mg, bcg, bands=meta["bands"], eep_bounds=meta["eep_bounds"])
     if timings is not None:
         timings["rebuild_s"] = _time.perf_counter() - t1

@@ -22,8 +22,8 @@ inline size_t stretch_persist_lds_bytes(int axes_len, int nb, int W, int np, boo
 //                             lane BC gather (one band), table-free priors during the model gather
 //   single model, std priors  UNI + STDP: model block through scalar loads, prior families compile-time constants
 //   single model              UNI
-//   single binary             k_stretch_pair (+ STDP): one star per lane, when a half-step's moves fit half a workgroup
-//   single triple             k_stretch_triple (+ STDP): one star per row of a wave, chunks of 64 moves
+//   single binary, std priors k_stretch_pair: one star per lane, when a half-step's moves fit half a workgroup
+//   single triple, std priors k_stretch_triple: one star per row of a wave, up to 64 moves per half-step
 // Models with asteroseismic terms (ASTERO) are single models by construction (iso_catalog_create refuses them) and
 // have no register-capped form: a run of very many ensembles of such a model takes the UNI kernel in rounds.
 struct PersistKernel {
@@ -76,10 +76,12 @@ inline PersistKernel persist_kernel(const StretchArgs& S)
             // measured (profiles/r04/pair_kernel_ab.jsonl, us per step): up to 16 moves per wave 13.2 -> 10.0 (1 band), 21.7 ->
             // 19.4 (12 bands); 17-32 moves per wave 14.4 -> 13.4 (1 band), nothing beyond 4 bands
             const int64_t moves = (n_ens < G ? n_ens : G) * h;
-            if (S.pair && moves <= BLOCK / 2 && (moves <= BLOCK / 4 || N <= 4)) {
-                k.fn = stdp ? (const void*)k_stretch_pair<N, true> : (const void*)k_stretch_pair<N, false>;
+            // (round 6: the reference's default prior families only - the run-time-prior twins of the one-star-per-lane /
+            // -per-row kernels were 39 instantiations for single fits with non-default priors, which keep the plain form)
+            if (S.pair && stdp && moves <= BLOCK / 2 && (moves <= BLOCK / 4 || N <= 4)) {
+                k.fn = (const void*)k_stretch_pair<N>;
                 k.dense = false;
-                snprintf(k.name, sizeof k.name, "k_stretch_pair<%d, %s>", N, tf(stdp));
+                snprintf(k.name, sizeof k.name, "k_stretch_pair<%d>", N);
                 return k;
             }
         }
@@ -91,10 +93,10 @@ inline PersistKernel persist_kernel(const StretchArgs& S)
             const int GL = persist_group(S.W);
             const int G = (S.group > 0 && S.group < GL) ? S.group : GL;
             const int64_t moves = (n_ens < G ? n_ens : G) * (S.W >> 1);
-            if (S.pair && moves <= S.triple_moves && (n_ens + G - 1) / G <= 512) {
-                k.fn = stdp ? (const void*)k_stretch_triple<N, true> : (const void*)k_stretch_triple<N, false>;
+            if (S.pair && stdp && moves <= S.triple_moves && (n_ens + G - 1) / G <= 512) {
+                k.fn = (const void*)k_stretch_triple<N>;
                 k.dense = false;
-                snprintf(k.name, sizeof k.name, "k_stretch_triple<%d, %s>", N, tf(stdp));
+                snprintf(k.name, sizeof k.name, "k_stretch_triple<%d>", N);
                 return k;
             }
         }

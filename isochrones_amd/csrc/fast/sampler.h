@@ -406,15 +406,20 @@ __global__ __launch_bounds__(BLOCK, DENSE ? ((persist_slim(DENSE, NB, NS) && !ST
 }
 
 // a single binary's fit (isochrone grid, no asteroseismic terms, at most BLOCK / 2 moves per half-step): one star per lane
-template <int NB, bool STDP>
+// (models whose priors are the reference's default families: compile-time constants)
+template <int NB>
 __global__ __launch_bounds__(BLOCK, 2) void k_stretch_pair(const FastArgs A, const StretchArgs S)
 {
-    persist_body<ISO_KIND_ISO, 2, NB, false, false, true, STDP, true>(A, S);
+    persist_body<ISO_KIND_ISO, 2, NB, false, false, true, true, true>(A, S);
 }
 
-// a single triple's fit (isochrone grid, no asteroseismic terms): one star per row of a wave, 64 moves per chunk
-template <int NB, bool STDP>
+// a single triple's fit (isochrone grid, no asteroseismic terms, default prior families): one star per row of a wave, 64 moves
+// per chunk.  Measured (profiles/r06/triple_sweep.jsonl, us per step at 3 / 9 bands): 16 moves per half-step 19.7 -> 15.1 /
+// 24.4 -> 21.4, 32 moves 20.8 -> 15.9 / 25.2 -> 22.8, 64 moves 21.1 -> 17.2 / 25.8 -> 23.9; beyond one chunk the form
+// LOSES (128 moves: 23.3 -> 32.7 / 31.4 -> 46.0) - a chunk is a whole dependent chain again, and the lanes were not idle
+// there - so the host takes it up to 64 moves (StretchArgs.triple_moves).
+template <int NB>
 __global__ __launch_bounds__(BLOCK, 2) void k_stretch_triple(const FastArgs A, const StretchArgs S)
 {
-    persist_body<ISO_KIND_ISO, 3, NB, false, false, true, STDP, false, true>(A, S);
+    persist_body<ISO_KIND_ISO, 3, NB, false, false, true, true, false, true>(A, S);
 }

@@ -6,6 +6,7 @@
 #include <cstdlib>
 
 #include "iso_fast_kernel.h"
+#include "fast/tree_mailbox.h"
 
 namespace iso {
 namespace fastk {
@@ -44,6 +45,73 @@ __global__ __launch_bounds__(tree_block<NL>(), 2) void k_lnpost_tree_fast(const 
     if (A.lnlike) A.lnlike[i] = lnl;
 }
 
+// The model's resident mailbox wave (fast/tree_mailbox.h): one wave polls the request lines and evaluates the one sample with
+// all 64 lanes helping in the gathers - tree_lnpost, the batch kernel's device function, with the parameters taken from the
+// request words (scalars: every lane computes the sample's brackets, lane 0 owns the result).  Register form only (trees of
+// 1-4 stars with up to eight bands - the shapes of the reference's examples); other trees keep the launch per call.
+// (A mailbox mode INSIDE the batch kernel was tried first, to save these instantiations: the second inlined copy of the
+// evaluation cost the batch kernel 30-40 registers and 250 spilled scalar registers.)
+template <int NB, int NL>
+__global__ __launch_bounds__(64, 2) void k_mailbox_tree(const FastArgs A, const DevTree* __restrict__ Tp, IsoTreeBox* mb,
+                                                        unsigned long long idle_ticks, unsigned long long life_ticks)
+{
+    static_assert(NL > 0, "register form");
+    extern __shared__ double lds[];
+    for (int j = threadIdx.x; j < A.axes_len; j += 64) lds[j] = A.axes_blob[j];
+    __syncthreads();
+    const CoopLds L = coop_lds<NB>(lds, A.axes_len);
+    const DevTree& T = *Tp;
+    TreeLeaves<NB, NL> S;
+    S.lds_ = nullptr;
+    S.stride_ = 64;
+    const int lane = (int)threadIdx.x;
+    auto sys_load = [](const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
+    auto sys_store = [](unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
+    unsigned long long last = sys_load(&mb->done[0]);
+    const unsigned long long t_start = wall_clock64();
+    unsigned long long t_idle = t_start;
+    const int np = T.n_params;
+    for (;;) {
+        const unsigned long long w = sys_load(&mb->req[lane & 31]);
+        const int wlo = (int)(unsigned)(w & 0xFFFFFFFFull), whi = (int)(unsigned)(w >> 32);
+        const unsigned long long seq = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(whi, 0) << 32) |
+                                       (unsigned long long)(unsigned)__builtin_amdgcn_readlane(wlo, 0);
+        if (seq == last) {
+            const unsigned long long now = wall_clock64();
+            const bool leave = (now - t_idle > idle_ticks) | (now - t_start > life_ticks) | (sys_load(&mb->ctl[1]) != 0);
+            if (leave) break;                              // (wave-uniform)
+            continue;
+        }
+        // parameter j of the request: the word lane 1 + j read
+        auto word = [&](int j) {
+            return ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(whi, 1 + j) << 32) |
+                   (unsigned long long)(unsigned)__builtin_amdgcn_readlane(wlo, 1 + j);
+        };
+        uint32_t c = 0x9E3779B9u;                          // mailbox_checksum (iso_internal.h) over the np parameter words
+        for (int q = 0; q < np; ++q) {
+            const unsigned long long x = word(q);
+            c = (c ^ (uint32_t)x) * 0x85EBCA6Bu;
+            c = (c ^ (uint32_t)(x >> 32)) * 0xC2B2AE35u + (uint32_t)q;
+        }
+        if (c != (uint32_t)(seq >> 32)) continue;          // the lines did not arrive together: poll again
+        const bool parts = ((seq >> 8) & 1) != 0;
+        auto par = [&](int j) { return __longlong_as_double((long long)word(j)); };
+        double lnp, lnl;
+        const double post = tree_lnpost<NB, NL>(A, T, lds, L, lane == 0, par, S, parts, lnp, lnl);
+        if (lane == 0) {
+            sys_store(&mb->done[1], (unsigned long long)__double_as_longlong(post));
+            sys_store(&mb->done[2], (unsigned long long)__double_as_longlong(lnp));
+            sys_store(&mb->done[3], (unsigned long long)__double_as_longlong(lnl));
+        }
+        __threadfence_system();                            // results before the sequence word
+        if (lane == 0) sys_store(&mb->done[0], seq);
+        last = seq;
+        t_idle = wall_clock64();
+    }
+    __threadfence_system();
+    if (lane == 0) sys_store(&mb->ctl[0], 2ull);          // state: exited
+}
+
 }  // namespace fastk
 
 template <int NL>
@@ -73,6 +141,38 @@ static bool launch_tree_nl(int nb, int n_leaves, const FastArgs& A, const DevTre
         }
     }
 #undef ISO_TREE_CASE
+}
+
+template <int NL>
+static bool launch_tree_mailbox_nl(int nb, const FastArgs& A, const DevTree* T, IsoTreeBox* d_box, unsigned long long idle,
+                                   unsigned long long life, hipStream_t s)
+{
+    using namespace fastk;
+    auto sh = [&](int n) { return (size_t)(((A.axes_len + 1) & ~1) + 64 * slot_stride(n)) * sizeof(double); };
+    switch (nb) {
+#define ISO_TREE_MB_CASE(N) \
+    case N: note_kernel("k_mailbox_tree<%d, %d>", N, NL); hipLaunchKernelGGL((k_mailbox_tree<N, NL>), dim3(1), dim3(64), sh(N), s, A, T, d_box, idle, life); return true;
+        ISO_TREE_MB_CASE(1) ISO_TREE_MB_CASE(2) ISO_TREE_MB_CASE(3) ISO_TREE_MB_CASE(4) ISO_TREE_MB_CASE(5) ISO_TREE_MB_CASE(6)
+        ISO_TREE_MB_CASE(7) ISO_TREE_MB_CASE(8)
+#undef ISO_TREE_MB_CASE
+    default: return false;
+    }
+}
+
+// the tree model's resident mailbox wave (fast/tree_mailbox.h); false: no instantiation for the shape (more than four stars,
+// more than eight bands, the runtime-leaf form forced)
+bool launch_tree_mailbox(int nb, int n_leaves, const FastArgs& A, const DevTree* T, IsoTreeBox* d_box, unsigned long long idle_ticks,
+                         unsigned long long life_ticks, hipStream_t s)
+{
+    const char* rt = getenv("ISOCHRONES_AMD_TREE_RUNTIME_LEAVES");
+    if (nb > 8 || (rt && rt[0] == '1')) return false;
+    switch (n_leaves) {
+    case 1: return launch_tree_mailbox_nl<1>(nb, A, T, d_box, idle_ticks, life_ticks, s);
+    case 2: return launch_tree_mailbox_nl<2>(nb, A, T, d_box, idle_ticks, life_ticks, s);
+    case 3: return launch_tree_mailbox_nl<3>(nb, A, T, d_box, idle_ticks, life_ticks, s);
+    case 4: return launch_tree_mailbox_nl<4>(nb, A, T, d_box, idle_ticks, life_ticks, s);
+    }
+    return false;
 }
 
 // n_leaves 1..4 with up to 8 bands run the register-resident instantiation, everything else the runtime one

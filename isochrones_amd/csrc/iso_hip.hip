@@ -45,6 +45,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include "iso_internal.h"
+#include "fast/tree_mailbox.h"
 #include "fast/axis_lut.h"
 
 using namespace iso;
@@ -300,6 +301,12 @@ struct iso_tree_model {
     double* d_axes_blob;
     bool fast_ok;
     FastArgs fast;
+    // resident mailbox wave of the per-point callback (lazy; calls are serialised by the context's stage_mu)
+    iso::IsoTreeBox* mbox;   // pinned, device-mapped
+    iso::IsoTreeBox* d_mbox;
+    hipStream_t mbox_stream;
+    unsigned long long mbox_count;
+    int mbox_state;          // 0 untried, 1 usable, -1 not available
 };
 
 struct iso_eep_table {
@@ -457,8 +464,26 @@ void iso_ctx_destroy(iso_ctx* ctx)
     delete ctx;
 }
 
+namespace {
+int table_create(iso_ctx* ctx, int ndim, const int64_t* shape, const double* grid, bool grid_on_device, const double* const* axes,
+                 iso_table** out);
+}
+
 int iso_table_create(iso_ctx* ctx, int ndim, const int64_t* shape, const double* grid, const double* const* axes,
                      iso_table** out)
+{
+    return table_create(ctx, ndim, shape, grid, false, axes, out);
+}
+
+int iso_table_create_from_device(iso_ctx* ctx, int ndim, const int64_t* shape, const double* d_grid, const double* const* axes,
+                                 iso_table** out)
+{
+    return table_create(ctx, ndim, shape, d_grid, true, axes, out);
+}
+
+namespace {
+int table_create(iso_ctx* ctx, int ndim, const int64_t* shape, const double* grid, bool grid_on_device, const double* const* axes,
+                 iso_table** out)
 {
     if (!ctx || !shape || !grid || !axes || !out) return fail(ISO_ERR_INVALID, "iso_table_create: NULL argument");
     if (ndim < 2 || ndim > ISO_MAX_DIM) return fail(ISO_ERR_INVALID, "iso_table_create: ndim must be 2, 3 or 4");
@@ -489,7 +514,7 @@ int iso_table_create(iso_ctx* ctx, int ndim, const int64_t* shape, const double*
     for (int d = 0; d <= ndim; ++d) t->shape[d] = shape[d];
     const size_t bytes = (size_t)ncells * (size_t)shape[ndim] * sizeof(double);
     hipError_t e = hipMalloc(&t->d_grid, bytes);
-    if (e == hipSuccess) e = hipMemcpy(t->d_grid, grid, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(t->d_grid, grid, bytes, grid_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice);
     for (int d = 0; d < ndim && e == hipSuccess; ++d) {
         t->h_axes[d].assign(axes[d], axes[d] + shape[d]);
         e = hipMalloc(&t->d_axes[d], shape[d] * sizeof(double));
@@ -508,6 +533,7 @@ int iso_table_create(iso_ctx* ctx, int ndim, const int64_t* shape, const double*
     *out = t;
     return ISO_OK;
 }
+}  // namespace
 
 void iso_table_destroy(iso_table* t)
 {
@@ -1735,7 +1761,6 @@ int iso_interp_eep(iso_eep_table* t, const double* x, const double* x0, const do
 namespace {
 struct SvcTargetRec {
     SvcTarget* d_target;
-    unsigned long long uid;
 };
 struct iso_service {
     IsoSvcBox* box = nullptr;      // pinned, device-mapped
@@ -1747,7 +1772,6 @@ struct iso_service {
 std::mutex g_svc_mu;                                             // guards the two maps below (calls are serialised per context
 std::unordered_map<iso_ctx*, iso_service*> g_services;           // by ctx->stage_mu, which every *_host entry point holds)
 std::unordered_map<const void*, SvcTargetRec> g_svc_targets;     // iso_table* / iso_ic* / iso_eep_table* -> its device record
-std::atomic<unsigned long long> g_svc_uid{1};
 
 inline unsigned long long svc_host_load(const volatile unsigned long long* p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
 
@@ -1834,11 +1858,8 @@ bool service_target(const void* key, const SvcTarget& host, SvcTargetRec* out)
         return true;
     }
     SvcTargetRec rec;
-    rec.uid = g_svc_uid.fetch_add(1);
-    SvcTarget h = host;
-    h.uid = rec.uid;
     if (hipMalloc(reinterpret_cast<void**>(&rec.d_target), sizeof(SvcTarget)) != hipSuccess ||
-        hipMemcpy(rec.d_target, &h, sizeof(SvcTarget), hipMemcpyHostToDevice) != hipSuccess) {
+        hipMemcpy(rec.d_target, &host, sizeof(SvcTarget), hipMemcpyHostToDevice) != hipSuccess) {
         (void)hipGetLastError();
         return false;
     }
@@ -1850,7 +1871,7 @@ bool service_target(const void* key, const SvcTarget& host, SvcTargetRec* out)
 // (before the object's tables are freed)
 void service_forget(const void* key)
 {
-    SvcTargetRec rec{nullptr, 0};
+    SvcTargetRec rec{nullptr};
     {
         std::lock_guard<std::mutex> lock(g_svc_mu);
         auto it = g_svc_targets.find(key);
@@ -1868,15 +1889,16 @@ int service_call(iso_ctx* ctx, int op, const SvcTargetRec& tgt, const double* x,
     iso_service* sv = service_of(ctx);
     if (!sv) return 1;
     IsoSvcBox* mb = sv->box;
-    unsigned long long words[15];
+    unsigned long long words[10];
     std::memset(words, 0, sizeof words);
     words[0] = (unsigned long long)(uintptr_t)tgt.d_target;
-    words[1] = tgt.uid;
-    for (int q = 0; q < nx; ++q) std::memcpy(&words[2 + q], x + q, 8);
-    for (int c = 0; c < k; ++c) words[7 + (c >> 3)] |= (unsigned long long)(cols[c] & 0xFF) << (8 * (c & 7));
-    const unsigned long long seq = ((unsigned long long)mailbox_checksum(words, 15) << 32) | ((++sv->count & 0xFFFFull) << 16) |
+    for (int q = 0; q < nx; ++q) std::memcpy(&words[1 + q], x + q, 8);
+    for (int c = 0; c < k; ++c) words[6 + (c >> 3)] |= (unsigned long long)(cols[c] & 0xFF) << (8 * (c & 7));
+    const unsigned long long seq = ((unsigned long long)mailbox_checksum(words, 10) << 32) | ((++sv->count & 0xFFFFull) << 16) |
                                    ((unsigned long long)k << 8) | (unsigned long long)op;
-    for (int q = 0; q < 15; ++q) __atomic_store_n(&mb->req[1 + q], words[q], __ATOMIC_RELAXED);
+    if (k > 8)
+        for (int q = 7; q < 10; ++q) __atomic_store_n(&mb->req[1 + q], words[q], __ATOMIC_RELAXED);    // behind the line, before it
+    for (int q = 0; q < 7; ++q) __atomic_store_n(&mb->req[1 + q], words[q], __ATOMIC_RELAXED);
     __atomic_store_n(&mb->req[0], seq, __ATOMIC_RELEASE);        // the sequence word last
     if (svc_host_load(&mb->ctl[0]) != 1 && !service_launch(sv)) return 1;
     const auto t0 = std::chrono::steady_clock::now();
@@ -2362,6 +2384,10 @@ int iso_tree_model_create(iso_ic* ic, const iso_tree_desc* d, iso_tree_model** o
     m->d_bcq = nullptr;
     m->d_axes_blob = nullptr;
     m->fast_ok = false;
+    m->mbox = m->d_mbox = nullptr;
+    m->mbox_stream = nullptr;
+    m->mbox_count = 0;
+    m->mbox_state = 0;
     m->n_bands = d->n_bands;
     m->n_leaves = d->n_leaves;
     DevTree* H = new DevTree();
@@ -2452,10 +2478,118 @@ int iso_tree_model_create(iso_ic* ic, const iso_tree_desc* d, iso_tree_model** o
     return ISO_OK;
 }
 
+namespace {
+inline unsigned long long tmb_load(const volatile unsigned long long* p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
+
+bool tree_mailbox_launch(iso_tree_model* m)
+{
+    double idle_us = 1000.0;
+    if (const char* e = std::getenv("ISOCHRONES_AMD_MAILBOX_IDLE_US")) idle_us = std::max(10.0, std::atof(e));
+    const unsigned long long idle = (unsigned long long)(idle_us * 1e-6 * 1.0e8);       // wall_clock64(): 100 MHz
+    const unsigned long long life = (unsigned long long)(30.0 * 1.0e8);
+    __atomic_store_n(&m->mbox->ctl[1], 0ull, __ATOMIC_RELAXED);
+    __atomic_store_n(&m->mbox->ctl[0], 1ull, __ATOMIC_RELEASE);
+    FastArgs F = m->fast;
+    F.pars = nullptr;
+    F.n = 0;
+    F.lnpost = F.lnprior = F.lnlike = nullptr;
+    if (!launch_tree_mailbox(m->n_bands, m->n_leaves, F, m->d_tree, m->d_mbox, idle, life, m->mbox_stream) ||
+        hipGetLastError() != hipSuccess) {
+        __atomic_store_n(&m->mbox->ctl[0], 2ull, __ATOMIC_RELEASE);
+        return false;
+    }
+    return true;
+}
+
+bool tree_mailbox_ready(iso_tree_model* m)
+{
+    if (m->mbox_state < 0) return false;
+    if (m->mbox_state > 0) return true;
+    m->mbox_state = -1;
+    if (!m->fast_ok || m->n_params > 24) return false;
+    if (hipHostMalloc(reinterpret_cast<void**>(&m->mbox), sizeof(IsoTreeBox), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+        (void)hipGetLastError();
+        m->mbox = nullptr;
+        return false;
+    }
+    std::memset(m->mbox, 0, sizeof(IsoTreeBox));
+    m->mbox->ctl[0] = 2;                             // no wave yet
+    if (hipHostGetDevicePointer(reinterpret_cast<void**>(&m->d_mbox), m->mbox, 0) != hipSuccess ||
+        hipStreamCreateWithFlags(&m->mbox_stream, hipStreamNonBlocking) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipHostFree(m->mbox);
+        m->mbox = nullptr;
+        return false;
+    }
+    m->mbox_state = 1;
+    return true;
+}
+
+// one row through the resident wave; ISO_OK, or 1 = not served (the caller launches instead)
+int tree_mailbox_call(iso_tree_model* m, const double* pars, double* lnpost_out, double* lnprior_out, double* lnlike_out)
+{
+    IsoTreeBox* mb = m->mbox;
+    const int np_ = m->n_params;
+    const bool parts = lnprior_out || lnlike_out;
+    unsigned long long words[24];
+    for (int q = 0; q < np_; ++q) {
+        std::memcpy(&words[q], pars + q, 8);
+        __atomic_store_n(&mb->req[1 + q], words[q], __ATOMIC_RELAXED);
+    }
+    const unsigned long long seq = ((unsigned long long)mailbox_checksum(words, np_) << 32) | ((++m->mbox_count & 0xFFFFull) << 16) |
+                                   ((unsigned long long)parts << 8);
+    __atomic_store_n(&mb->req[0], seq, __ATOMIC_RELEASE);        // the sequence word last
+    if (tmb_load(&mb->ctl[0]) != 1 && !tree_mailbox_launch(m)) {
+        m->mbox_state = -1;                                      // no instantiation for this shape: the launch path from now on
+        return 1;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint64_t spins = 1; tmb_load(&mb->done[0]) != seq; ++spins) {
+        if ((spins & 255) == 0) {
+            if (tmb_load(&mb->ctl[0]) == 2 && tmb_load(&mb->done[0]) != seq) {
+                if (!tree_mailbox_launch(m)) return 1;
+            } else if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
+                __atomic_store_n(&mb->ctl[1], 1ull, __ATOMIC_RELEASE);
+                (void)hipStreamSynchronize(m->mbox_stream);
+                m->mbox_state = -1;
+                return 1;
+            }
+        }
+    }
+    double r[3];
+    for (int k = 0; k < 3; ++k) {
+        const unsigned long long w = __atomic_load_n(&mb->done[1 + k], __ATOMIC_RELAXED);
+        std::memcpy(&r[k], &w, 8);
+    }
+    if (lnpost_out) *lnpost_out = r[0];
+    if (lnprior_out) *lnprior_out = r[1];
+    if (lnlike_out) *lnlike_out = r[2];
+    return ISO_OK;
+}
+
+void tree_mailbox_stop(iso_tree_model* m, bool release)
+{
+    if (!m->mbox) return;
+    if (tmb_load(&m->mbox->ctl[0]) == 1) {
+        __atomic_store_n(&m->mbox->ctl[1], 1ull, __ATOMIC_RELEASE);
+        (void)hipStreamSynchronize(m->mbox_stream);
+    }
+    if (release) {
+        (void)hipStreamSynchronize(m->mbox_stream);
+        (void)hipStreamDestroy(m->mbox_stream);
+        (void)hipHostFree(m->mbox);
+        m->mbox = m->d_mbox = nullptr;
+        m->mbox_stream = nullptr;
+        m->mbox_state = 0;
+    }
+}
+}  // namespace
+
 void iso_tree_model_destroy(iso_tree_model* m)
 {
     if (!m) return;
     DeviceGuard guard(m->device);
+    tree_mailbox_stop(m, true);        // the resident wave reads the tables below
     if (m->d_tree) (void)hipFree(m->d_tree);
     if (m->d_bc_hot) (void)hipFree(m->d_bc_hot);
     if (m->d_bcq) (void)hipFree(m->d_bcq);
@@ -2521,6 +2655,11 @@ int iso_tree_lnpost_host(iso_tree_model* m, const double* pars, int64_t n, doubl
     DeviceGuard guard(m->device);
     iso_ctx* ctx = m->ic->ctx;
     std::lock_guard<std::mutex> lock(ctx->stage_mu);
+    // a sampler's per-point callback: the model's resident mailbox wave - no launch (fast/tree_mailbox.h)
+    if (n == 1 && mailbox_enabled() && tree_mailbox_ready(m)) {
+        const int rc1 = tree_mailbox_call(m, pars, lnpost_out, lnprior_out, lnlike_out);
+        if (rc1 <= 0) return rc1;
+    }
     double *h = nullptr, *d = nullptr;
     int rc = ctx_stage(ctx, &h, &d);
     if (rc != ISO_OK) return rc;

@@ -35,39 +35,67 @@ __device__ __forceinline__ int64_t ref_searchsorted(const double* __restrict__ a
     return L;
 }
 
-// EEP of one star (interp.py:488-558).  Shared by the batch kernel below and the resident service wave (k_service.h).
+// EEP of one star (interp.py:488-558) in three steps - the cell on the (feh, mass) axes, the age search on each of the four
+// neighbouring tracks, the blend - shared by the batch kernel below (one lane does all of it) and the resident service wave
+// (k_service.h: four lanes search one track each).
+struct EepCell {
+    bool ok;
+    int64_t ind[4];
+    double d0, d1;
+};
+
+__device__ __forceinline__ EepCell interp_eep_cell(const EepArgs& A, const double* lds, double x, double x0, double x1)
+{
+    EepCell c;
+    c.ok = !(x != x || x0 != x0 || x1 != x1) && !out_of_axis(A.ax[0], lds, x0) && !out_of_axis(A.ax[1], lds, x1);
+    c.d0 = c.d1 = 0.0;
+    c.ind[0] = c.ind[1] = c.ind[2] = c.ind[3] = 0;
+    if (c.ok) {
+        int i0, i1;
+        bracket(A.ax[0], lds, x0, i0, c.d0);
+        bracket(A.ax[1], lds, x1, i1, c.d1);
+        c.ind[0] = (int64_t)i0 * A.n1 + i1;
+        c.ind[1] = (int64_t)i0 * A.n1 + i1 + 1;
+        c.ind[2] = (int64_t)(i0 + 1) * A.n1 + i1;
+        c.ind[3] = (int64_t)(i0 + 1) * A.n1 + i1 + 1;
+    }
+    return c;
+}
+
+__device__ __forceinline__ void interp_eep_track(const EepArgs& A, int64_t track, double x, int64_t& ie, int64_t& len)
+{
+    len = A.lengths[track];
+    ie = ref_searchsorted(A.ages + track * A.n_eep, x, len);
+}
+
+__device__ __forceinline__ double interp_eep_blend(const EepArgs& A, const EepCell& c, const int64_t* ie, const int64_t* len)
+{
+    if (!c.ok) return d_nan();
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) bad |= ie[k] > A.n_eep - 1;
+    if (bad) return d_nan();
+    double e[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) e[k] = A.eep0 + (double)ie[k];
+    if (ie[0] >= len[0]) e[0] = e[1];      // sequential substitution, as the reference
+    if (ie[1] >= len[1]) e[1] = e[0];
+    if (ie[2] >= len[2]) e[2] = e[3];
+    if (ie[3] >= len[3]) e[3] = e[2];
+    const double e_0 = (1 - c.d1) * e[0] + c.d1 * e[1];
+    const double e_1 = (1 - c.d1) * e[2] + c.d1 * e[3];
+    return (1 - c.d0) * e_0 + c.d0 * e_1;
+}
+
 __device__ __forceinline__ double interp_eep_point(const EepArgs& A, const double* lds, double x, double x0, double x1)
 {
-    double r = d_nan();
-    if (!(x != x || x0 != x0 || x1 != x1) && !out_of_axis(A.ax[0], lds, x0) && !out_of_axis(A.ax[1], lds, x1)) {
-        int i0, i1;
-        double d0, d1;
-        bracket(A.ax[0], lds, x0, i0, d0);
-        bracket(A.ax[1], lds, x1, i1, d1);
-        const int64_t ind[4] = {(int64_t)i0 * A.n1 + i1, (int64_t)i0 * A.n1 + i1 + 1,
-                                (int64_t)(i0 + 1) * A.n1 + i1, (int64_t)(i0 + 1) * A.n1 + i1 + 1};
-        int64_t ie[4], len[4];
-        bool bad = false;
+    const EepCell c = interp_eep_cell(A, lds, x, x0, x1);
+    int64_t ie[4] = {0, 0, 0, 0}, len[4] = {0, 0, 0, 0};
+    if (c.ok) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            len[k] = A.lengths[ind[k]];
-            ie[k] = ref_searchsorted(A.ages + ind[k] * A.n_eep, x, len[k]);
-            bad |= ie[k] > A.n_eep - 1;
-        }
-        if (!bad) {
-            double e[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) e[k] = A.eep0 + (double)ie[k];
-            if (ie[0] >= len[0]) e[0] = e[1];      // sequential substitution, as the reference
-            if (ie[1] >= len[1]) e[1] = e[0];
-            if (ie[2] >= len[2]) e[2] = e[3];
-            if (ie[3] >= len[3]) e[3] = e[2];
-            const double e_0 = (1 - d1) * e[0] + d1 * e[1];
-            const double e_1 = (1 - d1) * e[2] + d1 * e[3];
-            r = (1 - d0) * e_0 + d0 * e_1;
-        }
+        for (int k = 0; k < 4; ++k) interp_eep_track(A, c.ind[k], x, ie[k], len[k]);
     }
-    return r;
+    return interp_eep_blend(A, c, ie, len);
 }
 
 __global__ __launch_bounds__(BLOCK, 2) void k_interp_eep(const EepArgs A)

@@ -11,13 +11,14 @@
 // device-mapped host memory; here the request names what to evaluate:
 //
 //   host                                                   device (k_service, one wave)
-//   req[1..15] = target, its uid, <= 5 coordinates,
-//                <= 32 column / band numbers; req[0] = seq  -->  lanes 0-15 read the two request lines; the sequence word carries
-//                                                            the opcode, the column count and a 32-bit checksum of the other
-//                                                            fifteen words - two lines that did not arrive together are polled
-//                                                            again (iso_internal.h: mailbox_checksum)
-//                                                            the target's axes are staged in LDS when the target changes (its
-//                                                            uid: an address can be reused by another table)
+//   req[1..7] = target, <= 5 coordinates, <= 8 column /
+//               band numbers; req[0] = seq             -->  lanes 0-7 read the request line (one 64-B read over PCIe per poll); the
+//   (9-32 columns: req[8..10] behind the line)               sequence word carries the opcode, the column count and a 32-bit checksum
+//                                                            of the other words - a request whose words did not arrive together is
+//                                                            polled again (iso_internal.h: mailbox_checksum)
+//                                                            the target's axes are staged in LDS when the target changes (a
+//                                                            target's record is only freed after the wave was told to leave, so
+//                                                            its address names it)
 //                                                            evaluation: interp_point / interp_mag_point / interp_eep_point -
 //                                                            the per-sample bodies of k_interp / k_interp_mag / k_interp_eep,
 //                                                            the same instructions on the same inputs: results are the
@@ -32,7 +33,6 @@ constexpr int ISO_SVC_LDS_DOUBLES = MAX_LDS_AXIS_DOUBLES;
 
 // what a request addresses: device-resident, built once per table / interpolator / EEP table
 struct SvcTarget {
-    unsigned long long uid;
     int op, ndim, kind, pad_;
     InterpArgs I;          // op INTERP (x / out / icols / k / n unused: they come with the request)
     MagArgs M;             // op MAG    (pars / outputs / bc_cols / nb unused)
@@ -41,7 +41,8 @@ struct SvcTarget {
 
 struct IsoSvcBox {
     unsigned long long req[16];   // [0] sequence word (checksum << 32 | counter << 16 | columns << 8 | opcode), [1] target (device
-                                  // pointer), [2] its uid, [3..7] coordinates / parameters, [8..11] column numbers (a byte each)
+                                  // pointer), [2..6] coordinates / parameters, [7] column numbers 0-7 (a byte each); [8..10]
+                                  // column numbers 8-31 of a request with more than eight
     unsigned long long done[8];   // [0] sequence word of the last finished request
     unsigned long long ctl[8];    // [0] state (0 none, 1 running, 2 exited), [1] quit
     double out[8 + ISO_SVC_MAX_COLS];
@@ -65,11 +66,11 @@ __global__ __launch_bounds__(64, 1) void k_service(IsoSvcBox* mb, unsigned long 
     extern __shared__ double lds[];
     const int lane = (int)threadIdx.x;
     unsigned long long last = svc_load(&mb->done[0]);
-    unsigned long long staged = 0;                              // uid of the target whose axes are in LDS
+    unsigned long long staged = 0;                              // the target whose axes are in LDS
     const unsigned long long t_start = wall_clock64();
     unsigned long long t_idle = t_start;
     for (;;) {
-        const unsigned long long w = svc_load(&mb->req[lane & 15]);
+        const unsigned long long w = svc_load(&mb->req[lane & 7]);
         const unsigned long long seq = __shfl(w, 0);
         if (seq == last) {
             const unsigned long long now = wall_clock64();
@@ -77,13 +78,23 @@ __global__ __launch_bounds__(64, 1) void k_service(IsoSvcBox* mb, unsigned long 
             if (leave) break;                                  // (wave-uniform)
             continue;
         }
-        unsigned long long words[15];
-#pragma unroll
-        for (int q = 0; q < 15; ++q) words[q] = __shfl(w, 1 + q);
-        if (mailbox_checksum(words, 15) != (uint32_t)(seq >> 32)) continue;      // the two lines did not arrive together: poll again
         const int op = (int)(seq & 0xFF), k = (int)((seq >> 8) & 0xFF);
-        const SvcTarget* __restrict__ T = reinterpret_cast<const SvcTarget*>(words[0]);
-        if (words[1] != staged) {
+        unsigned long long words[10];
+#pragma unroll
+        for (int q = 0; q < 7; ++q) words[q] = __shfl(w, 1 + q);
+        words[7] = words[8] = words[9] = 0;
+        if (k > 8) {                                           // (wave-uniform) the column numbers behind the line
+            const unsigned long long w2 = svc_load(&mb->req[8 + (lane & 3)]);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) words[7 + q] = __shfl(w2, q);
+        }
+        if (mailbox_checksum(words, 10) != (uint32_t)(seq >> 32)) continue;      // the words did not arrive together: poll again
+        // the target's record through scalar loads (constant address space; the wave is told to leave before a record is freed)
+        typedef const __attribute__((address_space(4))) SvcTarget* const_target_ptr;
+        const unsigned long long tw = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(words[0] >> 32)) << 32) |
+                                      (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(words[0] & 0xFFFFFFFFull));
+        const SvcTarget* __restrict__ T = (const SvcTarget*)((const_target_ptr)(uintptr_t)tw);
+        if (tw != staged) {
             __syncthreads();
             if (op == ISO_SVC_INTERP) stage_axes<ISO_MAX_DIM>(T->I.ax, lds);
             else if (op == ISO_SVC_MAG) {
@@ -91,12 +102,12 @@ __global__ __launch_bounds__(64, 1) void k_service(IsoSvcBox* mb, unsigned long 
                 stage_axes<4>(T->M.g4.ax, lds);
             } else stage_axes<2>(T->E.ax, lds);
             __syncthreads();
-            staged = words[1];
+            staged = tw;
         }
         double x[5];
 #pragma unroll
-        for (int q = 0; q < 5; ++q) x[q] = __longlong_as_double((long long)words[2 + q]);
-        auto col = [&](int c) { return (int)((words[7 + (c >> 3)] >> (8 * (c & 7))) & 0xFFull); };
+        for (int q = 0; q < 5; ++q) x[q] = __longlong_as_double((long long)words[1 + q]);
+        auto col = [&](int c) { return (int)((words[6 + (c >> 3)] >> (8 * (c & 7))) & 0xFFull); };
         if (op == ISO_SVC_INTERP) {
             const int G = (k + 1) >> 1, sub = lane;            // lane `sub` owns the selected columns 2 sub, 2 sub + 1 (as k_interp)
             if (sub < G) {
@@ -129,8 +140,21 @@ __global__ __launch_bounds__(64, 1) void k_service(IsoSvcBox* mb, unsigned long 
                 if (has0) svc_out(&mb->out[3 + 2 * sub], m0);
                 if (has1) svc_out(&mb->out[3 + 2 * sub + 1], m1);
             }
-        } else if (lane == 0) {
-            svc_out(&mb->out[0], interp_eep_point(T->E, lds, x[0], x[1], x[2]));
+        } else {
+            // the four neighbouring tracks' age searches side by side (lanes 0-3; a search is up to eleven dependent reads)
+            const EepCell c = interp_eep_cell(T->E, lds, x[0], x[1], x[2]);
+            int64_t my_ie = 0, my_len = 0;
+            if (c.ok && lane < 4) {
+                const int64_t track = lane == 0 ? c.ind[0] : (lane == 1 ? c.ind[1] : (lane == 2 ? c.ind[2] : c.ind[3]));
+                interp_eep_track(T->E, track, x[0], my_ie, my_len);
+            }
+            int64_t ie[4], len[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                ie[q] = (int64_t)__shfl((long long)my_ie, q);
+                len[q] = (int64_t)__shfl((long long)my_len, q);
+            }
+            if (lane == 0) svc_out(&mb->out[0], interp_eep_blend(T->E, c, ie, len));
         }
         __threadfence_system();                                // results before the sequence word
         if (lane == 0) svc_store(&mb->done[0], seq);

@@ -28,9 +28,13 @@ def _is_scalar(v):
 
 class DFInterpolator:
     def __init__(self, df=None, filename=None, recalc=False, is_full=False, *, grid=None,
-                 index_columns=None, columns=None, index_names=None):
+                 index_columns=None, columns=None, index_names=None, device_grid=None):
         self.filename = filename
         self.is_full = is_full
+        # a table that ARRIVED on the device (broadcast_interpolator over RCCL): the device tensor is handed to the library as
+        # it is (iso_table_create_from_device) and the host copy behind `grid` is only made if somebody asks for it
+        self._device_grid = device_grid
+        self._grid = None
         self._handles = {}          # device index -> iso_table*
         self._generation = 0        # bumped whenever device tables are freed: dependants compare generations, not
                                     # pointer values (a new table often lands on the address of the freed one)
@@ -44,13 +48,17 @@ class DFInterpolator:
             self.index_columns = tuple(np.ascontiguousarray(a, dtype=float) for a in index_columns)
             self.index_names = list(index_names) if index_names is not None else [
                 "x%d" % i for i in range(len(self.index_columns))]
-            self.grid = np.ascontiguousarray(grid, dtype=float)
+            if device_grid is None:
+                self.grid = np.ascontiguousarray(grid, dtype=float)
+            elif (not device_grid.is_cuda or device_grid.dtype.itemsize != 8 or not device_grid.dtype.is_floating_point
+                  or not device_grid.is_contiguous()):
+                raise ValueError("device_grid must be a contiguous float64 CUDA tensor")
         self.n_columns = len(self.columns)
         self.ndim = len(self.index_columns)
         if self.ndim not in (2, 3, 4):
             raise ValueError("DFInterpolator supports 2-, 3- and 4-dimensional tables")
-        if self.grid.shape != tuple(len(a) for a in self.index_columns) + (self.n_columns,):
-            raise ValueError("grid shape %s does not match axes/columns" % (self.grid.shape,))
+        if self.grid_shape != tuple(len(a) for a in self.index_columns) + (self.n_columns,):
+            raise ValueError("grid shape %s does not match axes/columns" % (self.grid_shape,))
         for a in self.index_columns:
             if a.size < 2 or not np.all(np.diff(a) > 0):
                 raise ValueError("every index level needs >= 2 strictly increasing values")
@@ -59,6 +67,27 @@ class DFInterpolator:
     @classmethod
     def from_arrays(cls, grid, index_columns, columns, index_names=None):
         return cls(grid=grid, index_columns=index_columns, columns=columns, index_names=index_names)
+
+    @classmethod
+    def from_device(cls, device_grid, index_columns, columns, index_names=None):
+        """A table whose values are a float64 CUDA tensor [n0, .., n_columns] (axes on the host)."""
+        return cls(device_grid=device_grid, index_columns=index_columns, columns=columns, index_names=index_names)
+
+    @property
+    def grid(self):
+        """The dense table as a C-contiguous numpy array [n0, .., n_columns] (reference: DFInterpolator.grid); for a table
+        that arrived on the device the host copy is made on first use."""
+        if self._grid is None and self._device_grid is not None:
+            self._grid = self._device_grid.cpu().numpy()
+        return self._grid
+
+    @grid.setter
+    def grid(self, value):
+        self._grid = value
+
+    @property
+    def grid_shape(self):
+        return tuple(self._grid.shape) if self._grid is not None else tuple(self._device_grid.shape)
 
     # -- table construction (reference: _make_grid, interp.py:590-614) ---------------------
     def _make_grid(self, df, recalc=False):
@@ -90,6 +119,7 @@ class DFInterpolator:
         self.n_columns += 1
         self.columns = self.columns + [name]
         self.grid = newgrid
+        self._device_grid = None
         self.release()
 
     # -- device residency -------------------------------------------------------------------
@@ -100,12 +130,19 @@ class DFInterpolator:
         h = self._handles.get(device)
         if h is None:
             ctx = dev.context(device)
-            shape = (C.c_int64 * (self.ndim + 1))(*self.grid.shape)
+            shape = (C.c_int64 * (self.ndim + 1))(*self.grid_shape)
             dp = C.POINTER(C.c_double)
             axes = (dp * self.ndim)(*[a.ctypes.data_as(dp) for a in self.index_columns])
             h = C.c_void_p()
-            _cabi.check(_cabi.lib().iso_table_create(ctx, self.ndim, shape, self.grid.ctypes.data_as(dp),
-                                                     axes, C.byref(h)))
+            dg = self._device_grid
+            if dg is not None and dg.device.index == device and hasattr(_cabi.lib(), "iso_table_create_from_device"):
+                # the values are on this device already: one device-to-device copy instead of a download and an upload
+                _cabi.check(_cabi.lib().iso_table_create_from_device(ctx, self.ndim, shape, dev.ptr(dg), axes, C.byref(h)))
+                if self._grid is not None:
+                    self._device_grid = None            # (a host copy exists: the tensor is not needed any more)
+            else:
+                _cabi.check(_cabi.lib().iso_table_create(ctx, self.ndim, shape, self.grid.ctypes.data_as(dp),
+                                                         axes, C.byref(h)))
             self._handles[device] = h
         return h
 
@@ -152,7 +189,45 @@ class DFInterpolator:
                                            k, dev.ptr(out), dev.stream_ptr(device)))
         return out
 
+    def _scalar_interp(self, p, cols):
+        """One point given as plain numbers (the call form of the reference's notebooks and of optimisers that walk the
+        table, interp.py:631-660): everything a call needs besides the numbers - the table handle, the column numbers, a
+        coordinate buffer, an output buffer and their addresses - is kept per thread and per column list and revalidated by
+        one integer comparison, so that the wrapper adds about a microsecond to the C call (which the context's resident
+        service wave answers without a launch)."""
+        tls = self.__dict__.get("_scalar_tls")
+        if tls is None:
+            import threading
+            tls = self.__dict__.setdefault("_scalar_tls", threading.local())
+        cache = tls.__dict__.get("c")
+        if cache is None or cache[0] != self._generation:
+            cache = tls.c = (self._generation, {})
+        key = cols if type(cols) is str else tuple(cols)
+        c = cache[1].get(key)
+        if c is None:
+            icols = self._icols(cols)
+            if icols.size == 0 or icols.size > _cabi.ISO_MAX_COLS:
+                return None
+            xbuf = (C.c_double * self.ndim)()
+            out = np.empty(icols.size)
+            c = cache[1][key] = (self.handle(dev.current_device()), xbuf, C.addressof(xbuf), icols, icols.ctypes.data, icols.size, out,
+                                 out.ctypes.data, _cabi.lib().iso_interp_host)
+        xbuf = c[1]
+        for d in range(self.ndim):
+            xbuf[d] = p[d]
+        rc = c[8](c[0], c[2], 1, c[4], c[5], c[7])
+        if rc:
+            _cabi.check(rc)
+        return c[6].copy()
+
     def __call__(self, p, cols="all"):
+        tp = type(p)
+        if (tp is list or tp is tuple) and len(p) == self.ndim:
+            t0 = type(p[0])
+            if (t0 is float or t0 is int) and all(type(x) is float or type(x) is int for x in p):
+                r = self._scalar_interp(p, cols)
+                if r is not None:
+                    return r
         icols = self._icols(cols)
         p = list(p)[: self.ndim] if len(p) > self.ndim else list(p)
         if len(p) != self.ndim:

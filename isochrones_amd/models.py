@@ -243,10 +243,53 @@ class ModelGridInterpolator:
                                                    dev.stream_ptr(device)))
         return Teff, logg, feh, mags
 
+    def _scalar_interp_mag(self, pars, bands):
+        """interp_mag of five plain numbers (the reference's scalar form, models.py:416-431): handle, band columns, one
+        buffer [pars | Teff logg feh | mags] and its addresses are kept per thread and band list (revalidated by the
+        interpolator's generation number); the C call is answered by the context's resident service wave."""
+        for x in pars:
+            if not isinstance(x, (float, int, np.floating, np.integer)) or isinstance(x, bool):
+                return None
+        tls = self.__dict__.get("_scalar_tls")
+        if tls is None:
+            import threading
+            tls = self.__dict__.setdefault("_scalar_tls", threading.local())
+        cache = tls.__dict__.get("c")
+        gen = (self._generation, self.model_grid.interp._generation, self.bc_grid.interp._generation)
+        if cache is None or cache[0] != gen:
+            cache = tls.c = (gen, {})
+        key = tuple(bands) if bands else ()
+        c = cache[1].get(key)
+        if c is None:
+            nb = len(key)
+            if nb > _cabi.ISO_MAX_BANDS:
+                return None
+            h = self.handle(dev.current_device())
+            gen = (self._generation, self.model_grid.interp._generation, self.bc_grid.interp._generation)
+            if cache[0] != gen:                      # (handle() rebound the interpolator)
+                cache = tls.c = (gen, {})
+            buf = np.empty(8 + nb)
+            base = buf.ctypes.data
+            keep, bcp = dev.i32_array(self._band_cols(list(key)))
+            c = cache[1][key] = (h, buf, base, keep, bcp, nb, _cabi.lib().iso_interp_mag_host)
+        buf = c[1]
+        buf[0], buf[1], buf[2], buf[3], buf[4] = pars
+        base = c[2]
+        rc = c[6](c[0], base, 1, c[4], c[5], base + 40, base + 48, base + 56, base + 64)
+        if rc:
+            _cabi.check(rc)
+        out = buf[5:].copy()
+        return out[0], out[1], out[2], out[3:]
+
     def interp_mag(self, pars, bands):
         """(Teff, logg, feh, mags) at ``pars`` = the five ``param_names``.
         reference: isochrones/models.py:402-445 (scalar form -> mags.interp_mag, array form ->
         mags.interp_mags)."""
+        tp = type(pars)
+        if (tp is list or tp is tuple) and len(pars) == 5 and type(pars[0]) in (float, int, np.float64):
+            r = self._scalar_interp_mag(pars, bands)
+            if r is not None:
+                return r
         bands = list(bands) if bands else []
         if dev.is_tensor(pars) and pars.is_cuda:
             p = pars.double()
@@ -392,6 +435,26 @@ class ModelGridInterpolator:
             m, a, f = [np.resize(x, b.shape).astype(float).ravel() for x in (mass, age, feh)]
             return np.array([self.get_eep_accurate(mi, ai, fi, eep0=e if np.isfinite(e) else 300, **kwargs)
                              for mi, ai, fi, e in zip(m, a, f, np.ravel(eep0))])
+        if type(mass) in (float, int, np.float64) and type(age) in (float, int, np.float64) and type(feh) in (float, int, np.float64):
+            # the call form of the reference's notebooks: three plain numbers, one C call (the context's resident service
+            # wave); buffers and the table handle kept per thread
+            tls = self.__dict__.get("_eep_tls")
+            if tls is None:
+                import threading
+                tls = self.__dict__.setdefault("_eep_tls", threading.local())
+            c = tls.__dict__.get("c")
+            if c is None or c[0] != self._generation or c[1] != self.model_grid.interp._generation:
+                h = self._eep_handle(dev.current_device())
+                buf = (C.c_double * 4)()
+                base = C.addressof(buf)
+                c = tls.c = (self._generation, self.model_grid.interp._generation, h, buf, base, _cabi.lib().iso_interp_eep_host)
+            buf = c[3]
+            buf[0], buf[1], buf[2] = age, feh, mass
+            base = c[4]
+            rc = c[5](c[2], base, base + 8, base + 16, 1, base + 24)
+            if rc:
+                _cabi.check(rc)
+            return buf[3]
         args = [mass, age, feh]
         if any(dev.is_tensor(a) and a.is_cuda for a in args):
             import torch

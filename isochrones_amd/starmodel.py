@@ -1207,7 +1207,35 @@ class TreeStarModel(_NestedFitMixin, _ConvenienceMixin):
                                                     dev.ptr(prior), dev.ptr(like), dev.stream_ptr(device)))
         return (post, prior, like) if parts else post
 
+    def _scalar_call(self, p, which):
+        """lnpost / lnprior / lnlike of ONE host row as a float - how emcee / MultiNest drive a generic StarModel
+        (reference starmodel.py:538-542, 797, 952): handle, buffers and addresses are kept per thread and revalidated by
+        integer comparisons (as BasicStarModel._scalar_call); the C call is answered by the model's resident mailbox wave."""
+        from . import priors as _p
+        from .interp import TABLE_EPOCH
+        tls = self.__dict__.get("_scalar_tls")
+        if tls is None:
+            tls = self.__dict__.setdefault("_scalar_tls", threading.local())
+        c = getattr(tls, "c", None)
+        if (c is None or c[0] != _p.EPOCH[0] or c[1] != self.ic._generation or c[8] != TABLE_EPOCH[0]
+                or c[9] is not self._handles.get(c[10])):
+            device = dev.current_device()
+            h = self.handle(device)
+            buf, out = np.empty(self.n_params), np.empty(3)
+            c = tls.c = (_p.EPOCH[0], self.ic._generation, h, buf, out, buf.ctypes.data,
+                         tuple(out.ctypes.data + 8 * k for k in range(3)), _cabi.lib().iso_tree_lnpost_host, TABLE_EPOCH[0], h, device)
+        c[3][:] = p
+        a = c[6]
+        rc = c[7](c[2], c[5], 1, a[0] if which == 0 else None, a[1] if which == 1 else None, a[2] if which == 2 else None)
+        if rc:
+            _cabi.check(rc)
+        return float(c[4][which])
+
     def _evaluate(self, p, which):
+        tp = type(p)
+        if ((tp is list or tp is tuple or (tp is np.ndarray and p.ndim == 1)) and len(p) == self.n_params
+                and not isinstance(p[0], (list, tuple, np.ndarray))):
+            return self._scalar_call(p, which)
         if dev.is_tensor(p) and p.is_cuda:
             single = p.dim() == 1
             out = self.evaluate_device(p.double()[None, :] if single else p.double(), parts=which != 0)

@@ -135,8 +135,15 @@ def test_bench_single_rank_default_line_has_roofline_and_cpu_baseline():
     assert cb["parity_max_rel_err"] < 1e-9
     assert set(cb["modes"]) == {"B1_scalar_call", "B2_one_thread_1e4", "B2_one_thread_full_batch", "B3_all_cores_full_batch",
                                 "B3_quota_threads_full_batch"}
-    # the all-cores figure is the best pass; beside it the stable one: threads = min(cores, cgroup quota), median pass
-    assert cb["value_quota"] > 0 and cb["quota_threads"] >= 1 and cb["value_quota"] <= cb["value"] * 1.5
+    # `value` is the reproducible figure - threads = min(cores, cgroup quota), median pass; beside it the best pass of all threads
+    assert cb["value"] == cb["value_quota"] and cb["cores"] == cb["quota_threads"] >= 1
+    assert cb["value_best_pass"] > 0 and cb["value"] <= cb["value_best_pass"] * 1.5
+    # the one number of every secondary leg, in the head of the line
+    sm = r["summary"]
+    assert list(r).index("summary") < list(r).index("startup") and list(r).index("cpu_baseline") < list(r).index("startup")
+    for key in ("cfg3_binary_6_bands_prior_valid_evals_per_s", "cfg4_us_per_step", "catalog_reference_shape_stars_per_s",
+                "catalog_32x250_track_10000_stars_per_s", "speedup_vs_cpu_quota_threads", "catalog_reference_shape_projection_8gpu_speedup"):
+        assert sm[key] > 0, key
     # every secondary line carries what bounds it (memory side or VALU issue), as a fraction that cannot exceed 1
     c3 = r["cfg3_binary_6_bands"]
     assert "error" not in c3

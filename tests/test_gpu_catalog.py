@@ -297,6 +297,57 @@ def test_three_wave_workgroups_of_the_register_capped_form(N, nb, W, monkeypatch
     post.close()
 
 
+@pytest.mark.parametrize("W,nb,n_ens", [(16, 1, 1), (32, 3, 1), (100, 6, 1), (128, 9, 1), (128, 12, 1), (256, 9, 1), (32, 3, 2), (32, 3, 4), (300, 3, 1)])
+def test_single_triple_with_one_star_per_row_makes_the_plain_kernels_chain(W, nb, n_ens, monkeypatch):
+    """k_stretch_triple (a single triple with the default priors: lanes l, l + 16, l + 32 of a wave share a move, one star
+    each, 64 moves per chunk) against the plain persistent kernel (ISOCHRONES_AMD_STAR_LANES=0) and the step-wise kernel:
+    chains, lnprob, final state and acceptance counters bit for bit; the library names the kernel it took - the row form
+    up to 64 moves per half-step and workgroup, the plain one beyond.  The 256-walker, 9-band case is the shape whose LDS
+    (67 KB laid out for two ensembles) sent it to one launch per half-step until round 6."""
+    import torch
+    from isochrones_amd import _cabi
+    from isochrones_amd.catalog import initial_positions
+    bands = list(ia.grids.KNOWN_BANDS[:nb])
+    ic = ia.synthetic_isochrone(bands=bands)
+    cat, truth = synthetic_catalog(ic, 1, bands=bands, seed=8, mag_unc=0.02, with_parallax=True)
+    post = CatalogPosterior.from_catalog(cat, ic, N=3)
+    pos, lnp, failed = initial_positions(post, W, rng_seed=5, oversample=8, max_tries=4)
+    assert not bool(failed.any())
+    post.close()
+    mod = cat.model(0, ic, N=3)
+    p0, l0 = pos[0], lnp[0]
+    if n_ens > 1:
+        p0, l0 = p0.unsqueeze(0).repeat(n_ens, 1, 1), l0.unsqueeze(0).repeat(n_ens, 1)
+
+    def run(mode):
+        from isochrones_amd.sampler import FusedEnsembleSampler
+        monkeypatch.setenv("ISOCHRONES_AMD_SAMPLER", mode)
+        kw = dict(n_ensembles=n_ens) if n_ens > 1 else {}
+        fs = FusedEnsembleSampler(mod, W, seed=9, **kw)
+        a, b = fs.run_mcmc(p0, 20, lnprob0=l0, store=True)
+        a2, b2 = fs.run_mcmc(a, 5, lnprob0=b, store=True)
+        return a2.clone(), b2.clone(), fs.chain.clone(), fs.lnprobability.clone(), fs.accepted.clone()
+
+    monkeypatch.setenv("ISOCHRONES_AMD_STAR_LANES", "0")
+    step = run("stepwise")
+    plain = run("persistent")
+    monkeypatch.delenv("ISOCHRONES_AMD_STAR_LANES")
+    _cabi.trace_kernels(True)
+    try:
+        rows = run("persistent")
+        names = _cabi.traced_kernels()
+        plan = _cabi.last_sampler_plan()
+    finally:
+        _cabi.trace_kernels(False)
+    assert plan["persistent"] == 1, plan                   # (also the 256-walker, 9-band ensemble: 67 KB of LDS, asked for)
+    moves_per_workgroup = min(n_ens, plan["group"]) * W // 2
+    assert any(n.startswith("k_stretch_triple<%d>" % nb) for n in names) == (moves_per_workgroup <= 64), (names, plan)
+    for x, y, z in zip(step, plain, rows):
+        assert torch.equal(x, y) and torch.equal(x, z)
+    assert int(rows[4].sum()) > 0
+    ic.release()
+
+
 @pytest.mark.parametrize("W,nb,n_ens", [(16, 1, 1), (32, 3, 1), (100, 6, 1), (128, 11, 1), (200, 2, 1), (256, 4, 1), (32, 3, 4), (300, 3, 1)])
 def test_single_binary_with_one_star_per_lane_makes_the_plain_kernels_chain(W, nb, n_ens, monkeypatch):
     """k_stretch_pair (a single binary, lanes l and l + 32 of a wave share a move, one star each) against the plain
@@ -339,7 +390,7 @@ def test_single_binary_with_one_star_per_lane_makes_the_plain_kernels_chain(W, n
         _cabi.trace_kernels(False)
     moves = n_ens * W // 2
     expect_pair = moves <= 128 and (moves <= 64 or nb <= 4)
-    assert any(n.startswith("k_stretch_pair<%d, " % nb) for n in names) == expect_pair, names
+    assert any(n.startswith("k_stretch_pair<%d>" % nb) for n in names) == expect_pair, names
     for x, y, z in zip(step, plain, pair):
         assert torch.equal(x, y) and torch.equal(x, z)
     assert int(pair[4].sum()) > 0

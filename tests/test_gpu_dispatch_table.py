@@ -344,22 +344,18 @@ def test_fused_families(kind, ns, nb):
                     pw = start_ball(rng, mod, kind, ns, W)
                     with env(ISOCHRONES_AMD_SAMPLER="persistent", ISOCHRONES_AMD_STAR_LANES=None), traced(tid) as t:
                         check_sampler(mod, oic, pw, W, 10, 178 + nb + W, tid + " one star per lane, std priors, W=%d" % W)
-                    expect(t.names, "k_stretch_pair<%d, true>" % nb, tid)
-                with env(ISOCHRONES_AMD_SAMPLER="persistent", ISOCHRONES_AMD_STD_PRIORS="0", ISOCHRONES_AMD_STAR_LANES=None), traced(tid) as t:
-                    check_sampler(mod, oic, p0, 16, 10, 179 + nb, tid + " one star per lane, run-time priors")
-                expect(t.names, "k_stretch_pair<%d, false>" % nb, tid)
+                    expect(t.names, "k_stretch_pair<%d>" % nb, tid)
             if triple:
                 # one star per ROW of a wave (k_stretch_triple): 8 moves per half-step (half a row), 75 (two chunks of 64, the
                 # second one partly filled), 150 (the reference's default 300 walkers: three chunks)
-                for W in ((16, 150) if nb % 3 else (16, 300)):
+                for W in ((16, 128) if nb % 3 else (16, 100)):      # 8, 64, 50 moves per half-step (beyond 64 the plain form runs)
                     pw = start_ball(rng, mod, kind, ns, W)
                     with env(ISOCHRONES_AMD_SAMPLER="persistent", ISOCHRONES_AMD_STAR_LANES=None), traced(tid) as t:
                         check_sampler(mod, oic, pw, W, 6, 378 + nb + W, tid + " one star per row, std priors, W=%d" % W)
-                    expect(t.names, "k_stretch_triple<%d, true>" % nb, tid)
-                with env(ISOCHRONES_AMD_SAMPLER="persistent", ISOCHRONES_AMD_STD_PRIORS="0", ISOCHRONES_AMD_STAR_LANES=None), traced(tid) as t:
-                    check_sampler(mod, oic, p0, 16, 10, 379 + nb, tid + " one star per row, run-time priors")
+                    expect(t.names, "k_stretch_triple<%d>" % nb, tid)
+                with env(ISOCHRONES_AMD_SAMPLER="persistent", ISOCHRONES_AMD_STAR_LANES=None), traced(tid) as t:
                     check_sampler(mod, oic, p0, 16, 6, 380 + nb, tid + " one star per row, three ensembles", n_ensembles=3)
-                expect(t.names, "k_stretch_triple<%d, false>" % nb, tid)
+                expect(t.names, "k_stretch_triple<%d>" % nb, tid)
             if not astero:
                 # register-capped form with a single model (many ensembles of one star run it in rounds)
                 # (default priors: the register-capped form with the families compiled in; read at run time when told so)
@@ -392,14 +388,11 @@ def test_fused_families(kind, ns, nb):
             with env(ISOCHRONES_AMD_SAMPLER="persistent", ISOCHRONES_AMD_STAR_LANES="0"), traced(tid) as t:
                 check_sampler(mod, oic, p0, 16, 10, 278 + nb, w + " persistent")
             expect(t.names, "k_stretch_persist<%d, %d, %d, false, %s, true, false>" % (K, ns, nb, a), tid)
-            if kind == "iso" and ns == 2 and not astero:
+            if kind == "iso" and ns in (2, 3) and not astero:
+                # (non-default priors: the one-star-per-lane / -per-row kernels exist for the default families only)
                 with env(ISOCHRONES_AMD_SAMPLER="persistent", ISOCHRONES_AMD_STAR_LANES=None), traced(tid) as t:
-                    check_sampler(mod, oic, p0, 16, 10, 279 + nb, w + " one star per lane")
-                expect(t.names, "k_stretch_pair<%d, false>" % nb, tid)
-            if kind == "iso" and ns == 3 and not astero:
-                with env(ISOCHRONES_AMD_SAMPLER="persistent", ISOCHRONES_AMD_STAR_LANES=None), traced(tid) as t:
-                    check_sampler(mod, oic, p0, 16, 10, 289 + nb, w + " one star per row")
-                expect(t.names, "k_stretch_triple<%d, false>" % nb, tid)
+                    check_sampler(mod, oic, p0, 16, 10, 279 + nb, w + " star lanes allowed")
+                expect(t.names, "k_stretch_persist<%d, %d, %d, false, false, true, false>" % (K, ns, nb), tid)
             if not astero:
                 with env(ISOCHRONES_AMD_SAMPLER="persistent-dense"), traced(tid) as t:
                     check_sampler(mod, oic, p0, 16, 8, 280 + nb, w + " persistent dense", n_ensembles=3)
@@ -531,6 +524,18 @@ def check_tree(mod, oic, rng, what):
     fx.assert_close(mod.lnpost(x), w_post, RTOL, atol=ATOL, what=what + " lnpost")
     fx.assert_close(mod.lnprior(x), w_prior, RTOL, atol=ATOL, what=what + " lnprior")
     fx.assert_close(mod.lnlike(x), w_like, RTOL, atol=ATOL, what=what + " lnlike")
+    # the per-point callback: one row at a time through the model's resident mailbox wave (k_mailbox_tree,
+    # fast/tree_mailbox.h) - the batch's numbers bit for bit, special values included
+    if True:      # (a tree off the corner-packed path has no resident wave: the same calls then compare two launch paths)
+        rows = list(range(24)) + list(range(n - 6 * c.size, n - 6 * c.size + 12))
+        batch = [np.asarray(f(x[rows])) for f in (mod.lnpost, mod.lnprior, mod.lnlike)]
+        with env(ISOCHRONES_AMD_MAILBOX=None):
+            one = [np.array([f(list(x[r])) for r in rows]) for f in (mod.lnpost, mod.lnprior, mod.lnlike)]
+        with env(ISOCHRONES_AMD_MAILBOX="0"):
+            launch = [np.array([f(list(x[r])) for r in rows[:8]]) for f in (mod.lnpost, mod.lnprior, mod.lnlike)]
+        for a_, b_, c_ in zip(one, batch, launch):
+            assert np.array_equal(a_, b_, equal_nan=True), what + " mailbox wave vs batch"
+            assert np.array_equal(a_[:8], c_, equal_nan=True), what + " mailbox wave vs launch"
 
 
 def check_tree_sampler(mod, oic, rng, what, W=16, steps=10, seed=5):
@@ -571,6 +576,8 @@ def test_tree_families(nb):
                 check_tree(mod, oic, rng, "%s leaves=%d" % (tid, leaves))
             nl = leaves if (leaves <= 4 and nb <= 8) else 0
             expect(t.names, "k_lnpost_tree_fast<%d, %d>" % (nb, nl), tid)
+            if nl:      # the per-point callback's resident wave (register form only)
+                expect(t.names, "k_mailbox_tree<%d, %d>" % (nb, nl), tid)
             with traced(tid) as t:
                 check_tree_sampler(mod, oic, rng, "%s leaves=%d sampler" % (tid, leaves), seed=300 + 10 * nb + leaves)
             expect(t.names, "k_stretch_tree<%d, %d>" % (nb, nl), tid)
@@ -655,6 +662,19 @@ def test_interpolation_families():
         want = orc.OracleTable(grid, axes).interp(xs, [1, 3, 4])
         fx.assert_close(got, want, 1e-11, atol=1e-12, what="k_interp<%d>" % nd)
         expect(t.names, "k_interp<%d>" % nd, tid)
+        # ONE point: the context's resident service wave (kernels/k_service.h) - the launch path's numbers bit for bit, the
+        # oracle's to rounding; points outside the table and NaN coordinates included
+        __import__("time").sleep(0.005)                   # (a wave an earlier one-point call started has left: idle 1 ms)
+        pts = [[float(x[i]) for x in xs] for i in range(40)] + [[float("nan")] + [float(x[0]) for x in xs[1:]]]
+        with env(ISOCHRONES_AMD_MAILBOX=None), traced(tid) as t:
+            one = np.array([dfi(p, ["c1", "c3", "c4"]) for p in pts])
+            all5 = np.array([dfi(p) for p in pts[:8]])
+        expect(t.names, "k_service", tid)
+        with env(ISOCHRONES_AMD_MAILBOX="0"):
+            assert np.array_equal(one, np.array([dfi(p, ["c1", "c3", "c4"]) for p in pts]), equal_nan=True)
+            assert np.array_equal(all5, np.array([dfi(p) for p in pts[:8]]), equal_nan=True)
+        fx.assert_close(one[:40], want[:40], 1e-11, atol=1e-12, what="service wave, %d-D table" % nd)
+        assert np.isnan(one[40]).all()
     for kind in ("track", "iso"):
         K = KIND_ID[kind]
         for nb in range(1, 13):
@@ -668,6 +688,28 @@ def test_interpolation_families():
                 T, g_, f, m = ic.interp_mag([x[:, j] for j in range(5)], list(bands))        # >= 32 768 rows: the packed form
             fx.assert_close(T, wT, RTOL, what="Teff"); fx.assert_close(m, wm, RTOL, atol=ATOL, what="mags %s %d" % (kind, nb))
             expect(t.names, "k_interp_mag_fast<%d, %d>" % (K, nb), tid)
+            if nb in (1, 2, 5, 12):
+                # one point at a time: interp_mag / interp_value through the resident service wave, alternating targets (the
+                # wave restages its axes when the target changes) - bit for bit the one-point launch, and the oracle's numbers
+                rows = [list(map(float, x[i])) for i in range(24)]
+                mi = ic.model_grid.interp
+                order = [2, 0, 1] if kind == "track" else [1, 2, 0]
+                props = ["Teff", "logg", "Mbol"]
+                with env(ISOCHRONES_AMD_MAILBOX=None), traced(tid) as t:
+                    got_m = [ic.interp_mag(r, list(bands)) for r in rows]
+                    got_v = np.array([ic.interp_value(r, props) for r in rows])
+                expect(t.names, "k_service", tid)
+                with env(ISOCHRONES_AMD_MAILBOX="0"):
+                    ref_m = [ic.interp_mag(r, list(bands)) for r in rows]
+                    ref_v = np.array([ic.interp_value(r, props) for r in rows])
+                for a_, b_ in zip(got_m, ref_m):
+                    assert all(np.array_equal(np.asarray(u), np.asarray(v), equal_nan=True) for u, v in zip(a_, b_))
+                assert np.array_equal(got_v, ref_v, equal_nan=True)
+                fx.assert_close(np.array([np.asarray(g4[3]) for g4 in got_m]), wm[:24], RTOL, atol=ATOL, what="service wave mags %s %d" % (kind, nb))
+                fx.assert_close(np.array([g4[0] for g4 in got_m]), wT[:24], RTOL, what="service wave Teff")
+                want_v = orc.OracleTable(mi.grid, mi.index_columns).interp([x[:24, order[0]], x[:24, order[1]], x[:24, order[2]]],
+                                                                            [mi.column_index[c] for c in props])
+                fx.assert_close(got_v, want_v, RTOL, atol=ATOL, what="service wave interp_value")
             if nb == 2:
                 with traced(tid) as t:
                     T, g_, f, m = ic.interp_mag([x[:500, j] for j in range(5)], list(bands))  # small batch: column-parallel form
@@ -707,6 +749,28 @@ def test_eep_unit_cube_and_summary_families():
     want = orc.interp_eep(a, f, m, np.asarray(ic.model_grid.fehs, float), np.asarray(ic.model_grid.masses, float), ic._age_grid, ic._array_lengths)
     assert np.isfinite(want).sum() > 500
     fx.assert_close(e, want + (float(ic.model_grid.interp.index_columns[2][0]) - 1.0), 1e-12, what="get_eep vs oracle")
+    # ... and one star at a time through the resident service wave: the same numbers bit for bit
+    __import__("time").sleep(0.005)
+    with env(ISOCHRONES_AMD_MAILBOX=None), traced(tid) as t:
+        e1 = np.array([ic.get_eep(float(m[i]), float(a[i]), float(f[i])) for i in range(60)])
+    expect(t.names, "k_service", tid)
+    assert np.array_equal(e1, np.asarray(e)[:60], equal_nan=True)
+    with env(ISOCHRONES_AMD_MAILBOX="0"):
+        assert np.array_equal(e1, np.array([ic.get_eep(float(m[i]), float(a[i]), float(f[i])) for i in range(60)]), equal_nan=True)
+    # a catalog fit whose batch holds a star without start points (k_catalog_patch_failed keeps the batch rectangular on the
+    # device): the rows of the host-checked path of rounds 1-5, bit for bit; the hopeless star's row is blank with ok = 0
+    from isochrones_amd.catalog import fit_stars_gpu
+    icc = ia.synthetic_track(bands=("G", "BP", "RP"))
+    cat, _ = ia.synthetic_catalog(icc, 40, bands=["G", "BP", "RP"], seed=3, mag_unc=0.01)
+    cat.measurements["G"][1][7] = 0.0                 # an uncertainty of zero: log(0) in every candidate's likelihood - no start point
+    with traced(tid) as t:
+        rows_lean = fit_stars_gpu(cat, icc, np.arange(40), nwalkers=32, nburn=20, niter=20, seed=4)
+    expect(t.names, "k_catalog_patch_failed", tid)
+    with env(ISOCHRONES_AMD_CATALOG_LEAN="0"):
+        rows_host = fit_stars_gpu(cat, icc, np.arange(40), nwalkers=32, nburn=20, niter=20, seed=4)
+    assert np.array_equal(rows_lean, rows_host, equal_nan=True)
+    assert rows_lean[7, -1] == 0.0 and np.isnan(rows_lean[7, :-1]).all() and (rows_lean[np.arange(40) != 7, -1] == 1.0).all()
+    icc.release()
     # k_unit_cube
     mod = ia.SingleStarModel(ic, Teff=(5770, 100), G=(10.0, 0.02))
     cube = rng.uniform(size=(1000, 5))

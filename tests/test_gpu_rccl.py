@@ -34,10 +34,27 @@ tm = {}
 ic = ia.broadcast_interpolator(ic0, src=0, rebuild_on_src=True, timings=tm)
 assert ic is not ic0
 out["broadcast"] = tm
-for a, b in ((ic.model_grid.interp, ic0.model_grid.interp), (ic.bc_grid.interp, ic0.bc_grid.interp)):
-    assert np.array_equal(a.grid, b.grid, equal_nan=True) and list(a.columns) == list(b.columns)
-    assert all(np.array_equal(x, y) for x, y in zip(a.index_columns, b.index_columns))
+# ... and STAY on the device: the tensors that arrived are what the library's tables are made from (one device-to-device copy,
+# iso_table_create_from_device); no host copy exists until somebody asks for `.grid`
+assert tm["tables_stay_on_device"] is True
+for a in (ic.model_grid.interp, ic.bc_grid.interp):
+    assert a._device_grid is not None and a._device_grid.is_cuda and a._grid is None
 assert ic.bands == ic0.bands and tuple(ic.eep_bounds) == tuple(ic0.eep_bounds) and ic.kind == ic0.kind
+pts = np.random.default_rng(1).uniform([0.75, 260.0, -0.9, 50.0, 0.0], [1.9, 450.0, 0.4, 500.0, 0.5], (2000, 5))
+got = ic.interp_mag([pts[:, j] for j in range(5)], ["G", "BP", "RP"])
+ref = ic0.interp_mag([pts[:, j] for j in range(5)], ["G", "BP", "RP"])
+assert all(np.array_equal(np.asarray(x), np.asarray(y), equal_nan=True) for x, y in zip(got, ref))     # same tables, bit for bit
+assert ic.model_grid.interp._grid is None                                # (still no download)
+for a, b in ((ic.model_grid.interp, ic0.model_grid.interp), (ic.bc_grid.interp, ic0.bc_grid.interp)):
+    assert np.array_equal(a.grid, b.grid, equal_nan=True) and list(a.columns) == list(b.columns)     # the lazy host copy
+    assert all(np.array_equal(x, y) for x, y in zip(a.index_columns, b.index_columns))
+# the host round trip of rounds 1-5 on request: the same interpolator
+os.environ["ISOCHRONES_AMD_BROADCAST"] = "host"
+tmh = {}
+ich = ia.broadcast_interpolator(ic0, src=0, rebuild_on_src=True, timings=tmh)
+os.environ.pop("ISOCHRONES_AMD_BROADCAST")
+assert tmh["tables_stay_on_device"] is False and ich.model_grid.interp._device_grid is None
+out["broadcast_host_round_trip"] = tmh
 # 2. fit_catalog: the shard (all stars at world 1) is fitted on the device, the rows go through all_gather_into_tensor
 rng = np.random.default_rng(3)
 cat, truth = ia.synthetic_catalog(ic, 96, bands=["G", "BP", "RP"], seed=5, mag_unc=0.01)

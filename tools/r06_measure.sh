@@ -54,6 +54,18 @@ catalog)
   python tools/ab_kernels.py --cases cfg4,cfg5,cfg5ref --label default 2>/dev/null | grep '^{' | tee -a $OUT/ab_default.jsonl | cut -c1-1500 ;;
 catalog_tests)
   timeout 2400 python -m pytest tests/test_gpu_catalog.py tests/test_gpu_sampler_oracle.py tests/test_gpu_start_points.py -q -x 2>&1 | tail -8 | tee $OUT/pytest_catalog.txt ;;
+service)
+  timeout 1500 python -m pytest tests/test_gpu_dispatch_table.py -q -x -k "interpolation or eep_unit" 2>&1 | tail -15 | tee $OUT/pytest_service.txt
+  python tools/scalar_latency.py 2>&1 | grep -v amdgpu.ids | head -10 | tee $OUT/scalar_latency.txt
+  ISOCHRONES_AMD_MAILBOX=0 python tools/scalar_latency.py 2>&1 | grep -v amdgpu.ids | head -10 | tee $OUT/scalar_latency_launch_path.txt ;;
+waves)
+  timeout 1500 python -m pytest tests/test_gpu_resident_waves.py tests/test_gpu_sampler_any.py -q -x 2>&1 | tail -12 | tee $OUT/pytest_waves.txt
+  timeout 1500 python -m pytest tests/test_gpu_dispatch_table.py -q -x -k "tree or interpolation or eep_unit" 2>&1 | tail -12 | tee -a $OUT/pytest_waves.txt ;;
+groups)
+  python tools/catalog_sizes.py --sizes 313,1250,2500 --groups 0,2,4,8 2>/dev/null | grep "^{" | tee -a $OUT/catalog_groups.jsonl | cut -c1-330 ;;
+bcast)
+  python tools/broadcast_ab.py 3 2>/dev/null | grep "^{" | tee $OUT/broadcast_ab.jsonl
+  timeout 900 python -m pytest tests/test_gpu_rccl.py -q -x 2>&1 | tail -5 | tee $OUT/pytest_rccl.txt ;;
 replay)
   timeout 1500 python -m pytest tests/test_gpu_sampler_oracle.py -q -x -k "reference_shape" 2>&1 | tail -15 | tee $OUT/pytest_replay.txt ;;
 tree)

@@ -18,6 +18,11 @@ t("ic.interp_mag(p, ['V'])", lambda: ic.interp_mag(p, ["V"]))
 t("ic.model_grid.interp([0.0,1.0,355.0], ['Teff'])", lambda: ic.model_grid.interp([0.0, 1.0, 355.0], ["Teff"]))
 t("ic.get_eep(1.0, 9.6, 0.0)", lambda: ic.get_eep(1.0, 9.6, 0.0))
 t("ic.mass(*p[:3])", lambda: ic.mass(*p[:3]))
+import bench_configs
+tmod, tpars = bench_configs.tree_model_and_samples(16)
+tp = [float(v) for v in tpars[0]]
+t("tree model (resolved binary) lnpost(p)", lambda: tmod.lnpost(tp))
+assert tmod.lnpost(tp) == float(tmod.lnpost(np.array([tp, tp]))[0])
 half = np.tile(np.array(p), (128, 1)) * (1 + 1e-3 * np.random.default_rng(0).standard_normal((128, 5)))
 t("mod.lnpost(half ensemble [128, 5])", lambda: mod.lnpost(half))
 os.environ["ISOCHRONES_AMD_HOST_SYNC"] = "1"          # A/B: the stream-synchronise completion of round 1
