@@ -129,7 +129,10 @@ __device__ __forceinline__ void bterm_sum(const DevTree& T, const TreeLeaves<NB,
                 // the two sums independent of the flag)
                 const double ref = tt.relative ? S.template addmags_band<B>(tt.ref_mask) : 0.0;
                 const double r = tt.dmag - (mod - ref);
-                term[u] = have ? tt.g0 - (r * r) * tt.hinv : 0.0;
+                // (explicit fused multiply-adds in the likelihood's terms: the evaluation is instantiated in several kernels -
+                // batch, sampler, mailbox wave - and left to -ffp-contract=fast the compiler fused a term's g0 - r^2 h one
+                // way in one of them and another way in the next, a 1-ulp difference between the batch kernel and the mailbox)
+                term[u] = have ? fma(-(r * r), tt.hinv, tt.g0) : 0.0;
             }
 #pragma unroll
             for (int u = 0; u < ISO_TREE_TERM_UNROLL; ++u) lnl += term[u];
@@ -298,7 +301,7 @@ __device__ __forceinline__ double tree_lnpost(const FastArgs& A, const DevTree& 
                 mag -= tt.ref_mag;
             }
             const double r = mag - mod;
-            lnl += T.term_g0[t] - (r * r) * T.term_hinv[t];
+            lnl += fma(-(r * r), T.term_hinv[t], T.term_g0[t]);
             if (!isfinite(lnl)) bad = true;
         }
         // (register form: no exits - a partial sum that is not finite stays so, one test at the end says the same as the
@@ -307,7 +310,7 @@ __device__ __forceinline__ double tree_lnpost(const FastArgs& A, const DevTree& 
         for (int k = 0; k < T.n_spec && !(EXITS && bad); ++k) {
             const iso_tree_prop& sp = T.spec[k];
             const double r = sp.a - S.prop(sp.leaf, sp.prop);
-            lnl += T.spec_g0[k] - (r * r) * T.spec_hinv[k];
+            lnl += fma(-(r * r), T.spec_hinv[k], T.spec_g0[k]);
             if (EXITS && !isfinite(lnl)) bad = true;
         }
         for (int k = 0; k < T.n_limits && !(EXITS && bad); ++k) {
@@ -318,13 +321,13 @@ __device__ __forceinline__ double tree_lnpost(const FastArgs& A, const DevTree& 
         if (!EXITS || !bad) {
             for (int s = 0; s < T.n_systems; ++s)
                 if (T.has_plx[s]) {
-                    const double r = T.plx_val[s] - 1.0 / par(T.sys_base[s] + T.n_stars[s] + 2) * 1000.0;
-                    lnl += T.plx_g0[s] - (r * r) * T.plx_hinv[s];
+                    const double r = fma(-(1.0 / par(T.sys_base[s] + T.n_stars[s] + 2)), 1000.0, T.plx_val[s]);
+                    lnl += fma(-(r * r), T.plx_hinv[s], T.plx_g0[s]);
                 }
             for (int s = 0; s < T.n_systems; ++s)
                 if (T.has_av[s]) {
                     const double r = T.av_val[s] - par(T.sys_base[s] + T.n_stars[s] + 3);
-                    lnl += T.av_g0[s] - (r * r) * T.av_hinv[s];
+                    lnl += fma(-(r * r), T.av_hinv[s], T.av_g0[s]);
                 }
             if (!isfinite(lnl)) bad = true;
         }

@@ -165,9 +165,11 @@ static __device__ unsigned long long g_phase_stamps[16];
 #define ISO_COOP_STAR3_PER 2
 #endif
 // the resident catalog kernel of stars that share the reference's default priors (STDP without UNI): a small catalog is
-// latency-bound like a single star's fit - lane BC gather (one band: lnpost_wave.h) and the table-free priors during the model gather
+// latency-bound like a single star's fit - lane BC gather (one band: lnpost_wave.h), the table-free priors during the model
+// gather and (round 6) the model gather by three lanes per sample: 313 stars at 32 walkers 3.03 -> 2.81 ms, 1 250 stars
+// 3.50 -> 3.43, 10^4 stars 8.39 -> 8.23-8.41 (profiles/r06/catalog_msl.jsonl; the same rows)
 #ifndef ISO_MULTI_STD_LANE
-#define ISO_MULTI_STD_LANE 6
+#define ISO_MULTI_STD_LANE 14
 #endif
 
 #include "fast/brackets.h"

@@ -64,6 +64,7 @@ __global__ __launch_bounds__(64, 2) void k_mailbox_tree(const FastArgs A, const 
     TreeLeaves<NB, NL> S;
     S.lds_ = nullptr;
     S.stride_ = 64;
+    double* lpar = lds + ((A.axes_len + 1) & ~1) + 64 * slot_stride(NB);      // the request's 32 words behind the gather slots
     const int lane = (int)threadIdx.x;
     auto sys_load = [](const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
     auto sys_store = [](unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
@@ -95,7 +96,17 @@ __global__ __launch_bounds__(64, 2) void k_mailbox_tree(const FastArgs A, const 
         }
         if (c != (uint32_t)(seq >> 32)) continue;          // the lines did not arrive together: poll again
         const bool parts = ((seq >> 8) & 1) != 0;
-        auto par = [&](int j) { return __longlong_as_double((long long)word(j)); };
+        // the parameters go through LDS and are read from there as the batch kernel reads them from memory: plain loads, so
+        // that the evaluation is the same expression tree in both kernels (with the words taken straight from the request
+        // registers the compiler shared subexpressions differently and contracted other multiply-adds: lnlike of the
+        // one-band one-star tree differed from the batch kernel's in the last bits)
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 32) lpar[lane] = __longlong_as_double((long long)w);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const double* __restrict__ src = lpar + 1;
+        auto par = [&](int j) { return src[j]; };
         double lnp, lnl;
         const double post = tree_lnpost<NB, NL>(A, T, lds, L, lane == 0, par, S, parts, lnp, lnl);
         if (lane == 0) {
@@ -148,7 +159,7 @@ static bool launch_tree_mailbox_nl(int nb, const FastArgs& A, const DevTree* T, 
                                    unsigned long long life, hipStream_t s)
 {
     using namespace fastk;
-    auto sh = [&](int n) { return (size_t)(((A.axes_len + 1) & ~1) + 64 * slot_stride(n)) * sizeof(double); };
+    auto sh = [&](int n) { return (size_t)(((A.axes_len + 1) & ~1) + 64 * slot_stride(n) + 32) * sizeof(double); };
     switch (nb) {
 #define ISO_TREE_MB_CASE(N) \
     case N: note_kernel("k_mailbox_tree<%d, %d>", N, NL); hipLaunchKernelGGL((k_mailbox_tree<N, NL>), dim3(1), dim3(64), sh(N), s, A, T, d_box, idle, life); return true;

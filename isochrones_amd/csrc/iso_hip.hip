@@ -1278,20 +1278,14 @@ namespace {
 template <int KIND, int NS>
 void launch_lnpost_nb(int nb, dim3 g, dim3 b, size_t shmem, hipStream_t s, const PostArgs& A)
 {
-    // ISOCHRONES_AMD_GENERIC_RUNTIME_NB=1: the run-time band loop for every band count (A/B of the compile-time band counts)
-    static const bool runtime_nb = [] { const char* e = std::getenv("ISOCHRONES_AMD_GENERIC_RUNTIME_NB"); return e && e[0] == '1'; }();
-    if (runtime_nb) nb = 0;
-    switch (nb) {
-    case 1: note_kernel("k_lnpost<%d, %d, 1>", KIND, NS); hipLaunchKernelGGL((k_lnpost<KIND, NS, 1>), g, b, shmem, s, A); break;
-    case 2: note_kernel("k_lnpost<%d, %d, 2>", KIND, NS); hipLaunchKernelGGL((k_lnpost<KIND, NS, 2>), g, b, shmem, s, A); break;
-    case 3: note_kernel("k_lnpost<%d, %d, 3>", KIND, NS); hipLaunchKernelGGL((k_lnpost<KIND, NS, 3>), g, b, shmem, s, A); break;
-    case 4: note_kernel("k_lnpost<%d, %d, 4>", KIND, NS); hipLaunchKernelGGL((k_lnpost<KIND, NS, 4>), g, b, shmem, s, A); break;
-    case 5: note_kernel("k_lnpost<%d, %d, 5>", KIND, NS); hipLaunchKernelGGL((k_lnpost<KIND, NS, 5>), g, b, shmem, s, A); break;
-    case 6: note_kernel("k_lnpost<%d, %d, 6>", KIND, NS); hipLaunchKernelGGL((k_lnpost<KIND, NS, 6>), g, b, shmem, s, A); break;
-    case 7: note_kernel("k_lnpost<%d, %d, 7>", KIND, NS); hipLaunchKernelGGL((k_lnpost<KIND, NS, 7>), g, b, shmem, s, A); break;
-    case 8: note_kernel("k_lnpost<%d, %d, 8>", KIND, NS); hipLaunchKernelGGL((k_lnpost<KIND, NS, 8>), g, b, shmem, s, A); break;
-    default: note_kernel("k_lnpost<%d, %d, 0>", KIND, NS); hipLaunchKernelGGL((k_lnpost<KIND, NS, 0>), g, b, shmem, s, A); break;
-    }
+    // The generic kernel is the FALL-BACK for what the fused families do not take (a model table whose third axis is not
+    // uniform, tables too large for 32-bit cell numbers, ISOCHRONES_AMD_PATH=generic / compact) and the reference-order
+    // arithmetic the fused kernels are debugged against - not a throughput path (151 us per 10^6 rows where the fused
+    // kernel takes 73).  Round 6: one form per (parametrisation, stars), the band loop at run time; the eight compile-time
+    // band counts per shape (32 instantiations, 8-10 % on a path nobody times) are gone.
+    (void)nb;
+    note_kernel("k_lnpost<%d, %d, 0>", KIND, NS);
+    hipLaunchKernelGGL((k_lnpost<KIND, NS, 0>), g, b, shmem, s, A);
 }
 
 void launch_lnpost(const iso_model* m, dim3 g, dim3 b, size_t shmem, hipStream_t s, const PostArgs& A)
@@ -1375,7 +1369,6 @@ static int lnpost_host_pipelined(iso_model* m, const double* pars, int64_t n, do
 {
     const int np_ = m->desc.n_stars + 4;
     int64_t CH = int64_t(1) << 17;
-    if (const char* ce = getenv("ISO_PIPE_CHUNK")) CH = std::max<int64_t>(1024, atoll(ce));      // tuning hook
     if (m->pipe_rows < n) {
         if (m->d_pipe) (void)hipFree(m->d_pipe);
         if (m->h_pipe) (void)hipHostFree(m->h_pipe);
@@ -2911,8 +2904,7 @@ int iso_sampler_run(iso_sampler* sp, double* pos, double* lnp, int nsteps, doubl
     S.group = 0;
     S.threads = 0;
     S.dense_stdp = 0;
-    S.triple_moves = 64;  // ISOCHRONES_AMD_TRIPLE_MOVES: up to how many moves per half-step a single triple runs one star per row
-    if (const char* e = std::getenv("ISOCHRONES_AMD_TRIPLE_MOVES")) S.triple_moves = std::atoi(e);
+    S.triple_moves = 64;  // up to how many moves per half-step a single triple runs one star per row (profiles/r06/triple_sweep.jsonl)
     S.pair = 1;           // ISOCHRONES_AMD_STAR_LANES=0: a single binary's fit through the one-lane-walks-both-stars kernel (A/B, tests)
     if (const char* e = std::getenv("ISOCHRONES_AMD_STAR_LANES")) S.pair = std::atoi(e) != 0;
     S.pos = pos;

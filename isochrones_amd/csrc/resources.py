@@ -75,7 +75,8 @@ SCRATCH_BUDGET = {
     "k_lnpost_tree": 16,             # generic tree kernel: per-leaf values in LDS since round 5 (1 664 B of per-lane arrays before)
     "k_chain_quantiles_exact": 40,
     "k_stretch_isotrack": 24,        # 10-12 bands
-    "k_mailbox_tree": 16,            # one resident wave per tree model (four stars x eight bands: 12 B at 256 registers)
+    "k_mailbox_tree": 96,            # one resident wave per tree model, latency of ONE evaluation per request (four stars x seven / eight
+                                     # bands: 44 / 92 B at 256 registers; every other shape none)
     "k_stretch_tree": 24,            # register-leaf forms: 20 B (five dwords of the evaluator's record, written once)
 }
 DEFAULT_SCRATCH = 0

@@ -464,7 +464,7 @@ def test_band_tiled_family(kind, ns):
 @pytest.mark.parametrize("nb", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
 @pytest.mark.parametrize("kind,ns", SHAPES)
 def test_generic_family(kind, ns, nb):
-    """k_lnpost<KIND, NS, NB>: NB 1-8 compile-time, 0 = run-time loop (no band or more than 8)."""
+    """k_lnpost<KIND, NS, 0>: the generic fall-back, band loop at run time (one form per shape since round 6)."""
     tid = "generic-%s%d-%d" % (kind, ns, nb)
     rng = np.random.default_rng(9000 + 100 * KIND_ID[kind] + 10 * ns + nb)
     bands = ia.grids.KNOWN_BANDS[:nb]
@@ -477,8 +477,7 @@ def test_generic_family(kind, ns, nb):
         x = batch_rows(rng, kind, ns, lo, hi)
         with traced(tid) as t:
             check_batch(mod, oic, x, tid)
-    code = nb if 1 <= nb <= 8 else 0
-    expect(t.names, "k_lnpost<%d, %d, %d>" % (K, ns, code), tid)
+    expect(t.names, "k_lnpost<%d, %d, 0>" % (K, ns), tid)
     ic.release()
     RAN.add(tid)
 
@@ -525,17 +524,19 @@ def check_tree(mod, oic, rng, what):
     fx.assert_close(mod.lnprior(x), w_prior, RTOL, atol=ATOL, what=what + " lnprior")
     fx.assert_close(mod.lnlike(x), w_like, RTOL, atol=ATOL, what=what + " lnlike")
     # the per-point callback: one row at a time through the model's resident mailbox wave (k_mailbox_tree,
-    # fast/tree_mailbox.h) - the batch's numbers bit for bit, special values included
-    if True:      # (a tree off the corner-packed path has no resident wave: the same calls then compare two launch paths)
-        rows = list(range(24)) + list(range(n - 6 * c.size, n - 6 * c.size + 12))
-        batch = [np.asarray(f(x[rows])) for f in (mod.lnpost, mod.lnprior, mod.lnlike)]
-        with env(ISOCHRONES_AMD_MAILBOX=None):
-            one = [np.array([f(list(x[r])) for r in rows]) for f in (mod.lnpost, mod.lnprior, mod.lnlike)]
-        with env(ISOCHRONES_AMD_MAILBOX="0"):
-            launch = [np.array([f(list(x[r])) for r in rows[:8]]) for f in (mod.lnpost, mod.lnprior, mod.lnlike)]
-        for a_, b_, c_ in zip(one, batch, launch):
-            assert np.array_equal(a_, b_, equal_nan=True), what + " mailbox wave vs batch"
-            assert np.array_equal(a_[:8], c_, equal_nan=True), what + " mailbox wave vs launch"
+    # fast/tree_mailbox.h) - bit for bit what a one-row launch of the batch kernel gives, special values included.  (Against the
+    # same row INSIDE a batch only to rounding: a node above one model star skips the reference's -2.5 log10(10^(-0.4 m)) = m
+    # round trip unless some sample of its wavefront is beyond |m| = 700 mag - then the whole wave takes the logarithm, and
+    # its other samples differ from the short cut by an ulp.  The special rows of x sit in the last waves of the batch.)
+    rows = list(range(24)) + list(range(n - 6 * c.size, n - 6 * c.size + 12))
+    batch = [np.asarray(f(x[rows])) for f in (mod.lnpost, mod.lnprior, mod.lnlike)]
+    with env(ISOCHRONES_AMD_MAILBOX=None):
+        one = [np.array([f(list(x[r])) for r in rows]) for f in (mod.lnpost, mod.lnprior, mod.lnlike)]
+    with env(ISOCHRONES_AMD_MAILBOX="0"):
+        launch = [np.array([f(list(x[r])) for r in rows]) for f in (mod.lnpost, mod.lnprior, mod.lnlike)]
+    for a_, b_, c_ in zip(one, batch, launch):
+        assert np.array_equal(a_, c_, equal_nan=True), what + " mailbox wave vs one-row launch"
+        fx.assert_close(a_, b_, 1e-13, atol=1e-13, what=what + " mailbox wave vs batch")
 
 
 def check_tree_sampler(mod, oic, rng, what, W=16, steps=10, seed=5):

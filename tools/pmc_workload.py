@@ -6,7 +6,8 @@ several workloads run the same kernel (tools/pmc_summarize.py walks the dispatch
     python tools/pmc_workload.py --manifest out.json [--launches 6] [--cases cfg2,cfg3,...]
 
 cases: cfg2 (single star, 1 band: prior / prior_valid / posterior samples), cfg3 (binary, 6 bands + parallax: the same
-three), generic (cfg2 model on the generic kernel), astero, tree (resolved binary, fast tree kernel),
+three), generic (cfg2 model on the generic kernel), astero, tree (resolved binary, fast tree kernel), tree_generic (the same
+tree on the generic tree kernel),
 quantiles (chain summaries of a 10^4-star catalog, 32 walkers x 100 steps), sampler (the catalog sampler on 2 x 10^5 stars: step-wise and
 persistent kernels).
 """
@@ -118,6 +119,25 @@ def main():
         os.environ.pop("ISOCHRONES_AMD_TREE_RUNTIME_LEAVES")
         manifest.append(dict(label="tree_runtime_leaves/posterior", kernel="k_lnpost_tree_fast<3, 0>", launches=L + 1, skip=2, n=n,
                              algorithmic_bytes_per_launch=float(2 * 384 + 2 * 3 * 128 + 56) * n))
+        del mod
+    if "tree_generic" in cases:
+        # the generic tree kernel (any tree, tables off the corner-packed path; per-leaf values in LDS since round 5)
+        os.environ["ISOCHRONES_AMD_PATH"] = "generic"
+        mod, pars = bench_configs.tree_model_and_samples(n)
+        pt = torch.as_tensor(pars, device="cuda")
+        mod.lnpost(pt[:4096])
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(L):
+            mod.lnpost(pt)
+        e1.record()
+        torch.cuda.synchronize()
+        os.environ.pop("ISOCHRONES_AMD_PATH")
+        manifest.append(dict(label="tree_generic/posterior", kernel="k_lnpost_tree", launches=L + 1, skip=2, n=n,
+                             ms_per_launch_profiled=e0.elapsed_time(e1) / L,
+                             algorithmic_bytes_per_launch=float(2 * 384 + 2 * 3 * 128 + 56) * n))
+        mod.ic.release()
         del mod
     if "quantiles" in cases:
         from isochrones_amd.catalog import CatalogPosterior, initial_positions

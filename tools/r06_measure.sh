@@ -66,6 +66,31 @@ groups)
 bcast)
   python tools/broadcast_ab.py 3 2>/dev/null | grep "^{" | tee $OUT/broadcast_ab.jsonl
   timeout 900 python -m pytest tests/test_gpu_rccl.py -q -x 2>&1 | tail -5 | tee $OUT/pytest_rccl.txt ;;
+pmc)
+  bash tools/pmc_collect.sh gpurun_out/r06/pmc ${PMC_CASES:-cfg2,cfg3,generic,tree,tree_generic} 2>&1 | tail -12
+  python - <<PY
+import json
+d = json.load(open("$OUT/pmc/pmc_summary.json"))
+for k, v in (d.items() if isinstance(d, dict) else enumerate(d)):
+    print(k, json.dumps(v)[:400])
+PY
+  ;;
+msl)
+  for rep in 1 2; do
+  for name in default msl14; do
+    if [ "$name" = default ]; then unset ISOCHRONES_AMD_LIB; else export ISOCHRONES_AMD_LIB=$ROOT/variants/libs/libiso_hip_$name.so; fi
+    python tools/catalog_sizes.py --sizes 313,1250,10000 2>/dev/null | grep "^{" | sed "s/^{/{\"lib\": \"$name\", /" | tee -a $OUT/catalog_msl.jsonl | cut -c1-300
+    python tools/ab_kernels.py --cases cfg5,cfg5ref --label $name 2>/dev/null | grep '^{' | tee -a $OUT/ab_msl.jsonl | python -c "
+import sys, json
+for l in sys.stdin:
+    d = json.loads(l)
+    print(d['label'], {k: (round(v['wall_s_min'] * 1e3, 2), v['rows_digest']) for k, v in d.items() if isinstance(v, dict) and 'wall_s_min' in v})
+"
+  done
+  done
+  unset ISOCHRONES_AMD_LIB ;;
+dispatch)
+  timeout 2400 python -m pytest tests/test_gpu_dispatch_table.py -q 2>&1 | tail -12 | tee $OUT/pytest_dispatch.txt ;;
 replay)
   timeout 1500 python -m pytest tests/test_gpu_sampler_oracle.py -q -x -k "reference_shape" 2>&1 | tail -15 | tee $OUT/pytest_replay.txt ;;
 tree)
