@@ -356,3 +356,179 @@ __device__ __forceinline__ void coop_bc_tile(const FastArgs& A, const CoopLds& L
     for (int b = 0; b < TB; ++b) v[b] = need ? rs[b] : f_nan();
     __builtin_amdgcn_wave_barrier();
 }
+
+// ---- several requests per lane (round 6): the leaves of an observation tree side by side -------------------------------------
+// The tree evaluator gathers its model stars one after the other: bracket, model cell, BC bracket, BC cell, then the next star -
+// two dependent memory round trips per star.  For the mailbox wave of the per-point callback (ONE sample, nothing else on
+// the CU to hide them) a
+// lane publishes NREQ requests (slot q * 64 + lane of a wave's NREQ * 64 slots), and the rounds of all of them are served in
+// FLIGHTS that mix the requests - the loads of round k of request 0 and of request 1 are in flight together - so that two stars
+// cost one round trip per table.  The arithmetic of a round is coop_star's / coop_bc's (three lanes per sample for the model
+// cell - same bits as the quad form): every value is the one the single-request functions give, bit for bit.
+template <int NREQ>
+__device__ __forceinline__ CoopLds coop_lds_multi(double* lds, int axes_len, int stride)
+{
+    const int base = (axes_len + 1) & ~1;
+    const int wave = threadIdx.x >> 6;
+    CoopLds L;
+    L.req = lds + base + wave * 64 * NREQ * stride;
+    L.rsp = L.req;
+    L.stride = stride;
+    L.lane = threadIdx.x & 63;
+    return L;
+}
+
+template <int NREQ>
+__device__ __forceinline__ void coop_star_multi(const FastArgs& A, const CoopLds& L, const bool* need, const uint32_t* cell, const W3* w,
+                                                double (*v)[6])
+{
+#pragma unroll
+    for (int q = 0; q < NREQ; ++q) {
+        double* mine = L.req + (q * 64 + L.lane) * L.stride;
+        mine[0] = __hiloint2double(need[q] ? 1 : 0, (int)cell[q]);
+        mine[1] = w[q].t0;
+        mine[2] = w[q].t1;
+        mine[3] = w[q].t2;
+    }
+    __builtin_amdgcn_wave_barrier();
+    unsigned long long m[NREQ];
+#pragma unroll
+    for (int q = 0; q < NREQ; ++q) m[q] = __ballot(need[q]);
+    const int j = L.lane & 3, grp = L.lane >> 2;
+    const int qcol = j < 2 ? j : 2;
+    // virtual round vr = k * NREQ + q (round k of request q); a flight = FL consecutive virtual rounds
+    constexpr int FL = 4, NVR = 4 * NREQ;
+#pragma unroll
+    for (int f = 0; f < NVR / FL; ++f) {
+        bool any = false;
+#pragma unroll
+        for (int i = 0; i < FL; ++i) {
+            const int vr = f * FL + i, k = vr / NREQ, q = vr % NREQ;
+            any |= ((m[q] >> (16 * k)) & 0xFFFFull) != 0;
+        }
+        if (!any) continue;                                   // wave-uniform
+        double2 u[FL][8];
+        double tt[FL][3];
+#pragma unroll
+        for (int i = 0; i < FL; ++i) {
+            const int vr = f * FL + i, k = vr / NREQ, q = vr % NREQ;
+            if (((m[q] >> (16 * k)) & 0xFFFFull) == 0) continue;       // wave-uniform: nobody owns these 16 slots
+            const int src = q * 64 + 16 * k + grp;
+            const double* rq = L.req + src * L.stride;
+            const double hdr = rq[0];
+            const double t0 = rq[1], t1 = rq[2], t2 = rq[3];
+            const bool nd = __double2hiint(hdr) != 0;
+            const uint32_t c = nd ? (uint32_t)__double2loint(hdr) : 0u;      // cell 0 is always readable
+            const double2* __restrict__ pc = reinterpret_cast<const double2*>(A.hotq + (size_t)c * PACK_ENTRY) + 4 * qcol;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) u[i][e] = pc[12 * (e >> 2) + (e & 3)];
+            tt[i][0] = t0;
+            tt[i][1] = t1;
+            tt[i][2] = t2;
+        }
+#pragma unroll
+        for (int i = 0; i < FL; ++i) {
+            const int vr = f * FL + i, k = vr / NREQ, q = vr % NREQ;
+            if (((m[q] >> (16 * k)) & 0xFFFFull) == 0) continue;
+            const int src = q * 64 + 16 * k + grp;
+            const double t0 = tt[i][0], t1 = tt[i][1], t2 = tt[i][2];
+            const double a0 = 1 - t0, a1 = 1 - t1, a2 = 1 - t2;
+            double px[4], py[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const double g = ((jj & 2) ? t1 : a1) * ((jj & 1) ? t2 : a2);
+                const double wl = a0 * g, wh = t0 * g;
+                px[jj] = corner_pair(u[i][jj].x, wl, u[i][4 + jj].x, wh);
+                py[jj] = corner_pair(u[i][jj].y, wl, u[i][4 + jj].y, wh);
+            }
+            double* rs = L.rsp + src * L.stride + 2 * qcol;
+            if (j < 3) {
+                rs[0] = lane_quad_total(px);
+                rs[1] = lane_quad_total(py);
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int q = 0; q < NREQ; ++q) {
+        const double* rs = L.rsp + (q * 64 + L.lane) * L.stride;
+#pragma unroll
+        for (int e = 0; e < 6; ++e) v[q][e] = need[q] ? rs[e] : f_nan();
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int NB, int NREQ>
+__device__ __forceinline__ void coop_bc_multi(const FastArgs& A, const CoopLds& L, const bool* need, const uint32_t* cell, const W4* w,
+                                              double (*v)[NB])
+{
+#pragma unroll
+    for (int q = 0; q < NREQ; ++q) {
+        double* mine = L.req + (q * 64 + L.lane) * L.stride;
+        mine[0] = __hiloint2double(need[q] ? 1 : 0, (int)cell[q]);
+        mine[1] = w[q].t0;
+        mine[2] = w[q].t1;
+        mine[3] = w[q].t2;
+        mine[4] = w[q].t3;
+    }
+    __builtin_amdgcn_wave_barrier();
+    unsigned long long m[NREQ];
+#pragma unroll
+    for (int q = 0; q < NREQ; ++q) m[q] = __ballot(need[q]);
+    const int j = L.lane & 3, grp = L.lane >> 2;
+    // flights of <= 32 loads of 16 B per lane (2 NB per round), at least one round of every request
+    constexpr int NVR = 4 * NREQ;
+    constexpr int FL = (NB <= 4) ? 4 : NREQ;
+    static_assert(NVR % FL == 0, "flights tile the virtual rounds");
+#pragma unroll
+    for (int f = 0; f < NVR / FL; ++f) {
+        bool any = false;
+#pragma unroll
+        for (int i = 0; i < FL; ++i) {
+            const int vr = f * FL + i, k = vr / NREQ, q = vr % NREQ;
+            any |= ((m[q] >> (16 * k)) & 0xFFFFull) != 0;
+        }
+        if (!any) continue;                                   // wave-uniform
+        double2 x[FL][2 * NB];
+        double wa[FL][2], wb[FL][2];
+#pragma unroll
+        for (int i = 0; i < FL; ++i) {
+            const int vr = f * FL + i, k = vr / NREQ, q = vr % NREQ;
+            if (((m[q] >> (16 * k)) & 0xFFFFull) == 0) continue;
+            const int src = q * 64 + 16 * k + grp;
+            const double* rq = L.req + src * L.stride;
+            const double hdr = rq[0];
+            const double t0 = rq[1], t1 = rq[2], t2 = rq[3], t3 = rq[4];
+            const bool nd = __double2hiint(hdr) != 0;
+            const uint32_t c = nd ? (uint32_t)__double2loint(hdr) : 0u;
+            const double2* __restrict__ pc = reinterpret_cast<const double2*>(A.bcq + (size_t)c * (16 * NB)) + j;
+#pragma unroll
+            for (int e = 0; e < 2 * NB; ++e) x[i][e] = pc[4 * e];
+            const double g = nd ? ((j & 2) ? t1 : (1 - t1)) * ((j & 1) ? t2 : (1 - t2)) : 0.0;
+            wa[i][0] = (1 - t0) * g * (1 - t3);
+            wb[i][0] = (1 - t0) * g * t3;
+            wa[i][1] = t0 * g * (1 - t3);
+            wb[i][1] = t0 * g * t3;
+        }
+#pragma unroll
+        for (int i = 0; i < FL; ++i) {
+            const int vr = f * FL + i, k = vr / NREQ, q = vr % NREQ;
+            if (((m[q] >> (16 * k)) & 0xFFFFull) == 0) continue;
+            const int src = q * 64 + 16 * k + grp;
+            double* rs = L.rsp + src * L.stride;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const double part = quad_sum(corner_quad(x[i][b], wa[i][0], wb[i][0], x[i][NB + b], wa[i][1], wb[i][1]));
+                if (j == (b & 3)) rs[b] = part;
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int q = 0; q < NREQ; ++q) {
+        const double* rs = L.rsp + (q * 64 + L.lane) * L.stride;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) v[q][b] = need[q] ? rs[b] : f_nan();
+    }
+    __builtin_amdgcn_wave_barrier();
+}

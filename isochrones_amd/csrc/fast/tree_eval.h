@@ -101,6 +101,11 @@ struct TreeLeaves {
     }
 };
 
+// request slots per lane a LONE workgroup's evaluation needs: register form with two or three stars (or four with up to three
+// bands) - two stars at a time; four stars with more bands keep one at a time (the second flight's registers would spill
+// 50-120 B per lane at the 256 the kernel has)
+__host__ __device__ constexpr int tree_requests(int nl, int nb) { return (nl == 2 || nl == 3 || (nl == 4 && nb <= 3)) ? 2 : 1; }
+
 #ifndef ISO_TREE_BANDMAJOR
 #define ISO_TREE_BANDMAJOR 1
 #endif
@@ -146,7 +151,11 @@ __device__ __forceinline__ void bterm_sum(const DevTree& T, const TreeLeaves<NB,
 // (L1 / L2 hits), the proposal rebuilt from two LDS rows in the sampler.  `want_like`: evaluate the likelihood even
 // where the prior is not finite (the batch entry point's lnlike output).  An inactive lane's results mean nothing.
 // LONE: the caller is a lone workgroup (the sampler): model gather by three lanes per sample (coop_star's THREE).
-template <int NB, int NL, bool LONE = false, class Par>
+// PAIRS: the stars two at a time through the multi-request gathers (the caller laid the gather slots out for tree_requests
+// per lane).  The mailbox wave's form - ONE sample, nothing else in flight: 22.2 -> 19.9 us per lnpost(p) call.  The device
+// sampler keeps one star at a time: with 32-48 moves per wave and four waves per workgroup the round trips of the waves
+// already overlap, and the larger flights cost registers - resolved binary 25.2 -> 26.7 us per step (profiles/r06/tree_ab.txt).
+template <int NB, int NL, bool LONE = false, bool PAIRS = false, class Par>
 __device__ __forceinline__ double tree_lnpost(const FastArgs& A, const DevTree& T, const double* lds, const CoopLds& L,
                                               bool active, Par par, TreeLeaves<NB, NL>& S, bool want_like,
                                               double& lnp_out, double& lnl_out)
@@ -188,6 +197,65 @@ __device__ __forceinline__ double tree_lnpost(const FastArgs& A, const DevTree& 
 #pragma unroll
         for (int b = 0; b < NB; ++b) S.set_flux(l, b, v[3] + dm - bc[b]);
     };
+    if constexpr (PAIRS && tree_requests(NL, NB) == 2) {
+        // A lone WAVE (the mailbox wave of the per-point callback): the stars two at a time through the multi-request gathers
+        // (coop_gather.h) - brackets of both, ONE flight for both model cells, BC brackets of both, ONE flight for both BC cells -
+        // instead of four dependent memory round trips one behind the other.  Same brackets, same per-round arithmetic: the
+        // values are those of the one-star-at-a-time form, bit for bit.
+        constexpr int NPAIR = NL / 2;
+#pragma unroll
+        for (int pr = 0; pr < NPAIR; ++pr) {
+            bool ok3[2], ok4[2];
+            uint32_t c3[2], c4[2];
+            W3 w3[2];
+            W4 w4[2];
+            double dist2[2];
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const int l = 2 * pr + h2;
+                const int s = T.leaf_system[l];
+                const int base = T.sys_base[s], N = T.n_stars[s];
+                const double eep = par(base + T.leaf_slot[l]), age = par(base + N), feh = par(base + N + 1);
+                dist2[h2] = par(base + N + 2);
+                ok3[h2] = bool(active & !(age != age) & !(feh != feh) & !(eep != eep) & !lds_oob(lds, A.m0, age) &
+                               !lds_oob(lds, A.m1, feh) & !eep_oob(A, eep));
+                int i0 = 0, i1 = 0, i2 = 0;
+                w3[h2].t0 = w3[h2].t1 = w3[h2].t2 = 0.0;
+                if (ok3[h2]) {
+                    lds_bracket2(lds, A.m0, A.m1, age, feh, i0, i1, w3[h2].t0, w3[h2].t1);
+                    eep_bracket(A, lds, eep, i2, w3[h2].t2);
+                }
+                c3[h2] = cell3(A, i0, i1, i2);
+            }
+            double v2[2][6];
+            coop_star_multi<2>(A, L, ok3, c3, w3, v2);
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const int l = 2 * pr + h2;
+                const int s = T.leaf_system[l];
+                const double AV = par(T.sys_base[s] + T.n_stars[s] + 3);
+#pragma unroll
+                for (int q = 0; q < 6; ++q) S.set_star(l, q, v2[h2][q]);
+                const double Tf = v2[h2][0], g = v2[h2][1], f = v2[h2][2];
+                ok4[h2] = bool(ok3[h2] & !(AV != AV) & !(Tf != Tf) & !(g != g) & !(f != f) & !lds_oob(lds, A.b0, Tf) &
+                               !lds_oob(lds, A.b1, g) & !lds_oob(lds, A.b2, f) & !lds_oob(lds, A.b3, AV));
+                int j0 = 0, j1 = 0, j2 = 0, j3 = 0;
+                w4[h2].t0 = w4[h2].t1 = w4[h2].t2 = w4[h2].t3 = 0.0;
+                if (ok4[h2]) lds_bracket4(lds, A.b0, A.b1, A.b2, A.b3, Tf, g, f, AV, j0, j1, j2, j3, w4[h2].t0, w4[h2].t1, w4[h2].t2, w4[h2].t3);
+                c4[h2] = cell4(A, j0, j1, j2, j3);
+            }
+            double bc2[2][NB];
+            coop_bc_multi<NB, 2>(A, L, ok4, c4, w4, bc2);
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const int l = 2 * pr + h2;
+                const double dm = fma(fast_log(dist2[h2]), 5.0 * kInvLn10, -5.0);
+#pragma unroll
+                for (int b = 0; b < NB; ++b) S.set_flux(l, b, v2[h2][3] + dm - bc2[h2][b]);
+            }
+        }
+        if constexpr (NL & 1) leaf(NL - 1);
+    } else
     if constexpr (NL > 0) {
 #pragma unroll
         for (int l = 0; l < NL; ++l) leaf(l);

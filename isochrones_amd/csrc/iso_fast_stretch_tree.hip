@@ -36,11 +36,12 @@ __global__ __launch_bounds__(BLOCK, 2) void k_stretch_tree(const AnyStretchArgs 
 {
     extern __shared__ double lds[];
     for (int j = threadIdx.x; j < A.axes_len; j += BLOCK) lds[j] = A.axes_blob[j];
+    constexpr int NREQ = 1;
     const CoopLds L = coop_lds<NB>(lds, A.axes_len);
     TreeLeaves<NB, NL> leaves;
     // runtime-leaf form: this lane's column of the [slot][lane] block; lanes beyond S.lanes never take a move (their waves
     // skip the evaluation), so the block is S.lanes wide
-    leaves.lds_ = lds + ((A.axes_len + 1) & ~1) + BLOCK * slot_stride(NB) + (threadIdx.x < (unsigned)S.lanes ? threadIdx.x : 0);
+    leaves.lds_ = lds + ((A.axes_len + 1) & ~1) + NREQ * BLOCK * slot_stride(NB) + (threadIdx.x < (unsigned)S.lanes ? threadIdx.x : 0);
     leaves.stride_ = S.lanes;
     TreeEval<NB, NL> ev{lds, L, leaves};
     persist_any(ev, S, lds);       // (its first barrier also covers the staged axes)

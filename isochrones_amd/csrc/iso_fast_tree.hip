@@ -59,12 +59,15 @@ __global__ __launch_bounds__(64, 2) void k_mailbox_tree(const FastArgs A, const 
     extern __shared__ double lds[];
     for (int j = threadIdx.x; j < A.axes_len; j += 64) lds[j] = A.axes_blob[j];
     __syncthreads();
-    const CoopLds L = coop_lds<NB>(lds, A.axes_len);
+    // (a lone wave: the sampler's form of the evaluation - three-lane model gather, stars two at a time; the same bits as the
+    // batch kernel's form)
+    constexpr int NREQ = tree_requests(NL, NB);
+    const CoopLds L = coop_lds_multi<NREQ>(lds, A.axes_len, slot_stride(NB));
     const DevTree& T = *Tp;
     TreeLeaves<NB, NL> S;
     S.lds_ = nullptr;
     S.stride_ = 64;
-    double* lpar = lds + ((A.axes_len + 1) & ~1) + 64 * slot_stride(NB);      // the request's 32 words behind the gather slots
+    double* lpar = lds + ((A.axes_len + 1) & ~1) + NREQ * 64 * slot_stride(NB);      // the request's 32 words behind the gather slots
     const int lane = (int)threadIdx.x;
     auto sys_load = [](const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
     auto sys_store = [](unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(64, 2) void k_mailbox_tree(const FastArgs A, const 
         const double* __restrict__ src = lpar + 1;
         auto par = [&](int j) { return src[j]; };
         double lnp, lnl;
-        const double post = tree_lnpost<NB, NL>(A, T, lds, L, lane == 0, par, S, parts, lnp, lnl);
+        const double post = tree_lnpost<NB, NL, true, true>(A, T, lds, L, lane == 0, par, S, parts, lnp, lnl);
         if (lane == 0) {
             sys_store(&mb->done[1], (unsigned long long)__double_as_longlong(post));
             sys_store(&mb->done[2], (unsigned long long)__double_as_longlong(lnp));
@@ -159,7 +162,7 @@ static bool launch_tree_mailbox_nl(int nb, const FastArgs& A, const DevTree* T, 
                                    unsigned long long life, hipStream_t s)
 {
     using namespace fastk;
-    auto sh = [&](int n) { return (size_t)(((A.axes_len + 1) & ~1) + 64 * slot_stride(n) + 32) * sizeof(double); };
+    auto sh = [&](int n) { return (size_t)(((A.axes_len + 1) & ~1) + tree_requests(NL, n) * 64 * slot_stride(n) + 32) * sizeof(double); };
     switch (nb) {
 #define ISO_TREE_MB_CASE(N) \
     case N: note_kernel("k_mailbox_tree<%d, %d>", N, NL); hipLaunchKernelGGL((k_mailbox_tree<N, NL>), dim3(1), dim3(64), sh(N), s, A, T, d_box, idle, life); return true;
