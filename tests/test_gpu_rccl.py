@@ -71,6 +71,25 @@ with warnings.catch_warnings(record=True) as w:
     warnings.simplefilter("always")
     bad = ia.fit_catalog(cat, ic, strict=False, fit_fn=lambda *a, **k: (_ for _ in ()).throw(RuntimeError("boom")))
 assert bad["ok"].eq(0).all() and "boom" in bad.attrs["shard_errors"][0]
+# 4. the resident waves of the per-point calls next to RCCL collectives in the same process: a scalar accessor and a model's
+# lnpost(p) start their waves (kernels/k_service.h, iso_fast_mailbox.hip), collectives run while they are resident, the
+# calls give the same numbers afterwards
+import time
+mod1 = cat.model(0, ic)
+p1 = [1.0, 355.0, 0.0, 300.0, 0.1]
+v0, l0 = ic.interp_value(p1[:3], ["Teff", "logg"]), mod1.lnpost(p1)
+worst = 0.0
+for _ in range(20):
+    assert np.array_equal(ic.interp_value(p1[:3], ["Teff", "logg"]), v0) and mod1.lnpost(p1) == l0
+    t0 = time.perf_counter()
+    x = torch.ones(1 << 16, device="cuda")
+    dist.all_reduce(x)
+    dist.barrier()
+    torch.cuda.synchronize()
+    worst = max(worst, time.perf_counter() - t0)
+    assert float(x[0]) == 1.0
+out["collective_next_to_resident_waves_worst_s"] = worst
+assert worst < 0.25
 # which librccl the process has mapped
 maps = open("/proc/self/maps").read()
 out["rccl_mapped"] = sorted({ln.split()[-1] for ln in maps.splitlines() if "rccl" in ln.lower()})

@@ -91,6 +91,12 @@ for l in sys.stdin:
   unset ISOCHRONES_AMD_LIB ;;
 dispatch)
   timeout 2400 python -m pytest tests/test_gpu_dispatch_table.py -q 2>&1 | tail -12 | tee $OUT/pytest_dispatch.txt ;;
+soak)
+  # randomised GPU-vs-oracle runs on the round's final library (tests/soak): seeds of this round
+  python tests/soak/soak_sampler.py ${SOAK_S:-400} 61 2>/dev/null | tail -1 | tee $OUT/soak.txt
+  python tests/soak/soak.py 200 62 2>/dev/null | tail -1 | tee -a $OUT/soak.txt
+  python tests/soak/soak_tree.py 150 63 2>/dev/null | tail -1 | tee -a $OUT/soak.txt
+  python tests/soak/soak_primitives.py 100 64 2>/dev/null | tail -1 | tee -a $OUT/soak.txt ;;
 replay)
   timeout 1500 python -m pytest tests/test_gpu_sampler_oracle.py -q -x -k "reference_shape" 2>&1 | tail -15 | tee $OUT/pytest_replay.txt ;;
 tree)
