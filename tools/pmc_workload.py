@@ -75,7 +75,7 @@ def main():
             ic_g, mod_g = bench.build_model()
             mod_g.lnpost(samples["prior"][0][:4096])
             for wl in ("prior_valid", "posterior"):
-                lnpost_launches("generic/" + wl, "k_lnpost<0, 1, 1", mod_g, samples[wl], 560)
+                lnpost_launches("generic/" + wl, "k_lnpost<0, 1, 0", mod_g, samples[wl], 560)
             os.environ.pop("ISOCHRONES_AMD_PATH")
             del mod_g, ic_g
         del mod, ic, samples
@@ -134,7 +134,7 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         os.environ.pop("ISOCHRONES_AMD_PATH")
-        manifest.append(dict(label="tree_generic/posterior", kernel="k_lnpost_tree", launches=L + 1, skip=2, n=n,
+        manifest.append(dict(label="tree_generic/posterior", kernel="k_lnpost_tree(", launches=L + 1, skip=2, n=n,
                              ms_per_launch_profiled=e0.elapsed_time(e1) / L,
                              algorithmic_bytes_per_launch=float(2 * 384 + 2 * 3 * 128 + 56) * n))
         mod.ic.release()
