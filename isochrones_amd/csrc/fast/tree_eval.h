@@ -189,13 +189,30 @@ __device__ __forceinline__ double tree_lnpost(const FastArgs& A, const DevTree& 
         W4 w4v;
         w4v.t0 = w4v.t1 = w4v.t2 = w4v.t3 = 0.0;
         if (ok4) lds_bracket4(lds, A.b0, A.b1, A.b2, A.b3, Tf, g, f, AV, j0, j1, j2, j3, w4v.t0, w4v.t1, w4v.t2, w4v.t3);
-        double bc[NB];
-        if (l == 0) { ISO_STAMP(4, w4v.t3); }
-        coop_bc<NB>(A, L, ok4, cell4(A, j0, j1, j2, j3), w4v, bc);
-        if (l == 0) { ISO_STAMP(5, bc[0]); }
         const double dm = fma(fast_log(dist), 5.0 * kInvLn10, -5.0);      // 5 log10(d / 10), as lnpost_wave takes it
+        if constexpr (NB > FAST_MAX_NB) {
+            // 13 ... ISO_TREE_MAX_BANDS bands (round 6; runtime-leaf form only): the BC cell of A.nb_total bands is taken in tiles
+            // of eight (coop_bc_tile, the band-tiled BasicStarModel kernels' gather); NB is the width the per-leaf values
+            // are laid out for, the band count a run-time number
+            static_assert(NL == 0, "band-tiled trees keep their per-leaf values in LDS");
+            constexpr int TILE = 8;
+            const int nbt = A.nb_total;
+            const uint32_t c4 = cell4(A, j0, j1, j2, j3);
+            for (int b0 = 0; b0 < nbt; b0 += TILE) {                  // wave-uniform
+                double bc[TILE];
+                coop_bc_tile<TILE>(A, L, ok4, c4, w4v, nbt, b0, bc);
 #pragma unroll
-        for (int b = 0; b < NB; ++b) S.set_flux(l, b, v[3] + dm - bc[b]);
+                for (int b = 0; b < TILE; ++b)
+                    if (b0 + b < nbt) S.set_flux(l, b0 + b, v[3] + dm - bc[b]);
+            }
+        } else {
+            double bc[NB];
+            if (l == 0) { ISO_STAMP(4, w4v.t3); }
+            coop_bc<NB>(A, L, ok4, cell4(A, j0, j1, j2, j3), w4v, bc);
+            if (l == 0) { ISO_STAMP(5, bc[0]); }
+#pragma unroll
+            for (int b = 0; b < NB; ++b) S.set_flux(l, b, v[3] + dm - bc[b]);
+        }
     };
     if constexpr (PAIRS && tree_requests(NL, NB) == 2) {
         // A lone WAVE (the mailbox wave of the per-point callback): the stars two at a time through the multi-request gathers

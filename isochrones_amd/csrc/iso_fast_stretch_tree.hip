@@ -59,17 +59,20 @@ template <int NL>
 static bool launch_stretch_tree_nl(int nb, int n_leaves, const FastArgs& A, const DevTree* T, AnyStretchArgs S, int* query, hipStream_t s)
 {
     constexpr bool RT = NL == 0;
+    // 13 ... 16 bands: the band-tiled runtime-leaf form, laid out for ISO_TREE_MAX_BANDS bands (fast/tree_eval.h)
+    const int nb_layout = nb > 12 ? ISO_TREE_MAX_BANDS : nb;
+    if (nb > 12 && (!RT || nb > ISO_TREE_MAX_BANDS)) return false;
     // the widest lane count whose LDS fits a CU
     size_t bytes = 0;
     int lanes = BLOCK;
     for (; lanes >= 64; lanes -= 64) {
-        bytes = (tree_eval_doubles(A.axes_len, nb, n_leaves, RT, lanes) + any_own_doubles(S.W, S.NP)) * sizeof(double);
+        bytes = (tree_eval_doubles(A.axes_len, nb_layout, n_leaves, RT, lanes) + any_own_doubles(S.W, S.NP)) * sizeof(double);
         if (bytes <= LDS_PER_CU) break;
         if (!RT) return false;                 // nothing shrinks with the lane count in the register form
     }
     if (lanes < 64) return false;
     S.lanes = lanes;
-    S.own_off = (int)tree_eval_doubles(A.axes_len, nb, n_leaves, RT, lanes);
+    S.own_off = (int)tree_eval_doubles(A.axes_len, nb_layout, n_leaves, RT, lanes);
     const void* fn = nullptr;
     switch (nb) {
 #define ISO_TREE_STRETCH_CASE(N) case N: fn = (const void*)k_stretch_tree<N, NL>; break;
@@ -82,6 +85,7 @@ static bool launch_stretch_tree_nl(int nb, int n_leaves, const FastArgs& A, cons
             ISO_TREE_STRETCH_CASE(9) ISO_TREE_STRETCH_CASE(10) ISO_TREE_STRETCH_CASE(11) ISO_TREE_STRETCH_CASE(12)
         default: break;
         }
+        if (nb > 12) fn = (const void*)k_stretch_tree<ISO_TREE_MAX_BANDS, NL>;
     }
 #undef ISO_TREE_STRETCH_CASE
     if (!fn) return false;
@@ -90,7 +94,7 @@ static bool launch_stretch_tree_nl(int nb, int n_leaves, const FastArgs& A, cons
         return true;
     }
     if (bytes > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return false;
-    note_kernel("k_stretch_tree<%d, %d>", nb, NL);
+    note_kernel("k_stretch_tree<%d, %d>", nb_layout, NL);
     void* args[] = {&S, const_cast<FastArgs*>(&A), &T};
     return hipLaunchKernel(fn, dim3((unsigned)S.n_ens), dim3(BLOCK), args, bytes, s) == hipSuccess;
 }

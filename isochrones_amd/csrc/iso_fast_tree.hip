@@ -138,10 +138,16 @@ static bool launch_tree_nl(int nb, int n_leaves, const FastArgs& A, const DevTre
     auto sh = [&](int n) {
         return (size_t)(((A.axes_len + 1) & ~1) + TB * slot_stride(n) + (NL > 0 ? 0 : n_leaves * (6 + n) * TB)) * sizeof(double);
     };
-    if (sh(nb) > 64 * 1024) return false;      // (7-8 stars x 10-12 bands: the generic tree kernel takes those)
+    // (beyond the 64 KB a launch gets without asking - seven or eight stars with 10-12 bands, five and more with 13-16 - the
+    // kernel is given what it needs of the CU's 160 KB; round 6)
+    auto lds_ok = [&](const void* fn, size_t bytes) {
+        return bytes <= 64 * 1024 ||
+               (bytes <= 160 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess);
+    };
     switch (nb) {
 #define ISO_TREE_CASE(N) \
-    case N: note_kernel("k_lnpost_tree_fast<%d, %d>", N, NL); hipLaunchKernelGGL((k_lnpost_tree_fast<N, NL>), g, b, sh(N), s, A, T); return true;
+    case N: if (!lds_ok((const void*)k_lnpost_tree_fast<N, NL>, sh(N))) return false; \
+        note_kernel("k_lnpost_tree_fast<%d, %d>", N, NL); hipLaunchKernelGGL((k_lnpost_tree_fast<N, NL>), g, b, sh(N), s, A, T); return true;
         ISO_TREE_CASE(1) ISO_TREE_CASE(2) ISO_TREE_CASE(3) ISO_TREE_CASE(4) ISO_TREE_CASE(5) ISO_TREE_CASE(6)
         ISO_TREE_CASE(7) ISO_TREE_CASE(8)
     default: break;
@@ -151,8 +157,16 @@ static bool launch_tree_nl(int nb, int n_leaves, const FastArgs& A, const DevTre
     } else {
         switch (nb) {
             ISO_TREE_CASE(9) ISO_TREE_CASE(10) ISO_TREE_CASE(11) ISO_TREE_CASE(12)
-        default: return false;
+        default: break;
         }
+        // 13 ... 16 bands (ISO_TREE_MAX_BANDS): the band-tiled form, per-leaf values laid out for 16 bands
+        if (nb > 12 && nb <= ISO_TREE_MAX_BANDS) {
+            if (!lds_ok((const void*)k_lnpost_tree_fast<ISO_TREE_MAX_BANDS, NL>, sh(ISO_TREE_MAX_BANDS))) return false;
+            note_kernel("k_lnpost_tree_fast<%d, %d>", ISO_TREE_MAX_BANDS, NL);
+            hipLaunchKernelGGL((k_lnpost_tree_fast<ISO_TREE_MAX_BANDS, NL>), g, b, sh(ISO_TREE_MAX_BANDS), s, A, T);
+            return true;
+        }
+        return false;
     }
 #undef ISO_TREE_CASE
 }

@@ -2456,7 +2456,7 @@ int iso_tree_model_create(iso_ic* ic, const iso_tree_desc* d, iso_tree_model** o
         m->g4.tab = m->d_bc_hot;
         m->g4.ncol = d->n_bands;
     }
-    if (e == hipSuccess && path_mode() == PATH_AUTO && ic->d_hotq && d->n_bands >= 1 && d->n_bands <= 12 &&
+    if (e == hipSuccess && path_mode() == PATH_AUTO && ic->d_hotq && d->n_bands >= 1 && d->n_bands <= ISO_TREE_MAX_BANDS &&
         third_axis_ok(ic)) {
         bool ok = false;
         e = build_fast(ic, d->n_bands, m->d_bc_hot, &m->d_axes_blob, &m->d_bcq, m->fast, &ok);
@@ -2821,7 +2821,7 @@ int iso_sampler_create_tree(iso_tree_model* m, int64_t n_ensembles, int nwalkers
     if (n_ensembles < 1 || n_ensembles > (int64_t(1) << 24))
         return fail(ISO_ERR_INVALID, "iso_sampler_create_tree: n_ensembles out of range");
     if (!m->fast_ok)
-        return fail(ISO_ERR_INVALID, "iso_sampler_create_tree: the tree model is not on the corner-packed fast path (1-12 bands, "
+        return fail(ISO_ERR_INVALID, "iso_sampler_create_tree: the tree model is not on the corner-packed fast path (1-16 bands, "
                                      "ISOCHRONES_AMD_PATH=auto)");
     iso_sampler* sp = new (std::nothrow) iso_sampler();
     if (!sp) return fail(ISO_ERR_NOMEM, "iso_sampler_create_tree: out of host memory");

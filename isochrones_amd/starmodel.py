@@ -1297,7 +1297,7 @@ class TreeStarModel(_NestedFitMixin, _ConvenienceMixin):
         """Stretch-move ensemble resident on the device: burn-in and sampling are one persistent launch each
         (``k_stretch_tree``: proposal, tree lnpost and accept step of every iteration inside the kernel, positions in
         LDS).  ``fused=False`` selects the framework-op sampler around the batch kernel (debugging aid; also what runs
-        when the tree has no device-resident form - more than 12 bands or tables off the corner-packed path)."""
+        when the tree has no device-resident form - tables off the corner-packed path)."""
         self._sampler = _run_mcmc_fit(self, nwalkers, nburn, niter, p0, seed, fused, n_ensembles)
         self._samples = None
         self._fit_kind = "mcmc"
