@@ -2110,6 +2110,67 @@ int iso_interp_eep_host(iso_eep_table* t, const double* age, const double* feh, 
     return ISO_OK;
 }
 
+
+// ---- a small pool of device blocks for the per-fit buffers of a catalog -------------------------------------------------------
+// A catalog fit of a few thousand stars is a few milliseconds, and it used to start with two hipMalloc and end with two hipFree
+// (each a device-wide synchronise plus ~0.1 ms in the driver): a tenth of the 3.3 ms of a 1 250-star fit.  Blocks given back are
+// kept (at most POOL_BLOCKS of them, POOL_BYTES in total, per device) and handed out again to the next request they fit;
+// giving a block back waits for the device first - whatever stream read it has finished, as with hipFree.
+namespace {
+struct PoolBlock {
+    void* p;
+    size_t bytes;
+    int device;
+};
+std::mutex g_pool_mu;
+std::vector<PoolBlock> g_pool;
+constexpr size_t POOL_BLOCKS = 8, POOL_BYTES = (size_t)512 << 20;
+
+hipError_t pool_alloc(void** out, size_t bytes, int device, size_t* got)
+{
+    {
+        std::lock_guard<std::mutex> lock(g_pool_mu);
+        size_t best = g_pool.size();
+        for (size_t k = 0; k < g_pool.size(); ++k)
+            if (g_pool[k].device == device && g_pool[k].bytes >= bytes && g_pool[k].bytes <= 2 * bytes + 4096 &&
+                (best == g_pool.size() || g_pool[k].bytes < g_pool[best].bytes))
+                best = k;
+        if (best < g_pool.size()) {
+            *out = g_pool[best].p;
+            *got = g_pool[best].bytes;
+            g_pool.erase(g_pool.begin() + (long)best);
+            return hipSuccess;
+        }
+    }
+    *got = bytes;
+    return hipMalloc(out, bytes);
+}
+
+void pool_free(void* p, size_t bytes, int device)
+{
+    if (!p) return;
+    (void)hipDeviceSynchronize();
+    void* drop = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_pool_mu);
+        size_t total = bytes;
+        for (const PoolBlock& b : g_pool) total += b.bytes;
+        if (bytes > POOL_BYTES / 2 || total > POOL_BYTES || g_pool.size() >= POOL_BLOCKS) {
+            if (bytes <= POOL_BYTES / 2 && !g_pool.empty()) {      // make room: the oldest block goes
+                drop = g_pool.front().p;
+                g_pool.erase(g_pool.begin());
+                g_pool.push_back(PoolBlock{p, bytes, device});
+            } else {
+                drop = p;
+            }
+        } else {
+            g_pool.push_back(PoolBlock{p, bytes, device});
+        }
+    }
+    if (drop) (void)hipFree(drop);
+}
+}  // namespace
+
 int iso_catalog_create(iso_ic* ic, const iso_model_desc* descs, int64_t n_models, iso_catalog** out)
 {
     if (!ic || !descs || !out || n_models < 1) return fail(ISO_ERR_INVALID, "iso_catalog_create: bad argument");
@@ -2134,6 +2195,7 @@ int iso_catalog_create(iso_ic* ic, const iso_model_desc* descs, int64_t n_models
     c->n_stars = d0.n_stars;
     c->n_bands = d0.n_bands;
     c->d_models = nullptr;
+    c->models_bytes = 0;
     c->d_bc_hot = c->d_bcq = c->d_axes_blob = nullptr;
     std::vector<DevModel> H((size_t)n_models);
     for (int64_t k = 0; k < n_models; ++k) fill_dev_model(&descs[k], ic->kind, H[(size_t)k]);
@@ -2199,6 +2261,7 @@ int iso_catalog_create_columns(iso_ic* ic, const iso_model_desc* tmpl, int64_t n
     c->n_stars = tmpl->n_stars;
     c->n_bands = tmpl->n_bands;
     c->d_models = nullptr;
+    c->models_bytes = 0;
     c->d_bc_hot = c->d_bcq = c->d_axes_blob = nullptr;
     const int nb = tmpl->n_bands;
     DevModel H;
@@ -2212,8 +2275,9 @@ int iso_catalog_create_columns(iso_ic* ic, const iso_model_desc* tmpl, int64_t n
     std::vector<double> stage((stage_bytes + 7) / 8);
     std::memcpy(stage.data(), &H, sizeof(DevModel));
     double* d_stage = nullptr;
-    hipError_t e = hipMalloc(&c->d_models, sizeof(DevModel) * n);
-    if (e == hipSuccess) e = hipMalloc(&d_stage, stage.size() * sizeof(double));
+    size_t stage_got = 0;
+    hipError_t e = pool_alloc(reinterpret_cast<void**>(&c->d_models), sizeof(DevModel) * n, c->device, &c->models_bytes);
+    if (e == hipSuccess) e = pool_alloc(reinterpret_cast<void**>(&d_stage), stage.size() * sizeof(double), c->device, &stage_got);
     FillCatalogArgs F;
     std::memset(&F, 0, sizeof(F));
     if (e == hipSuccess) {
@@ -2247,7 +2311,7 @@ int iso_catalog_create_columns(iso_ic* ic, const iso_model_desc* tmpl, int64_t n
         hipLaunchKernelGGL(k_catalog_fill, dim3(grid_blocks(n_models)), dim3(BLOCK), 0, 0, F);
         e = hipGetLastError();
     }
-    if (d_stage) (void)hipFree(d_stage);                 // (hipFree waits for the kernels that read it)
+    if (d_stage) pool_free(d_stage, stage_got, c->device);      // (waits for the kernels that read it)
     bool ok = false;
     if (e == hipSuccess) e = acquire_band_pack(ic, tmpl->bc_cols, nb, &c->pack, &ok);
     if (e == hipSuccess && !ok) {
@@ -2273,7 +2337,10 @@ void iso_catalog_destroy(iso_catalog* c)
 {
     if (!c) return;
     DeviceGuard guard(c->device);
-    if (c->d_models) (void)hipFree(c->d_models);
+    if (c->d_models) {
+        if (c->models_bytes) pool_free(c->d_models, c->models_bytes, c->device);     // (iso_catalog_create_columns' block)
+        else (void)hipFree(c->d_models);
+    }
     if (c->d_bc_hot) (void)hipFree(c->d_bc_hot);
     if (c->d_bcq) (void)hipFree(c->d_bcq);
     if (c->d_axes_blob) (void)hipFree(c->d_axes_blob);

@@ -311,6 +311,7 @@ struct iso_catalog {
     int64_t n_models;
     int n_stars, n_bands;
     iso::DevModel* d_models;  // [n_models]
+    size_t models_bytes;      // size of d_models' block when it came from the pool of per-fit buffers (0: plain hipMalloc)
     double* d_bc_hot;
     double* d_bcq;
     double* d_axes_blob;
