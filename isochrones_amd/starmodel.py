@@ -537,6 +537,11 @@ class BasicStarModel(_NestedFitMixin, _ConvenienceMixin):
                          TABLE_EPOCH[0], self._scalar_cache)
         c[3][:] = p                                      # (a row of the wrong length raises here)
         a = c[6]
+        if which is None:                                # all three parts in one call: (lnpost, lnprior, lnlike)
+            rc = c[7](c[2], c[5], 1, a[0], a[1], a[2])
+            if rc:
+                _cabi.check(rc)
+            return float(c[4][0]), float(c[4][1]), float(c[4][2])
         rc = c[7](c[2], c[5], 1, a[0] if which == 0 else None, a[1] if which == 1 else None, a[2] if which == 2 else None)
         if rc:
             _cabi.check(rc)
@@ -1426,7 +1431,25 @@ class IsoTrackModel(_NestedFitMixin):
         lnpost = torch.where(torch.isfinite(lnprior), lnprior + lnlike, torch.full_like(lnprior, -float("inf")))
         return lnpost, lnprior, lnlike
 
+    def _scalar_parts(self, p):
+        """(lnpost, lnprior, lnlike) of ONE host row - the per-point callback of emcee / MultiNest (reference
+        starmodel.py:2069-2104: lnprior from the track model and the age prior, lnlike = isochrone-grid + track-grid terms):
+        two per-point calls through the component models' resident mailbox waves and the closed-form age prior on the host,
+        instead of two batch launches and a dozen framework operations on one-row tensors."""
+        eep, mass, age, feh, dist, av = (float(x) for x in p)
+        _, t_prior, t_like = self._track_model._scalar_call((mass, eep, feh, dist, av), None)
+        i_like = self._iso_model._scalar_call((eep, age, feh, dist, av), 2)
+        lo, hi, lnorm = self.age_prior_constants()
+        ln_age = -math.inf if (age < lo or age > hi) else lnorm + age * math.log(10.0)
+        lnprior = t_prior + ln_age
+        lnlike = i_like + t_like
+        return (lnprior + lnlike if math.isfinite(lnprior) else -math.inf), lnprior, lnlike
+
     def _evaluate(self, p, which):
+        tp = type(p)
+        if ((tp is list or tp is tuple or (tp is np.ndarray and p.ndim == 1)) and len(p) == 6
+                and not isinstance(p[0], (list, tuple, np.ndarray))):
+            return self._scalar_parts(p)[which]
         if dev.is_tensor(p) and p.is_cuda:
             single = p.dim() == 1
             out = self.evaluate_device(p.double()[None, :] if single else p.double())[which]

@@ -638,6 +638,12 @@ def test_isotrack_family(nb):
         assert p0 is not None, tid + ": no start points"
         # the batch composition (two fused launches + framework ops) agrees with the oracle's ...
         fx.assert_close(mod.lnpost(p0), fn(None, p0), RTOL, atol=1e-8, what=tid + " batch")
+        # ... one point at a time - two per-point calls through the component models' resident waves and the age prior on the
+        # host (IsoTrackModel._scalar_parts) - gives the batch's numbers (to rounding: the host adds where the batch's framework
+        # kernel may fuse), an age outside the prior's support included
+        rows = np.vstack([p0[:8], p0[:2] * [1, 1, 0, 1, 1, 1] + [0, 0, 20.0, 0, 0, 0]])
+        for f in (mod.lnpost, mod.lnprior, mod.lnlike):
+            fx.assert_close(np.array([f(list(r)) for r in rows]), np.asarray(f(rows)), 1e-13, atol=1e-13, what=tid + " one point at a time")
         # ... and so does every move of the resident sampler
         with traced(tid) as t:
             check_sampler(mod, None, p0, W, 10, 15100 + nb, tid + " sampler", fn=fn)

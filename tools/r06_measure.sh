@@ -56,8 +56,8 @@ catalog_tests)
   timeout 2400 python -m pytest tests/test_gpu_catalog.py tests/test_gpu_sampler_oracle.py tests/test_gpu_start_points.py -q -x 2>&1 | tail -8 | tee $OUT/pytest_catalog.txt ;;
 service)
   timeout 1500 python -m pytest tests/test_gpu_dispatch_table.py -q -x -k "interpolation or eep_unit" 2>&1 | tail -15 | tee $OUT/pytest_service.txt
-  python tools/scalar_latency.py 2>&1 | grep -v amdgpu.ids | head -10 | tee $OUT/scalar_latency.txt
-  ISOCHRONES_AMD_MAILBOX=0 python tools/scalar_latency.py 2>&1 | grep -v amdgpu.ids | head -10 | tee $OUT/scalar_latency_launch_path.txt ;;
+  python tools/scalar_latency.py 2>&1 | grep -v amdgpu.ids | head -11 | tee $OUT/scalar_latency.txt
+  ISOCHRONES_AMD_MAILBOX=0 python tools/scalar_latency.py 2>&1 | grep -v amdgpu.ids | head -11 | tee $OUT/scalar_latency_launch_path.txt ;;
 waves)
   timeout 1500 python -m pytest tests/test_gpu_resident_waves.py tests/test_gpu_sampler_any.py -q -x 2>&1 | tail -12 | tee $OUT/pytest_waves.txt
   timeout 1500 python -m pytest tests/test_gpu_dispatch_table.py -q -x -k "tree or interpolation or eep_unit" 2>&1 | tail -12 | tee -a $OUT/pytest_waves.txt ;;

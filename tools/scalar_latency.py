@@ -23,6 +23,11 @@ tmod, tpars = bench_configs.tree_model_and_samples(16)
 tp = [float(v) for v in tpars[0]]
 t("tree model (resolved binary) lnpost(p)", lambda: tmod.lnpost(tp))
 assert tmod.lnpost(tp) == float(tmod.lnpost(np.array([tp, tp]))[0])
+import isochrones_amd as ia
+iso_ic = ia.synthetic_isochrone(bands=("V",))
+itm = ia.IsoTrackModel(iso_ic, ic, Teff=(5770, 100), logg=(4.5, 0.1), feh=(0.0, 0.15), V=(10.0, 0.05))
+ip = [355.0, 1.0, 9.6, 0.0, 100.0, 0.1]
+t("IsoTrackModel lnpost(p)", lambda: itm.lnpost(ip))
 half = np.tile(np.array(p), (128, 1)) * (1 + 1e-3 * np.random.default_rng(0).standard_normal((128, 5)))
 t("mod.lnpost(half ensemble [128, 5])", lambda: mod.lnpost(half))
 os.environ["ISOCHRONES_AMD_HOST_SYNC"] = "1"          # A/B: the stream-synchronise completion of round 1
