@@ -2944,48 +2944,33 @@ int iso_sampler_set_chain_layout(iso_sampler* s, int layout)
 }
 
 
-int iso_sampler_run(iso_sampler* sp, double* pos, double* lnp, int nsteps, double* chain, double* chain_lnp,
-                    int32_t* accepted, void* stream)
+namespace {
+// What one iso_sampler_run launches for the BasicStarModel / catalog kernels - decided in ONE place, readable from outside
+// (iso_debug_sampler_plan) and asserted by tests.  The rules, in the order they are applied (S = the launch's StretchArgs;
+// "resident" = every workgroup of the launch on the chip at once, by the runtime's occupancy figure for the very
+// instantiation that would be launched):
+//
+//   | question                              | rule                                                                          | evidence                         |
+//   |---------------------------------------|-------------------------------------------------------------------------------|----------------------------------|
+//   | persistent or one launch per half-step| persistent whenever an ensemble's LDS fits the CU's 160 KB (mode `auto`);      | r03/sampler_mode_sweep.txt,      |
+//   |                                       | `stepwise` / `persistent` / `persistent-dense` force a form (tests, A/B)      | r06 (the 64-KB limit: 55 -> 31 us)|
+//   | uncapped or register-capped (dense)   | the uncapped form if it keeps the launch resident (2 workgroups per CU), else | r03, r04                         |
+//   |                                       | the dense one (3-4 per CU) in rounds; dense needs priors the stars share      |                                  |
+//   | threads per workgroup (dense)         | 192 for ensembles of 129-192 moves per half-step (5 workgroups per CU), else  | r05/ab_three_wave_workgroups     |
+//   |                                       | 256                                                                           |                                  |
+//   | priors compiled in (dense, defaults)  | yes, unless that splits into rounds a launch the run-time form keeps resident | r05/ab_dense_stdp_final          |
+//   | ensembles per workgroup               | halved while >= 64 moves per half-step remain and the workgroups still fit    | r04, r06/catalog_groups          |
+//   |                                       | the CUs; kept only if the launch stays resident with the smaller groups       |                                  |
+//   | one star per lane / row (single model)| binary: <= 128 moves (<= 64 beyond 4 bands); triple: <= 64 moves; default     | r04/pair_kernel_ab,              |
+//   |                                       | prior families only (fast/launch.h picks the kernel from S.pair / triple_moves)| r06/triple_sweep                 |
+struct SamplerPlan {
+    bool persistent;
+    int per_cu;          // workgroups per CU of the instantiation that will be launched (occupancy query)
+    int group;           // ensembles a workgroup's LDS is laid out for
+};
+
+int plan_sampler_run(iso_sampler* sp, int nsteps, hipStream_t s, StretchArgs& S, SamplerPlan& P)
 {
-    if (!sp || !pos || !lnp) return fail(ISO_ERR_INVALID, "iso_sampler_run: NULL argument");
-    if (nsteps < 0) return fail(ISO_ERR_INVALID, "iso_sampler_run: nsteps < 0");
-    DeviceGuard guard(sp->device);
-    hipStream_t s = as_stream(stream);
-    const int64_t rows = sp->n_ensembles * sp->W;
-    if (sp->form != 0) {
-        // trees, IsoTrackModel, 13-32 bands: one persistent launch, one workgroup per ensemble (fast/sampler_any.h)
-        if (nsteps == 0) return ISO_OK;
-        const AnyStretchArgs S = any_args(sp, pos, lnp, accepted, nsteps, chain, chain_lnp);
-        sp->step += (uint32_t)nsteps;
-        if (!launch_any_form(sp, S, nullptr, s)) {
-            const hipError_t e = hipGetLastError();
-            return fail(e == hipSuccess ? ISO_ERR_INVALID : ISO_ERR_HIP,
-                        std::string("iso_sampler_run: any-model sampler launch failed") + (e == hipSuccess ? "" : std::string(": ") + hipGetErrorString(e)));
-        }
-        HIP_TRY(hipGetLastError());
-        return ISO_OK;
-    }
-    StretchArgs S;
-    S.occupancy_query = nullptr;
-    S.dense = 0;
-    S.group = 0;
-    S.threads = 0;
-    S.dense_stdp = 0;
-    S.triple_moves = 64;  // up to how many moves per half-step a single triple runs one star per row (profiles/r06/triple_sweep.jsonl)
-    S.pair = 1;           // ISOCHRONES_AMD_STAR_LANES=0: a single binary's fit through the one-lane-walks-both-stars kernel (A/B, tests)
-    if (const char* e = std::getenv("ISOCHRONES_AMD_STAR_LANES")) S.pair = std::atoi(e) != 0;
-    S.pos = pos;
-    S.lnp = lnp;
-    S.accepted = accepted;
-    S.W = sp->W;
-    S.multi = sp->multi;
-    S.std_priors = sp->std_priors;
-    S.n_active = sp->n_ensembles * (sp->W / 2);
-    if (S.n_active >= (int64_t(1) << 31)) return fail(ISO_ERR_INVALID, "iso_sampler_run: more than 2^31 moves per half-step");
-    S.a = sp->a;
-    S.seed = sp->seed;
-    S.chain_rs = sp->chain_layout == ISO_CHAIN_PARAM_MAJOR ? 1 : sp->n_params;
-    S.chain_ps = sp->chain_layout == ISO_CHAIN_PARAM_MAJOR ? rows : 1;
     // ISOCHRONES_AMD_SAMPLER = auto | persistent | stepwise.  Both forms produce bit-identical chains.  The persistent
     // kernel (workgroups own their ensembles for all iterations of the call, positions in LDS) is the faster one
     // at every catalog size measured (tools/sampler_mode_sweep.py, profiles/r03: 25-35 % over 2 x 10^3 ... 4 x 10^5 stars,
@@ -3096,7 +3081,62 @@ int iso_sampler_run(iso_sampler* sp, double* pos, double* lnp, int nsteps, doubl
     }
     // (round 2 kept the step-wise form for catalogs of 1-1.4 rounds, where a nearly empty second round cost more than it;
     // with four workgroups per CU the persistent form is ahead there too - profiles/r03/sampler_mode_sweep.txt)
-    const bool persistent = nsteps > 0 && fits && per_cu > 0 && mode != "stepwise";
+    P.persistent = nsteps > 0 && fits && per_cu > 0 && mode != "stepwise";
+    P.per_cu = per_cu;
+    P.group = group;
+    return ISO_OK;
+}
+}  // namespace
+
+int iso_sampler_run(iso_sampler* sp, double* pos, double* lnp, int nsteps, double* chain, double* chain_lnp,
+                    int32_t* accepted, void* stream)
+{
+    if (!sp || !pos || !lnp) return fail(ISO_ERR_INVALID, "iso_sampler_run: NULL argument");
+    if (nsteps < 0) return fail(ISO_ERR_INVALID, "iso_sampler_run: nsteps < 0");
+    DeviceGuard guard(sp->device);
+    hipStream_t s = as_stream(stream);
+    const int64_t rows = sp->n_ensembles * sp->W;
+    if (sp->form != 0) {
+        // trees, IsoTrackModel, 13-32 bands: one persistent launch, one workgroup per ensemble (fast/sampler_any.h)
+        if (nsteps == 0) return ISO_OK;
+        const AnyStretchArgs S = any_args(sp, pos, lnp, accepted, nsteps, chain, chain_lnp);
+        sp->step += (uint32_t)nsteps;
+        if (!launch_any_form(sp, S, nullptr, s)) {
+            const hipError_t e = hipGetLastError();
+            return fail(e == hipSuccess ? ISO_ERR_INVALID : ISO_ERR_HIP,
+                        std::string("iso_sampler_run: any-model sampler launch failed") + (e == hipSuccess ? "" : std::string(": ") + hipGetErrorString(e)));
+        }
+        HIP_TRY(hipGetLastError());
+        return ISO_OK;
+    }
+    StretchArgs S;
+    S.occupancy_query = nullptr;
+    S.dense = 0;
+    S.group = 0;
+    S.threads = 0;
+    S.dense_stdp = 0;
+    S.triple_moves = 64;  // up to how many moves per half-step a single triple runs one star per row (profiles/r06/triple_sweep.jsonl)
+    S.pair = 1;           // ISOCHRONES_AMD_STAR_LANES=0: a single binary's fit through the one-lane-walks-both-stars kernel (A/B, tests)
+    if (const char* e = std::getenv("ISOCHRONES_AMD_STAR_LANES")) S.pair = std::atoi(e) != 0;
+    S.pos = pos;
+    S.lnp = lnp;
+    S.accepted = accepted;
+    S.W = sp->W;
+    S.multi = sp->multi;
+    S.std_priors = sp->std_priors;
+    S.n_active = sp->n_ensembles * (sp->W / 2);
+    if (S.n_active >= (int64_t(1) << 31)) return fail(ISO_ERR_INVALID, "iso_sampler_run: more than 2^31 moves per half-step");
+    S.a = sp->a;
+    S.seed = sp->seed;
+    S.chain_rs = sp->chain_layout == ISO_CHAIN_PARAM_MAJOR ? 1 : sp->n_params;
+    S.chain_ps = sp->chain_layout == ISO_CHAIN_PARAM_MAJOR ? rows : 1;
+    SamplerPlan P;
+    {
+        const int rc = plan_sampler_run(sp, nsteps, s, S, P);
+        if (rc != ISO_OK) return rc;
+    }
+    const int per_cu = P.per_cu, group = P.group;
+    const bool persistent = P.persistent;
     {
         int32_t* pl = iso::t_sampler_plan;
         pl[0] = persistent ? 1 : 0;
