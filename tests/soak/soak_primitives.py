@@ -57,8 +57,30 @@ def eep_case(rng):
                          torch.as_tensor(f, device="cuda")).cpu().numpy()
     cfg = dict(what="interp_eep", nf=nf, nm=nm, ne=ne)
     bad = (soak.same(got, want, "get_eep host arrays", cfg) >= 0) + (soak.same(got_dev, want, "get_eep device", cfg) >= 0)
+    # ONE point at a time through the context's resident service wave (kernels/k_service.h): the batch's numbers bit for bit -
+    # get_eep, interp_value (two column lists, alternating: the wave restages the axes when the target changes) and interp_mag
+    idx = rng.integers(0, n, 24)
+    one = np.array([ic.get_eep(float(m[i]), float(a[i]), float(f[i])) for i in idx])
+    if not np.array_equal(one, got[idx], equal_nan=True):
+        print("MISMATCH get_eep one point", json.dumps(cfg), flush=True)
+        bad += 1
+    e = rng.uniform(eeps[0] - 2, eeps[-1] + 2, idx.size)
+    for cols_ in (["Teff", "logg", "age"], ["mass"], list(cols)):
+        batch = np.atleast_2d(ic.interp_value([m[idx], e, f[idx]], cols_))
+        pts = np.array([np.asarray(ic.interp_value([float(m[i]), float(ee), float(f[i])], cols_)) for i, ee in zip(idx, e)])
+        if not np.array_equal(pts.reshape(batch.shape), batch, equal_nan=True):
+            print("MISMATCH interp_value one point", cols_[:3], json.dumps(cfg), flush=True)
+            bad += 1
+    d_, av = rng.uniform(5.0, 3000.0, idx.size), rng.uniform(-0.1, 1.2, idx.size)
+    bT, bg, bf, bm = ic.interp_mag([m[idx], e, f[idx], d_, av], ["G"])
+    for k_, i in enumerate(idx):
+        T1, g1, f1, m1 = ic.interp_mag([float(m[i]), float(e[k_]), float(f[i]), float(d_[k_]), float(av[k_])], ["G"])
+        if not (np.array_equal([T1, g1, f1], [bT[k_], bg[k_], bf[k_]], equal_nan=True) and np.array_equal(np.asarray(m1), np.asarray(bm[k_]), equal_nan=True)):
+            print("MISMATCH interp_mag one point", json.dumps(cfg), flush=True)
+            bad += 1
+            break
     ic.release()
-    return bad, 2 * n
+    return bad, 2 * n + 6 * idx.size
 
 
 def cube_case(rng):
