@@ -283,11 +283,18 @@ __global__ __launch_bounds__(BLOCK, 2) void k_chain_quantiles_select(const Quant
 //            that interval with the whole list area (2 048 values) as capacity - until it fits, or lo == hi (all equal).
 // Every pass streams the pair's values from memory (the W values of a step are contiguous in the parameter-major chain);
 // a 30 000-value pair is 240 KB - L2 / Infinity Cache hits after the first pass.  Bit for bit numpy.percentile.
+// (Round 6, measured and not kept: ONE pass that also keeps the values of sampled WINDOWS around each level in LDS and ranks
+// from there - 99.9 % of the targets found, the chain read 1 1/8 times, and 6.2 ms where this form takes 4.3: the pass is
+// bound by instruction issue, not by the chain's bytes, and 53 KB of LDS leave three workgroups per CU.
+// docs/history/qbig_windows_experiment.patch, profiles/r06/quantile_big_ab_windows_experiment.jsonl.)
 // -------------------------------------------------------------------------------------------
 constexpr int QBIG_BINS = 4096;
 constexpr int QBIG_CAP = 128;                              // values per gathered list in the common pass (36 KB of LDS: four workgroups per CU)
 constexpr int QBIG_POOL = QSEL_RANKS * QBIG_CAP;           // = the single list of a refinement pass (2 048 values)
 constexpr size_t QBIG_LDS = (size_t)QBIG_POOL * 8 + QBIG_BINS * 4 + QBIG_BINS + 6 * QSEL_RANKS * 4 + 16 * 8 + 8 * 4 + QSEL_RANKS * 8;
+constexpr int QBIG_UN = 4;                                 // loads in flight per lane and round (2 and 8: the same time)
+constexpr int QBIG_NS = 16;                                // sampled values per thread (up to 4 096 per pair)
+struct QbigValues { double v[QBIG_UN]; };
 
 __global__ __launch_bounds__(BLOCK, 4) void k_chain_quantiles_big(const QuantArgs A)
 {
@@ -329,14 +336,21 @@ __global__ __launch_bounds__(BLOCK, 4) void k_chain_quantiles_big(const QuantArg
         w -= up ? (uint32_t)A.W : 0u;
         return value((int)t, (int)w);
     };
-    constexpr int QBIG_UN = 4;
+    // The loads of the NEXT round are issued before this round's values are used: what is done with a value (LDS atomics, a table
+    // look-up) runs under the next loads' latency instead of between two round trips.
+    auto load_values = [&](int i) {
+        QbigValues r;
+#pragma unroll
+        for (int u = 0; u < QBIG_UN; ++u) r.v[u] = value_at(min(i + u * BLOCK, m - 1));
+        return r;
+    };
+    struct QbigCursor { int i; QbigValues cur, nxt; };
 #define QBIG_FOR_VALUES(v)                                                                                       \
-    for (int i_ = tid; i_ < m; i_ += QBIG_UN * BLOCK)                                                             \
-        if (const double v0_ = value_at(i_), v1_ = value_at(min(i_ + BLOCK, m - 1)),                              \
-            v2_ = value_at(min(i_ + 2 * BLOCK, m - 1)), v3_ = value_at(min(i_ + 3 * BLOCK, m - 1)); true)         \
+    for (QbigCursor it_ = {tid, load_values(tid), {}}; it_.i < m; it_.i += QBIG_UN * BLOCK, it_.cur = it_.nxt)    \
+        if ((it_.nxt = load_values(it_.i + QBIG_UN * BLOCK)), true)                                               \
             _Pragma("unroll") for (int u_ = 0; u_ < QBIG_UN; ++u_)                                                \
-                if (i_ + u_ * BLOCK < m)                                                                          \
-                if (const double v = (u_ == 0) ? v0_ : (u_ == 1) ? v1_ : (u_ == 2) ? v2_ : v3_; true)
+                if (it_.i + u_ * BLOCK < m)                                                                       \
+                if (const double v = it_.cur.v[u_]; true)
 
     auto block_minmax = [&](double& mn, double& mx) {        // workgroup reduction; every thread gets the result
         for (int off = 32; off > 0; off >>= 1) {
@@ -405,13 +419,26 @@ __global__ __launch_bounds__(BLOCK, 4) void k_chain_quantiles_big(const QuantArg
     // the finite min / max of every 8th chunk of BLOCK values (an eighth of the traffic of a pass) spans the histogram, values
     // outside fall into its end bins, and the counts of the infinities come out of the histogram pass.  A sample without two
     // distinct finite values (a constant chain, a chain of infinities) takes the exact pass instead. ----
+    // The sample's loads are all in flight at once (QBIG_NS per thread, one round trip; a loop over the sample took a round
+    // trip per value: 15 for 30 000 values); a chain of more than QBIG_NS x 8 chunks is sampled at a wider stride.
     double mn = d_inf(), mx = -d_inf();
     int n_neg = 0, n_pos = 0;
-    for (int i_ = tid; i_ < m; i_ += 8 * BLOCK) {
-        const double v = value_at(i_);
-        const bool inf = (v == -d_inf()) | (v == d_inf());
-        mn = inf ? mn : fmin(mn, v);
-        mx = inf ? mx : fmax(mx, v);
+    {
+        const int n_chunks = (m + BLOCK - 1) / BLOCK;
+        const int sample_stride = max(8, (n_chunks + QBIG_NS - 1) / QBIG_NS) * BLOCK;
+        double sv[QBIG_NS];
+#pragma unroll
+        for (int u = 0; u < QBIG_NS; ++u) {
+            const int i = tid + u * sample_stride;
+            const double v = value_at(min(i, m - 1));
+            sv[u] = (i < m) ? v : d_inf();                   // (an infinity is no part of the sample)
+        }
+#pragma unroll
+        for (int u = 0; u < QBIG_NS; ++u) {
+            const bool inf = (sv[u] == -d_inf()) | (sv[u] == d_inf());
+            mn = inf ? mn : fmin(mn, sv[u]);
+            mx = inf ? mx : fmax(mx, sv[u]);
+        }
     }
     block_minmax(mn, mx);
     const bool exact_range = !(mx > mn);                     // workgroup-uniform (block_minmax gives every thread the same numbers)

@@ -89,6 +89,17 @@ for l in sys.stdin:
   done
   done
   unset ISOCHRONES_AMD_LIB ;;
+qbig)
+  # k_chain_quantiles_big on the chains of a reference-shape catalog fit (QBIG_LIBS: variant libraries to put beside the default)
+  timeout 900 python -m pytest tests/test_gpu_catalog.py -q -k "chain_quantiles" 2>&1 | tail -3
+  for rep in 1 2; do
+  for name in ${QBIG_LIBS:-default}; do
+    if [ "$name" = default ]; then unset ISOCHRONES_AMD_LIB; else export ISOCHRONES_AMD_LIB=$ROOT/variants/libs/libiso_hip_$name.so; fi
+    [ "$name" = default ] || [ -f "$ISOCHRONES_AMD_LIB" ] || continue
+    python tools/quantile_big_timing.py --label $name 2>/dev/null | grep '^{' | tee -a $OUT/quantile_big_ab.jsonl
+  done
+  done
+  unset ISOCHRONES_AMD_LIB ;;
 dispatch)
   timeout 2400 python -m pytest tests/test_gpu_dispatch_table.py -q 2>&1 | tail -12 | tee $OUT/pytest_dispatch.txt ;;
 soak)
