@@ -90,7 +90,13 @@ class StarCatalog:
         return ((q, self.measurements[q]) for q in self.props)
 
     def set_prior(self, **kwargs):
-        """Prior objects every model built from this catalog receives (reference: catalog.py:117-124)."""
+        """Prior objects every model built from this catalog receives (reference: catalog.py:117-124).  A catalog is fitted
+        inside the resident kernels, so these have to be families the device evaluates."""
+        from .priors import is_host_prior
+        for prop, prior in kwargs.items():
+            if prop != "eep" and is_host_prior(prior):
+                raise NotImplementedError("prior %r for %r is not evaluable on the device: a catalog fit needs one of "
+                                          "isochrones_amd.priors.DEVICE_PRIOR_TYPES (single models accept any Prior)" % (prior, prop))
         self._prior_settings.update(kwargs)
 
     def model(self, i, ic, N=1, **kwargs):

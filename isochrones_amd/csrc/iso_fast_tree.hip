@@ -86,6 +86,9 @@ __global__ __launch_bounds__(64, 2) void k_mailbox_tree(const FastArgs A, const 
             if (leave) break;                              // (wave-uniform)
             continue;
         }
+#ifdef ISO_MAILBOX_CLOCK
+        const unsigned long long t_seen = wall_clock64();
+#endif
         // parameter j of the request: the word lane 1 + j read
         auto word = [&](int j) {
             return ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(whi, 1 + j) << 32) |
@@ -116,6 +119,9 @@ __global__ __launch_bounds__(64, 2) void k_mailbox_tree(const FastArgs A, const 
             sys_store(&mb->done[1], (unsigned long long)__double_as_longlong(post));
             sys_store(&mb->done[2], (unsigned long long)__double_as_longlong(lnp));
             sys_store(&mb->done[3], (unsigned long long)__double_as_longlong(lnl));
+#ifdef ISO_MAILBOX_CLOCK
+            sys_store(&mb->done[4], wall_clock64() - t_seen);
+#endif
         }
         __threadfence_system();                            // results before the sequence word
         if (lane == 0) sys_store(&mb->done[0], seq);

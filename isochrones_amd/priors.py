@@ -4,8 +4,12 @@ On the GPU the priors are evaluated inside the fused ``lnpost`` kernel; the host
 per-model *constants* (bounds, normalisations) and packs them into ``iso_prior`` records
 (include/isochrones_amd.h).  Class names and the meaning of ``bounds`` follow the reference
 (isochrones/priors.py) so that ``StarModel._priors`` / ``set_prior`` / ``set_bounds`` read the
-same; only the families the reference's ``BasicStarModel`` installs by default (plus the
-simple bounded ones) are supported on the device — anything else raises at model build time.
+same.  The families the reference ships (its ``BasicStarModel`` defaults plus the simple bounded
+ones) are evaluated on the device.  Any OTHER ``Prior`` object — a user's subclass that defines
+``_pdf`` (and optionally ``_lnpdf`` / ``distribution``) the way the reference's base class expects
+(priors.py:31-73) — is a *host prior*: the device sees a flat stand-in over its bounds and the model
+adds ``lnpdf`` of that parameter on the host (``starmodel._HostPriorMixin``); such a model is fitted
+by the framework-op sampler, not by the resident kernels.
 
 Normalisation constants are obtained exactly the way the reference obtains them
 (``scipy.integrate.quad`` over the same integrand: priors.py:42-45 for ``FehPrior``,
@@ -55,13 +59,19 @@ class Prior:
         self._bounds = (float(new[0]), float(new[1]))
         self._version += 1
         EPOCH[0] += 1
+        if self.kind == 0 and getattr(self, "_pdf", None) is not None and _quad is not None:
+            self._norm = _quad(self._pdf, *self._bounds)[0]          # (reference priors.py:42-45)
         self._rebuild()
 
     def _rebuild(self):
         pass
 
     def _raw(self, x):
-        raise NotImplementedError
+        # a user's subclass in the reference's style defines _pdf; _norm is the integral over its bounds (priors.py:42-60)
+        f = getattr(self, "_pdf", None)
+        if f is None:
+            raise NotImplementedError
+        return f(x) / getattr(self, "_norm", 1.0)
 
     def pdf(self, x):
         lo, hi = self.bounds
@@ -84,6 +94,9 @@ class Prior:
         return np.array([self._raw(float(v)) for v in x.ravel()]).reshape(x.shape)
 
     def lnpdf(self, x):
+        own = getattr(self, "_lnpdf", None)          # (the reference's hook, priors.py:62-67: no bounds test in front of it)
+        if own is not None and self.kind == 0:
+            return own(x)
         if self.bounded:
             lo, hi = self.bounds
             if x < lo or x > hi:
@@ -92,7 +105,23 @@ class Prior:
         return float(np.log(p)) if p else -np.inf
 
     def sample(self, n, rng=None):
-        raise NotImplementedError
+        """The reference's base class draws from ``self.distribution`` when a subclass has one (priors.py:69-73); a prior
+        with finite bounds and a pdf is drawn by rejection under its largest value on a grid (start points only need
+        draws that cover the support)."""
+        dist = getattr(self, "distribution", None)
+        if dist is not None:
+            return np.asarray(dist.rvs(n), dtype=float)
+        lo, hi = self.bounds
+        if not (np.isfinite(lo) and np.isfinite(hi)) or getattr(self, "_pdf", None) is None:
+            raise NotImplementedError
+        rng = rng or np.random.default_rng()
+        top = 1.05 * max(self.pdf(float(v)) for v in np.linspace(lo, hi, 2049))
+        out = np.empty(0)
+        while out.size < n:
+            x = rng.uniform(lo, hi, size=max(2 * (n - out.size), 64))
+            keep = rng.uniform(0.0, top, size=x.size) < np.array([self.pdf(float(v)) for v in x])
+            out = np.concatenate([out, x[keep]])
+        return out[:n]
 
     # the reference's self-checks (priors.py:74-104), used by its tests/test_priors.py
     def test_integral(self):
@@ -522,6 +551,36 @@ def __getattr__(name):      # priors.EEP_prior (reference priors.py:384-463) liv
 
 DEVICE_PRIOR_TYPES = (FlatPrior, FlatLogPrior, PowerLawPrior, GaussianPrior, LogNormalPrior,
                       ChabrierPrior, FehPrior)
+
+
+def is_host_prior(p) -> bool:
+    """A prior object the device has no family for (a user's ``Prior`` subclass, a foreign object with ``lnpdf`` and
+    ``bounds``): evaluated on the host, parameter by parameter."""
+    return not isinstance(p, DEVICE_PRIOR_TYPES)
+
+
+def check_host_prior(p, prop):
+    if not callable(getattr(p, "lnpdf", None)) or not hasattr(p, "bounds"):
+        raise TypeError("prior for %r must offer lnpdf(x) and bounds (got %r)" % (prop, p))
+
+
+def flat_stand_in(p) -> "FlatPrior":
+    """What the device evaluates in a host prior's place: flat over the prior's bounds (an unbounded side becomes
+    +-1e300), so the bounds test stays on the device and the host adds ``lnpdf(x) + log(width)``."""
+    lo, hi = p.bounds
+    lo = float(lo) if np.isfinite(lo) else -1e300
+    hi = float(hi) if np.isfinite(hi) else 1e300
+    return FlatPrior((lo, hi))
+
+
+def lnpdf_array(p, x):
+    """``p.lnpdf`` of every element of ``x`` (a prior's own ``lnpdf_array`` if it has one)."""
+    x = np.asarray(x, dtype=float)
+    own = getattr(p, "lnpdf_array", None)
+    if own is not None:
+        return np.asarray(own(x), dtype=float)
+    with np.errstate(all="ignore"):
+        return np.array([p.lnpdf(float(v)) for v in x.ravel()], dtype=float).reshape(x.shape)
 
 # ---- plain-data form of a prior (saved models) ----------------------------------------------------
 #: the only classes a saved model may name

@@ -138,6 +138,10 @@ class FusedEnsembleSampler:
         self.nwalkers = int(nwalkers)
         self.ndim = target.n_params
         self.is_catalog = isinstance(target, CatalogPosterior)
+        host = getattr(target, "_host_terms", None)
+        if host is not None and host():
+            raise ValueError("the resident sampler evaluates priors in the kernel; this model has priors evaluated on the host "
+                             "(use fit_mcmc, which takes the framework-op sampler for it)")
         # a model with n_ensembles > 1: that many independent ensembles of the one posterior in the same launches (shapes
         # then carry a leading ensemble axis, as a catalog's carry the star axis)
         self.multi_ensemble = (not self.is_catalog) and int(n_ensembles) > 1
