@@ -824,9 +824,13 @@ class BasicStarModel(_NestedFitMixin, _ConvenienceMixin, _HostPriorMixin):
             if (fused is None or fused) and not host_priors:
                 try:
                     return FusedEnsembleSampler(self, nwalkers, seed=int(rng.integers(2 ** 62)))
-                except _cabi.IsoError:
-                    if fused:
+                except _cabi.IsoError as e:
+                    # (as _run_mcmc_fit: only "no resident kernel for this shape" changes samplers; a HIP / memory failure is an error)
+                    if fused or e.rc not in (None, _cabi.ERR_INVALID):
                         raise
+                    import warnings
+                    warnings.warn("fit_mcmc: no device-resident sampler for this model shape (%s); using the framework-op "
+                                  "EnsembleSampler, whose random numbers differ" % e, RuntimeWarning, stacklevel=3)
             return EnsembleSampler(nwalkers, npars, self.lnpost, seed=int(rng.integers(2 ** 62)), device=device)
 
         if p0 is None:
