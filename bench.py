@@ -501,7 +501,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary workloads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-catalog", action="store_true", help="skip the catalog leg (BASELINE configs[4])")
-    ap.add_argument("--extras-timeout", type=float, default=900.0,
+    ap.add_argument("--extras-timeout", type=float, default=300.0,
                     help="seconds after which the line is printed with whatever the secondary legs have produced")
     ap.add_argument("--path", default=None, choices=["auto", "compact", "generic"],
                     help="kernel/table-layout selection (default: library default = auto)")

@@ -912,7 +912,10 @@ def broadcast_interpolator(ic=None, src=0, rebuild_on_src=False, timings=None):
         return ic
     t0 = _time.perf_counter()
     rank = dist.get_rank()
-    use_gpu = dist.get_backend() == "nccl"
+    # (ISOCHRONES_AMD_BROADCAST=device with gloo: CUDA tensors through gloo's staged broadcast - how the receiving side of the
+    # device route is exercised with more than one rank on a box with one GPU, which RCCL refuses to share between ranks)
+    nccl = dist.get_backend() == "nccl"
+    use_gpu = nccl or (os.environ.get("ISOCHRONES_AMD_BROADCAST") == "device" and torch.cuda.is_available())
     devt = torch.device("cuda", torch.cuda.current_device()) if use_gpu else torch.device("cpu")
     meta = [None]
     if rank == src:
@@ -922,7 +925,7 @@ def broadcast_interpolator(ic=None, src=0, rebuild_on_src=False, timings=None):
                                   limits=dict(ic.model_grid._limits)),
                        bc=dict(shape=b.grid.shape, columns=list(b.columns), names=list(b.index_names),
                                bands=list(ic.bc_grid.bands or b.columns)))
-    dist.broadcast_object_list(meta, src=src, device=devt if use_gpu else None)
+    dist.broadcast_object_list(meta, src=src, device=devt if nccl else None)
     meta = meta[0]
     keep = rank != src or rebuild_on_src
 

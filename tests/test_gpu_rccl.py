@@ -118,3 +118,70 @@ def test_world1_nccl_group_runs_broadcast_and_fit_catalog(tmp_path):
     assert out["ok_fraction"] > 0.9
     assert out["rccl_mapped"], "no librccl in the process map: the nccl backend did not load RCCL"
     assert out["broadcast"]["broadcast_bytes"] > 0 and out["broadcast"]["broadcast_s"] > 0
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The RECEIVING side of the device route with more than one rank.  RCCL does not let two ranks share a GPU, and the test
+# box has one; gloo broadcasts CUDA tensors (staged through the host), so with ISOCHRONES_AMD_BROADCAST=device two ranks
+# on cuda:0 run exactly what a rank of the 8-GPU job runs after its `dist.broadcast` returned: the tensor that arrived is
+# handed to the library as it is (DFInterpolator.from_device -> iso_table_create_from_device), the host copy behind
+# `.grid` is made only on request, and the interpolator built from it evaluates the same bits as the sender's.
+# ---------------------------------------------------------------------------------------------------------------
+SCRIPT_WORLD2 = r'''
+import hashlib, json, os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+import torch
+import torch.distributed as dist
+torch.cuda.set_device(0)
+dist.init_process_group("gloo")
+rank = dist.get_rank()
+import isochrones_amd as ia
+ic = ia.synthetic_track(bands=("G", "BP", "RP")) if rank == 0 else None
+tb = {}
+ic = ia.broadcast_interpolator(ic, src=0, timings=tb)
+m = ic.model_grid.interp
+out = {"rank": rank, "stay": tb["tables_stay_on_device"], "bytes": tb["broadcast_bytes"],
+       "device_grid": getattr(m, "_device_grid", None) is not None, "host_copy_before": getattr(m, "_grid", None) is not None}
+mod = ia.SingleStarModel(ic, Teff=(5770, 100), logg=(4.4, 0.1), feh=(0.0, 0.15), G=(10.0, 0.05), parallax=(10.0, 0.1))
+rng = np.random.default_rng(5)
+x = np.column_stack([rng.uniform(0.7, 2.0, 20000), rng.uniform(250, 500, 20000), rng.uniform(-1, 0.4, 20000),
+                     rng.uniform(50, 150, 20000), rng.uniform(0, 1, 20000)])
+post = mod.lnpost(x)
+out["finite"] = int(np.isfinite(post).sum())
+out["lnpost_digest"] = hashlib.sha256(np.ascontiguousarray(post).tobytes()).hexdigest()
+mags = ic.interp_mag([1.0, 355.0, 0.0, 100.0, 0.1], ["G", "BP", "RP"])
+out["mag_digest"] = hashlib.sha256(np.ascontiguousarray(np.concatenate([np.ravel(v) for v in mags])).tobytes()).hexdigest()
+# a catalog shard fitted on what arrived
+cat, _ = ia.synthetic_catalog(ic, 64, bands=["G", "BP", "RP"], seed=3, mag_unc=0.01)
+res = ia.fit_catalog(cat, ic, nwalkers=32, nburn=40, niter=20, seed=2)
+out["rows"] = len(res) if res is not None else None
+out["ok"] = float(np.mean(res["ok"])) if res is not None else None
+out["host_copy_after_fit"] = getattr(m, "_grid", None) is not None
+out["grid_digest"] = hashlib.sha256(np.ascontiguousarray(m.grid).tobytes()).hexdigest()       # (asks for the host copy)
+gathered = [None, None]
+dist.all_gather_object(gathered, out)
+if rank == 0:
+    print("RESULT " + json.dumps(gathered))
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_two_ranks_receive_the_tables_on_the_device(tmp_path):
+    script = tmp_path / "bcast_world2.py"
+    script.write_text(SCRIPT_WORLD2 % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", ISOCHRONES_AMD_BROADCAST="device")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(_free_port()), str(script)], cwd=ROOT, env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-4000:])
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")][-1]
+    r0, r1 = sorted(json.loads(line[len("RESULT "):]), key=lambda d: d["rank"])
+    assert r0["stay"] and r1["stay"] and r1["bytes"] > 7e8
+    assert r1["device_grid"] and not r1["host_copy_before"]          # what arrived was adopted where it was
+    assert not r1["host_copy_after_fit"]                              # evaluating and fitting never asked for a host copy
+    assert r0["finite"] > 1000
+    for key in ("finite", "lnpost_digest", "mag_digest", "grid_digest"):
+        assert r0[key] == r1[key], key                                # the receiver evaluates the sender's bits
+    assert r0["rows"] == 64 and r0["ok"] > 0.9
