@@ -8,6 +8,10 @@
 #include "iso_fast_kernel.h"
 #include "fast/tree_mailbox.h"
 
+#ifndef ISO_TREE_MAILBOX_LDS_TREE
+#define ISO_TREE_MAILBOX_LDS_TREE 1
+#endif
+
 namespace iso {
 namespace fastk {
 
@@ -63,12 +67,26 @@ __global__ __launch_bounds__(64, 2) void k_mailbox_tree(const FastArgs A, const 
     // batch kernel's form)
     constexpr int NREQ = tree_requests(NL, NB);
     const CoopLds L = coop_lds_multi<NREQ>(lds, A.axes_len, slot_stride(NB));
-    const DevTree& T = *Tp;
     TreeLeaves<NB, NL> S;
     S.lds_ = nullptr;
     S.stride_ = 64;
     double* lpar = lds + ((A.axes_len + 1) & ~1) + NREQ * 64 * slot_stride(NB);      // the request's 32 words behind the gather slots
     const int lane = (int)threadIdx.x;
+#if ISO_TREE_MAILBOX_LDS_TREE
+    // The tree's record (term tables, prior constants: 7 KB) once into LDS: a LONE wave reads it field by field through
+    // dependent scalar loads otherwise - 40 of them one behind the other in an evaluation, each a few hundred cycles with
+    // nothing else to run (priors + likelihood: 15 900 of the evaluation's 32 700 shader clocks, profiles/r06/tree_mailbox_device_clock.txt)
+    static_assert(sizeof(DevTree) % 8 == 0, "copied in 8-byte words");
+    {
+        unsigned long long* dst = reinterpret_cast<unsigned long long*>(lpar + 32);
+        const unsigned long long* src = reinterpret_cast<const unsigned long long*>(Tp);
+        for (int j = lane; j < (int)(sizeof(DevTree) / 8); j += 64) dst[j] = src[j];
+        __syncthreads();
+    }
+    const DevTree& T = *reinterpret_cast<const DevTree*>(lpar + 32);
+#else
+    const DevTree& T = *Tp;
+#endif
     auto sys_load = [](const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
     auto sys_store = [](unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
     unsigned long long last = sys_load(&mb->done[0]);
@@ -88,6 +106,9 @@ __global__ __launch_bounds__(64, 2) void k_mailbox_tree(const FastArgs A, const 
         }
 #ifdef ISO_MAILBOX_CLOCK
         const unsigned long long t_seen = wall_clock64();
+#ifdef ISO_PHASE_CLOCK
+        const unsigned long long c_seen = __builtin_readcyclecounter();
+#endif
 #endif
         // parameter j of the request: the word lane 1 + j read
         auto word = [&](int j) {
@@ -121,6 +142,13 @@ __global__ __launch_bounds__(64, 2) void k_mailbox_tree(const FastArgs A, const 
             sys_store(&mb->done[3], (unsigned long long)__double_as_longlong(lnl));
 #ifdef ISO_MAILBOX_CLOCK
             sys_store(&mb->done[4], wall_clock64() - t_seen);
+#ifdef ISO_PHASE_CLOCK          // shader-clock stamps of the evaluation's phases, from the request's arrival (tree_eval.h: ISO_STAMP)
+            sys_store(&mb->done[5], g_phase_stamps[3] - c_seen);          // first model cell in
+            sys_store(&mb->done[6], g_phase_stamps[6] - c_seen);          // every leaf gathered, fluxes formed
+            sys_store(&mb->done[7], g_phase_stamps[7] - c_seen);          // priors
+            sys_store(&mb->ctl[4], g_phase_stamps[8] - c_seen);           // likelihood
+            sys_store(&mb->ctl[5], __builtin_readcyclecounter() - c_seen);
+#endif
 #endif
         }
         __threadfence_system();                            // results before the sequence word
@@ -182,7 +210,10 @@ static bool launch_tree_mailbox_nl(int nb, const FastArgs& A, const DevTree* T, 
                                    unsigned long long life, hipStream_t s)
 {
     using namespace fastk;
-    auto sh = [&](int n) { return (size_t)(((A.axes_len + 1) & ~1) + tree_requests(NL, n) * 64 * slot_stride(n) + 32) * sizeof(double); };
+    auto sh = [&](int n) {
+        return (size_t)(((A.axes_len + 1) & ~1) + tree_requests(NL, n) * 64 * slot_stride(n) + 32) * sizeof(double) +
+               (ISO_TREE_MAILBOX_LDS_TREE ? sizeof(DevTree) : 0);
+    };
     switch (nb) {
 #define ISO_TREE_MB_CASE(N) \
     case N: note_kernel("k_mailbox_tree<%d, %d>", N, NL); hipLaunchKernelGGL((k_mailbox_tree<N, NL>), dim3(1), dim3(64), sh(N), s, A, T, d_box, idle, life); return true;

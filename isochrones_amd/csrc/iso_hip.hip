@@ -2626,10 +2626,19 @@ int tree_mailbox_call(iso_tree_model* m, const double* pars, double* lnpost_out,
     if (lnlike_out) *lnlike_out = r[2];
 #ifdef ISO_MAILBOX_CLOCK        // (variant builds: the wave's own time from seeing a request to its results, 100 MHz ticks)
     {
-        static unsigned long long calls = 0, ticks = 0;
+        static unsigned long long calls = 0, ticks = 0, ph[5] = {0, 0, 0, 0, 0};
         ticks += __atomic_load_n(&mb->done[4], __ATOMIC_RELAXED);
+#ifdef ISO_PHASE_CLOCK
+        for (int k = 0; k < 3; ++k) ph[k] += __atomic_load_n(&mb->done[5 + k], __ATOMIC_RELAXED);
+        for (int k = 0; k < 2; ++k) ph[3 + k] += __atomic_load_n(&mb->ctl[4 + k], __ATOMIC_RELAXED);
+#endif
         if (++calls % 2000 == 0) {
             std::fprintf(stderr, "tree mailbox: %.2f us on the device per call (%llu calls)\n", ticks * 0.01 / (double)calls, calls);
+#ifdef ISO_PHASE_CLOCK
+            std::fprintf(stderr, "tree mailbox: shader clocks from the request: first model cell %.0f, leaves done %.0f, priors %.0f, likelihood %.0f, results written %.0f\n",
+                         ph[0] / (double)calls, ph[1] / (double)calls, ph[2] / (double)calls, ph[3] / (double)calls, ph[4] / (double)calls);
+            for (auto& v : ph) v = 0;
+#endif
             calls = ticks = 0;
         }
     }
