@@ -60,6 +60,9 @@ __global__ __launch_bounds__(64, 2) void k_mailbox_lnpost(const FastArgs A0, Iso
         // the argument block is read again from the kernel-argument segment for every request (scalar loads where a field is
         // used, through a pointer the optimiser cannot see through) instead of living in spilled scalar registers across the
         // polling loop - as the persistent samplers do (fast/sampler.h)
+#ifdef ISO_MAILBOX_CLOCK
+        const unsigned long long t_seen = wall_clock64();
+#endif
         typedef const __attribute__((address_space(4))) char* kernarg_ptr;
         kernarg_ptr kp = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
         asm volatile("" : "+s"(kp));
@@ -102,6 +105,9 @@ __global__ __launch_bounds__(64, 2) void k_mailbox_lnpost(const FastArgs A0, Iso
                 mb->out[2 * ISO_MAILBOX_ROWS + r] = lnl;
             }
         }
+#ifdef ISO_MAILBOX_CLOCK
+        if (lane == 0) sys_store(&mb->done[4], wall_clock64() - t_seen);
+#endif
         __threadfence_system();                                // results before the sequence word
         if (lane == 0) sys_store(&mb->done[0], seq);
         last = seq;

@@ -1560,6 +1560,16 @@ int mailbox_call(iso_model* m, const double* pars, int n, double* lnpost_out, do
         if (lnpost_out) *lnpost_out = r[0];
         if (lnprior_out) *lnprior_out = r[1];
         if (lnlike_out) *lnlike_out = r[2];
+#ifdef ISO_MAILBOX_CLOCK        // (variant builds: the wave's own time from seeing a request to its results, 100 MHz ticks)
+        {
+            static unsigned long long calls = 0, ticks = 0;
+            ticks += __atomic_load_n(&mb->done[4], __ATOMIC_RELAXED);
+            if (++calls % 2000 == 0) {
+                std::fprintf(stderr, "model mailbox: %.2f us on the device per call (%llu calls)\n", ticks * 0.01 / (double)calls, calls);
+                calls = ticks = 0;
+            }
+        }
+#endif
     } else {
         if (lnpost_out) std::memcpy(lnpost_out, mb->out, sizeof(double) * n);
         if (lnprior_out) std::memcpy(lnprior_out, mb->out + ISO_MAILBOX_ROWS, sizeof(double) * n);
