@@ -4,7 +4,10 @@
 //
 // One workgroup = one ensemble for all iterations of the launch.  LDS: [axes][gather slots][leaf values (runtime-leaf form)]
 // [positions W x NP][lnpost W][acceptance counters W].  The tree record is read through the constant address space
-// (scalar loads: none of the kernel's stores can touch it).
+// (scalar loads: none of the kernel's stores can touch it).  Round 6, measured and not kept: the record copied into LDS when
+// the kernel starts and read from there (what helps the lone mailbox wave, iso_fast_tree.hip) - resolved binary 25.2 -> 26.1
+// us per step; values read from LDS live in vector registers (four stars x 6-8 bands: 48-148 B of scratch per lane) and
+// the scalar loads of four waves hit the scalar cache (profiles/r06/tree_ab_lds_record.txt).
 #include "iso_fast_kernel.h"
 
 namespace iso {

@@ -8,10 +8,6 @@
 #include "iso_fast_kernel.h"
 #include "fast/tree_mailbox.h"
 
-#ifndef ISO_TREE_MAILBOX_LDS_TREE
-#define ISO_TREE_MAILBOX_LDS_TREE 1
-#endif
-
 namespace iso {
 namespace fastk {
 
@@ -29,7 +25,10 @@ __global__ __launch_bounds__(tree_block<NL>(), 2) void k_lnpost_tree_fast(const 
     for (int j = threadIdx.x; j < A.axes_len; j += TB) lds[j] = A.axes_blob[j];
     __syncthreads();
     const CoopLds L = coop_lds<NB>(lds, A.axes_len);
-    const DevTree& T = *Tp;
+    // (the tree's record through the constant address space: scalar loads whatever the compiler can prove about the pointer -
+    // as the sampler and the mailbox wave read it; 110.5-112.4 -> 109.0-110.1 us)
+    typedef const __attribute__((address_space(4))) DevTree* const_tree_ptr;
+    const DevTree& T = *(const DevTree*)((const_tree_ptr)(uintptr_t)Tp);
     const int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x;
     const bool active = i < A.n;
     const int64_t ii = active ? i : (A.n - 1);
@@ -72,21 +71,12 @@ __global__ __launch_bounds__(64, 2) void k_mailbox_tree(const FastArgs A, const 
     S.stride_ = 64;
     double* lpar = lds + ((A.axes_len + 1) & ~1) + NREQ * 64 * slot_stride(NB);      // the request's 32 words behind the gather slots
     const int lane = (int)threadIdx.x;
-#if ISO_TREE_MAILBOX_LDS_TREE
-    // The tree's record (term tables, prior constants: 7 KB) once into LDS: a LONE wave reads it field by field through
-    // dependent scalar loads otherwise - 40 of them one behind the other in an evaluation, each a few hundred cycles with
-    // nothing else to run (priors + likelihood: 15 900 of the evaluation's 32 700 shader clocks, profiles/r06/tree_mailbox_device_clock.txt)
-    static_assert(sizeof(DevTree) % 8 == 0, "copied in 8-byte words");
-    {
-        unsigned long long* dst = reinterpret_cast<unsigned long long*>(lpar + 32);
-        const unsigned long long* src = reinterpret_cast<const unsigned long long*>(Tp);
-        for (int j = lane; j < (int)(sizeof(DevTree) / 8); j += 64) dst[j] = src[j];
-        __syncthreads();
-    }
-    const DevTree& T = *reinterpret_cast<const DevTree*>(lpar + 32);
-#else
-    const DevTree& T = *Tp;
-#endif
+    // The tree's record (term tables, prior constants: 7 KB) through the constant address space - scalar loads, as the
+    // sampler reads it: through the plain pointer an evaluation read it field by field with dependent VECTOR loads, a few
+    // hundred cycles each with nothing else to run on a lone wave (lnpost(p) 19.8-20.9 -> 18.0-18.9 us; a copy in LDS: the
+    // same, for 7 KB - profiles/r06/tree_mailbox_record_ab.txt)
+    typedef const __attribute__((address_space(4))) DevTree* const_tree_ptr;
+    const DevTree& T = *(const DevTree*)((const_tree_ptr)(uintptr_t)Tp);
     auto sys_load = [](const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
     auto sys_store = [](unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
     unsigned long long last = sys_load(&mb->done[0]);
@@ -210,10 +200,7 @@ static bool launch_tree_mailbox_nl(int nb, const FastArgs& A, const DevTree* T, 
                                    unsigned long long life, hipStream_t s)
 {
     using namespace fastk;
-    auto sh = [&](int n) {
-        return (size_t)(((A.axes_len + 1) & ~1) + tree_requests(NL, n) * 64 * slot_stride(n) + 32) * sizeof(double) +
-               (ISO_TREE_MAILBOX_LDS_TREE ? sizeof(DevTree) : 0);
-    };
+    auto sh = [&](int n) { return (size_t)(((A.axes_len + 1) & ~1) + tree_requests(NL, n) * 64 * slot_stride(n) + 32) * sizeof(double); };
     switch (nb) {
 #define ISO_TREE_MB_CASE(N) \
     case N: note_kernel("k_mailbox_tree<%d, %d>", N, NL); hipLaunchKernelGGL((k_mailbox_tree<N, NL>), dim3(1), dim3(64), sh(N), s, A, T, d_box, idle, life); return true;
