@@ -50,13 +50,21 @@ inline PersistKernel persist_kernel(const StretchArgs& S)
         // at the registers of three waves per SIMD (the straight-line priors need them: 136 B of scratch at the cap of four)
         // (single stars with up to six bands only: the other shapes sit at three waves per SIMD either way, and there the
         // compiled-in form only adds scratch - 400-480 B per lane for systems with 11-12 bands)
+        // (round 6) single stars, ONE ensemble per workgroup (258 and more walkers - the reference's default 300 -, or a launch
+        // the host spreads one ensemble per workgroup): the star's block through scalar loads (DENSE + UNI, sampler.h)
+        const int GL = persist_group(S.W);
+        const bool one = NS == 1 && ((S.group > 0 && S.group < GL) ? S.group : GL) == 1;
         if constexpr (persist_slim(true, N, NS)) {
             stdp = S.std_priors != 0 && S.dense_stdp != 0;
-            k.fn = stdp ? (const void*)k_stretch_persist<KIND, NS, N, true, false, false, true>
-                        : (const void*)k_stretch_persist<KIND, NS, N, true, false>;
+            if (one) k.fn = stdp ? (const void*)k_stretch_persist<KIND, 1, N, true, false, true, true>
+                                 : (const void*)k_stretch_persist<KIND, 1, N, true, false, true, false>;
+            else k.fn = stdp ? (const void*)k_stretch_persist<KIND, NS, N, true, false, false, true>
+                             : (const void*)k_stretch_persist<KIND, NS, N, true, false>;
         } else {
-            k.fn = (const void*)k_stretch_persist<KIND, NS, N, true, false>;
+            if (one) k.fn = (const void*)k_stretch_persist<KIND, 1, N, true, false, true, false>;
+            else k.fn = (const void*)k_stretch_persist<KIND, NS, N, true, false>;
         }
+        uni = one;
     } else if (S.multi) {
         // resident catalog: when its stars share their priors and those are the reference's defaults, the form that reads
         // them through scalar loads with the families as compile-time constants (STDP without UNI)

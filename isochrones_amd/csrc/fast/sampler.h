@@ -36,6 +36,8 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 // counter is (step, half, global row): both kernels draw identical numbers for a given move.
 // UNI: every row of the launch evaluates the one model A.m[0] (a single star's fit): its constants then come through scalar
 // loads instead of one vector load per field and lane (a catalog row has to index its own star's block).
+// DENSE_ONE (with UNI): the register-capped form with ONE ensemble per workgroup - the star's own block A.m[star] through
+// scalar loads (`star` is workgroup-uniform there).
 // STDP (with UNI): that model's priors are the reference's defaults - their families are compile-time constants.
 // LANE: lnpost_wave's gather / overlap form (ISO_UNI_LANE for the single-model kernel, ISO_DENSE_LANE for the register-capped
 // catalog kernel, 0 otherwise).
@@ -47,7 +49,7 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 // 2.7 % SLOWER on cfg 4 (8.44 -> 8.67 us per step, profiles/r05/ab_rng_ahead.jsonl): the wait it was meant to fill is
 // shorter than ten rounds of Philox, and nine more live registers across the evaluation cost more than the start of a
 // half-step gains.)
-template <int KIND, int NS, int NB, bool ASTERO, bool UNI = false, bool STDP = false, int LANE = 0, bool SHAREDP = false>
+template <int KIND, int NS, int NB, bool ASTERO, bool UNI = false, bool STDP = false, int LANE = 0, bool SHAREDP = false, bool DENSE_ONE = false>
 __device__ __forceinline__ void stretch_move(const FastArgs& A, const StretchArgs& S, double* lds, const CoopLds& L,
                                              bool active, bool owner, int64_t star, int k, int half, uint32_t step,
                                              double* __restrict__ pos, double* __restrict__ lnp, int32_t* acc_cnt,
@@ -86,7 +88,13 @@ __device__ __forceinline__ void stretch_move(const FastArgs& A, const StretchArg
     // UNI: the block is read through the constant address space (same memory; tells the compiler that none of this
     // kernel's stores can touch it, which is what a scalar load needs)
     typedef const __attribute__((address_space(4))) DevModel* const_model_ptr;
-    const DevModel& M = UNI ? *(const DevModel*)((const_model_ptr)(uintptr_t)A.m) : A.m[S.multi ? star : 0];
+    // DENSE + UNI (round 6): the register-capped catalog form when every workgroup owns ONE ensemble (258 and more walkers: the
+    // reference's default 300) - `star` is the same number in every lane, so the star's block is read through the constant
+    // address space as well (scalar loads instead of a vector load per field and lane): 1 250 reference-shape stars 11.0 ->
+    // 10.45 ms, 10^4 71.6 -> 70.2 (profiles/r06/one_star_blocks_ab.jsonl)
+    const int64_t star_u = ((int64_t)__builtin_amdgcn_readfirstlane((int)(star >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)star);
+    const DevModel& M = (DENSE_ONE && UNI) ? *(const DevModel*)((const_model_ptr)(uintptr_t)(A.m + (S.multi ? star_u : 0)))
+                                            : (UNI ? *(const DevModel*)((const_model_ptr)(uintptr_t)A.m) : A.m[S.multi ? star : 0]);
     double lnp_unused, lnl_unused;
     // UNI: a single star's fit (or a few ensembles of it) - one workgroup per CU at most, nothing to overlap with
     const DevModel& MP = SHAREDP ? *(const DevModel*)((const_model_ptr)(uintptr_t)A.m)
@@ -375,8 +383,8 @@ __device__ __forceinline__ void persist_body(const FastArgs& A, const StretchArg
                 const bool active = mine && k < h;
                 if (__any(active))                        // wave-uniform: idle waves go straight to the barrier
                     stretch_move<KIND, NS, NB, ASTERO, UNI, STDP,
-                                 (UNI ? ISO_UNI_LANE : (DENSE ? ISO_DENSE_LANE : (STDP ? ISO_MULTI_STD_LANE : ISO_MULTI_LANE))) | (PAIR ? 16 : 0),
-                                 (DENSE && ISO_DENSE_SHARED) || (!UNI && !DENSE && STDP)>(A, S, lds, L, active, active && owns, star0 + gs, active ? k : h - 1, half,
+                                 (DENSE ? ISO_DENSE_LANE : (UNI ? ISO_UNI_LANE : (STDP ? ISO_MULTI_STD_LANE : ISO_MULTI_LANE))) | (PAIR ? 16 : 0),
+                                 (DENSE && ISO_DENSE_SHARED) || (!UNI && !DENSE && STDP), DENSE && UNI>(A, S, lds, L, active, active && owns, star0 + gs, active ? k : h - 1, half,
                                                S.step + (uint32_t)it, lpos + gs * W * NP, llnp + gs * W,
                                                lacc ? lacc + gs * W : nullptr, cp, cl);
             }

@@ -366,6 +366,15 @@ def test_fused_families(kind, ns, nb):
                 with env(ISOCHRONES_AMD_SAMPLER="persistent-dense", ISOCHRONES_AMD_DENSE_STDP="0"), traced(tid) as t:
                     check_sampler(mod, oic, p0, 16, 8, 81 + nb, tid + " persistent dense, one model, run-time priors", n_ensembles=3)
                 expect(t.names, "k_stretch_persist<%d, %d, %d, true, false, false, false>" % (K, ns, nb), tid)
+                if ns == 1:
+                    # ONE ensemble per workgroup (what 258 and more walkers give; here: asked for): single stars read the
+                    # star's block through scalar loads - the register-capped form with UNI
+                    with env(ISOCHRONES_AMD_SAMPLER="persistent-dense", ISOCHRONES_AMD_PERSIST_GROUP="1"), traced(tid) as t:
+                        check_sampler(mod, oic, p0, 16, 8, 82 + nb, tid + " persistent dense, one ensemble per workgroup", n_ensembles=3)
+                    expect(t.names, "k_stretch_persist<%d, 1, %d, true, false, true, %s>" % (K, nb, "true" if nb <= 6 else "false"), tid)
+                    with env(ISOCHRONES_AMD_SAMPLER="persistent-dense", ISOCHRONES_AMD_PERSIST_GROUP="1", ISOCHRONES_AMD_DENSE_STDP="0"), traced(tid) as t:
+                        check_sampler(mod, oic, p0, 16, 8, 83 + nb, tid + " persistent dense, one ensemble per workgroup, run-time priors", n_ensembles=3)
+                    expect(t.names, "k_stretch_persist<%d, 1, %d, true, false, true, false>" % (K, nb), tid)
             del mod
     # ---- the same table entries with NON-DEFAULT prior families in every slot: the arms of ln_pdf's run-time switch inside
     # the batch, step-wise, persistent (run-time priors), one-star-per-lane and register-capped kernels (the default-prior
@@ -418,6 +427,14 @@ def test_fused_families(kind, ns, nb):
             with env(ISOCHRONES_AMD_SAMPLER="persistent-dense", ISOCHRONES_AMD_DENSE_STDP="0"), traced(tid) as t:
                 check_catalog_sampler(cat, post, ic, oic, ns, pos, lnp, good, 8, 94 + nb, tid + " catalog dense, run-time priors")
             expect(t.names, "k_stretch_persist<%d, %d, %d, true, false, false, false>" % (K, ns, nb), tid)
+            if ns == 1:
+                # a catalog with one ensemble per workgroup: every workgroup reads ITS star's block through scalar loads
+                with env(ISOCHRONES_AMD_SAMPLER="persistent-dense", ISOCHRONES_AMD_PERSIST_GROUP="1"), traced(tid) as t:
+                    check_catalog_sampler(cat, post, ic, oic, ns, pos, lnp, good, 8, 95 + nb, tid + " catalog dense, one star per workgroup")
+                expect(t.names, "k_stretch_persist<%d, 1, %d, true, false, true, %s>" % (K, nb, "true" if nb <= 6 else "false"), tid)
+                with env(ISOCHRONES_AMD_SAMPLER="persistent-dense", ISOCHRONES_AMD_PERSIST_GROUP="1", ISOCHRONES_AMD_DENSE_STDP="0"), traced(tid) as t:
+                    check_catalog_sampler(cat, post, ic, oic, ns, pos, lnp, good, 8, 96 + nb, tid + " catalog dense, one star per workgroup, run-time priors")
+                expect(t.names, "k_stretch_persist<%d, 1, %d, true, false, true, false>" % (K, nb), tid)
             with env(ISOCHRONES_AMD_SAMPLER="stepwise"), traced(tid) as t:
                 check_catalog_sampler(cat, post, ic, oic, ns, pos, lnp, good, 6, 92 + nb, tid + " catalog stepwise")
             expect(t.names, "k_stretch_half<%d, %d, %d, false>" % (K, ns, nb), tid)

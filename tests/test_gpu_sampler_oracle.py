@@ -359,7 +359,8 @@ def test_reference_shape_catalog_replayed_against_the_oracle(n_sys, n_stars, std
     assert chain.shape == (n_stars, W, niter, D)
     # the launch the reference-shape leg of bench.py measures: register-capped persistent form, three-wave workgroups
     stretch = [k for k in names if k.startswith("k_stretch")]
-    want = ("k_stretch_persist<1, %d, 3, true, false, false, %s>" % (n_sys, "true" if stdp else "false"))
+    # (300 walkers = one ensemble per workgroup: single stars read their star's block through scalar loads - DENSE + UNI)
+    want = ("k_stretch_persist<1, %d, 3, true, false, %s, %s>" % (n_sys, "true" if n_sys == 1 else "false", "true" if stdp else "false"))
     assert stretch == [want], stretch
     assert plan["persistent"] == 1 and plan["dense"] == 1 and plan["threads"] == 192, plan
     if n_sys == 1:          # (systems have the run-time-prior form only: the kernel's name says which one ran)
