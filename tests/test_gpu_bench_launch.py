@@ -25,6 +25,15 @@ def _free_port():
 def _launch(nproc, extra):
     env = dict(os.environ, ISO_BENCH_SHARE_GPU="1", ISO_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1",
                HSA_ENABLE_IPC_MODE_LEGACY="0")
+    # the ranks share the one GPU with this pytest process: give back what earlier tests left in torch's caching allocator
+    # (tens of GB after the full-size and catalog tests - eight ranks next to it have run out of device memory before)
+    try:
+        import gc
+        import torch
+        gc.collect()
+        torch.cuda.empty_cache()
+    except Exception:
+        pass
     first = None
     for attempt in range(2):
         # (a rendezvous that loses its port between _free_port() and the launcher's bind - another test's ranks, a socket in
