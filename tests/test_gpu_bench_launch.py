@@ -72,9 +72,9 @@ def test_bench_two_ranks_prints_one_valid_line():
         assert "error" not in leg, leg
         assert leg["stars_per_s"] > 0 and leg["ok_fraction"] > 0.99
         assert leg["fit_s"] > 0 and leg["gather_s"] > 0 and leg["wall_s"] >= leg["fit_s"]
-        # the fit by phase (rank 0's shard): blocks, start points, sampler, summaries - the sampler is the bulk of it
+        # the fit by phase (rank 0's shard): blocks, start points, sampler, summaries (their order means nothing while the ranks share a GPU)
         assert leg["build_s"] > 0 and leg["start_s"] > 0 and leg["sample_s"] > 0 and leg["summary_s"] > 0
-        assert leg["sample_s"] > leg["start_s"] and leg["build_s"] + leg["start_s"] + leg["sample_s"] + leg["summary_s"] <= leg["fit_s"] * 1.05
+        assert leg["build_s"] + leg["start_s"] + leg["sample_s"] + leg["summary_s"] <= leg["fit_s"] * 1.05
         # star i -> rank (i + 1) % 2: each rank owns n // 2 stars, and after the all-gather rank 0 holds every row
         assert leg["stars_per_rank_all"] == [n // 2, n // 2]
         assert leg["rows_gathered_on_rank0"] == n
@@ -92,7 +92,9 @@ def _check_reference_shape(cat, world):
     assert "error" not in leg, leg
     assert leg["stars_per_s"] > 0 and leg["ok_fraction"] > 0.99 and leg["rows_gathered_on_rank0"] == 10_000
     assert leg["lnpost_evals"] == 10_000 * 300 * 300
-    assert leg["build_s"] > 0 and leg["start_s"] > 0 and leg["sample_s"] > leg["start_s"] and leg["summary_s"] > 0
+    # (phase clocks of rank 0's shard: all there; their ORDER means nothing while the ranks share one GPU - rank 0's start-point
+    # kernel has waited behind seven other ranks' samplers: start_s 46 ms next to sample_s 23 ms in one run of the suite)
+    assert leg["build_s"] > 0 and leg["start_s"] > 0 and leg["sample_s"] > 0 and leg["summary_s"] > 0
     assert sum(leg["stars_per_rank_all"]) == 10_000 and max(leg["stars_per_rank_all"]) - min(leg["stars_per_rank_all"]) <= 1
     return leg
 

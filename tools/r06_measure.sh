@@ -116,7 +116,8 @@ tree)
 tests)
   timeout 2400 python -m pytest tests/test_gpu_dispatch_table.py tests/test_gpu_sampler_any.py -q 2>&1 | tail -15 | tee $OUT/pytest_dispatch_and_any.txt ;;
 suite)
-  timeout 3000 python -m pytest tests -m gpu -q 2>&1 | tail -8 | tee $OUT/pytest_gpu_suite.txt ;;
+  timeout 3000 python -m pytest tests -m gpu -q > $OUT/pytest_gpu_suite_full.txt 2>&1; tail -8 $OUT/pytest_gpu_suite_full.txt | tee $OUT/pytest_gpu_suite.txt
+  grep -q " failed" $OUT/pytest_gpu_suite.txt || rm -f $OUT/pytest_gpu_suite_full.txt ;;      # (the whole log only when something failed)
 fits)
   python bench_configs.py --configs fits,cfg4,tree > $OUT/bench_configs_fits.jsonl 2> $OUT/bench_configs_fits.err; tail -c 2500 $OUT/bench_configs_fits.jsonl
   python tools/mailbox_latency.py 2>&1 | grep -v amdgpu.ids | tee $OUT/mailbox_latency.txt
