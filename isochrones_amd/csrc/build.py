@@ -32,7 +32,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math"
 # registers (5 -> 4 waves per SIMD) and 134 -> 149 us per 10^6 rows, so their unit - and the generic / interpolation /
 # summary kernels of iso_hip.hip, which were not measured - keep the default scheduler.
 MAX_ILP_UNITS = {"iso_fast_track1", "iso_fast_iso1", "iso_fast_iso2", "iso_fast_iso3", "iso_fast_ast_track1", "iso_fast_ast_iso1",
-                 "iso_fast_ast_iso2", "iso_fast_ast_iso3", "iso_fast_stretch_more", "iso_fast_stretch_tree", "iso_fast_mailbox"}
+                 "iso_fast_ast_iso2", "iso_fast_ast_iso3", "iso_fast_stretch_more", "iso_fast_stretch_tree", "iso_fast_mailbox",
+                 "iso_fast_stretch_track1", "iso_fast_stretch_iso1", "iso_fast_stretch_iso2", "iso_fast_stretch_iso3"}
 
 
 def unit_flags(src) -> list:

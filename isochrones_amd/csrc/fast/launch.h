@@ -54,15 +54,19 @@ inline PersistKernel persist_kernel(const StretchArgs& S)
         // the host spreads one ensemble per workgroup): the star's block through scalar loads (DENSE + UNI, sampler.h)
         const int GL = persist_group(S.W);
         const bool one = NS == 1 && ((S.group > 0 && S.group < GL) ? S.group : GL) == 1;
-        if constexpr (persist_slim(true, N, NS)) {
-            stdp = S.std_priors != 0 && S.dense_stdp != 0;
-            if (one) k.fn = stdp ? (const void*)k_stretch_persist<KIND, 1, N, true, false, true, true>
-                                 : (const void*)k_stretch_persist<KIND, 1, N, true, false, true, false>;
-            else k.fn = stdp ? (const void*)k_stretch_persist<KIND, NS, N, true, false, false, true>
-                             : (const void*)k_stretch_persist<KIND, NS, N, true, false>;
+        if constexpr (NS == 1) {
+            if constexpr (persist_slim(true, N, NS)) {
+                stdp = S.std_priors != 0 && S.dense_stdp != 0;
+                if (one) k.fn = stdp ? (const void*)k_stretch_persist<KIND, NS, N, true, false, true, true>
+                                     : (const void*)k_stretch_persist<KIND, NS, N, true, false, true, false>;
+                else k.fn = stdp ? (const void*)k_stretch_persist<KIND, NS, N, true, false, false, true>
+                                 : (const void*)k_stretch_persist<KIND, NS, N, true, false>;
+            } else {
+                if (one) k.fn = (const void*)k_stretch_persist<KIND, NS, N, true, false, true, false>;
+                else k.fn = (const void*)k_stretch_persist<KIND, NS, N, true, false>;
+            }
         } else {
-            if (one) k.fn = (const void*)k_stretch_persist<KIND, 1, N, true, false, true, false>;
-            else k.fn = (const void*)k_stretch_persist<KIND, NS, N, true, false>;
+            k.fn = (const void*)k_stretch_persist<KIND, NS, N, true, false>;      // (systems: at three waves per SIMD either way - persist_slim)
         }
         uni = one;
     } else if (S.multi) {

@@ -1,0 +1,15 @@
+// Instantiations of the stretch-move sampler kernels (step-wise and persistent forms, fast/sampler.h) for (ISO_KIND_TRACK, 1 star(s));
+// the batch and start-point kernels of the shape: iso_fast_track1.hip.
+#include "iso_fast_kernel.h"
+
+namespace iso {
+ISO_DEFINE_STRETCH_LAUNCHER(launch_stretch_track1, ISO_KIND_TRACK, 1)
+}  // namespace iso
+
+#ifdef ISO_PHASE_CLOCK
+// instrumentation build (tools/phase_clock.py): the shader-clock stamps of the last evaluation workgroup 0 ran
+extern "C" int iso_debug_phase_stamps(unsigned long long* out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(iso::fastk::g_phase_stamps), 16 * sizeof(unsigned long long));
+}
+#endif
