@@ -5,7 +5,7 @@ several workloads run the same kernel (tools/pmc_summarize.py walks the dispatch
 
     python tools/pmc_workload.py --manifest out.json [--launches 6] [--cases cfg2,cfg3,...]
 
-cases: cfg2 (single star, 1 band: prior / prior_valid / posterior samples), cfg3 (binary, 6 bands + parallax: the same
+cases: catalog_ref (reference-shape catalog sampler, 10^4 stars x 300 walkers), cfg2 (single star, 1 band: prior / prior_valid / posterior samples), cfg3 (binary, 6 bands + parallax: the same
 three), generic (cfg2 model on the generic kernel), astero, tree (resolved binary, fast tree kernel), tree_generic (the same
 tree on the generic tree kernel),
 quantiles (chain summaries of a 10^4-star catalog, 32 walkers x 100 steps), sampler (the catalog sampler on 2 x 10^5 stars: step-wise and
@@ -227,6 +227,30 @@ def main():
         manifest.append(dict(label="sampler_persistent/200000x32", kernel="k_stretch_persist<0, 1, 3", launches=2, skip=1,
                              n=S * W * (L // 2), iterations=L // 2,
                              algorithmic_bytes_per_launch=float(S * W * (L // 2)) * (384 + 3 * 128) + float(S * W) * 2 * 48))
+    if "catalog_ref" in cases:
+        # the reference's own catalog shape in rounds: isochrones, 300 walkers (one ensemble per workgroup: the register-capped
+        # kernel reads its star's block through scalar loads - DENSE + UNI), 10^4 stars, L // 2 iterations per launch
+        from isochrones_amd.catalog import CatalogPosterior, initial_positions
+        from isochrones_amd.sampler import FusedEnsembleSampler
+        bands = ["G", "BP", "RP"]
+        ic = ia.synthetic_isochrone(bands=bands)
+        S, W = 10_000, 300
+        cat, _ = ia.synthetic_catalog(ic, S, bands=bands, seed=7, mag_unc=0.01)
+        post = CatalogPosterior.from_catalog(cat, ic)
+        pos, lnp, failed = initial_positions(post, W, rng_seed=0)
+        if bool(failed.any()):
+            good = int(torch.nonzero(~failed)[0])
+            pos[failed] = pos[good]
+            lnp[failed] = 0.0
+        fs = FusedEnsembleSampler(post, W, seed=1)
+        pos, lnp = fs.run_mcmc(pos, 60, lnprob0=lnp, store=False)           # burn in
+        torch.cuda.synchronize()
+        it = 20
+        fs.run_mcmc(pos, it, lnprob0=lnp, store=False)
+        torch.cuda.synchronize()
+        manifest.append(dict(label="catalog_reference_shape/10000x300", kernel="k_stretch_persist<1, 1, 3, true, false, true", launches=2, skip=1,
+                             n=S * W * it, iterations=it,
+                             algorithmic_bytes_per_launch=float(S * W * it) * (384 + 3 * 128) + float(S * W) * 2 * 48))
     json.dump(manifest, open(args.manifest, "w"), indent=1)
     print("manifest:", args.manifest, [m["label"] for m in manifest])
 
